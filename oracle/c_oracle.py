@@ -1,0 +1,132 @@
+"""ctypes binding of oracle/pcg_oracle.c -- TEST INFRASTRUCTURE ONLY (see that file's header)."""
+
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+import subprocess
+
+import numpy as np
+import scipy.sparse as sp
+
+_HERE = pathlib.Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "liboracle_pcg.so"
+
+KINDS = {"none": 0, "jacobi": 1, "csr": 2, "llt_multiply": 3, "llt_solve": 4}
+
+
+def build(force: bool = False) -> pathlib.Path:
+    """Compile the C restatement with gcc (no GPU, no reference needed)."""
+    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < (_HERE / "pcg_oracle.c").stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE), "-B", "liboracle_pcg.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(str(_LIB_PATH))
+        _lib.orc_pcg.restype = C.c_double
+        _lib.orc_dot.restype = C.c_double
+        _lib.orc_ic0.restype = C.c_int64
+        _lib.orc_num_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _csr_parts(M):
+    if M is None:
+        return None, None, None
+    M = M.tocsr()
+    return (np.ascontiguousarray(M.indptr, dtype=np.int32), np.ascontiguousarray(M.indices, dtype=np.int32),
+            np.ascontiguousarray(M.data, dtype=np.float64))
+
+
+def num_threads() -> int:
+    return int(lib().orc_num_threads())
+
+
+def spmv(A: sp.csr_matrix, x: np.ndarray) -> np.ndarray:
+    rp, ci, v = _csr_parts(A)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty(A.shape[0], dtype=np.float64)
+    lib().orc_spmv(C.c_int64(A.shape[0]), _p(rp), _p(ci), _p(v), _p(x), _p(y))
+    return y
+
+
+def spmv_f32(A: sp.csr_matrix, x: np.ndarray) -> np.ndarray:
+    rp, ci, _ = _csr_parts(A)
+    v = np.ascontiguousarray(A.data, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty(A.shape[0], dtype=np.float32)
+    lib().orc_spmv_f32(C.c_int64(A.shape[0]), _p(rp), _p(ci), _p(v), _p(x), _p(y))
+    return y
+
+
+def dot(a: np.ndarray, b: np.ndarray) -> float:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return float(lib().orc_dot(C.c_int64(len(a)), _p(a), _p(b)))
+
+
+def ic0(A: sp.csr_matrix) -> sp.csr_matrix:
+    """IC(0) factor L of SPD A (pattern tril(A)); raises on a non-positive pivot."""
+    T = sp.tril(A, format="csr")
+    T.sort_indices()
+    rp, ci, v = _csr_parts(T)
+    v = v.copy()
+    bad = lib().orc_ic0(C.c_int64(T.shape[0]), _p(rp), _p(ci), _p(v))
+    if bad:
+        raise ArithmeticError(f"IC(0) breakdown at row {bad - 1}")
+    return sp.csr_matrix((v, ci, rp), shape=T.shape)
+
+
+def transpose_csr(L: sp.csr_matrix) -> sp.csr_matrix:
+    Lt = L.T.tocsr()
+    Lt.sort_indices()
+    return Lt
+
+
+def sptrsv_lower(L: sp.csr_matrix, r: np.ndarray) -> np.ndarray:
+    rp, ci, v = _csr_parts(L)
+    r = np.ascontiguousarray(r, dtype=np.float64)
+    y = np.empty_like(r)
+    lib().orc_sptrsv_lower(C.c_int64(L.shape[0]), _p(rp), _p(ci), _p(v), _p(r), _p(y))
+    return y
+
+
+def sptrsv_upper(U: sp.csr_matrix, y: np.ndarray) -> np.ndarray:
+    rp, ci, v = _csr_parts(U)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    z = np.empty_like(y)
+    lib().orc_sptrsv_upper(C.c_int64(U.shape[0]), _p(rp), _p(ci), _p(v), _p(y), _p(z))
+    return z
+
+
+def pcg(A: sp.csr_matrix, b: np.ndarray, kind: str = "none", *, dinv=None, M=None, L=None, x0=None, rtol=1e-8,
+        max_iter=1024, init_check="z"):
+    """Returns (seconds, iterations, residual_history, x) -- same tuple as oracle.oracle's PCG."""
+    n = A.shape[0]
+    rp, ci, v = _csr_parts(A)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=np.float64)
+    dinv_a = None if dinv is None else np.ascontiguousarray(dinv, dtype=np.float64)
+    m = _csr_parts(M)
+    l = _csr_parts(L)
+    lt = _csr_parts(transpose_csr(L)) if L is not None else (None, None, None)
+    x = np.empty(n, dtype=np.float64)
+    hist = np.full(max_iter + 1, np.nan)
+    iters = C.c_int(0)
+    sec = lib().orc_pcg(C.c_int64(n), _p(rp), _p(ci), _p(v), _p(b), _p(x0a), C.c_int(KINDS[kind]), _p(dinv_a),
+                        _p(m[0]), _p(m[1]), _p(m[2]), _p(l[0]), _p(l[1]), _p(l[2]), _p(lt[0]), _p(lt[1]), _p(lt[2]),
+                        C.c_double(rtol), C.c_int(max_iter), C.c_int(1 if init_check == "z" else 0),
+                        _p(x), _p(hist), C.byref(iters))
+    k = iters.value
+    return float(sec), k, hist[: k + 1].copy(), x

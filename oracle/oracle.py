@@ -1,0 +1,349 @@
+"""CPU oracle for the preconditioned-CG hot path -- TEST INFRASTRUCTURE ONLY.
+
+This module is a numpy/scipy restatement of the reference algorithm
+(`uibk/deep_preconditioning/cg.py`, `utils.py`, and the preconditioner constructors of
+`test.py`).  It is the checker the HIP path is compared against.  Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import it; the product
+package `deeppreconditioning_amd` never does.
+
+Parity status: PINNED.  Every function here that restates an importable reference function
+(`cg.py`, `utils.py`) is checked in `tests/test_oracle_golden.py` against fixtures in
+`tests/golden/` that were produced by importing the reference itself in the build container
+(`tests/golden/make_golden.py`).  The preconditioner *constructors* that need ilupp / pyamg /
+spconv (absent, `test.py:81-105`) are unpinned; see DESIGN.md.
+
+Every function cites the reference file:line it follows (paths relative to the reference root).
+"""
+
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+# --------------------------------------------------------------------------------------------
+# Synthetic inputs.  The reference cannot generate these sizes itself
+# (its matrices come from OpenFOAM, generate_data.py:55-81); the generators are closed-form.
+# --------------------------------------------------------------------------------------------
+
+
+def poisson2d(n: int, dtype=np.float64) -> sp.csr_matrix:
+    """5-point Laplacian kron(I,T)+kron(T,I), T=tridiag(-1,2,-1): diag 4, off-diag -1.
+
+    Row i = iy*n + ix; columns sorted ascending (i-n, i-1, i, i+1, i+n).  int32 indices.
+    """
+    idx = np.arange(n * n, dtype=np.int64)
+    ix = idx % n
+    iy = idx // n
+    cols = np.stack([idx - n, idx - 1, idx, idx + 1, idx + n], axis=1)
+    mask = np.stack([iy > 0, ix > 0, np.ones_like(ix, bool), ix < n - 1, iy < n - 1], axis=1)
+    vals = np.broadcast_to(np.array([-1.0, -1.0, 4.0, -1.0, -1.0], dtype=dtype), cols.shape)
+    rowptr = np.zeros(n * n + 1, dtype=np.int32)
+    np.cumsum(mask.sum(axis=1), out=rowptr[1:])
+    return sp.csr_matrix(
+        (vals[mask].astype(dtype), cols[mask].astype(np.int32), rowptr), shape=(n * n, n * n)
+    )
+
+
+def poisson3d(n: int, dtype=np.float64) -> sp.csr_matrix:
+    """7-point Laplacian on an n^3 grid: diag 6, off-diag -1.  Row i = (iz*n + iy)*n + ix."""
+    N = n * n * n
+    idx = np.arange(N, dtype=np.int64)
+    ix = idx % n
+    iy = (idx // n) % n
+    iz = idx // (n * n)
+    cols = np.stack([idx - n * n, idx - n, idx - 1, idx, idx + 1, idx + n, idx + n * n], axis=1)
+    mask = np.stack(
+        [iz > 0, iy > 0, ix > 0, np.ones_like(ix, bool), ix < n - 1, iy < n - 1, iz < n - 1], axis=1
+    )
+    vals = np.broadcast_to(np.array([-1.0, -1.0, -1.0, 6.0, -1.0, -1.0, -1.0], dtype=dtype), cols.shape)
+    rowptr = np.zeros(N + 1, dtype=np.int32)
+    np.cumsum(mask.sum(axis=1), out=rowptr[1:])
+    return sp.csr_matrix((vals[mask].astype(dtype), cols[mask].astype(np.int32), rowptr), shape=(N, N))
+
+
+def unstructured_like(A: sp.csr_matrix, seed: int = 0) -> sp.csr_matrix:
+    """Stand-in for an OpenFOAM pressure matrix: D (P A P^T) D with a seeded random symmetric
+    permutation P and SPD diagonal scaling D = diag(U(0.5, 2)).
+
+    Column indices are sorted within each row (canonical CSR), int32.
+    """
+    rng = np.random.default_rng(seed)
+    n = A.shape[0]
+    perm = rng.permutation(n)
+    d = rng.uniform(0.5, 2.0, n)
+    B = A.tocsr()[perm][:, perm]
+    B = sp.diags(d) @ B @ sp.diags(d)
+    B = B.tocsr()
+    B.sort_indices()
+    B.indices = B.indices.astype(np.int32)
+    B.indptr = B.indptr.astype(np.int32)
+    return B
+
+
+def rhs(n: int, seed: int = 0) -> np.ndarray:
+    """b ~ U(-1, 1), the distribution of generate_data.py:106, seeded as SURVEY.md 8-c3."""
+    return np.random.default_rng(seed).uniform(-1.0, 1.0, n)
+
+
+# --------------------------------------------------------------------------------------------
+# Operators
+# --------------------------------------------------------------------------------------------
+
+
+def spmv(A: sp.csr_matrix, x: np.ndarray) -> np.ndarray:
+    """y = A x, CSR row sums in column order (what `A @ pk` means at cg.py:75 for a CSR A).
+
+    scipy's csr_matvec accumulates each row sequentially `sum += Ax[jj] * Xx[Aj[jj]]` with no
+    FMA contraction on the x86-64 baseline build; the HIP kernel reproduces exactly that order
+    and rounding, so SpMV parity is bit-exact.
+    """
+    return A @ x
+
+
+def jacobi_dinv(A: sp.csr_matrix) -> np.ndarray:
+    """Diagonal of the Jacobi preconditioner, `1 / matrix.diagonal()` (test.py:74-79)."""
+    return 1.0 / A.diagonal()
+
+
+def ic0(A: sp.csr_matrix) -> sp.csr_matrix:
+    """Zero-fill incomplete Cholesky factor L (lower triangular CSR, pattern = tril(A)).
+
+    Stands in for `ilupp.ichol0` (test.py:83; ilupp is absent, so this is the textbook IC(0),
+    Saad 2003 Alg. 10.x, row-oriented):  for each row i, for each stored j<i ascending:
+        L_ij = (a_ij - sum_{m<j, m in pat(i) & pat(j)} L_im L_jm) / L_jj
+        L_ii = sqrt(a_ii - sum_{m<i} L_im^2)
+    Sums run over ascending m, one product at a time, no FMA -- the native setup routine
+    follows the same order so the factors agree bit for bit.
+    """
+    T = sp.tril(A, format="csr")
+    T.sort_indices()
+    n = T.shape[0]
+    rp, ci = T.indptr, T.indices
+    lv = T.data.astype(np.float64).copy()
+    for i in range(n):
+        s_i, e_i = rp[i], rp[i + 1]
+        for k in range(s_i, e_i):
+            j = ci[k]
+            s_j, e_j = rp[j], rp[j + 1]
+            acc = lv[k]
+            # two-pointer intersection of row i and row j restricted to columns < j
+            a, b = s_i, s_j
+            while a < k and b < e_j - 1:
+                ca, cb = ci[a], ci[b]
+                if ca == cb:
+                    acc = acc - lv[a] * lv[b]
+                    a += 1
+                    b += 1
+                elif ca < cb:
+                    a += 1
+                else:
+                    b += 1
+            if j < i:
+                lv[k] = acc / lv[e_j - 1]  # diagonal is the last entry of a tril row
+            else:
+                lv[k] = np.sqrt(acc)
+    return sp.csr_matrix((lv, ci.copy(), rp.copy()), shape=T.shape)
+
+
+def learned_like_factor(A: sp.csr_matrix, seed: int = 0, scale: float = 0.05, diag_sigma: float = 1.0) -> sp.csr_matrix:
+    """A seeded stand-in for the CNN output L = PreconditionerNet(tril(A)) (model.py:42-59).
+
+    Pattern: tril(A)'s pattern dilated by offsets [-2,2]x[-2,2] (the Minkowski sum of the four
+    2x2 sparse convolutions, model.py:33-37), clipped to the matrix and to the lower triangle
+    (model.py:53-54 zeroes the strict upper part; `to_sparse_csr` drops it, test.py:105).
+    Values: strict-lower ~ scale*N(0,1) in fp32, diagonal = softplus(diag_sigma*N(0,1)) > 0 (model.py:56-57),
+    upcast to fp64 as the reference does (test.py:105).  No checkpoint or spconv is available,
+    so the values are random; only the algebraic contract is honoured (parity unpinned).
+    """
+    rng = np.random.default_rng(seed)
+    T = sp.tril(A, format="coo")
+    n = A.shape[0]
+    rows, cols = [], []
+    for dr in range(-2, 3):
+        for dc in range(-2, 3):
+            r = T.row.astype(np.int64) + dr
+            c = T.col.astype(np.int64) + dc
+            ok = (r >= 0) & (r < n) & (c >= 0) & (c < n) & (c <= r)
+            rows.append(r[ok])
+            cols.append(c[ok])
+    rows = np.concatenate(rows)
+    cols = np.concatenate(cols)
+    key = np.unique(rows * n + cols)
+    rows, cols = key // n, key % n
+    vals = (scale * rng.standard_normal(len(key))).astype(np.float32)
+    diag = rows == cols
+    g = (diag_sigma * rng.standard_normal(int(diag.sum()))).astype(np.float32)
+    vals[diag] = np.log1p(np.exp(g))  # softplus
+    L = sp.csr_matrix((vals.astype(np.float64), (rows, cols)), shape=(n, n))
+    L.sort_indices()
+    L.indices = L.indices.astype(np.int32)
+    L.indptr = L.indptr.astype(np.int32)
+    return L
+
+
+def sptrsv_lower(L: sp.csr_matrix, r: np.ndarray) -> np.ndarray:
+    """Solve L y = r by forward substitution, row sums in column order, then divide by L_ii."""
+    rp, ci, lv = L.indptr, L.indices, L.data
+    y = np.zeros_like(r, dtype=np.float64)
+    for i in range(L.shape[0]):
+        acc = r[i]
+        e = rp[i + 1] - 1
+        for k in range(rp[i], e):
+            acc = acc - lv[k] * y[ci[k]]
+        y[i] = acc / lv[e]
+    return y
+
+
+def sptrsv_upper_t(L: sp.csr_matrix, y: np.ndarray) -> np.ndarray:
+    """Solve L^T z = y by backward substitution on U = L^T stored as CSR (diagonal first in a
+    row, remaining columns ascending), row sums in column order, then divide by U_ii."""
+    U = L.T.tocsr()
+    U.sort_indices()
+    rp, ci, uv = U.indptr, U.indices, U.data
+    z = np.zeros_like(y, dtype=np.float64)
+    for i in range(U.shape[0] - 1, -1, -1):
+        acc = y[i]
+        s = rp[i]
+        for k in range(s + 1, rp[i + 1]):
+            acc = acc - uv[k] * z[ci[k]]
+        z[i] = acc / uv[s]
+    return z
+
+
+class Precond:
+    """The ways `zk = M @ rk` (cg.py:61,81) is realised.  kinds:
+
+    none          M = I                                 (test.py:70-72)
+    jacobi        M = diag(1/a_ii)                      (test.py:74-79)
+    csr           M given as CSR, z = M r               (test.py:88,105: M = L L^T materialised)
+    llt_multiply  z = L (L^T r) without forming L L^T   (same operator as test.py:102-105)
+    llt_solve     z = L^-T (L^-1 r), true IC apply      (north_star; not in the reference)
+    """
+
+    def __init__(self, kind: str, *, dinv=None, M=None, L=None):
+        self.kind = kind
+        self.dinv = dinv
+        self.M = M
+        self.L = L
+        self.Lt = L.T.tocsr() if L is not None else None
+        if self.Lt is not None:
+            self.Lt.sort_indices()
+
+    def __matmul__(self, r: np.ndarray) -> np.ndarray:
+        if self.kind == "none":
+            return r.copy()
+        if self.kind == "jacobi":
+            return self.dinv * r
+        if self.kind == "csr":
+            return self.M @ r
+        if self.kind == "llt_multiply":
+            return self.L @ (self.Lt @ r)
+        if self.kind == "llt_solve":
+            y = spla.spsolve_triangular(self.L, r, lower=True)
+            return spla.spsolve_triangular(self.Lt, y, lower=False)
+        raise ValueError(self.kind)
+
+
+# --------------------------------------------------------------------------------------------
+# Solvers
+# --------------------------------------------------------------------------------------------
+
+
+def stopping_criterion(_, rk: np.ndarray, b: np.ndarray) -> float:
+    """<rk,rk>/<b,b>: the SQUARED relative residual (cg.py:15-17)."""
+    return float(np.dot(rk, rk) / np.dot(b, b))
+
+
+def preconditioned_conjugate_gradient(A, b, M, x0=None, rtol=1e-8, max_iter=1024, init_check="z"):
+    """Restatement of cg.py:50-90 without the wasted `A @ zeros` of cg.py:85-87.
+
+    Returns (seconds, iterations, residual_history, x).  `residual_history[k]` is the value the
+    reference appends to `errors` (cg.py:67,88): entry 0 is <z0,z0>/<b,b> (the cg.py:66 quirk:
+    the initial check uses zk), entries k>=1 are <rk,rk>/<b,b>.  `init_check="r"` gives the
+    scipy-style first test on r instead (utils.py:66-72 path).
+    """
+    x = np.zeros_like(b, dtype=np.float64) if x0 is None else np.array(x0, dtype=np.float64)  # cg.py:58
+    r = b - A @ x  # cg.py:60
+    z = M @ r  # cg.py:61
+    p = z.copy()  # cg.py:62
+    bb = np.dot(b, b)
+    res = np.dot(z, z) / bb if init_check == "z" else np.dot(r, r) / bb  # cg.py:66
+    hist = [float(res)]
+    t0 = time.perf_counter()  # cg.py:69
+    for _ in range(max_iter):  # cg.py:70
+        if res < rtol:  # cg.py:71
+            break
+        Ap = A @ p  # cg.py:75
+        rz = np.dot(r, z)  # cg.py:76
+        a = rz / np.dot(Ap, p)  # cg.py:78
+        x = x + a * p  # cg.py:79
+        r = r - a * Ap  # cg.py:80
+        z = M @ r  # cg.py:81
+        beta = np.dot(r, z) / rz  # cg.py:82
+        p = z + beta * p  # cg.py:83
+        res = np.dot(r, r) / bb  # cg.py:86
+        hist.append(float(res))
+    t1 = time.perf_counter()  # cg.py:88
+    return t1 - t0, len(hist) - 1, np.array(hist), x  # cg.py:90 (+ history and x for the checker)
+
+
+def conjugate_gradient(A, b, x0=None, x_true=None, rtol=1e-8, max_iter=1024):
+    """Restatement of cg.py:20-47.  Returns (errors, x_hat), errors[k] = (A-norm error or 0, res)."""
+    x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=b.dtype)  # cg.py:22
+    r = b - A @ x  # cg.py:23
+    p = r.copy()  # cg.py:24
+    bb = np.dot(b, b)
+
+    def a_norm_err(xh):
+        if x_true is None:
+            return 0.0
+        e = xh - x_true  # cg.py:27
+        return float(np.dot(e, A @ e))  # cg.py:29
+
+    res = np.dot(r, r) / bb  # cg.py:28
+    errors = [(a_norm_err(x), float(res))]
+    for _ in range(max_iter):  # cg.py:31
+        if res < rtol:  # cg.py:32
+            break
+        Ap = A @ p  # cg.py:35
+        r_norm = np.dot(r, r)  # cg.py:36
+        a = r_norm / np.dot(Ap, p)  # cg.py:38
+        x = x + a * p  # cg.py:39
+        r = r - a * Ap  # cg.py:40
+        p = r + (np.dot(r, r) / r_norm) * p  # cg.py:41
+        res = np.dot(r, r) / bb  # cg.py:44
+        errors.append((a_norm_err(x), float(res)))
+    return errors, x
+
+
+def sparse_matvec_mul(indices: np.ndarray, features: np.ndarray, batch_size: int, vector_batch: np.ndarray,
+                      transpose: bool) -> np.ndarray:
+    """Restatement of utils.py:15-43 on plain arrays: batched COO SpMV / SpMV^T in fp32.
+
+    indices (nnz,3) int32 = (batch,row,col); features (nnz,1) fp32; vector_batch (B, dof) fp32.
+    Products are scattered onto rows in storage order (scatter_reduce "sum", utils.py:36-41).
+    """
+    b_idx = indices[:, 0].astype(np.int64)
+    r_idx = indices[:, 2 if transpose else 1].astype(np.int64)  # utils.py:27
+    c_idx = indices[:, 1 if transpose else 2].astype(np.int64)  # utils.py:28
+    out = np.zeros_like(vector_batch, dtype=np.float32)
+    prod = (features[:, 0].astype(np.float32) * vector_batch[b_idx, c_idx].astype(np.float32)).astype(np.float32)
+    for k in range(len(prod)):  # sequential fp32 accumulation in storage order
+        out[b_idx[k], r_idx[k]] = np.float32(out[b_idx[k], r_idx[k]] + prod[k])
+    return out
+
+
+def benchmark_cg(matrix, right_hand_side, preconditioner=None):
+    """Restatement of utils.py:46-76: scipy cg, maxiter=512, default rtol=1e-5, callback count."""
+    iterations = 0
+
+    def _callback(_):
+        nonlocal iterations
+        iterations += 1
+
+    t0 = time.perf_counter()
+    _, info = spla.cg(matrix, right_hand_side, maxiter=512, M=preconditioner, callback=_callback)
+    return time.perf_counter() - t0, iterations, info
