@@ -82,14 +82,15 @@ def test_pcg_llt_multiply_modes(golden):
     Ll = O.learned_like_factor(A32, seed=0)
     _, it, hist, _ = CO.pcg(A32, b32, "csr", M=(Ll @ Ll.T).tocsr())
     _check_chaotic(golden, "pcg_poisson2d_32_learnedlike_multiply_bseed3", it, hist, stable=20)
-    # well-conditioned learned-like factor: the whole history is pinned
+    # better-conditioned learned-like factor: rounding differences still grow past ~50 iterations
+    # (1e-13 at k=50, 1e-3 at k=100) because a random M breaks the Poisson spectrum's symmetry
     Lw = O.learned_like_factor(A, seed=1, scale=0.02, diag_sigma=0.1)
     _, it, hist, _ = CO.pcg(A, b, "csr", M=(Lw @ Lw.T).tocsr())
-    _check(golden, "pcg_poisson2d_64_learnedlike_wellcond_multiply", it, hist)
+    _check_chaotic(golden, "pcg_poisson2d_64_learnedlike_wellcond_multiply", it, hist, stable=40)
     _, it, hist, _ = CO.pcg(A, b, "llt_multiply", L=Lw)
-    _check(golden, "pcg_poisson2d_64_learnedlike_wellcond_multiply", it, hist)
+    _check_chaotic(golden, "pcg_poisson2d_64_learnedlike_wellcond_multiply", it, hist, stable=40)
     _, it, hist, _ = O.preconditioned_conjugate_gradient(A, b, O.Precond("llt_multiply", L=Lw))
-    _check(golden, "pcg_poisson2d_64_learnedlike_wellcond_multiply", it, hist)
+    _check_chaotic(golden, "pcg_poisson2d_64_learnedlike_wellcond_multiply", it, hist, stable=40)
 
 
 def test_pcg_llt_solve_modes(golden):
