@@ -1,0 +1,988 @@
+// Host side of libdpcg.so: the C ABI declared in include/dpcg.h, handle management, setup analysis
+// (row-block plan, IC(0), transpose, level sets) and the PCG driver that replays the iteration
+// kernels from a hipGraph without a host round trip per iteration.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include "dpcg_internal.h"
+
+using namespace dpcg;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+namespace dpcg {
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_last_error = buf;
+    return DPCG_ERR_HIP;
+}
+}  // namespace dpcg
+
+static int invalid(const char *msg) {
+    set_error(msg);
+    return DPCG_ERR_INVALID;
+}
+
+#define DPCG_TRY(expr)               \
+    do {                             \
+        int _st = (expr);            \
+        if (_st < 0) return _st;     \
+    } while (0)
+
+#define DPCG_CHECK_LAUNCH() DPCG_HIP(hipGetLastError())
+
+extern "C" int dpcg_version(void) { return 100; }
+
+extern "C" const char *dpcg_status_string(int st) {
+    switch (st) {
+        case DPCG_OK: return "ok";
+        case DPCG_MAX_ITER: return "max_iter reached";
+        case DPCG_BREAKDOWN: return "breakdown (NaN/Inf in the recurrence)";
+        case DPCG_ERR_INVALID: return "invalid argument";
+        case DPCG_ERR_HIP: return "HIP runtime error";
+        case DPCG_ERR_NOMEM: return "out of memory";
+        case DPCG_ERR_PIVOT: return "IC(0): non-positive pivot";
+        case DPCG_ERR_STATE: return "invalid state";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char *dpcg_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int dpcg_device_info(int *cu_count, int64_t *hbm_bytes, char *name, int name_len) {
+    int dev = 0;
+    DPCG_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    DPCG_HIP(hipGetDeviceProperties(&prop, dev));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (name && name_len > 0) {
+        snprintf(name, (size_t)name_len, "%s", prop.gcnArchName);
+    }
+    return DPCG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// memory helpers
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static int dev_alloc(T **p, int64_t count) {
+    *p = nullptr;
+    if (count <= 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, (size_t)count * sizeof(T));
+    if (e != hipSuccess) {
+        set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? DPCG_ERR_NOMEM : DPCG_ERR_HIP;
+    }
+    return DPCG_OK;
+}
+
+template <typename T>
+static void dev_free(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+static void free_csr(CsrDev &c) {
+    if (c.owned) {
+        dev_free(c.rowptr);
+        dev_free(c.col);
+        dev_free(c.val);
+    }
+    dev_free(c.val32);  // the converted copy is always ours
+    c = CsrDev();
+}
+
+static void free_levels(Levels &l) {
+    dev_free(l.rows);
+    dev_free(l.level_ptr_dev);
+    l = Levels();
+}
+
+static int grid_for(int64_t n) {
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g > kMaxGrid) g = kMaxGrid;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// Upload (or adopt) a CSR matrix.  val_dtype F32 input keeps the fp32 array and adds an fp64 copy.
+static int upload_csr(CsrDev &out, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col, const void *val,
+                      int val_dtype, int memspace, int copy, hipStream_t s) {
+    out = CsrDev();
+    out.n = n;
+    out.nnz = nnz;
+    const hipMemcpyKind kind = memspace == DPCG_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    const bool borrow = (memspace == DPCG_DEVICE && !copy);
+    if (borrow) {
+        out.owned = false;
+        out.rowptr = const_cast<int32_t *>(rowptr);
+        out.col = const_cast<int32_t *>(col);
+        if (val_dtype == DPCG_F64) {
+            out.val = const_cast<double *>((const double *)val);
+        } else {
+            // borrowed fp32 values: the fp64 copy is ours; freed through val32/val bookkeeping below
+            DPCG_TRY(dev_alloc(&out.val32, nnz));
+            DPCG_HIP(hipMemcpyAsync(out.val32, val, (size_t)nnz * sizeof(float), hipMemcpyDeviceToDevice, s));
+            double *v64 = nullptr;
+            DPCG_TRY(dev_alloc(&v64, nnz));
+            launch_f32_to_f64(nnz, out.val32, v64, s);
+            // adopt ownership of everything to keep freeing simple
+            int32_t *rp = nullptr, *ci = nullptr;
+            DPCG_TRY(dev_alloc(&rp, n + 1));
+            DPCG_TRY(dev_alloc(&ci, nnz));
+            DPCG_HIP(hipMemcpyAsync(rp, rowptr, (size_t)(n + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+            DPCG_HIP(hipMemcpyAsync(ci, col, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+            out.rowptr = rp;
+            out.col = ci;
+            out.val = v64;
+            out.owned = true;
+        }
+        return DPCG_OK;
+    }
+    out.owned = true;
+    DPCG_TRY(dev_alloc(&out.rowptr, n + 1));
+    DPCG_TRY(dev_alloc(&out.col, nnz));
+    DPCG_TRY(dev_alloc(&out.val, nnz));
+    DPCG_HIP(hipMemcpyAsync(out.rowptr, rowptr, (size_t)(n + 1) * sizeof(int32_t), kind, s));
+    DPCG_HIP(hipMemcpyAsync(out.col, col, (size_t)nnz * sizeof(int32_t), kind, s));
+    if (val_dtype == DPCG_F64) {
+        DPCG_HIP(hipMemcpyAsync(out.val, val, (size_t)nnz * sizeof(double), kind, s));
+    } else {
+        DPCG_TRY(dev_alloc(&out.val32, nnz));
+        DPCG_HIP(hipMemcpyAsync(out.val32, val, (size_t)nnz * sizeof(float), kind, s));
+        launch_f32_to_f64(nnz, out.val32, out.val, s);
+    }
+    DPCG_HIP(hipStreamSynchronize(s));  // host source buffers may be released by the caller
+    return DPCG_OK;
+}
+
+// Choose the SpMV kernel: CSR-stream when every 256-row block's non-zeros fit the LDS product
+// buffer (stencils, OpenFOAM-like rows), otherwise CSR-vector with lanes-per-row ~ mean row length.
+static int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s) {
+    plan = SpmvPlan();
+    int *d_max = nullptr;
+    DPCG_TRY(dev_alloc(&d_max, 1));
+    DPCG_HIP(hipMemsetAsync(d_max, 0, sizeof(int), s));
+    launch_block_nnz_max(A, kStreamRows, d_max, s);
+    int h_max = 0;
+    DPCG_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    dev_free(d_max);
+    const char *force = getenv("DPCG_SPMV_KERNEL");
+    const bool force_vector = force && strcmp(force, "vector") == 0;
+    if (h_max <= kStreamCap && !force_vector) {
+        plan.kernel = SPMV_STREAM;
+        plan.nrb = (int)((A.n + kStreamRows - 1) / kStreamRows);
+        int g = plan.nrb < kMaxGrid ? plan.nrb : kMaxGrid;
+        if (g > 8) g -= g % 8;
+        plan.grid = g < 1 ? 1 : g;
+    } else {
+        plan.kernel = SPMV_VECTOR;
+        const double mean = A.n > 0 ? (double)A.nnz / (double)A.n : 1.0;
+        int tpr = 2;
+        while (tpr < 64 && tpr < mean) tpr *= 2;
+        plan.tpr = tpr;
+        const int64_t ngroups = (A.n + (kBlock / tpr) - 1) / (kBlock / tpr);
+        int g = ngroups < kMaxGrid ? (int)ngroups : kMaxGrid;
+        if (g > 8) g -= g % 8;
+        plan.grid = g < 1 ? 1 : g;
+    }
+    return DPCG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------
+struct HandleExtras {
+    hipStream_t cap_stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int *flag_host = nullptr;  // pinned, 2 ints
+};
+// kept outside dpcg_system so the struct in the header stays POD-like
+#include <map>
+static std::map<dpcg_system *, HandleExtras> &extras() {
+    static std::map<dpcg_system *, HandleExtras> m;
+    return m;
+}
+
+static void drop_graph(dpcg_system *h) {
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    h->graph_exec = nullptr;
+    h->graph_key = -1;
+}
+
+static void free_precond(dpcg_system *h) {
+    drop_graph(h);
+    dev_free(h->dinv);
+    free_csr(h->M);
+    free_csr(h->L);
+    free_csr(h->Lt);
+    free_levels(h->lvlL);
+    free_levels(h->lvlU);
+    h->precond = DPCG_PRECOND_NONE;
+}
+
+extern "C" int dpcg_create(dpcg_handle_t *out, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                           const void *val, int val_dtype, int memspace, int copy, dpcg_stream_t stream) {
+    if (!out) return invalid("dpcg_create: out is NULL");
+    *out = nullptr;
+    if (n <= 0 || nnz < 0 || !rowptr || (nnz > 0 && (!col || !val))) return invalid("dpcg_create: bad sizes/pointers");
+    if (nnz > 2147483647LL || n > 2147483646LL) return invalid("dpcg_create: int32 CSR limits exceeded");
+    if (val_dtype != DPCG_F64 && val_dtype != DPCG_F32) return invalid("dpcg_create: bad val_dtype");
+    int ndev = 0;
+    DPCG_HIP(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) {
+        set_error("no HIP device visible");
+        return DPCG_ERR_HIP;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dpcg_system *h = new dpcg_system();
+    int st = upload_csr(h->A, n, nnz, rowptr, col, val, val_dtype, memspace, copy, s);
+    if (st >= 0) st = make_plan(h->A, h->planA, s);
+    HandleExtras ex;
+    if (st >= 0 && hipStreamCreateWithFlags(&ex.cap_stream, hipStreamNonBlocking) != hipSuccess) st = DPCG_ERR_HIP;
+    if (st >= 0 && hipEventCreateWithFlags(&ex.ev[0], hipEventDisableTiming) != hipSuccess) st = DPCG_ERR_HIP;
+    if (st >= 0 && hipEventCreateWithFlags(&ex.ev[1], hipEventDisableTiming) != hipSuccess) st = DPCG_ERR_HIP;
+    if (st >= 0 && hipHostMalloc((void **)&ex.flag_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess)
+        st = DPCG_ERR_HIP;
+    if (st >= 0 && hipHostMalloc((void **)&h->scal_host, sizeof(Scalars), hipHostMallocDefault) != hipSuccess)
+        st = DPCG_ERR_HIP;
+    if (st >= 0) st = dev_alloc(&h->scal, 1);
+    extras()[h] = ex;
+    if (st < 0) {
+        dpcg_destroy(h);
+        return st;
+    }
+    h->vec_grid = grid_for(n);
+    *out = h;
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_destroy(dpcg_handle_t h) {
+    if (!h) return DPCG_OK;
+    (void)hipDeviceSynchronize();
+    free_precond(h);
+    free_csr(h->A);
+    dev_free(h->x); dev_free(h->r); dev_free(h->z); dev_free(h->p); dev_free(h->q); dev_free(h->t); dev_free(h->e);
+    dev_free(h->p32);
+    dev_free(h->part_pq); dev_free(h->part_rz); dev_free(h->part_rr); dev_free(h->part_bb);
+    dev_free(h->scal); dev_free(h->hist); dev_free(h->err_hist);
+    if (h->scal_host) (void)hipHostFree(h->scal_host);
+    auto it = extras().find(h);
+    if (it != extras().end()) {
+        HandleExtras &ex = it->second;
+        if (ex.cap_stream) (void)hipStreamDestroy(ex.cap_stream);
+        if (ex.ev[0]) (void)hipEventDestroy(ex.ev[0]);
+        if (ex.ev[1]) (void)hipEventDestroy(ex.ev[1]);
+        if (ex.flag_host) (void)hipHostFree(ex.flag_host);
+        extras().erase(it);
+    }
+    delete h;
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spmv_kernel, int *precond_kind,
+                             int64_t *precond_nnz, int *n_levels_lower, int *n_levels_upper) {
+    if (!h) return invalid("dpcg_get_info: NULL handle");
+    if (n) *n = h->A.n;
+    if (nnz) *nnz = h->A.nnz;
+    if (spmv_kernel) *spmv_kernel = h->planA.kernel;
+    if (precond_kind) *precond_kind = h->precond;
+    if (precond_nnz) *precond_nnz = h->precond == DPCG_PRECOND_CSR ? h->M.nnz : h->L.nnz;
+    if (n_levels_lower) *n_levels_lower = h->lvlL.n_levels;
+    if (n_levels_upper) *n_levels_upper = h->lvlU.n_levels;
+    return DPCG_OK;
+}
+
+static int ensure_work(dpcg_system *h, int max_iter, bool need_f32, bool need_err) {
+    const int64_t n = h->A.n;
+    if (!h->x) {
+        DPCG_TRY(dev_alloc(&h->x, n));
+        DPCG_TRY(dev_alloc(&h->r, n));
+        DPCG_TRY(dev_alloc(&h->z, n));
+        DPCG_TRY(dev_alloc(&h->p, n));
+        DPCG_TRY(dev_alloc(&h->q, n));
+        DPCG_TRY(dev_alloc(&h->t, n));
+        DPCG_TRY(dev_alloc(&h->part_pq, kMaxGrid));
+        DPCG_TRY(dev_alloc(&h->part_rz, kMaxGrid));
+        DPCG_TRY(dev_alloc(&h->part_rr, kMaxGrid));
+        DPCG_TRY(dev_alloc(&h->part_bb, kMaxGrid));
+    }
+    if (need_err && !h->e) DPCG_TRY(dev_alloc(&h->e, n));
+    if (need_f32) {
+        if (!h->p32) {
+            DPCG_TRY(dev_alloc(&h->p32, n));
+            drop_graph(h);
+        }
+        if (!h->A.val32) {
+            DPCG_TRY(dev_alloc(&h->A.val32, h->A.nnz));
+            launch_f64_to_f32(h->A.nnz, h->A.val, h->A.val32, nullptr);
+            DPCG_HIP(hipDeviceSynchronize());
+        }
+    }
+    if (h->hist_cap < max_iter + 1) {
+        drop_graph(h);  // graph nodes hold the old pointers
+        dev_free(h->hist);
+        dev_free(h->err_hist);
+        h->hist_cap = max_iter + 1;
+        DPCG_TRY(dev_alloc(&h->hist, h->hist_cap));
+        DPCG_TRY(dev_alloc(&h->err_hist, h->hist_cap));
+    }
+    return DPCG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// preconditioners
+// ------------------------------------------------------------------------------------------------
+extern "C" int dpcg_set_precond_none(dpcg_handle_t h) {
+    if (!h) return invalid("NULL handle");
+    free_precond(h);
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_set_precond_jacobi(dpcg_handle_t h, const double *dinv, int memspace, dpcg_stream_t stream) {
+    if (!h) return invalid("NULL handle");
+    hipStream_t s = (hipStream_t)stream;
+    free_precond(h);
+    DPCG_TRY(dev_alloc(&h->dinv, h->A.n));
+    if (dinv) {
+        DPCG_HIP(hipMemcpyAsync(h->dinv, dinv, (size_t)h->A.n * sizeof(double),
+                                memspace == DPCG_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+    } else {
+        int *d_bad = nullptr, h_bad = 0;
+        DPCG_TRY(dev_alloc(&d_bad, 1));
+        DPCG_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), s));
+        launch_extract_dinv(h->A, h->dinv, d_bad, s);
+        DPCG_HIP(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        dev_free(d_bad);
+        if (h_bad) {
+            dev_free(h->dinv);
+            set_error("Jacobi: missing or non-positive diagonal entry");
+            return DPCG_ERR_PIVOT;
+        }
+    }
+    h->precond = DPCG_PRECOND_JACOBI;
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_set_precond_csr(dpcg_handle_t h, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                                    const double *val, int memspace, dpcg_stream_t stream) {
+    if (!h) return invalid("NULL handle");
+    if (nnz <= 0 || !rowptr || !col || !val) return invalid("dpcg_set_precond_csr: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    free_precond(h);
+    DPCG_TRY(upload_csr(h->M, h->A.n, nnz, rowptr, col, val, DPCG_F64, memspace, 1, s));
+    DPCG_TRY(make_plan(h->M, h->planM, s));
+    h->precond = DPCG_PRECOND_CSR;
+    return DPCG_OK;
+}
+
+// Level sets of a triangular CSR factor on the host (setup): level(i) = 1 + max level of the rows
+// it depends on.  Rows are then grouped by level; runs of narrow levels become one merged segment.
+static void build_levels_host(int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci, bool upper,
+                              std::vector<int32_t> &rows_sorted, std::vector<int32_t> &level_ptr) {
+    std::vector<int32_t> level((size_t)n, 0);
+    int32_t max_level = 0;
+    if (!upper) {
+        for (int64_t i = 0; i < n; ++i) {
+            int32_t l = 0;
+            for (int32_t k = rp[i]; k < rp[i + 1] - 1; ++k) l = std::max(l, level[ci[k]] + 1);
+            level[i] = l;
+            max_level = std::max(max_level, l);
+        }
+    } else {
+        for (int64_t i = n - 1; i >= 0; --i) {
+            int32_t l = 0;
+            for (int32_t k = rp[i] + 1; k < rp[i + 1]; ++k) l = std::max(l, level[ci[k]] + 1);
+            level[i] = l;
+            max_level = std::max(max_level, l);
+        }
+    }
+    const int nl = max_level + 1;
+    level_ptr.assign((size_t)nl + 1, 0);
+    for (int64_t i = 0; i < n; ++i) level_ptr[level[i] + 1]++;
+    for (int l = 0; l < nl; ++l) level_ptr[l + 1] += level_ptr[l];
+    rows_sorted.resize((size_t)n);
+    std::vector<int32_t> cursor(level_ptr.begin(), level_ptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) rows_sorted[cursor[level[i]]++] = (int32_t)i;
+}
+
+static int upload_levels(Levels &lv, const std::vector<int32_t> &rows_sorted, const std::vector<int32_t> &level_ptr,
+                         hipStream_t s) {
+    constexpr int kMergeMax = 2048;  // levels this narrow are walked by one 1024-thread workgroup
+    lv.level_ptr = level_ptr;
+    lv.n_levels = (int)level_ptr.size() - 1;
+    DPCG_TRY(dev_alloc(&lv.rows, (int64_t)rows_sorted.size()));
+    DPCG_TRY(dev_alloc(&lv.level_ptr_dev, (int64_t)level_ptr.size()));
+    DPCG_HIP(hipMemcpyAsync(lv.rows, rows_sorted.data(), rows_sorted.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    DPCG_HIP(hipMemcpyAsync(lv.level_ptr_dev, level_ptr.data(), level_ptr.size() * sizeof(int32_t),
+                            hipMemcpyHostToDevice, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    lv.segments.clear();
+    int l = 0;
+    while (l < lv.n_levels) {
+        const bool narrow = (level_ptr[l + 1] - level_ptr[l]) <= kMergeMax;
+        int e = l + 1;
+        while (e < lv.n_levels && ((level_ptr[e + 1] - level_ptr[e]) <= kMergeMax) == narrow) ++e;
+        Levels::Segment seg;
+        seg.lo = l;
+        seg.hi = e;
+        seg.merged = narrow && (e - l) >= 2;
+        lv.segments.push_back(seg);
+        l = e;
+    }
+    return DPCG_OK;
+}
+
+static int set_llt_from_host(dpcg_system *h, int mode, int64_t nnz, const int32_t *rp_in, const int32_t *ci_in,
+                             const double *v_in, hipStream_t s) {
+    const int64_t n = h->A.n;
+    // validate: lower triangular, ascending columns, diagonal last and positive
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t a = rp_in[i], b = rp_in[i + 1];
+        if (b <= a || ci_in[b - 1] != i) return invalid("L: every row needs its diagonal stored last");
+        for (int32_t k = a; k < b - 1; ++k)
+            if (ci_in[k] >= ci_in[k + 1]) return invalid("L: columns must ascend within a row (lower triangular)");
+        if (!(v_in[b - 1] > 0.0)) {
+            set_error("L: non-positive diagonal");
+            return DPCG_ERR_PIVOT;
+        }
+    }
+    if (rp_in[n] != nnz) return invalid("L: rowptr[n] != nnz");
+    DPCG_TRY(upload_csr(h->L, n, nnz, rp_in, ci_in, v_in, DPCG_F64, DPCG_HOST, 1, s));
+    // L^T as CSR: counting transpose, stable in the row index so columns ascend and the diagonal is first
+    std::vector<int32_t> trp((size_t)n + 1, 0), tci((size_t)nnz);
+    std::vector<double> tv((size_t)nnz);
+    for (int64_t k = 0; k < nnz; ++k) trp[ci_in[k] + 1]++;
+    for (int64_t i = 0; i < n; ++i) trp[i + 1] += trp[i];
+    {
+        std::vector<int32_t> cur(trp.begin(), trp.end() - 1);
+        for (int64_t i = 0; i < n; ++i)
+            for (int32_t k = rp_in[i]; k < rp_in[i + 1]; ++k) {
+                const int32_t dst = cur[ci_in[k]]++;
+                tci[dst] = (int32_t)i;
+                tv[dst] = v_in[k];
+            }
+    }
+    DPCG_TRY(upload_csr(h->Lt, n, nnz, trp.data(), tci.data(), tv.data(), DPCG_F64, DPCG_HOST, 1, s));
+    DPCG_TRY(make_plan(h->L, h->planL, s));
+    DPCG_TRY(make_plan(h->Lt, h->planLt, s));
+    if (mode == DPCG_PRECOND_LLT_SOLVE) {
+        std::vector<int32_t> rp(rp_in, rp_in + n + 1), ci(ci_in, ci_in + nnz), rows, lptr;
+        build_levels_host(n, rp, ci, false, rows, lptr);
+        DPCG_TRY(upload_levels(h->lvlL, rows, lptr, s));
+        build_levels_host(n, trp, tci, true, rows, lptr);
+        DPCG_TRY(upload_levels(h->lvlU, rows, lptr, s));
+    }
+    h->precond = mode;
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_set_precond_llt(dpcg_handle_t h, int mode, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                                    const double *val, int memspace, dpcg_stream_t stream) {
+    if (!h) return invalid("NULL handle");
+    if (mode != DPCG_PRECOND_LLT_MULTIPLY && mode != DPCG_PRECOND_LLT_SOLVE) return invalid("bad LLT mode");
+    if (nnz <= 0 || !rowptr || !col || !val) return invalid("dpcg_set_precond_llt: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    free_precond(h);
+    const int64_t n = h->A.n;
+    if (memspace == DPCG_HOST) return set_llt_from_host(h, mode, nnz, rowptr, col, val, s);
+    // device-resident factor (e.g. straight from the CNN): the structural analysis runs on the host
+    std::vector<int32_t> rp((size_t)n + 1), ci((size_t)nnz);
+    std::vector<double> v((size_t)nnz);
+    DPCG_HIP(hipMemcpyAsync(rp.data(), rowptr, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipMemcpyAsync(ci.data(), col, ci.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipMemcpyAsync(v.data(), val, v.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    return set_llt_from_host(h, mode, nnz, rp.data(), ci.data(), v.data(), s);
+}
+
+// IC(0) of A on its lower-triangular pattern (setup; stands in for ilupp.ichol0, test.py:83).
+// Row-oriented, sums over ascending columns, one product at a time (no FMA) -- the order the
+// oracle uses, so the factors agree bit for bit.
+extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t stream) {
+    if (!h) return invalid("NULL handle");
+    if (mode != DPCG_PRECOND_LLT_MULTIPLY && mode != DPCG_PRECOND_LLT_SOLVE) return invalid("bad LLT mode");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = h->A.n, nnz = h->A.nnz;
+    std::vector<int32_t> rp((size_t)n + 1), ci((size_t)nnz);
+    std::vector<double> v((size_t)nnz);
+    DPCG_HIP(hipMemcpyAsync(rp.data(), h->A.rowptr, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipMemcpyAsync(ci.data(), h->A.col, ci.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipMemcpyAsync(v.data(), h->A.val, v.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    std::vector<int32_t> lrp((size_t)n + 1, 0), lci;
+    std::vector<double> lv;
+    lci.reserve((size_t)nnz / 2 + n);
+    lv.reserve((size_t)nnz / 2 + n);
+    for (int64_t i = 0; i < n; ++i) {
+        for (int32_t k = rp[i]; k < rp[i + 1]; ++k)
+            if (ci[k] <= i) {
+                lci.push_back(ci[k]);
+                lv.push_back(v[k]);
+            }
+        lrp[i + 1] = (int32_t)lci.size();
+        if (lrp[i + 1] == lrp[i] || lci.back() != i) {
+            set_error("IC(0): missing diagonal entry");
+            return DPCG_ERR_PIVOT;
+        }
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t s_i = lrp[i], e_i = lrp[i + 1];
+        for (int32_t k = s_i; k < e_i; ++k) {
+            const int32_t j = lci[k];
+            const int32_t s_j = lrp[j], e_j = lrp[j + 1];
+            double acc = lv[k];
+            int32_t a = s_i, b = s_j;
+            while (a < k && b < e_j - 1) {
+                const int32_t ca = lci[a], cb = lci[b];
+                if (ca == cb) {
+                    const double prod = lv[a] * lv[b];
+                    acc = acc - prod;
+                    ++a;
+                    ++b;
+                } else if (ca < cb) ++a;
+                else ++b;
+            }
+            if (j < i) lv[k] = acc / lv[e_j - 1];
+            else {
+                if (!(acc > 0.0)) {
+                    set_error("IC(0): non-positive pivot at row " + std::to_string(i));
+                    return DPCG_ERR_PIVOT;
+                }
+                lv[k] = std::sqrt((double)acc);
+            }
+        }
+    }
+    free_precond(h);
+    return set_llt_from_host(h, mode, (int64_t)lci.size(), lrp.data(), lci.data(), lv.data(), s);
+}
+
+extern "C" int dpcg_get_factor(dpcg_handle_t h, int32_t *rowptr, int32_t *col, double *val) {
+    if (!h) return invalid("NULL handle");
+    if (h->precond != DPCG_PRECOND_LLT_MULTIPLY && h->precond != DPCG_PRECOND_LLT_SOLVE) {
+        set_error("dpcg_get_factor: no L factor set");
+        return DPCG_ERR_STATE;
+    }
+    DPCG_HIP(hipMemcpy(rowptr, h->L.rowptr, (size_t)(h->L.n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    DPCG_HIP(hipMemcpy(col, h->L.col, (size_t)h->L.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    DPCG_HIP(hipMemcpy(val, h->L.val, (size_t)h->L.nnz * sizeof(double), hipMemcpyDeviceToHost));
+    return DPCG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// standalone operators
+// ------------------------------------------------------------------------------------------------
+extern "C" int dpcg_spmv(dpcg_handle_t h, const double *x, double *y, dpcg_stream_t stream) {
+    if (!h || !x || !y) return invalid("dpcg_spmv: NULL argument");
+    launch_spmv(h->A, h->planA, x, y, nullptr, nullptr, (hipStream_t)stream);
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_spmv_f32(dpcg_handle_t h, const float *x, float *y, dpcg_stream_t stream) {
+    if (!h || !x || !y) return invalid("dpcg_spmv_f32: NULL argument");
+    if (!h->A.val32) {
+        DPCG_TRY(dev_alloc(&h->A.val32, h->A.nnz));
+        launch_f64_to_f32(h->A.nnz, h->A.val, h->A.val32, (hipStream_t)stream);
+    }
+    launch_spmv_f32out(h->A, h->planA, x, y, (hipStream_t)stream);
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
+// z = M r for the handle's preconditioner (cg.py:61,81).  `t` is the handle's scratch vector.
+static int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s) {
+    switch (h->precond) {
+        case DPCG_PRECOND_NONE:
+            if (z != r) DPCG_HIP(hipMemcpyAsync(z, r, (size_t)h->A.n * sizeof(double), hipMemcpyDeviceToDevice, s));
+            break;
+        case DPCG_PRECOND_JACOBI:
+            launch_scale(h->A.n, h->dinv, r, z, h->vec_grid, s);
+            break;
+        case DPCG_PRECOND_CSR:
+            launch_spmv(h->M, h->planM, r, z, nullptr, nullptr, s);
+            break;
+        case DPCG_PRECOND_LLT_MULTIPLY:
+            launch_spmv(h->Lt, h->planLt, r, h->t, nullptr, nullptr, s);
+            launch_spmv(h->L, h->planL, h->t, z, nullptr, nullptr, s);
+            break;
+        case DPCG_PRECOND_LLT_SOLVE:
+            launch_sptrsv(h->L, h->lvlL, false, r, h->t, s);
+            launch_sptrsv(h->Lt, h->lvlU, true, h->t, z, s);
+            break;
+        default:
+            set_error("unknown preconditioner kind");
+            return DPCG_ERR_STATE;
+    }
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_precond_apply(dpcg_handle_t h, const double *r, double *z, dpcg_stream_t stream) {
+    if (!h || !r || !z) return invalid("dpcg_precond_apply: NULL argument");
+    DPCG_TRY(ensure_work(h, 0, false, false));
+    DPCG_TRY(apply_precond(h, r, z, (hipStream_t)stream));
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_sptrsv(dpcg_handle_t h, int upper, const double *rhs, double *out, dpcg_stream_t stream) {
+    if (!h || !rhs || !out) return invalid("dpcg_sptrsv: NULL argument");
+    if (h->precond != DPCG_PRECOND_LLT_SOLVE) {
+        set_error("dpcg_sptrsv: needs dpcg_set_precond_llt/ic0 in LLT_SOLVE mode");
+        return DPCG_ERR_STATE;
+    }
+    if (upper) launch_sptrsv(h->Lt, h->lvlU, true, rhs, out, (hipStream_t)stream);
+    else launch_sptrsv(h->L, h->lvlL, false, rhs, out, (hipStream_t)stream);
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_dot(int64_t n, const double *a, const double *b, double *out_host, dpcg_stream_t stream) {
+    if (n <= 0 || !a || !b || !out_host) return invalid("dpcg_dot: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    double *part = nullptr;
+    DPCG_TRY(dev_alloc(&part, kMaxGrid + 1));
+    const int g = grid_for(n);
+    launch_dot_partials(n, nullptr, a, b, part, g, s);
+    launch_dot_final(part, g, part + kMaxGrid, s);
+    hipError_t e = hipMemcpyAsync(out_host, part + kMaxGrid, sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    dev_free(part);
+    DPCG_HIP(e);
+    return DPCG_OK;
+}
+
+// Times the SpMV+<p,Ap> kernel in exactly the instantiation the PCG loop launches (iteration head
+// included), `repeats` back-to-back launches bracketed by HIP events on `stream`.
+extern "C" int dpcg_spmv_dot_bench(dpcg_handle_t h, const double *x, double *y, int repeats, float *ms_per_launch,
+                                   dpcg_stream_t stream) {
+    if (!h || !x || !y || repeats <= 0 || !ms_per_launch) return invalid("dpcg_spmv_dot_bench: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    DPCG_TRY(ensure_work(h, 0, false, false));
+    // a never-converging control block: rr partials = {1,0,...}, bb = 1, thresholds 0
+    DPCG_HIP(hipMemsetAsync(h->part_rr, 0, kMaxGrid * sizeof(double), s));
+    DPCG_HIP(hipMemsetAsync(h->part_rz, 0, kMaxGrid * sizeof(double), s));
+    const double one = 1.0;
+    DPCG_HIP(hipMemcpyAsync(h->part_rr, &one, sizeof(double), hipMemcpyHostToDevice, s));
+    launch_finalize_init(h->scal, h->part_rr, 1, 0.0, 0.0, s);
+    IterCtl ctl{h->scal, h->part_rr, h->part_rz, h->vec_grid, h->hist, 0};
+    hipEvent_t e0, e1;
+    DPCG_HIP(hipEventCreate(&e0));
+    DPCG_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_spmv(h->A, h->planA, x, y, h->part_pq, &ctl, s);  // warm-up
+    DPCG_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < repeats; ++i) launch_spmv(h->A, h->planA, x, y, h->part_pq, &ctl, s);
+    DPCG_HIP(hipEventRecord(e1, s));
+    DPCG_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    DPCG_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = ms / (float)repeats;
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the solve
+// ------------------------------------------------------------------------------------------------
+static int default_chunk() {
+    const char *e = getenv("DPCG_CHUNK");
+    int c = e ? atoi(e) : 16;
+    return c < 1 ? 1 : (c > 256 ? 256 : c);
+}
+
+// One PCG update (cg.py:75-86) as kernel launches on `s`.
+static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hipStream_t s) {
+    const int64_t n = h->A.n;
+    const bool f32 = (flags & DPCG_SPMV_F32) != 0;
+    IterCtl ctl{h->scal, h->part_rr, h->part_rz, h->vec_grid, h->hist, h->hist_cap};
+    // K1: stopping test + Ap = A p + partials of <p,Ap>            cg.py:71,75,78
+    if (f32) launch_spmv_f32in(h->A, h->planA, h->p32, h->p, h->q, h->part_pq, &ctl, s);
+    else launch_spmv(h->A, h->planA, h->p, h->q, h->part_pq, &ctl, s);
+    // K2: alpha; x += alpha p; r -= alpha Ap; (z = M r fused); partials <r,z>, <r,r>   cg.py:78-82,86
+    const int pre = h->precond == DPCG_PRECOND_NONE ? 0 : (h->precond == DPCG_PRECOND_JACOBI ? 1 : 2);
+    double *z = pre == 0 ? h->r : h->z;
+    launch_update_xr(pre, n, h->scal, h->part_pq, h->planA.grid, h->p, h->q, h->x, h->r, h->dinv, h->z, h->part_rz,
+                     h->part_rr, h->vec_grid, s);
+    if (pre == 2) {
+        DPCG_TRY(apply_precond(h, h->r, h->z, s));                                   // cg.py:81
+        launch_dot_partials(n, h->scal, h->r, h->z, h->part_rz, h->vec_grid, s);     // cg.py:82
+    }
+    if (x_true) {                                                                    // cg.py:43-45
+        launch_anorm_err(n, h->scal, h->x, x_true, h->e, h->vec_grid, s);
+        launch_spmv(h->A, h->planA, h->e, h->t, h->part_bb, nullptr, s);
+        launch_record_err(h->scal, h->part_bb, h->planA.grid, h->err_hist, h->hist_cap, 0, s);
+    }
+    // K3: beta; p = z + beta p                                                      cg.py:82-83
+    launch_update_p(n, h->scal, h->part_rz, h->vec_grid, z, h->p, f32 ? h->p32 : nullptr, h->vec_grid, s);
+    return DPCG_OK;
+}
+
+static int ensure_graph(dpcg_system *h, int flags, int chunk) {
+    const int key = (h->precond << 8) | (flags & DPCG_SPMV_F32);
+    if (h->graph_exec && h->graph_key == key && h->graph_chunk == chunk) return DPCG_OK;
+    drop_graph(h);
+    HandleExtras &ex = extras()[h];
+    hipGraph_t graph = nullptr;
+    DPCG_HIP(hipStreamBeginCapture(ex.cap_stream, hipStreamCaptureModeThreadLocal));
+    int st = DPCG_OK;
+    for (int i = 0; i < chunk && st >= 0; ++i) st = enqueue_iteration(h, flags, nullptr, ex.cap_stream);
+    hipError_t e = hipStreamEndCapture(ex.cap_stream, &graph);
+    if (st < 0) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return st;
+    }
+    DPCG_HIP(e);
+    e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    DPCG_HIP(e);
+    h->graph_key = key;
+    h->graph_chunk = chunk;
+    return DPCG_OK;
+}
+
+namespace {
+struct Solve {
+    dpcg_system *h = nullptr;
+    hipStream_t s = nullptr;
+    int max_iter = 0, flags = 0, chunk = 16;
+    const double *x_true = nullptr;
+    bool use_graph = true;
+    int enq = 0;          // iterations enqueued
+    int inflight = 0;     // chunks enqueued whose flag has not been read yet
+    int head = 0, tail = 0;
+    bool converged = false, complete = false;
+    std::chrono::steady_clock::time_point t0;
+
+    int enqueue_chunk() {
+        HandleExtras &ex = extras()[h];
+        const int c = std::min(chunk, max_iter - enq);
+        if (use_graph && c == chunk) {
+            DPCG_HIP(hipGraphLaunch(h->graph_exec, s));
+        } else {
+            for (int i = 0; i < c; ++i) DPCG_TRY(enqueue_iteration(h, flags, x_true, s));
+        }
+        enq += c;
+        DPCG_HIP(hipMemcpyAsync(&ex.flag_host[tail], &h->scal->done, sizeof(int), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipEventRecord(ex.ev[tail], s));
+        tail ^= 1;
+        ++inflight;
+        return DPCG_OK;
+    }
+
+    // Enqueue the start of the solve (cg.py:58-67) and the first chunk; the timer starts after the
+    // initial residual/preconditioner work has drained, as the reference's does (cg.py:69).
+    int start(const double *b, const double *x0, double rtol_sq, double atol_sq) {
+        const int64_t n = h->A.n;
+        const bool f32 = (flags & DPCG_SPMV_F32) != 0;
+        DPCG_TRY(ensure_work(h, max_iter, f32, x_true != nullptr));
+        use_graph = !(flags & DPCG_NO_GRAPH) && !x_true && max_iter >= chunk;
+        if (use_graph) DPCG_TRY(ensure_graph(h, flags, chunk));
+        if (x0) {
+            DPCG_HIP(hipMemcpyAsync(h->x, x0, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+            launch_spmv(h->A, h->planA, h->x, h->q, nullptr, nullptr, s);
+            launch_residual(n, b, h->q, h->r, h->vec_grid, s);                       // cg.py:60
+        } else {
+            DPCG_HIP(hipMemsetAsync(h->x, 0, (size_t)n * sizeof(double), s));        // cg.py:58
+            DPCG_HIP(hipMemcpyAsync(h->r, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        double *z = h->precond == DPCG_PRECOND_NONE ? h->r : h->z;
+        if (h->precond != DPCG_PRECOND_NONE) DPCG_TRY(apply_precond(h, h->r, h->z, s));   // cg.py:61
+        launch_init_state(n, h->scal, b, h->r, z, h->p, f32 ? h->p32 : nullptr, h->part_bb, h->part_rz, h->part_rr,
+                          (flags & DPCG_INIT_CHECK_R) ? 1 : 0, h->vec_grid, s);
+        launch_finalize_init(h->scal, h->part_bb, h->vec_grid, rtol_sq, atol_sq, s);
+        if (x_true) {                                                                // cg.py:27-29
+            launch_anorm_err(n, h->scal, h->x, x_true, h->e, h->vec_grid, s);
+            launch_spmv(h->A, h->planA, h->e, h->t, h->part_bb, nullptr, s);
+            launch_record_err(h->scal, h->part_bb, h->planA.grid, h->err_hist, h->hist_cap, 0, s);
+        }
+        DPCG_CHECK_LAUNCH();
+        DPCG_HIP(hipStreamSynchronize(s));
+        t0 = std::chrono::steady_clock::now();                                       // cg.py:69
+        if (max_iter > 0) DPCG_TRY(enqueue_chunk());
+        else complete = true;
+        return DPCG_OK;
+    }
+
+    // Advance: keep two chunks in flight, read the oldest chunk's `done` flag.  Returns a negative
+    // status on error, 1 when the solve is complete, 0 when it has to be called again.
+    int step(bool blocking) {
+        if (complete) return 1;
+        HandleExtras &ex = extras()[h];
+        if (enq < max_iter && inflight < 2) DPCG_TRY(enqueue_chunk());
+        if (blocking) {
+            DPCG_HIP(hipEventSynchronize(ex.ev[head]));
+        } else {
+            hipError_t q = hipEventQuery(ex.ev[head]);
+            if (q == hipErrorNotReady) return 0;
+            DPCG_HIP(q);
+        }
+        const int flag = ex.flag_host[head];
+        head ^= 1;
+        --inflight;
+        if (flag) converged = true;
+        if (flag || (enq >= max_iter && inflight == 0)) complete = true;
+        return complete ? 1 : 0;
+    }
+
+    int finish(double *x, int *iters, double *final_res, double *seconds, double *res_history, double *err_history) {
+        const int64_t n = h->A.n;
+        launch_final_check(h->scal, h->part_rr, h->vec_grid, h->hist, h->hist_cap, max_iter, s);
+        DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        const auto t1 = std::chrono::steady_clock::now();                            // cg.py:88
+        const Scalars sc = *h->scal_host;
+        if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+        if (iters) *iters = sc.k;                                                    // cg.py:90
+        if (final_res) *final_res = sc.res;
+        if (res_history)
+            DPCG_HIP(hipMemcpyAsync(res_history, h->hist, (size_t)(sc.k + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (err_history && x_true)
+            DPCG_HIP(hipMemcpyAsync(err_history, h->err_hist, (size_t)(sc.k + 1) * sizeof(double),
+                                    hipMemcpyDeviceToHost, s));
+        if (x) DPCG_HIP(hipMemcpyAsync(x, h->x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        DPCG_CHECK_LAUNCH();
+        return sc.status;
+    }
+};
+}  // namespace
+
+static int check_solve_args(dpcg_handle_t h, const double *b, int max_iter, int flags, const double *x_true,
+                            double *err_history) {
+    if (!h || !b) return invalid("dpcg_solve: NULL handle or b");
+    if (max_iter < 0) return invalid("dpcg_solve: max_iter < 0");
+    if ((x_true == nullptr) != (err_history == nullptr) && x_true == nullptr)
+        return invalid("dpcg_solve: err_history needs x_true");
+    if ((flags & DPCG_SPMV_F32) && x_true) return invalid("dpcg_solve: x_true tracking is fp64 only");
+    if (h->precond == DPCG_PRECOND_JACOBI && !h->dinv) return DPCG_ERR_STATE;
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_solve(dpcg_handle_t h, const double *b, const double *x0, double *x, double rtol_sq,
+                          double atol_sq, int max_iter, int flags, dpcg_stream_t stream, int *iters,
+                          double *final_res, double *seconds, double *res_history, const double *x_true,
+                          double *err_history) {
+    DPCG_TRY(check_solve_args(h, b, max_iter, flags, x_true, err_history));
+    Solve sv;
+    sv.h = h;
+    sv.s = (hipStream_t)stream;
+    sv.max_iter = max_iter;
+    sv.flags = flags;
+    sv.chunk = default_chunk();
+    sv.x_true = x_true;
+    DPCG_TRY(sv.start(b, x0, rtol_sq, atol_sq));
+    for (;;) {
+        const int r = sv.step(true);
+        if (r < 0) return r;
+        if (r == 1) break;
+    }
+    return sv.finish(x, iters, final_res, seconds, res_history, err_history);
+}
+
+extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double *const *b, const double *const *x0,
+                                double *const *x, double rtol_sq, double atol_sq, int max_iter, int flags,
+                                int n_streams, int *iters, double *final_res, double *seconds, int *status) {
+    if (count <= 0 || !handles || !b) return invalid("dpcg_solve_batch: bad arguments");
+    if (n_streams < 1) n_streams = 1;
+    if (n_streams > 8) n_streams = 8;
+    if (n_streams > count) n_streams = count;
+    for (int i = 0; i < count; ++i) DPCG_TRY(check_solve_args(handles[i], b[i], max_iter, flags, nullptr, nullptr));
+    std::vector<hipStream_t> streams((size_t)n_streams, nullptr);
+    for (auto &st : streams) DPCG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    std::vector<Solve> sv((size_t)count);
+    std::vector<int> state((size_t)count, 0);  // 0 = waiting, 1 = running, 2 = finished
+    std::vector<int> slot_owner((size_t)n_streams, -1);
+    int worst = DPCG_OK, next = 0, done = 0, err = 0;
+    while (done < count && !err) {
+        bool progressed = false;
+        for (int sl = 0; sl < n_streams && !err; ++sl) {
+            int i = slot_owner[sl];
+            if (i < 0) {
+                if (next >= count) continue;
+                i = next++;
+                slot_owner[sl] = i;
+                Solve &v = sv[i];
+                v.h = handles[i];
+                v.s = streams[sl];
+                v.max_iter = max_iter;
+                v.flags = flags;
+                v.chunk = default_chunk();
+                int st = v.start(b[i], x0 ? x0[i] : nullptr, rtol_sq, atol_sq);
+                if (st < 0) { err = st; break; }
+                state[i] = 1;
+                progressed = true;
+            }
+            Solve &v = sv[i];
+            const int r = v.step(false);
+            if (r < 0) { err = r; break; }
+            if (r == 1) {
+                const int st = v.finish(x ? x[i] : nullptr, iters ? &iters[i] : nullptr,
+                                        final_res ? &final_res[i] : nullptr, seconds ? &seconds[i] : nullptr, nullptr,
+                                        nullptr);
+                if (st < 0) { err = st; break; }
+                if (status) status[i] = st;
+                worst = std::max(worst, st);
+                state[i] = 2;
+                slot_owner[sl] = -1;
+                ++done;
+                progressed = true;
+            }
+        }
+        if (!progressed) std::this_thread::yield();
+    }
+    for (auto &st : streams) {
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamDestroy(st);
+    }
+    return err ? err : worst;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generators and the batched COO SpMV
+// ------------------------------------------------------------------------------------------------
+extern "C" int dpcg_poisson_sizes(int dim, int64_t n, int64_t *rows, int64_t *nnz) {
+    if ((dim != 2 && dim != 3) || n < 1) return invalid("dpcg_poisson_sizes: dim must be 2 or 3, n >= 1");
+    const int64_t N = dim == 2 ? n * n : n * n * n;
+    const int64_t z = dim == 2 ? 5 * n * n - 4 * n : 7 * n * n * n - 6 * n * n;
+    if (z > 2147483647LL) return invalid("dpcg_poisson_sizes: nnz exceeds int32 CSR");
+    if (rows) *rows = N;
+    if (nnz) *nnz = z;
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void *val, int val_dtype,
+                                dpcg_stream_t stream) {
+    int64_t rows = 0, nnz = 0;
+    DPCG_TRY(dpcg_poisson_sizes(dim, n, &rows, &nnz));
+    if (!rowptr || !col || !val) return invalid("dpcg_gen_poisson: NULL output");
+    launch_gen_poisson(dim, n, rowptr, col, val, val_dtype, (hipStream_t)stream);
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_batched_coo_spmv(int64_t nnz, const int32_t *indices, const float *features, int batch,
+                                     int64_t dof, const float *vectors, float *out, int transpose,
+                                     dpcg_stream_t stream) {
+    if (nnz < 0 || batch <= 0 || dof <= 0 || !vectors || !out || (nnz > 0 && (!indices || !features)))
+        return invalid("dpcg_batched_coo_spmv: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DPCG_HIP(hipMemsetAsync(out, 0, (size_t)batch * (size_t)dof * sizeof(float), s));   // utils.py:29
+    if (nnz > 0) launch_batched_coo_spmv(nnz, indices, features, batch, dof, vectors, out, transpose, s);
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}

@@ -1,0 +1,154 @@
+// Internal declarations shared by the HIP translation units of libdpcg.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dpcg.h"
+
+namespace dpcg {
+
+// ---- launch geometry -----------------------------------------------------------------------
+// 256-thread workgroups = 4 wave64s, one per SIMD of a CU.  Persistent-style grids: at most
+// kMaxGrid workgroups (4 per CU on the 256 CUs of an MI355X) that stride over the work, so the
+// number of reduction partials is bounded and every kernel after a reduction can re-reduce the
+// partials itself (deterministically) instead of waiting on a host round trip or a float atomic.
+constexpr int kBlock = 256;
+constexpr int kMaxGrid = 1024;
+constexpr int kStreamCap = 2048;      // products staged in LDS per 256-row block (16 KiB)
+constexpr int kStreamRows = 256;      // rows per row-block of the CSR-stream SpMV
+
+enum SpmvKernel { SPMV_STREAM = 0, SPMV_VECTOR = 1 };
+
+struct CsrDev {
+    int64_t n = 0, nnz = 0;
+    int32_t *rowptr = nullptr;
+    int32_t *col = nullptr;
+    double *val = nullptr;    // fp64 values (always present after create)
+    float *val32 = nullptr;   // fp32 copy (created on demand / when given fp32)
+    bool owned = false;
+};
+
+struct SpmvPlan {
+    int kernel = SPMV_VECTOR;
+    int grid = 1;
+    int nrb = 0;          // row-blocks of kStreamRows rows (stream kernel)
+    int tpr = 4;          // threads per row (vector kernel)
+};
+
+// Device-resident scalar state of one solve.  Only block 0 of a kernel writes it; everybody else
+// reads values written by an EARLIER kernel, so no intra-kernel hand-off is needed.
+struct Scalars {
+    double rz;         // <r,z> of the current iterate (cg.py:76)
+    double bb;         // <b,b> (cg.py:17), computed once
+    double res;        // last tested squared relative residual
+    double rtol_sq;    // cg.py:71 threshold
+    double atol_sq;    // absolute threshold on <r,r> (0 for the reference)
+    int k;             // completed updates
+    int done;          // 1 once the stopping test held (kernels become no-ops)
+    int status;        // dpcg_status of the solve
+    int pad;
+};
+
+struct Levels {
+    int n_levels = 0;
+    int32_t *rows = nullptr;               // device: rows sorted by (level, row)
+    std::vector<int32_t> level_ptr;        // host: offsets into rows, n_levels+1
+    struct Segment { int lo, hi; bool merged; };  // [lo,hi) levels; merged = one workgroup walks them
+    std::vector<Segment> segments;
+    int32_t *level_ptr_dev = nullptr;      // device copy of level_ptr
+};
+
+}  // namespace dpcg
+
+struct dpcg_system {
+    dpcg::CsrDev A;
+    dpcg::SpmvPlan planA;
+    int precond = DPCG_PRECOND_NONE;
+    double *dinv = nullptr;
+    dpcg::CsrDev M;
+    dpcg::SpmvPlan planM;
+    dpcg::CsrDev L, Lt;
+    dpcg::SpmvPlan planL, planLt;
+    dpcg::Levels lvlL, lvlU;
+    // work vectors (fp64[n]) and reduction partials
+    double *x = nullptr, *r = nullptr, *z = nullptr, *p = nullptr, *q = nullptr, *t = nullptr, *e = nullptr;
+    float *p32 = nullptr;
+    double *part_pq = nullptr, *part_rz = nullptr, *part_rr = nullptr, *part_bb = nullptr;
+    dpcg::Scalars *scal = nullptr;        // device
+    dpcg::Scalars *scal_host = nullptr;   // pinned
+    double *hist = nullptr;               // device, hist_cap doubles
+    double *err_hist = nullptr;           // device, hist_cap doubles (x_true mode)
+    int hist_cap = 0;
+    int vec_grid = 1;
+    // cached iteration graph
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_key = -1;
+    int graph_chunk = 0;
+};
+
+namespace dpcg {
+
+// ---- error plumbing ------------------------------------------------------------------------
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+#define DPCG_HIP(call)                                                         \
+    do {                                                                       \
+        hipError_t _e = (call);                                                \
+        if (_e != hipSuccess) return ::dpcg::hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// ---- kernel launchers (dpcg_kernels.hip) -----------------------------------------------------
+// y = A x.  If part_pq != nullptr also writes per-workgroup partials of <x, y> (plan.grid of them).
+// `ctl` (may be null): when given, the kernel is the head of a PCG iteration: it first runs the
+// stopping test on part_rr/part_rz (n_part partials), records history, and returns early when done.
+struct IterCtl {
+    Scalars *scal;
+    const double *part_rr;
+    const double *part_rz;
+    int n_part;
+    double *hist;
+    int hist_cap;
+};
+void launch_spmv(const CsrDev &A, const SpmvPlan &plan, const double *x, double *y, double *part_pq,
+                 const IterCtl *ctl, hipStream_t s);
+void launch_spmv_f32in(const CsrDev &A, const SpmvPlan &plan, const float *x32, const double *x64, double *y,
+                       double *part_pq, const IterCtl *ctl, hipStream_t s);
+void launch_spmv_f32out(const CsrDev &A, const SpmvPlan &plan, const float *x32, float *y32, hipStream_t s);
+
+void launch_update_xr(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
+                      const double *p, const double *q, double *x, double *r, const double *dinv, double *z,
+                      double *part_rz, double *part_rr, int grid, hipStream_t s);
+void launch_dot_partials(int64_t n, const Scalars *scal, const double *a, const double *b, double *part, int grid,
+                         hipStream_t s);
+void launch_update_p(int64_t n, const Scalars *scal, const double *part_rz, int n_part, const double *z, double *p,
+                     float *p32, int grid, hipStream_t s);
+void launch_final_check(Scalars *scal, const double *part_rr, int n_part, double *hist, int hist_cap, int max_iter,
+                        hipStream_t s);
+void launch_init_state(int64_t n, Scalars *scal, const double *b, const double *r, const double *z, double *p,
+                       float *p32, double *part_bb, double *part_rz, double *part_rr, int init_check_r, int grid,
+                       hipStream_t s);
+void launch_finalize_init(Scalars *scal, const double *part_bb, int n_part, double rtol_sq, double atol_sq,
+                          hipStream_t s);
+void launch_residual(int64_t n, const double *b, const double *ax, double *r, int grid, hipStream_t s);
+void launch_scale(int64_t n, const double *dinv, const double *r, double *z, int grid, hipStream_t s);
+void launch_extract_dinv(const CsrDev &A, double *dinv, int *bad_flag, hipStream_t s);
+void launch_f64_to_f32(int64_t n, const double *in, float *out, hipStream_t s);
+void launch_f32_to_f64(int64_t n, const float *in, double *out, hipStream_t s);
+void launch_anorm_err(int64_t n, const Scalars *scal, const double *x, const double *x_true, double *e, int grid,
+                      hipStream_t s);
+void launch_record_err(const Scalars *scal, const double *part, int n_part, double *err_hist, int hist_cap,
+                       int at_k_minus_one, hipStream_t s);
+void launch_dot_final(const double *part, int n_part, double *out_dev, hipStream_t s);
+
+void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s);
+
+void launch_block_nnz_max(const CsrDev &A, int rows_per_block, int *out_max_dev, hipStream_t s);
+void launch_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void *val, int val_dtype, hipStream_t s);
+void launch_batched_coo_spmv(int64_t nnz, const int32_t *indices, const float *features, int batch, int64_t dof,
+                             const float *vectors, float *out, int transpose, hipStream_t s);
+
+}  // namespace dpcg

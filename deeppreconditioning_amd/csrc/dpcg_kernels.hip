@@ -1,0 +1,728 @@
+// Device kernels of libdpcg.so -- hand-written HIP for gfx950 (MI355X, CDNA4, wave64).
+//
+// Everything here is HBM-bandwidth work (SpMV, triangular solves, dots, axpys): no MFMA.  The
+// rules that matter are coalesced streams, LDS staging, enough workgroups in flight and as few
+// kernel boundaries / bytes per PCG iteration as possible.  Compiled with -ffp-contract=off so
+// that a*b+c is two roundings, as in the CPU reference path (scipy/ATen CSR row sums, unfused
+// torch mul+add at cg.py:79-83); the in-order row sums below then reproduce the oracle bit for bit.
+#include "dpcg_internal.h"
+
+namespace dpcg {
+
+// ------------------------------------------------------------------------------------------------
+// Deterministic reductions: wave64 shuffle tree -> 4 wave sums in LDS -> fixed-order add.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;  // valid in lane 0
+}
+
+// Sum over the 256 threads of the workgroup; every thread gets the result.  sh: 4 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+    v = wave_sum(v);
+    __syncthreads();  // sh may still be read from a previous use
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+// Every workgroup re-reduces the <= kMaxGrid partials a previous kernel wrote: same order in every
+// workgroup, so all of them hold bit-identical scalars without any inter-workgroup hand-off.
+__device__ __forceinline__ double reduce_partials(const double *__restrict__ part, int n_part, double *sh) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += kBlock) s += part[i];
+    return block_sum(s, sh);
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD one contiguous slab of the
+// work so the x-vector halo of neighbouring row-blocks is shared in that XCD's 4 MiB L2.
+// Placement is a speed matter only; any mapping gives the same result.
+__device__ __forceinline__ int virtual_block() {
+    const int G = gridDim.x, b = blockIdx.x;
+    return (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head of a PCG iteration (cg.py:71): stopping test, history, iteration count.  Returns true when
+// the iteration has to run.  All workgroups take the same decision from the same partials.
+// ------------------------------------------------------------------------------------------------
+struct IterCtlDev {
+    Scalars *scal;
+    const double *part_rr;
+    const double *part_rz;
+    int n_part;
+    double *hist;
+    int hist_cap;
+};
+
+__device__ __forceinline__ bool iteration_head(const IterCtlDev &c, double *sh) {
+    Scalars *sc = c.scal;
+    if (sc->done) return false;
+    const double rr = reduce_partials(c.part_rr, c.n_part, sh);
+    const double res = rr / sc->bb;                                     // cg.py:15-17
+    const bool conv = (res < sc->rtol_sq) || (rr < sc->atol_sq);        // cg.py:71
+    const bool bad = !(res == res);
+    if (blockIdx.x == 0) {
+        double rz = 0.0;
+        if (!conv && !bad) rz = reduce_partials(c.part_rz, c.n_part, sh);   // cg.py:76
+        if (threadIdx.x == 0) {
+            const int k = sc->k;
+            if (k < c.hist_cap) c.hist[k] = res;                         // cg.py:67,88
+            sc->res = res;
+            if (conv) { sc->done = 1; sc->status = DPCG_OK; }
+            else if (bad) { sc->done = 1; sc->status = DPCG_BREAKDOWN; }
+            else { sc->k = k + 1; sc->rz = rz; }
+        }
+    }
+    return !(conv || bad);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR-stream SpMV (rows with few non-zeros: 5/7-point stencils, OpenFOAM-like matrices).
+//
+// A workgroup takes 256 consecutive rows.  Their val[]/col[] segment is contiguous in CSR, so the
+// 256 threads stream it with fully coalesced loads (lane i <-> non-zero base+i), multiply by the
+// gathered x[col] (served by L1/L2: neighbouring rows share columns) and park the products in LDS.
+// After a barrier thread i adds up the products of row i IN COLUMN ORDER -- the same order and
+// rounding as a sequential CPU CSR row sum.  LDS reads are conflict-free for odd row lengths
+// (stride 5 or 7 doubles over 32 lanes).  Algorithmic bytes: nnz*(wv+4) + (n+1)*4 + 2*n*wx.
+// ------------------------------------------------------------------------------------------------
+template <typename VT, typename XT, bool CTL, bool DOT, typename YT>
+__global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t *__restrict__ rowptr,
+                                                        const int32_t *__restrict__ col,
+                                                        const VT *__restrict__ val, const XT *__restrict__ x,
+                                                        const double *__restrict__ xdot, YT *__restrict__ y,
+                                                        int nrb, double *__restrict__ part_pq, IterCtlDev ctl) {
+    __shared__ double prod[kStreamCap];
+    __shared__ double sh[4];
+    if (CTL) {
+        if (!iteration_head(ctl, sh)) return;
+    }
+    const int t = threadIdx.x;
+    const int G = gridDim.x;
+    const int v = virtual_block();
+    const int rb_lo = (int)(((int64_t)v * nrb) / G);
+    const int rb_hi = (int)(((int64_t)(v + 1) * nrb) / G);
+    double acc = 0.0;
+    for (int rb = rb_lo; rb < rb_hi; ++rb) {
+        const int64_t r0 = (int64_t)rb * kStreamRows;
+        const int64_t row = r0 + t;
+        const int64_t rlast = (r0 + kStreamRows < n) ? r0 + kStreamRows : n;
+        const int base = rowptr[r0];
+        const int cnt = rowptr[rlast] - base;
+        int rs = 0, re = 0;
+        if (row < n) {
+            rs = rowptr[row] - base;
+            re = rowptr[row + 1] - base;
+        }
+        const int32_t *__restrict__ cb = col + base;
+        const VT *__restrict__ vb = val + base;
+        // product phase: 4 independent (col,val) loads in flight per thread before the gathers
+        for (int k0 = t; k0 < cnt; k0 += 4 * kBlock) {
+            int c[4];
+            VT a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * kBlock;
+                const int kk = k < cnt ? k : cnt - 1;
+                c[u] = cb[kk];
+                a[u] = vb[kk];
+            }
+            double xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xv[u] = (double)x[c[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * kBlock;
+                if (k < cnt) prod[k] = (double)a[u] * xv[u];
+            }
+        }
+        __syncthreads();
+        if (row < n) {
+            double s = 0.0;
+            for (int k = rs; k < re; ++k) s += prod[k];
+            y[row] = (YT)s;
+            if (DOT) acc += s * xdot[row];
+        }
+        __syncthreads();
+    }
+    if (DOT) {
+        const double tot = block_sum(acc, sh);
+        if (t == 0) part_pq[blockIdx.x] = tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR-vector SpMV (longer rows: M = L L^T, dilated learned factors).  TPR lanes share a row, each
+// strides over its non-zeros, then a shuffle tree combines them (order differs from the sequential
+// sum: parity for this kernel is tolerance-based, ~1 ulp of the row's magnitude).
+// ------------------------------------------------------------------------------------------------
+template <int TPR, typename VT, typename XT, bool CTL, bool DOT, typename YT>
+__global__ __launch_bounds__(kBlock) void k_spmv_vector(int64_t n, const int32_t *__restrict__ rowptr,
+                                                        const int32_t *__restrict__ col,
+                                                        const VT *__restrict__ val, const XT *__restrict__ x,
+                                                        const double *__restrict__ xdot, YT *__restrict__ y,
+                                                        double *__restrict__ part_pq, IterCtlDev ctl) {
+    __shared__ double sh[4];
+    if (CTL) {
+        if (!iteration_head(ctl, sh)) return;
+    }
+    constexpr int RPB = kBlock / TPR;  // rows per workgroup step
+    const int t = threadIdx.x;
+    const int lane = t % TPR;
+    const int G = gridDim.x;
+    const int v = virtual_block();
+    const int64_t ngroups = (n + RPB - 1) / RPB;
+    const int64_t g_lo = (v * ngroups) / G, g_hi = ((v + 1) * ngroups) / G;
+    double acc = 0.0;
+    for (int64_t g = g_lo; g < g_hi; ++g) {
+        const int64_t row = g * RPB + t / TPR;
+        double s = 0.0;
+        if (row < n) {
+            const int rs = rowptr[row], re = rowptr[row + 1];
+            for (int k = rs + lane; k < re; k += TPR) s += (double)val[k] * (double)x[col[k]];
+        }
+#pragma unroll
+        for (int off = TPR / 2; off > 0; off >>= 1) s += __shfl_down(s, off, TPR);
+        if (lane == 0 && row < n) {
+            y[row] = (YT)s;
+            if (DOT) acc += s * xdot[row];
+        }
+    }
+    if (DOT) {
+        const double tot = block_sum(acc, sh);
+        if (t == 0) part_pq[blockIdx.x] = tot;
+    }
+}
+
+static IterCtlDev to_dev(const IterCtl *c) {
+    IterCtlDev d{nullptr, nullptr, nullptr, 0, nullptr, 0};
+    if (c) d = IterCtlDev{c->scal, c->part_rr, c->part_rz, c->n_part, c->hist, c->hist_cap};
+    return d;
+}
+
+template <typename VT, typename XT, typename YT>
+static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, const XT *x, const double *xdot,
+                          YT *y, double *part_pq, const IterCtl *ctl, hipStream_t s) {
+    const IterCtlDev d = to_dev(ctl);
+    const bool dot = part_pq != nullptr;
+    const bool c = ctl != nullptr;
+#define DPCG_LAUNCH_STREAM(CTLV, DOTV)                                                                     \
+    hipLaunchKernelGGL((k_spmv_stream<VT, XT, CTLV, DOTV, YT>), dim3(plan.grid), dim3(kBlock), 0, s, A.n, \
+                       A.rowptr, A.col, val, x, xdot, y, plan.nrb, part_pq, d)
+#define DPCG_LAUNCH_VECTOR(TPRV, CTLV, DOTV)                                                                     \
+    hipLaunchKernelGGL((k_spmv_vector<TPRV, VT, XT, CTLV, DOTV, YT>), dim3(plan.grid), dim3(kBlock), 0, s, A.n, \
+                       A.rowptr, A.col, val, x, xdot, y, part_pq, d)
+#define DPCG_VECTOR_CASE(TPRV)                         \
+    case TPRV:                                         \
+        if (c && dot) DPCG_LAUNCH_VECTOR(TPRV, true, true);   \
+        else if (dot) DPCG_LAUNCH_VECTOR(TPRV, false, true);  \
+        else DPCG_LAUNCH_VECTOR(TPRV, false, false);          \
+        break
+    if (plan.kernel == SPMV_STREAM) {
+        if (c && dot) DPCG_LAUNCH_STREAM(true, true);
+        else if (dot) DPCG_LAUNCH_STREAM(false, true);
+        else DPCG_LAUNCH_STREAM(false, false);
+    } else {
+        switch (plan.tpr) {
+            DPCG_VECTOR_CASE(2);
+            DPCG_VECTOR_CASE(4);
+            DPCG_VECTOR_CASE(8);
+            DPCG_VECTOR_CASE(16);
+            DPCG_VECTOR_CASE(32);
+            default:
+                DPCG_VECTOR_CASE(64);
+        }
+    }
+#undef DPCG_VECTOR_CASE
+#undef DPCG_LAUNCH_VECTOR
+#undef DPCG_LAUNCH_STREAM
+}
+
+void launch_spmv(const CsrDev &A, const SpmvPlan &plan, const double *x, double *y, double *part_pq,
+                 const IterCtl *ctl, hipStream_t s) {
+    spmv_dispatch<double, double, double>(A, plan, A.val, x, x, y, part_pq, ctl, s);
+}
+
+// Mixed precision (config C5): fp32 matrix values and fp32 gathered vector, fp64 products/sums.
+void launch_spmv_f32in(const CsrDev &A, const SpmvPlan &plan, const float *x32, const double *x64, double *y,
+                       double *part_pq, const IterCtl *ctl, hipStream_t s) {
+    spmv_dispatch<float, float, double>(A, plan, A.val32, x32, x64, y, part_pq, ctl, s);
+}
+
+void launch_spmv_f32out(const CsrDev &A, const SpmvPlan &plan, const float *x32, float *y32, hipStream_t s) {
+    spmv_dispatch<float, float, float>(A, plan, A.val32, x32, nullptr, y32, nullptr, nullptr, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Vector updates of the iteration (cg.py:78-83), fused: one pass over p,q,x,r,(dinv) -> x,r,z.
+// ------------------------------------------------------------------------------------------------
+// PRE: 0 = M = I (z aliases r, not stored), 1 = Jacobi fused, 2 = generic M (z computed later).
+template <int PRE>
+__global__ __launch_bounds__(kBlock) void k_update_xr(int64_t n, const Scalars *__restrict__ sc,
+                                                      const double *__restrict__ part_pq, int n_part_pq,
+                                                      const double *__restrict__ p, const double *__restrict__ q,
+                                                      double *__restrict__ x, double *__restrict__ r,
+                                                      const double *__restrict__ dinv, double *__restrict__ z,
+                                                      double *__restrict__ part_rz, double *__restrict__ part_rr) {
+    __shared__ double sh[4];
+    if (sc->done) return;
+    const double pq = reduce_partials(part_pq, n_part_pq, sh);
+    const double alpha = sc->rz / pq;                                   // cg.py:78
+    double a_rz = 0.0, a_rr = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double pi = p[i], qi = q[i];
+        x[i] = x[i] + alpha * pi;                                       // cg.py:79
+        const double ri = r[i] - alpha * qi;                            // cg.py:80
+        r[i] = ri;
+        a_rr += ri * ri;                                                // cg.py:86
+        if (PRE == 1) {
+            const double zi = dinv[i] * ri;                             // cg.py:81 (M = diag(1/a_ii))
+            z[i] = zi;
+            a_rz += ri * zi;                                            // cg.py:82
+        }
+    }
+    const double t_rr = block_sum(a_rr, sh);
+    if (PRE == 1) {
+        const double t_rz = block_sum(a_rz, sh);
+        if (threadIdx.x == 0) part_rz[blockIdx.x] = t_rz;
+    }
+    if (threadIdx.x == 0) {
+        part_rr[blockIdx.x] = t_rr;
+        if (PRE == 0) part_rz[blockIdx.x] = t_rr;                       // z = r
+    }
+}
+
+void launch_update_xr(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
+                      const double *p, const double *q, double *x, double *r, const double *dinv, double *z,
+                      double *part_rz, double *part_rr, int grid, hipStream_t s) {
+    if (precond_fused == 0)
+        hipLaunchKernelGGL(k_update_xr<0>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, p, q, x, r,
+                           dinv, z, part_rz, part_rr);
+    else if (precond_fused == 1)
+        hipLaunchKernelGGL(k_update_xr<1>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, p, q, x, r,
+                           dinv, z, part_rz, part_rr);
+    else
+        hipLaunchKernelGGL(k_update_xr<2>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, p, q, x, r,
+                           dinv, z, part_rz, part_rr);
+}
+
+// part[b] = partial of <a,b>; skipped once the solve is done (scal may be null: always run).
+__global__ __launch_bounds__(kBlock) void k_dot_partials(int64_t n, const Scalars *__restrict__ sc,
+                                                         const double *__restrict__ a, const double *__restrict__ b,
+                                                         double *__restrict__ part) {
+    __shared__ double sh[4];
+    if (sc && sc->done) return;
+    double acc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) acc += a[i] * b[i];
+    const double tot = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+void launch_dot_partials(int64_t n, const Scalars *scal, const double *a, const double *b, double *part, int grid,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(k_dot_partials, dim3(grid), dim3(kBlock), 0, s, n, scal, a, b, part);
+}
+
+// p = z + beta p (cg.py:82-83); optionally also the fp32 copy the mixed-precision SpMV gathers.
+template <bool P32>
+__global__ __launch_bounds__(kBlock) void k_update_p(int64_t n, const Scalars *__restrict__ sc,
+                                                     const double *__restrict__ part_rz, int n_part,
+                                                     const double *__restrict__ z, double *__restrict__ p,
+                                                     float *__restrict__ p32) {
+    __shared__ double sh[4];
+    if (sc->done) return;
+    const double rz_new = reduce_partials(part_rz, n_part, sh);
+    const double beta = rz_new / sc->rz;                                // cg.py:82
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double pi = z[i] + beta * p[i];                           // cg.py:83
+        p[i] = pi;
+        if (P32) p32[i] = (float)pi;
+    }
+}
+
+void launch_update_p(int64_t n, const Scalars *scal, const double *part_rz, int n_part, const double *z, double *p,
+                     float *p32, int grid, hipStream_t s) {
+    if (p32)
+        hipLaunchKernelGGL(k_update_p<true>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, n_part, z, p, p32);
+    else
+        hipLaunchKernelGGL(k_update_p<false>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, n_part, z, p, p32);
+}
+
+// After the last permitted update: test the final residual (cg.py:86 of the last pass) and set status.
+__global__ __launch_bounds__(kBlock) void k_final_check(Scalars *sc, const double *__restrict__ part_rr, int n_part,
+                                                        double *hist, int hist_cap, int max_iter) {
+    __shared__ double sh[4];
+    if (sc->done) return;
+    const double rr = reduce_partials(part_rr, n_part, sh);
+    if (threadIdx.x == 0) {
+        const double res = rr / sc->bb;
+        const int k = sc->k;
+        if (k < hist_cap) hist[k] = res;
+        sc->res = res;
+        const bool conv = (res < sc->rtol_sq) || (rr < sc->atol_sq);
+        sc->status = conv ? DPCG_OK : (res == res ? DPCG_MAX_ITER : DPCG_BREAKDOWN);
+        sc->done = 1;
+        (void)max_iter;
+    }
+}
+
+void launch_final_check(Scalars *scal, const double *part_rr, int n_part, double *hist, int hist_cap, int max_iter,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(k_final_check, dim3(1), dim3(kBlock), 0, s, scal, part_rr, n_part, hist, hist_cap, max_iter);
+}
+
+// Start of a solve (cg.py:62-66): p = z, partials of <b,b>, <r,z> and of the first tested quantity
+// (<z,z> for the reference's quirk at cg.py:66, <r,r> for scipy-style).
+template <bool P32>
+__global__ __launch_bounds__(kBlock) void k_init_state(int64_t n, const double *__restrict__ b,
+                                                       const double *__restrict__ r, const double *__restrict__ z,
+                                                       double *__restrict__ p, float *__restrict__ p32,
+                                                       double *__restrict__ part_bb, double *__restrict__ part_rz,
+                                                       double *__restrict__ part_rr, int init_check_r) {
+    __shared__ double sh[4];
+    double a_bb = 0.0, a_rz = 0.0, a_t = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double bi = b[i], ri = r[i], zi = z[i];
+        p[i] = zi;                                                      // cg.py:62
+        if (P32) p32[i] = (float)zi;
+        a_bb += bi * bi;
+        a_rz += ri * zi;
+        a_t += init_check_r ? ri * ri : zi * zi;                        // cg.py:66 tests zk
+    }
+    const double t_bb = block_sum(a_bb, sh);
+    const double t_rz = block_sum(a_rz, sh);
+    const double t_t = block_sum(a_t, sh);
+    if (threadIdx.x == 0) {
+        part_bb[blockIdx.x] = t_bb;
+        part_rz[blockIdx.x] = t_rz;
+        part_rr[blockIdx.x] = t_t;
+    }
+}
+
+void launch_init_state(int64_t n, Scalars *scal, const double *b, const double *r, const double *z, double *p,
+                       float *p32, double *part_bb, double *part_rz, double *part_rr, int init_check_r, int grid,
+                       hipStream_t s) {
+    (void)scal;
+    if (p32)
+        hipLaunchKernelGGL(k_init_state<true>, dim3(grid), dim3(kBlock), 0, s, n, b, r, z, p, p32, part_bb, part_rz,
+                           part_rr, init_check_r);
+    else
+        hipLaunchKernelGGL(k_init_state<false>, dim3(grid), dim3(kBlock), 0, s, n, b, r, z, p, p32, part_bb, part_rz,
+                           part_rr, init_check_r);
+}
+
+__global__ __launch_bounds__(kBlock) void k_finalize_init(Scalars *sc, const double *__restrict__ part_bb, int n_part,
+                                                          double rtol_sq, double atol_sq) {
+    __shared__ double sh[4];
+    const double bb = reduce_partials(part_bb, n_part, sh);
+    if (threadIdx.x == 0) {
+        sc->bb = bb;
+        sc->rz = 0.0;
+        sc->res = 0.0;
+        sc->rtol_sq = rtol_sq;
+        sc->atol_sq = atol_sq;
+        sc->k = 0;
+        sc->done = 0;
+        sc->status = DPCG_MAX_ITER;
+        sc->pad = 0;
+    }
+}
+
+void launch_finalize_init(Scalars *scal, const double *part_bb, int n_part, double rtol_sq, double atol_sq,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize_init, dim3(1), dim3(kBlock), 0, s, scal, part_bb, n_part, rtol_sq, atol_sq);
+}
+
+// r = b - A x0 (cg.py:60), ax = A x0 computed by the SpMV before.
+__global__ __launch_bounds__(kBlock) void k_residual(int64_t n, const double *__restrict__ b,
+                                                     const double *__restrict__ ax, double *__restrict__ r) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) r[i] = b[i] - ax[i];
+}
+
+void launch_residual(int64_t n, const double *b, const double *ax, double *r, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(k_residual, dim3(grid), dim3(kBlock), 0, s, n, b, ax, r);
+}
+
+// z = dinv .* r (Jacobi apply outside the fused path).
+__global__ __launch_bounds__(kBlock) void k_scale(int64_t n, const double *__restrict__ dinv,
+                                                  const double *__restrict__ r, double *__restrict__ z) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) z[i] = dinv[i] * r[i];
+}
+
+void launch_scale(int64_t n, const double *dinv, const double *r, double *z, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(k_scale, dim3(grid), dim3(kBlock), 0, s, n, dinv, r, z);
+}
+
+// dinv[i] = 1 / a_ii (test.py:76); flags a missing or non-positive diagonal.
+__global__ __launch_bounds__(kBlock) void k_extract_dinv(int64_t n, const int32_t *__restrict__ rowptr,
+                                                         const int32_t *__restrict__ col,
+                                                         const double *__restrict__ val, double *__restrict__ dinv,
+                                                         int *bad) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        double d = 0.0;
+        for (int k = rowptr[i]; k < rowptr[i + 1]; ++k)
+            if (col[k] == i) d = val[k];
+        if (!(d > 0.0)) atomicExch(bad, 1);
+        dinv[i] = 1.0 / d;
+    }
+}
+
+void launch_extract_dinv(const CsrDev &A, double *dinv, int *bad_flag, hipStream_t s) {
+    int64_t g = (A.n + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_extract_dinv, dim3((int)g), dim3(kBlock), 0, s, A.n, A.rowptr, A.col, A.val, dinv, bad_flag);
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(kBlock) void k_convert(int64_t n, const TI *__restrict__ in, TO *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = (TO)in[i];
+}
+
+static int conv_grid(int64_t n) {
+    int64_t g = (n + kBlock - 1) / kBlock;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+void launch_f64_to_f32(int64_t n, const double *in, float *out, hipStream_t s) {
+    hipLaunchKernelGGL((k_convert<double, float>), dim3(conv_grid(n)), dim3(kBlock), 0, s, n, in, out);
+}
+void launch_f32_to_f64(int64_t n, const float *in, double *out, hipStream_t s) {
+    hipLaunchKernelGGL((k_convert<float, double>), dim3(conv_grid(n)), dim3(kBlock), 0, s, n, in, out);
+}
+
+// e = x - x_true (cg.py:27,43): only for conjugate_gradient(..., x_true=...).
+__global__ __launch_bounds__(kBlock) void k_anorm_err(int64_t n, const Scalars *__restrict__ sc,
+                                                      const double *__restrict__ x,
+                                                      const double *__restrict__ x_true, double *__restrict__ e) {
+    if (sc->done) return;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) e[i] = x[i] - x_true[i];
+}
+
+void launch_anorm_err(int64_t n, const Scalars *scal, const double *x, const double *x_true, double *e, int grid,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_anorm_err, dim3(grid), dim3(kBlock), 0, s, n, scal, x, x_true, e);
+}
+
+// err_hist[k] = <e, A e> (cg.py:29,45) for the iterate the loop has just produced.
+__global__ __launch_bounds__(kBlock) void k_record_err(const Scalars *__restrict__ sc, const double *__restrict__ part,
+                                                       int n_part, double *err_hist, int hist_cap) {
+    __shared__ double sh[4];
+    if (sc->done) return;
+    const double v = reduce_partials(part, n_part, sh);
+    if (threadIdx.x == 0 && sc->k < hist_cap) err_hist[sc->k] = v;
+}
+
+void launch_record_err(const Scalars *scal, const double *part, int n_part, double *err_hist, int hist_cap,
+                       int at_k_minus_one, hipStream_t s) {
+    (void)at_k_minus_one;
+    hipLaunchKernelGGL(k_record_err, dim3(1), dim3(kBlock), 0, s, scal, part, n_part, err_hist, hist_cap);
+}
+
+__global__ __launch_bounds__(kBlock) void k_dot_final(const double *__restrict__ part, int n_part, double *out) {
+    __shared__ double sh[4];
+    const double v = reduce_partials(part, n_part, sh);
+    if (threadIdx.x == 0) *out = v;
+}
+
+void launch_dot_final(const double *part, int n_part, double *out_dev, hipStream_t s) {
+    hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(kBlock), 0, s, part, n_part, out_dev);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Level-scheduled sparse triangular solves (LLT_SOLVE: z = L^-T (L^-1 r)).
+// Rows of one level are independent; one thread owns a row and subtracts its products in column
+// order, then divides by the diagonal -- bit-identical to sequential substitution.
+// Lower factor: diagonal LAST in the row.  Upper (L^T as CSR): diagonal FIRST.
+// ------------------------------------------------------------------------------------------------
+template <bool UPPER>
+__device__ __forceinline__ double trsv_row(int i, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                           const double *__restrict__ v, const double *__restrict__ rhs,
+                                           const double *out) {
+    const int s = rp[i], e = rp[i + 1];
+    double acc = rhs[i];
+    if (UPPER) {
+        for (int k = s + 1; k < e; ++k) acc -= v[k] * out[ci[k]];
+        return acc / v[s];
+    } else {
+        for (int k = s; k < e - 1; ++k) acc -= v[k] * out[ci[k]];
+        return acc / v[e - 1];
+    }
+}
+
+template <bool UPPER>
+__global__ __launch_bounds__(kBlock) void k_sptrsv_level(const int32_t *__restrict__ rows, int count,
+                                                         const int32_t *__restrict__ rp,
+                                                         const int32_t *__restrict__ ci,
+                                                         const double *__restrict__ v,
+                                                         const double *__restrict__ rhs, double *out) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= count) return;
+    const int i = rows[idx];
+    out[i] = trsv_row<UPPER>(i, rp, ci, v, rhs, out);
+}
+
+// A run of narrow levels walked by ONE workgroup of 1024 threads with a barrier between levels
+// (cheaper than one launch per level: ~1.5 us boundary each).  Values handed from level to level
+// go through L2 with agent-scope (sc1) accesses so no wave reads a stale line from its CU's L1.
+constexpr int kMergedBlock = 1024;
+template <bool UPPER>
+__global__ __launch_bounds__(kMergedBlock) void k_sptrsv_merged(const int32_t *__restrict__ rows,
+                                                                const int32_t *__restrict__ level_ptr, int lvl_lo,
+                                                                int lvl_hi, const int32_t *__restrict__ rp,
+                                                                const int32_t *__restrict__ ci,
+                                                                const double *__restrict__ v,
+                                                                const double *__restrict__ rhs, double *out) {
+    for (int lvl = lvl_lo; lvl < lvl_hi; ++lvl) {
+        const int lo = level_ptr[lvl], hi = level_ptr[lvl + 1];
+        for (int idx = lo + (int)threadIdx.x; idx < hi; idx += kMergedBlock) {
+            const int i = rows[idx];
+            const int s = rp[i], e = rp[i + 1];
+            double acc = rhs[i];
+            const int ks = UPPER ? s + 1 : s, ke = UPPER ? e : e - 1;
+            for (int k = ks; k < ke; ++k)
+                acc -= v[k] * __hip_atomic_load(out + ci[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double res = acc / v[UPPER ? s : e - 1];
+            __hip_atomic_store(out + i, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();  // includes s_waitcnt vmcnt(0): this level's stores have reached L2
+    }
+}
+
+void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s) {
+    for (const auto &seg : lv.segments) {
+        if (seg.merged) {
+            if (upper)
+                hipLaunchKernelGGL(k_sptrsv_merged<true>, dim3(1), dim3(kMergedBlock), 0, s, lv.rows, lv.level_ptr_dev,
+                                   seg.lo, seg.hi, T.rowptr, T.col, T.val, rhs, out);
+            else
+                hipLaunchKernelGGL(k_sptrsv_merged<false>, dim3(1), dim3(kMergedBlock), 0, s, lv.rows,
+                                   lv.level_ptr_dev, seg.lo, seg.hi, T.rowptr, T.col, T.val, rhs, out);
+        } else {
+            for (int l = seg.lo; l < seg.hi; ++l) {
+                const int lo = lv.level_ptr[l], cnt = lv.level_ptr[l + 1] - lo;
+                const int grid = (cnt + kBlock - 1) / kBlock;
+                if (upper)
+                    hipLaunchKernelGGL(k_sptrsv_level<true>, dim3(grid), dim3(kBlock), 0, s, lv.rows + lo, cnt,
+                                       T.rowptr, T.col, T.val, rhs, out);
+                else
+                    hipLaunchKernelGGL(k_sptrsv_level<false>, dim3(grid), dim3(kBlock), 0, s, lv.rows + lo, cnt,
+                                       T.rowptr, T.col, T.val, rhs, out);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Setup helpers
+// ------------------------------------------------------------------------------------------------
+// max over row-blocks of the non-zeros in `rows_per_block` consecutive rows (stream-kernel test).
+__global__ __launch_bounds__(kBlock) void k_block_nnz_max(int64_t n, const int32_t *__restrict__ rowptr,
+                                                          int rows_per_block, int *out_max) {
+    const int64_t nrb = (n + rows_per_block - 1) / rows_per_block;
+    int m = 0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t rb = (int64_t)blockIdx.x * kBlock + threadIdx.x; rb < nrb; rb += stride) {
+        const int64_t r0 = rb * rows_per_block;
+        const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+        const int c = rowptr[r1] - rowptr[r0];
+        m = c > m ? c : m;
+    }
+    atomicMax(out_max, m);
+}
+
+void launch_block_nnz_max(const CsrDev &A, int rows_per_block, int *out_max_dev, hipStream_t s) {
+    const int64_t nrb = (A.n + rows_per_block - 1) / rows_per_block;
+    int64_t g = (nrb + kBlock - 1) / kBlock;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_block_nnz_max, dim3((int)g), dim3(kBlock), 0, s, A.n, A.rowptr, rows_per_block, out_max_dev);
+}
+
+// Closed-form 5-point / 7-point Poisson CSR (kron(I,T)+kron(T,I)[+...], T = tridiag(-1,2,-1)),
+// one thread per row, columns ascending.  Generated in HBM so the 256^3 systems (1.4 GB each) never
+// cross PCIe.
+template <typename VT>
+__global__ __launch_bounds__(kBlock) void k_gen_poisson(int dim, int64_t n, int32_t *__restrict__ rowptr,
+                                                        int32_t *__restrict__ col, VT *__restrict__ val) {
+    const int64_t n2 = n * n;
+    const int64_t N = dim == 2 ? n2 : n2 * n;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= N; i += stride) {
+        // non-zeros before row i: full stencil minus the neighbours cut off by each face
+        int64_t before;
+        if (dim == 2) {
+            const int64_t lo_y = i < n ? i : n;                         // rows with iy == 0
+            const int64_t hi_y = i > n * (n - 1) ? i - n * (n - 1) : 0; // rows with iy == n-1
+            before = 5 * i - lo_y - hi_y - (i + n - 1) / n - i / n;
+        } else {
+            const int64_t lo_z = i < n2 ? i : n2;
+            const int64_t hi_z = i > n2 * (n - 1) ? i - n2 * (n - 1) : 0;
+            const int64_t planes = i / n2, rem = i % n2;
+            const int64_t lo_y = planes * n + (rem < n ? rem : n);
+            const int64_t hi_y = planes * n + (rem > n * (n - 1) ? rem - n * (n - 1) : 0);
+            before = 7 * i - lo_z - hi_z - lo_y - hi_y - (i + n - 1) / n - i / n;
+        }
+        rowptr[i] = (int32_t)before;
+        if (i == N) continue;
+        int64_t k = before;
+        const int64_t ix = i % n, iy = (i / n) % n, iz = i / n2;
+        if (dim == 3 && iz > 0) { col[k] = (int32_t)(i - n2); val[k++] = (VT)-1; }
+        if (iy > 0) { col[k] = (int32_t)(i - n); val[k++] = (VT)-1; }
+        if (ix > 0) { col[k] = (int32_t)(i - 1); val[k++] = (VT)-1; }
+        col[k] = (int32_t)i;
+        val[k++] = (VT)(dim == 2 ? 4 : 6);
+        if (ix < n - 1) { col[k] = (int32_t)(i + 1); val[k++] = (VT)-1; }
+        if (iy < n - 1) { col[k] = (int32_t)(i + n); val[k++] = (VT)-1; }
+        if (dim == 3 && iz < n - 1) { col[k] = (int32_t)(i + n2); val[k++] = (VT)-1; }
+    }
+}
+
+void launch_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void *val, int val_dtype, hipStream_t s) {
+    const int64_t N = dim == 2 ? n * n : n * n * n;
+    int64_t g = (N + 1 + kBlock - 1) / kBlock;
+    if (g > 8192) g = 8192;
+    if (val_dtype == DPCG_F32)
+        hipLaunchKernelGGL(k_gen_poisson<float>, dim3((int)g), dim3(kBlock), 0, s, dim, n, rowptr, col, (float *)val);
+    else
+        hipLaunchKernelGGL(k_gen_poisson<double>, dim3((int)g), dim3(kBlock), 0, s, dim, n, rowptr, col,
+                           (double *)val);
+}
+
+// sparse_matvec_mul (utils.py:26-41): out[b, row] += feature * vec[b, col] over COO triples.
+// One lane per triple, fp32 atomics on the output -- the same scatter-add the reference's own
+// CUDA path performs (torch scatter_reduce on a GPU tensor is an atomicAdd).
+__global__ __launch_bounds__(kBlock) void k_batched_coo_spmv(int64_t nnz, const int32_t *__restrict__ idx,
+                                                             const float *__restrict__ feat, int batch, int64_t dof,
+                                                             const float *__restrict__ vec, float *__restrict__ out,
+                                                             int transpose) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += stride) {
+        const int b = idx[3 * k];
+        const int r = idx[3 * k + (transpose ? 2 : 1)];                 // utils.py:27
+        const int c = idx[3 * k + (transpose ? 1 : 2)];                 // utils.py:28
+        if (b < 0 || b >= batch || r < 0 || r >= dof || c < 0 || c >= dof) continue;
+        atomicAdd(out + (int64_t)b * dof + r, feat[k] * vec[(int64_t)b * dof + c]);   // utils.py:32,36-41
+    }
+}
+
+void launch_batched_coo_spmv(int64_t nnz, const int32_t *indices, const float *features, int batch, int64_t dof,
+                             const float *vectors, float *out, int transpose, hipStream_t s) {
+    int64_t g = (nnz + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_batched_coo_spmv, dim3((int)g), dim3(kBlock), 0, s, nnz, indices, features, batch, dof,
+                       vectors, out, transpose);
+}
+
+}  // namespace dpcg

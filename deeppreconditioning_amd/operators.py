@@ -1,0 +1,426 @@
+"""GPU operators behind the reference's duck-typed `A @ v` / `M @ v` protocol (cg.py:60,61,75,81).
+
+`CsrSystem` owns a libdpcg handle for the system matrix A; the preconditioner classes describe how
+`M @ r` is applied (test.py:70-105).  All arithmetic happens in the hand-written HIP kernels of
+libdpcg.so; torch is used for device memory and streams only.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+try:  # scipy is optional plumbing for host-side CSR inputs
+    import scipy.sparse as _sp
+except Exception:  # pragma: no cover
+    _sp = None
+
+
+# --------------------------------------------------------------------------------------------
+# input normalisation (host logic, no GPU needed)
+# --------------------------------------------------------------------------------------------
+def _is_scipy(A) -> bool:
+    return _sp is not None and _sp.issparse(A)
+
+
+def csr_arrays(A):
+    """Normalise a matrix-like to CSR parts: (space, rowptr, col, val, n).
+
+    space = "host": numpy int32/int32/float64 arrays.  space = "device": torch CUDA tensors.
+    Accepts scipy sparse, numpy 2-D, torch sparse-CSR / sparse-COO / dense tensors (the reference's
+    callers pass DENSE fp64 tensors, test.py:61-68, train.py:93-95).  Columns ascend within a row.
+    """
+    if _is_scipy(A):
+        M = A.tocsr()
+        if not M.has_canonical_format:
+            M = M.copy()
+            M.sum_duplicates()
+        return ("host", np.ascontiguousarray(M.indptr, dtype=np.int32), np.ascontiguousarray(M.indices, dtype=np.int32),
+                np.ascontiguousarray(M.data, dtype=np.float64), M.shape[0])
+    if isinstance(A, np.ndarray):
+        if A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError("expected a square 2-D array")
+        return csr_arrays(_sp.csr_matrix(A))
+    if isinstance(A, torch.Tensor):
+        if A.dim() != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError("expected a square 2-D tensor")
+        if A.layout != torch.sparse_csr:
+            A = A.to_sparse_csr() if A.layout == torch.strided else A.coalesce().to_sparse_csr()
+        rp, ci, v = A.crow_indices(), A.col_indices(), A.values()
+        if A.is_cuda:
+            return ("device", rp.to(torch.int32).contiguous(), ci.to(torch.int32).contiguous(),
+                    v.to(torch.float64).contiguous(), A.shape[0])
+        return ("host", np.ascontiguousarray(rp.numpy(), dtype=np.int32), np.ascontiguousarray(ci.numpy(), dtype=np.int32),
+                np.ascontiguousarray(v.to(torch.float64).numpy()), A.shape[0])
+    raise TypeError(f"cannot interpret {type(A).__name__} as a sparse system matrix")
+
+
+def diagonal_only(rowptr, col, n) -> bool:
+    """True when the CSR pattern is exactly one entry (i, i) per row -- M = diag(d) (test.py:74-79)."""
+    if isinstance(rowptr, torch.Tensor):
+        if rowptr.numel() != n + 1 or col.numel() != n:
+            return False
+        ar = torch.arange(n + 1, device=rowptr.device, dtype=rowptr.dtype)
+        return bool(torch.equal(rowptr, ar) and torch.equal(col, ar[:-1]))
+    return len(col) == n and np.array_equal(rowptr, np.arange(n + 1)) and np.array_equal(col, np.arange(n))
+
+
+def _dev_ptr(t: torch.Tensor | None, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("expected a CUDA (ROCm) tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("expected a contiguous tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def _np_ptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _to_device_f64(v, device) -> torch.Tensor:
+    if isinstance(v, np.ndarray):
+        v = torch.from_numpy(np.ascontiguousarray(v))
+    return v.to(device=device, dtype=torch.float64).contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# preconditioner descriptions (how `M @ r` is applied)
+# --------------------------------------------------------------------------------------------
+class Preconditioner:
+    """Base: a description that `CsrSystem.set_preconditioner` turns into libdpcg state.
+
+    Instances also work stand-alone as duck-typed operators (`M @ r`), so they drop into an
+    unmodified copy of the reference loop; that path builds a private handle on first use.
+    """
+
+    _private: "CsrSystem | None" = None
+
+    def _attach(self, system: "CsrSystem") -> None:
+        raise NotImplementedError
+
+    def _private_system(self) -> "CsrSystem":
+        raise NotImplementedError
+
+    def __matmul__(self, r: torch.Tensor) -> torch.Tensor:
+        if self._private is None:
+            self._private = self._private_system()
+            self._attach(self._private)
+        return self._private.precond_apply(r)
+
+
+class Identity(Preconditioner):
+    """M = I, the `vanilla` technique (test.py:70-72)."""
+
+    def _attach(self, system):
+        L.check(L.lib().dpcg_set_precond_none(system._h))
+
+    def __matmul__(self, r):
+        return r.clone()
+
+
+class Jacobi(Preconditioner):
+    """M = diag(1/a_ii) (test.py:74-79).  `dinv=None` extracts the diagonal of A on the device."""
+
+    def __init__(self, dinv=None):
+        self.dinv = dinv
+
+    def _attach(self, system):
+        if self.dinv is None:
+            L.check(L.lib().dpcg_set_precond_jacobi(system._h, None, L.DEVICE, _stream()))
+        else:
+            d = _to_device_f64(self.dinv, system.device)
+            if d.numel() != system.n:
+                raise ValueError("dinv has the wrong length")
+            L.check(L.lib().dpcg_set_precond_jacobi(system._h, _dev_ptr(d), L.DEVICE, _stream()))
+
+    def _private_system(self):
+        if self.dinv is None:
+            raise ValueError("a stand-alone Jacobi operator needs explicit dinv")
+        d = _to_device_f64(self.dinv, torch.device("cuda", torch.cuda.current_device()))
+        n = d.numel()
+        ar = torch.arange(n + 1, device=d.device, dtype=torch.int32)
+        return CsrSystem(ar, ar[:-1].clone(), torch.ones(n, device=d.device, dtype=torch.float64), n)
+
+
+class _CsrBacked(Preconditioner):
+    def __init__(self, matrix):
+        self.space, self.rowptr, self.col, self.val, self.n = csr_arrays(matrix)
+
+    def _parts(self):
+        if self.space == "host":
+            return L.HOST, _np_ptr(self.rowptr), _np_ptr(self.col), _np_ptr(self.val), len(self.col)
+        return L.DEVICE, _dev_ptr(self.rowptr), _dev_ptr(self.col), _dev_ptr(self.val), self.col.numel()
+
+    def _private_system(self):
+        if self.space == "host":
+            return CsrSystem.from_host(self.rowptr, self.col, self.val, self.n)
+        return CsrSystem(self.rowptr, self.col, self.val, self.n)
+
+
+class CsrPreconditioner(_CsrBacked):
+    """z = M r with M an explicit CSR matrix -- what test.py:88,105 hand to the solver (M = L L^T)."""
+
+    def _attach(self, system):
+        if self.n != system.n:
+            raise ValueError("preconditioner size mismatch")
+        space, rp, ci, v, nnz = self._parts()
+        L.check(L.lib().dpcg_set_precond_csr(system._h, nnz, rp, ci, v, space, _stream()))
+
+
+class LLtMultiply(_CsrBacked):
+    """z = L (L^T r): the learned preconditioner of test.py:100-105 without forming L L^T."""
+
+    mode = L.PRECOND_LLT_MULTIPLY
+
+    def __init__(self, lower):
+        super().__init__(lower)
+
+    def _attach(self, system):
+        if self.n != system.n:
+            raise ValueError("factor size mismatch")
+        space, rp, ci, v, nnz = self._parts()
+        L.check(L.lib().dpcg_set_precond_llt(system._h, self.mode, nnz, rp, ci, v, space, _stream()))
+
+
+class LLtSolve(LLtMultiply):
+    """z = L^-T (L^-1 r): a true incomplete-Cholesky apply by level-scheduled triangular solves."""
+
+    mode = L.PRECOND_LLT_SOLVE
+
+
+class IC0(Preconditioner):
+    """IC(0) of A computed at setup (stands in for ilupp.ichol0, test.py:83).
+
+    mode="solve" applies it by triangular solves; mode="multiply" reproduces the reference's
+    `_construct_incomplete_cholesky`, which multiplies by L L^T (test.py:88, marked unstable at
+    test.py:45).
+    """
+
+    def __init__(self, mode: str = "solve"):
+        if mode not in ("solve", "multiply"):
+            raise ValueError("mode must be 'solve' or 'multiply'")
+        self.mode = L.PRECOND_LLT_SOLVE if mode == "solve" else L.PRECOND_LLT_MULTIPLY
+
+    def _attach(self, system):
+        L.check(L.lib().dpcg_set_precond_ic0(system._h, self.mode, _stream()))
+
+    def __matmul__(self, r):
+        raise TypeError("IC0 needs the system matrix: attach it with CsrSystem.set_preconditioner")
+
+
+def as_preconditioner(M, n: int) -> Preconditioner:
+    """Map whatever the reference's callers pass as `M` to an apply mode.
+
+    None -> identity; a Preconditioner -> itself; a matrix (torch sparse/dense, scipy, numpy) ->
+    Jacobi when it is exactly diagonal (bit-identical to the CSR product, one term per row),
+    otherwise an explicit CSR multiply.  Anything else is refused: there is no generic fallback.
+    """
+    if M is None:
+        return Identity()
+    if isinstance(M, Preconditioner):
+        return M
+    if isinstance(M, CsrSystem):
+        raise TypeError("pass the preconditioner as a matrix or a Preconditioner, not a CsrSystem")
+    space, rp, ci, v, m = csr_arrays(M)
+    if m != n:
+        raise ValueError("preconditioner size mismatch")
+    if diagonal_only(rp, ci, n):
+        return Jacobi(v)
+    pc = CsrPreconditioner.__new__(CsrPreconditioner)
+    pc.space, pc.rowptr, pc.col, pc.val, pc.n = space, rp, ci, v, m
+    return pc
+
+
+# --------------------------------------------------------------------------------------------
+# the system operator
+# --------------------------------------------------------------------------------------------
+@dataclass
+class SolveResult:
+    x: torch.Tensor
+    iterations: int
+    status: int          # 0 converged, 1 max_iter, 2 breakdown
+    final_res: float     # last tested <r,r>/<b,b>
+    seconds: float       # wall time of the iteration loop, device-synchronised (cg.py:69,88)
+    res_history: np.ndarray
+    err_history: np.ndarray | None = None
+
+
+class CsrSystem:
+    """The operator A of `A @ v` (cg.py:60,75) as a CSR matrix resident in HBM.
+
+    rowptr/col int32, val float64 or float32 CUDA tensors are borrowed (kept alive here).
+    """
+
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: int):
+        if not (rowptr.is_cuda and col.is_cuda and val.is_cuda):
+            raise ValueError("CsrSystem expects CUDA tensors; use CsrSystem.from_host / from_any for host data")
+        if rowptr.dtype != torch.int32 or col.dtype != torch.int32:
+            raise ValueError("rowptr/col must be int32")
+        if val.dtype not in (torch.float64, torch.float32):
+            raise ValueError("val must be float64 or float32")
+        if rowptr.numel() != n + 1 or col.numel() != val.numel():
+            raise ValueError("inconsistent CSR sizes")
+        self._keep = (rowptr.contiguous(), col.contiguous(), val.contiguous())
+        self.device = val.device
+        self.n = int(n)
+        self.nnz = int(col.numel())
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(L.lib().dpcg_create(C.byref(self._h), self.n, self.nnz, _dev_ptr(self._keep[0]),
+                                        _dev_ptr(self._keep[1]), _dev_ptr(self._keep[2]),
+                                        L.F64 if val.dtype == torch.float64 else L.F32, L.DEVICE, 0, _stream()))
+        self._precond: Preconditioner | None = None
+
+    # -- constructors ----------------------------------------------------------------------
+    @classmethod
+    def from_host(cls, rowptr: np.ndarray, col: np.ndarray, val: np.ndarray, n: int, device=None) -> "CsrSystem":
+        self = cls.__new__(cls)
+        self._keep = ()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.n, self.nnz = int(n), int(len(col))
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        dt = L.F32 if val.dtype == np.float32 else L.F64
+        val = np.ascontiguousarray(val, dtype=np.float32 if dt == L.F32 else np.float64)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(L.lib().dpcg_create(C.byref(self._h), self.n, self.nnz, _np_ptr(rowptr), _np_ptr(col), _np_ptr(val),
+                                        dt, L.HOST, 1, _stream()))
+        self._precond = None
+        return self
+
+    @classmethod
+    def from_any(cls, A, device=None) -> "CsrSystem":
+        if isinstance(A, CsrSystem):
+            return A
+        space, rp, ci, v, n = csr_arrays(A)
+        if space == "host":
+            return cls.from_host(rp, ci, v, n, device)
+        return cls(rp, ci, v, n)
+
+    # -- bookkeeping -------------------------------------------------------------------------
+    @property
+    def shape(self):
+        return (self.n, self.n)
+
+    def info(self) -> dict:
+        n, nnz, pn = C.c_int64(), C.c_int64(), C.c_int64()
+        k, pk, ll, lu = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        L.check(L.lib().dpcg_get_info(self._h, C.byref(n), C.byref(nnz), C.byref(k), C.byref(pk), C.byref(pn),
+                                      C.byref(ll), C.byref(lu)))
+        return {"n": n.value, "nnz": nnz.value, "spmv_kernel": ("stream", "vector")[k.value],
+                "precond": pk.value, "precond_nnz": pn.value, "levels_lower": ll.value, "levels_upper": lu.value}
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            L.lib().dpcg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _vec(self, v) -> torch.Tensor:
+        t = _to_device_f64(v, self.device)
+        if t.dim() != 1 or t.numel() != self.n:
+            raise ValueError(f"expected a vector of length {self.n}")
+        return t
+
+    # -- operators -------------------------------------------------------------------------
+    def __matmul__(self, v) -> torch.Tensor:
+        """y = A v (cg.py:60,75)."""
+        x = self._vec(v)
+        y = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().dpcg_spmv(self._h, _dev_ptr(x), _dev_ptr(y), _stream()))
+        return y
+
+    def spmv_f32(self, v: torch.Tensor) -> torch.Tensor:
+        x = v.to(device=self.device, dtype=torch.float32).contiguous()
+        y = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().dpcg_spmv_f32(self._h, _dev_ptr(x), _dev_ptr(y), _stream()))
+        return y
+
+    def set_preconditioner(self, M) -> Preconditioner:
+        pc = as_preconditioner(M, self.n)
+        with torch.cuda.device(self.device):
+            pc._attach(self)
+        self._precond = pc
+        return pc
+
+    def precond_apply(self, r) -> torch.Tensor:
+        """z = M r (cg.py:61,81) for the attached preconditioner."""
+        rv = self._vec(r)
+        z = torch.empty_like(rv)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().dpcg_precond_apply(self._h, _dev_ptr(rv), _dev_ptr(z), _stream()))
+        return z
+
+    def sptrsv(self, rhs, upper: bool) -> torch.Tensor:
+        rv = self._vec(rhs)
+        out = torch.empty_like(rv)
+        with torch.cuda.device(self.device):
+            L.check(L.lib().dpcg_sptrsv(self._h, 1 if upper else 0, _dev_ptr(rv), _dev_ptr(out), _stream()))
+        return out
+
+    def factor(self):
+        """The attached L factor as host CSR arrays (rowptr, col, val)."""
+        nnz = self.info()["precond_nnz"]
+        rp = np.empty(self.n + 1, dtype=np.int32)
+        ci = np.empty(nnz, dtype=np.int32)
+        v = np.empty(nnz, dtype=np.float64)
+        L.check(L.lib().dpcg_get_factor(self._h, _np_ptr(rp), _np_ptr(ci), _np_ptr(v)))
+        return rp, ci, v
+
+    def spmv_dot_bench(self, repeats: int = 100) -> float:
+        """Average milliseconds of the in-PCG SpMV+<p,Ap> kernel over `repeats` launches (HIP events)."""
+        x = torch.rand(self.n, device=self.device, dtype=torch.float64)
+        y = torch.empty_like(x)
+        ms = C.c_float()
+        with torch.cuda.device(self.device):
+            L.check(L.lib().dpcg_spmv_dot_bench(self._h, _dev_ptr(x), _dev_ptr(y), repeats, C.byref(ms), _stream()))
+        return float(ms.value)
+
+    def solve(self, b, x0=None, *, rtol_sq: float = 1e-8, atol_sq: float = 0.0, max_iter: int = 1024, flags: int = 0,
+              x_true=None, want_history: bool = True) -> SolveResult:
+        """Run the PCG loop of cg.py:58-90 on the GPU (see dpcg_solve in include/dpcg.h)."""
+        bv = self._vec(b)
+        x0v = None if x0 is None else self._vec(x0)
+        xt = None if x_true is None else self._vec(x_true)
+        x = torch.empty_like(bv)
+        hist = np.full(max_iter + 1, np.nan) if want_history else None
+        err = np.full(max_iter + 1, np.nan) if xt is not None else None
+        iters, res, sec = C.c_int(), C.c_double(), C.c_double()
+        with torch.cuda.device(self.device):
+            status = L.check(L.lib().dpcg_solve(
+                self._h, _dev_ptr(bv), _dev_ptr(x0v), _dev_ptr(x), rtol_sq, atol_sq, int(max_iter), int(flags),
+                _stream(), C.byref(iters), C.byref(res), C.byref(sec), _np_ptr(hist), _dev_ptr(xt), _np_ptr(err)))
+        k = iters.value
+        return SolveResult(x, k, status, res.value, sec.value, hist[: k + 1] if hist is not None else np.empty(0),
+                           err[: k + 1] if err is not None else None)
+
+
+def dot(a: torch.Tensor, b: torch.Tensor) -> float:
+    """<a,b> by the deterministic two-stage HIP reduction (torch.inner at cg.py:17,76,78,82)."""
+    a = a.to(torch.float64).contiguous()
+    b = b.to(device=a.device, dtype=torch.float64).contiguous()
+    out = C.c_double()
+    with torch.cuda.device(a.device):
+        L.check(L.lib().dpcg_dot(a.numel(), _dev_ptr(a), _dev_ptr(b), C.byref(out), _stream()))
+    return float(out.value)

@@ -1,0 +1,69 @@
+"""GPU drop-ins for `uibk/deep_preconditioning/utils.py` (same names and signatures)."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .operators import CsrSystem, _dev_ptr, _stream
+
+
+def sparse_matvec_mul(spconv_batch, vector_batch: torch.Tensor, transpose: bool) -> torch.Tensor:
+    """Batched sparse matrix-vector product on COO triples (utils.py:15-43).
+
+    `spconv_batch` needs `.indices` (nnz,3) int32 `(batch,row,col)`, `.features` (nnz,1) and
+    `.batch_size` -- an spconv `SparseConvTensor` or this package's `SparseBatch`.
+    """
+    dev = vector_batch.device
+    if not vector_batch.is_cuda:
+        raise ValueError("sparse_matvec_mul runs on the GPU: vector_batch must be a CUDA tensor")
+    idx = spconv_batch.indices.to(device=dev, dtype=torch.int32).contiguous()
+    feat = spconv_batch.features.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+    vec = vector_batch.to(torch.float32).contiguous()
+    batch, dof = vec.shape
+    if batch != spconv_batch.batch_size:
+        raise ValueError("batch size mismatch")
+    out = torch.empty_like(vec)
+    with torch.cuda.device(dev):
+        L.check(L.lib().dpcg_batched_coo_spmv(idx.shape[0], _dev_ptr(idx), _dev_ptr(feat), batch, dof, _dev_ptr(vec),
+                                              _dev_ptr(out), 1 if transpose else 0, _stream()))
+    return out.to(vector_batch.dtype)
+
+
+def benchmark_cg(matrix, right_hand_side, preconditioner=None) -> tuple[float, int, int]:
+    """`scipy.sparse.linalg.cg(matrix, rhs, maxiter=512, M=preconditioner)` semantics (utils.py:46-76)
+    on the GPU: stop when ||r|| < 1e-5 ||b|| (scipy's default rtol, tested on r before each update),
+    at most 512 updates; returns `(duration, iterations, info)` with scipy's info (0 or 512).
+    """
+    system = CsrSystem.from_any(matrix)
+    system.set_preconditioner(preconditioner)
+    rtol = 1e-5
+    result = system.solve(right_hand_side, None, rtol_sq=rtol * rtol, max_iter=512, flags=L.INIT_CHECK_R,
+                          want_history=False)
+    info = 0 if result.status == L.OK else 512
+    return result.seconds, result.iterations, info
+
+
+class SparseBatch:
+    """Minimal stand-in for `spconv.pytorch.SparseConvTensor` (absent on ROCm): the attributes the
+    reference's hot path touches (utils.py:26-35, data_set.py:122-125)."""
+
+    def __init__(self, features: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int):
+        self.features = features
+        self.indices = indices
+        self.spatial_shape = list(spatial_shape)
+        self.batch_size = int(batch_size)
+
+    def replace_feature(self, features: torch.Tensor) -> "SparseBatch":
+        return SparseBatch(features, self.indices, self.spatial_shape, self.batch_size)
+
+    def dense(self) -> torch.Tensor:
+        """(batch, channels, H, W) dense tensor, as `SparseConvTensor.dense()`."""
+        ch = self.features.shape[1]
+        out = torch.zeros(self.batch_size, ch, *self.spatial_shape, dtype=self.features.dtype,
+                          device=self.features.device)
+        b, r, c = (self.indices[:, i].long() for i in range(3))
+        out[b, :, r, c] = self.features
+        return out

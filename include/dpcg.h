@@ -1,0 +1,144 @@
+/*
+ * dpcg.h -- C ABI of the MI355X-native preconditioned-CG solve path (libdpcg.so).
+ *
+ * Drop-in boundary for the hot path of jsappl/DeepPreconditioning.
+ * The reference has no native interface of its own: its "operator API" is Python duck typing
+ * (`A @ v`, `M @ v`, `torch.inner`) inside uibk/deep_preconditioning/cg.py.  Each entry point
+ * below names the reference lines whose work it replaces.  The Python mirror of the reference
+ * signatures (deeppreconditioning_amd/cg.py, utils.py) binds these symbols with ctypes; the stub
+ * a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; no exceptions cross the ABI; every function returns a
+ *     dpcg_status (negative = error, dpcg_last_error() gives the message for this thread).
+ *   - Vectors are fp64, length n, DEVICE pointers unless a parameter says "host".
+ *   - CSR: int32 rowptr[n+1], int32 col[nnz] (ascending inside a row), fp64 or fp32 val[nnz].
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue on it;
+ *     only dpcg_solve*, dpcg_create (host inputs) and the setup routines synchronise it.
+ *   - The caller owns every buffer it passes.  The handle owns its copies/analysis data (row-block
+ *     maps, level sets, transposed factor, work vectors, graph).  A handle may be used by one
+ *     thread at a time.
+ */
+#ifndef DPCG_H
+#define DPCG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dpcg_system *dpcg_handle_t;
+typedef void *dpcg_stream_t; /* hipStream_t */
+
+enum dpcg_status {
+    DPCG_OK = 0,            /* converged: res < rtol_sq (cg.py:71)                                  */
+    DPCG_MAX_ITER = 1,      /* max_iter updates done without meeting the test (cg.py:70)            */
+    DPCG_BREAKDOWN = 2,     /* NaN/Inf in the recurrence (<Ap,p> = 0 ...); reference spins silently */
+    DPCG_ERR_INVALID = -1,  /* bad argument                                                         */
+    DPCG_ERR_HIP = -2,      /* a HIP runtime call failed (no device, launch failure, ...)           */
+    DPCG_ERR_NOMEM = -3,    /* allocation failed                                                    */
+    DPCG_ERR_PIVOT = -4,    /* IC(0): non-positive pivot                                            */
+    DPCG_ERR_STATE = -5     /* call order error (e.g. solve mode without a factor)                  */
+};
+
+enum dpcg_dtype { DPCG_F64 = 0, DPCG_F32 = 1 };
+enum dpcg_memspace { DPCG_DEVICE = 0, DPCG_HOST = 1 };
+
+/* How `zk = M @ rk` (cg.py:61,81) is applied. */
+enum dpcg_precond {
+    DPCG_PRECOND_NONE = 0,         /* M = I                         test.py:70-72  (vanilla)        */
+    DPCG_PRECOND_JACOBI = 1,       /* M = diag(1/a_ii)              test.py:74-79                   */
+    DPCG_PRECOND_CSR = 2,          /* z = M r, M an explicit CSR    test.py:88,105 (M = L L^T)      */
+    DPCG_PRECOND_LLT_MULTIPLY = 3, /* z = L (L^T r), same operator as test.py:102-105, never formed */
+    DPCG_PRECOND_LLT_SOLVE = 4     /* z = L^-T (L^-1 r), level-scheduled SpTRSV (north_star)        */
+};
+
+/* dpcg_solve flags */
+enum dpcg_solve_flags {
+    DPCG_INIT_CHECK_R = 1,   /* first test on <r0,r0> (scipy cg, utils.py:66-72) instead of the
+                                reference's <z0,z0> (cg.py:66)                                      */
+    DPCG_SPMV_F32 = 2,       /* mixed precision: A@p with fp32 val and fp32 p, fp64 everywhere else */
+    DPCG_NO_GRAPH = 4        /* launch kernels one by one instead of replaying a hipGraph           */
+};
+
+/* ---- library ------------------------------------------------------------------------------- */
+int dpcg_version(void);
+const char *dpcg_status_string(int status);
+const char *dpcg_last_error(void);
+/* Device facts for the roofline report: CU count, HBM bytes, gcnArchName into name[name_len]. */
+int dpcg_device_info(int *cu_count, int64_t *hbm_bytes, char *name, int name_len);
+
+/* ---- system handle: the operator A (test.py:61-68 / train.py:93-95 pass it dense; here CSR) -- */
+/* copy = 0 with DEVICE pointers borrows the arrays (caller keeps them alive); otherwise copied. */
+int dpcg_create(dpcg_handle_t *out, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                const void *val, int val_dtype, int memspace, int copy, dpcg_stream_t stream);
+int dpcg_destroy(dpcg_handle_t h);
+int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spmv_kernel, int *precond_kind,
+                  int64_t *precond_nnz, int *n_levels_lower, int *n_levels_upper);
+
+/* ---- preconditioner M (test.py:70-105) ------------------------------------------------------- */
+int dpcg_set_precond_none(dpcg_handle_t h);
+/* dinv = NULL: 1/diag(A) is extracted on the device (test.py:76). */
+int dpcg_set_precond_jacobi(dpcg_handle_t h, const double *dinv, int memspace, dpcg_stream_t stream);
+int dpcg_set_precond_csr(dpcg_handle_t h, int64_t nnz, const int32_t *rowptr, const int32_t *col, const double *val,
+                         int memspace, dpcg_stream_t stream);
+/* L: lower-triangular CSR, columns ascending, diagonal stored LAST in each row.
+ * mode = DPCG_PRECOND_LLT_MULTIPLY or DPCG_PRECOND_LLT_SOLVE.  Builds L^T and (solve) level sets. */
+int dpcg_set_precond_llt(dpcg_handle_t h, int mode, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                         const double *val, int memspace, dpcg_stream_t stream);
+/* IC(0) of A (stands in for ilupp.ichol0, test.py:83), then as dpcg_set_precond_llt. */
+int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t stream);
+/* Copy the current factor L out (host arrays sized from dpcg_get_info's precond_nnz). */
+int dpcg_get_factor(dpcg_handle_t h, int32_t *rowptr, int32_t *col, double *val);
+
+/* ---- standalone operators (roofline benches, unit parity, duck-typed `@`) -------------------- */
+int dpcg_spmv(dpcg_handle_t h, const double *x, double *y, dpcg_stream_t stream);          /* cg.py:60,75 */
+int dpcg_spmv_f32(dpcg_handle_t h, const float *x, float *y, dpcg_stream_t stream);        /* config C5   */
+int dpcg_precond_apply(dpcg_handle_t h, const double *r, double *z, dpcg_stream_t stream); /* cg.py:61,81 */
+int dpcg_sptrsv(dpcg_handle_t h, int upper, const double *rhs, double *out, dpcg_stream_t stream);
+/* *out_host = <a,b> (torch.inner, cg.py:17,76,78,82); deterministic two-stage reduction. */
+int dpcg_dot(int64_t n, const double *a, const double *b, double *out_host, dpcg_stream_t stream);
+/* The SpMV fused with <p,Ap> exactly as launched inside the PCG iteration (for kernel timing). */
+int dpcg_spmv_dot_bench(dpcg_handle_t h, const double *x, double *y, int repeats, float *ms_per_launch,
+                        dpcg_stream_t stream);
+
+/* ---- the solve: cg.py:50-90 (PCG) and cg.py:20-47 (CG = PCG with M = I, test on r) ----------- */
+/*
+ * b, x0 (may be NULL = zeros, cg.py:58), x (out, may be NULL): device fp64[n].
+ * Stop when res_k = <r_k,r_k>/<b,b> < rtol_sq or <r_k,r_k> < atol_sq (cg.py:15-17,71: SQUARED
+ * ratio; atol_sq = 0 for the reference, 1e-12 for generate_data.py:107), k = 0 tested on
+ * <z_0,z_0>/<b,b> unless DPCG_INIT_CHECK_R (cg.py:66).  At most max_iter updates (cg.py:70).
+ * iters = completed updates = len(errors)-1 (cg.py:90).  seconds = host wall time around the
+ * iteration loop, device-synchronised (cg.py:69,88).  res_history: host fp64[max_iter+1] or NULL,
+ * entry k is what the reference appends to `errors` (cg.py:67,88).
+ * x_true / err_history (both NULL for PCG): when given, err_history[k] = (x_k-x_true)^T A (x_k-x_true)
+ * (cg.py:27-29,43-45), one extra SpMV per iteration as in the reference.
+ * Returns DPCG_OK / DPCG_MAX_ITER / DPCG_BREAKDOWN or a negative error.
+ */
+int dpcg_solve(dpcg_handle_t h, const double *b, const double *x0, double *x, double rtol_sq, double atol_sq,
+               int max_iter, int flags, dpcg_stream_t stream, int *iters, double *final_res, double *seconds,
+               double *res_history, const double *x_true, double *err_history);
+
+/* `count` independent systems (train.py:90-108 / test.py:121-149 loop over samples): handles[i],
+ * b[i], x0[i], x[i] as above; outputs are arrays of length count.  Systems are interleaved on
+ * `n_streams` internal streams (1..8).  Returns the worst status. */
+int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double *const *b, const double *const *x0,
+                     double *const *x, double rtol_sq, double atol_sq, int max_iter, int flags, int n_streams,
+                     int *iters, double *final_res, double *seconds, int *status);
+
+/* ---- synthetic pressure-Poisson systems generated on the device -------------- */
+/* dim = 2: 5-point, n*n rows; dim = 3: 7-point, n^3 rows.  Sizes via dpcg_poisson_sizes. */
+int dpcg_poisson_sizes(int dim, int64_t n, int64_t *rows, int64_t *nnz);
+int dpcg_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void *val, int val_dtype,
+                     dpcg_stream_t stream);
+
+/* ---- sparse_matvec_mul (utils.py:15-43): batched COO SpMV / SpMV^T, fp32 ---------------------- */
+/* indices: int32[nnz*3] rows of (batch,row,col); features fp32[nnz]; vectors/out fp32[batch*dof]. */
+int dpcg_batched_coo_spmv(int64_t nnz, const int32_t *indices, const float *features, int batch, int64_t dof,
+                          const float *vectors, float *out, int transpose, dpcg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPCG_H */

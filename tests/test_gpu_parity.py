@@ -1,0 +1,377 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference-generated
+golden fixtures.  Needs a real MI355X: `pytest -m gpu`.
+
+Bars: bit-exact for index work and for the in-order kernels (CSR-stream SpMV, SpTRSV, IC(0));
+iteration counts identical and residual histories within 1e-10 relative (north_star) wherever the
+recurrence is numerically stable -- see tests/test_oracle_golden.py for the chaotic cases.
+"""
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from oracle import c_oracle as CO
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+HIST_RTOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def D():
+    import deeppreconditioning_amd as pkg
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    pkg._lib.lib()  # raises if the HIP extension is missing: no silent fallback
+    return pkg
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _check(golden, name, res, rtol=HIST_RTOL):
+    assert res.iterations == int(golden[f"{name}/iters"]), (name, res.iterations)
+    np.testing.assert_allclose(res.res_history, golden[f"{name}/hist"], rtol=rtol, atol=0, err_msg=name)
+
+
+def _check_chaotic(golden, name, res, stable):
+    g = golden[f"{name}/hist"]
+    np.testing.assert_allclose(res.res_history[:stable], g[:stable], rtol=HIST_RTOL, err_msg=name)
+    gi = int(golden[f"{name}/iters"])
+    assert abs(res.iterations - gi) <= 0.02 * gi + 1, (name, res.iterations)
+
+
+# ---- SpMV --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("make", [lambda: O.poisson2d(64), lambda: O.poisson2d(37), lambda: O.poisson3d(20),
+                                  lambda: O.unstructured_like(O.poisson3d(12), 3), lambda: O.poisson2d(1)])
+def test_spmv_stream_bit_exact(D, make):
+    A = make()
+    S = D.CsrSystem.from_any(A)
+    assert S.info()["spmv_kernel"] == "stream"
+    x = O.rhs(A.shape[0], 5)
+    y = (S @ _dev(x)).cpu().numpy()
+    assert np.array_equal(y, CO.spmv(A, x))
+
+
+def test_spmv_vector_kernel(D):
+    A = O.poisson2d(48)
+    L_ = O.learned_like_factor(A, seed=2)
+    M = (L_ @ L_.T).tocsr()  # ~60 non-zeros per row -> CSR-vector kernel
+    S = D.CsrSystem.from_any(M)
+    assert S.info()["spmv_kernel"] == "vector"
+    x = O.rhs(M.shape[0], 1)
+    y = (S @ _dev(x)).cpu().numpy()
+    ref = CO.spmv(M, x)
+    np.testing.assert_allclose(y, ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+
+
+def test_spmv_ragged_rows_and_empty_rows(D):
+    rng = np.random.default_rng(0)
+    n = 1000
+    dense = sp.random(n, n, density=0.004, random_state=rng, format="csr")
+    dense.data[:] = rng.standard_normal(dense.nnz)
+    assert (np.diff(dense.indptr) == 0).any()  # some empty rows
+    S = D.CsrSystem.from_any(dense)
+    x = O.rhs(n, 2)
+    assert np.array_equal((S @ _dev(x)).cpu().numpy(), CO.spmv(dense, x))
+
+
+def test_spmv_dense_input_as_reference_callers_pass(D):
+    A = O.poisson2d(12)
+    S = D.CsrSystem.from_any(torch.from_numpy(A.toarray()))  # dense fp64, test.py:61-68
+    x = O.rhs(A.shape[0], 0)
+    assert np.array_equal((S @ _dev(x)).cpu().numpy(), CO.spmv(A, x))
+
+
+def test_generators_match_oracle(D):
+    from deeppreconditioning_amd import poisson
+    for dim, n, ref in ((2, 33, O.poisson2d(33)), (3, 9, O.poisson3d(9)), (2, 1, O.poisson2d(1)), (3, 2, O.poisson3d(2))):
+        rp, ci, v = poisson.poisson_csr(dim, n)
+        assert np.array_equal(rp.cpu().numpy(), ref.indptr)
+        assert np.array_equal(ci.cpu().numpy(), ref.indices)
+        assert np.array_equal(v.cpu().numpy(), ref.data)
+
+
+def test_dot_and_stopping_criterion(D, golden):
+    from deeppreconditioning_amd import cg
+    r = np.random.default_rng(5).uniform(-1, 1, 1000)
+    b = np.random.default_rng(6).uniform(-1, 1, 1000)
+    v = cg.stopping_criterion(None, _dev(r), _dev(b))
+    assert v.dim() == 0
+    assert float(v) == pytest.approx(float(golden["stopping_criterion_seed5_6/value"]), rel=1e-13)
+    a = O.rhs(1_000_003, 1)
+    assert D.dot(_dev(a), _dev(a)) == pytest.approx(float(np.dot(a, a)), rel=1e-13)
+
+
+# ---- PCG vs the reference's own outputs ----------------------------------------------------------
+@pytest.mark.parametrize("kind,n", [("poisson2d", 64), ("poisson2d", 256), ("poisson3d", 32), ("poisson3d", 64),
+                                    ("poisson3d", 100), ("poisson2d", 1024)])
+def test_pcg_jacobi_golden(D, golden, kind, n):
+    A = getattr(O, kind)(n)
+    S = D.CsrSystem.from_any(A)
+    S.set_preconditioner(D.Jacobi())
+    res = S.solve(_dev(O.rhs(A.shape[0], 0)))
+    _check(golden, f"pcg_{kind}_{n}_jacobi", res)
+    assert res.status == (1 if n == 1024 else 0)
+
+
+def test_pcg_reference_signature(D, golden):
+    """The drop-in call exactly as test.py:138 / train.py:102-106 make it."""
+    from deeppreconditioning_amd.cg import preconditioned_conjugate_gradient
+    A = O.poisson2d(64)
+    b = torch.from_numpy(O.rhs(A.shape[0], 0))
+    A_t = torch.sparse_csr_tensor(torch.from_numpy(A.indptr.astype(np.int64)), torch.from_numpy(A.indices.astype(np.int64)),
+                                  torch.from_numpy(A.data), size=A.shape)
+    M_t = torch.sparse_coo_tensor(torch.vstack((torch.arange(A.shape[0]), torch.arange(A.shape[0]))),
+                                  torch.from_numpy(1 / A.diagonal()), size=A.shape).to_sparse_csr()  # test.py:74-79
+    duration, iterations, info = preconditioned_conjugate_gradient(A_t, b, M_t)
+    assert iterations == 129 and info == 0 and duration > 0
+    duration, iterations, info = preconditioned_conjugate_gradient(A_t.cuda(), b.cuda(), M=M_t.cuda())
+    assert iterations == 129 and info == 0
+    # dense A and dense M, as train.py:93-100 builds them
+    A32 = O.poisson2d(32)
+    b32 = torch.from_numpy(O.rhs(A32.shape[0], 3)).cuda()
+    _, iterations, _ = preconditioned_conjugate_gradient(torch.from_numpy(A32.toarray()).cuda(), b32,
+                                                         M=torch.from_numpy(np.diag(1 / A32.diagonal())).cuda())
+    assert iterations == int(golden["pcg_poisson2d_32_dense_jacobi_bseed3/iters"])
+    with pytest.raises(TypeError):
+        preconditioned_conjugate_gradient(A_t, b, object())  # unknown operator: refused, no fallback
+
+
+def test_pcg_identity_x0_maxiter(D, golden):
+    A = O.poisson2d(64)
+    b = _dev(O.rhs(A.shape[0], 0))
+    S = D.CsrSystem.from_any(A)
+    S.set_preconditioner(None)
+    _check(golden, "pcg_poisson2d_64_identity", S.solve(b))
+    S.set_preconditioner(D.Jacobi(1 / A.diagonal()))
+    x0 = np.random.default_rng(7).uniform(-1, 1, A.shape[0])
+    _check(golden, "pcg_poisson2d_64_jacobi_x0seed7", S.solve(b, _dev(x0)))
+    res = S.solve(b, max_iter=20)
+    _check(golden, "pcg_poisson2d_64_jacobi_maxiter20", res)
+    assert res.status == 1
+    res = S.solve(b, max_iter=0)
+    assert res.iterations == 0 and res.res_history[0] == pytest.approx(0.0625, rel=1e-12)
+
+
+def test_pcg_no_graph_path_matches_graph_path(D):
+    A = O.poisson3d(24)
+    b = _dev(O.rhs(A.shape[0], 0))
+    S = D.CsrSystem.from_any(A)
+    S.set_preconditioner(D.Jacobi())
+    r1 = S.solve(b)
+    r2 = S.solve(b, flags=D._lib.NO_GRAPH)
+    assert r1.iterations == r2.iterations and np.array_equal(r1.res_history, r2.res_history)
+    assert torch.equal(r1.x, r2.x)  # deterministic reductions: bitwise reproducible
+
+
+def test_pcg_solution_and_true_residual(D):
+    A = O.unstructured_like(O.poisson3d(20), seed=0)
+    b = O.rhs(A.shape[0], 0)
+    S = D.CsrSystem.from_any(A)
+    S.set_preconditioner(D.Jacobi())
+    res = S.solve(_dev(b))
+    _, it, hist, x = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A))
+    assert res.iterations == it
+    np.testing.assert_allclose(res.res_history, hist, rtol=HIST_RTOL)
+    np.testing.assert_allclose(res.x.cpu().numpy(), x, rtol=1e-9, atol=1e-12)
+    true_r = b - A @ res.x.cpu().numpy()
+    assert np.dot(true_r, true_r) / np.dot(b, b) < 1.01e-8
+
+
+# ---- preconditioner apply modes --------------------------------------------------------------------
+def test_ic0_factor_bit_exact(D):
+    for A in (O.poisson2d(40), O.unstructured_like(O.poisson3d(10), 1)):
+        S = D.CsrSystem.from_any(A)
+        S.set_preconditioner(D.IC0("solve"))
+        rp, ci, v = S.factor()
+        Lref = CO.ic0(A)
+        assert np.array_equal(rp, Lref.indptr) and np.array_equal(ci, Lref.indices)
+        assert np.array_equal(v, Lref.data)
+
+
+@pytest.mark.parametrize("make", [lambda: O.poisson2d(64), lambda: O.poisson3d(16),
+                                  lambda: O.unstructured_like(O.poisson3d(16), 0), lambda: O.poisson2d(80)])
+def test_sptrsv_bit_exact(D, make):
+    A = make()
+    S = D.CsrSystem.from_any(A)
+    S.set_preconditioner(D.IC0("solve"))
+    Lref = CO.ic0(A)
+    r = O.rhs(A.shape[0], 4)
+    y = S.sptrsv(_dev(r), upper=False).cpu().numpy()
+    y_ref = CO.sptrsv_lower(Lref, r)
+    assert np.array_equal(y, y_ref)
+    z = S.sptrsv(_dev(y_ref), upper=True).cpu().numpy()
+    assert np.array_equal(z, CO.sptrsv_upper(CO.transpose_csr(Lref), y_ref))
+    zz = S.precond_apply(_dev(r)).cpu().numpy()
+    assert np.array_equal(zz, z)
+    info = S.info()
+    assert info["levels_lower"] >= 1 and info["levels_upper"] == info["levels_lower"]
+
+
+def test_pcg_llt_solve_golden(D, golden):
+    A = O.poisson2d(64)
+    b = _dev(O.rhs(A.shape[0], 0))
+    S = D.CsrSystem.from_any(A)
+    S.set_preconditioner(D.IC0("solve"))
+    _check(golden, "pcg_poisson2d_64_ic0_solve", S.solve(b))
+    S.set_preconditioner(D.LLtSolve(CO.ic0(A)))  # factor handed in, as the CNN would
+    _check(golden, "pcg_poisson2d_64_ic0_solve", S.solve(b))
+    Au = O.unstructured_like(O.poisson3d(16), seed=0)
+    Su = D.CsrSystem.from_any(Au)
+    Su.set_preconditioner(D.IC0("solve"))
+    _check(golden, "pcg_unstructured3d_16_ic0_solve", Su.solve(_dev(O.rhs(Au.shape[0], 0))))
+    Su.set_preconditioner(D.Jacobi())
+    _check(golden, "pcg_unstructured3d_16_jacobi", Su.solve(_dev(O.rhs(Au.shape[0], 0))))
+
+
+def test_pcg_multiply_modes_golden(D, golden):
+    A = O.poisson2d(64)
+    b = _dev(O.rhs(A.shape[0], 0))
+    S = D.CsrSystem.from_any(A)
+    Lf = CO.ic0(A)
+    S.set_preconditioner((Lf @ Lf.T).tocsr())  # M = L L^T as one CSR, test.py:88
+    _check_chaotic(golden, "pcg_poisson2d_64_ic0_multiply", S.solve(b), stable=100)
+    S.set_preconditioner(D.IC0("multiply"))
+    _check_chaotic(golden, "pcg_poisson2d_64_ic0_multiply", S.solve(b), stable=100)
+    Lw = O.learned_like_factor(A, seed=1, scale=0.02, diag_sigma=0.1)
+    S.set_preconditioner((Lw @ Lw.T).tocsr())  # the learned technique, test.py:100-105
+    _check_chaotic(golden, "pcg_poisson2d_64_learnedlike_wellcond_multiply", S.solve(b), stable=40)
+    S.set_preconditioner(D.LLtMultiply(Lw))
+    _check_chaotic(golden, "pcg_poisson2d_64_learnedlike_wellcond_multiply", S.solve(b), stable=40)
+    # the two apply forms agree with each other on one application
+    r = O.rhs(A.shape[0], 8)
+    z2 = S.precond_apply(_dev(r)).cpu().numpy()
+    ref = Lw @ (Lw.T @ r)
+    np.testing.assert_allclose(z2, ref, rtol=1e-13, atol=1e-15)
+
+
+def test_duck_typed_operators_in_a_plain_loop(D, golden):
+    """A and M objects only need `@` (cg.py:60,61,75,81): run the textbook loop over them."""
+    A = O.poisson2d(64)
+    b = _dev(O.rhs(A.shape[0], 0))
+    S = D.CsrSystem.from_any(A)
+    M = D.LLtSolve(CO.ic0(A))
+    x = torch.zeros_like(b)
+    r = b - S @ x
+    z = M @ r
+    p = z.clone()
+    bb = torch.inner(b, b)
+    k = 0
+    while torch.inner(r, r) / bb >= 1e-8 or k == 0:
+        Ap = S @ p
+        rz = torch.inner(r, z)
+        a = rz / torch.inner(Ap, p)
+        x, r = x + a * p, r - a * Ap
+        z = M @ r
+        p = z + (torch.inner(r, z) / rz) * p
+        k += 1
+    assert k == int(golden["pcg_poisson2d_64_ic0_solve/iters"])
+
+
+# ---- the other reference entry points --------------------------------------------------------------
+def test_conjugate_gradient(D, golden):
+    from deeppreconditioning_amd.cg import conjugate_gradient
+    A32 = O.poisson2d(32)
+    x_true = np.random.default_rng(11).uniform(-1, 1, A32.shape[0])
+    errors, x = conjugate_gradient(A32, _dev(A32 @ x_true), x_true=_dev(x_true))
+    g_hist, g_err = golden["cg_poisson2d_32_xtrue11/hist"], golden["cg_poisson2d_32_xtrue11/err"]
+    assert len(errors) == len(g_hist)
+    np.testing.assert_allclose([float(r) for _, r in errors], g_hist, rtol=HIST_RTOL)
+    np.testing.assert_allclose([float(e) for e, _ in errors], g_err, rtol=1e-8, atol=1e-18)
+    np.testing.assert_allclose(x.cpu().numpy(), golden["cg_poisson2d_32_xtrue11/x"], rtol=1e-10, atol=1e-12)
+    A = O.poisson2d(64)
+    errors, x = conjugate_gradient(A, _dev(O.rhs(A.shape[0], 0)))
+    np.testing.assert_allclose([float(r) for _, r in errors], golden["cg_poisson2d_64/hist"], rtol=HIST_RTOL)
+    assert all(float(e) == 0.0 for e, _ in errors)
+    np.testing.assert_allclose(x.cpu().numpy(), golden["cg_poisson2d_64/x"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("case", ["spmm_kat", "spmm_rand21"])
+def test_sparse_matvec_mul(D, golden, case):
+    from deeppreconditioning_amd.utils import SparseBatch, sparse_matvec_mul
+    idx, feat, vec = golden[f"{case}/indices"], golden[f"{case}/features"], golden[f"{case}/vectors"]
+    t = SparseBatch(_dev(feat), _dev(idx), [vec.shape[1]] * 2, vec.shape[0])
+    y = sparse_matvec_mul(t, _dev(vec), transpose=False).cpu().numpy()
+    yt = sparse_matvec_mul(t, _dev(vec), transpose=True).cpu().numpy()
+    tol = dict(rtol=0, atol=0) if case == "spmm_kat" else dict(rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(y, golden[f"{case}/y"], **tol)    # KAT of tests/test_utils.py:39
+    np.testing.assert_allclose(yt, golden[f"{case}/yt"], **tol)
+
+
+def test_benchmark_cg(D, golden):
+    from deeppreconditioning_amd.utils import benchmark_cg
+    A = O.poisson2d(64)
+    b = _dev(O.rhs(A.shape[0], 0))
+    _, it, info = benchmark_cg(A, b)
+    assert [it, info] == list(golden["benchmark_cg_poisson2d_64/none"])
+    _, it, info = benchmark_cg(A, b, sp.diags(1 / A.diagonal()).tocsr())
+    assert [it, info] == list(golden["benchmark_cg_poisson2d_64/jacobi"])
+    A = O.poisson2d(256)
+    _, it, info = benchmark_cg(A, _dev(O.rhs(A.shape[0], 0)))
+    assert [it, info] == list(golden["benchmark_cg_poisson2d_256/none"])
+
+
+# ---- mixed precision, batches, full-size properties ---------------------------------------------------
+def test_mixed_precision_residual_matched(D):
+    A = O.poisson3d(48)
+    b = O.rhs(A.shape[0], 0)
+    S = D.CsrSystem.from_any(A)
+    S.set_preconditioner(D.Jacobi())
+    r64 = S.solve(_dev(b))
+    r32 = S.solve(_dev(b), flags=D._lib.SPMV_F32)
+    assert abs(r32.iterations - r64.iterations) <= 2
+    true_r = b - A @ r32.x.cpu().numpy()
+    assert np.dot(true_r, true_r) / np.dot(b, b) < 2e-8  # residual-matched to the fp64 run's target
+    m = min(len(r32.res_history), len(r64.res_history), 40)
+    np.testing.assert_allclose(r32.res_history[:m], r64.res_history[:m], rtol=1e-4)
+    y32 = S.spmv_f32(_dev(b.astype(np.float32))).cpu().numpy()
+    np.testing.assert_allclose(y32, CO.spmv_f32(A, b.astype(np.float32)), rtol=2e-6, atol=1e-5)
+
+
+def test_solve_batch_matches_single(D):
+    import ctypes as C
+    from deeppreconditioning_amd.batch import solve_batch
+    mats = [O.poisson2d(40), O.poisson3d(14), O.unstructured_like(O.poisson3d(10), 2), O.poisson2d(64), O.poisson2d(23)]
+    systems, rhs_list, single = [], [], []
+    for i, A in enumerate(mats):
+        S = D.CsrSystem.from_any(A)
+        S.set_preconditioner(D.Jacobi())
+        b = _dev(O.rhs(A.shape[0], i))
+        systems.append(S)
+        rhs_list.append(b)
+        single.append(S.solve(b))
+    out = solve_batch(systems, rhs_list, n_streams=3)
+    for s, o in zip(single, out):
+        assert o.iterations == s.iterations and o.status == s.status
+        assert torch.equal(o.x, s.x)
+        assert o.final_res == s.res_history[-1]
+
+
+def test_full_size_256cubed_properties(D):
+    """BASELINE config 4 size (16.7M DoF, 117M non-zeros, generated in HBM): size-independent checks."""
+    from deeppreconditioning_amd import poisson
+    n = 256
+    S = poisson.poisson_system(3, n)
+    N = n ** 3
+    assert S.n == N and S.nnz == 7 * n ** 3 - 6 * n ** 2
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand(N, device="cuda", dtype=torch.float64, generator=g) - 0.5
+    y = torch.rand(N, device="cuda", dtype=torch.float64, generator=g) - 0.5
+    Ax, Ay = S @ x, S @ y
+    # symmetry <x,Ay> = <Ax,y>, linearity A(2x - y) = 2Ax - Ay (exact: powers of two and integers), constants
+    assert D.dot(x, Ay) == pytest.approx(D.dot(Ax, y), rel=1e-12)
+    assert torch.equal(S @ (2 * x), 2 * Ax)
+    ones = torch.ones(N, device="cuda", dtype=torch.float64)
+    A1 = S @ ones  # interior rows sum to 0, each missing neighbour adds 1
+    assert float(A1.sum()) == 6.0 * n * n
+    S.set_preconditioner(D.Jacobi())
+    b = poisson.rhs(N, 0)
+    res = S.solve(b, max_iter=64)
+    assert res.iterations == 64 and res.status == 1
+    h = res.res_history
+    assert h[0] == pytest.approx(1.0 / 36.0, rel=1e-12) and np.all(np.isfinite(h))
+    r_true = b - S @ res.x
+    assert D.dot(r_true, r_true) / D.dot(b, b) == pytest.approx(h[-1], rel=1e-6)
