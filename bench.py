@@ -1,0 +1,185 @@
+"""bench.py -- PCG iterations/s and SpMV GB/s vs the HBM roofline on a 1M-DoF Poisson CSR system.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A step = one pass of the hot path over one batch: every rank solves `--systems-per-gpu` (default 1)
+1M-DoF pressure-Poisson systems (3-D 7-point, 100^3, Jacobi-preconditioned fp64 PCG, rtol 1e-8 on
+<r,r>/<b,b>, max_iter 1024 -- the reference defaults, cg.py:51) that are already resident in HBM.
+N > 1: one process per GPU (torch.distributed over RCCL), systems sharded with no data-path
+collective; the timed region is bracketed by barrier + synchronize and the MAX over ranks is taken.
+Rank 0 prints ONE JSON line.  `value` = PCG iterations of all ranks / that time.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import pathlib
+import subprocess
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def spmv_bytes(n: int, nnz: int, wv: int = 8, wx: int = 8) -> int:
+    """Algorithmic bytes of one CSR SpMV: nnz*(wv+4) + (n+1)*4 + 2*n*wx."""
+    return nnz * (wv + 4) + (n + 1) * 4 + 2 * n * wx
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--systems-per-gpu", type=int, default=1)
+    ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--n", type=int, default=100, help="grid points per side (3-D 100 -> 1,000,000 DoF)")
+    ap.add_argument("--precond", default="jacobi", choices=["jacobi", "none", "ic0"])
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(dim: int, n: int) -> dict:
+    """The CPU oracle (C restatement of cg.py, oracle/pcg_oracle.c, OpenMP) timed on this box's host
+    cores on the same system -- a reported baseline, not the target."""
+    from oracle import c_oracle as CO
+    from oracle import oracle as O
+    A = O.poisson3d(n) if dim == 3 else O.poisson2d(n)
+    b = O.rhs(A.shape[0], 0)
+    dinv = O.jacobi_dinv(A)
+    CO.pcg(A, b, "jacobi", dinv=dinv, max_iter=3)  # warm caches / thread pool
+    sec, iters, _, _ = CO.pcg(A, b, "jacobi", dinv=dinv)
+    return {"value": round(iters / sec, 2), "unit": "iterations/s", "cores": CO.num_threads(), "kind": "port",
+            "sample": f"1 full solve of the same system ({iters} PCG iterations, {sec:.2f} s) by oracle/pcg_oracle.c "
+                      f"with {CO.num_threads()} OpenMP threads of {os.cpu_count()} host CPUs",
+            "iterations": iters}
+
+
+def main() -> None:
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # convenience: launch the one-process-per-GPU job as a child (never exec after touching the GPU)
+        port = os.environ.get("MASTER_PORT", "29531")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", port, str(ROOT / "bench.py")] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import deeppreconditioning_amd as D
+    from deeppreconditioning_amd import poisson
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- the batch: systems already resident in HBM before the timed region --------------------
+    system = poisson.poisson_system(args.dim, args.n)
+    system.set_preconditioner({"jacobi": D.Jacobi(), "none": None, "ic0": D.IC0("solve")}[args.precond])
+    # every rank owns systems rank, rank+world, ... of the global batch; distinct b per system
+    my_ids = [rank + world * j for j in range(args.systems_per_gpu)]
+    rhs = [poisson.rhs(system.n, seed=i) for i in my_ids]
+
+    def step() -> int:
+        its = 0
+        for b in rhs:
+            its += system.solve(b, want_history=False).iterations
+        return its
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    iters_local = 0
+    for _ in range(args.steps):
+        iters_local += step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([float(iters_local)], device="cuda", dtype=torch.float64)
+    tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_iters, t = float(tot.item()), float(tmax.item())
+
+    if rank == 0:
+        n, nnz = system.n, system.nnz
+        check = system.solve(poisson.rhs(n, 0))
+        # ---- roofline of the dominant kernel: the SpMV+<p,Ap> launch inside the PCG iteration ----
+        ms = system.spmv_dot_bench(repeats=200)     # HIP events on the launch stream, 200 launches
+        b_alg = spmv_bytes(n, nnz)
+        achieved = b_alg / (ms * 1e-3) / 1e9
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_traffic.json"
+        if pmc.exists():
+            traffic = json.loads(pmc.read_text()).get(f"spmv_{args.dim}d_{args.n}")
+        line = {
+            "metric": "pcg_iterations_per_sec", "value": round(total_iters / t, 1), "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * t / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"poisson{args.dim}d_{args.n}_{args.precond}_pcg_fp64", "dof": n, "nnz": nnz,
+                       "rtol_sq": 1e-8, "max_iter": 1024, "iterations_per_solve": check.iterations,
+                       "final_res": check.final_res, "systems_per_gpu_per_step": args.systems_per_gpu,
+                       "parallelism": f"independent systems sharded one-per-rank x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<double,double,CTL,DOT> (SpMV + <p,Ap>)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": b_alg, "us_per_launch": round(ms * 1e3, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.dim, args.n)
+        if world == 1 and not args.no_extra:
+            line["extra"] = extra_workloads(D, poisson, torch)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def extra_workloads(D, poisson, torch) -> dict:
+    """Secondary numbers (not the headline): 2-D 1M-DoF fixed-work solve and the HBM-bound 256^3 system."""
+    out = {}
+    s2 = poisson.poisson_system(2, 1024)
+    s2.set_preconditioner(D.Jacobi())
+    b2 = poisson.rhs(s2.n, 0)
+    s2.solve(b2, want_history=False)
+    r = s2.solve(b2, want_history=False)
+    ms = s2.spmv_dot_bench(200)
+    out["poisson2d_1024_jacobi"] = {"iterations": r.iterations, "iterations_per_s": round(r.iterations / r.seconds, 1),
+                                    "spmv_gbs": round(spmv_bytes(s2.n, s2.nnz) / (ms * 1e-3) / 1e9, 1)}
+    del s2
+    s3 = poisson.poisson_system(3, 256)
+    s3.set_preconditioner(D.Jacobi())
+    b3 = poisson.rhs(s3.n, 0)
+    s3.solve(b3, max_iter=16, want_history=False)
+    r = s3.solve(b3, max_iter=64, want_history=False)
+    ms = s3.spmv_dot_bench(50)
+    gbs = spmv_bytes(s3.n, s3.nnz) / (ms * 1e-3) / 1e9
+    out["poisson3d_256_jacobi"] = {"iterations": r.iterations, "iterations_per_s": round(r.iterations / r.seconds, 2),
+                                   "spmv_gbs": round(gbs, 1), "spmv_frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                                   "note": "1.74 GB per SpMV: beyond the 256 MiB Infinity Cache, HBM-bound"}
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -183,7 +183,11 @@ static int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s) {
     if (h_max <= kStreamCap && !force_vector) {
         plan.kernel = SPMV_STREAM;
         plan.nrb = (int)((A.n + kStreamRows - 1) / kStreamRows);
-        int g = plan.nrb < kMaxGrid ? plan.nrb : kMaxGrid;
+        // 8 workgroups per CU while the matrix stream stays in the 256 MiB Infinity Cache, 6 per CU once
+        // it comes from HBM (measured: tools/lib_lab, 100^3: 20.7 vs 21.7 us; 256^3: 457 vs 424 us)
+        const double stream_bytes = 12.0 * (double)A.nnz + 20.0 * (double)A.n;
+        const int cap = stream_bytes < 192e6 ? kMaxSpmvGrid : (kMaxSpmvGrid * 3) / 4;
+        int g = plan.nrb < cap ? plan.nrb : cap;
         if (g > 8) g -= g % 8;
         plan.grid = g < 1 ? 1 : g;
     } else {
@@ -193,7 +197,7 @@ static int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s) {
         while (tpr < 64 && tpr < mean) tpr *= 2;
         plan.tpr = tpr;
         const int64_t ngroups = (A.n + (kBlock / tpr) - 1) / (kBlock / tpr);
-        int g = ngroups < kMaxGrid ? (int)ngroups : kMaxGrid;
+        int g = ngroups < kMaxSpmvGrid ? (int)ngroups : kMaxSpmvGrid;
         if (g > 8) g -= g % 8;
         plan.grid = g < 1 ? 1 : g;
     }
@@ -313,10 +317,10 @@ static int ensure_work(dpcg_system *h, int max_iter, bool need_f32, bool need_er
         DPCG_TRY(dev_alloc(&h->p, n));
         DPCG_TRY(dev_alloc(&h->q, n));
         DPCG_TRY(dev_alloc(&h->t, n));
-        DPCG_TRY(dev_alloc(&h->part_pq, kMaxGrid));
+        DPCG_TRY(dev_alloc(&h->part_pq, kMaxSpmvGrid));
         DPCG_TRY(dev_alloc(&h->part_rz, kMaxGrid));
         DPCG_TRY(dev_alloc(&h->part_rr, kMaxGrid));
-        DPCG_TRY(dev_alloc(&h->part_bb, kMaxGrid));
+        DPCG_TRY(dev_alloc(&h->part_bb, kMaxSpmvGrid));
     }
     if (need_err && !h->e) DPCG_TRY(dev_alloc(&h->e, n));
     if (need_f32) {
@@ -672,13 +676,12 @@ extern "C" int dpcg_spmv_dot_bench(dpcg_handle_t h, const double *x, double *y, 
     if (!h || !x || !y || repeats <= 0 || !ms_per_launch) return invalid("dpcg_spmv_dot_bench: bad argument");
     hipStream_t s = (hipStream_t)stream;
     DPCG_TRY(ensure_work(h, 0, false, false));
-    // a never-converging control block: rr partials = {1,0,...}, bb = 1, thresholds 0
+    // a never-finishing control block: done = 0 (thresholds 0, <b,b> = 1)
     DPCG_HIP(hipMemsetAsync(h->part_rr, 0, kMaxGrid * sizeof(double), s));
-    DPCG_HIP(hipMemsetAsync(h->part_rz, 0, kMaxGrid * sizeof(double), s));
     const double one = 1.0;
     DPCG_HIP(hipMemcpyAsync(h->part_rr, &one, sizeof(double), hipMemcpyHostToDevice, s));
-    launch_finalize_init(h->scal, h->part_rr, 1, 0.0, 0.0, s);
-    IterCtl ctl{h->scal, h->part_rr, h->part_rz, h->vec_grid, h->hist, 0};
+    launch_finalize_init(h->scal, h->part_rr, h->part_rr, h->part_rr, 1, 0.0, 0.0, h->hist, 0, s);
+    IterCtl ctl{h->scal};
     hipEvent_t e0, e1;
     DPCG_HIP(hipEventCreate(&e0));
     DPCG_HIP(hipEventCreate(&e1));
@@ -709,26 +712,27 @@ static int default_chunk() {
 static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hipStream_t s) {
     const int64_t n = h->A.n;
     const bool f32 = (flags & DPCG_SPMV_F32) != 0;
-    IterCtl ctl{h->scal, h->part_rr, h->part_rz, h->vec_grid, h->hist, h->hist_cap};
-    // K1: stopping test + Ap = A p + partials of <p,Ap>            cg.py:71,75,78
+    IterCtl ctl{h->scal};
+    // K1: (skip when done) Ap = A p + partials of <p,Ap>           cg.py:71,75,78
     if (f32) launch_spmv_f32in(h->A, h->planA, h->p32, h->p, h->q, h->part_pq, &ctl, s);
     else launch_spmv(h->A, h->planA, h->p, h->q, h->part_pq, &ctl, s);
-    // K2: alpha; x += alpha p; r -= alpha Ap; (z = M r fused); partials <r,z>, <r,r>   cg.py:78-82,86
+    // K2: alpha; r -= alpha Ap; (z = M r fused); partials <r,z>, <r,r>              cg.py:78,80-82,86
     const int pre = h->precond == DPCG_PRECOND_NONE ? 0 : (h->precond == DPCG_PRECOND_JACOBI ? 1 : 2);
     double *z = pre == 0 ? h->r : h->z;
-    launch_update_xr(pre, n, h->scal, h->part_pq, h->planA.grid, h->p, h->q, h->x, h->r, h->dinv, h->z, h->part_rz,
-                     h->part_rr, h->vec_grid, s);
+    launch_update_r(pre, n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->dinv, h->z, h->part_rz, h->part_rr,
+                    h->vec_grid, s);
     if (pre == 2) {
         DPCG_TRY(apply_precond(h, h->r, h->z, s));                                   // cg.py:81
         launch_dot_partials(n, h->scal, h->r, h->z, h->part_rz, h->vec_grid, s);     // cg.py:82
     }
+    // K3: beta; x += alpha p; p = z + beta p; workgroup 0: stopping test of the new iterate   cg.py:79,82-83,86,71
+    launch_update_xp(n, h->scal, h->part_rz, h->part_rr, h->vec_grid, z, h->p, h->x, f32 ? h->p32 : nullptr, h->hist,
+                     h->hist_cap, h->vec_grid, s);
     if (x_true) {                                                                    // cg.py:43-45
         launch_anorm_err(n, h->scal, h->x, x_true, h->e, h->vec_grid, s);
         launch_spmv(h->A, h->planA, h->e, h->t, h->part_bb, nullptr, s);
         launch_record_err(h->scal, h->part_bb, h->planA.grid, h->err_hist, h->hist_cap, 0, s);
     }
-    // K3: beta; p = z + beta p                                                      cg.py:82-83
-    launch_update_p(n, h->scal, h->part_rz, h->vec_grid, z, h->p, f32 ? h->p32 : nullptr, h->vec_grid, s);
     return DPCG_OK;
 }
 
@@ -804,7 +808,8 @@ struct Solve {
         if (h->precond != DPCG_PRECOND_NONE) DPCG_TRY(apply_precond(h, h->r, h->z, s));   // cg.py:61
         launch_init_state(n, h->scal, b, h->r, z, h->p, f32 ? h->p32 : nullptr, h->part_bb, h->part_rz, h->part_rr,
                           (flags & DPCG_INIT_CHECK_R) ? 1 : 0, h->vec_grid, s);
-        launch_finalize_init(h->scal, h->part_bb, h->vec_grid, rtol_sq, atol_sq, s);
+        launch_finalize_init(h->scal, h->part_bb, h->part_rz, h->part_rr, h->vec_grid, rtol_sq, atol_sq, h->hist,
+                             h->hist_cap, s);
         if (x_true) {                                                                // cg.py:27-29
             launch_anorm_err(n, h->scal, h->x, x_true, h->e, h->vec_grid, s);
             launch_spmv(h->A, h->planA, h->e, h->t, h->part_bb, nullptr, s);
@@ -841,7 +846,7 @@ struct Solve {
 
     int finish(double *x, int *iters, double *final_res, double *seconds, double *res_history, double *err_history) {
         const int64_t n = h->A.n;
-        launch_final_check(h->scal, h->part_rr, h->vec_grid, h->hist, h->hist_cap, max_iter, s);
+        launch_final_check(h->scal, s);
         DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
         DPCG_HIP(hipStreamSynchronize(s));
         const auto t1 = std::chrono::steady_clock::now();                            // cg.py:88

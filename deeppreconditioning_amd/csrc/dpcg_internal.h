@@ -17,7 +17,8 @@ namespace dpcg {
 // number of reduction partials is bounded and every kernel after a reduction can re-reduce the
 // partials itself (deterministically) instead of waiting on a host round trip or a float atomic.
 constexpr int kBlock = 256;
-constexpr int kMaxGrid = 1024;
+constexpr int kMaxGrid = 512;         // vector kernels: 2 workgroups per CU (fewer partials to re-reduce)
+constexpr int kMaxSpmvGrid = 2048;    // SpMV: 8 workgroups per CU = 32 waves per CU (40 VGPRs, 16 KiB LDS each)
 constexpr int kStreamCap = 2048;      // products staged in LDS per 256-row block (16 KiB)
 constexpr int kStreamRows = 256;      // rows per row-block of the CSR-stream SpMV
 
@@ -43,6 +44,8 @@ struct SpmvPlan {
 // reads values written by an EARLIER kernel, so no intra-kernel hand-off is needed.
 struct Scalars {
     double rz;         // <r,z> of the current iterate (cg.py:76)
+    double rz_next;    // <r,z> of the iterate K3 has just produced; K1 rotates it into rz
+    double alpha;      // step length of the current update (cg.py:78), written by K2 for K3
     double bb;         // <b,b> (cg.py:17), computed once
     double res;        // last tested squared relative residual
     double rtol_sq;    // cg.py:71 threshold
@@ -103,15 +106,10 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 // ---- kernel launchers (dpcg_kernels.hip) -----------------------------------------------------
 // y = A x.  If part_pq != nullptr also writes per-workgroup partials of <x, y> (plan.grid of them).
-// `ctl` (may be null): when given, the kernel is the head of a PCG iteration: it first runs the
-// stopping test on part_rr/part_rz (n_part partials), records history, and returns early when done.
+// `ctl` (may be null): when given, the kernel is the head of a PCG update: it returns at once when
+// the device-resident `done` word is set and rotates rz_next -> rz (see dpcg_kernels.hip).
 struct IterCtl {
     Scalars *scal;
-    const double *part_rr;
-    const double *part_rz;
-    int n_part;
-    double *hist;
-    int hist_cap;
 };
 void launch_spmv(const CsrDev &A, const SpmvPlan &plan, const double *x, double *y, double *part_pq,
                  const IterCtl *ctl, hipStream_t s);
@@ -119,20 +117,20 @@ void launch_spmv_f32in(const CsrDev &A, const SpmvPlan &plan, const float *x32, 
                        double *part_pq, const IterCtl *ctl, hipStream_t s);
 void launch_spmv_f32out(const CsrDev &A, const SpmvPlan &plan, const float *x32, float *y32, hipStream_t s);
 
-void launch_update_xr(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
-                      const double *p, const double *q, double *x, double *r, const double *dinv, double *z,
-                      double *part_rz, double *part_rr, int grid, hipStream_t s);
+void launch_update_r(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
+                     const double *q, double *r, const double *dinv, double *z, double *part_rz, double *part_rr,
+                     int grid, hipStream_t s);
 void launch_dot_partials(int64_t n, const Scalars *scal, const double *a, const double *b, double *part, int grid,
                          hipStream_t s);
-void launch_update_p(int64_t n, const Scalars *scal, const double *part_rz, int n_part, const double *z, double *p,
-                     float *p32, int grid, hipStream_t s);
-void launch_final_check(Scalars *scal, const double *part_rr, int n_part, double *hist, int hist_cap, int max_iter,
-                        hipStream_t s);
+void launch_update_xp(int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
+                      const double *z, double *p, double *x, float *p32, double *hist, int hist_cap, int grid,
+                      hipStream_t s);
+void launch_final_check(Scalars *scal, hipStream_t s);
 void launch_init_state(int64_t n, Scalars *scal, const double *b, const double *r, const double *z, double *p,
                        float *p32, double *part_bb, double *part_rz, double *part_rr, int init_check_r, int grid,
                        hipStream_t s);
-void launch_finalize_init(Scalars *scal, const double *part_bb, int n_part, double rtol_sq, double atol_sq,
-                          hipStream_t s);
+void launch_finalize_init(Scalars *scal, const double *part_bb, const double *part_rz, const double *part_t,
+                          int n_part, double rtol_sq, double atol_sq, double *hist, int hist_cap, hipStream_t s);
 void launch_residual(int64_t n, const double *b, const double *ax, double *r, int grid, hipStream_t s);
 void launch_scale(int64_t n, const double *dinv, const double *r, double *z, int grid, hipStream_t s);
 void launch_extract_dinv(const CsrDev &A, double *dinv, int *bad_flag, hipStream_t s);

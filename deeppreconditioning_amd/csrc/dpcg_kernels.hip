@@ -43,39 +43,37 @@ __device__ __forceinline__ int virtual_block() {
     return (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b;
 }
 
+
 // ------------------------------------------------------------------------------------------------
-// Head of a PCG iteration (cg.py:71): stopping test, history, iteration count.  Returns true when
-// the iteration has to run.  All workgroups take the same decision from the same partials.
+// Control flow of the iteration without a host round trip (cg.py:70-71):
+//   * the stopping test for iterate k+1 is evaluated by workgroup 0 of K3 (the last kernel of
+//     update k+1), which writes done / k / history / rz_next into the device-resident Scalars;
+//   * K1 (the SpMV, head of the next update) only reads the `done` word an EARLIER kernel wrote and
+//     workgroup 0 rotates rz_next -> rz.  No kernel reads a scalar that the same kernel writes.
+// Once `done` is set every later kernel of the replayed graph returns at once.
 // ------------------------------------------------------------------------------------------------
 struct IterCtlDev {
     Scalars *scal;
-    const double *part_rr;
-    const double *part_rz;
-    int n_part;
-    double *hist;
-    int hist_cap;
 };
 
-__device__ __forceinline__ bool iteration_head(const IterCtlDev &c, double *sh) {
+__device__ __forceinline__ bool iteration_head(const IterCtlDev &c) {
     Scalars *sc = c.scal;
     if (sc->done) return false;
-    const double rr = reduce_partials(c.part_rr, c.n_part, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->rz = sc->rz_next;     // <r,z> of the current iterate, cg.py:76
+    return true;
+}
+
+// The test of cg.py:71 on the iterate that update k has just produced; one thread of one workgroup.
+__device__ __forceinline__ void record_and_test(Scalars *sc, double rr, double rz_next, double *hist, int hist_cap,
+                                                int k) {
     const double res = rr / sc->bb;                                     // cg.py:15-17
     const bool conv = (res < sc->rtol_sq) || (rr < sc->atol_sq);        // cg.py:71
-    const bool bad = !(res == res);
-    if (blockIdx.x == 0) {
-        double rz = 0.0;
-        if (!conv && !bad) rz = reduce_partials(c.part_rz, c.n_part, sh);   // cg.py:76
-        if (threadIdx.x == 0) {
-            const int k = sc->k;
-            if (k < c.hist_cap) c.hist[k] = res;                         // cg.py:67,88
-            sc->res = res;
-            if (conv) { sc->done = 1; sc->status = DPCG_OK; }
-            else if (bad) { sc->done = 1; sc->status = DPCG_BREAKDOWN; }
-            else { sc->k = k + 1; sc->rz = rz; }
-        }
-    }
-    return !(conv || bad);
+    if (k < hist_cap) hist[k] = res;                                    // cg.py:67,88
+    sc->res = res;
+    sc->k = k;
+    sc->rz_next = rz_next;
+    if (conv) { sc->done = 1; sc->status = DPCG_OK; }
+    else if (!(res == res)) { sc->done = 1; sc->status = DPCG_BREAKDOWN; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -94,49 +92,55 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t
                                                         const VT *__restrict__ val, const XT *__restrict__ x,
                                                         const double *__restrict__ xdot, YT *__restrict__ y,
                                                         int nrb, double *__restrict__ part_pq, IterCtlDev ctl) {
+    constexpr int U = kStreamCap / kBlock;  // (col,val) loads per thread per row-block
     __shared__ double prod[kStreamCap];
     __shared__ double sh[4];
-    if (CTL) {
-        if (!iteration_head(ctl, sh)) return;
-    }
     const int t = threadIdx.x;
     const int G = gridDim.x;
     const int v = virtual_block();
     const int rb_lo = (int)(((int64_t)v * nrb) / G);
     const int rb_hi = (int)(((int64_t)(v + 1) * nrb) / G);
-    double acc = 0.0;
-    for (int rb = rb_lo; rb < rb_hi; ++rb) {
+    int c[U];
+    VT a[U];
+    int cnt = 0, rs = 0, re = 0;
+    // matrix stream of one row-block -> registers (all 2U loads of a thread in flight at once)
+    auto fetch = [&](int rb) {
         const int64_t r0 = (int64_t)rb * kStreamRows;
         const int64_t row = r0 + t;
         const int64_t rlast = (r0 + kStreamRows < n) ? r0 + kStreamRows : n;
         const int base = rowptr[r0];
-        const int cnt = rowptr[rlast] - base;
-        int rs = 0, re = 0;
+        cnt = rowptr[rlast] - base;
+        rs = re = 0;
         if (row < n) {
             rs = rowptr[row] - base;
             re = rowptr[row + 1] - base;
         }
         const int32_t *__restrict__ cb = col + base;
         const VT *__restrict__ vb = val + base;
-        // product phase: 4 independent (col,val) loads in flight per thread before the gathers
-        for (int k0 = t; k0 < cnt; k0 += 4 * kBlock) {
-            int c[4];
-            VT a[4];
+        const int last = cnt > 0 ? cnt - 1 : 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u * kBlock;
-                const int kk = k < cnt ? k : cnt - 1;
-                c[u] = cb[kk];
-                a[u] = vb[kk];
-            }
-            double xv[4];
+        for (int u = 0; u < U; ++u) {
+            const int k = t + u * kBlock;
+            const int kk = k < cnt ? k : last;
+            c[u] = cnt > 0 ? cb[kk] : 0;
+            a[u] = cnt > 0 ? vb[kk] : (VT)0;
+        }
+    };
+    // The first row-block's loads are issued before the `done` word is looked at.
+    if (rb_lo < rb_hi) fetch(rb_lo);
+    if (CTL) {
+        if (!iteration_head(ctl)) return;
+    }
+    double acc = 0.0;
+    for (int rb = rb_lo; rb < rb_hi; ++rb) {
+        const int64_t row = (int64_t)rb * kStreamRows + t;
+        double xv[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) xv[u] = (double)x[c[u]];
+        for (int u = 0; u < U; ++u) xv[u] = (double)x[c[u]];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u * kBlock;
-                if (k < cnt) prod[k] = (double)a[u] * xv[u];
-            }
+        for (int u = 0; u < U; ++u) {
+            const int k = t + u * kBlock;
+            if (k < cnt) prod[k] = (double)a[u] * xv[u];
         }
         __syncthreads();
         if (row < n) {
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t
             if (DOT) acc += s * xdot[row];
         }
         __syncthreads();
+        if (rb + 1 < rb_hi) fetch(rb + 1);
     }
     if (DOT) {
         const double tot = block_sum(acc, sh);
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_vector(int64_t n, const int32_t
                                                         double *__restrict__ part_pq, IterCtlDev ctl) {
     __shared__ double sh[4];
     if (CTL) {
-        if (!iteration_head(ctl, sh)) return;
+        if (!iteration_head(ctl)) return;
     }
     constexpr int RPB = kBlock / TPR;  // rows per workgroup step
     const int t = threadIdx.x;
@@ -197,8 +202,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_vector(int64_t n, const int32_t
 }
 
 static IterCtlDev to_dev(const IterCtl *c) {
-    IterCtlDev d{nullptr, nullptr, nullptr, 0, nullptr, 0};
-    if (c) d = IterCtlDev{c->scal, c->part_rr, c->part_rz, c->n_part, c->hist, c->hist_cap};
+    IterCtlDev d{nullptr};
+    if (c) d = IterCtlDev{c->scal};
     return d;
 }
 
@@ -256,32 +261,74 @@ void launch_spmv_f32out(const CsrDev &A, const SpmvPlan &plan, const float *x32,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Vector updates of the iteration (cg.py:78-83), fused: one pass over p,q,x,r,(dinv) -> x,r,z.
+// Vector updates of the iteration (cg.py:78-83) in two passes of 40 bytes per row each:
+//   K2 (k_update_r):  alpha;  r -= alpha q;  z = dinv r;  partials <r,z>, <r,r>     reads q,r,dinv  writes r,z
+//   K3 (k_update_xp): beta;   x += alpha p;  p = z + beta p                         reads z,p,x     writes x,p
+// p is read once for both of its uses.  All vectors are handle-owned (256-B aligned): 16-byte
+// accesses, loads of the next pair issued before the current pair is consumed, and the first loads
+// issued before the partial reduction so that its latency is hidden.
 // ------------------------------------------------------------------------------------------------
 // PRE: 0 = M = I (z aliases r, not stored), 1 = Jacobi fused, 2 = generic M (z computed later).
 template <int PRE>
-__global__ __launch_bounds__(kBlock) void k_update_xr(int64_t n, const Scalars *__restrict__ sc,
-                                                      const double *__restrict__ part_pq, int n_part_pq,
-                                                      const double *__restrict__ p, const double *__restrict__ q,
-                                                      double *__restrict__ x, double *__restrict__ r,
-                                                      const double *__restrict__ dinv, double *__restrict__ z,
-                                                      double *__restrict__ part_rz, double *__restrict__ part_rr) {
+__global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restrict__ sc,
+                                                     const double *__restrict__ part_pq, int n_part_pq,
+                                                     const double *__restrict__ q, double *__restrict__ r,
+                                                     const double *__restrict__ dinv, double *__restrict__ z,
+                                                     double *__restrict__ part_rz, double *__restrict__ part_rr) {
     __shared__ double sh[4];
     if (sc->done) return;
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const double2 *__restrict__ q2 = reinterpret_cast<const double2 *>(q);
+    const double2 *__restrict__ d2 = reinterpret_cast<const double2 *>(dinv);
+    double2 *__restrict__ r2 = reinterpret_cast<double2 *>(r);
+    double2 *__restrict__ z2 = reinterpret_cast<double2 *>(z);
+    double2 qa = make_double2(0, 0), ra = qa, da = qa;
+    bool have = i < n2;
+    if (have) {
+        qa = q2[i];
+        ra = r2[i];
+        if (PRE == 1) da = d2[i];
+    }
     const double pq = reduce_partials(part_pq, n_part_pq, sh);
     const double alpha = sc->rz / pq;                                   // cg.py:78
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;         // read by K3 (a later kernel)
     double a_rz = 0.0, a_rr = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const double pi = p[i], qi = q[i];
-        x[i] = x[i] + alpha * pi;                                       // cg.py:79
-        const double ri = r[i] - alpha * qi;                            // cg.py:80
-        r[i] = ri;
-        a_rr += ri * ri;                                                // cg.py:86
+    while (have) {
+        const int64_t cur = i;
+        const double2 qc = qa, rc = ra, dc = da;
+        i += stride;
+        have = i < n2;
+        if (have) {
+            qa = q2[i];
+            ra = r2[i];
+            if (PRE == 1) da = d2[i];
+        }
+        double2 rn;
+        rn.x = rc.x - alpha * qc.x;                                     // cg.py:80
+        rn.y = rc.y - alpha * qc.y;
+        r2[cur] = rn;
+        a_rr += rn.x * rn.x;                                            // cg.py:86
+        a_rr += rn.y * rn.y;
         if (PRE == 1) {
-            const double zi = dinv[i] * ri;                             // cg.py:81 (M = diag(1/a_ii))
-            z[i] = zi;
-            a_rz += ri * zi;                                            // cg.py:82
+            double2 zn;
+            zn.x = dc.x * rn.x;                                         // cg.py:81 (M = diag(1/a_ii))
+            zn.y = dc.y * rn.y;
+            z2[cur] = zn;
+            a_rz += rn.x * zn.x;                                        // cg.py:82
+            a_rz += rn.y * zn.y;
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {               // odd tail element
+        const int64_t e = n - 1;
+        const double rn = r[e] - alpha * q[e];
+        r[e] = rn;
+        a_rr += rn * rn;
+        if (PRE == 1) {
+            const double zn = dinv[e] * rn;
+            z[e] = zn;
+            a_rz += rn * zn;
         }
     }
     const double t_rr = block_sum(a_rr, sh);
@@ -295,18 +342,18 @@ __global__ __launch_bounds__(kBlock) void k_update_xr(int64_t n, const Scalars *
     }
 }
 
-void launch_update_xr(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
-                      const double *p, const double *q, double *x, double *r, const double *dinv, double *z,
-                      double *part_rz, double *part_rr, int grid, hipStream_t s) {
+void launch_update_r(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
+                     const double *q, double *r, const double *dinv, double *z, double *part_rz, double *part_rr,
+                     int grid, hipStream_t s) {
     if (precond_fused == 0)
-        hipLaunchKernelGGL(k_update_xr<0>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, p, q, x, r,
-                           dinv, z, part_rz, part_rr);
+        hipLaunchKernelGGL(k_update_r<0>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, dinv, z,
+                           part_rz, part_rr);
     else if (precond_fused == 1)
-        hipLaunchKernelGGL(k_update_xr<1>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, p, q, x, r,
-                           dinv, z, part_rz, part_rr);
+        hipLaunchKernelGGL(k_update_r<1>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, dinv, z,
+                           part_rz, part_rr);
     else
-        hipLaunchKernelGGL(k_update_xr<2>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, p, q, x, r,
-                           dinv, z, part_rz, part_rr);
+        hipLaunchKernelGGL(k_update_r<2>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, dinv, z,
+                           part_rz, part_rr);
 }
 
 // part[b] = partial of <a,b>; skipped once the solve is done (scal may be null: always run).
@@ -327,53 +374,88 @@ void launch_dot_partials(int64_t n, const Scalars *scal, const double *a, const 
     hipLaunchKernelGGL(k_dot_partials, dim3(grid), dim3(kBlock), 0, s, n, scal, a, b, part);
 }
 
-// p = z + beta p (cg.py:82-83); optionally also the fp32 copy the mixed-precision SpMV gathers.
+// x += alpha p; p = z + beta p (cg.py:79,82-83); optionally also the fp32 copy of p that the
+// mixed-precision SpMV gathers.
 template <bool P32>
-__global__ __launch_bounds__(kBlock) void k_update_p(int64_t n, const Scalars *__restrict__ sc,
-                                                     const double *__restrict__ part_rz, int n_part,
-                                                     const double *__restrict__ z, double *__restrict__ p,
-                                                     float *__restrict__ p32) {
+__global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__restrict__ sc,
+                                                      const double *__restrict__ part_rz,
+                                                      const double *__restrict__ part_rr, int n_part,
+                                                      const double *__restrict__ z, double *__restrict__ p,
+                                                      double *__restrict__ x, float *__restrict__ p32,
+                                                      double *__restrict__ hist, int hist_cap) {
     __shared__ double sh[4];
     if (sc->done) return;
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const double2 *__restrict__ z2 = reinterpret_cast<const double2 *>(z);
+    double2 *__restrict__ p2 = reinterpret_cast<double2 *>(p);
+    double2 *__restrict__ x2 = reinterpret_cast<double2 *>(x);
+    float2 *__restrict__ f2 = reinterpret_cast<float2 *>(p32);
+    double2 za = make_double2(0, 0), pa = za, xa = za;
+    bool have = i < n2;
+    if (have) {
+        za = z2[i];
+        pa = p2[i];
+        xa = x2[i];
+    }
     const double rz_new = reduce_partials(part_rz, n_part, sh);
     const double beta = rz_new / sc->rz;                                // cg.py:82
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const double pi = z[i] + beta * p[i];                           // cg.py:83
-        p[i] = pi;
-        if (P32) p32[i] = (float)pi;
+    const double alpha = sc->alpha;
+    if (blockIdx.x == 0) {                                              // cg.py:86 + the test of cg.py:71
+        const double rr = reduce_partials(part_rr, n_part, sh);
+        if (threadIdx.x == 0) record_and_test(sc, rr, rz_new, hist, hist_cap, sc->k + 1);
+    }
+    while (have) {
+        const int64_t cur = i;
+        const double2 zc = za, pc = pa, xc = xa;
+        i += stride;
+        have = i < n2;
+        if (have) {
+            za = z2[i];
+            pa = p2[i];
+            xa = x2[i];
+        }
+        double2 xn, pn;
+        xn.x = xc.x + alpha * pc.x;                                     // cg.py:79
+        xn.y = xc.y + alpha * pc.y;
+        pn.x = zc.x + beta * pc.x;                                      // cg.py:83
+        pn.y = zc.y + beta * pc.y;
+        x2[cur] = xn;
+        p2[cur] = pn;
+        if (P32) f2[cur] = make_float2((float)pn.x, (float)pn.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t e = n - 1;
+        const double pe = p[e];
+        x[e] = x[e] + alpha * pe;
+        const double pn = z[e] + beta * pe;
+        p[e] = pn;
+        if (P32) p32[e] = (float)pn;
     }
 }
 
-void launch_update_p(int64_t n, const Scalars *scal, const double *part_rz, int n_part, const double *z, double *p,
-                     float *p32, int grid, hipStream_t s) {
+void launch_update_xp(int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
+                      const double *z, double *p, double *x, float *p32, double *hist, int hist_cap, int grid,
+                      hipStream_t s) {
     if (p32)
-        hipLaunchKernelGGL(k_update_p<true>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, n_part, z, p, p32);
+        hipLaunchKernelGGL(k_update_xp<true>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, part_rr, n_part, z, p,
+                           x, p32, hist, hist_cap);
     else
-        hipLaunchKernelGGL(k_update_p<false>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, n_part, z, p, p32);
+        hipLaunchKernelGGL(k_update_xp<false>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, part_rr, n_part, z, p,
+                           x, p32, hist, hist_cap);
 }
 
-// After the last permitted update: test the final residual (cg.py:86 of the last pass) and set status.
-__global__ __launch_bounds__(kBlock) void k_final_check(Scalars *sc, const double *__restrict__ part_rr, int n_part,
-                                                        double *hist, int hist_cap, int max_iter) {
-    __shared__ double sh[4];
-    if (sc->done) return;
-    const double rr = reduce_partials(part_rr, n_part, sh);
-    if (threadIdx.x == 0) {
-        const double res = rr / sc->bb;
-        const int k = sc->k;
-        if (k < hist_cap) hist[k] = res;
-        sc->res = res;
-        const bool conv = (res < sc->rtol_sq) || (rr < sc->atol_sq);
-        sc->status = conv ? DPCG_OK : (res == res ? DPCG_MAX_ITER : DPCG_BREAKDOWN);
+// After the last permitted update (cg.py:70 exhausted): the test has already been recorded by K3.
+__global__ void k_final_check(Scalars *sc) {
+    if (threadIdx.x == 0 && !sc->done) {
+        sc->status = DPCG_MAX_ITER;
         sc->done = 1;
-        (void)max_iter;
     }
 }
 
-void launch_final_check(Scalars *scal, const double *part_rr, int n_part, double *hist, int hist_cap, int max_iter,
-                        hipStream_t s) {
-    hipLaunchKernelGGL(k_final_check, dim3(1), dim3(kBlock), 0, s, scal, part_rr, n_part, hist, hist_cap, max_iter);
+void launch_final_check(Scalars *scal, hipStream_t s) {
+    hipLaunchKernelGGL(k_final_check, dim3(1), dim3(64), 0, s, scal);
 }
 
 // Start of a solve (cg.py:62-66): p = z, partials of <b,b>, <r,z> and of the first tested quantity
@@ -417,26 +499,31 @@ void launch_init_state(int64_t n, Scalars *scal, const double *b, const double *
                            part_rr, init_check_r);
 }
 
-__global__ __launch_bounds__(kBlock) void k_finalize_init(Scalars *sc, const double *__restrict__ part_bb, int n_part,
-                                                          double rtol_sq, double atol_sq) {
+__global__ __launch_bounds__(kBlock) void k_finalize_init(Scalars *sc, const double *__restrict__ part_bb,
+                                                          const double *__restrict__ part_rz,
+                                                          const double *__restrict__ part_t, int n_part,
+                                                          double rtol_sq, double atol_sq, double *hist, int hist_cap) {
     __shared__ double sh[4];
     const double bb = reduce_partials(part_bb, n_part, sh);
+    const double rz = reduce_partials(part_rz, n_part, sh);
+    const double tt = reduce_partials(part_t, n_part, sh);             // <z0,z0> (cg.py:66) or <r0,r0>
     if (threadIdx.x == 0) {
         sc->bb = bb;
-        sc->rz = 0.0;
-        sc->res = 0.0;
+        sc->rz = rz;
+        sc->alpha = 0.0;
         sc->rtol_sq = rtol_sq;
         sc->atol_sq = atol_sq;
-        sc->k = 0;
         sc->done = 0;
         sc->status = DPCG_MAX_ITER;
         sc->pad = 0;
+        record_and_test(sc, tt, rz, hist, hist_cap, 0);                 // cg.py:66-67 and the first cg.py:71
     }
 }
 
-void launch_finalize_init(Scalars *scal, const double *part_bb, int n_part, double rtol_sq, double atol_sq,
-                          hipStream_t s) {
-    hipLaunchKernelGGL(k_finalize_init, dim3(1), dim3(kBlock), 0, s, scal, part_bb, n_part, rtol_sq, atol_sq);
+void launch_finalize_init(Scalars *scal, const double *part_bb, const double *part_rz, const double *part_t,
+                          int n_part, double rtol_sq, double atol_sq, double *hist, int hist_cap, hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize_init, dim3(1), dim3(kBlock), 0, s, scal, part_bb, part_rz, part_t, n_part, rtol_sq,
+                       atol_sq, hist, hist_cap);
 }
 
 // r = b - A x0 (cg.py:60), ax = A x0 computed by the SpMV before.
@@ -504,7 +591,7 @@ void launch_f32_to_f64(int64_t n, const float *in, double *out, hipStream_t s) {
 __global__ __launch_bounds__(kBlock) void k_anorm_err(int64_t n, const Scalars *__restrict__ sc,
                                                       const double *__restrict__ x,
                                                       const double *__restrict__ x_true, double *__restrict__ e) {
-    if (sc->done) return;
+    (void)sc;  // runs even when `done` is set: the iterate the test fired on still gets its error recorded
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) e[i] = x[i] - x_true[i];
 }
@@ -518,7 +605,6 @@ void launch_anorm_err(int64_t n, const Scalars *scal, const double *x, const dou
 __global__ __launch_bounds__(kBlock) void k_record_err(const Scalars *__restrict__ sc, const double *__restrict__ part,
                                                        int n_part, double *err_hist, int hist_cap) {
     __shared__ double sh[4];
-    if (sc->done) return;
     const double v = reduce_partials(part, n_part, sh);
     if (threadIdx.x == 0 && sc->k < hist_cap) err_hist[sc->k] = v;
 }
