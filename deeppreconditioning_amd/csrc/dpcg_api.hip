@@ -209,8 +209,8 @@ static int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 struct HandleExtras {
     hipStream_t cap_stream = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    int *flag_host = nullptr;  // pinned, 2 ints
+    unsigned long long *prog_host = nullptr;  // pinned + mapped: the solve's progress word
+    unsigned long long *prog_dev = nullptr;   // device-side address of the same word
 };
 // kept outside dpcg_system so the struct in the header stays POD-like
 #include <map>
@@ -255,10 +255,8 @@ extern "C" int dpcg_create(dpcg_handle_t *out, int64_t n, int64_t nnz, const int
     if (st >= 0) st = make_plan(h->A, h->planA, s);
     HandleExtras ex;
     if (st >= 0 && hipStreamCreateWithFlags(&ex.cap_stream, hipStreamNonBlocking) != hipSuccess) st = DPCG_ERR_HIP;
-    if (st >= 0 && hipEventCreateWithFlags(&ex.ev[0], hipEventDisableTiming) != hipSuccess) st = DPCG_ERR_HIP;
-    if (st >= 0 && hipEventCreateWithFlags(&ex.ev[1], hipEventDisableTiming) != hipSuccess) st = DPCG_ERR_HIP;
-    if (st >= 0 && hipHostMalloc((void **)&ex.flag_host, 2 * sizeof(int), hipHostMallocDefault) != hipSuccess)
-        st = DPCG_ERR_HIP;
+    if (st >= 0 && hipHostMalloc((void **)&ex.prog_host, 64, hipHostMallocMapped) != hipSuccess) st = DPCG_ERR_HIP;
+    if (st >= 0 && hipHostGetDevicePointer((void **)&ex.prog_dev, ex.prog_host, 0) != hipSuccess) st = DPCG_ERR_HIP;
     if (st >= 0 && hipHostMalloc((void **)&h->scal_host, sizeof(Scalars), hipHostMallocDefault) != hipSuccess)
         st = DPCG_ERR_HIP;
     if (st >= 0) st = dev_alloc(&h->scal, 1);
@@ -286,9 +284,7 @@ extern "C" int dpcg_destroy(dpcg_handle_t h) {
     if (it != extras().end()) {
         HandleExtras &ex = it->second;
         if (ex.cap_stream) (void)hipStreamDestroy(ex.cap_stream);
-        if (ex.ev[0]) (void)hipEventDestroy(ex.ev[0]);
-        if (ex.ev[1]) (void)hipEventDestroy(ex.ev[1]);
-        if (ex.flag_host) (void)hipHostFree(ex.flag_host);
+        if (ex.prog_host) (void)hipHostFree(ex.prog_host);
         extras().erase(it);
     }
     delete h;
@@ -680,7 +676,7 @@ extern "C" int dpcg_spmv_dot_bench(dpcg_handle_t h, const double *x, double *y, 
     DPCG_HIP(hipMemsetAsync(h->part_rr, 0, kMaxGrid * sizeof(double), s));
     const double one = 1.0;
     DPCG_HIP(hipMemcpyAsync(h->part_rr, &one, sizeof(double), hipMemcpyHostToDevice, s));
-    launch_finalize_init(h->scal, h->part_rr, h->part_rr, h->part_rr, 1, 0.0, 0.0, h->hist, 0, s);
+    launch_finalize_init(h->scal, h->part_rr, h->part_rr, h->part_rr, 1, 0.0, 0.0, h->hist, 0, nullptr, s);
     IterCtl ctl{h->scal};
     hipEvent_t e0, e1;
     DPCG_HIP(hipEventCreate(&e0));
@@ -704,7 +700,7 @@ extern "C" int dpcg_spmv_dot_bench(dpcg_handle_t h, const double *x, double *y, 
 // ------------------------------------------------------------------------------------------------
 static int default_chunk() {
     const char *e = getenv("DPCG_CHUNK");
-    int c = e ? atoi(e) : 16;
+    int c = e ? atoi(e) : 8;
     return c < 1 ? 1 : (c > 256 ? 256 : c);
 }
 
@@ -760,42 +756,54 @@ static int ensure_graph(dpcg_system *h, int flags, int chunk) {
 }
 
 namespace {
+// Host side of one solve.  The GPU never waits for the host: iterations are enqueued ahead of the
+// progress word that K3 posts to pinned memory, as a replayed hipGraph of `chunk` updates (launch-bound
+// small systems) or update by update (large systems, where one update outlasts its three launches).
 struct Solve {
     dpcg_system *h = nullptr;
     hipStream_t s = nullptr;
-    int max_iter = 0, flags = 0, chunk = 16;
+    int max_iter = 0, flags = 0, chunk = 8;
     const double *x_true = nullptr;
     bool use_graph = true;
-    int enq = 0;          // iterations enqueued
-    int inflight = 0;     // chunks enqueued whose flag has not been read yet
-    int head = 0, tail = 0;
-    bool converged = false, complete = false;
+    int enq = 0;             // updates enqueued so far
+    bool complete = false;
+    double t_iter = 0.0;     // measured seconds per update (0 = not known yet)
     std::chrono::steady_clock::time_point t0;
 
-    int enqueue_chunk() {
-        HandleExtras &ex = extras()[h];
-        const int c = std::min(chunk, max_iter - enq);
-        if (use_graph && c == chunk) {
+    volatile unsigned long long *prog() { return extras()[h].prog_host; }
+
+    int enqueue_some() {
+        const bool graph_now = use_graph && (max_iter - enq) >= chunk && !(t_iter > 25e-6);
+        if (graph_now) {
             DPCG_HIP(hipGraphLaunch(h->graph_exec, s));
+            enq += chunk;
         } else {
-            for (int i = 0; i < c; ++i) DPCG_TRY(enqueue_iteration(h, flags, x_true, s));
+            DPCG_TRY(enqueue_iteration(h, flags, x_true, s));
+            enq += 1;
         }
-        enq += c;
-        DPCG_HIP(hipMemcpyAsync(&ex.flag_host[tail], &h->scal->done, sizeof(int), hipMemcpyDeviceToHost, s));
-        DPCG_HIP(hipEventRecord(ex.ev[tail], s));
-        tail ^= 1;
-        ++inflight;
         return DPCG_OK;
     }
 
-    // Enqueue the start of the solve (cg.py:58-67) and the first chunk; the timer starts after the
-    // initial residual/preconditioner work has drained, as the reference's does (cg.py:69).
+    // how many updates to keep enqueued beyond the last one the GPU reported
+    int run_ahead() const {
+        if (t_iter <= 0.0) return 2 * chunk;
+        const double cover = 150e-6;  // host launch + scheduling latency to hide
+        int it = (int)(cover / t_iter) + 2;
+        if (t_iter > 25e-6) return it < 3 ? 3 : it;
+        const int chunks = (it + chunk - 1) / chunk + 1;
+        return chunks * chunk;
+    }
+
+    // Enqueue the start of the solve (cg.py:58-67); the timer starts after the initial residual /
+    // preconditioner work has drained, as the reference's does (cg.py:69).
     int start(const double *b, const double *x0, double rtol_sq, double atol_sq) {
         const int64_t n = h->A.n;
         const bool f32 = (flags & DPCG_SPMV_F32) != 0;
+        HandleExtras &ex = extras()[h];
         DPCG_TRY(ensure_work(h, max_iter, f32, x_true != nullptr));
         use_graph = !(flags & DPCG_NO_GRAPH) && !x_true && max_iter >= chunk;
         if (use_graph) DPCG_TRY(ensure_graph(h, flags, chunk));
+        *ex.prog_host = 0;
         if (x0) {
             DPCG_HIP(hipMemcpyAsync(h->x, x0, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
             launch_spmv(h->A, h->planA, h->x, h->q, nullptr, nullptr, s);
@@ -809,7 +817,7 @@ struct Solve {
         launch_init_state(n, h->scal, b, h->r, z, h->p, f32 ? h->p32 : nullptr, h->part_bb, h->part_rz, h->part_rr,
                           (flags & DPCG_INIT_CHECK_R) ? 1 : 0, h->vec_grid, s);
         launch_finalize_init(h->scal, h->part_bb, h->part_rz, h->part_rr, h->vec_grid, rtol_sq, atol_sq, h->hist,
-                             h->hist_cap, s);
+                             h->hist_cap, ex.prog_dev, s);
         if (x_true) {                                                                // cg.py:27-29
             launch_anorm_err(n, h->scal, h->x, x_true, h->e, h->vec_grid, s);
             launch_spmv(h->A, h->planA, h->e, h->t, h->part_bb, nullptr, s);
@@ -818,30 +826,40 @@ struct Solve {
         DPCG_CHECK_LAUNCH();
         DPCG_HIP(hipStreamSynchronize(s));
         t0 = std::chrono::steady_clock::now();                                       // cg.py:69
-        if (max_iter > 0) DPCG_TRY(enqueue_chunk());
-        else complete = true;
+        if (max_iter == 0) complete = true;
         return DPCG_OK;
     }
 
-    // Advance: keep two chunks in flight, read the oldest chunk's `done` flag.  Returns a negative
-    // status on error, 1 when the solve is complete, 0 when it has to be called again.
+    // Advance.  Returns a negative status on error, 1 when the solve is complete, 0 otherwise.
     int step(bool blocking) {
         if (complete) return 1;
-        HandleExtras &ex = extras()[h];
-        if (enq < max_iter && inflight < 2) DPCG_TRY(enqueue_chunk());
-        if (blocking) {
-            DPCG_HIP(hipEventSynchronize(ex.ev[head]));
-        } else {
-            hipError_t q = hipEventQuery(ex.ev[head]);
-            if (q == hipErrorNotReady) return 0;
+        for (;;) {
+            const unsigned long long v = *prog();
+            const int k = (int)(v >> 1);
+            if ((v & 1ull) || k >= max_iter) {
+                complete = true;
+                return 1;
+            }
+            if (k >= 4) t_iter = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / k;
+            const int target = run_ahead();
+            while (enq < max_iter && enq - k < target) DPCG_TRY(enqueue_some());
+            if (!blocking) return 0;
+            // wait for the progress word to move; watch the stream so that a fault cannot hang the host
+            bool moved = false;
+            for (int spin = 0; spin < 4000 && !moved; ++spin) {
+                moved = *prog() != v;
+                if (!moved) __builtin_ia32_pause();
+            }
+            if (moved) continue;
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipErrorNotReady) continue;
             DPCG_HIP(q);
+            // stream drained: every enqueued update has run, the word is final for them
+            if (*prog() == v && enq > k) {
+                set_error("PCG driver: enqueued updates finished without reporting progress");
+                return DPCG_ERR_STATE;
+            }
         }
-        const int flag = ex.flag_host[head];
-        head ^= 1;
-        --inflight;
-        if (flag) converged = true;
-        if (flag || (enq >= max_iter && inflight == 0)) complete = true;
-        return complete ? 1 : 0;
     }
 
     int finish(double *x, int *iters, double *final_res, double *seconds, double *res_history, double *err_history) {

@@ -54,6 +54,9 @@ struct Scalars {
     int done;          // 1 once the stopping test held (kernels become no-ops)
     int status;        // dpcg_status of the solve
     int pad;
+    // Host-visible progress word (pinned, mapped): (k << 1) | done, written by the one thread that runs
+    // the stopping test.  The host steers its run-ahead from it without copies, events or syncs.
+    unsigned long long *progress;
 };
 
 struct Levels {
@@ -130,7 +133,8 @@ void launch_init_state(int64_t n, Scalars *scal, const double *b, const double *
                        float *p32, double *part_bb, double *part_rz, double *part_rr, int init_check_r, int grid,
                        hipStream_t s);
 void launch_finalize_init(Scalars *scal, const double *part_bb, const double *part_rz, const double *part_t,
-                          int n_part, double rtol_sq, double atol_sq, double *hist, int hist_cap, hipStream_t s);
+                          int n_part, double rtol_sq, double atol_sq, double *hist, int hist_cap,
+                          unsigned long long *progress, hipStream_t s);
 void launch_residual(int64_t n, const double *b, const double *ax, double *r, int grid, hipStream_t s);
 void launch_scale(int64_t n, const double *dinv, const double *r, double *z, int grid, hipStream_t s);
 void launch_extract_dinv(const CsrDev &A, double *dinv, int *bad_flag, hipStream_t s);

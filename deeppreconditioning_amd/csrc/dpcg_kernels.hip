@@ -72,8 +72,13 @@ __device__ __forceinline__ void record_and_test(Scalars *sc, double rr, double r
     sc->res = res;
     sc->k = k;
     sc->rz_next = rz_next;
-    if (conv) { sc->done = 1; sc->status = DPCG_OK; }
-    else if (!(res == res)) { sc->done = 1; sc->status = DPCG_BREAKDOWN; }
+    int done = 0;
+    if (conv) { done = 1; sc->status = DPCG_OK; }
+    else if (!(res == res)) { done = 1; sc->status = DPCG_BREAKDOWN; }
+    if (done) sc->done = 1;
+    if (sc->progress)   // one posted 8-byte write to pinned host memory per update
+        __hip_atomic_store(sc->progress, ((unsigned long long)k << 1) | (unsigned long long)done, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -502,7 +507,8 @@ void launch_init_state(int64_t n, Scalars *scal, const double *b, const double *
 __global__ __launch_bounds__(kBlock) void k_finalize_init(Scalars *sc, const double *__restrict__ part_bb,
                                                           const double *__restrict__ part_rz,
                                                           const double *__restrict__ part_t, int n_part,
-                                                          double rtol_sq, double atol_sq, double *hist, int hist_cap) {
+                                                          double rtol_sq, double atol_sq, double *hist, int hist_cap,
+                                                          unsigned long long *progress) {
     __shared__ double sh[4];
     const double bb = reduce_partials(part_bb, n_part, sh);
     const double rz = reduce_partials(part_rz, n_part, sh);
@@ -516,14 +522,16 @@ __global__ __launch_bounds__(kBlock) void k_finalize_init(Scalars *sc, const dou
         sc->done = 0;
         sc->status = DPCG_MAX_ITER;
         sc->pad = 0;
+        sc->progress = progress;
         record_and_test(sc, tt, rz, hist, hist_cap, 0);                 // cg.py:66-67 and the first cg.py:71
     }
 }
 
 void launch_finalize_init(Scalars *scal, const double *part_bb, const double *part_rz, const double *part_t,
-                          int n_part, double rtol_sq, double atol_sq, double *hist, int hist_cap, hipStream_t s) {
+                          int n_part, double rtol_sq, double atol_sq, double *hist, int hist_cap,
+                          unsigned long long *progress, hipStream_t s) {
     hipLaunchKernelGGL(k_finalize_init, dim3(1), dim3(kBlock), 0, s, scal, part_bb, part_rz, part_t, n_part, rtol_sq,
-                       atol_sq, hist, hist_cap);
+                       atol_sq, hist, hist_cap, progress);
 }
 
 // r = b - A x0 (cg.py:60), ax = A x0 computed by the SpMV before.
