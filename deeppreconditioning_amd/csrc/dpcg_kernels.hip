@@ -44,6 +44,15 @@ __device__ __forceinline__ int virtual_block() {
 }
 
 
+// [lo,hi) = floor(v*total/G), floor((v+1)*total/G) for G = gridDim.x <= 2048, without 64-bit division:
+// total = q*G + r  =>  floor(v*total/G) = v*q + floor(v*r/G), and v*r < G*G fits 32 bits.
+__device__ __forceinline__ void split_range(int total, int v, int &lo, int &hi) {
+    const unsigned G = gridDim.x;
+    const unsigned q = (unsigned)total / G, r = (unsigned)total - q * G;
+    lo = (int)((unsigned)v * q + ((unsigned)v * r) / G);
+    hi = (int)((unsigned)(v + 1) * q + ((unsigned)(v + 1) * r) / G);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Control flow of the iteration without a host round trip (cg.py:70-71):
 //   * the stopping test for iterate k+1 is evaluated by workgroup 0 of K3 (the last kernel of
@@ -101,24 +110,25 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t
     __shared__ double prod[kStreamCap];
     __shared__ double sh[4];
     const int t = threadIdx.x;
-    const int G = gridDim.x;
+    // contiguous ranges of row-blocks per (virtual) workgroup, the remainder spread evenly over the
+    // grid (so every XCD slab carries the same load); 32-bit scalar arithmetic only
     const int v = virtual_block();
-    const int rb_lo = (int)(((int64_t)v * nrb) / G);
-    const int rb_hi = (int)(((int64_t)(v + 1) * nrb) / G);
+    int rb_lo, rb_hi;
+    split_range(nrb, v, rb_lo, rb_hi);
     int c[U];
     VT a[U];
-    int cnt = 0, rs = 0, re = 0;
+    int cnt = 0, base = 0, rs = 0, re = 0;   // rs/re stay absolute until the row-sum phase (no early wait)
     // matrix stream of one row-block -> registers (all 2U loads of a thread in flight at once)
     auto fetch = [&](int rb) {
         const int64_t r0 = (int64_t)rb * kStreamRows;
         const int64_t row = r0 + t;
         const int64_t rlast = (r0 + kStreamRows < n) ? r0 + kStreamRows : n;
-        const int base = rowptr[r0];
+        base = rowptr[r0];
         cnt = rowptr[rlast] - base;
         rs = re = 0;
         if (row < n) {
-            rs = rowptr[row] - base;
-            re = rowptr[row + 1] - base;
+            rs = rowptr[row];
+            re = rowptr[row + 1];
         }
         const int32_t *__restrict__ cb = col + base;
         const VT *__restrict__ vb = val + base;
@@ -139,6 +149,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t
     double acc = 0.0;
     for (int rb = rb_lo; rb < rb_hi; ++rb) {
         const int64_t row = (int64_t)rb * kStreamRows + t;
+        const int ks = rs - base, ke = re - base;
         double xv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) xv[u] = (double)x[c[u]];
@@ -150,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t
         __syncthreads();
         if (row < n) {
             double s = 0.0;
-            for (int k = rs; k < re; ++k) s += prod[k];
+            for (int k = ks; k < ke; ++k) s += prod[k];
             y[row] = (YT)s;
             if (DOT) acc += s * xdot[row];
         }
@@ -181,13 +192,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv_vector(int64_t n, const int32_t
     constexpr int RPB = kBlock / TPR;  // rows per workgroup step
     const int t = threadIdx.x;
     const int lane = t % TPR;
-    const int G = gridDim.x;
     const int v = virtual_block();
-    const int64_t ngroups = (n + RPB - 1) / RPB;
-    const int64_t g_lo = (v * ngroups) / G, g_hi = ((v + 1) * ngroups) / G;
+    const int ngroups = (int)((n + RPB - 1) / RPB);
+    int g_lo, g_hi;
+    split_range(ngroups, v, g_lo, g_hi);
     double acc = 0.0;
-    for (int64_t g = g_lo; g < g_hi; ++g) {
-        const int64_t row = g * RPB + t / TPR;
+    for (int g = g_lo; g < g_hi; ++g) {
+        const int64_t row = (int64_t)g * RPB + t / TPR;
         double s = 0.0;
         if (row < n) {
             const int rs = rowptr[row], re = rowptr[row + 1];

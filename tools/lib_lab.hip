@@ -29,7 +29,7 @@ int main(int argc, char **argv) {
         for (double *p : {x, y, z, r, q, dinv}) CK(hipMemcpy(p, hx.data(), N * 8, hipMemcpyHostToDevice));
         CK(hipMemset(part_rr, 0, 4096 * 8)); CK(hipMemset(part_rz, 0, 4096 * 8)); CK(hipMemset(part_pq, 0, 4096 * 8));
         const double one = 1.0; CK(hipMemcpy(part_rr, &one, 8, hipMemcpyHostToDevice)); CK(hipMemcpy(part_pq, &one, 8, hipMemcpyHostToDevice));
-        launch_finalize_init(sc, part_rr, part_rr, part_rr, 1, 0.0, 0.0, hist, 0, s);
+        launch_finalize_init(sc, part_rr, part_rr, part_rr, 1, 0.0, 0.0, hist, 0, nullptr, s);
         CK(hipStreamSynchronize(s));
         const double b_spmv = (double)nnz * 12 + (N + 1) * 4.0 + 16.0 * N;
         printf("== poisson%dd n=%ld N=%ld: SpMV %.1f MB, K2 %.1f MB, K3 %.1f MB\n", cs.dim, (long)cs.n, (long)N, b_spmv / 1e6, 40.0 * N / 1e6, 40.0 * N / 1e6);
@@ -60,7 +60,7 @@ int main(int argc, char **argv) {
                 times[vi].push_back(ms * 1e3f / reps);
                 CK(hipMemsetAsync(part_rr, 0, 4096 * 8, s)); CK(hipMemcpyAsync(part_rr, &one, 8, hipMemcpyHostToDevice, s));
                 CK(hipMemsetAsync(part_pq, 0, 4096 * 8, s)); CK(hipMemcpyAsync(part_pq, &one, 8, hipMemcpyHostToDevice, s));
-                launch_finalize_init(sc, part_rr, part_rr, part_rr, 1, 0.0, 0.0, hist, 0, s);
+                launch_finalize_init(sc, part_rr, part_rr, part_rr, 1, 0.0, 0.0, hist, 0, nullptr, s);
                 for (double *p : {x, y, z, r, q}) CK(hipMemcpyAsync(p, dinv, N * 8, hipMemcpyDeviceToDevice, s));
             }
         {   // the iteration as the PCG loop runs it: K1 -> K2 -> K3, back to back
@@ -70,7 +70,7 @@ int main(int argc, char **argv) {
                 std::vector<float> tt;
                 for (int rd = 0; rd < rounds; ++rd) {
                     CK(hipMemsetAsync(part_rr, 0, 4096 * 8, s)); CK(hipMemcpyAsync(part_rr, &one, 8, hipMemcpyHostToDevice, s));
-                    launch_finalize_init(sc, part_rr, part_rr, part_rr, 1, 0.0, 0.0, hist, 0, s);
+                    launch_finalize_init(sc, part_rr, part_rr, part_rr, 1, 0.0, 0.0, hist, 0, nullptr, s);
                     for (double *p : {x, y, z, r, q}) CK(hipMemcpyAsync(p, dinv, N * 8, hipMemcpyDeviceToDevice, s));
                     CK(hipEventRecord(e0, s));
                     for (int i = 0; i < 40; ++i) {
