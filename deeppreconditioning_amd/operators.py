@@ -35,6 +35,15 @@ def csr_arrays(A):
     Accepts scipy sparse, numpy 2-D, torch sparse-CSR / sparse-COO / dense tensors (the reference's
     callers pass DENSE fp64 tensors, test.py:61-68, train.py:93-95).  Columns ascend within a row.
     """
+    if isinstance(A, tuple) and len(A) == 3:  # ready-made CSR parts (rowptr, col, val)
+        rp, ci, v = A
+        if isinstance(v, torch.Tensor):
+            if v.is_cuda:
+                return ("device", rp.to(torch.int32).contiguous(), ci.to(torch.int32).contiguous(),
+                        v.to(torch.float64).contiguous(), rp.numel() - 1)
+            rp, ci, v = rp.numpy(), ci.numpy(), v.numpy()
+        return ("host", np.ascontiguousarray(rp, dtype=np.int32), np.ascontiguousarray(ci, dtype=np.int32),
+                np.ascontiguousarray(v, dtype=np.float64), len(rp) - 1)
     if _is_scipy(A):
         M = A.tocsr()
         if not M.has_canonical_format:

@@ -44,3 +44,34 @@ def rhs(n: int, seed: int = 0, device=None) -> torch.Tensor:
     """b ~ U(-1,1) as generate_data.py:106, seeded like the golden fixtures (`default_rng(seed)`)."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     return torch.from_numpy(np.random.default_rng(seed).uniform(-1.0, 1.0, n)).to(device)
+
+
+def unstructured_like_csr(dim: int, n: int, seed: int = 0):
+    """Host-side stand-in for an OpenFOAM pressure matrix: D (P A P^T) D of the
+    Poisson matrix with a seeded random symmetric permutation P and D = diag(U(0.5, 2)).  Returns a scipy CSR
+    matrix with sorted int32 indices (setup-time plumbing; the solve never touches the host copy)."""
+    import scipy.sparse as sp
+    rows, nnz = poisson_sizes(dim, n)
+    idx = np.arange(rows, dtype=np.int64)
+    offs = [1, n] if dim == 2 else [1, n, n * n]
+    coords = [idx % n, (idx // n) % n] if dim == 2 else [idx % n, (idx // n) % n, idx // (n * n)]
+    r_list, c_list, v_list = [idx], [idx], [np.full(rows, 2.0 * dim)]
+    for off, co in zip(offs, coords):
+        ok = co < n - 1
+        r_list += [idx[ok], idx[ok] + off]
+        c_list += [idx[ok] + off, idx[ok]]
+        v_list += [np.full(int(ok.sum()), -1.0)] * 2
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(rows)
+    d = rng.uniform(0.5, 2.0, rows)
+    inv = np.empty(rows, dtype=np.int64)
+    inv[perm] = idx                                   # B[i, j] = A[perm[i], perm[j]]
+    r = inv[np.concatenate(r_list)]
+    c = inv[np.concatenate(c_list)]
+    v = np.concatenate(v_list) * d[r] * d[c]
+    B = sp.csr_matrix((v, (r, c)), shape=(rows, rows))
+    B.sort_indices()
+    B.indices = B.indices.astype(np.int32)
+    B.indptr = B.indptr.astype(np.int32)
+    assert B.nnz == nnz
+    return B

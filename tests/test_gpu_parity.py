@@ -375,3 +375,33 @@ def test_full_size_256cubed_properties(D):
     assert h[0] == pytest.approx(1.0 / 36.0, rel=1e-12) and np.all(np.isfinite(h))
     r_true = b - S @ res.x
     assert D.dot(r_true, r_true) / D.dot(b, b) == pytest.approx(h[-1], rel=1e-6)
+
+
+# ---- f1: the CNN emits L on the GPU, the HIP solver consumes it without densifying --------------------------
+def test_preconditioner_net_output_drives_the_solver(D):
+    from deeppreconditioning_amd import model as Mdl
+    torch.manual_seed(69)
+    A = O.poisson2d(24)
+    n = A.shape[0]
+    net = Mdl.PreconditionerNet([1, 16, 32, 64, 32, 16, 1]).cuda()
+    inp, sizes = Mdl.tril_batch_from_csr([A], device="cuda")
+    with torch.no_grad():
+        out = net(inp)
+    rp, ci, v = Mdl.lower_factor_csr(out, 0, sizes[0])           # L as CSR, still in HBM
+    S = D.CsrSystem.from_any(A)
+    b = _dev(O.rhs(n, 0))
+    S.set_preconditioner(D.LLtMultiply((rp, ci, v)))              # z = L (L^T r), test.py:102-105 without the dense product
+    r_mul = S.solve(b)
+    # the reference's way: M = L L^T formed densely, handed over as CSR (test.py:103-105)
+    Ld = out.dense()[0, 0, :n, :n].double()
+    M = (Ld @ Ld.T).cpu().to_sparse_csr()
+    S.set_preconditioner(M)
+    r_csr = S.solve(b)
+    Lsp = sp.csr_matrix((v.cpu().numpy(), ci.cpu().numpy(), rp.cpu().numpy()), shape=(n, n))
+    _, it, hist, _ = CO.pcg(A, O.rhs(n, 0), "llt_multiply", L=Lsp)
+    m = min(len(hist), len(r_mul.res_history), 30)
+    np.testing.assert_allclose(r_mul.res_history[:m], hist[:m], rtol=1e-9)
+    np.testing.assert_allclose(r_csr.res_history[:m], hist[:m], rtol=1e-6)   # fp32 dense product in between
+    assert abs(r_mul.iterations - it) <= 0.05 * it + 2
+    z = S.precond_apply(b).cpu().numpy()
+    np.testing.assert_allclose(z, Lsp @ (Lsp.T @ O.rhs(n, 0)), rtol=1e-6, atol=1e-9)
