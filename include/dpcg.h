@@ -138,6 +138,13 @@ int dpcg_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void *va
 int dpcg_batched_coo_spmv(int64_t nnz, const int32_t *indices, const float *features, int batch, int64_t dof,
                           const float *vectors, float *out, int transpose, dpcg_stream_t stream);
 
+/* ---- coordinate triplets -> CSR on the device (the reference's file formats are COO: scipy npz,
+ * generate_data.py:109; OpenFOAM `i,j,value` dump, pEqn.H:98-108; StAn npz, data_set.py:186-188) ------------- */
+/* rows/cols int32[nnz], vals fp64[nnz]: device.  Stable sort by (row,col), duplicates summed in storage order.
+ * rowptr int32[n+1], col_out int32[nnz], val_out fp64[nnz]: device, capacity nnz; *nnz_out = unique entries. */
+int dpcg_coo_to_csr(int64_t n, int64_t nnz, const int32_t *rows, const int32_t *cols, const double *vals,
+                    int32_t *rowptr, int32_t *col_out, double *val_out, int64_t *nnz_out, dpcg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
