@@ -1,0 +1,135 @@
+"""`BenchmarkSuite` harness compatible with `uibk/deep_preconditioning/test.py:31-198`.
+
+Same technique names, same result columns (`kappas,densities,iterations,setups,durations,totals,successes`,
+test.py:180) and the same `table.csv` / `totals.csv` layout, but the systems stay sparse and on the GPU: no dense
+N x N reconstruction (test.py:61-68), no dense `L @ L.T` (test.py:103-104).  Unlike the reference, result lists are
+instance attributes and nothing is created at import time (test.py:50-59 does both at class definition).
+"""
+
+from __future__ import annotations
+
+import pathlib
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from .cg import preconditioned_conjugate_gradient
+from .io import coo_to_csr_device
+from .model import lower_factor_csr, tril_batch_from_csr
+from .operators import IC0, CsrSystem, Identity, Jacobi, LLtMultiply
+
+PARAMETERS = ["kappas", "densities", "iterations", "setups", "durations", "totals", "successes"]  # test.py:180
+
+
+class ListDataSet:
+    """In-memory stand-in for the reference's data sets: item = (systems_tril, solutions, right_hand_sides,
+    original_sizes) with batch size 1, as `SludgePatternDataSet.__getitem__` returns (data_set.py:73-130)."""
+
+    def __init__(self, matrices, right_hand_sides, solutions=None, dof_max: int | None = None, device="cuda"):
+        self.matrices, self.rhs = list(matrices), list(right_hand_sides)
+        self.solutions = list(solutions) if solutions is not None else [np.ones(m.shape[0]) for m in self.matrices]
+        self.dof_max = max(m.shape[0] for m in self.matrices) if dof_max is None else dof_max
+        self.device = device
+
+    def __len__(self) -> int:
+        return len(self.matrices)
+
+    def __getitem__(self, index: int):
+        m = self.matrices[index]
+        tril, sizes = tril_batch_from_csr([m], dof_max=self.dof_max, device=self.device)
+        pad = self.dof_max - m.shape[0]
+        to = lambda v: torch.from_numpy(np.pad(np.asarray(v, dtype=np.float64), (0, pad), constant_values=1)).float().unsqueeze(0).to(self.device)  # noqa: E731
+        return tril, to(self.solutions[index]), to(self.rhs[index]), sizes
+
+
+@dataclass
+class BenchmarkSuite:
+    data_set: object
+    model: torch.nn.Module | None
+    techniques: tuple[str, ...] = ("vanilla", "jacobi", "incomplete_cholesky", "incomplete_cholesky_solve", "learned")
+    results_directory: pathlib.Path = pathlib.Path("./assets/results/")
+    kappa_max_n: int = 3000   # cond(M A) needs dense N x N matrices (test.py:111-113): only for small systems
+    results: dict = field(default_factory=dict)
+
+    def __post_init__(self):
+        for p in PARAMETERS:
+            setattr(self, p, {name: [] for name in self.techniques})
+
+    # -- test.py:61-68 without densifying: mirror the strict lower triangle, compress on the device ----------
+    def _reconstruct_system(self, system_tril, original_size: int) -> CsrSystem:
+        assert system_tril.batch_size == 1, "Set batch size to one for testing"
+        idx = system_tril.indices.long()
+        keep = (idx[:, 1] < original_size) & (idx[:, 2] < original_size)
+        r, c, v = idx[keep, 1], idx[keep, 2], system_tril.features[keep, 0].to(torch.float64)
+        off = r != c
+        rows = torch.cat((r, c[off]))
+        cols = torch.cat((c, r[off]))
+        vals = torch.cat((v, v[off]))
+        rowptr, col, val = coo_to_csr_device(rows, cols, vals, original_size, device=v.device)
+        return CsrSystem(rowptr, col, val, original_size)
+
+    def _construct(self, name: str, system: CsrSystem, system_tril, original_size: int):
+        if name == "vanilla":                       # test.py:70-72
+            return Identity()
+        if name == "jacobi":                        # test.py:74-79
+            return Jacobi()
+        if name == "incomplete_cholesky":           # test.py:81-88: the factor is MULTIPLIED, as the reference does
+            return IC0("multiply")
+        if name == "incomplete_cholesky_solve":     # the same factor applied by triangular solves
+            return IC0("solve")
+        if name == "learned":                       # test.py:100-105
+            with torch.no_grad():
+                out = self.model(system_tril)
+            return LLtMultiply(lower_factor_csr(out, 0, original_size))
+        raise ValueError(name)
+
+    def _density_and_kappa(self, system: CsrSystem, n: int):
+        """100 * nnz(M) / n^2 (test.py:107-109) and cond(M A) (test.py:111-113) -- reporting only, small n only."""
+        if n > self.kappa_max_n:
+            return float("nan"), float("nan")
+        eye = torch.eye(n, dtype=torch.float64, device=system.device)
+        M = torch.stack([system.precond_apply(eye[:, j]) for j in range(n)], dim=1)
+        A = torch.stack([system @ eye[:, j] for j in range(n)], dim=1)
+        density = 100.0 * float((M != 0).sum()) / (n * n)
+        return density, float(torch.linalg.cond(M @ A))
+
+    def run(self) -> None:
+        """test.py:119-155."""
+        for index in range(len(self.data_set)):
+            system_tril, _, right_hand_side, original_size = self.data_set[index]
+            n = int(original_size[0])
+            system = self._reconstruct_system(system_tril, n)
+            rhs = right_hand_side[0, :n].squeeze().to(torch.float64)
+            for name in self.techniques:
+                torch.cuda.synchronize()
+                start = time.perf_counter()
+                system.set_preconditioner(self._construct(name, system, system_tril, n))
+                torch.cuda.synchronize()
+                setup = time.perf_counter() - start if name != "vanilla" else 0.0      # test.py:135
+                duration, iteration, info = preconditioned_conjugate_gradient(system, rhs, system._precond)
+                density, kappa = self._density_and_kappa(system, n)
+                self.kappas[name].append(kappa)
+                self.densities[name].append(density)
+                self.iterations[name].append(iteration)
+                self.setups[name].append(setup)
+                self.durations[name].append(duration)
+                self.totals[name].append(setup + duration)
+                self.successes[name].append(100 * (1 if info == 0 else 0))             # test.py:149
+            system.close()
+
+    def dump_csv(self) -> None:
+        """test.py:175-198: `table.csv` (means per technique) and `totals.csv` (per-sample totals)."""
+        self.results_directory.mkdir(parents=True, exist_ok=True)
+        with (self.results_directory / "table.csv").open(mode="w") as f:
+            f.write("technique," + ",".join(PARAMETERS) + "\n")
+            for technique in self.techniques:
+                line = technique
+                for parameter in PARAMETERS:
+                    line += "," + str(np.mean(getattr(self, parameter)[technique], dtype=float))
+                f.write(line + "\n")
+        with (self.results_directory / "totals.csv").open(mode="w") as f:
+            f.write(",".join(self.techniques) + "\n")
+            for index in range(len(self.totals[self.techniques[0]])):
+                f.write(",".join(str(self.totals[t][index]) for t in self.techniques) + "\n")

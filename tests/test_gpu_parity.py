@@ -405,3 +405,29 @@ def test_preconditioner_net_output_drives_the_solver(D):
     assert abs(r_mul.iterations - it) <= 0.05 * it + 2
     z = S.precond_apply(b).cpu().numpy()
     np.testing.assert_allclose(z, Lsp @ (Lsp.T @ O.rhs(n, 0)), rtol=1e-6, atol=1e-9)
+
+
+# ---- f2: BenchmarkSuite-compatible harness ------------------------------------------------------------
+def test_benchmark_suite_harness(D, tmp_path):
+    import csv
+    from deeppreconditioning_amd import model as Mdl
+    from deeppreconditioning_amd.benchmark_suite import PARAMETERS, BenchmarkSuite, ListDataSet
+    torch.manual_seed(69)                                              # test.py:205
+    mats = [O.poisson2d(16), O.unstructured_like(O.poisson2d(14), 2), O.poisson3d(6)]
+    rhs = [O.rhs(m.shape[0], i) for i, m in enumerate(mats)]
+    data = ListDataSet(mats, rhs)                                      # padded to dof_max with identity rows
+    net = Mdl.PreconditionerNet([1, 8, 8, 8, 1]).cuda()
+    suite = BenchmarkSuite(data, net, results_directory=tmp_path)
+    suite.run()
+    suite.dump_csv()
+    for i, (m, b) in enumerate(zip(mats, rhs)):
+        assert suite.iterations["vanilla"][i] == CO.pcg(m, b, "none")[1]
+        assert suite.iterations["jacobi"][i] == CO.pcg(m, b, "jacobi", dinv=O.jacobi_dinv(m))[1]
+        assert suite.iterations["incomplete_cholesky_solve"][i] == CO.pcg(m, b, "llt_solve", L=CO.ic0(m))[1]
+        assert suite.densities["jacobi"][i] == pytest.approx(100.0 / m.shape[0])
+        assert np.isfinite(suite.kappas["learned"][i]) and suite.setups["vanilla"][i] == 0.0
+    rows = list(csv.reader((tmp_path / "table.csv").open()))
+    assert rows[0] == ["technique"] + PARAMETERS                      # test.py:180-183
+    assert [r[0] for r in rows[1:]] == list(suite.techniques)
+    totals = list(csv.reader((tmp_path / "totals.csv").open()))
+    assert totals[0] == list(suite.techniques) and len(totals) == 1 + len(mats)
