@@ -157,27 +157,67 @@ def main() -> None:
 
 
 def extra_workloads(D, poisson, torch) -> dict:
-    """Secondary numbers (not the headline): 2-D 1M-DoF fixed-work solve and the HBM-bound 256^3 system."""
+    """Secondary numbers (not the headline), one entry per BASELINE.json config that fits one GPU."""
     out = {}
+
+    def solve_twice(system, b, **kw):
+        system.solve(b, want_history=False, **kw)
+        return system.solve(b, want_history=False, **kw)
+
+    # config 2: 256^2 2-D system, CNN-like factor applied as L (L^T r), IC(0) by triangular solves, Jacobi
+    s = poisson.poisson_system(2, 256)
+    b = poisson.rhs(s.n, 0)
+    c2 = {}
+    for name, pc in (("jacobi", D.Jacobi()), ("ic0_solve", D.IC0("solve"))):
+        s.set_preconditioner(pc)
+        r = solve_twice(s, b)
+        c2[name] = {"iterations": r.iterations, "ms": round(r.seconds * 1e3, 3), "iterations_per_s": round(r.iterations / r.seconds, 1)}
+    c2["levels"] = s.info()["levels_lower"]
+    out["c2_poisson2d_256"] = c2
+    del s
+    # 1M-DoF 2-D system: hits max_iter = 1024 like the reference (fixed-work throughput)
     s2 = poisson.poisson_system(2, 1024)
     s2.set_preconditioner(D.Jacobi())
     b2 = poisson.rhs(s2.n, 0)
-    s2.solve(b2, want_history=False)
-    r = s2.solve(b2, want_history=False)
+    r = solve_twice(s2, b2)
     ms = s2.spmv_dot_bench(200)
     out["poisson2d_1024_jacobi"] = {"iterations": r.iterations, "iterations_per_s": round(r.iterations / r.seconds, 1),
                                     "spmv_gbs": round(spmv_bytes(s2.n, s2.nnz) / (ms * 1e-3) / 1e9, 1)}
     del s2
-    s3 = poisson.poisson_system(3, 256)
-    s3.set_preconditioner(D.Jacobi())
+    # config 3: ~1M-DoF unstructured stand-in (random symmetric permutation + SPD scaling of the 3-D matrix)
+    A = poisson.unstructured_like_csr(3, 100, 0)
+    s3 = D.CsrSystem.from_any(A)
     b3 = poisson.rhs(s3.n, 0)
-    s3.solve(b3, max_iter=16, want_history=False)
-    r = s3.solve(b3, max_iter=64, want_history=False)
-    ms = s3.spmv_dot_bench(50)
-    gbs = spmv_bytes(s3.n, s3.nnz) / (ms * 1e-3) / 1e9
-    out["poisson3d_256_jacobi"] = {"iterations": r.iterations, "iterations_per_s": round(r.iterations / r.seconds, 2),
-                                   "spmv_gbs": round(gbs, 1), "spmv_frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
-                                   "note": "1.74 GB per SpMV: beyond the 256 MiB Infinity Cache, HBM-bound"}
+    c3 = {}
+    for name, pc in (("jacobi", D.Jacobi()), ("ic0_solve", D.IC0("solve"))):
+        s3.set_preconditioner(pc)
+        r = solve_twice(s3, b3)
+        c3[name] = {"iterations": r.iterations, "ms": round(r.seconds * 1e3, 3), "iterations_per_s": round(r.iterations / r.seconds, 1)}
+    c3["levels"] = s3.info()["levels_lower"]
+    ms = s3.spmv_dot_bench(100)
+    c3["spmv_gbs"] = round(spmv_bytes(s3.n, s3.nnz) / (ms * 1e-3) / 1e9, 1)
+    out["c3_unstructured3d_100"] = c3
+    del s3, A
+    # config 5: mixed fp32 SpMV / fp64 everything else on the headline system
+    s5 = poisson.poisson_system(3, 100)
+    s5.set_preconditioner(D.Jacobi())
+    b5 = poisson.rhs(s5.n, 0)
+    r64 = solve_twice(s5, b5)
+    r32 = solve_twice(s5, b5, flags=D._lib.SPMV_F32)
+    out["c5_mixed_precision_poisson3d_100"] = {"iterations_fp64": r64.iterations, "iterations_mixed": r32.iterations,
+                                               "final_res_fp64": r64.final_res, "final_res_mixed": r32.final_res,
+                                               "iterations_per_s_mixed": round(r32.iterations / r32.seconds, 1)}
+    del s5
+    # config 4 (one GPU's share): 256^3 systems, 1.74 GB per SpMV, beyond the Infinity Cache -> HBM-bound
+    s4 = poisson.poisson_system(3, 256)
+    s4.set_preconditioner(D.Jacobi())
+    b4 = poisson.rhs(s4.n, 0)
+    s4.solve(b4, max_iter=16, want_history=False)
+    r = s4.solve(b4, max_iter=64, want_history=False)
+    ms = s4.spmv_dot_bench(50)
+    gbs = spmv_bytes(s4.n, s4.nnz) / (ms * 1e-3) / 1e9
+    out["c4_poisson3d_256_jacobi"] = {"iterations": r.iterations, "iterations_per_s": round(r.iterations / r.seconds, 2),
+                                      "spmv_gbs": round(gbs, 1), "spmv_frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
     return out
 
 
