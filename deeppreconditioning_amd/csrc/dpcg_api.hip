@@ -105,6 +105,9 @@ static void free_csr(CsrDev &c) {
 static void free_levels(Levels &l) {
     dev_free(l.rows);
     dev_free(l.level_ptr_dev);
+    dev_free(l.lo_rowptr);
+    dev_free(l.lo_col);
+    dev_free(l.lo_val);
     l = Levels();
 }
 
@@ -420,10 +423,34 @@ static void build_levels_host(int64_t n, const std::vector<int32_t> &rp, const s
 }
 
 static int upload_levels(Levels &lv, const std::vector<int32_t> &rows_sorted, const std::vector<int32_t> &level_ptr,
-                         hipStream_t s) {
+                         const int32_t *rp, const int32_t *ci, const double *v, hipStream_t s) {
     constexpr int kMergeMax = 2048;  // levels this narrow are walked by one 1024-thread workgroup
     lv.level_ptr = level_ptr;
     lv.n_levels = (int)level_ptr.size() - 1;
+    // level-ordered copy of the factor (row j = original row rows_sorted[j])
+    const int64_t n = (int64_t)rows_sorted.size();
+    std::vector<int32_t> lo_rp((size_t)n + 1, 0);
+    for (int64_t j = 0; j < n; ++j) lo_rp[j + 1] = lo_rp[j] + (rp[rows_sorted[j] + 1] - rp[rows_sorted[j]]);
+    const int64_t nnz = lo_rp[n];
+    std::vector<int32_t> lo_ci((size_t)nnz);
+    std::vector<double> lo_v((size_t)nnz);
+    for (int64_t j = 0; j < n; ++j) {
+        const int32_t src = rp[rows_sorted[j]], len = rp[rows_sorted[j] + 1] - src, dst = lo_rp[j];
+        std::copy(ci + src, ci + src + len, lo_ci.begin() + dst);
+        std::copy(v + src, v + src + len, lo_v.begin() + dst);
+    }
+    lv.stream_ok = true;
+    for (int l = 0; l < lv.n_levels && lv.stream_ok; ++l)
+        for (int32_t jb = level_ptr[l]; jb < level_ptr[l + 1]; jb += kStreamRows) {
+            const int32_t je = std::min<int32_t>(jb + kStreamRows, level_ptr[l + 1]);
+            if (lo_rp[je] - lo_rp[jb] > kStreamCap) { lv.stream_ok = false; break; }
+        }
+    DPCG_TRY(dev_alloc(&lv.lo_rowptr, n + 1));
+    DPCG_TRY(dev_alloc(&lv.lo_col, nnz));
+    DPCG_TRY(dev_alloc(&lv.lo_val, nnz));
+    DPCG_HIP(hipMemcpyAsync(lv.lo_rowptr, lo_rp.data(), lo_rp.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    DPCG_HIP(hipMemcpyAsync(lv.lo_col, lo_ci.data(), lo_ci.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    DPCG_HIP(hipMemcpyAsync(lv.lo_val, lo_v.data(), lo_v.size() * sizeof(double), hipMemcpyHostToDevice, s));
     DPCG_TRY(dev_alloc(&lv.rows, (int64_t)rows_sorted.size()));
     DPCG_TRY(dev_alloc(&lv.level_ptr_dev, (int64_t)level_ptr.size()));
     DPCG_HIP(hipMemcpyAsync(lv.rows, rows_sorted.data(), rows_sorted.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
@@ -482,9 +509,9 @@ static int set_llt_from_host(dpcg_system *h, int mode, int64_t nnz, const int32_
     if (mode == DPCG_PRECOND_LLT_SOLVE) {
         std::vector<int32_t> rp(rp_in, rp_in + n + 1), ci(ci_in, ci_in + nnz), rows, lptr;
         build_levels_host(n, rp, ci, false, rows, lptr);
-        DPCG_TRY(upload_levels(h->lvlL, rows, lptr, s));
+        DPCG_TRY(upload_levels(h->lvlL, rows, lptr, rp_in, ci_in, v_in, s));
         build_levels_host(n, trp, tci, true, rows, lptr);
-        DPCG_TRY(upload_levels(h->lvlU, rows, lptr, s));
+        DPCG_TRY(upload_levels(h->lvlU, rows, lptr, trp.data(), tci.data(), tv.data(), s));
     }
     h->precond = mode;
     return DPCG_OK;

@@ -66,6 +66,12 @@ struct Levels {
     struct Segment { int lo, hi; bool merged; };  // [lo,hi) levels; merged = one workgroup walks them
     std::vector<Segment> segments;
     int32_t *level_ptr_dev = nullptr;      // device copy of level_ptr
+    // the factor once more, rows stored in level order (row j of this copy = original row rows[j]): the
+    // rows of a level are contiguous, so a level streams its val/col segment coalesced like the SpMV does
+    int32_t *lo_rowptr = nullptr;
+    int32_t *lo_col = nullptr;
+    double *lo_val = nullptr;
+    bool stream_ok = false;                // every 256-row block of every wide level fits the LDS product buffer
 };
 
 }  // namespace dpcg

@@ -650,31 +650,70 @@ void launch_dot_final(const double *part, int n_part, double *out_dev, hipStream
 // order, then divides by the diagonal -- bit-identical to sequential substitution.
 // Lower factor: diagonal LAST in the row.  Upper (L^T as CSR): diagonal FIRST.
 // ------------------------------------------------------------------------------------------------
+// One wide level, CSR-stream style: a workgroup takes 256 consecutive rows of the level-ordered copy, streams
+// their contiguous val/col segment coalesced, parks v*out[col] in LDS and lets thread j subtract the products
+// of row j in column order.  The diagonal's slot is skipped (its "product" is never read).
 template <bool UPPER>
-__device__ __forceinline__ double trsv_row(int i, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
-                                           const double *__restrict__ v, const double *__restrict__ rhs,
-                                           const double *out) {
-    const int s = rp[i], e = rp[i + 1];
-    double acc = rhs[i];
-    if (UPPER) {
-        for (int k = s + 1; k < e; ++k) acc -= v[k] * out[ci[k]];
-        return acc / v[s];
-    } else {
-        for (int k = s; k < e - 1; ++k) acc -= v[k] * out[ci[k]];
-        return acc / v[e - 1];
+__global__ __launch_bounds__(kBlock) void k_sptrsv_level_stream(const int32_t *__restrict__ rows, int j0, int count,
+                                                                const int32_t *__restrict__ lo_rp,
+                                                                const int32_t *__restrict__ lo_ci,
+                                                                const double *__restrict__ lo_v,
+                                                                const double *__restrict__ rhs, double *out) {
+    constexpr int U = kStreamCap / kBlock;
+    __shared__ double prod[kStreamCap];
+    const int t = threadIdx.x;
+    const int jb = j0 + blockIdx.x * kBlock;
+    const int jend = (jb + kBlock < j0 + count) ? jb + kBlock : j0 + count;
+    const int j = jb + t;
+    const int base = lo_rp[jb];
+    const int cnt = lo_rp[jend] - base;
+    int rs = 0, re = 0, i = 0;
+    double bi = 0.0;
+    if (j < jend) {
+        rs = lo_rp[j] - base;
+        re = lo_rp[j + 1] - base;
+        i = rows[j];
+        bi = rhs[i];
+    }
+    const int last = cnt > 0 ? cnt - 1 : 0;
+    int c[U];
+    double a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int k = t + u * kBlock;
+        const int kk = k < cnt ? k : last;
+        c[u] = lo_ci[base + kk];
+        a[u] = lo_v[base + kk];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int k = t + u * kBlock;
+        if (k < cnt) prod[k] = a[u] * out[c[u]];
+    }
+    __syncthreads();
+    if (j < jend) {
+        double acc = bi;
+        const int ks = UPPER ? rs + 1 : rs, ke = UPPER ? re : re - 1;
+        for (int k = ks; k < ke; ++k) acc -= prod[k];
+        out[i] = acc / lo_v[base + (UPPER ? rs : re - 1)];
     }
 }
 
+// One level, one thread per row (rows too long for the LDS product buffer).
 template <bool UPPER>
-__global__ __launch_bounds__(kBlock) void k_sptrsv_level(const int32_t *__restrict__ rows, int count,
-                                                         const int32_t *__restrict__ rp,
-                                                         const int32_t *__restrict__ ci,
-                                                         const double *__restrict__ v,
+__global__ __launch_bounds__(kBlock) void k_sptrsv_level(const int32_t *__restrict__ rows, int j0, int count,
+                                                         const int32_t *__restrict__ lo_rp,
+                                                         const int32_t *__restrict__ lo_ci,
+                                                         const double *__restrict__ lo_v,
                                                          const double *__restrict__ rhs, double *out) {
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= count) return;
-    const int i = rows[idx];
-    out[i] = trsv_row<UPPER>(i, rp, ci, v, rhs, out);
+    const int j = j0 + idx, i = rows[j];
+    const int s = lo_rp[j], e = lo_rp[j + 1];
+    double acc = rhs[i];
+    const int ks = UPPER ? s + 1 : s, ke = UPPER ? e : e - 1;
+    for (int k = ks; k < ke; ++k) acc -= lo_v[k] * out[lo_ci[k]];
+    out[i] = acc / lo_v[UPPER ? s : e - 1];
 }
 
 // A run of narrow levels walked by ONE workgroup of 1024 threads with a barrier between levels
@@ -684,20 +723,20 @@ constexpr int kMergedBlock = 1024;
 template <bool UPPER>
 __global__ __launch_bounds__(kMergedBlock) void k_sptrsv_merged(const int32_t *__restrict__ rows,
                                                                 const int32_t *__restrict__ level_ptr, int lvl_lo,
-                                                                int lvl_hi, const int32_t *__restrict__ rp,
-                                                                const int32_t *__restrict__ ci,
-                                                                const double *__restrict__ v,
+                                                                int lvl_hi, const int32_t *__restrict__ lo_rp,
+                                                                const int32_t *__restrict__ lo_ci,
+                                                                const double *__restrict__ lo_v,
                                                                 const double *__restrict__ rhs, double *out) {
     for (int lvl = lvl_lo; lvl < lvl_hi; ++lvl) {
         const int lo = level_ptr[lvl], hi = level_ptr[lvl + 1];
-        for (int idx = lo + (int)threadIdx.x; idx < hi; idx += kMergedBlock) {
-            const int i = rows[idx];
-            const int s = rp[i], e = rp[i + 1];
+        for (int j = lo + (int)threadIdx.x; j < hi; j += kMergedBlock) {
+            const int i = rows[j];
+            const int s = lo_rp[j], e = lo_rp[j + 1];
             double acc = rhs[i];
             const int ks = UPPER ? s + 1 : s, ke = UPPER ? e : e - 1;
             for (int k = ks; k < ke; ++k)
-                acc -= v[k] * __hip_atomic_load(out + ci[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double res = acc / v[UPPER ? s : e - 1];
+                acc -= lo_v[k] * __hip_atomic_load(out + lo_ci[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double res = acc / lo_v[UPPER ? s : e - 1];
             __hip_atomic_store(out + i, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();  // includes s_waitcnt vmcnt(0): this level's stores have reached L2
@@ -705,25 +744,30 @@ __global__ __launch_bounds__(kMergedBlock) void k_sptrsv_merged(const int32_t *_
 }
 
 void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s) {
+    (void)T;  // the level-ordered copy in `lv` carries the factor
     for (const auto &seg : lv.segments) {
         if (seg.merged) {
             if (upper)
                 hipLaunchKernelGGL(k_sptrsv_merged<true>, dim3(1), dim3(kMergedBlock), 0, s, lv.rows, lv.level_ptr_dev,
-                                   seg.lo, seg.hi, T.rowptr, T.col, T.val, rhs, out);
+                                   seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_val, rhs, out);
             else
                 hipLaunchKernelGGL(k_sptrsv_merged<false>, dim3(1), dim3(kMergedBlock), 0, s, lv.rows,
-                                   lv.level_ptr_dev, seg.lo, seg.hi, T.rowptr, T.col, T.val, rhs, out);
-        } else {
-            for (int l = seg.lo; l < seg.hi; ++l) {
-                const int lo = lv.level_ptr[l], cnt = lv.level_ptr[l + 1] - lo;
-                const int grid = (cnt + kBlock - 1) / kBlock;
-                if (upper)
-                    hipLaunchKernelGGL(k_sptrsv_level<true>, dim3(grid), dim3(kBlock), 0, s, lv.rows + lo, cnt,
-                                       T.rowptr, T.col, T.val, rhs, out);
-                else
-                    hipLaunchKernelGGL(k_sptrsv_level<false>, dim3(grid), dim3(kBlock), 0, s, lv.rows + lo, cnt,
-                                       T.rowptr, T.col, T.val, rhs, out);
+                                   lv.level_ptr_dev, seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_val, rhs, out);
+            continue;
+        }
+        for (int l = seg.lo; l < seg.hi; ++l) {
+            const int j0 = lv.level_ptr[l], cnt = lv.level_ptr[l + 1] - j0;
+            const int grid = (cnt + kBlock - 1) / kBlock;
+#define DPCG_TRSV(KERNEL, UP) \
+    hipLaunchKernelGGL(KERNEL<UP>, dim3(grid), dim3(kBlock), 0, s, lv.rows, j0, cnt, lv.lo_rowptr, lv.lo_col, lv.lo_val, rhs, out)
+            if (lv.stream_ok) {
+                if (upper) DPCG_TRSV(k_sptrsv_level_stream, true);
+                else DPCG_TRSV(k_sptrsv_level_stream, false);
+            } else {
+                if (upper) DPCG_TRSV(k_sptrsv_level, true);
+                else DPCG_TRSV(k_sptrsv_level, false);
             }
+#undef DPCG_TRSV
         }
     }
 }
