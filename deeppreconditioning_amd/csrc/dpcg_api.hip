@@ -536,9 +536,9 @@ extern "C" int dpcg_set_precond_llt(dpcg_handle_t h, int mode, int64_t nnz, cons
     return set_llt_from_host(h, mode, nnz, rp.data(), ci.data(), v.data(), s);
 }
 
-// IC(0) of A on its lower-triangular pattern (setup; stands in for ilupp.ichol0, test.py:83).
-// Row-oriented, sums over ascending columns, one product at a time (no FMA) -- the order the
-// oracle uses, so the factors agree bit for bit.
+// IC(0) of A on its lower-triangular pattern (stands in for ilupp.ichol0, test.py:83).  The symbolic part
+// (tril pattern, level sets) is integer work on the host; the numeric factorisation runs on the device,
+// one launch per level (k_ic0_level), in the operation order of the CPU restatement (bit-identical factor).
 extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t stream) {
     if (!h) return invalid("NULL handle");
     if (mode != DPCG_PRECOND_LLT_MULTIPLY && mode != DPCG_PRECOND_LLT_SOLVE) return invalid("bad LLT mode");
@@ -566,35 +566,40 @@ extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t str
             return DPCG_ERR_PIVOT;
         }
     }
-    for (int64_t i = 0; i < n; ++i) {
-        const int32_t s_i = lrp[i], e_i = lrp[i + 1];
-        for (int32_t k = s_i; k < e_i; ++k) {
-            const int32_t j = lci[k];
-            const int32_t s_j = lrp[j], e_j = lrp[j + 1];
-            double acc = lv[k];
-            int32_t a = s_i, b = s_j;
-            while (a < k && b < e_j - 1) {
-                const int32_t ca = lci[a], cb = lci[b];
-                if (ca == cb) {
-                    const double prod = lv[a] * lv[b];
-                    acc = acc - prod;
-                    ++a;
-                    ++b;
-                } else if (ca < cb) ++a;
-                else ++b;
-            }
-            if (j < i) lv[k] = acc / lv[e_j - 1];
-            else {
-                if (!(acc > 0.0)) {
-                    set_error("IC(0): non-positive pivot at row " + std::to_string(i));
-                    return DPCG_ERR_PIVOT;
-                }
-                lv[k] = std::sqrt((double)acc);
-            }
-        }
+    const int64_t lnnz = (int64_t)lci.size();
+    std::vector<int32_t> rows, lptr;
+    build_levels_host(n, lrp, lci, false, rows, lptr);
+    int32_t *d_rp = nullptr, *d_ci = nullptr, *d_rows = nullptr;
+    double *d_lv = nullptr;
+    int *d_bad = nullptr, h_bad = 0;
+    int st = DPCG_OK;
+    auto cleanup = [&]() { dev_free(d_rp); dev_free(d_ci); dev_free(d_rows); dev_free(d_lv); dev_free(d_bad); };
+    if ((st = dev_alloc(&d_rp, n + 1)) < 0 || (st = dev_alloc(&d_ci, lnnz)) < 0 || (st = dev_alloc(&d_rows, n)) < 0 ||
+        (st = dev_alloc(&d_lv, lnnz)) < 0 || (st = dev_alloc(&d_bad, 1)) < 0) {
+        cleanup();
+        return st;
+    }
+    hipError_t e = hipMemcpyAsync(d_rp, lrp.data(), lrp.size() * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ci, lci.data(), lci.size() * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_lv, lv.data(), lv.size() * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int), s);
+    if (e == hipSuccess) {
+        const int nl = (int)lptr.size() - 1;
+        for (int l = 0; l < nl; ++l) launch_ic0_level(d_rows, lptr[l], lptr[l + 1] - lptr[l], d_rp, d_ci, d_lv, d_bad, s);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(lv.data(), d_lv, lv.size() * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    cleanup();
+    DPCG_HIP(e);
+    if (h_bad) {
+        set_error("IC(0): non-positive pivot at row " + std::to_string(h_bad - 1));
+        return DPCG_ERR_PIVOT;
     }
     free_precond(h);
-    return set_llt_from_host(h, mode, (int64_t)lci.size(), lrp.data(), lci.data(), lv.data(), s);
+    return set_llt_from_host(h, mode, lnnz, lrp.data(), lci.data(), lv.data(), s);
 }
 
 extern "C" int dpcg_get_factor(dpcg_handle_t h, int32_t *rowptr, int32_t *col, double *val) {

@@ -773,6 +773,48 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
 }
 
 // ------------------------------------------------------------------------------------------------
+// IC(0) numeric factorisation, level by level (stands in for ilupp.ichol0, test.py:83).
+// Row i of L needs the finished rows j < i of its own pattern -- the dependency DAG of the lower
+// solve, so the same level sets apply.  One thread owns a row; every sum runs over ascending columns,
+// one product and one subtraction at a time (two roundings): the order of the CPU restatement, so the
+// factor is bit-identical to it.  lv holds tril(A) on entry and L on exit (diagonal last in a row).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_ic0_level(const int32_t *__restrict__ rows, int j0, int count,
+                                                      const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                      double *lv, int *bad) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= count) return;
+    const int i = rows[j0 + idx];
+    const int s_i = rp[i], e_i = rp[i + 1];
+    for (int k = s_i; k < e_i; ++k) {
+        const int j = ci[k];
+        const int s_j = rp[j], e_j = rp[j + 1];
+        double acc = lv[k];
+        int a = s_i, b = s_j;
+        while (a < k && b < e_j - 1) {
+            const int ca = ci[a], cb = ci[b];
+            if (ca == cb) {
+                acc -= lv[a] * lv[b];
+                ++a;
+                ++b;
+            } else if (ca < cb) ++a;
+            else ++b;
+        }
+        if (j < i) lv[k] = acc / lv[e_j - 1];
+        else {
+            if (!(acc > 0.0)) atomicExch(bad, i + 1);
+            lv[k] = sqrt(acc);
+        }
+    }
+}
+
+void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_ic0_level, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, rows, j0, count, rp, ci, lv,
+                       bad);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Setup helpers
 // ------------------------------------------------------------------------------------------------
 // max over row-blocks of the non-zeros in `rows_per_block` consecutive rows (stream-kernel test).
