@@ -171,8 +171,15 @@ static int upload_csr(CsrDev &out, int64_t n, int64_t nnz, const int32_t *rowptr
 
 // Choose the SpMV kernel: CSR-stream when every 256-row block's non-zeros fit the LDS product
 // buffer (stencils, OpenFOAM-like rows), otherwise CSR-vector with lanes-per-row ~ mean row length.
-static int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s) {
+static void free_plan(SpmvPlan &plan) {
+    dev_free(plan.tile_chunks);
+    dev_free(plan.tile_nchunks);
+    dev_free(plan.tile_lidx);
     plan = SpmvPlan();
+}
+
+static int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s, bool allow_tile = false) {
+    free_plan(plan);
     int *d_max = nullptr;
     DPCG_TRY(dev_alloc(&d_max, 1));
     DPCG_HIP(hipMemsetAsync(d_max, 0, sizeof(int), s));
@@ -189,7 +196,36 @@ static int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s) {
         // 8 workgroups per CU while the matrix stream stays in the 256 MiB Infinity Cache, 6 per CU once
         // it comes from HBM (measured: tools/lib_lab, 100^3: 20.7 vs 21.7 us; 256^3: 457 vs 424 us)
         const double stream_bytes = 12.0 * (double)A.nnz + 20.0 * (double)A.n;
-        const int cap = stream_bytes < 192e6 ? kMaxSpmvGrid : (kMaxSpmvGrid * 3) / 4;
+        int cap = stream_bytes < 192e6 ? kMaxSpmvGrid : (kMaxSpmvGrid * 3) / 4;
+        // x-tile variant: stage the block's chunks of x in LDS when the columns of every block form a few runs.
+        // Measured (tools/lib_lab): it wins once the matrix streams from HBM (256^3: 389 vs 419 us, 2 B less
+        // per non-zero and no x re-gather) and loses slightly while everything sits in the Infinity Cache
+        // (100^3: 22.0 vs 21.0 us: the per-CU L2->L1 rate is the limit there and staging moves more bytes).
+        const bool force_stream = force && strcmp(force, "stream") == 0;
+        const bool force_tile = force && strcmp(force, "tile") == 0;
+        if (allow_tile && !force_stream && A.nnz > 0 && (force_tile || stream_bytes >= 192e6)) {
+            int *d_flags = nullptr, h_flags[2] = {1, 0};
+            DPCG_TRY(dev_alloc(&plan.tile_chunks, (int64_t)plan.nrb * kTileMaxChunks));
+            DPCG_TRY(dev_alloc(&plan.tile_nchunks, plan.nrb));
+            DPCG_TRY(dev_alloc(&plan.tile_lidx, A.nnz));
+            DPCG_TRY(dev_alloc(&d_flags, 2));
+            DPCG_HIP(hipMemcpyAsync(d_flags, h_flags, sizeof(h_flags), hipMemcpyHostToDevice, s));
+            launch_tile_plan(A, plan.nrb, plan.tile_chunks, plan.tile_nchunks, plan.tile_lidx, d_flags, s);
+            DPCG_HIP(hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+            DPCG_HIP(hipStreamSynchronize(s));
+            dev_free(d_flags);
+            if (h_flags[0] == 1 && h_flags[1] > 0) {
+                plan.kernel = SPMV_TILE;
+                plan.tile_max_chunks = h_flags[1];
+                const size_t lds = (size_t)(h_flags[1] * kTileChunk + kStreamCap + 4) * sizeof(double);
+                const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+                cap = std::min(cap, per_cu * 256);
+            } else {
+                dev_free(plan.tile_chunks);
+                dev_free(plan.tile_nchunks);
+                dev_free(plan.tile_lidx);
+            }
+        }
         int g = plan.nrb < cap ? plan.nrb : cap;
         if (g > 8) g -= g % 8;
         plan.grid = g < 1 ? 1 : g;
@@ -255,7 +291,7 @@ extern "C" int dpcg_create(dpcg_handle_t *out, int64_t n, int64_t nnz, const int
     hipStream_t s = (hipStream_t)stream;
     dpcg_system *h = new dpcg_system();
     int st = upload_csr(h->A, n, nnz, rowptr, col, val, val_dtype, memspace, copy, s);
-    if (st >= 0) st = make_plan(h->A, h->planA, s);
+    if (st >= 0) st = make_plan(h->A, h->planA, s, true);
     HandleExtras ex;
     if (st >= 0 && hipStreamCreateWithFlags(&ex.cap_stream, hipStreamNonBlocking) != hipSuccess) st = DPCG_ERR_HIP;
     if (st >= 0 && hipHostMalloc((void **)&ex.prog_host, 64, hipHostMallocMapped) != hipSuccess) st = DPCG_ERR_HIP;
@@ -278,6 +314,7 @@ extern "C" int dpcg_destroy(dpcg_handle_t h) {
     (void)hipDeviceSynchronize();
     free_precond(h);
     free_csr(h->A);
+    free_plan(h->planA);
     dev_free(h->x); dev_free(h->r); dev_free(h->z); dev_free(h->p); dev_free(h->q); dev_free(h->t); dev_free(h->e);
     dev_free(h->p32);
     dev_free(h->part_pq); dev_free(h->part_rz); dev_free(h->part_rr); dev_free(h->part_bb);

@@ -22,7 +22,10 @@ constexpr int kMaxSpmvGrid = 2048;    // SpMV: 8 workgroups per CU = 32 waves pe
 constexpr int kStreamCap = 2048;      // products staged in LDS per 256-row block (16 KiB)
 constexpr int kStreamRows = 256;      // rows per row-block of the CSR-stream SpMV
 
-enum SpmvKernel { SPMV_STREAM = 0, SPMV_VECTOR = 1 };
+enum SpmvKernel { SPMV_STREAM = 0, SPMV_VECTOR = 1, SPMV_TILE = 2 };
+constexpr int kTileChunk = 64;        // x is staged in LDS in chunks of 64 doubles (512 B, one wave-load)
+constexpr int kTileMaxChunks = 40;    // at most 40 chunks (20 KiB) per 256-row block
+constexpr int kTileTableMax = 4096;   // chunk-id span a block may cover (262,144 columns)
 
 struct CsrDev {
     int64_t n = 0, nnz = 0;
@@ -38,6 +41,12 @@ struct SpmvPlan {
     int grid = 1;
     int nrb = 0;          // row-blocks of kStreamRows rows (stream kernel)
     int tpr = 4;          // threads per row (vector kernel)
+    // x-tile plan (SPMV_TILE): per row-block the list of 64-double chunks of x its columns touch, and per
+    // non-zero a 16-bit index into the LDS tile those chunks are staged in.  Owned by the plan.
+    int32_t *tile_chunks = nullptr;    // [nrb][kTileMaxChunks]
+    int32_t *tile_nchunks = nullptr;   // [nrb]
+    uint16_t *tile_lidx = nullptr;     // [nnz]
+    int tile_max_chunks = 0;           // largest chunk count of any block (sizes the dynamic LDS)
 };
 
 // Device-resident scalar state of one solve.  Only block 0 of a kernel writes it; everybody else
@@ -154,6 +163,9 @@ void launch_dot_final(const double *part, int n_part, double *out_dev, hipStream
 
 void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s);
 
+// Builds the x-tile plan of A on the device; *ok = 1 when every block is tileable, *max_chunks its widest tile.
+void launch_tile_plan(const CsrDev &A, int nrb, int32_t *chunks, int32_t *nchunks, uint16_t *lidx, int *ok_and_max_dev,
+                      hipStream_t s);
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
                       hipStream_t s);
 void launch_block_nnz_max(const CsrDev &A, int rows_per_block, int *out_max_dev, hipStream_t s);

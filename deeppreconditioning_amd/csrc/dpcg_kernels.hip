@@ -5,6 +5,8 @@
 // kernel boundaries / bytes per PCG iteration as possible.  Compiled with -ffp-contract=off so
 // that a*b+c is two roundings, as in the CPU reference path (scipy/ATen CSR row sums, unfused
 // torch mul+add at cg.py:79-83); the in-order row sums below then reproduce the oracle bit for bit.
+#include <type_traits>
+
 #include "dpcg_internal.h"
 
 namespace dpcg {
@@ -217,6 +219,163 @@ __global__ __launch_bounds__(kBlock) void k_spmv_vector(int64_t n, const int32_t
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// CSR SpMV with the x-vector tile staged in LDS (banded / stencil-like matrices).
+//
+// The columns of a 256-row block fall into a few runs (5-point: i-n, i, i+n; 7-point: five runs).  At setup
+// (k_tile_plan) each block gets the list of 64-double chunks of x it touches and every non-zero a 16-bit
+// index into the LDS image of those chunks.  At run time the block stages its chunks with coalesced 512-B
+// wave loads, streams val[] (8 B) and the local index (2 B instead of the 4-B column) coalesced, takes
+// x from LDS instead of gathering it through L1/L2, and finishes like the CSR-stream kernel: products
+// parked in LDS, thread i adds row i in column order -- the same bits as the gather kernels and the CPU.
+// Per non-zero the matrix stream shrinks from 12 to 10 bytes and the global gathers disappear.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_tile_plan(int64_t n, const int32_t *__restrict__ rowptr,
+                                                      const int32_t *__restrict__ col, int nrb,
+                                                      int32_t *__restrict__ chunks, int32_t *__restrict__ nchunks,
+                                                      uint16_t *__restrict__ lidx, int *ok_and_max) {
+    __shared__ int s_min, s_max, s_nc;
+    __shared__ uint16_t slot_of[kTileTableMax];
+    const int t = threadIdx.x;
+    for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        const int64_t r0 = (int64_t)rb * kStreamRows;
+        const int64_t rlast = (r0 + kStreamRows < n) ? r0 + kStreamRows : n;
+        const int base = rowptr[r0], cnt = rowptr[rlast] - base;
+        if (t == 0) { s_min = 0x7fffffff; s_max = -1; s_nc = 0; }
+        __syncthreads();
+        int lo = 0x7fffffff, hi = -1;
+        for (int k = t; k < cnt; k += kBlock) {
+            const int c = col[base + k];
+            lo = c < lo ? c : lo;
+            hi = c > hi ? c : hi;
+        }
+        if (hi >= 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+        __syncthreads();
+        if (cnt == 0) {
+            if (t == 0) nchunks[rb] = 0;
+            __syncthreads();
+            continue;
+        }
+        const int cb = s_min / kTileChunk;
+        const int span = s_max / kTileChunk - cb + 1;
+        if (span > kTileTableMax) {                       // columns too spread out: not tileable
+            if (t == 0) { nchunks[rb] = 0; atomicExch(&ok_and_max[0], 0); }
+            __syncthreads();
+            continue;
+        }
+        for (int e = t; e < span; e += kBlock) slot_of[e] = 0;
+        __syncthreads();
+        for (int k = t; k < cnt; k += kBlock) slot_of[col[base + k] / kTileChunk - cb] = 1;
+        __syncthreads();
+        if (t == 0) {                                     // ascending chunk ids -> slots 1..nc
+            int nc = 0;
+            for (int e = 0; e < span; ++e)
+                if (slot_of[e]) {
+                    if (nc < kTileMaxChunks) chunks[(int64_t)rb * kTileMaxChunks + nc] = cb + e;
+                    slot_of[e] = (uint16_t)(++nc);
+                }
+            s_nc = nc;
+            nchunks[rb] = nc <= kTileMaxChunks ? nc : 0;
+            if (nc > kTileMaxChunks) atomicExch(&ok_and_max[0], 0);
+            else atomicMax(&ok_and_max[1], nc);
+        }
+        __syncthreads();
+        if (s_nc <= kTileMaxChunks)
+            for (int k = t; k < cnt; k += kBlock) {
+                const int c = col[base + k];
+                lidx[base + k] = (uint16_t)((slot_of[c / kTileChunk - cb] - 1) * kTileChunk + c % kTileChunk);
+            }
+        __syncthreads();
+    }
+}
+
+void launch_tile_plan(const CsrDev &A, int nrb, int32_t *chunks, int32_t *nchunks, uint16_t *lidx, int *ok_and_max_dev,
+                      hipStream_t s) {
+    const int grid = nrb < 2048 ? nrb : 2048;
+    hipLaunchKernelGGL(k_tile_plan, dim3(grid), dim3(kBlock), 0, s, A.n, A.rowptr, A.col, nrb, chunks, nchunks, lidx,
+                       ok_and_max_dev);
+}
+
+template <bool CTL, bool DOT>
+__global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *__restrict__ rowptr,
+                                                      const double *__restrict__ val,
+                                                      const uint16_t *__restrict__ lidx,
+                                                      const int32_t *__restrict__ chunks,
+                                                      const int32_t *__restrict__ nchunks,
+                                                      const double *__restrict__ x, double *__restrict__ y, int nrb,
+                                                      int tile_doubles, double *__restrict__ part_pq, IterCtlDev ctl) {
+    constexpr int U = kStreamCap / kBlock;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *xs = smem;                      // the staged x chunks of this block
+    double *prod = smem + tile_doubles;     // products, kStreamCap doubles
+    double *sh = prod + kStreamCap;         // 4 doubles for the block reduction
+    const int t = threadIdx.x;
+    const int v = virtual_block();
+    int rb_lo, rb_hi;
+    split_range(nrb, v, rb_lo, rb_hi);
+    double a[U];
+    int li[U];
+    int cnt = 0, base = 0, rs = 0, re = 0;
+    auto fetch = [&](int rb) {
+        const int64_t r0 = (int64_t)rb * kStreamRows;
+        const int64_t row = r0 + t;
+        const int64_t rlast = (r0 + kStreamRows < n) ? r0 + kStreamRows : n;
+        base = rowptr[r0];
+        cnt = rowptr[rlast] - base;
+        rs = re = 0;
+        if (row < n) {
+            rs = rowptr[row];
+            re = rowptr[row + 1];
+        }
+        const int last = cnt > 0 ? cnt - 1 : 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = t + u * kBlock;
+            const int kk = k < cnt ? k : last;
+            a[u] = cnt > 0 ? val[base + kk] : 0.0;
+            li[u] = cnt > 0 ? (int)lidx[base + kk] : 0;
+        }
+    };
+    if (rb_lo < rb_hi) fetch(rb_lo);
+    if (CTL) {
+        if (!iteration_head(ctl)) return;
+    }
+    double acc = 0.0;
+    for (int rb = rb_lo; rb < rb_hi; ++rb) {
+        const int64_t row = (int64_t)rb * kStreamRows + t;
+        const int ks = rs - base, ke = re - base;
+        // stage this block's chunks of x: wave w takes chunks w, w+4, ... (64 lanes x 8 B = one 512-B run);
+        // the chunk id is wave-uniform, so it travels through the scalar unit
+        const int nc = nchunks[rb];
+        const int32_t *__restrict__ cl = chunks + (int64_t)rb * kTileMaxChunks;
+        const int lane = t & 63;
+        for (int ci = t >> 6; ci < nc; ci += kBlock / 64) {
+            const int chunk = __builtin_amdgcn_readfirstlane(cl[ci]);
+            const int64_t gi = (int64_t)chunk * kTileChunk + lane;
+            xs[ci * kTileChunk + lane] = gi < n ? x[gi] : 0.0;
+        }
+        __syncthreads();                    // tile complete (and every thread is past the previous row sums)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = t + u * kBlock;
+            if (k < cnt) prod[k] = a[u] * xs[li[u]];
+        }
+        __syncthreads();
+        if (rb + 1 < rb_hi) fetch(rb + 1);   // next block's stream is in flight during the row sums and staging
+        if (row < n) {
+            double s = 0.0;
+            for (int k = ks; k < ke; ++k) s += prod[k];
+            y[row] = s;
+            if (DOT) acc += s * x[row];
+        }
+    }
+    if (DOT) {
+        const double tot = block_sum(acc, sh);
+        if (t == 0) part_pq[blockIdx.x] = tot;
+    }
+}
+
 static IterCtlDev to_dev(const IterCtl *c) {
     IterCtlDev d{nullptr};
     if (c) d = IterCtlDev{c->scal};
@@ -241,7 +400,19 @@ static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, 
         else if (dot) DPCG_LAUNCH_VECTOR(TPRV, false, true);  \
         else DPCG_LAUNCH_VECTOR(TPRV, false, false);          \
         break
-    if (plan.kernel == SPMV_STREAM) {
+    if (plan.kernel == SPMV_TILE && std::is_same<VT, double>::value && std::is_same<XT, double>::value &&
+        std::is_same<YT, double>::value) {
+        const int tile_doubles = plan.tile_max_chunks * kTileChunk;
+        const size_t lds = (size_t)(tile_doubles + kStreamCap + 4) * sizeof(double);
+#define DPCG_LAUNCH_TILE(CTLV, DOTV)                                                                                 \
+    hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr,              \
+                       (const double *)val, plan.tile_lidx, plan.tile_chunks, plan.tile_nchunks, (const double *)x,  \
+                       (double *)y, plan.nrb, tile_doubles, part_pq, d)
+        if (c && dot) DPCG_LAUNCH_TILE(true, true);
+        else if (dot) DPCG_LAUNCH_TILE(false, true);
+        else DPCG_LAUNCH_TILE(false, false);
+#undef DPCG_LAUNCH_TILE
+    } else if (plan.kernel == SPMV_STREAM || plan.kernel == SPMV_TILE) {
         if (c && dot) DPCG_LAUNCH_STREAM(true, true);
         else if (dot) DPCG_LAUNCH_STREAM(false, true);
         else DPCG_LAUNCH_STREAM(false, false);

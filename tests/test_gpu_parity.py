@@ -46,13 +46,36 @@ def _check_chaotic(golden, name, res, stable):
 # ---- SpMV --------------------------------------------------------------------------------------
 @pytest.mark.parametrize("make", [lambda: O.poisson2d(64), lambda: O.poisson2d(37), lambda: O.poisson3d(20),
                                   lambda: O.unstructured_like(O.poisson3d(12), 3), lambda: O.poisson2d(1)])
-def test_spmv_stream_bit_exact(D, make):
+def test_spmv_stream_bit_exact(D, make, monkeypatch):
     A = make()
-    S = D.CsrSystem.from_any(A)
-    assert S.info()["spmv_kernel"] == "stream"
     x = O.rhs(A.shape[0], 5)
-    y = (S @ _dev(x)).cpu().numpy()
-    assert np.array_equal(y, CO.spmv(A, x))
+    ref = CO.spmv(A, x)
+    S = D.CsrSystem.from_any(A)                    # small systems: the gather (CSR-stream) kernel
+    assert S.info()["spmv_kernel"] == "stream"
+    assert np.array_equal((S @ _dev(x)).cpu().numpy(), ref)
+    monkeypatch.setenv("DPCG_SPMV_KERNEL", "tile")    # the same systems through the x-tile kernel where tileable
+    S2 = D.CsrSystem.from_any(A)
+    assert S2.info()["spmv_kernel"] in ("tile", "stream")
+    assert np.array_equal((S2 @ _dev(x)).cpu().numpy(), ref)
+
+
+def test_spmv_tile_plan_selection(D, monkeypatch):
+    """Poisson grids are tileable (few runs of columns per 256-row block); a random permutation is not.  The
+    tile kernel is chosen by default only for systems that stream from HBM (checked at full size in
+    test_full_size_256cubed_properties)."""
+    monkeypatch.setenv("DPCG_SPMV_KERNEL", "tile")
+    assert D.CsrSystem.from_any(O.poisson3d(20)).info()["spmv_kernel"] == "tile"
+    assert D.CsrSystem.from_any(O.poisson2d(300)).info()["spmv_kernel"] == "tile"
+    assert D.CsrSystem.from_any(O.unstructured_like(O.poisson3d(40), 3)).info()["spmv_kernel"] == "stream"
+    A = O.poisson2d(300)
+    S = D.CsrSystem.from_any(A)
+    x = O.rhs(A.shape[0], 1)
+    assert np.array_equal((S @ _dev(x)).cpu().numpy(), CO.spmv(A, x))
+    S.set_preconditioner(D.Jacobi())                 # the whole PCG through the tile kernel
+    res = S.solve(_dev(O.rhs(A.shape[0], 0)))
+    _, it, hist, _ = CO.pcg(A, O.rhs(A.shape[0], 0), "jacobi", dinv=O.jacobi_dinv(A))
+    assert res.iterations == it
+    np.testing.assert_allclose(res.res_history, hist, rtol=HIST_RTOL)
 
 
 def test_spmv_vector_kernel(D):
@@ -357,6 +380,7 @@ def test_full_size_256cubed_properties(D):
     S = poisson.poisson_system(3, n)
     N = n ** 3
     assert S.n == N and S.nnz == 7 * n ** 3 - 6 * n ** 2
+    assert S.info()["spmv_kernel"] == "tile"         # HBM-resident banded system: x tiles staged in LDS
     g = torch.Generator(device="cuda").manual_seed(0)
     x = torch.rand(N, device="cuda", dtype=torch.float64, generator=g) - 0.5
     y = torch.rand(N, device="cuda", dtype=torch.float64, generator=g) - 0.5

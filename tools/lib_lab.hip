@@ -35,7 +35,14 @@ int main(int argc, char **argv) {
         printf("== poisson%dd n=%ld N=%ld: SpMV %.1f MB, K2 %.1f MB, K3 %.1f MB\n", cs.dim, (long)cs.n, (long)N, b_spmv / 1e6, 40.0 * N / 1e6, 40.0 * N / 1e6);
         struct V { const char *name; int kind; int grid; bool ctl; double bytes; int npart; };
         std::vector<V> vs;
-        for (int g : {1536, 2048}) { vs.push_back({"spmv+dot no ctl", 0, g, false, b_spmv, 0}); vs.push_back({"spmv+dot ctl", 0, g, true, b_spmv, 512}); }
+        for (int g : {1536, 2048}) { vs.push_back({"spmv+dot ctl (gather)", 0, g, true, b_spmv, 512}); }
+        for (int g : {1024, 1280, 1536}) { vs.push_back({"spmv+dot ctl (x-tile)", 3, g, true, b_spmv, 512}); }
+        // x-tile plan
+        SpmvPlan tplan; tplan.kernel = SPMV_TILE; tplan.nrb = (int)((N + 255) / 256);
+        CK(hipMalloc(&tplan.tile_chunks, (size_t)tplan.nrb * kTileMaxChunks * 4)); CK(hipMalloc(&tplan.tile_nchunks, (size_t)tplan.nrb * 4)); CK(hipMalloc(&tplan.tile_lidx, nnz * 2));
+        { int *fl; CK(hipMalloc(&fl, 8)); int hf[2] = {1, 0}; CK(hipMemcpy(fl, hf, 8, hipMemcpyHostToDevice));
+          launch_tile_plan(A, tplan.nrb, tplan.tile_chunks, tplan.tile_nchunks, tplan.tile_lidx, fl, s); CK(hipStreamSynchronize(s));
+          CK(hipMemcpy(hf, fl, 8, hipMemcpyDeviceToHost)); tplan.tile_max_chunks = hf[1]; printf("  tile plan: ok=%d max chunks=%d (LDS %zu B per block)\n", hf[0], hf[1], (size_t)(hf[1] * 64 + 2052) * 8); hipFree(fl); }
         vs.push_back({"K2 update_r np=2048", 1, 512, false, 40.0 * N, 2048});
         vs.push_back({"K3 update_xp np=512", 2, 512, false, 40.0 * N, 512});
         const int reps = N > 4000000 ? 10 : 50;
@@ -46,7 +53,8 @@ int main(int argc, char **argv) {
                 SpmvPlan plan; plan.kernel = SPMV_STREAM; plan.nrb = (int)((N + 255) / 256); plan.grid = std::min(plan.nrb, v.grid);
                 IterCtl ctl{sc};
                 auto go = [&]() {
-                    if (v.kind == 0) launch_spmv(A, plan, x, y, part_pq, v.ctl ? &ctl : nullptr, s);
+                    if (v.kind == 3) { SpmvPlan tp = tplan; tp.grid = std::min(tp.nrb, v.grid); launch_spmv(A, tp, x, y, part_pq, v.ctl ? &ctl : nullptr, s); }
+                    else if (v.kind == 0) launch_spmv(A, plan, x, y, part_pq, v.ctl ? &ctl : nullptr, s);
                     else if (v.kind == 1) launch_update_r(1, N, sc, part_pq, v.npart, q, r, dinv, z, part_rz, part_rr, v.grid, s);
                     else launch_update_xp(N, sc, part_rz, part_rr, v.npart, z, y, x, nullptr, hist, 0, v.grid, s);
                 };
