@@ -264,8 +264,11 @@ static void drop_graph(dpcg_system *h) {
     h->graph_key = -1;
 }
 
+static void free_ell(SmallEll &e);
 static void free_precond(dpcg_system *h) {
     drop_graph(h);
+    free_ell(h->ell_m);
+    free_ell(h->ell_t);
     dev_free(h->dinv);
     free_csr(h->M);
     free_csr(h->L);
@@ -315,10 +318,11 @@ extern "C" int dpcg_destroy(dpcg_handle_t h) {
     free_precond(h);
     free_csr(h->A);
     free_plan(h->planA);
+    free_ell(h->ell_a);
     dev_free(h->x); dev_free(h->r); dev_free(h->z); dev_free(h->p); dev_free(h->q); dev_free(h->t); dev_free(h->e);
     dev_free(h->p32);
     dev_free(h->part_pq); dev_free(h->part_rz); dev_free(h->part_rr); dev_free(h->part_bb);
-    dev_free(h->scal); dev_free(h->hist); dev_free(h->err_hist);
+    dev_free(h->scal); dev_free(h->hist); dev_free(h->err_hist); dev_free(h->small_desc);
     if (h->scal_host) (void)hipHostFree(h->scal_host);
     auto it = extras().find(h);
     if (it != extras().end()) {
@@ -954,6 +958,100 @@ struct Solve {
 };
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// small systems: the whole solve in one launch, one workgroup per system (dpcg_small.hip)
+// ------------------------------------------------------------------------------------------------
+static bool small_eligible(const dpcg_system *h, int flags, const double *x_true) {
+    static const bool enabled = [] { const char *e = getenv("DPCG_SMALL"); return !(e && e[0] == '0'); }();
+    if (!enabled || x_true || (flags & (DPCG_SPMV_F32 | DPCG_NO_SMALL))) return false;
+    if (h->A.n > kSmallMaxN) return false;
+    return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI || h->precond == DPCG_PRECOND_CSR ||
+           h->precond == DPCG_PRECOND_LLT_MULTIPLY;
+}
+
+static void free_ell(SmallEll &e) {
+    dev_free(e.col);
+    dev_free(e.val);
+    e = SmallEll();
+}
+
+static int build_ell(const CsrDev &A, SmallEll &e, hipStream_t s) {
+    if (e.col) return DPCG_OK;
+    int *d_w = nullptr, w = 0;
+    DPCG_TRY(dev_alloc(&d_w, 1));
+    DPCG_HIP(hipMemsetAsync(d_w, 0, sizeof(int), s));
+    launch_max_row_len((int)A.n, A.rowptr, d_w, s);
+    DPCG_HIP(hipMemcpyAsync(&w, d_w, sizeof(int), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    dev_free(d_w);
+    const int64_t slabs = (A.n + 1023) / 1024;
+    e.W = w < 1 ? 1 : w;
+    DPCG_TRY(dev_alloc(&e.col, slabs * e.W * 1024));
+    DPCG_TRY(dev_alloc(&e.val, slabs * e.W * 1024));
+    launch_build_ell((int)A.n, A.rowptr, A.col, A.val, e.W, e.col, e.val, s);
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
+// slab-ELL copies of the matrices the small-system kernel multiplies by (built once per matrix)
+static int ensure_small(dpcg_system *h, hipStream_t s) {
+    DPCG_TRY(build_ell(h->A, h->ell_a, s));
+    if (h->precond == DPCG_PRECOND_CSR) DPCG_TRY(build_ell(h->M, h->ell_m, s));
+    if (h->precond == DPCG_PRECOND_LLT_MULTIPLY) {
+        DPCG_TRY(build_ell(h->L, h->ell_m, s));
+        DPCG_TRY(build_ell(h->Lt, h->ell_t, s));
+    }
+    return DPCG_OK;
+}
+
+static SmallDesc make_small_desc(dpcg_system *h, const double *b, const double *x0, double *x, double rtol_sq,
+                                 double atol_sq, int max_iter, int flags) {
+    SmallDesc d;
+    memset(&d, 0, sizeof(d));
+    d.n = (int)h->A.n;
+    d.precond = h->precond;
+    d.max_iter = max_iter;
+    d.init_check_r = (flags & DPCG_INIT_CHECK_R) ? 1 : 0;
+    d.hist_cap = h->hist_cap;
+    d.lds_vectors = h->precond == DPCG_PRECOND_CSR ? 2 : (h->precond == DPCG_PRECOND_LLT_MULTIPLY ? 3 : 1);
+    d.rp = h->A.rowptr; d.dinv = h->dinv;
+    d.ell_a = h->ell_a; d.ell_m = h->ell_m; d.ell_t = h->ell_t;
+    if (h->precond == DPCG_PRECOND_CSR) d.m_rp = h->M.rowptr;
+    if (h->precond == DPCG_PRECOND_LLT_MULTIPLY) { d.m_rp = h->L.rowptr; d.t_rp = h->Lt.rowptr; }
+    d.b = b; d.x0 = x0; d.x = x ? x : h->x; d.hist = h->hist;
+    d.rtol_sq = rtol_sq; d.atol_sq = atol_sq;
+    d.out = h->scal;
+    return d;
+}
+
+static int small_lds_bytes(const SmallDesc &d) { return (int)(((size_t)d.lds_vectors * d.n + 64) * sizeof(double)); }
+
+static int solve_small_one(dpcg_system *h, const double *b, const double *x0, double *x, double rtol_sq, double atol_sq,
+                           int max_iter, int flags, hipStream_t s, int *iters, double *final_res, double *seconds,
+                           double *res_history) {
+    DPCG_TRY(ensure_work(h, max_iter, false, false));
+    DPCG_TRY(ensure_small(h, s));
+    if (!h->small_desc) DPCG_TRY(dev_alloc(&h->small_desc, 1));
+    const SmallDesc d = make_small_desc(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags);
+    DPCG_HIP(hipMemcpyAsync(h->small_desc, &d, sizeof(d), hipMemcpyHostToDevice, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    const auto t0 = std::chrono::steady_clock::now();                                // cg.py:69 (the launch is the loop)
+    DPCG_TRY(launch_pcg_small(h->small_desc, 1, small_lds_bytes(d), 1 << h->precond, s));
+    DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    const auto t1 = std::chrono::steady_clock::now();                                // cg.py:88
+    DPCG_CHECK_LAUNCH();
+    const Scalars sc = *h->scal_host;
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    if (iters) *iters = sc.k;
+    if (final_res) *final_res = sc.res;
+    if (res_history) {
+        DPCG_HIP(hipMemcpyAsync(res_history, h->hist, (size_t)(sc.k + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+    }
+    return sc.status;
+}
+
 static int check_solve_args(dpcg_handle_t h, const double *b, int max_iter, int flags, const double *x_true,
                             double *err_history) {
     if (!h || !b) return invalid("dpcg_solve: NULL handle or b");
@@ -970,6 +1068,9 @@ extern "C" int dpcg_solve(dpcg_handle_t h, const double *b, const double *x0, do
                           double *final_res, double *seconds, double *res_history, const double *x_true,
                           double *err_history) {
     DPCG_TRY(check_solve_args(h, b, max_iter, flags, x_true, err_history));
+    if (small_eligible(h, flags, x_true))
+        return solve_small_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
+                               seconds, res_history);
     Solve sv;
     sv.h = h;
     sv.s = (hipStream_t)stream;
@@ -994,6 +1095,43 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
     if (n_streams > 8) n_streams = 8;
     if (n_streams > count) n_streams = count;
     for (int i = 0; i < count; ++i) DPCG_TRY(check_solve_args(handles[i], b[i], max_iter, flags, nullptr, nullptr));
+    bool all_small = true;
+    for (int i = 0; i < count; ++i) all_small = all_small && small_eligible(handles[i], flags, nullptr);
+    if (all_small) {
+        // one launch, one workgroup (one CU) per system
+        std::vector<SmallDesc> descs((size_t)count);
+        int lds = 0, kinds = 0;
+        for (int i = 0; i < count; ++i) {
+            kinds |= 1 << handles[i]->precond;
+            DPCG_TRY(ensure_work(handles[i], max_iter, false, false));
+            DPCG_TRY(ensure_small(handles[i], nullptr));
+            descs[i] = make_small_desc(handles[i], b[i], x0 ? x0[i] : nullptr, x ? x[i] : nullptr, rtol_sq, atol_sq,
+                                       max_iter, flags);
+            lds = std::max(lds, small_lds_bytes(descs[i]));
+        }
+        SmallDesc *d_descs = nullptr;
+        std::vector<Scalars> out((size_t)count);
+        DPCG_TRY(dev_alloc(&d_descs, count));
+        hipError_t e = hipMemcpy(d_descs, descs.data(), descs.size() * sizeof(SmallDesc), hipMemcpyHostToDevice);
+        const auto t0 = std::chrono::steady_clock::now();
+        int st = e == hipSuccess ? launch_pcg_small(d_descs, count, lds, kinds, nullptr) : DPCG_ERR_HIP;
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (int i = 0; i < count && e == hipSuccess; ++i)
+            e = hipMemcpy(&out[i], handles[i]->scal, sizeof(Scalars), hipMemcpyDeviceToHost);
+        dev_free(d_descs);
+        DPCG_HIP(e);
+        if (st < 0) return st;
+        int worst_small = DPCG_OK;
+        for (int i = 0; i < count; ++i) {
+            if (iters) iters[i] = out[i].k;
+            if (final_res) final_res[i] = out[i].res;
+            if (seconds) seconds[i] = sec;   // the batch ran as one launch
+            if (status) status[i] = out[i].status;
+            worst_small = std::max(worst_small, out[i].status);
+        }
+        return worst_small;
+    }
     std::vector<hipStream_t> streams((size_t)n_streams, nullptr);
     for (auto &st : streams) DPCG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     std::vector<Solve> sv((size_t)count);

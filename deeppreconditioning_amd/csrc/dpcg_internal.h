@@ -68,6 +68,26 @@ struct Scalars {
     unsigned long long *progress;
 };
 
+// One system of the whole-solve kernel for small systems (dpcg_small.hip): everything a workgroup needs.
+constexpr int kSmallMaxN = 6144;      // 6 rows per thread of a 1024-thread workgroup; 3 LDS vectors = 144 KiB
+struct SmallEll {                     // slab-ELL copy of a small matrix (dpcg_small.hip)
+    int W = 0;                        // entries per row (max row length)
+    int32_t *col = nullptr;
+    double *val = nullptr;
+};
+struct SmallDesc {
+    int n, precond, max_iter, init_check_r, hist_cap, lds_vectors;
+    const int32_t *rp;                // row pointers of A (row lengths)
+    const double *dinv;
+    const int32_t *m_rp;              // row pointers of CSR M, or of L for LLT_MULTIPLY
+    const int32_t *t_rp;              // row pointers of L^T for LLT_MULTIPLY
+    SmallEll ell_a, ell_m, ell_t;
+    const double *b, *x0;
+    double *x, *hist;
+    double rtol_sq, atol_sq;
+    Scalars *out;
+};
+
 struct Levels {
     int n_levels = 0;
     int32_t *rows = nullptr;               // device: rows sorted by (level, row)
@@ -106,6 +126,8 @@ struct dpcg_system {
     int hist_cap = 0;
     int vec_grid = 1;
     // cached iteration graph
+    dpcg::SmallDesc *small_desc = nullptr;   // device, one entry (single small solves)
+    dpcg::SmallEll ell_a, ell_m, ell_t;      // slab-ELL copies of A, M (or L), L^T for the small-system kernel
     hipGraphExec_t graph_exec = nullptr;
     int graph_key = -1;
     int graph_chunk = 0;
@@ -166,6 +188,10 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
 // Builds the x-tile plan of A on the device; *ok = 1 when every block is tileable, *max_chunks its widest tile.
 void launch_tile_plan(const CsrDev &A, int nrb, int32_t *chunks, int32_t *nchunks, uint16_t *lidx, int *ok_and_max_dev,
                       hipStream_t s);
+void launch_max_row_len(int n, const int32_t *rp, int *out_dev, hipStream_t s);
+void launch_build_ell(int n, const int32_t *rp, const int32_t *ci, const double *v, int W, int32_t *ell_col,
+                      double *ell_val, hipStream_t s);
+int launch_pcg_small(const SmallDesc *descs_dev, int count, int lds_bytes, int kinds_mask, hipStream_t s);
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
                       hipStream_t s);
 void launch_block_nnz_max(const CsrDev &A, int rows_per_block, int *out_max_dev, hipStream_t s);

@@ -1,0 +1,289 @@
+// Whole-solve kernel for SMALL systems: one 1024-thread workgroup runs the complete PCG (cg.py:58-90) of one
+// system in a single launch; a batch is one launch with one workgroup per system (one system per CU).
+//
+// Why: the reference's real matrices have 2.4k-5.5k rows (params.yaml mesh_cells 2).
+// At that size a PCG update is three ~3 us launches of almost empty kernels; here an update is a handful of
+// workgroup barriers.  Vectors a thread owns (x, r, z, its part of p and A p) live in registers, the vectors other
+// threads gather from (p for A p; r and L^T r for the multiply-type preconditioners) live in LDS, the matrix streams
+// from L2.  Row sums run in column order with one rounding per operation, exactly as in the large-system kernels and
+// the CPU path; reductions use a fixed shuffle/LDS tree, so results are bitwise reproducible.
+#include "dpcg_internal.h"
+
+namespace dpcg {
+
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallRows = kSmallMaxN / kSmallThreads;   // rows per thread (6)
+
+__device__ __forceinline__ double small_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Two sums over the 1024 threads at once; every thread gets both.  `red` = 2 x 32 doubles of LDS, `phase`
+// alternates between two halves so one barrier per reduction suffices.
+__device__ __forceinline__ void small_reduce2(double &a, double &b, double *red, int &phase) {
+    a = small_wave_sum(a);
+    b = small_wave_sum(b);
+    double *slot = red + (phase & 1) * 32;
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        slot[w] = a;
+        slot[16 + w] = b;
+    }
+    __syncthreads();
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        sa += slot[i];
+        sb += slot[16 + i];
+    }
+    a = sa;
+    b = sb;
+    ++phase;
+}
+
+// The matrices of a small system are re-laid out once as slab-ELL: rows in slabs of 1024 (one per thread),
+// entry j of row i at [(slab*W + j)*1024 + i%1024].  Lanes of a wave then read consecutive addresses for a fixed j
+// (coalesced 512-B loads; thread-per-row CSR reads touch 20 lines per load and thrash the 32 KiB L1), and the
+// per-row order of the entries -- hence the rounding of the row sum -- is exactly the CSR order.
+__global__ void k_build_ell(int n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                            const double *__restrict__ v, int W, int32_t *__restrict__ ell_col,
+                            double *__restrict__ ell_val) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int slab = i / kSmallThreads, lane = i % kSmallThreads;
+    const int s = rp[i], len = rp[i + 1] - s;
+    for (int j = 0; j < W; ++j) {
+        const size_t o = ((size_t)slab * W + j) * kSmallThreads + lane;
+        ell_col[o] = j < len ? ci[s + j] : i;
+        ell_val[o] = j < len ? v[s + j] : 0.0;
+    }
+}
+
+__global__ void k_max_row_len(int n, const int32_t *__restrict__ rp, int *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicMax(out, rp[i + 1] - rp[i]);
+}
+
+void launch_max_row_len(int n, const int32_t *rp, int *out_dev, hipStream_t s) {
+    hipLaunchKernelGGL(k_max_row_len, dim3((n + 255) / 256), dim3(256), 0, s, n, rp, out_dev);
+}
+void launch_build_ell(int n, const int32_t *rp, const int32_t *ci, const double *v, int W, int32_t *ell_col,
+                      double *ell_val, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_ell, dim3((n + 255) / 256), dim3(256), 0, s, n, rp, ci, v, W, ell_col, ell_val);
+}
+
+// q[k] = (row t + 1024 k) . xs with xs in LDS.  Entry index j is the OUTER loop so that the loads of all six
+// rows of a thread are in flight together (memory-level parallelism); each row's sum still runs in column order.
+__device__ __forceinline__ void small_spmv(const SmallEll &E, const int (&len)[kSmallRows], const double *xs,
+                                           double (&q)[kSmallRows]) {
+    const int t = threadIdx.x;
+    int lmax = 0;
+#pragma unroll
+    for (int k = 0; k < kSmallRows; ++k) {
+        q[k] = 0.0;
+        lmax = len[k] > lmax ? len[k] : lmax;
+    }
+    const size_t slab = (size_t)E.W * kSmallThreads;
+#pragma unroll 2
+    for (int j = 0; j < lmax; ++j) {
+        int cc[kSmallRows];
+        double vv[kSmallRows];
+#pragma unroll
+        for (int k = 0; k < kSmallRows; ++k) {
+            const size_t o = (size_t)k * slab + (size_t)(j < len[k] ? j : 0) * kSmallThreads + t;
+            cc[k] = len[k] > 0 ? E.col[o] : 0;
+            vv[k] = len[k] > 0 ? E.val[o] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < kSmallRows; ++k)
+            if (j < len[k]) q[k] += vv[k] * xs[cc[k]];
+    }
+}
+
+__device__ __forceinline__ void small_rows(int n, const int32_t *__restrict__ rp, int (&len)[kSmallRows]) {
+#pragma unroll
+    for (int k = 0; k < kSmallRows; ++k) {
+        const int i = (int)threadIdx.x + k * kSmallThreads;
+        len[k] = i < n ? rp[i + 1] - rp[i] : 0;
+    }
+}
+
+// PRE: DPCG_PRECOND_NONE / JACOBI / CSR / LLT_MULTIPLY (compile-time, so each variant carries only its state)
+template <int PRE>
+__global__ __launch_bounds__(kSmallThreads) void k_pcg_small(const SmallDesc *__restrict__ descs) {
+    const SmallDesc d = descs[blockIdx.x];
+    if (d.precond != PRE) return;           // a mixed batch is launched once per preconditioner kind
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int n = d.n;
+    double *ps = lds;                 // p, gathered by A p
+    double *w1 = ps + n;              // r, gathered by M r / L^T r (multiply-type preconditioners)
+    double *w2 = w1 + n;              // L^T r, gathered by L (L^T r)
+    double *red = lds + (size_t)d.lds_vectors * n;   // 64 doubles
+    int phase = 0;
+    const int t = threadIdx.x;
+    double x[kSmallRows], r[kSmallRows], p[kSmallRows], q[kSmallRows], z[kSmallRows], dinv[kSmallRows];
+    int len[kSmallRows], mlen[kSmallRows], tlen[kSmallRows];
+    small_rows(n, d.rp, len);               // the row lengths never change: read them once
+    if (PRE == DPCG_PRECOND_CSR || PRE == DPCG_PRECOND_LLT_MULTIPLY) small_rows(n, d.m_rp, mlen);
+    if (PRE == DPCG_PRECOND_LLT_MULTIPLY) small_rows(n, d.t_rp, tlen);
+#pragma unroll
+    for (int k = 0; k < kSmallRows; ++k) {
+        const int i = t + k * kSmallThreads;
+        dinv[k] = (PRE == DPCG_PRECOND_JACOBI && i < n) ? d.dinv[i] : 0.0;
+    }
+
+    // z = M r for this thread's rows (cg.py:61,81)
+    auto apply_precond = [&]() {
+        if (PRE == DPCG_PRECOND_NONE) {
+#pragma unroll
+            for (int k = 0; k < kSmallRows; ++k) z[k] = r[k];
+        } else if (PRE == DPCG_PRECOND_JACOBI) {
+#pragma unroll
+            for (int k = 0; k < kSmallRows; ++k) z[k] = dinv[k] * r[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < kSmallRows; ++k) {
+                const int i = t + k * kSmallThreads;
+                if (i < n) w1[i] = r[k];
+            }
+            __syncthreads();
+            if (PRE == DPCG_PRECOND_CSR) {
+                small_spmv(d.ell_m, mlen, w1, z);                                  // z = M r
+            } else {                                                              // z = L (L^T r)
+                double tmp[kSmallRows];
+                small_spmv(d.ell_t, tlen, w1, tmp);
+#pragma unroll
+                for (int k = 0; k < kSmallRows; ++k) {
+                    const int i = t + k * kSmallThreads;
+                    if (i < n) w2[i] = tmp[k];
+                }
+                __syncthreads();
+                small_spmv(d.ell_m, mlen, w2, z);
+            }
+            __syncthreads();  // w1/w2 are rewritten by the next apply
+        }
+    };
+
+    // ---- start of the solve (cg.py:58-67) ----
+    double a_bb = 0.0, a_dummy = 0.0;
+#pragma unroll
+    for (int k = 0; k < kSmallRows; ++k) {
+        const int i = t + k * kSmallThreads;
+        const double bi = i < n ? d.b[i] : 0.0;
+        x[k] = (i < n && d.x0) ? d.x0[i] : 0.0;                                    // cg.py:58
+        r[k] = bi;
+        a_bb += bi * bi;
+    }
+    if (d.x0) {                                                                    // r = b - A x0 (cg.py:60)
+#pragma unroll
+        for (int k = 0; k < kSmallRows; ++k) {
+            const int i = t + k * kSmallThreads;
+            if (i < n) ps[i] = x[k];
+        }
+        __syncthreads();
+        small_spmv(d.ell_a, len, ps, q);
+#pragma unroll
+        for (int k = 0; k < kSmallRows; ++k) r[k] = r[k] - q[k];
+        __syncthreads();
+    }
+    apply_precond();                                                               // cg.py:61
+    double a_rz = 0.0, a_t = 0.0;
+#pragma unroll
+    for (int k = 0; k < kSmallRows; ++k) {
+        const int i = t + k * kSmallThreads;
+        p[k] = z[k];                                                               // cg.py:62
+        if (i < n) ps[i] = z[k];
+        a_rz += r[k] * z[k];
+        a_t += d.init_check_r ? r[k] * r[k] : z[k] * z[k];                         // cg.py:66 tests zk
+    }
+    small_reduce2(a_bb, a_dummy, red, phase);
+    small_reduce2(a_rz, a_t, red, phase);                                          // also orders the ps writes
+    const double bb = a_bb;
+    double rz = a_rz;
+    double res = a_t / bb;
+    bool conv = (res < d.rtol_sq) || (a_t < d.atol_sq);
+    if (t == 0 && d.hist_cap > 0) d.hist[0] = res;
+    int it = 0, status = DPCG_MAX_ITER;
+    if (conv) status = DPCG_OK;
+    else if (!(res == res)) status = DPCG_BREAKDOWN;
+
+    // ---- the loop (cg.py:70-87) ----
+    while (status == DPCG_MAX_ITER && it < d.max_iter) {
+        small_spmv(d.ell_a, len, ps, q);                                           // cg.py:75
+        double a_pq = 0.0, a_z = 0.0;
+#pragma unroll
+        for (int k = 0; k < kSmallRows; ++k) a_pq += p[k] * q[k];
+        small_reduce2(a_pq, a_z, red, phase);
+        const double alpha = rz / a_pq;                                            // cg.py:78
+#pragma unroll
+        for (int k = 0; k < kSmallRows; ++k) {
+            x[k] = x[k] + alpha * p[k];                                            // cg.py:79
+            r[k] = r[k] - alpha * q[k];                                            // cg.py:80
+        }
+        apply_precond();                                                           // cg.py:81
+        double a_rzn = 0.0, a_rr = 0.0;
+#pragma unroll
+        for (int k = 0; k < kSmallRows; ++k) {
+            a_rzn += r[k] * z[k];
+            a_rr += r[k] * r[k];
+        }
+        small_reduce2(a_rzn, a_rr, red, phase);   // every wave is past its reads of ps here
+        const double beta = a_rzn / rz;                                            // cg.py:82
+        rz = a_rzn;
+#pragma unroll
+        for (int k = 0; k < kSmallRows; ++k) {
+            const int i = t + k * kSmallThreads;
+            p[k] = z[k] + beta * p[k];                                             // cg.py:83
+            if (i < n) ps[i] = p[k];
+        }
+        __syncthreads();
+        ++it;
+        res = a_rr / bb;                                                           // cg.py:86
+        if (t == 0 && it < d.hist_cap) d.hist[it] = res;
+        conv = (res < d.rtol_sq) || (a_rr < d.atol_sq);                            // cg.py:71
+        if (conv) status = DPCG_OK;
+        else if (!(res == res)) status = DPCG_BREAKDOWN;
+    }
+#pragma unroll
+    for (int k = 0; k < kSmallRows; ++k) {
+        const int i = t + k * kSmallThreads;
+        if (i < n && d.x) d.x[i] = x[k];
+    }
+    if (t == 0) {
+        d.out->k = it;
+        d.out->res = res;
+        d.out->status = status;
+        d.out->done = 1;
+        d.out->rz = rz;
+        d.out->bb = bb;
+    }
+}
+
+template <int PRE>
+static int launch_one(const SmallDesc *descs_dev, int count, int lds_bytes, hipStream_t s) {
+    static int attr_set_for = 0;
+    if (lds_bytes > attr_set_for) {
+        if (hipFuncSetAttribute((const void *)k_pcg_small<PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) !=
+            hipSuccess)
+            return DPCG_ERR_HIP;
+        attr_set_for = lds_bytes;
+    }
+    hipLaunchKernelGGL(k_pcg_small<PRE>, dim3(count), dim3(kSmallThreads), (size_t)lds_bytes, s, descs_dev);
+    return DPCG_OK;
+}
+
+// kinds_mask: bit p set = some system of the batch uses preconditioner kind p (one launch per kind present;
+// workgroups of another kind return at once).
+int launch_pcg_small(const SmallDesc *descs_dev, int count, int lds_bytes, int kinds_mask, hipStream_t s) {
+    int st = DPCG_OK;
+    if (st >= 0 && (kinds_mask & (1 << DPCG_PRECOND_NONE))) st = launch_one<DPCG_PRECOND_NONE>(descs_dev, count, lds_bytes, s);
+    if (st >= 0 && (kinds_mask & (1 << DPCG_PRECOND_JACOBI))) st = launch_one<DPCG_PRECOND_JACOBI>(descs_dev, count, lds_bytes, s);
+    if (st >= 0 && (kinds_mask & (1 << DPCG_PRECOND_CSR))) st = launch_one<DPCG_PRECOND_CSR>(descs_dev, count, lds_bytes, s);
+    if (st >= 0 && (kinds_mask & (1 << DPCG_PRECOND_LLT_MULTIPLY)))
+        st = launch_one<DPCG_PRECOND_LLT_MULTIPLY>(descs_dev, count, lds_bytes, s);
+    return st;
+}
+
+}  // namespace dpcg

@@ -59,7 +59,8 @@ enum dpcg_solve_flags {
     DPCG_INIT_CHECK_R = 1,   /* first test on <r0,r0> (scipy cg, utils.py:66-72) instead of the
                                 reference's <z0,z0> (cg.py:66)                                      */
     DPCG_SPMV_F32 = 2,       /* mixed precision: A@p with fp32 val and fp32 p, fp64 everywhere else */
-    DPCG_NO_GRAPH = 4        /* launch kernels one by one instead of replaying a hipGraph           */
+    DPCG_NO_GRAPH = 4,       /* launch kernels one by one instead of replaying a hipGraph           */
+    DPCG_NO_SMALL = 8        /* do not use the one-workgroup whole-solve kernel for systems <= 6144 rows */
 };
 
 /* ---- library ------------------------------------------------------------------------------- */

@@ -445,6 +445,9 @@ def test_benchmark_suite_harness(D, tmp_path):
     suite.run()
     suite.dump_csv()
     for i, (m, b) in enumerate(zip(mats, rhs)):
+        # the reference's data sets carry fp32 values (data_set.py:121-128): compare with the same rounded inputs
+        m = sp.csr_matrix((m.data.astype(np.float32).astype(np.float64), m.indices, m.indptr), shape=m.shape)
+        b = b.astype(np.float32).astype(np.float64)
         assert suite.iterations["vanilla"][i] == CO.pcg(m, b, "none")[1]
         assert suite.iterations["jacobi"][i] == CO.pcg(m, b, "jacobi", dinv=O.jacobi_dinv(m))[1]
         assert suite.iterations["incomplete_cholesky_solve"][i] == CO.pcg(m, b, "llt_solve", L=CO.ic0(m))[1]
@@ -455,3 +458,52 @@ def test_benchmark_suite_harness(D, tmp_path):
     assert [r[0] for r in rows[1:]] == list(suite.techniques)
     totals = list(csv.reader((tmp_path / "totals.csv").open()))
     assert totals[0] == list(suite.techniques) and len(totals) == 1 + len(mats)
+
+
+# ---- small systems: the whole solve in one launch (one workgroup per system) -------------------------------
+@pytest.mark.parametrize("make,seed", [(lambda: O.poisson2d(64), 0), (lambda: O.poisson2d(32), 3),
+                                       (lambda: O.unstructured_like(O.poisson3d(16), 0), 0), (lambda: O.poisson3d(18), 2),
+                                       (lambda: O.poisson2d(78), 1), (lambda: O.poisson2d(1), 0)])
+def test_small_kernel_matches_general_path_and_oracle(D, make, seed):
+    A = make()
+    n = A.shape[0]
+    assert n <= 6144
+    b = O.rhs(n, seed)
+    S = D.CsrSystem.from_any(A)
+    for kind, pc, okw in (("jacobi", D.Jacobi(), dict(dinv=O.jacobi_dinv(A))), ("none", None, {})):
+        S.set_preconditioner(pc)
+        small = S.solve(_dev(b))
+        general = S.solve(_dev(b), flags=D._lib.NO_SMALL)
+        _, it, hist, x = CO.pcg(A, b, kind, **okw)
+        assert small.iterations == general.iterations == it
+        np.testing.assert_allclose(small.res_history, hist, rtol=HIST_RTOL)
+        np.testing.assert_allclose(general.res_history, hist, rtol=HIST_RTOL)
+        np.testing.assert_allclose(small.x.cpu().numpy(), x, rtol=1e-9, atol=1e-12)
+        assert small.status == general.status == 0
+    x0 = np.random.default_rng(7).uniform(-1, 1, n)
+    S.set_preconditioner(D.Jacobi())
+    r_small = S.solve(_dev(b), _dev(x0), max_iter=25)
+    _, it, hist, x = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A), x0=x0, max_iter=25)
+    assert r_small.iterations == it
+    np.testing.assert_allclose(r_small.res_history, hist, rtol=HIST_RTOL)
+    np.testing.assert_allclose(r_small.x.cpu().numpy(), x, rtol=1e-9, atol=1e-12)
+
+
+def test_small_kernel_multiply_preconditioners(D, golden):
+    A = O.poisson2d(64)
+    b = _dev(O.rhs(A.shape[0], 0))
+    S = D.CsrSystem.from_any(A)
+    Lw = O.learned_like_factor(A, seed=1, scale=0.02, diag_sigma=0.1)
+    for pc in ((Lw @ Lw.T).tocsr(), D.LLtMultiply(Lw)):
+        S.set_preconditioner(pc)
+        small = S.solve(b)
+        general = S.solve(b, flags=D._lib.NO_SMALL)
+        _check_chaotic(golden, "pcg_poisson2d_64_learnedlike_wellcond_multiply", small, stable=40)
+        _check_chaotic(golden, "pcg_poisson2d_64_learnedlike_wellcond_multiply", general, stable=40)
+    # breakdown: a singular "SPD" system with b in the null-space direction gives <Ap,p> = 0 -> NaN -> status 2
+    Z = sp.csr_matrix((np.array([1.0, 1.0, 0.0]), (np.arange(3), np.arange(3))), shape=(3, 3))
+    Sz = D.CsrSystem.from_any(sp.csr_matrix((np.array([1.0, 1.0, 1e-300]), (np.arange(3), np.arange(3))), shape=(3, 3)))
+    Sz.set_preconditioner(None)
+    rz = Sz.solve(_dev(np.array([0.0, 0.0, 0.0])))       # b = 0: <b,b> = 0 -> 0/0
+    assert rz.status == 2 and rz.iterations == 0
+    del Z
