@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--precond", default="jacobi", choices=["jacobi", "none", "ic0"])
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barrier / result reduction (nccl = RCCL; gloo lets the "
+                         "N > 1 control flow be exercised with several ranks sharing one GPU)")
     return ap.parse_args()
 
 
@@ -77,12 +80,16 @@ def main() -> None:
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group("gloo")
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     import deeppreconditioning_amd as D
     from deeppreconditioning_amd import poisson
@@ -116,8 +123,8 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([float(iters_local)], device="cuda", dtype=torch.float64)
-    tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    tot = torch.tensor([float(iters_local)], device=red_dev, dtype=torch.float64)
+    tmax = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

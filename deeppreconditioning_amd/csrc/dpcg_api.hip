@@ -251,11 +251,29 @@ struct HandleExtras {
     unsigned long long *prog_host = nullptr;  // pinned + mapped: the solve's progress word
     unsigned long long *prog_dev = nullptr;   // device-side address of the same word
 };
-// kept outside dpcg_system so the struct in the header stays POD-like
+// kept outside dpcg_system so the struct in the header stays POD-like; the registry itself is guarded so that
+// handles may be created/destroyed from several host threads (one handle is still used by one thread at a time)
 #include <map>
-static std::map<dpcg_system *, HandleExtras> &extras() {
-    static std::map<dpcg_system *, HandleExtras> m;
-    return m;
+#include <mutex>
+struct ExtrasRegistry {
+    std::mutex mu;
+    std::map<dpcg_system *, HandleExtras> m;
+    HandleExtras &operator[](dpcg_system *h) {
+        std::lock_guard<std::mutex> lock(mu);
+        return m[h];   // std::map nodes are stable: the reference stays valid while the handle lives
+    }
+    bool take(dpcg_system *h, HandleExtras &out) {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = m.find(h);
+        if (it == m.end()) return false;
+        out = it->second;
+        m.erase(it);
+        return true;
+    }
+};
+static ExtrasRegistry &extras() {
+    static ExtrasRegistry r;
+    return r;
 }
 
 static void drop_graph(dpcg_system *h) {
@@ -324,12 +342,10 @@ extern "C" int dpcg_destroy(dpcg_handle_t h) {
     dev_free(h->part_pq); dev_free(h->part_rz); dev_free(h->part_rr); dev_free(h->part_bb);
     dev_free(h->scal); dev_free(h->hist); dev_free(h->err_hist); dev_free(h->small_desc);
     if (h->scal_host) (void)hipHostFree(h->scal_host);
-    auto it = extras().find(h);
-    if (it != extras().end()) {
-        HandleExtras &ex = it->second;
+    HandleExtras ex;
+    if (extras().take(h, ex)) {
         if (ex.cap_stream) (void)hipStreamDestroy(ex.cap_stream);
         if (ex.prog_host) (void)hipHostFree(ex.prog_host);
-        extras().erase(it);
     }
     delete h;
     return DPCG_OK;
