@@ -507,3 +507,22 @@ def test_small_kernel_multiply_preconditioners(D, golden):
     rz = Sz.solve(_dev(np.array([0.0, 0.0, 0.0])))       # b = 0: <b,b> = 0 -> 0/0
     assert rz.status == 2 and rz.iterations == 0
     del Z
+
+
+def test_reference_import_lines_resolve_through_the_compat_shim(D, monkeypatch):
+    """`compat/` on sys.path: the reference's own import statements (test.py:19-20) reach the HIP path."""
+    import importlib
+    import pathlib
+    import sys
+    monkeypatch.syspath_prepend(str(pathlib.Path(__file__).resolve().parent.parent / "compat"))
+    for name in [m for m in sys.modules if m == "uibk" or m.startswith("uibk.")]:
+        monkeypatch.delitem(sys.modules, name)
+    cg_mod = importlib.import_module("uibk.deep_preconditioning.cg")
+    models = importlib.import_module("uibk.deep_preconditioning.model")
+    A = O.poisson2d(20)
+    b = torch.from_numpy(O.rhs(A.shape[0], 0))
+    M = torch.sparse_coo_tensor(torch.vstack((torch.arange(400), torch.arange(400))), torch.from_numpy(1 / A.diagonal()),
+                                size=(400, 400)).to_sparse_csr()
+    duration, iterations, info = cg_mod.preconditioned_conjugate_gradient(torch.from_numpy(A.toarray()), b, M)
+    assert iterations == CO.pcg(A, O.rhs(400, 0), "jacobi", dinv=O.jacobi_dinv(A))[1] and info == 0
+    assert hasattr(models, "PreconditionerNet")
