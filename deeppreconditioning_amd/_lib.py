@@ -53,6 +53,7 @@ SIGNATURES = {
     "dpcg_poisson_sizes": (_int, [_int, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "dpcg_gen_poisson": (_int, [_int, _i64, _p, _p, _p, _int, _p]),
     "dpcg_batched_coo_spmv": (_int, [_i64, _p, _p, _int, _i64, _p, _p, _int, _p]),
+    "dpcg_batched_coo_edge": (_int, [_i64, _p, _int, _i64, _p, _p, _p, _int, _p]),
     "dpcg_coo_to_csr": (_int, [_i64, _i64, _p, _p, _p, _p, _p, _p, C.POINTER(_i64), _p]),
 }
 

@@ -1232,3 +1232,12 @@ extern "C" int dpcg_batched_coo_spmv(int64_t nnz, const int32_t *indices, const 
     DPCG_CHECK_LAUNCH();
     return DPCG_OK;
 }
+
+extern "C" int dpcg_batched_coo_edge(int64_t nnz, const int32_t *indices, int batch, int64_t dof, const float *a,
+                                     const float *c, float *out, int transpose, dpcg_stream_t stream) {
+    if (nnz < 0 || batch <= 0 || dof <= 0 || (nnz > 0 && (!indices || !a || !c || !out)))
+        return invalid("dpcg_batched_coo_edge: bad arguments");
+    if (nnz > 0) launch_batched_coo_edge(nnz, indices, batch, dof, a, c, out, transpose, (hipStream_t)stream);
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}

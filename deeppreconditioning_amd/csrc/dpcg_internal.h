@@ -196,6 +196,8 @@ void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp,
                       hipStream_t s);
 void launch_block_nnz_max(const CsrDev &A, int rows_per_block, int *out_max_dev, hipStream_t s);
 void launch_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void *val, int val_dtype, hipStream_t s);
+void launch_batched_coo_edge(int64_t nnz, const int32_t *indices, int batch, int64_t dof, const float *a, const float *c,
+                             float *out, int transpose, hipStream_t s);
 void launch_batched_coo_spmv(int64_t nnz, const int32_t *indices, const float *features, int batch, int64_t dof,
                              const float *vectors, float *out, int transpose, hipStream_t s);
 

@@ -1078,6 +1078,32 @@ __global__ __launch_bounds__(kBlock) void k_batched_coo_spmv(int64_t nnz, const 
     }
 }
 
+// Per-triple products out[k] = a[b, row_k] * c[b, col_k]: the gradient of sparse_matvec_mul with respect to the
+// matrix entries (d/d feature_k of sum_b <g_b, A_b v_b> = g[b,row_k] * v[b,col_k]); needed to train through
+// `frobenius_loss` (metrics.py:28-29).
+__global__ __launch_bounds__(kBlock) void k_batched_coo_edge(int64_t nnz, const int32_t *__restrict__ idx, int batch,
+                                                             int64_t dof, const float *__restrict__ a,
+                                                             const float *__restrict__ c, float *__restrict__ out,
+                                                             int transpose) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += stride) {
+        const int b = idx[3 * k];
+        const int r = idx[3 * k + (transpose ? 2 : 1)];
+        const int cc = idx[3 * k + (transpose ? 1 : 2)];
+        const bool ok = b >= 0 && b < batch && r >= 0 && r < dof && cc >= 0 && cc < dof;
+        out[k] = ok ? a[(int64_t)b * dof + r] * c[(int64_t)b * dof + cc] : 0.0f;
+    }
+}
+
+void launch_batched_coo_edge(int64_t nnz, const int32_t *indices, int batch, int64_t dof, const float *a, const float *c,
+                             float *out, int transpose, hipStream_t s) {
+    int64_t g = (nnz + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_batched_coo_edge, dim3((int)g), dim3(kBlock), 0, s, nnz, indices, batch, dof, a, c, out,
+                       transpose);
+}
+
 void launch_batched_coo_spmv(int64_t nnz, const int32_t *indices, const float *features, int batch, int64_t dof,
                              const float *vectors, float *out, int transpose, hipStream_t s) {
     int64_t g = (nnz + kBlock - 1) / kBlock;

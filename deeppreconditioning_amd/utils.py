@@ -10,8 +10,44 @@ from . import _lib as L
 from .operators import CsrSystem, _dev_ptr, _stream
 
 
+def _coo_spmv(idx, feat, vec, transpose: bool) -> torch.Tensor:
+    batch, dof = vec.shape
+    out = torch.empty_like(vec)
+    with torch.cuda.device(vec.device):
+        L.check(L.lib().dpcg_batched_coo_spmv(idx.shape[0], _dev_ptr(idx), _dev_ptr(feat), batch, dof, _dev_ptr(vec),
+                                              _dev_ptr(out), 1 if transpose else 0, _stream()))
+    return out
+
+
+class _SparseMatvec(torch.autograd.Function):
+    """y[b] = A[b] v[b] (or A[b]^T v[b]) on COO triples, with gradients for training through it
+    (metrics.frobenius_loss, metrics.py:28-29): dL/dv = A^T g (the same kernel with `transpose` flipped),
+    dL/dfeature_k = g[b,row_k] * v[b,col_k] (dpcg_batched_coo_edge)."""
+
+    @staticmethod
+    def forward(ctx, feat, vec, idx, transpose):
+        ctx.save_for_backward(feat, vec, idx)
+        ctx.transpose = bool(transpose)
+        return _coo_spmv(idx, feat, vec, ctx.transpose)
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, vec, idx = ctx.saved_tensors
+        g = g.contiguous()
+        g_feat = g_vec = None
+        if ctx.needs_input_grad[0]:
+            g_feat = torch.empty_like(feat)
+            batch, dof = vec.shape
+            with torch.cuda.device(vec.device):
+                L.check(L.lib().dpcg_batched_coo_edge(idx.shape[0], _dev_ptr(idx), batch, dof, _dev_ptr(g), _dev_ptr(vec),
+                                                      _dev_ptr(g_feat), 1 if ctx.transpose else 0, _stream()))
+        if ctx.needs_input_grad[1]:
+            g_vec = _coo_spmv(idx, feat, g, not ctx.transpose)
+        return g_feat, g_vec, None, None
+
+
 def sparse_matvec_mul(spconv_batch, vector_batch: torch.Tensor, transpose: bool) -> torch.Tensor:
-    """Batched sparse matrix-vector product on COO triples (utils.py:15-43).
+    """Batched sparse matrix-vector product on COO triples (utils.py:15-43), differentiable.
 
     `spconv_batch` needs `.indices` (nnz,3) int32 `(batch,row,col)`, `.features` (nnz,1) and
     `.batch_size` -- an spconv `SparseConvTensor` or this package's `SparseBatch`.
@@ -22,14 +58,9 @@ def sparse_matvec_mul(spconv_batch, vector_batch: torch.Tensor, transpose: bool)
     idx = spconv_batch.indices.to(device=dev, dtype=torch.int32).contiguous()
     feat = spconv_batch.features.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
     vec = vector_batch.to(torch.float32).contiguous()
-    batch, dof = vec.shape
-    if batch != spconv_batch.batch_size:
+    if vec.shape[0] != spconv_batch.batch_size:
         raise ValueError("batch size mismatch")
-    out = torch.empty_like(vec)
-    with torch.cuda.device(dev):
-        L.check(L.lib().dpcg_batched_coo_spmv(idx.shape[0], _dev_ptr(idx), _dev_ptr(feat), batch, dof, _dev_ptr(vec),
-                                              _dev_ptr(out), 1 if transpose else 0, _stream()))
-    return out.to(vector_batch.dtype)
+    return _SparseMatvec.apply(feat, vec, idx, bool(transpose)).to(vector_batch.dtype)
 
 
 def benchmark_cg(matrix, right_hand_side, preconditioner=None) -> tuple[float, int, int]:

@@ -139,6 +139,11 @@ int dpcg_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void *va
 int dpcg_batched_coo_spmv(int64_t nnz, const int32_t *indices, const float *features, int batch, int64_t dof,
                           const float *vectors, float *out, int transpose, dpcg_stream_t stream);
 
+/* Gradient of sparse_matvec_mul w.r.t. the matrix entries (training through frobenius_loss, metrics.py:28-29):
+ * out[k] = a[batch_k, row_k] * c[batch_k, col_k] with (row,col) as in dpcg_batched_coo_spmv for `transpose`. */
+int dpcg_batched_coo_edge(int64_t nnz, const int32_t *indices, int batch, int64_t dof, const float *a, const float *c,
+                          float *out, int transpose, dpcg_stream_t stream);
+
 /* ---- coordinate triplets -> CSR on the device (the reference's file formats are COO: scipy npz,
  * generate_data.py:109; OpenFOAM `i,j,value` dump, pEqn.H:98-108; StAn npz, data_set.py:186-188) ------------- */
 /* rows/cols int32[nnz], vals fp64[nnz]: device.  Stable sort by (row,col), duplicates summed in storage order.
