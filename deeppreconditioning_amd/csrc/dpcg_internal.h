@@ -201,4 +201,26 @@ void launch_batched_coo_edge(int64_t nnz, const int32_t *indices, int batch, int
 void launch_batched_coo_spmv(int64_t nnz, const int32_t *indices, const float *features, int batch, int64_t dof,
                              const float *vectors, float *out, int transpose, hipStream_t s);
 
+// ---- device helpers shared by the kernel translation units --------------------------------------------
+// Cross-lane moves on the DPP path (no LDS crossbar round trip as with ds_bpermute/__shfl): ~8 cycles per step
+// instead of ~70.  A 64-bit value moves as two 32-bit halves.  Lanes without a source lane read 0 (bound_ctrl).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes of a wave in a fixed order; the result is valid in lane 63.
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_move<0xb1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v += dpp_move<0x4e, 0xf>(v);    // quad_perm [2,3,0,1]
+    v += dpp_move<0x114, 0xf>(v);   // row_shr:4
+    v += dpp_move<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of each row holds the row sum
+    v += dpp_move<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_move<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+    return v;
+}
+
+
 }  // namespace dpcg

@@ -14,17 +14,11 @@ namespace dpcg {
 // ------------------------------------------------------------------------------------------------
 // Deterministic reductions: wave64 shuffle tree -> 4 wave sums in LDS -> fixed-order add.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;  // valid in lane 0
-}
-
 // Sum over the 256 threads of the workgroup; every thread gets the result.  sh: 4 doubles of LDS.
 __device__ __forceinline__ double block_sum(double v, double *sh) {
     v = wave_sum(v);
     __syncthreads();  // sh may still be read from a previous use
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     return ((sh[0] + sh[1]) + sh[2]) + sh[3];
 }

@@ -14,20 +14,14 @@ namespace dpcg {
 constexpr int kSmallThreads = 1024;
 constexpr int kSmallRows = kSmallMaxN / kSmallThreads;   // rows per thread (6)
 
-__device__ __forceinline__ double small_wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
 // Two sums over the 1024 threads at once; every thread gets both.  `red` = 2 x 32 doubles of LDS, `phase`
 // alternates between two halves so one barrier per reduction suffices.
 __device__ __forceinline__ void small_reduce2(double &a, double &b, double *red, int &phase) {
-    a = small_wave_sum(a);
-    b = small_wave_sum(b);
+    a = wave_sum(a);   // DPP tree, result in lane 63
+    b = wave_sum(b);
     double *slot = red + (phase & 1) * 32;
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 63) {
         slot[w] = a;
         slot[16 + w] = b;
     }
