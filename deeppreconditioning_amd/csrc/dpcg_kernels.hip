@@ -23,6 +23,20 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
     return ((sh[0] + sh[1]) + sh[2]) + sh[3];
 }
 
+// Two sums at once (one pair of barriers).  sh: 8 doubles of LDS.
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *sh) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) {
+        sh[threadIdx.x >> 6] = a;
+        sh[4 + (threadIdx.x >> 6)] = b;
+    }
+    __syncthreads();
+    a = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    b = ((sh[4] + sh[5]) + sh[6]) + sh[7];
+}
+
 // Every workgroup re-reduces the <= kMaxGrid partials a previous kernel wrote: same order in every
 // workgroup, so all of them hold bit-identical scalars without any inter-workgroup hand-off.
 __device__ __forceinline__ double reduce_partials(const double *__restrict__ part, int n_part, double *sh) {
@@ -456,7 +470,7 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
                                                      const double *__restrict__ q, double *__restrict__ r,
                                                      const double *__restrict__ dinv, double *__restrict__ z,
                                                      double *__restrict__ part_rz, double *__restrict__ part_rr) {
-    __shared__ double sh[4];
+    __shared__ double sh[8];
     if (sc->done) return;
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -512,14 +526,10 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
             a_rz += rn * zn;
         }
     }
-    const double t_rr = block_sum(a_rr, sh);
-    if (PRE == 1) {
-        const double t_rz = block_sum(a_rz, sh);
-        if (threadIdx.x == 0) part_rz[blockIdx.x] = t_rz;
-    }
+    block_sum2(a_rr, a_rz, sh);
     if (threadIdx.x == 0) {
-        part_rr[blockIdx.x] = t_rr;
-        if (PRE == 0) part_rz[blockIdx.x] = t_rr;                       // z = r
+        part_rr[blockIdx.x] = a_rr;
+        if (PRE != 2) part_rz[blockIdx.x] = PRE == 1 ? a_rz : a_rr;     // PRE 0: z = r; PRE 2: <r,z> comes later
     }
 }
 
