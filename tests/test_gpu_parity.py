@@ -577,3 +577,44 @@ def test_sparse_matvec_mul_gradients_and_frobenius_loss(D, golden):
     l1 = frobenius_loss(net(inp), rhs, x)
     assert float(l1) < float(l0)
     assert float(inverse_loss(inp, net(inp))) > 0
+
+
+# ---- BASELINE config 3 / 5 at full size against the C oracle ---------------------------------------------------
+def test_c3_unstructured_million_dof_vs_oracle(D):
+    """~1M-DoF unstructured stand-in: Jacobi and level-scheduled IC(0) trisolve vs oracle/pcg_oracle.c."""
+    from deeppreconditioning_amd import poisson
+    A = poisson.unstructured_like_csr(3, 100, 0)
+    n = A.shape[0]
+    b = O.rhs(n, 0)
+    S = D.CsrSystem.from_any(A)
+    S.set_preconditioner(D.Jacobi())
+    res = S.solve(_dev(b))
+    _, it, hist, x = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A))
+    assert res.iterations == it
+    np.testing.assert_allclose(res.res_history, hist, rtol=HIST_RTOL)
+    np.testing.assert_allclose(res.x.cpu().numpy(), x, rtol=1e-8, atol=1e-11)
+    S.set_preconditioner(D.IC0("solve"))
+    info = S.info()
+    assert 5 <= info["levels_lower"] <= 64            # a random ordering gives a shallow dependency DAG
+    res = S.solve(_dev(b))
+    Lref = CO.ic0(A)
+    rp, ci, v = S.factor()
+    assert np.array_equal(v, Lref.data)               # device IC(0) == CPU IC(0), bit for bit, at 1M rows
+    _, it, hist, _ = CO.pcg(A, b, "llt_solve", L=Lref)
+    assert res.iterations == it
+    np.testing.assert_allclose(res.res_history, hist, rtol=HIST_RTOL)
+
+
+def test_c5_mixed_precision_million_dof(D, golden):
+    """fp32 SpMV operands / fp64 everything else on the 1M-DoF system: residual-matched to the fp64 reference run."""
+    from deeppreconditioning_amd import poisson
+    S = poisson.poisson_system(3, 100)
+    S.set_preconditioner(D.Jacobi())
+    b = poisson.rhs(S.n, 0)
+    r32 = S.solve(b, flags=D._lib.SPMV_F32)
+    g = golden["pcg_poisson3d_100_jacobi/hist"]
+    assert abs(r32.iterations - int(golden["pcg_poisson3d_100_jacobi/iters"])) <= 2
+    m = min(len(g), len(r32.res_history))
+    np.testing.assert_allclose(r32.res_history[:m], g[:m], rtol=2e-3)   # fp32 rounding of p: ~1e-7 per update
+    r_true = b - S @ r32.x
+    assert D.dot(r_true, r_true) / D.dot(b, b) < 1.5e-8
