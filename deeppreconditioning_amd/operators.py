@@ -312,8 +312,11 @@ class CsrSystem:
         return self
 
     @classmethod
-    def from_any(cls, A, device=None) -> "CsrSystem":
-        if isinstance(A, CsrSystem):
+    def from_any(cls, A, device=None, reorder: str | None = None):
+        """`reorder="rcm"` returns a `ReorderedSystem` (same `solve` / `@` / `set_preconditioner` surface)."""
+        if reorder:
+            return ReorderedSystem(A, device, reorder)
+        if isinstance(A, (CsrSystem, ReorderedSystem)):
             return A
         space, rp, ci, v, n = csr_arrays(A)
         if space == "host":
@@ -423,6 +426,63 @@ class CsrSystem:
         k = iters.value
         return SolveResult(x, k, status, res.value, sec.value, hist[: k + 1] if hist is not None else np.empty(0),
                            err[: k + 1] if err is not None else None)
+
+
+class ReorderedSystem:
+    """A system solved in a bandwidth-reducing symmetric ordering: P A P^T (P x) = P b.
+
+    Matrices whose numbering scatters neighbours (the scrambled stand-in for OpenFOAM dumps, a mesh after
+    refinement) make every x[col] of the SpMV a separate 128-B line; reverse Cuthill-McKee brings the columns of a
+    row-block back into a few contiguous runs (and makes the x-tile kernel applicable).  The permutation is setup
+    work on the host (scipy); b is gathered and x scattered on the device around the solve.  Only preconditioners
+    that are built from A itself (None, Jacobi(), IC0(...)) can be attached: a user-supplied M or L refers to the
+    original numbering.  PCG is invariant under symmetric permutation up to the order of the floating-point sums,
+    so iteration counts match the unpermuted solve wherever the recurrence is numerically stable.
+    """
+
+    def __init__(self, A, device=None, method: str = "rcm"):
+        if method != "rcm":
+            raise ValueError("only 'rcm' is implemented")
+        import scipy.sparse as sp
+        from scipy.sparse.csgraph import reverse_cuthill_mckee
+        space, rp, ci, v, n = csr_arrays(A)
+        if space == "device":
+            rp, ci, v = rp.cpu().numpy(), ci.cpu().numpy(), v.cpu().numpy()
+        M = sp.csr_matrix((v, ci, rp), shape=(n, n))
+        perm = np.asarray(reverse_cuthill_mckee(M, symmetric_mode=True), dtype=np.int64)
+        B = M[perm][:, perm].tocsr()
+        B.sort_indices()
+        self.system = CsrSystem.from_host(B.indptr, B.indices, B.data, n, device)
+        self.device, self.n, self.nnz = self.system.device, n, self.system.nnz
+        self.perm = torch.from_numpy(perm).to(self.device)
+        self.bandwidth = int(np.abs(B.tocoo().row - B.tocoo().col).max())
+
+    def _in(self, v):
+        return None if v is None else self.system._vec(v)[self.perm]
+
+    def _out(self, v):
+        out = torch.empty_like(v)
+        out[self.perm] = v
+        return out
+
+    def info(self) -> dict:
+        return dict(self.system.info(), bandwidth=self.bandwidth, reordered="rcm")
+
+    def set_preconditioner(self, M):
+        if not (M is None or isinstance(M, (Identity, IC0)) or (isinstance(M, Jacobi) and M.dinv is None)):
+            raise TypeError("a reordered system only takes preconditioners built from A itself: None, Jacobi(), IC0(...)")
+        return self.system.set_preconditioner(M)
+
+    def __matmul__(self, v):
+        return self._out(self.system @ self._in(v))
+
+    def solve(self, b, x0=None, *, x_true=None, **kw) -> "SolveResult":
+        res = self.system.solve(self._in(b), self._in(x0), x_true=self._in(x_true), **kw)
+        res.x = self._out(res.x)
+        return res
+
+    def close(self):
+        self.system.close()
 
 
 def dot(a: torch.Tensor, b: torch.Tensor) -> float:

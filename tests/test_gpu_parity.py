@@ -618,3 +618,35 @@ def test_c5_mixed_precision_million_dof(D, golden):
     np.testing.assert_allclose(r32.res_history[:m], g[:m], rtol=2e-3)   # fp32 rounding of p: ~1e-7 per update
     r_true = b - S @ r32.x
     assert D.dot(r_true, r_true) / D.dot(b, b) < 1.5e-8
+
+
+def test_rcm_reordered_system(D):
+    """Solving in reverse Cuthill-McKee ordering gives the same PCG (counts, histories to 1e-10, x in the
+    caller's numbering) and turns the scrambled system back into a banded one."""
+    A = O.unstructured_like(O.poisson3d(24), seed=0)
+    n = A.shape[0]
+    b = O.rhs(n, 0)
+    R = D.CsrSystem.from_any(A, reorder="rcm")
+    assert isinstance(R, D.ReorderedSystem) and R.info()["bandwidth"] < n // 4
+    x = O.rhs(n, 3)
+    np.testing.assert_allclose((R @ _dev(x)).cpu().numpy(), A @ x, rtol=1e-13, atol=1e-13)
+    for pc, kind, kw in ((D.Jacobi(), "jacobi", dict(dinv=O.jacobi_dinv(A))), (None, "none", {})):
+        R.set_preconditioner(pc)
+        res = R.solve(_dev(b))
+        _, it, hist, xs = CO.pcg(A, b, kind, **kw)
+        if kind == "jacobi":
+            assert res.iterations == it
+            np.testing.assert_allclose(res.res_history, hist, rtol=1e-9)
+            np.testing.assert_allclose(res.x.cpu().numpy(), xs, rtol=1e-8, atol=1e-11)
+        else:
+            assert abs(res.iterations - it) <= 2      # unpreconditioned on the scaled system: chaotic regime
+    R.set_preconditioner(D.IC0("solve"))              # IC(0) of the REORDERED matrix: a different (valid) factor
+    res = R.solve(_dev(b))
+    r = b - A @ res.x.cpu().numpy()
+    assert res.status == 0 and np.dot(r, r) / np.dot(b, b) < 1.01e-8
+    with pytest.raises(TypeError):
+        R.set_preconditioner(D.LLtSolve(CO.ic0(A)))   # a factor in the original numbering is refused
+    from deeppreconditioning_amd.cg import preconditioned_conjugate_gradient
+    R.set_preconditioner(D.Jacobi())
+    _, its, info = preconditioned_conjugate_gradient(R, _dev(b), D.Jacobi())
+    assert its == CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A))[1] and info == 0

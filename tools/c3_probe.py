@@ -19,3 +19,9 @@ for dim, n in ((3, 16), (3, 100)):
 S = poisson.poisson_system(3, 100); b = poisson.rhs(S.n, 0)
 S.set_preconditioner(D.IC0("solve")); print("natural 100^3 ic0", S.info()); r = S.solve(b); r = S.solve(b); print(" ic0-solve", r.iterations, round(r.seconds * 1e3, 2), "ms")
 S.set_preconditioner(D.Jacobi()); r = S.solve(b, flags=D._lib.SPMV_F32); r = S.solve(b, flags=D._lib.SPMV_F32); print(" natural jacobi mixed", r.iterations, round(r.seconds * 1e3, 2), "ms", round(r.iterations / r.seconds), "it/s")
+print("---- RCM reordering of the 1M-DoF scrambled system ----")
+A = poisson.unstructured_like_csr(3, 100, 0)
+t = time.time(); R = D.CsrSystem.from_any(A, reorder="rcm"); print("rcm setup s", round(time.time() - t, 2), R.info())
+b = poisson.rhs(R.n, 0)
+R.set_preconditioner(D.Jacobi()); r = R.solve(b); r = R.solve(b); print(" rcm jacobi", r.iterations, round(r.seconds * 1e3, 2), "ms", round(r.iterations / r.seconds), "it/s")
+R.set_preconditioner(D.IC0("solve")); print(R.info()); r = R.solve(b); r = R.solve(b); print(" rcm ic0-solve", r.iterations, round(r.seconds * 1e3, 2), "ms", round(r.iterations / r.seconds), "it/s")
