@@ -650,3 +650,40 @@ def test_rcm_reordered_system(D):
     R.set_preconditioner(D.Jacobi())
     _, its, info = preconditioned_conjugate_gradient(R, _dev(b), D.Jacobi())
     assert its == CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A))[1] and info == 0
+
+
+# ---- error behaviour at the boundary: loud, typed, never a silent fallback ----------------------------------
+def test_error_paths(D):
+    from deeppreconditioning_amd._lib import DpcgError, ERR_INVALID, ERR_PIVOT, ERR_STATE
+    A = O.poisson2d(10)
+    S = D.CsrSystem.from_any(A)
+    # a system without a diagonal entry cannot take Jacobi
+    nodiag = sp.csr_matrix(np.array([[0.0, 1.0], [1.0, 2.0]]))
+    with pytest.raises(DpcgError) as e:
+        D.CsrSystem.from_any(nodiag).set_preconditioner(D.Jacobi())
+    assert e.value.status == ERR_PIVOT
+    # IC(0) of an indefinite matrix breaks down with a pivot error, as a factorisation should
+    indef = (A - 5.0 * sp.eye(A.shape[0])).tocsr()
+    with pytest.raises(DpcgError) as e:
+        D.CsrSystem.from_any(indef).set_preconditioner(D.IC0("solve"))
+    assert e.value.status == ERR_PIVOT
+    # L must be lower triangular with its diagonal last
+    with pytest.raises(DpcgError) as e:
+        S.set_preconditioner(D.LLtSolve(A))
+    assert e.value.status == ERR_INVALID
+    with pytest.raises(ValueError):
+        S.set_preconditioner(sp.eye(7, format="csr"))                       # wrong size
+    with pytest.raises(ValueError):
+        S.solve(torch.ones(5, dtype=torch.float64, device="cuda"))          # wrong vector length
+    S.set_preconditioner(D.Jacobi())
+    with pytest.raises(DpcgError) as e:
+        S.sptrsv(torch.ones(100, dtype=torch.float64, device="cuda"), upper=False)   # no factor attached
+    assert e.value.status == ERR_STATE
+    with pytest.raises(DpcgError):
+        S.solve(torch.ones(100, dtype=torch.float64, device="cuda"), max_iter=-1)
+    # a negative-definite system makes <Ap,p> < 0: CG still "converges" or caps, but never raises or hangs
+    res = D.CsrSystem.from_any((-A).tocsr()).solve(_dev(O.rhs(100, 0)), max_iter=50)
+    assert res.status in (0, 1, 2) and res.iterations <= 50
+    # after an error the handle is still usable
+    res = S.solve(_dev(O.rhs(100, 0)))
+    assert res.status == 0 and res.iterations == CO.pcg(A, O.rhs(100, 0), "jacobi", dinv=O.jacobi_dinv(A))[1]
