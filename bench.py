@@ -248,6 +248,11 @@ def extra_workloads(D, poisson, torch) -> dict:
     out["c5_mixed_precision_poisson3d_100"] = {"iterations_fp64": r64.iterations, "iterations_mixed": r32.iterations,
                                                "final_res_fp64": r64.final_res, "final_res_mixed": r32.final_res,
                                                "iterations_per_s_mixed": round(r32.iterations / r32.seconds, 1)}
+    # opt-in: matrix values streamed as fp32 because they are fp32-representable (bit-identical fp64 results)
+    rc = solve_twice(s5, b5, flags=D._lib.VAL32_IF_LOSSLESS)
+    out["lossless_fp32_value_storage_poisson3d_100"] = {
+        "iterations": rc.iterations, "final_res": rc.final_res, "bitwise_equal_to_fp64_values": bool(rc.final_res == r64.final_res),
+        "iterations_per_s": round(rc.iterations / rc.seconds, 1), "spmv_bytes_per_launch": spmv_bytes(s5.n, s5.nnz, wv=4)}
     del s5
     # config 4 (one GPU's share): 256^3 systems, 1.74 GB per SpMV, beyond the Infinity Cache -> HBM-bound
     s4 = poisson.poisson_system(3, 256)

@@ -41,18 +41,21 @@ def _system_and_device(A, b):
 
 
 def preconditioned_conjugate_gradient(A, b, M, x0=None, x_true=None, rtol=1e-8, max_iter=1024, *,
-                                      mixed_precision=False, details=False):
+                                      mixed_precision=False, compact_values=False, details=False):
     """PCG, cg.py:50-90.  Returns `(duration_seconds, iterations, info)`.
 
     `rtol` is compared with <r,r>/<b,b> (squared ratio, cg.py:71); the first test uses z0
     (cg.py:66).  `duration` covers the iteration loop only, device-synchronised (cg.py:69,88).
     Keyword-only extras: `mixed_precision` runs A@p with fp32 matrix values and an fp32 copy of p
-    (fp64 everywhere else, BASELINE config 5); `details=True` returns the full `SolveResult`.
+    (fp64 everywhere else, BASELINE config 5); `compact_values` streams the matrix values as fp32
+    when that is lossless (the reference's matrices are fp32 data upcast to fp64, test.py:68) --
+    bit-identical results, 8 instead of 12 bytes per non-zero; `details=True` returns the full
+    `SolveResult`.
     """
     del x_true  # unused by the reference's return value
     system = _system_and_device(A, b)
     system.set_preconditioner(M)
-    flags = L.SPMV_F32 if mixed_precision else 0
+    flags = (L.SPMV_F32 if mixed_precision else 0) | (L.VAL32_IF_LOSSLESS if compact_values else 0)
     result = system.solve(b, x0, rtol_sq=float(rtol), max_iter=int(max_iter), flags=flags)
     if details:
         return result

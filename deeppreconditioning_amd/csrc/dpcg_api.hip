@@ -799,7 +799,9 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
     const bool f32 = (flags & DPCG_SPMV_F32) != 0;
     IterCtl ctl{h->scal};
     // K1: (skip when done) Ap = A p + partials of <p,Ap>           cg.py:71,75,78
+    const bool v32 = !f32 && (flags & DPCG_VAL32_IF_LOSSLESS) && h->A.val32_lossless == 1;
     if (f32) launch_spmv_f32in(h->A, h->planA, h->p32, h->p, h->q, h->part_pq, &ctl, s);
+    else if (v32) launch_spmv_val32(h->A, h->planA, h->p, h->q, h->part_pq, &ctl, s);
     else launch_spmv(h->A, h->planA, h->p, h->q, h->part_pq, &ctl, s);
     // K2: alpha; r -= alpha Ap; (z = M r fused); partials <r,z>, <r,r>              cg.py:78,80-82,86
     const int pre = h->precond == DPCG_PRECOND_NONE ? 0 : (h->precond == DPCG_PRECOND_JACOBI ? 1 : 2);
@@ -822,7 +824,7 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
 }
 
 static int ensure_graph(dpcg_system *h, int flags, int chunk) {
-    const int key = (h->precond << 8) | (flags & DPCG_SPMV_F32);
+    const int key = (h->precond << 8) | (flags & (DPCG_SPMV_F32 | DPCG_VAL32_IF_LOSSLESS)) | (h->A.val32_lossless == 1 ? 64 : 0);
     if (h->graph_exec && h->graph_key == key && h->graph_chunk == chunk) return DPCG_OK;
     drop_graph(h);
     HandleExtras &ex = extras()[h];
@@ -890,6 +892,17 @@ struct Solve {
         const bool f32 = (flags & DPCG_SPMV_F32) != 0;
         HandleExtras &ex = extras()[h];
         DPCG_TRY(ensure_work(h, max_iter, f32, x_true != nullptr));
+        if ((flags & DPCG_VAL32_IF_LOSSLESS) && h->A.val32_lossless == 0) {   // decide once per matrix
+            int *d_lossy = nullptr, lossy = 0;
+            DPCG_TRY(dev_alloc(&d_lossy, 1));
+            if (!h->A.val32) DPCG_TRY(dev_alloc(&h->A.val32, h->A.nnz));
+            DPCG_HIP(hipMemsetAsync(d_lossy, 0, sizeof(int), s));
+            launch_val32_check(h->A.nnz, h->A.val, h->A.val32, d_lossy, s);
+            DPCG_HIP(hipMemcpyAsync(&lossy, d_lossy, sizeof(int), hipMemcpyDeviceToHost, s));
+            DPCG_HIP(hipStreamSynchronize(s));
+            dev_free(d_lossy);
+            h->A.val32_lossless = lossy ? -1 : 1;
+        }
         use_graph = !(flags & DPCG_NO_GRAPH) && !x_true && max_iter >= chunk;
         if (use_graph) DPCG_TRY(ensure_graph(h, flags, chunk));
         *ex.prog_host = 0;

@@ -33,6 +33,7 @@ struct CsrDev {
     int32_t *col = nullptr;
     double *val = nullptr;    // fp64 values (always present after create)
     float *val32 = nullptr;   // fp32 copy (created on demand / when given fp32)
+    int val32_lossless = 0;   // 0 unknown, 1 every (double)(float)val == val, -1 not
     bool owned = false;
 };
 
@@ -155,6 +156,11 @@ void launch_spmv(const CsrDev &A, const SpmvPlan &plan, const double *x, double 
                  const IterCtl *ctl, hipStream_t s);
 void launch_spmv_f32in(const CsrDev &A, const SpmvPlan &plan, const float *x32, const double *x64, double *y,
                        double *part_pq, const IterCtl *ctl, hipStream_t s);
+// fp32-stored values, fp64 x and arithmetic (exact when the values are fp32-representable)
+void launch_spmv_val32(const CsrDev &A, const SpmvPlan &plan, const double *x, double *y, double *part_pq,
+                       const IterCtl *ctl, hipStream_t s);
+// *lossy_dev is set to 1 if some value changes under fp64 -> fp32 -> fp64; also fills val32
+void launch_val32_check(int64_t nnz, const double *val, float *val32, int *lossy_dev, hipStream_t s);
 void launch_spmv_f32out(const CsrDev &A, const SpmvPlan &plan, const float *x32, float *y32, hipStream_t s);
 
 void launch_update_r(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,

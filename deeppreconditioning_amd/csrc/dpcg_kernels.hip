@@ -451,6 +451,33 @@ void launch_spmv_f32in(const CsrDev &A, const SpmvPlan &plan, const float *x32, 
     spmv_dispatch<float, float, double>(A, plan, A.val32, x32, x64, y, part_pq, ctl, s);
 }
 
+void launch_spmv_val32(const CsrDev &A, const SpmvPlan &plan, const double *x, double *y, double *part_pq,
+                       const IterCtl *ctl, hipStream_t s) {
+    SpmvPlan p = plan;
+    if (p.kernel == SPMV_TILE) p.kernel = SPMV_STREAM;   // the tile kernel reads fp64 values
+    spmv_dispatch<float, double, double>(A, p, A.val32, x, x, y, part_pq, ctl, s);
+}
+
+__global__ __launch_bounds__(kBlock) void k_val32_check(int64_t nnz, const double *__restrict__ val,
+                                                        float *__restrict__ val32, int *lossy) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    bool bad = false;
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += stride) {
+        const double v = val[k];
+        const float f = (float)v;
+        val32[k] = f;
+        bad = bad || ((double)f != v);
+    }
+    if (bad) atomicExch(lossy, 1);
+}
+
+void launch_val32_check(int64_t nnz, const double *val, float *val32, int *lossy_dev, hipStream_t s) {
+    int64_t g = (nnz + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_val32_check, dim3((int)g), dim3(kBlock), 0, s, nnz, val, val32, lossy_dev);
+}
+
 void launch_spmv_f32out(const CsrDev &A, const SpmvPlan &plan, const float *x32, float *y32, hipStream_t s) {
     spmv_dispatch<float, float, float>(A, plan, A.val32, x32, nullptr, y32, nullptr, nullptr, s);
 }

@@ -60,7 +60,11 @@ enum dpcg_solve_flags {
                                 reference's <z0,z0> (cg.py:66)                                      */
     DPCG_SPMV_F32 = 2,       /* mixed precision: A@p with fp32 val and fp32 p, fp64 everywhere else */
     DPCG_NO_GRAPH = 4,       /* launch kernels one by one instead of replaying a hipGraph           */
-    DPCG_NO_SMALL = 8        /* do not use the one-workgroup whole-solve kernel for systems <= 6144 rows */
+    DPCG_NO_SMALL = 8,       /* do not use the one-workgroup whole-solve kernel for systems <= 6144 rows */
+    DPCG_VAL32_IF_LOSSLESS = 16 /* stream the matrix values as fp32 when every value survives the round trip
+                                fp64 -> fp32 -> fp64 unchanged (true for the reference's data, which is fp32
+                                upcast to fp64: data_set.py:121, test.py:68): 8 instead of 12 bytes per non-zero,
+                                products and sums still fp64, results bit-identical.  Ignored when lossy. */
 };
 
 /* ---- library ------------------------------------------------------------------------------- */

@@ -687,3 +687,24 @@ def test_error_paths(D):
     # after an error the handle is still usable
     res = S.solve(_dev(O.rhs(100, 0)))
     assert res.status == 0 and res.iterations == CO.pcg(A, O.rhs(100, 0), "jacobi", dinv=O.jacobi_dinv(A))[1]
+
+
+def test_lossless_fp32_value_storage_is_bit_identical(D):
+    """DPCG_VAL32_IF_LOSSLESS: values that survive fp64->fp32->fp64 are streamed as fp32 (8 instead of 12 bytes per
+    non-zero); arithmetic stays fp64, so the solve is bitwise the same.  Lossy matrices silently keep fp64 values."""
+    flag = D._lib.VAL32_IF_LOSSLESS | D._lib.NO_SMALL
+    for A in (O.poisson3d(30), O.unstructured_like(O.poisson3d(22), 1)):      # exact in fp32 / not exact
+        S = D.CsrSystem.from_any(A)
+        S.set_preconditioner(D.Jacobi())
+        b = _dev(O.rhs(A.shape[0], 0))
+        r0 = S.solve(b, flags=D._lib.NO_SMALL)
+        r1 = S.solve(b, flags=flag)
+        assert r0.iterations == r1.iterations and np.array_equal(r0.res_history, r1.res_history)
+        assert torch.equal(r0.x, r1.x)
+    A32 = O.unstructured_like(O.poisson3d(22), 1)
+    A32.data = A32.data.astype(np.float32).astype(np.float64)                  # the reference's data: fp32 upcast (test.py:68)
+    S = D.CsrSystem.from_any(A32)
+    S.set_preconditioner(D.Jacobi())
+    b = _dev(O.rhs(A32.shape[0], 0))
+    r0, r1 = S.solve(b, flags=D._lib.NO_SMALL), S.solve(b, flags=flag)
+    assert np.array_equal(r0.res_history, r1.res_history) and torch.equal(r0.x, r1.x)
