@@ -708,3 +708,25 @@ def test_lossless_fp32_value_storage_is_bit_identical(D):
     b = _dev(O.rhs(A32.shape[0], 0))
     r0, r1 = S.solve(b, flags=D._lib.NO_SMALL), S.solve(b, flags=flag)
     assert np.array_equal(r0.res_history, r1.res_history) and torch.equal(r0.x, r1.x)
+
+
+def test_solve_batch_general_path_interleaves_streams(D):
+    """Systems too large for the one-workgroup kernel are interleaved on several HIP streams (non-blocking state
+    machines): same results as solving them one by one, whatever the stream count."""
+    from deeppreconditioning_amd.batch import solve_batch
+    mats = [O.poisson3d(24), O.poisson2d(100), O.unstructured_like(O.poisson3d(22), 2), O.poisson2d(64), O.poisson3d(26)]
+    systems, rhs_list, single = [], [], []
+    for i, A in enumerate(mats):
+        S = D.CsrSystem.from_any(A)
+        S.set_preconditioner(D.Jacobi())
+        b = _dev(O.rhs(A.shape[0], i))
+        systems.append(S)
+        rhs_list.append(b)
+        single.append(S.solve(b, flags=D._lib.NO_SMALL))
+    for n_streams in (1, 3, 8):
+        out = solve_batch(systems, rhs_list, n_streams=n_streams)
+        for s, o, A in zip(single, out, mats):
+            assert o.iterations == s.iterations and o.status == 0
+            assert torch.equal(o.x, s.x)
+    its = [CO.pcg(A, O.rhs(A.shape[0], i), "jacobi", dinv=O.jacobi_dinv(A))[1] for i, A in enumerate(mats)]
+    assert [s.iterations for s in single] == its
