@@ -107,6 +107,7 @@ static void free_levels(Levels &l) {
     dev_free(l.level_ptr_dev);
     dev_free(l.lo_rowptr);
     dev_free(l.lo_col);
+    dev_free(l.lo_cpos);
     dev_free(l.lo_val);
     l = Levels();
 }
@@ -502,9 +503,15 @@ static int upload_levels(Levels &lv, const std::vector<int32_t> &rows_sorted, co
             const int32_t je = std::min<int32_t>(jb + kStreamRows, level_ptr[l + 1]);
             if (lo_rp[je] - lo_rp[jb] > kStreamCap) { lv.stream_ok = false; break; }
         }
+    // level-order position of every entry's column
+    std::vector<int32_t> pos((size_t)n), lo_cp((size_t)nnz);
+    for (int64_t j = 0; j < n; ++j) pos[rows_sorted[j]] = (int32_t)j;
+    for (int64_t k = 0; k < nnz; ++k) lo_cp[k] = pos[lo_ci[k]];
     DPCG_TRY(dev_alloc(&lv.lo_rowptr, n + 1));
     DPCG_TRY(dev_alloc(&lv.lo_col, nnz));
+    DPCG_TRY(dev_alloc(&lv.lo_cpos, nnz));
     DPCG_TRY(dev_alloc(&lv.lo_val, nnz));
+    DPCG_HIP(hipMemcpyAsync(lv.lo_cpos, lo_cp.data(), lo_cp.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
     DPCG_HIP(hipMemcpyAsync(lv.lo_rowptr, lo_rp.data(), lo_rp.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
     DPCG_HIP(hipMemcpyAsync(lv.lo_col, lo_ci.data(), lo_ci.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
     DPCG_HIP(hipMemcpyAsync(lv.lo_val, lo_v.data(), lo_v.size() * sizeof(double), hipMemcpyHostToDevice, s));
@@ -524,6 +531,19 @@ static int upload_levels(Levels &lv, const std::vector<int32_t> &rows_sorted, co
         seg.lo = l;
         seg.hi = e;
         seg.merged = narrow && (e - l) >= 2;
+        seg.ring_w = 0;
+        if (seg.merged) {
+            // LDS ring: in level order, how far back do this segment's rows reach (within the segment)?
+            const int32_t seg_start = level_ptr[l];
+            int64_t maxdist = 0, width = 0;
+            for (int q = l; q < e; ++q) width = std::max<int64_t>(width, level_ptr[q + 1] - level_ptr[q]);
+            for (int32_t j = seg_start; j < level_ptr[e]; ++j)
+                for (int32_t k = lo_rp[j]; k < lo_rp[j + 1]; ++k)
+                    if (lo_cp[k] >= seg_start && lo_cp[k] < j) maxdist = std::max<int64_t>(maxdist, j - lo_cp[k]);
+            int64_t w = 64;
+            while (w < maxdist + width + 1) w *= 2;
+            if (w <= 8192) seg.ring_w = (int)w;            // 64 KiB of LDS at most
+        }
         lv.segments.push_back(seg);
         l = e;
     }

@@ -93,13 +93,16 @@ struct Levels {
     int n_levels = 0;
     int32_t *rows = nullptr;               // device: rows sorted by (level, row)
     std::vector<int32_t> level_ptr;        // host: offsets into rows, n_levels+1
-    struct Segment { int lo, hi; bool merged; };  // [lo,hi) levels; merged = one workgroup walks them
+    // [lo,hi) levels; merged = one workgroup walks them; ring_w > 0: the solution entries the segment's rows depend
+    // on lie within the last ring_w level-order positions, so they are handed from level to level through LDS
+    struct Segment { int lo, hi; bool merged; int ring_w; };
     std::vector<Segment> segments;
     int32_t *level_ptr_dev = nullptr;      // device copy of level_ptr
     // the factor once more, rows stored in level order (row j of this copy = original row rows[j]): the
     // rows of a level are contiguous, so a level streams its val/col segment coalesced like the SpMV does
     int32_t *lo_rowptr = nullptr;
     int32_t *lo_col = nullptr;
+    int32_t *lo_cpos = nullptr;            // level-order position of each entry's column (position of row lo_col[k])
     double *lo_val = nullptr;
     bool stream_ok = false;                // every 256-row block of every wide level fits the LDS product buffer
 };

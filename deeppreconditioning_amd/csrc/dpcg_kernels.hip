@@ -5,6 +5,7 @@
 // kernel boundaries / bytes per PCG iteration as possible.  Compiled with -ffp-contract=off so
 // that a*b+c is two roundings, as in the CPU reference path (scipy/ATen CSR row sums, unfused
 // torch mul+add at cg.py:79-83); the in-order row sums below then reproduce the oracle bit for bit.
+#include <algorithm>
 #include <type_traits>
 
 #include "dpcg_internal.h"
@@ -945,9 +946,116 @@ __global__ __launch_bounds__(kMergedBlock) void k_sptrsv_merged(const int32_t *_
     }
 }
 
+// The same walk with the dependencies handed over through an LDS ring instead of L2.  In level order the
+// entries a banded factor's rows depend on sit within the last W positions (for a 5-point grid: the previous
+// anti-diagonal), so y lives in a ring of W doubles indexed by position & (W-1); entries solved before this
+// segment are read from `out` (written by earlier kernels).  Everything that does not depend on y -- the row
+// id, rhs, extents and the first three entries of the NEXT level's rows -- is loaded one level ahead, so a
+// level costs an LDS round trip, a division and a barrier instead of three dependent L2 round trips.
+constexpr int kRingE = 3;   // entries per row held in registers one level ahead
+template <bool UPPER>
+__global__ __launch_bounds__(kMergedBlock) void k_sptrsv_ring(const int32_t *__restrict__ rows,
+                                                              const int32_t *__restrict__ level_ptr, int lvl_lo,
+                                                              int lvl_hi, const int32_t *__restrict__ lo_rp,
+                                                              const int32_t *__restrict__ lo_ci,
+                                                              const int32_t *__restrict__ lo_cpos,
+                                                              const double *__restrict__ lo_v,
+                                                              const double *__restrict__ rhs, double *out,
+                                                              int seg_start, int W) {
+    extern __shared__ __attribute__((aligned(16))) double ring[];
+    struct Row {
+        int j, i, s, e;
+        double b, diag;
+        int cpos[kRingE], ci[kRingE];
+        double v[kRingE];
+    };
+    const int t = threadIdx.x;
+    auto load_row = [&](Row &r, int j, int hi) {
+        r.j = j < hi ? j : -1;
+        if (r.j < 0) return;
+        r.i = rows[j];
+        r.s = lo_rp[j];
+        r.e = lo_rp[j + 1];
+        r.b = rhs[r.i];
+        r.diag = lo_v[UPPER ? r.s : r.e - 1];
+        const int ks = UPPER ? r.s + 1 : r.s, ke = UPPER ? r.e : r.e - 1;
+#pragma unroll
+        for (int m = 0; m < kRingE; ++m) {
+            const int k = ks + m < ke ? ks + m : ks;      // clamped: an unused slot re-reads a valid entry
+            r.cpos[m] = ks < ke ? lo_cpos[k] : 0;
+            r.ci[m] = ks < ke ? lo_ci[k] : 0;
+            r.v[m] = ks < ke ? lo_v[k] : 0.0;
+        }
+    };
+    auto solve_row = [&](const Row &r) {
+        if (r.j < 0) return;
+        const int ks = UPPER ? r.s + 1 : r.s, ke = UPPER ? r.e : r.e - 1;
+        double acc = r.b;
+#pragma unroll
+        for (int m = 0; m < kRingE; ++m)
+            if (ks + m < ke) {
+                const double yv = r.cpos[m] >= seg_start ? ring[r.cpos[m] & (W - 1)] : out[r.ci[m]];
+                acc -= r.v[m] * yv;
+            }
+        for (int k = ks + kRingE; k < ke; ++k) {           // longer rows: the rest straight from memory
+            const int cp = lo_cpos[k];
+            const double yv = cp >= seg_start ? ring[cp & (W - 1)] : out[lo_ci[k]];
+            acc -= lo_v[k] * yv;
+        }
+        const double y = acc / r.diag;
+        ring[r.j & (W - 1)] = y;
+        out[r.i] = y;
+    };
+    // Two register sets in ping-pong (no register moves: a move of a register with a load in flight would wait
+    // for it).  Each thread owns at most two rows of a level (levels of a merged run have <= 2048 rows).
+    auto load_level = [&](Row &a, Row &b, int lvl) {
+        if (lvl < lvl_hi) {
+            const int lo = level_ptr[lvl], hi = level_ptr[lvl + 1];
+            load_row(a, lo + t, hi);
+            load_row(b, lo + t + (int)blockDim.x, hi);
+        } else {
+            a.j = b.j = -1;
+        }
+    };
+    // LDS-only hand-off: wait for this wave's ring writes, then the workgroup barrier.  A __syncthreads() would
+    // also drain vmcnt, i.e. wait for the out[] store and for the prefetch loads that must stay in flight.
+    auto level_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    Row a0, b0, a1, b1;
+    load_level(a0, b0, lvl_lo);
+    for (int lvl = lvl_lo; lvl < lvl_hi; lvl += 2) {
+        load_level(a1, b1, lvl + 1);        // flies while level `lvl` is solved
+        solve_row(a0);
+        solve_row(b0);
+        level_barrier();
+        if (lvl + 1 >= lvl_hi) break;
+        load_level(a0, b0, lvl + 2);
+        solve_row(a1);
+        solve_row(b1);
+        level_barrier();
+    }
+}
+
 void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s) {
     (void)T;  // the level-ordered copy in `lv` carries the factor
     for (const auto &seg : lv.segments) {
+        if (seg.merged && seg.ring_w > 0) {
+            const size_t lds = (size_t)seg.ring_w * sizeof(double);
+            const int seg_start = lv.level_ptr[seg.lo];
+            // as few waves as the widest level needs (two rows per thread): a barrier among 4 waves is cheaper
+            int width = 0;
+            for (int q = seg.lo; q < seg.hi; ++q) width = std::max(width, lv.level_ptr[q + 1] - lv.level_ptr[q]);
+            int threads = ((width + 1) / 2 + 63) / 64 * 64;
+            threads = threads < 64 ? 64 : (threads > kMergedBlock ? kMergedBlock : threads);
+            if (upper)
+                hipLaunchKernelGGL(k_sptrsv_ring<true>, dim3(1), dim3(threads), lds, s, lv.rows, lv.level_ptr_dev,
+                                   seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, rhs, out, seg_start,
+                                   seg.ring_w);
+            else
+                hipLaunchKernelGGL(k_sptrsv_ring<false>, dim3(1), dim3(threads), lds, s, lv.rows, lv.level_ptr_dev,
+                                   seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, rhs, out, seg_start,
+                                   seg.ring_w);
+            continue;
+        }
         if (seg.merged) {
             if (upper)
                 hipLaunchKernelGGL(k_sptrsv_merged<true>, dim3(1), dim3(kMergedBlock), 0, s, lv.rows, lv.level_ptr_dev,
