@@ -1063,6 +1063,7 @@ static SmallDesc make_small_desc(dpcg_system *h, const double *b, const double *
     d.init_check_r = (flags & DPCG_INIT_CHECK_R) ? 1 : 0;
     d.hist_cap = h->hist_cap;
     d.lds_vectors = h->precond == DPCG_PRECOND_CSR ? 2 : (h->precond == DPCG_PRECOND_LLT_MULTIPLY ? 3 : 1);
+    d.variant = small_variant((int)h->A.n, h->ell_a.W, h->precond);
     d.rp = h->A.rowptr; d.dinv = h->dinv;
     d.ell_a = h->ell_a; d.ell_m = h->ell_m; d.ell_t = h->ell_t;
     if (h->precond == DPCG_PRECOND_CSR) d.m_rp = h->M.rowptr;
@@ -1073,6 +1074,7 @@ static SmallDesc make_small_desc(dpcg_system *h, const double *b, const double *
     return d;
 }
 
+static int small_variant_bit(const SmallDesc &d) { return d.variant == 3 * 16 + 7 ? 2 : (d.variant == 4 * 16 + 5 ? 4 : 1); }
 static int small_lds_bytes(const SmallDesc &d) { return (int)(((size_t)d.lds_vectors * d.n + 64) * sizeof(double)); }
 
 static int solve_small_one(dpcg_system *h, const double *b, const double *x0, double *x, double rtol_sq, double atol_sq,
@@ -1085,7 +1087,7 @@ static int solve_small_one(dpcg_system *h, const double *b, const double *x0, do
     DPCG_HIP(hipMemcpyAsync(h->small_desc, &d, sizeof(d), hipMemcpyHostToDevice, s));
     DPCG_HIP(hipStreamSynchronize(s));
     const auto t0 = std::chrono::steady_clock::now();                                // cg.py:69 (the launch is the loop)
-    DPCG_TRY(launch_pcg_small(h->small_desc, 1, small_lds_bytes(d), 1 << h->precond, s));
+    DPCG_TRY(launch_pcg_small(h->small_desc, 1, small_lds_bytes(d), 1 << h->precond, small_variant_bit(d), s));
     DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
     const auto t1 = std::chrono::steady_clock::now();                                // cg.py:88
@@ -1149,7 +1151,7 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
     if (all_small) {
         // one launch, one workgroup (one CU) per system
         std::vector<SmallDesc> descs((size_t)count);
-        int lds = 0, kinds = 0;
+        int lds = 0, kinds = 0, variants = 0;
         for (int i = 0; i < count; ++i) {
             kinds |= 1 << handles[i]->precond;
             DPCG_TRY(ensure_work(handles[i], max_iter, false, false));
@@ -1157,13 +1159,14 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
             descs[i] = make_small_desc(handles[i], b[i], x0 ? x0[i] : nullptr, x ? x[i] : nullptr, rtol_sq, atol_sq,
                                        max_iter, flags);
             lds = std::max(lds, small_lds_bytes(descs[i]));
+            variants |= small_variant_bit(descs[i]);
         }
         SmallDesc *d_descs = nullptr;
         std::vector<Scalars> out((size_t)count);
         DPCG_TRY(dev_alloc(&d_descs, count));
         hipError_t e = hipMemcpy(d_descs, descs.data(), descs.size() * sizeof(SmallDesc), hipMemcpyHostToDevice);
         const auto t0 = std::chrono::steady_clock::now();
-        int st = e == hipSuccess ? launch_pcg_small(d_descs, count, lds, kinds, nullptr) : DPCG_ERR_HIP;
+        int st = e == hipSuccess ? launch_pcg_small(d_descs, count, lds, kinds, variants, nullptr) : DPCG_ERR_HIP;
         if (e == hipSuccess) e = hipDeviceSynchronize();
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         for (int i = 0; i < count && e == hipSuccess; ++i)

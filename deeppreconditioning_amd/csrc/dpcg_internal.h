@@ -78,6 +78,7 @@ struct SmallEll {                     // slab-ELL copy of a small matrix (dpcg_s
 };
 struct SmallDesc {
     int n, precond, max_iter, init_check_r, hist_cap, lds_vectors;
+    int variant;                      // rows-per-thread * 16 + register width of the kernel variant (dpcg_small.hip)
     const int32_t *rp;                // row pointers of A (row lengths)
     const double *dinv;
     const int32_t *m_rp;              // row pointers of CSR M, or of L for LLT_MULTIPLY
@@ -200,7 +201,9 @@ void launch_tile_plan(const CsrDev &A, int nrb, int32_t *chunks, int32_t *nchunk
 void launch_max_row_len(int n, const int32_t *rp, int *out_dev, hipStream_t s);
 void launch_build_ell(int n, const int32_t *rp, const int32_t *ci, const double *v, int W, int32_t *ell_col,
                       double *ell_val, hipStream_t s);
-int launch_pcg_small(const SmallDesc *descs_dev, int count, int lds_bytes, int kinds_mask, hipStream_t s);
+int small_variant(int n, int max_row_len, int precond);
+int launch_pcg_small(const SmallDesc *descs_dev, int count, int lds_bytes, int kinds_mask, int variants_mask,
+                     hipStream_t s);
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
                       hipStream_t s);
 void launch_block_nnz_max(const CsrDev &A, int rows_per_block, int *out_max_dev, hipStream_t s);

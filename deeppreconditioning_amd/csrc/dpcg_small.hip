@@ -70,45 +70,87 @@ void launch_build_ell(int n, const int32_t *rp, const int32_t *ci, const double 
 
 // q[k] = (row t + 1024 k) . xs with xs in LDS.  Entry index j is the OUTER loop so that the loads of all six
 // rows of a thread are in flight together (memory-level parallelism); each row's sum still runs in column order.
-__device__ __forceinline__ void small_spmv(const SmallEll &E, const int (&len)[kSmallRows], const double *xs,
-                                           double (&q)[kSmallRows]) {
+template <int RR>
+__device__ __forceinline__ void small_spmv(const SmallEll &E, const int (&len)[RR], const double *xs,
+                                           double (&q)[RR]) {
     const int t = threadIdx.x;
     int lmax = 0;
 #pragma unroll
-    for (int k = 0; k < kSmallRows; ++k) {
+    for (int k = 0; k < RR; ++k) {
         q[k] = 0.0;
         lmax = len[k] > lmax ? len[k] : lmax;
     }
     const size_t slab = (size_t)E.W * kSmallThreads;
 #pragma unroll 2
     for (int j = 0; j < lmax; ++j) {
-        int cc[kSmallRows];
-        double vv[kSmallRows];
+        int cc[RR];
+        double vv[RR];
 #pragma unroll
-        for (int k = 0; k < kSmallRows; ++k) {
+        for (int k = 0; k < RR; ++k) {
             const size_t o = (size_t)k * slab + (size_t)(j < len[k] ? j : 0) * kSmallThreads + t;
             cc[k] = len[k] > 0 ? E.col[o] : 0;
             vv[k] = len[k] > 0 ? E.val[o] : 0.0;
         }
 #pragma unroll
-        for (int k = 0; k < kSmallRows; ++k)
+        for (int k = 0; k < RR; ++k)
             if (j < len[k]) q[k] += vv[k] * xs[cc[k]];
     }
 }
 
-__device__ __forceinline__ void small_rows(int n, const int32_t *__restrict__ rp, int (&len)[kSmallRows]) {
+// The matrix of a really small system (<= RR rows per thread, <= WR entries per row) fits the register file:
+// it is read ONCE before the loop; an update then touches no global memory at all except the history word.
+template <int RR, int WR>
+struct RegMatrix {
+    static constexpr int WP = WR > 0 ? (WR + 1) / 2 : 1;
+    double v[RR][WR > 0 ? WR : 1];
+    unsigned c2[RR][WP];      // two 16-bit column indices per register (n <= 6144 < 65536)
+    __device__ __forceinline__ void load(const SmallEll &E, const int (&len)[RR]) {
+        const int t = threadIdx.x;
+        const size_t slab = (size_t)E.W * kSmallThreads;
 #pragma unroll
-    for (int k = 0; k < kSmallRows; ++k) {
+        for (int k = 0; k < RR; ++k) {
+#pragma unroll
+            for (int j = 0; j < WP; ++j) c2[k][j] = 0u;
+#pragma unroll
+            for (int j = 0; j < WR; ++j) {
+                // entries beyond the row's length become 0.0 * x[col of entry 0]: the sum below then runs
+                // branch-free over all WR slots (adding +-0.0 changes nothing)
+                const size_t o = (size_t)k * slab + (size_t)(j < len[k] ? j : 0) * kSmallThreads + t;
+                v[k][j] = (len[k] > 0 && j < len[k]) ? E.val[o] : 0.0;
+                const unsigned c = len[k] > 0 ? (unsigned)E.col[o] : 0u;
+                c2[k][j / 2] |= (j & 1) ? (c << 16) : c;
+            }
+        }
+    }
+    __device__ __forceinline__ void spmv(const int (&len)[RR], const double *xs, double (&q)[RR]) const {
+#pragma unroll
+        for (int k = 0; k < RR; ++k) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < WR; ++j)
+                s += v[k][j] * xs[(j & 1) ? (c2[k][j / 2] >> 16) : (c2[k][j / 2] & 0xffffu)];
+            q[k] = s;
+        }
+        (void)len;
+    }
+};
+
+template <int RR>
+__device__ __forceinline__ void small_rows(int n, const int32_t *__restrict__ rp, int (&len)[RR]) {
+#pragma unroll
+    for (int k = 0; k < RR; ++k) {
         const int i = (int)threadIdx.x + k * kSmallThreads;
         len[k] = i < n ? rp[i + 1] - rp[i] : 0;
     }
 }
 
 // PRE: DPCG_PRECOND_NONE / JACOBI / CSR / LLT_MULTIPLY (compile-time, so each variant carries only its state)
-template <int PRE>
+// RR = rows per thread this variant is compiled for, WR = register width of the matrix (0: stream it from L2)
+template <int PRE, int RR, int WR>
 __global__ __launch_bounds__(kSmallThreads) void k_pcg_small(const SmallDesc *__restrict__ descs) {
     const SmallDesc d = descs[blockIdx.x];
-    if (d.precond != PRE) return;           // a mixed batch is launched once per preconditioner kind
+    if (d.precond != PRE || d.variant != (RR * 16 + WR)) return;   // a mixed batch is launched once per variant present
+    constexpr int kSmallRows = RR;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int n = d.n;
     double *ps = lds;                 // p, gathered by A p
@@ -117,9 +159,18 @@ __global__ __launch_bounds__(kSmallThreads) void k_pcg_small(const SmallDesc *__
     double *red = lds + (size_t)d.lds_vectors * n;   // 64 doubles
     int phase = 0;
     const int t = threadIdx.x;
-    double x[kSmallRows], r[kSmallRows], p[kSmallRows], q[kSmallRows], z[kSmallRows], dinv[kSmallRows];
+    constexpr bool kFusedZ = PRE == DPCG_PRECOND_NONE || PRE == DPCG_PRECOND_JACOBI;   // z = r or dinv*r on the fly
+    double x[kSmallRows], r[kSmallRows], p[kSmallRows], q[kSmallRows], dinv[kSmallRows];
+    double z[kFusedZ ? 1 : kSmallRows];
+    auto zk = [&](int k) -> double {
+        if (PRE == DPCG_PRECOND_NONE) return r[k];
+        if (PRE == DPCG_PRECOND_JACOBI) return dinv[k] * r[k];
+        return z[kFusedZ ? 0 : k];
+    };
     int len[kSmallRows], mlen[kSmallRows], tlen[kSmallRows];
     small_rows(n, d.rp, len);               // the row lengths never change: read them once
+    RegMatrix<RR, WR> regA;
+    if (WR > 0) regA.load(d.ell_a, len);
     if (PRE == DPCG_PRECOND_CSR || PRE == DPCG_PRECOND_LLT_MULTIPLY) small_rows(n, d.m_rp, mlen);
     if (PRE == DPCG_PRECOND_LLT_MULTIPLY) small_rows(n, d.t_rp, tlen);
 #pragma unroll
@@ -130,12 +181,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_pcg_small(const SmallDesc *__
 
     // z = M r for this thread's rows (cg.py:61,81)
     auto apply_precond = [&]() {
-        if (PRE == DPCG_PRECOND_NONE) {
-#pragma unroll
-            for (int k = 0; k < kSmallRows; ++k) z[k] = r[k];
-        } else if (PRE == DPCG_PRECOND_JACOBI) {
-#pragma unroll
-            for (int k = 0; k < kSmallRows; ++k) z[k] = dinv[k] * r[k];
+        if (kFusedZ) {
+            // nothing to store: zk(k) recomputes r or dinv*r where it is used
         } else {
 #pragma unroll
             for (int k = 0; k < kSmallRows; ++k) {
@@ -144,7 +191,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_pcg_small(const SmallDesc *__
             }
             __syncthreads();
             if (PRE == DPCG_PRECOND_CSR) {
-                small_spmv(d.ell_m, mlen, w1, z);                                  // z = M r
+                small_spmv(d.ell_m, mlen, w1, q);                                  // z = M r (q is free here)
             } else {                                                              // z = L (L^T r)
                 double tmp[kSmallRows];
                 small_spmv(d.ell_t, tlen, w1, tmp);
@@ -154,8 +201,10 @@ __global__ __launch_bounds__(kSmallThreads) void k_pcg_small(const SmallDesc *__
                     if (i < n) w2[i] = tmp[k];
                 }
                 __syncthreads();
-                small_spmv(d.ell_m, mlen, w2, z);
+                small_spmv(d.ell_m, mlen, w2, q);
             }
+#pragma unroll
+            for (int k = 0; k < kSmallRows; ++k) z[kFusedZ ? 0 : k] = q[k];
             __syncthreads();  // w1/w2 are rewritten by the next apply
         }
     };
@@ -177,7 +226,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_pcg_small(const SmallDesc *__
             if (i < n) ps[i] = x[k];
         }
         __syncthreads();
-        small_spmv(d.ell_a, len, ps, q);
+        if (WR > 0) regA.spmv(len, ps, q);
+        else small_spmv(d.ell_a, len, ps, q);
 #pragma unroll
         for (int k = 0; k < kSmallRows; ++k) r[k] = r[k] - q[k];
         __syncthreads();
@@ -187,10 +237,11 @@ __global__ __launch_bounds__(kSmallThreads) void k_pcg_small(const SmallDesc *__
 #pragma unroll
     for (int k = 0; k < kSmallRows; ++k) {
         const int i = t + k * kSmallThreads;
-        p[k] = z[k];                                                               // cg.py:62
-        if (i < n) ps[i] = z[k];
-        a_rz += r[k] * z[k];
-        a_t += d.init_check_r ? r[k] * r[k] : z[k] * z[k];                         // cg.py:66 tests zk
+        const double zi = zk(k);
+        p[k] = zi;                                                                 // cg.py:62
+        if (i < n) ps[i] = zi;
+        a_rz += r[k] * zi;
+        a_t += d.init_check_r ? r[k] * r[k] : zi * zi;                             // cg.py:66 tests zk
     }
     small_reduce2(a_bb, a_dummy, red, phase);
     small_reduce2(a_rz, a_t, red, phase);                                          // also orders the ps writes
@@ -205,7 +256,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_pcg_small(const SmallDesc *__
 
     // ---- the loop (cg.py:70-87) ----
     while (status == DPCG_MAX_ITER && it < d.max_iter) {
-        small_spmv(d.ell_a, len, ps, q);                                           // cg.py:75
+        if (WR > 0) regA.spmv(len, ps, q);                                         // cg.py:75
+        else small_spmv(d.ell_a, len, ps, q);
         double a_pq = 0.0, a_z = 0.0;
 #pragma unroll
         for (int k = 0; k < kSmallRows; ++k) a_pq += p[k] * q[k];
@@ -220,7 +272,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_pcg_small(const SmallDesc *__
         double a_rzn = 0.0, a_rr = 0.0;
 #pragma unroll
         for (int k = 0; k < kSmallRows; ++k) {
-            a_rzn += r[k] * z[k];
+            a_rzn += r[k] * zk(k);
             a_rr += r[k] * r[k];
         }
         small_reduce2(a_rzn, a_rr, red, phase);   // every wave is past its reads of ps here
@@ -229,7 +281,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_pcg_small(const SmallDesc *__
 #pragma unroll
         for (int k = 0; k < kSmallRows; ++k) {
             const int i = t + k * kSmallThreads;
-            p[k] = z[k] + beta * p[k];                                             // cg.py:83
+            p[k] = zk(k) + beta * p[k];                                            // cg.py:83
             if (i < n) ps[i] = p[k];
         }
         __syncthreads();
@@ -255,28 +307,51 @@ __global__ __launch_bounds__(kSmallThreads) void k_pcg_small(const SmallDesc *__
     }
 }
 
-template <int PRE>
+template <int PRE, int RR, int WR>
 static int launch_one(const SmallDesc *descs_dev, int count, int lds_bytes, hipStream_t s) {
     static int attr_set_for = 0;
     if (lds_bytes > attr_set_for) {
-        if (hipFuncSetAttribute((const void *)k_pcg_small<PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) !=
-            hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_pcg_small<PRE, RR, WR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_bytes) != hipSuccess)
             return DPCG_ERR_HIP;
         attr_set_for = lds_bytes;
     }
-    hipLaunchKernelGGL(k_pcg_small<PRE>, dim3(count), dim3(kSmallThreads), (size_t)lds_bytes, s, descs_dev);
+    hipLaunchKernelGGL((k_pcg_small<PRE, RR, WR>), dim3(count), dim3(kSmallThreads), (size_t)lds_bytes, s, descs_dev);
     return DPCG_OK;
 }
 
-// kinds_mask: bit p set = some system of the batch uses preconditioner kind p (one launch per kind present;
-// workgroups of another kind return at once).
-int launch_pcg_small(const SmallDesc *descs_dev, int count, int lds_bytes, int kinds_mask, hipStream_t s) {
+// Register-resident variants exist for M in {I, Jacobi}: (3 rows/thread, <= 7 entries/row) covers n <= 3072 -- the
+// reference's res-2 meshes (2424 rows) -- and (4, <= 5) covers 5-point systems up to 4096 rows.
+int small_variant(int n, int max_row_len, int precond) {
+    const int rows = (n + kSmallThreads - 1) / kSmallThreads;
+    if (precond == DPCG_PRECOND_NONE || precond == DPCG_PRECOND_JACOBI) {
+        if (rows <= 3 && max_row_len <= 7) return 3 * 16 + 7;
+        if (rows <= 4 && max_row_len <= 5) return 4 * 16 + 5;
+    }
+    return (kSmallMaxN / kSmallThreads) * 16 + 0;
+}
+
+// kinds_mask: bit p set = some system of the batch uses preconditioner kind p; variants_mask: bit 0 = streamed
+// matrix, bit 1 = (3,7) registers, bit 2 = (4,5) registers.  One launch per combination present; workgroups of
+// another combination return at once.
+int launch_pcg_small(const SmallDesc *descs_dev, int count, int lds_bytes, int kinds_mask, int variants_mask,
+                     hipStream_t s) {
     int st = DPCG_OK;
-    if (st >= 0 && (kinds_mask & (1 << DPCG_PRECOND_NONE))) st = launch_one<DPCG_PRECOND_NONE>(descs_dev, count, lds_bytes, s);
-    if (st >= 0 && (kinds_mask & (1 << DPCG_PRECOND_JACOBI))) st = launch_one<DPCG_PRECOND_JACOBI>(descs_dev, count, lds_bytes, s);
-    if (st >= 0 && (kinds_mask & (1 << DPCG_PRECOND_CSR))) st = launch_one<DPCG_PRECOND_CSR>(descs_dev, count, lds_bytes, s);
-    if (st >= 0 && (kinds_mask & (1 << DPCG_PRECOND_LLT_MULTIPLY)))
-        st = launch_one<DPCG_PRECOND_LLT_MULTIPLY>(descs_dev, count, lds_bytes, s);
+    constexpr int R6 = kSmallMaxN / kSmallThreads;
+#define DPCG_SMALL(PREV)                                                                                              \
+    if (st >= 0 && (kinds_mask & (1 << PREV)) && (variants_mask & 1)) st = launch_one<PREV, R6, 0>(descs_dev, count, lds_bytes, s)
+    DPCG_SMALL(DPCG_PRECOND_NONE);
+    DPCG_SMALL(DPCG_PRECOND_JACOBI);
+    DPCG_SMALL(DPCG_PRECOND_CSR);
+    DPCG_SMALL(DPCG_PRECOND_LLT_MULTIPLY);
+#undef DPCG_SMALL
+#define DPCG_SMALL_REG(PREV, RRV, WRV, BIT)                                                                           \
+    if (st >= 0 && (kinds_mask & (1 << PREV)) && (variants_mask & BIT)) st = launch_one<PREV, RRV, WRV>(descs_dev, count, lds_bytes, s)
+    DPCG_SMALL_REG(DPCG_PRECOND_NONE, 3, 7, 2);
+    DPCG_SMALL_REG(DPCG_PRECOND_JACOBI, 3, 7, 2);
+    DPCG_SMALL_REG(DPCG_PRECOND_NONE, 4, 5, 4);
+    DPCG_SMALL_REG(DPCG_PRECOND_JACOBI, 4, 5, 4);
+#undef DPCG_SMALL_REG
     return st;
 }
 
