@@ -1064,6 +1064,7 @@ static SmallDesc make_small_desc(dpcg_system *h, const double *b, const double *
     d.hist_cap = h->hist_cap;
     d.lds_vectors = h->precond == DPCG_PRECOND_CSR ? 2 : (h->precond == DPCG_PRECOND_LLT_MULTIPLY ? 3 : 1);
     d.variant = small_variant((int)h->A.n, h->ell_a.W, h->precond);
+    if (d.variant % 16 != 0) d.lds_vectors = 3;   // register-matrix variants: p, x and dinv live in LDS
     d.rp = h->A.rowptr; d.dinv = h->dinv;
     d.ell_a = h->ell_a; d.ell_m = h->ell_m; d.ell_t = h->ell_t;
     if (h->precond == DPCG_PRECOND_CSR) d.m_rp = h->M.rowptr;
@@ -1074,7 +1075,7 @@ static SmallDesc make_small_desc(dpcg_system *h, const double *b, const double *
     return d;
 }
 
-static int small_variant_bit(const SmallDesc &d) { return d.variant == 3 * 16 + 7 ? 2 : (d.variant == 4 * 16 + 5 ? 4 : 1); }
+static int small_variant_bit(const SmallDesc &d) { return d.variant == 4 * 16 + 7 ? 2 : (d.variant == 6 * 16 + 5 ? 4 : 1); }
 static int small_lds_bytes(const SmallDesc &d) { return (int)(((size_t)d.lds_vectors * d.n + 64) * sizeof(double)); }
 
 static int solve_small_one(dpcg_system *h, const double *b, const double *x0, double *x, double rtol_sq, double atol_sq,
@@ -1162,16 +1163,19 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
             variants |= small_variant_bit(descs[i]);
         }
         SmallDesc *d_descs = nullptr;
+        Scalars *d_out = nullptr;            // one contiguous result array: a single copy back for the whole batch
         std::vector<Scalars> out((size_t)count);
         DPCG_TRY(dev_alloc(&d_descs, count));
+        int st_alloc = dev_alloc(&d_out, count);
+        if (st_alloc < 0) { dev_free(d_descs); return st_alloc; }
+        for (int i = 0; i < count; ++i) descs[i].out = d_out + i;
         hipError_t e = hipMemcpy(d_descs, descs.data(), descs.size() * sizeof(SmallDesc), hipMemcpyHostToDevice);
         const auto t0 = std::chrono::steady_clock::now();
         int st = e == hipSuccess ? launch_pcg_small(d_descs, count, lds, kinds, variants, nullptr) : DPCG_ERR_HIP;
-        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(out.data(), d_out, out.size() * sizeof(Scalars), hipMemcpyDeviceToHost);
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        for (int i = 0; i < count && e == hipSuccess; ++i)
-            e = hipMemcpy(&out[i], handles[i]->scal, sizeof(Scalars), hipMemcpyDeviceToHost);
         dev_free(d_descs);
+        dev_free(d_out);
         DPCG_HIP(e);
         if (st < 0) return st;
         int worst_small = DPCG_OK;
