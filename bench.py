@@ -254,6 +254,26 @@ def extra_workloads(D, poisson, torch) -> dict:
         "iterations": rc.iterations, "final_res": rc.final_res, "bitwise_equal_to_fp64_values": bool(rc.final_res == r64.final_res),
         "iterations_per_s": round(rc.iterations / rc.seconds, 1), "spmv_bytes_per_launch": spmv_bytes(s5.n, s5.nnz, wv=4)}
     del s5
+    # the reference's real size class (2.4k-5.5k rows): a batch of 256 independent systems,
+    # one launch, one workgroup per system
+    from deeppreconditioning_amd.batch import solve_batch
+    systems = [poisson.poisson_system(2, 49 + (i % 4)) for i in range(256)]
+    for sy in systems:
+        sy.set_preconditioner(D.Jacobi())
+    rhs_b = [poisson.rhs(sy.n, i) for i, sy in enumerate(systems)]
+    solve_batch(systems, rhs_b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res_b = solve_batch(systems, rhs_b)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    one = systems[0].solve(rhs_b[0], want_history=False)
+    one = systems[0].solve(rhs_b[0], want_history=False)
+    out["batch_256_systems_2401_to_2704_rows"] = {"batch_ms": round(dt * 1e3, 3), "iterations_total": int(sum(r.iterations for r in res_b)),
+                                                 "iterations_per_s_aggregate": round(sum(r.iterations for r in res_b) / dt, 1),
+                                                 "systems_per_s": round(256 / dt, 1),
+                                                 "single_system_us_per_update": round(one.seconds / one.iterations * 1e6, 2)}
+    del systems, rhs_b
     # config 4 (one GPU's share): 256^3 systems, 1.74 GB per SpMV, beyond the Infinity Cache -> HBM-bound
     s4 = poisson.poisson_system(3, 256)
     s4.set_preconditioner(D.Jacobi())
