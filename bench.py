@@ -150,7 +150,7 @@ def main() -> None:
                        "rtol_sq": 1e-8, "max_iter": 1024, "iterations_per_solve": check.iterations,
                        "final_res": check.final_res, "systems_per_gpu_per_step": args.systems_per_gpu,
                        "parallelism": f"independent systems sharded one-per-rank x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_spmv_stream<double,double,CTL,DOT> (SpMV + <p,Ap>)",
+            "roofline": {"bound": "hbm", "kernel": f"k_spmv_{system.info()['spmv_kernel']}<CTL,DOT> (SpMV + <p,Ap>)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_alg, "us_per_launch": round(ms * 1e3, 3)},

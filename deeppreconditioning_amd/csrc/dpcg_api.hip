@@ -198,13 +198,14 @@ static int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s, bool allow_
         // it comes from HBM (measured: tools/lib_lab, 100^3: 20.7 vs 21.7 us; 256^3: 457 vs 424 us)
         const double stream_bytes = 12.0 * (double)A.nnz + 20.0 * (double)A.n;
         int cap = stream_bytes < 192e6 ? kMaxSpmvGrid : (kMaxSpmvGrid * 3) / 4;
-        // x-tile variant: stage the block's chunks of x in LDS when the columns of every block form a few runs.
-        // Measured (tools/lib_lab): it wins once the matrix streams from HBM (256^3: 389 vs 419 us, 2 B less
-        // per non-zero and no x re-gather) and loses slightly while everything sits in the Infinity Cache
-        // (100^3: 22.0 vs 21.0 us: the per-CU L2->L1 rate is the limit there and staging moves more bytes).
+        // x-tile variant: stage the block's chunks of x in LDS when the columns of every block form a few runs
+        // (2 B less per non-zero, no x re-gather, and the next block's stream AND x chunks prefetched into
+        // registers).  Measured (tools/lib_lab, tools/c4_probe.py): 256^3 350-362 vs 419 us, 100^3 20.1 vs
+        // 20.9 us, 1024^2 +2.7 % its/s; it loses when there are too few row blocks to keep 6 workgroups per CU
+        // busy (256^2, 256 blocks: 86K vs 91K its/s), hence the block-count threshold.
         const bool force_stream = force && strcmp(force, "stream") == 0;
         const bool force_tile = force && strcmp(force, "tile") == 0;
-        if (allow_tile && !force_stream && A.nnz > 0 && (force_tile || stream_bytes >= 192e6)) {
+        if (allow_tile && !force_stream && A.nnz > 0 && (force_tile || plan.nrb >= kTileMinBlocks)) {
             int *d_flags = nullptr, h_flags[2] = {1, 0};
             DPCG_TRY(dev_alloc(&plan.tile_chunks, (int64_t)plan.nrb * kTileMaxChunks));
             DPCG_TRY(dev_alloc(&plan.tile_nchunks, plan.nrb));

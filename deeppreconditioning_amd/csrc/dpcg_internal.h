@@ -25,6 +25,7 @@ constexpr int kStreamRows = 256;      // rows per row-block of the CSR-stream Sp
 enum SpmvKernel { SPMV_STREAM = 0, SPMV_VECTOR = 1, SPMV_TILE = 2 };
 constexpr int kTileChunk = 64;        // x is staged in LDS in chunks of 64 doubles (512 B, one wave-load)
 constexpr int kTileMaxChunks = 40;    // at most 40 chunks (20 KiB) per 256-row block
+constexpr int kTileMinBlocks = 1536;   // fewest 256-row blocks for which the x-tile SpMV is chosen
 constexpr int kTileTableMax = 4096;   // chunk-id span a block may cover (262,144 columns)
 
 struct CsrDev {

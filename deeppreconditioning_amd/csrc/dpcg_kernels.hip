@@ -306,7 +306,7 @@ void launch_tile_plan(const CsrDev &A, int nrb, int32_t *chunks, int32_t *nchunk
                        ok_and_max_dev);
 }
 
-template <bool CTL, bool DOT>
+template <bool CTL, bool DOT, int XT>   // XT: x-tile doubles staged per thread (tile_max_chunks * 64 / 256, rounded up)
 __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *__restrict__ rowptr,
                                                       const double *__restrict__ val,
                                                       const uint16_t *__restrict__ lidx,
@@ -325,7 +325,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
     split_range(nrb, v, rb_lo, rb_hi);
     double a[U];
     int li[U];
-    int cnt = 0, base = 0, rs = 0, re = 0;
+    double xt[XT];
+    int cnt = 0, base = 0, rs = 0, re = 0, nc = 0;
+    const int lane = t & 63, wv = t >> 6;
+    // Everything block `rb` needs from memory -> registers: its slice of the matrix stream AND its x chunks
+    // (wave w stages chunks w, w+4, ...: 64 lanes x 8 B = one 512-B run; the chunk id is wave-uniform and travels
+    // through the scalar unit).  Issued one block ahead, so the loads fly during the previous block's phases.
     auto fetch = [&](int rb) {
         const int64_t r0 = (int64_t)rb * kStreamRows;
         const int64_t row = r0 + t;
@@ -345,6 +350,17 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
             a[u] = cnt > 0 ? val[base + kk] : 0.0;
             li[u] = cnt > 0 ? (int)lidx[base + kk] : 0;
         }
+        nc = nchunks[rb];
+        const int32_t *__restrict__ cl = chunks + (int64_t)rb * kTileMaxChunks;
+#pragma unroll
+        for (int u = 0; u < XT; ++u) {
+            const int ci = wv + u * (kBlock / 64);
+            if (ci < nc) {
+                const int chunk = __builtin_amdgcn_readfirstlane(cl[ci]);
+                const int64_t gi = (int64_t)chunk * kTileChunk + lane;
+                xt[u] = gi < n ? x[gi] : 0.0;
+            }
+        }
     };
     if (rb_lo < rb_hi) fetch(rb_lo);
     if (CTL) {
@@ -353,25 +369,20 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
     double acc = 0.0;
     for (int rb = rb_lo; rb < rb_hi; ++rb) {
         const int64_t row = (int64_t)rb * kStreamRows + t;
-        const int ks = rs - base, ke = re - base;
-        // stage this block's chunks of x: wave w takes chunks w, w+4, ... (64 lanes x 8 B = one 512-B run);
-        // the chunk id is wave-uniform, so it travels through the scalar unit
-        const int nc = nchunks[rb];
-        const int32_t *__restrict__ cl = chunks + (int64_t)rb * kTileMaxChunks;
-        const int lane = t & 63;
-        for (int ci = t >> 6; ci < nc; ci += kBlock / 64) {
-            const int chunk = __builtin_amdgcn_readfirstlane(cl[ci]);
-            const int64_t gi = (int64_t)chunk * kTileChunk + lane;
-            xs[ci * kTileChunk + lane] = gi < n ? x[gi] : 0.0;
+        const int ks = rs - base, ke = re - base, cnt_cur = cnt;
+#pragma unroll
+        for (int u = 0; u < XT; ++u) {
+            const int ci = wv + u * (kBlock / 64);
+            if (ci < nc) xs[ci * kTileChunk + lane] = xt[u];
         }
         __syncthreads();                    // tile complete (and every thread is past the previous row sums)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = t + u * kBlock;
-            if (k < cnt) prod[k] = a[u] * xs[li[u]];
+            if (k < cnt_cur) prod[k] = a[u] * xs[li[u]];
         }
+        if (rb + 1 < rb_hi) fetch(rb + 1);   // next block's stream and x chunks are in flight from here on
         __syncthreads();
-        if (rb + 1 < rb_hi) fetch(rb + 1);   // next block's stream is in flight during the row sums and staging
         if (row < n) {
             double s = 0.0;
             for (int k = ks; k < ke; ++k) s += prod[k];
@@ -413,14 +424,20 @@ static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, 
         std::is_same<YT, double>::value) {
         const int tile_doubles = plan.tile_max_chunks * kTileChunk;
         const size_t lds = (size_t)(tile_doubles + kStreamCap + 4) * sizeof(double);
-#define DPCG_LAUNCH_TILE(CTLV, DOTV)                                                                                 \
-    hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr,              \
+#define DPCG_LAUNCH_TILE_X(CTLV, DOTV, XTV)                                                                          \
+    hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV, XTV>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr,              \
                        (const double *)val, plan.tile_lidx, plan.tile_chunks, plan.tile_nchunks, (const double *)x,  \
                        (double *)y, plan.nrb, tile_doubles, part_pq, d)
+#define DPCG_LAUNCH_TILE(CTLV, DOTV)                                                  \
+    do {                                                                              \
+        if (plan.tile_max_chunks <= 20) DPCG_LAUNCH_TILE_X(CTLV, DOTV, 5);            \
+        else DPCG_LAUNCH_TILE_X(CTLV, DOTV, (kTileMaxChunks * kTileChunk / kBlock));  \
+    } while (0)
         if (c && dot) DPCG_LAUNCH_TILE(true, true);
         else if (dot) DPCG_LAUNCH_TILE(false, true);
         else DPCG_LAUNCH_TILE(false, false);
 #undef DPCG_LAUNCH_TILE
+#undef DPCG_LAUNCH_TILE_X
     } else if (plan.kernel == SPMV_STREAM || plan.kernel == SPMV_TILE) {
         if (c && dot) DPCG_LAUNCH_STREAM(true, true);
         else if (dot) DPCG_LAUNCH_STREAM(false, true);

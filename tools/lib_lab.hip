@@ -12,7 +12,11 @@ namespace dpcg { void set_error(const std::string &) {} int hip_fail(hipError_t,
 
 int main(int argc, char **argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 11;
-    struct Case { int dim; int64_t n; } cases[] = {{3, 100}, {3, 256}};
+    struct Case { int dim; int64_t n; };
+    std::vector<Case> cases = {{3, 100}, {3, 256}};
+    if (argc > 3) cases = {{atoi(argv[2]), atol(argv[3])}};
+    std::vector<int> tile_grids = {1024, 1280, 1536};
+    if (argc > 4) { tile_grids.clear(); for (int i = 4; i < argc; ++i) tile_grids.push_back(atoi(argv[i])); }
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto cs : cases) {
@@ -36,7 +40,7 @@ int main(int argc, char **argv) {
         struct V { const char *name; int kind; int grid; bool ctl; double bytes; int npart; };
         std::vector<V> vs;
         for (int g : {1536, 2048}) { vs.push_back({"spmv+dot ctl (gather)", 0, g, true, b_spmv, 512}); }
-        for (int g : {1024, 1280, 1536}) { vs.push_back({"spmv+dot ctl (x-tile)", 3, g, true, b_spmv, 512}); }
+        for (int g : tile_grids) { vs.push_back({"spmv+dot ctl (x-tile)", 3, g, true, b_spmv, 512}); }
         // x-tile plan
         SpmvPlan tplan; tplan.kernel = SPMV_TILE; tplan.nrb = (int)((N + 255) / 256);
         CK(hipMalloc(&tplan.tile_chunks, (size_t)tplan.nrb * kTileMaxChunks * 4)); CK(hipMalloc(&tplan.tile_nchunks, (size_t)tplan.nrb * 4)); CK(hipMalloc(&tplan.tile_lidx, nnz * 2));
@@ -72,8 +76,9 @@ int main(int argc, char **argv) {
                 for (double *p : {x, y, z, r, q}) CK(hipMemcpyAsync(p, dinv, N * 8, hipMemcpyDeviceToDevice, s));
             }
         {   // the iteration as the PCG loop runs it: K1 -> K2 -> K3, back to back
-            for (int gs : {1536, 2048}) {
+            for (int gs : {1536, 2048, -1536}) {
                 SpmvPlan plan; plan.kernel = SPMV_STREAM; plan.nrb = (int)((N + 255) / 256); plan.grid = std::min(plan.nrb, gs);
+                if (gs < 0) { plan = tplan; plan.grid = std::min(plan.nrb, -gs); }   // negative: the x-tile kernel
                 IterCtl ctl{sc};
                 std::vector<float> tt;
                 for (int rd = 0; rd < rounds; ++rd) {

@@ -62,7 +62,7 @@ for k, seg, what, rd, wr in cal:
           + 32 * mean(R[(seg, k, "TCC_EA0_RDREQ_32B_sum")] or [0], -1))
     w = 1024 * mean(W[(seg, k, "WRITE_SIZE")], floor)
     lines.append(f"| {k} ({what}) | {rd / MB:.1f} | {f2 / MB:.1f} | {rq / MB:.1f} | {wr / MB:.1f} | {w / MB:.1f} |")
-lines += ["", "## SpMV + <p,Ap> kernel of the PCG loop (k_spmv_stream for the 1M-DoF systems, k_spmv_tile for 256^3): bytes per launch", "",
+lines += ["", "## SpMV + <p,Ap> kernel of the PCG loop (k_spmv_tile: the plan picks the x-tile kernel for all three systems): bytes per launch", "",
           "| system | algorithmic MB (nnz*12 + (n+1)*4 + 16n) | read MB = 2 x FETCH_SIZE x 1024 | read MB from RDREQ sizes | write MB | traffic MB | traffic / algorithmic |",
           "|---|---|---|---|---|---|---|"]
 traffic = {}
@@ -75,9 +75,9 @@ for seg, (name, n, nnz) in enumerate(SYSTEMS[:3]):
     tot = rd + wr
     traffic[f"spmv_{name}"] = round(tot)
     lines.append(f"| poisson{name} | {alg / MB:.2f} | {rd / MB:.2f} | {rq / MB:.2f} | {wr / MB:.2f} | {tot / MB:.2f} | {tot / alg:.3f} |")
-lines += ["", "Reading: traffic is within a few % of the algorithmic CSR bytes on the 1M-DoF systems.  On 256^3 the x-tile kernel",
-          "reads a 2-byte local index instead of the 4-byte column (-234 MB) and stages x in LDS; the gather kernel",
-          "measured 1906 MB there (x planes at i +- n^2 re-fetched: reuse distance 6.8 MB per XCD > the 4 MiB L2).",
+lines += ["", "Reading: traffic is BELOW the algorithmic CSR bytes: the x-tile kernel reads a 2-byte local index instead of the",
+          "4-byte column (-2 B per non-zero: -13.9 MB at 100^3, -234 MB at 256^3) and stages x in LDS; the gather kernel",
+          "measured 107.2 MB at 100^3 (ratio 1.038) and 1906 MB at 256^3 (x planes at i +- n^2 re-fetched: reuse distance 6.8 MB per XCD > the 4 MiB L2).",
           "The 1M-DoF working set (~150 MB) sits in the Infinity Cache; these counters are the L2's memory-side requests",
           "(Infinity-Cache hits included), i.e. fabric traffic rather than DRAM traffic for those two rows.", ""]
 (ROOT / "profiles").mkdir(exist_ok=True)
