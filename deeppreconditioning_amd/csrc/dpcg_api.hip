@@ -109,6 +109,9 @@ static void free_levels(Levels &l) {
     dev_free(l.lo_col);
     dev_free(l.lo_cpos);
     dev_free(l.lo_val);
+    dev_free(l.pk_meta);
+    dev_free(l.pk_val);
+    dev_free(l.b_lo);
     l = Levels();
 }
 
@@ -527,12 +530,16 @@ static int upload_levels(Levels &lv, const std::vector<int32_t> &rows_sorted, co
     while (l < lv.n_levels) {
         const bool narrow = (level_ptr[l + 1] - level_ptr[l]) <= kMergeMax;
         int e = l + 1;
-        while (e < lv.n_levels && ((level_ptr[e + 1] - level_ptr[e]) <= kMergeMax) == narrow) ++e;
+        while (e < lv.n_levels && ((level_ptr[e + 1] - level_ptr[e]) <= kMergeMax) == narrow &&
+               (!narrow || e - l < kRingMaxLevels))
+            ++e;
         Levels::Segment seg;
         seg.lo = l;
         seg.hi = e;
         seg.merged = narrow && (e - l) >= 2;
         seg.ring_w = 0;
+        seg.max_width = 0;
+        for (int q = l; q < e; ++q) seg.max_width = std::max<int>(seg.max_width, level_ptr[q + 1] - level_ptr[q]);
         if (seg.merged) {
             // LDS ring: in level order, how far back do this segment's rows reach (within the segment)?
             const int32_t seg_start = level_ptr[l];
@@ -547,6 +554,41 @@ static int upload_levels(Levels &lv, const std::vector<int32_t> &rows_sorted, co
         }
         lv.segments.push_back(seg);
         l = e;
+    }
+    // fixed-width row records for the ring segments (see Levels::pk_meta)
+    bool any_ring = false;
+    for (const auto &seg : lv.segments) any_ring = any_ring || seg.ring_w > 0;
+    if (any_ring) {
+        std::vector<int32_t> meta((size_t)n * 4, -1);
+        std::vector<double> pv((size_t)n * 4, 0.0);
+        for (const auto &seg : lv.segments) {
+            if (seg.ring_w <= 0) continue;
+            const int32_t seg_start = level_ptr[seg.lo];
+            for (int32_t j = seg_start; j < level_ptr[seg.hi]; ++j) {
+                const int32_t a = lo_rp[j], b = lo_rp[j + 1], row = rows_sorted[j];
+                // the diagonal is the first entry of a row of L^T and the last of a row of L
+                const bool diag_first = lo_ci[a] == row && (b - a == 1 || lo_ci[b - 1] != row);
+                const int32_t ks = diag_first ? a + 1 : a, ke = diag_first ? b : b - 1;
+                meta[(size_t)j * 4 + 3] = row;
+                pv[(size_t)j * 4 + 3] = lo_v[diag_first ? a : b - 1];
+                bool fast = ke - ks <= 3;
+                for (int32_t k = ks; k < ke && fast; ++k) fast = lo_cp[k] >= seg_start;
+                if (!fast) {
+                    meta[(size_t)j * 4] = -2;
+                    continue;
+                }
+                for (int32_t k = ks; k < ke; ++k) {
+                    meta[(size_t)j * 4 + (k - ks)] = lo_cp[k];
+                    pv[(size_t)j * 4 + (k - ks)] = lo_v[k];
+                }
+            }
+        }
+        DPCG_TRY(dev_alloc(&lv.pk_meta, n * 4));
+        DPCG_TRY(dev_alloc(&lv.pk_val, n * 4));
+        DPCG_TRY(dev_alloc(&lv.b_lo, n));
+        DPCG_HIP(hipMemcpyAsync(lv.pk_meta, meta.data(), meta.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        DPCG_HIP(hipMemcpyAsync(lv.pk_val, pv.data(), pv.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        DPCG_HIP(hipStreamSynchronize(s));
     }
     return DPCG_OK;
 }
@@ -714,7 +756,7 @@ extern "C" int dpcg_spmv_f32(dpcg_handle_t h, const float *x, float *y, dpcg_str
 }
 
 // z = M r for the handle's preconditioner (cg.py:61,81).  `t` is the handle's scratch vector.
-static int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s) {
+static int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, bool in_loop = false) {
     switch (h->precond) {
         case DPCG_PRECOND_NONE:
             if (z != r) DPCG_HIP(hipMemcpyAsync(z, r, (size_t)h->A.n * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -730,8 +772,8 @@ static int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t
             launch_spmv(h->L, h->planL, h->t, z, nullptr, nullptr, s);
             break;
         case DPCG_PRECOND_LLT_SOLVE:
-            launch_sptrsv(h->L, h->lvlL, false, r, h->t, s);
-            launch_sptrsv(h->Lt, h->lvlU, true, h->t, z, s);
+            launch_sptrsv(h->L, h->lvlL, false, r, h->t, s, in_loop ? &h->scal->done : nullptr);
+            launch_sptrsv(h->Lt, h->lvlU, true, h->t, z, s, in_loop ? &h->scal->done : nullptr);
             break;
         default:
             set_error("unknown preconditioner kind");
@@ -830,7 +872,7 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
     launch_update_r(pre, n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->dinv, h->z, h->part_rz, h->part_rr,
                     h->vec_grid, s);
     if (pre == 2) {
-        DPCG_TRY(apply_precond(h, h->r, h->z, s));                                   // cg.py:81
+        DPCG_TRY(apply_precond(h, h->r, h->z, s, true));                             // cg.py:81
         launch_dot_partials(n, h->scal, h->r, h->z, h->part_rz, h->vec_grid, s);     // cg.py:82
     }
     // K3: beta; x += alpha p; p = z + beta p; workgroup 0: stopping test of the new iterate   cg.py:79,82-83,86,71
@@ -867,6 +909,21 @@ static int ensure_graph(dpcg_system *h, int flags, int chunk) {
     return DPCG_OK;
 }
 
+// kernel launches one preconditioner application costs (the SpTRSVs launch once per wide level)
+static int precond_launches(const dpcg_system *h) {
+    auto trsv = [](const Levels &lv) {
+        int c = 0;
+        for (const auto &seg : lv.segments) c += seg.merged ? 2 : seg.hi - seg.lo;
+        return c;
+    };
+    switch (h->precond) {
+        case DPCG_PRECOND_CSR: return 1;
+        case DPCG_PRECOND_LLT_MULTIPLY: return 2;
+        case DPCG_PRECOND_LLT_SOLVE: return trsv(h->lvlL) + trsv(h->lvlU);
+        default: return 0;
+    }
+}
+
 namespace {
 // Host side of one solve.  The GPU never waits for the host: iterations are enqueued ahead of the
 // progress word that K3 posts to pinned memory, as a replayed hipGraph of `chunk` updates (launch-bound
@@ -880,12 +937,13 @@ struct Solve {
     int enq = 0;             // updates enqueued so far
     bool complete = false;
     double t_iter = 0.0;     // measured seconds per update (0 = not known yet)
+    bool many_launches = false;   // an update is dozens of small launches (level-scheduled SpTRSV): always replay a graph
     std::chrono::steady_clock::time_point t0;
 
     volatile unsigned long long *prog() { return extras()[h].prog_host; }
 
     int enqueue_some() {
-        const bool graph_now = use_graph && (max_iter - enq) >= chunk && !(t_iter > 25e-6);
+        const bool graph_now = use_graph && (max_iter - enq) >= chunk && (many_launches || !(t_iter > 25e-6));
         if (graph_now) {
             DPCG_HIP(hipGraphLaunch(h->graph_exec, s));
             enq += chunk;
@@ -901,7 +959,7 @@ struct Solve {
         if (t_iter <= 0.0) return 2 * chunk;
         const double cover = 150e-6;  // host launch + scheduling latency to hide
         int it = (int)(cover / t_iter) + 2;
-        if (t_iter > 25e-6) return it < 3 ? 3 : it;
+        if (t_iter > 25e-6 && !(many_launches && use_graph)) return it < 3 ? 3 : it;
         const int chunks = (it + chunk - 1) / chunk + 1;
         return chunks * chunk;
     }
@@ -924,6 +982,9 @@ struct Solve {
             dev_free(d_lossy);
             h->A.val32_lossless = lossy ? -1 : 1;
         }
+        const int per_update = 3 + precond_launches(h);
+        many_launches = per_update >= 16;
+        if (many_launches) chunk = std::max(1, std::min(chunk, 1024 / per_update));   // keep the graph at ~1K nodes
         use_graph = !(flags & DPCG_NO_GRAPH) && !x_true && max_iter >= chunk;
         if (use_graph) DPCG_TRY(ensure_graph(h, flags, chunk));
         *ex.prog_host = 0;

@@ -25,6 +25,7 @@ constexpr int kStreamRows = 256;      // rows per row-block of the CSR-stream Sp
 enum SpmvKernel { SPMV_STREAM = 0, SPMV_VECTOR = 1, SPMV_TILE = 2 };
 constexpr int kTileChunk = 64;        // x is staged in LDS in chunks of 64 doubles (512 B, one wave-load)
 constexpr int kTileMaxChunks = 40;    // at most 40 chunks (20 KiB) per 256-row block
+constexpr int kRingMaxLevels = 8192;   // levels per LDS-ring segment (their offsets are staged in LDS)
 constexpr int kTileMinBlocks = 1536;   // fewest 256-row blocks for which the x-tile SpMV is chosen
 constexpr int kTileTableMax = 4096;   // chunk-id span a block may cover (262,144 columns)
 
@@ -97,7 +98,7 @@ struct Levels {
     std::vector<int32_t> level_ptr;        // host: offsets into rows, n_levels+1
     // [lo,hi) levels; merged = one workgroup walks them; ring_w > 0: the solution entries the segment's rows depend
     // on lie within the last ring_w level-order positions, so they are handed from level to level through LDS
-    struct Segment { int lo, hi; bool merged; int ring_w; };
+    struct Segment { int lo, hi; bool merged; int ring_w; int max_width; };
     std::vector<Segment> segments;
     int32_t *level_ptr_dev = nullptr;      // device copy of level_ptr
     // the factor once more, rows stored in level order (row j of this copy = original row rows[j]): the
@@ -107,6 +108,14 @@ struct Levels {
     int32_t *lo_cpos = nullptr;            // level-order position of each entry's column (position of row lo_col[k])
     double *lo_val = nullptr;
     bool stream_ok = false;                // every 256-row block of every wide level fits the LDS product buffer
+    // Fixed-width records of the rows of ring segments, indexed by level-order position j, so that a row's data
+    // can be requested several levels ahead without first reading its extents:
+    //   pk_meta[j] = {cpos0, cpos1, cpos2, original row}: level-order positions of the first three off-diagonal
+    //                columns (-1 = no such entry; cpos0 = -2: the row takes the general path through lo_rowptr);
+    //   pk_val[4j..4j+3] = {v0, v1, v2, diagonal}.
+    int32_t *pk_meta = nullptr;
+    double *pk_val = nullptr;
+    double *b_lo = nullptr;                // scratch: the right-hand side gathered into level order
 };
 
 }  // namespace dpcg
@@ -194,7 +203,9 @@ void launch_record_err(const Scalars *scal, const double *part, int n_part, doub
                        int at_k_minus_one, hipStream_t s);
 void launch_dot_final(const double *part, int n_part, double *out_dev, hipStream_t s);
 
-void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s);
+// done: optional device flag (Scalars::done); when set the kernels return at once
+void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s,
+                   const int *done = nullptr);
 
 // Builds the x-tile plan of A on the device; *ok = 1 when every block is tileable, *max_chunks its widest tile.
 void launch_tile_plan(const CsrDev &A, int nrb, int32_t *chunks, int32_t *nchunks, uint16_t *lidx, int *ok_and_max_dev,

@@ -878,7 +878,8 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_level_stream(const int32_t *_
                                                                 const int32_t *__restrict__ lo_rp,
                                                                 const int32_t *__restrict__ lo_ci,
                                                                 const double *__restrict__ lo_v,
-                                                                const double *__restrict__ rhs, double *out) {
+                                                                const double *__restrict__ rhs, double *out, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     constexpr int U = kStreamCap / kBlock;
     __shared__ double prod[kStreamCap];
     const int t = threadIdx.x;
@@ -925,7 +926,8 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_level(const int32_t *__restri
                                                          const int32_t *__restrict__ lo_rp,
                                                          const int32_t *__restrict__ lo_ci,
                                                          const double *__restrict__ lo_v,
-                                                         const double *__restrict__ rhs, double *out) {
+                                                         const double *__restrict__ rhs, double *out, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= count) return;
     const int j = j0 + idx, i = rows[j];
@@ -946,7 +948,8 @@ __global__ __launch_bounds__(kMergedBlock) void k_sptrsv_merged(const int32_t *_
                                                                 int lvl_hi, const int32_t *__restrict__ lo_rp,
                                                                 const int32_t *__restrict__ lo_ci,
                                                                 const double *__restrict__ lo_v,
-                                                                const double *__restrict__ rhs, double *out) {
+                                                                const double *__restrict__ rhs, double *out, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     for (int lvl = lvl_lo; lvl < lvl_hi; ++lvl) {
         const int lo = level_ptr[lvl], hi = level_ptr[lvl + 1];
         for (int j = lo + (int)threadIdx.x; j < hi; j += kMergedBlock) {
@@ -978,7 +981,8 @@ __global__ __launch_bounds__(kMergedBlock) void k_sptrsv_ring(const int32_t *__r
                                                               const int32_t *__restrict__ lo_cpos,
                                                               const double *__restrict__ lo_v,
                                                               const double *__restrict__ rhs, double *out,
-                                                              int seg_start, int W) {
+                                                              int seg_start, int W, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     extern __shared__ __attribute__((aligned(16))) double ring[];
     struct Row {
         int j, i, s, e;
@@ -1052,9 +1056,161 @@ __global__ __launch_bounds__(kMergedBlock) void k_sptrsv_ring(const int32_t *__r
     }
 }
 
-void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s) {
+// The ring walk with a deep software pipeline.  A level of a 5-point grid's factor is ~100 rows: the LDS round
+// trip, three multiply-adds, the division and a barrier take ~0.2 us, but fetching a row's data only one level
+// ahead (k_sptrsv_ring: row id -> extents -> entries, two dependent trips to L2) costs ~1.4 us per level.  Here a
+// row's data sits in fixed-width records addressed by its level-order position alone (Levels::pk_meta / pk_val,
+// right-hand side pre-gathered into level order), four 16-byte loads per row, and is requested D levels ahead;
+// the segment's level offsets are staged in LDS up front.  Arithmetic and its order are those of every other
+// SpTRSV kernel here (ascending columns, one product and one subtraction at a time, then the division).
+__global__ __launch_bounds__(kBlock) void k_gather_lo(const int32_t *__restrict__ rows, const double *__restrict__ rhs,
+                                                      double *__restrict__ b_lo, int j0, int count, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx < count) b_lo[j0 + idx] = rhs[rows[j0 + idx]];
+}
+
+// The prefetch is chunked: while the C levels of one chunk are solved out of one register set, the records of
+// the next chunk fly into the other set; at a chunk boundary one s_waitcnt vmcnt(0) retires them (by then C levels
+// of work have covered the memory latency).  The explicit wait + register "touch" keeps the compiler from
+// inserting its own conservative vmcnt(0) at each first use, which would also wait for the loads just issued.
+template <bool UPPER, int C, int ROWS>   // ROWS rows of a level per thread, C levels per prefetch chunk
+__global__ __launch_bounds__(512) void k_sptrsv_ring_pipe(const int32_t *__restrict__ level_ptr, int lvl_lo,
+                                                          int lvl_hi, const int32_t *__restrict__ lo_rp,
+                                                          const int32_t *__restrict__ lo_ci,
+                                                          const int32_t *__restrict__ lo_cpos,
+                                                          const double *__restrict__ lo_v,
+                                                          const int4 *__restrict__ pk_meta,
+                                                          const double2 *__restrict__ pk_val,
+                                                          const double *__restrict__ b_lo, double *out, int seg_start,
+                                                          int W, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
+    extern __shared__ __attribute__((aligned(16))) double ring[];
+    int *lp = reinterpret_cast<int *>(ring + W);        // level offsets of this segment, padded with empty levels
+    const int t = threadIdx.x, T = blockDim.x;
+    const int nl = lvl_hi - lvl_lo;
+    const int nchunks = (nl + C - 1) / C;
+    const int seg_end = level_ptr[lvl_hi];
+    for (int i = t; i <= (nchunks + 2) * C; i += T) lp[i] = i <= nl ? level_ptr[lvl_lo + i] : seg_end;
+    __syncthreads();
+    const int jmax = seg_end - 1;
+    struct Row {
+        int j;           // level-order position, -1 for a lane without a row in this level 
+        int4 m;          // cpos0..2, original row
+        double2 v01, v2d;
+        double b;
+    };
+    auto load_row = [&](Row &r, int j, int hi) {
+        const int jc = j < hi ? j : jmax;                 // lanes without a row load a valid record and ignore it
+        r.j = j < hi ? j : -1;
+        r.m = pk_meta[jc];
+        r.v01 = pk_val[2 * (int64_t)jc];
+        r.v2d = pk_val[2 * (int64_t)jc + 1];
+        r.b = b_lo[jc];
+    };
+    auto load_chunk = [&](Row (&S)[C][ROWS], int chunk) {
+#pragma unroll
+        for (int d = 0; d < C; ++d) {
+            const int rel = chunk * C + d;
+            const int lo = lp[rel], hi = lp[rel + 1];
+#pragma unroll
+            for (int h = 0; h < ROWS; ++h) load_row(S[d][h], lo + t + h * T, hi);
+        }
+    };
+    // all outstanding loads have landed; tell the compiler so (the registers are "redefined" here)
+    auto retire = [&](Row (&S)[C][ROWS]) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < C; ++d)
+#pragma unroll
+            for (int h = 0; h < ROWS; ++h) {
+                Row &r = S[d][h];
+                asm volatile("" : "+v"(r.m.x), "+v"(r.m.y), "+v"(r.m.z), "+v"(r.m.w), "+v"(r.v01.x), "+v"(r.v01.y),
+                             "+v"(r.v2d.x), "+v"(r.v2d.y), "+v"(r.b));
+            }
+    };
+    auto solve_row = [&](const Row &r) {
+        const bool valid = r.j >= 0;
+        double acc = r.b;
+        if (valid && r.m.x == -2) {                       // long row, or one that reaches back before the segment
+            const int s = lo_rp[r.j], e = lo_rp[r.j + 1];
+            const int ks = UPPER ? s + 1 : s, ke = UPPER ? e : e - 1;
+            for (int k = ks; k < ke; ++k) {
+                const int cp = lo_cpos[k];
+                const double yv = cp >= seg_start ? ring[cp & (W - 1)] : out[lo_ci[k]];
+                acc -= lo_v[k] * yv;
+            }
+        } else {
+            const double y0 = ring[(r.m.x < 0 ? 0 : r.m.x) & (W - 1)];
+            const double y1 = ring[(r.m.y < 0 ? 0 : r.m.y) & (W - 1)];
+            const double y2 = ring[(r.m.z < 0 ? 0 : r.m.z) & (W - 1)];
+            if (r.m.x >= 0) acc -= r.v01.x * y0;
+            if (r.m.y >= 0) acc -= r.v01.y * y1;
+            if (r.m.z >= 0) acc -= r.v2d.x * y2;
+        }
+        const double y = acc / r.v2d.y;
+        if (valid) {
+            ring[r.j & (W - 1)] = y;
+            out[r.m.w] = y;
+        }
+    };
+    // LDS-only hand-off (see k_sptrsv_ring): no vmcnt drain, the prefetched loads stay in flight across it
+    auto level_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto solve_chunk = [&](Row (&S)[C][ROWS]) {
+#pragma unroll
+        for (int d = 0; d < C; ++d) {
+#pragma unroll
+            for (int h = 0; h < ROWS; ++h) solve_row(S[d][h]);
+            level_barrier();
+        }
+    };
+    Row S0[C][ROWS], S1[C][ROWS];
+    load_chunk(S0, 0);
+    for (int c = 0; c < nchunks; c += 2) {
+        retire(S0);
+        load_chunk(S1, c + 1);                            // flies while chunk c is solved
+        solve_chunk(S0);
+        if (c + 1 >= nchunks) break;
+        retire(S1);
+        load_chunk(S0, c + 2);
+        solve_chunk(S1);
+    }
+}
+
+constexpr int kRingChunk = 6;   // levels per prefetch chunk of k_sptrsv_ring_pipe (3 with two rows per thread)
+static bool ring_pipe_disabled() {
+    static const bool off = [] { const char *e = getenv("DPCG_RING_PIPE"); return e && e[0] == '0'; }();
+    return off;
+}
+
+void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s,
+                   const int *done) {
     (void)T;  // the level-ordered copy in `lv` carries the factor
     for (const auto &seg : lv.segments) {
+        if (seg.merged && seg.ring_w > 0 && lv.pk_meta && !ring_pipe_disabled() && seg.max_width <= 1024 &&
+            (size_t)seg.ring_w * sizeof(double) + (size_t)(seg.hi - seg.lo + 4 * kRingChunk) * sizeof(int) <= 64 * 1024) {
+            const int seg_start = lv.level_ptr[seg.lo], seg_rows = lv.level_ptr[seg.hi] - seg_start;
+            const size_t lds = (size_t)seg.ring_w * sizeof(double) + (size_t)(seg.hi - seg.lo + 4 * kRingChunk) * sizeof(int);
+            const int width = seg.max_width;
+            hipLaunchKernelGGL(k_gather_lo, dim3((seg_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, s, lv.rows, rhs,
+                               lv.b_lo, seg_start, seg_rows, done);
+#define DPCG_RING_PIPE(UP, CV, ROWSV, threads)                                                                      \
+    hipLaunchKernelGGL((k_sptrsv_ring_pipe<UP, CV, ROWSV>), dim3(1), dim3(threads), lds, s, lv.level_ptr_dev, seg.lo,  \
+                       seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, (const int4 *)lv.pk_meta,            \
+                       (const double2 *)lv.pk_val, lv.b_lo, out, seg_start, seg.ring_w, done)
+            if (width <= 512) {                              // one row per thread
+                int threads = (width + 63) / 64 * 64;
+                threads = threads < 64 ? 64 : threads;
+                if (upper) DPCG_RING_PIPE(true, kRingChunk, 1, threads);
+                else DPCG_RING_PIPE(false, kRingChunk, 1, threads);
+            } else {                                         // two rows per thread
+                const int threads = ((width + 1) / 2 + 63) / 64 * 64;
+                if (upper) DPCG_RING_PIPE(true, kRingChunk / 2, 2, threads);
+                else DPCG_RING_PIPE(false, kRingChunk / 2, 2, threads);
+            }
+#undef DPCG_RING_PIPE
+            continue;
+        }
         if (seg.merged && seg.ring_w > 0) {
             const size_t lds = (size_t)seg.ring_w * sizeof(double);
             const int seg_start = lv.level_ptr[seg.lo];
@@ -1066,27 +1222,27 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
             if (upper)
                 hipLaunchKernelGGL(k_sptrsv_ring<true>, dim3(1), dim3(threads), lds, s, lv.rows, lv.level_ptr_dev,
                                    seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, rhs, out, seg_start,
-                                   seg.ring_w);
+                                   seg.ring_w, done);
             else
                 hipLaunchKernelGGL(k_sptrsv_ring<false>, dim3(1), dim3(threads), lds, s, lv.rows, lv.level_ptr_dev,
                                    seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, rhs, out, seg_start,
-                                   seg.ring_w);
+                                   seg.ring_w, done);
             continue;
         }
         if (seg.merged) {
             if (upper)
                 hipLaunchKernelGGL(k_sptrsv_merged<true>, dim3(1), dim3(kMergedBlock), 0, s, lv.rows, lv.level_ptr_dev,
-                                   seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_val, rhs, out);
+                                   seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_val, rhs, out, done);
             else
                 hipLaunchKernelGGL(k_sptrsv_merged<false>, dim3(1), dim3(kMergedBlock), 0, s, lv.rows,
-                                   lv.level_ptr_dev, seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_val, rhs, out);
+                                   lv.level_ptr_dev, seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_val, rhs, out, done);
             continue;
         }
         for (int l = seg.lo; l < seg.hi; ++l) {
             const int j0 = lv.level_ptr[l], cnt = lv.level_ptr[l + 1] - j0;
             const int grid = (cnt + kBlock - 1) / kBlock;
 #define DPCG_TRSV(KERNEL, UP) \
-    hipLaunchKernelGGL(KERNEL<UP>, dim3(grid), dim3(kBlock), 0, s, lv.rows, j0, cnt, lv.lo_rowptr, lv.lo_col, lv.lo_val, rhs, out)
+    hipLaunchKernelGGL(KERNEL<UP>, dim3(grid), dim3(kBlock), 0, s, lv.rows, j0, cnt, lv.lo_rowptr, lv.lo_col, lv.lo_val, rhs, out, done)
             if (lv.stream_ok) {
                 if (upper) DPCG_TRSV(k_sptrsv_level_stream, true);
                 else DPCG_TRSV(k_sptrsv_level_stream, false);
