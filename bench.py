@@ -34,6 +34,18 @@ def spmv_bytes(n: int, nnz: int, wv: int = 8, wx: int = 8) -> int:
     return nnz * (wv + 4) + (n + 1) * 4 + 2 * n * wx
 
 
+def fused_update_bytes(n: int) -> int:
+    """Extra algorithmic bytes of the two-kernel iteration's SpMV kernel, which also does the vector update of
+    cg.py:79,83: reads z and x, writes x and the new p (the old p it reads is the SpMV's x operand): 4 x 8 B per row."""
+    return 32 * n
+
+
+def loop_kernel_bytes(system) -> int:
+    """Algorithmic bytes of the kernel `spmv_dot_bench` times: the SpMV of the PCG loop, fused with the vector update
+    when the system runs two-kernel updates."""
+    return spmv_bytes(system.n, system.nnz) + (fused_update_bytes(system.n) if system.info()["two_kernel_updates"] else 0)
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,7 +147,8 @@ def main() -> None:
         check = system.solve(poisson.rhs(n, 0))
         # ---- roofline of the dominant kernel: the SpMV+<p,Ap> launch inside the PCG iteration ----
         ms = system.spmv_dot_bench(repeats=200)     # HIP events on the launch stream, 200 launches
-        b_alg = spmv_bytes(n, nnz)
+        info = system.info()
+        b_alg = loop_kernel_bytes(system)
         achieved = b_alg / (ms * 1e-3) / 1e9
         traffic = None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
@@ -150,7 +163,9 @@ def main() -> None:
                        "rtol_sq": 1e-8, "max_iter": 1024, "iterations_per_solve": check.iterations,
                        "final_res": check.final_res, "systems_per_gpu_per_step": args.systems_per_gpu,
                        "parallelism": f"independent systems sharded one-per-rank x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": f"k_spmv_{system.info()['spmv_kernel']}<CTL,DOT> (SpMV + <p,Ap>)",
+            "roofline": {"bound": "hbm", "kernel": (f"k_spmv_{info['spmv_kernel']}<FUSE> (p = z + beta p, x += alpha p, q = A p, <p,q>)"
+                                    if info["two_kernel_updates"] else
+                                    f"k_spmv_{info['spmv_kernel']}<CTL,DOT> (SpMV + <p,Ap>)"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_alg, "us_per_launch": round(ms * 1e3, 3)},
@@ -215,7 +230,7 @@ def extra_workloads(D, poisson, torch) -> dict:
     r = solve_twice(s2, b2)
     ms = s2.spmv_dot_bench(200)
     out["poisson2d_1024_jacobi"] = {"iterations": r.iterations, "iterations_per_s": round(r.iterations / r.seconds, 1),
-                                    "spmv_gbs": round(spmv_bytes(s2.n, s2.nnz) / (ms * 1e-3) / 1e9, 1)}
+                                    "spmv_gbs": round(loop_kernel_bytes(s2) / (ms * 1e-3) / 1e9, 1)}
     del s2
     # config 3: ~1M-DoF unstructured stand-in (random symmetric permutation + SPD scaling of the 3-D matrix)
     A = poisson.unstructured_like_csr(3, 100, 0)
@@ -228,7 +243,7 @@ def extra_workloads(D, poisson, torch) -> dict:
         c3[name] = {"iterations": r.iterations, "ms": round(r.seconds * 1e3, 3), "iterations_per_s": round(r.iterations / r.seconds, 1)}
     c3["levels"] = s3.info()["levels_lower"]
     ms = s3.spmv_dot_bench(100)
-    c3["spmv_gbs"] = round(spmv_bytes(s3.n, s3.nnz) / (ms * 1e-3) / 1e9, 1)
+    c3["spmv_gbs"] = round(loop_kernel_bytes(s3) / (ms * 1e-3) / 1e9, 1)
     # the same system solved in reverse Cuthill-McKee ordering (setup on the host, b/x permuted on the device)
     t0 = time.perf_counter()
     s3r = D.CsrSystem.from_any(A, reorder="rcm")
@@ -281,7 +296,7 @@ def extra_workloads(D, poisson, torch) -> dict:
     s4.solve(b4, max_iter=16, want_history=False)
     r = s4.solve(b4, max_iter=64, want_history=False)
     ms = s4.spmv_dot_bench(50)
-    gbs = spmv_bytes(s4.n, s4.nnz) / (ms * 1e-3) / 1e9
+    gbs = loop_kernel_bytes(s4) / (ms * 1e-3) / 1e9
     out["c4_poisson3d_256_jacobi"] = {"iterations": r.iterations, "iterations_per_s": round(r.iterations / r.seconds, 2),
                                       "spmv_gbs": round(gbs, 1), "spmv_frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
     return out

@@ -19,7 +19,7 @@ ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_PIVOT, ERR_STATE = -1, -2, -3, -4, -5
 F64, F32 = 0, 1
 DEVICE, HOST = 0, 1
 PRECOND_NONE, PRECOND_JACOBI, PRECOND_CSR, PRECOND_LLT_MULTIPLY, PRECOND_LLT_SOLVE = 0, 1, 2, 3, 4
-INIT_CHECK_R, SPMV_F32, NO_GRAPH, NO_SMALL, VAL32_IF_LOSSLESS = 1, 2, 4, 8, 16
+INIT_CHECK_R, SPMV_F32, NO_GRAPH, NO_SMALL, VAL32_IF_LOSSLESS, NO_FUSE = 1, 2, 4, 8, 16, 32
 
 # name -> (restype, argtypes); every symbol include/dpcg.h declares
 _p = C.c_void_p

@@ -342,7 +342,7 @@ extern "C" int dpcg_destroy(dpcg_handle_t h) {
     free_csr(h->A);
     free_plan(h->planA);
     free_ell(h->ell_a);
-    dev_free(h->x); dev_free(h->r); dev_free(h->z); dev_free(h->p); dev_free(h->q); dev_free(h->t); dev_free(h->e);
+    dev_free(h->x); dev_free(h->r); dev_free(h->z); dev_free(h->p); dev_free(h->p2); dev_free(h->q); dev_free(h->t); dev_free(h->e);
     dev_free(h->p32);
     dev_free(h->part_pq); dev_free(h->part_rz); dev_free(h->part_rr); dev_free(h->part_bb);
     dev_free(h->scal); dev_free(h->hist); dev_free(h->err_hist); dev_free(h->small_desc);
@@ -356,12 +356,41 @@ extern "C" int dpcg_destroy(dpcg_handle_t h) {
     return DPCG_OK;
 }
 
+// Two-kernel updates (fused_head in dpcg_kernels.hip) trade one kernel boundary and one pass over p for a second
+// gather per non-zero.  Measured with tools/fuse_probe.py (Jacobi PCG, its/s, two- vs three-kernel): 16K rows
+// +18 %, 65K +20 %, 147K +12 %, 262K +8 %, 512K -6 %, 1M -8 % (scrambled 1M: -48 %).  So: systems below the x-tile
+// threshold, where an update is launch-bound rather than bandwidth-bound.
+static bool fuse_eligible(const dpcg_system *h, int flags, const double *x_true) {
+    static const int64_t max_rows = [] {
+        const char *e = getenv("DPCG_FUSE_MAX_ROWS");
+        return e ? (int64_t)atoll(e) : (int64_t)kTileMinBlocks * kStreamRows;
+    }();
+    if (x_true || (flags & (DPCG_NO_FUSE | DPCG_SPMV_F32))) return false;
+    if ((flags & DPCG_VAL32_IF_LOSSLESS) && h->A.val32_lossless == 1) return false;
+    if (h->A.n >= max_rows) return false;
+    return h->planA.kernel == SPMV_STREAM || h->planA.kernel == SPMV_TILE;
+}
+
+static FuseArgs fuse_args(dpcg_system *h) {
+    FuseArgs fa;
+    fa.z = h->precond == DPCG_PRECOND_NONE ? h->r : h->z;
+    fa.p0 = h->p;
+    fa.p1 = h->p2;
+    fa.xvec = h->x;
+    fa.part_rz = h->part_rz;
+    fa.part_rr = h->part_rr;
+    fa.n_part = h->vec_grid;
+    fa.hist = h->hist;
+    fa.hist_cap = h->hist_cap;
+    return fa;
+}
+
 extern "C" int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spmv_kernel, int *precond_kind,
                              int64_t *precond_nnz, int *n_levels_lower, int *n_levels_upper) {
     if (!h) return invalid("dpcg_get_info: NULL handle");
     if (n) *n = h->A.n;
     if (nnz) *nnz = h->A.nnz;
-    if (spmv_kernel) *spmv_kernel = h->planA.kernel;
+    if (spmv_kernel) *spmv_kernel = h->planA.kernel + (fuse_eligible(h, 0, nullptr) ? 16 : 0);   // +16: two-kernel updates
     if (precond_kind) *precond_kind = h->precond;
     if (precond_nnz) *precond_nnz = h->precond == DPCG_PRECOND_CSR ? h->M.nnz : h->L.nnz;
     if (n_levels_lower) *n_levels_lower = h->lvlL.n_levels;
@@ -830,12 +859,32 @@ extern "C" int dpcg_spmv_dot_bench(dpcg_handle_t h, const double *x, double *y, 
     DPCG_HIP(hipMemcpyAsync(h->part_rr, &one, sizeof(double), hipMemcpyHostToDevice, s));
     launch_finalize_init(h->scal, h->part_rr, h->part_rr, h->part_rr, 1, 0.0, 0.0, h->hist, 0, nullptr, s);
     IterCtl ctl{h->scal};
+    // the kernel a default solve launches: KA of the two-kernel iteration (update 0: beta = 0, so y = A x still
+    // holds with z := x) or the plain SpMV + <p,Ap> kernel of the three-kernel form
+    const bool fused = fuse_eligible(h, 0, nullptr);
+    FuseArgs fa;
+    if (fused) {
+        if (!h->p2) {
+            DPCG_TRY(dev_alloc(&h->p2, h->A.n));
+            drop_graph(h);
+        }
+        DPCG_HIP(hipMemsetAsync(h->p2, 0, (size_t)h->A.n * sizeof(double), s));
+        DPCG_HIP(hipMemsetAsync(h->x, 0, (size_t)h->A.n * sizeof(double), s));
+        DPCG_HIP(hipMemsetAsync(h->part_rz, 0, kMaxGrid * sizeof(double), s));
+        launch_fused_init(h->scal, s);
+        fa = fuse_args(h);
+        fa.z = x;
+    }
+    auto go = [&]() {
+        if (fused) launch_spmv_fused(h->A, h->planA, fa, y, h->part_pq, h->scal, s);
+        else launch_spmv(h->A, h->planA, x, y, h->part_pq, &ctl, s);
+    };
     hipEvent_t e0, e1;
     DPCG_HIP(hipEventCreate(&e0));
     DPCG_HIP(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) launch_spmv(h->A, h->planA, x, y, h->part_pq, &ctl, s);  // warm-up
+    for (int i = 0; i < 3; ++i) go();  // warm-up
     DPCG_HIP(hipEventRecord(e0, s));
-    for (int i = 0; i < repeats; ++i) launch_spmv(h->A, h->planA, x, y, h->part_pq, &ctl, s);
+    for (int i = 0; i < repeats; ++i) go();
     DPCG_HIP(hipEventRecord(e1, s));
     DPCG_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -860,6 +909,19 @@ static int default_chunk() {
 static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hipStream_t s) {
     const int64_t n = h->A.n;
     const bool f32 = (flags & DPCG_SPMV_F32) != 0;
+    if (fuse_eligible(h, flags, x_true)) {
+        // KA: test of the current iterate, p = z + beta p, deferred x += alpha p, q = A p, partials of <p,q>
+        launch_spmv_fused(h->A, h->planA, fuse_args(h), h->q, h->part_pq, h->scal, s);          // cg.py:71,83,79,75
+        // KB: alpha; r -= alpha q; (z = M r fused); partials <r,z>, <r,r>; k += 1                cg.py:78,80-82,86
+        const int pre = h->precond == DPCG_PRECOND_NONE ? 0 : (h->precond == DPCG_PRECOND_JACOBI ? 1 : 2);
+        launch_update_r_two_kernel(pre, n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->dinv, h->z, h->part_rz,
+                                   h->part_rr, h->vec_grid, s);
+        if (pre == 2) {
+            DPCG_TRY(apply_precond(h, h->r, h->z, s, true));                                     // cg.py:81
+            launch_dot_partials(n, h->scal, h->r, h->z, h->part_rz, h->vec_grid, s);             // cg.py:82
+        }
+        return DPCG_OK;
+    }
     IterCtl ctl{h->scal};
     // K1: (skip when done) Ap = A p + partials of <p,Ap>           cg.py:71,75,78
     const bool v32 = !f32 && (flags & DPCG_VAL32_IF_LOSSLESS) && h->A.val32_lossless == 1;
@@ -887,7 +949,8 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
 }
 
 static int ensure_graph(dpcg_system *h, int flags, int chunk) {
-    const int key = (h->precond << 8) | (flags & (DPCG_SPMV_F32 | DPCG_VAL32_IF_LOSSLESS)) | (h->A.val32_lossless == 1 ? 64 : 0);
+    const int key = (h->precond << 8) | (flags & (DPCG_SPMV_F32 | DPCG_VAL32_IF_LOSSLESS | DPCG_NO_FUSE)) |
+                    (h->A.val32_lossless == 1 ? 64 : 0) | (fuse_eligible(h, flags, nullptr) ? 128 : 0);
     if (h->graph_exec && h->graph_key == key && h->graph_chunk == chunk) return DPCG_OK;
     drop_graph(h);
     HandleExtras &ex = extras()[h];
@@ -937,6 +1000,7 @@ struct Solve {
     int enq = 0;             // updates enqueued so far
     bool complete = false;
     double t_iter = 0.0;     // measured seconds per update (0 = not known yet)
+    bool fused = false;           // two-kernel updates (x lags one update behind until finish())
     bool many_launches = false;   // an update is dozens of small launches (level-scheduled SpTRSV): always replay a graph
     std::chrono::steady_clock::time_point t0;
 
@@ -982,6 +1046,11 @@ struct Solve {
             dev_free(d_lossy);
             h->A.val32_lossless = lossy ? -1 : 1;
         }
+        fused = fuse_eligible(h, flags, x_true);
+        if (fused && !h->p2) {
+            DPCG_TRY(dev_alloc(&h->p2, n));
+            drop_graph(h);
+        }
         const int per_update = 3 + precond_launches(h);
         many_launches = per_update >= 16;
         if (many_launches) chunk = std::max(1, std::min(chunk, 1024 / per_update));   // keep the graph at ~1K nodes
@@ -1002,6 +1071,10 @@ struct Solve {
                           (flags & DPCG_INIT_CHECK_R) ? 1 : 0, h->vec_grid, s);
         launch_finalize_init(h->scal, h->part_bb, h->part_rz, h->part_rr, h->vec_grid, rtol_sq, atol_sq, h->hist,
                              h->hist_cap, ex.prog_dev, s);
+        if (fused) {
+            DPCG_HIP(hipMemsetAsync(h->p2, 0, (size_t)n * sizeof(double), s));       // "p_{-1}": multiplied by beta_0 = 0
+            launch_fused_init(h->scal, s);
+        }
         if (x_true) {                                                                // cg.py:27-29
             launch_anorm_err(n, h->scal, h->x, x_true, h->e, h->vec_grid, s);
             launch_spmv(h->A, h->planA, h->e, h->t, h->part_bb, nullptr, s);
@@ -1048,7 +1121,11 @@ struct Solve {
 
     int finish(double *x, int *iters, double *final_res, double *seconds, double *res_history, double *err_history) {
         const int64_t n = h->A.n;
-        launch_final_check(h->scal, s);
+        if (fused)
+            launch_final_fused(n, h->scal, h->part_rr, h->vec_grid, h->hist, h->hist_cap, h->x, h->p, h->p2, h->vec_grid,
+                               s);
+        else
+            launch_final_check(h->scal, s);
         DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
         DPCG_HIP(hipStreamSynchronize(s));
         const auto t1 = std::chrono::steady_clock::now();                            // cg.py:88

@@ -62,6 +62,7 @@ struct Scalars {
     double res;        // last tested squared relative residual
     double rtol_sq;    // cg.py:71 threshold
     double atol_sq;    // absolute threshold on <r,r> (0 for the reference)
+    double rz_prev;    // two-kernel iteration only: <r,z> of the previous iterate (+inf before the first update)
     int k;             // completed updates
     int done;          // 1 once the stopping test held (kernels become no-ops)
     int status;        // dpcg_status of the solve
@@ -132,6 +133,7 @@ struct dpcg_system {
     dpcg::Levels lvlL, lvlU;
     // work vectors (fp64[n]) and reduction partials
     double *x = nullptr, *r = nullptr, *z = nullptr, *p = nullptr, *q = nullptr, *t = nullptr, *e = nullptr;
+    double *p2 = nullptr;                 // second direction buffer of the two-kernel iteration
     float *p32 = nullptr;
     double *part_pq = nullptr, *part_rz = nullptr, *part_rr = nullptr, *part_bb = nullptr;
     dpcg::Scalars *scal = nullptr;        // device
@@ -166,6 +168,23 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 struct IterCtl {
     Scalars *scal;
 };
+// Extra operands of the SpMV kernels in the two-kernel iteration (see fused_head in dpcg_kernels.hip): the kernel
+// first forms p_k = z + beta p_{k-1} and x += alpha_{k-1} p_{k-1} (cg.py:83,79), then q = A p_k (cg.py:75).
+struct FuseArgs {
+    const double *z;          // preconditioned residual of the current iterate
+    double *p0, *p1;          // direction vectors: update k writes P[k & 1] and reads P[(k + 1) & 1]
+    double *xvec;             // the iterate, one update behind
+    const double *part_rz;    // partials of <r,z> and <r,r> of the current iterate (K2 or the initial state)
+    const double *part_rr;
+    int n_part;
+    double *hist;
+    int hist_cap;
+};
+void launch_spmv_fused(const CsrDev &A, const SpmvPlan &plan, const FuseArgs &fa, double *q, double *part_pq,
+                       Scalars *scal, hipStream_t s);
+void launch_fused_init(Scalars *scal, hipStream_t s);
+void launch_final_fused(int64_t n, Scalars *scal, const double *part_rr, int n_part, double *hist, int hist_cap,
+                        double *x, const double *p0, const double *p1, int grid, hipStream_t s);
 void launch_spmv(const CsrDev &A, const SpmvPlan &plan, const double *x, double *y, double *part_pq,
                  const IterCtl *ctl, hipStream_t s);
 void launch_spmv_f32in(const CsrDev &A, const SpmvPlan &plan, const float *x32, const double *x64, double *y,
@@ -177,6 +196,9 @@ void launch_spmv_val32(const CsrDev &A, const SpmvPlan &plan, const double *x, d
 void launch_val32_check(int64_t nnz, const double *val, float *val32, int *lossy_dev, hipStream_t s);
 void launch_spmv_f32out(const CsrDev &A, const SpmvPlan &plan, const float *x32, float *y32, hipStream_t s);
 
+void launch_update_r_two_kernel(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
+                                const double *q, double *r, const double *dinv, double *z, double *part_rz,
+                                double *part_rr, int grid, hipStream_t s);
 void launch_update_r(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
                      const double *q, double *r, const double *dinv, double *z, double *part_rz, double *part_rr,
                      int grid, hipStream_t s);

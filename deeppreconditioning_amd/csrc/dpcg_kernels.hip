@@ -102,6 +102,53 @@ __device__ __forceinline__ void record_and_test(Scalars *sc, double rr, double r
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two-kernel iteration.  CG has two global reductions per update (<p,Ap> and <r,z>), so two kernels is the floor:
+//   KA (an SpMV kernel with FUSE): every workgroup re-reduces the partials of <r,z> and <r,r> that KB (or the
+//      initial state) left, runs the stopping test of cg.py:71 on the current iterate k, forms
+//      beta = <r,z>_k / <r,z>_{k-1} (cg.py:82), then  p_k = z + beta p_{k-1} (cg.py:83) and the deferred
+//      x += alpha_{k-1} p_{k-1} (cg.py:79) for its own rows, and q = A p_k with the partials of <p_k,q>.  The
+//      columns it gathers are recomputed as z[c] + beta p_{k-1}[c]: the same expression, hence the same bits,
+//      as the stored p_k.  p is double-buffered (P[k & 1]) because neighbours still read p_{k-1}.
+//   KB (k_update_r<PRE, true>): alpha, r, z, partials as before; workgroup 0 also advances k and rz_prev.
+// x lags one update behind; k_final_fused applies the last one.  Before the first update rz_prev = +inf and
+// alpha = 0, P[1] = 0, so update 0 degenerates to p_0 = z_0, x unchanged.  Scalars obey the same rule as in the
+// three-kernel form: nobody reads a word that the same kernel writes (`done` excepted: a workgroup that sees it
+// set early returns, which is what it would have decided anyway).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool fused_head(Scalars *sc, const FuseArgs &f, double *sh, double &alpha, double &beta) {
+    if (sc->done) return false;
+    const int k = sc->k;                                   // updates completed (written by KB / the initial state)
+    double rz = 0.0, rr = 0.0;
+    for (int i = threadIdx.x; i < f.n_part; i += kBlock) {
+        rz += f.part_rz[i];
+        rr += f.part_rr[i];
+    }
+    block_sum2(rz, rr, sh);                                // the arithmetic of reduce_partials, twice
+    alpha = sc->alpha;
+    beta = rz / sc->rz_prev;                               // cg.py:82
+    bool stop = false;
+    if (k > 0) {                                           // iterate 0 was tested by k_finalize_init (cg.py:66)
+        const double res = rr / sc->bb;                    // cg.py:15-17
+        const bool conv = (res < sc->rtol_sq) || (rr < sc->atol_sq);   // cg.py:71
+        stop = conv || !(res == res);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (k < f.hist_cap) f.hist[k] = res;           // cg.py:88
+            sc->res = res;
+            if (stop) {
+                sc->status = conv ? DPCG_OK : DPCG_BREAKDOWN;
+                sc->done = 1;
+                if (sc->progress)
+                    __hip_atomic_store(sc->progress, ((unsigned long long)k << 1) | 1ull, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    if (stop) return false;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->rz = rz;  // <r,z> of the current iterate, read by KB (cg.py:76)
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // CSR-stream SpMV (rows with few non-zeros: 5/7-point stencils, OpenFOAM-like matrices).
 //
 // A workgroup takes 256 consecutive rows.  Their val[]/col[] segment is contiguous in CSR, so the
@@ -111,15 +158,16 @@ __device__ __forceinline__ void record_and_test(Scalars *sc, double rr, double r
 // rounding as a sequential CPU CSR row sum.  LDS reads are conflict-free for odd row lengths
 // (stride 5 or 7 doubles over 32 lanes).  Algorithmic bytes: nnz*(wv+4) + (n+1)*4 + 2*n*wx.
 // ------------------------------------------------------------------------------------------------
-template <typename VT, typename XT, bool CTL, bool DOT, typename YT>
+template <typename VT, typename XT, bool CTL, bool DOT, typename YT, bool FUSE = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t *__restrict__ rowptr,
                                                         const int32_t *__restrict__ col,
                                                         const VT *__restrict__ val, const XT *__restrict__ x,
                                                         const double *__restrict__ xdot, YT *__restrict__ y,
-                                                        int nrb, double *__restrict__ part_pq, IterCtlDev ctl) {
+                                                        int nrb, double *__restrict__ part_pq, IterCtlDev ctl,
+                                                        FuseArgs fa) {
     constexpr int U = kStreamCap / kBlock;  // (col,val) loads per thread per row-block
     __shared__ double prod[kStreamCap];
-    __shared__ double sh[4];
+    __shared__ double sh[8];
     const int t = threadIdx.x;
     // contiguous ranges of row-blocks per (virtual) workgroup, the remainder spread evenly over the
     // grid (so every XCD slab carries the same load); 32-bit scalar arithmetic only
@@ -154,16 +202,35 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t
     };
     // The first row-block's loads are issued before the `done` word is looked at.
     if (rb_lo < rb_hi) fetch(rb_lo);
-    if (CTL) {
+    double alpha = 0.0, beta = 0.0;
+    const double *__restrict__ p_old = nullptr;
+    double *__restrict__ p_new = nullptr;
+    if (FUSE) {
+        const int kpar = ctl.scal->k & 1;
+        p_new = kpar ? fa.p1 : fa.p0;
+        p_old = kpar ? fa.p0 : fa.p1;
+        if (!fused_head(ctl.scal, fa, sh, alpha, beta)) return;
+    } else if (CTL) {
         if (!iteration_head(ctl)) return;
     }
     double acc = 0.0;
     for (int rb = rb_lo; rb < rb_hi; ++rb) {
         const int64_t row = (int64_t)rb * kStreamRows + t;
         const int ks = rs - base, ke = re - base;
+        double zo = 0.0, po = 0.0, xo = 0.0;
+        if (FUSE && row < n) {
+            zo = fa.z[row];
+            po = p_old[row];
+            xo = fa.xvec[row];
+        }
         double xv[U];
+        if (FUSE) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) xv[u] = (double)x[c[u]];
+            for (int u = 0; u < U; ++u) xv[u] = fa.z[c[u]] + beta * p_old[c[u]];      // = p_k[c], cg.py:83
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = (double)x[c[u]];
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = t + u * kBlock;
@@ -174,7 +241,14 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t
             double s = 0.0;
             for (int k = ks; k < ke; ++k) s += prod[k];
             y[row] = (YT)s;
-            if (DOT) acc += s * xdot[row];
+            if (FUSE) {
+                const double pn = zo + beta * po;                                      // cg.py:83
+                p_new[row] = pn;
+                fa.xvec[row] = xo + alpha * po;                                        // cg.py:79, one update late
+                acc += s * pn;
+            } else if (DOT) {
+                acc += s * xdot[row];
+            }
         }
         __syncthreads();
         if (rb + 1 < rb_hi) fetch(rb + 1);
@@ -410,7 +484,7 @@ static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, 
     const bool c = ctl != nullptr;
 #define DPCG_LAUNCH_STREAM(CTLV, DOTV)                                                                     \
     hipLaunchKernelGGL((k_spmv_stream<VT, XT, CTLV, DOTV, YT>), dim3(plan.grid), dim3(kBlock), 0, s, A.n, \
-                       A.rowptr, A.col, val, x, xdot, y, plan.nrb, part_pq, d)
+                       A.rowptr, A.col, val, x, xdot, y, plan.nrb, part_pq, d, FuseArgs{})
 #define DPCG_LAUNCH_VECTOR(TPRV, CTLV, DOTV)                                                                     \
     hipLaunchKernelGGL((k_spmv_vector<TPRV, VT, XT, CTLV, DOTV, YT>), dim3(plan.grid), dim3(kBlock), 0, s, A.n, \
                        A.rowptr, A.col, val, x, xdot, y, part_pq, d)
@@ -456,6 +530,16 @@ static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, 
 #undef DPCG_VECTOR_CASE
 #undef DPCG_LAUNCH_VECTOR
 #undef DPCG_LAUNCH_STREAM
+}
+
+// KA of the two-kernel iteration (see fused_head): the gather kernel with FUSE.  A system whose plan is the x-tile
+// kernel is too large for this form to pay (dpcg_api.hip: fuse_eligible); should it be asked for anyway, the gather
+// kernel runs over the same row blocks.
+void launch_spmv_fused(const CsrDev &A, const SpmvPlan &plan, const FuseArgs &fa, double *q, double *part_pq,
+                       Scalars *scal, hipStream_t s) {
+    const IterCtlDev d{scal};
+    hipLaunchKernelGGL((k_spmv_stream<double, double, true, true, double, true>), dim3(plan.grid), dim3(kBlock), 0, s,
+                       A.n, A.rowptr, A.col, A.val, nullptr, nullptr, q, plan.nrb, part_pq, d, fa);
 }
 
 void launch_spmv(const CsrDev &A, const SpmvPlan &plan, const double *x, double *y, double *part_pq,
@@ -509,7 +593,7 @@ void launch_spmv_f32out(const CsrDev &A, const SpmvPlan &plan, const float *x32,
 // issued before the partial reduction so that its latency is hidden.
 // ------------------------------------------------------------------------------------------------
 // PRE: 0 = M = I (z aliases r, not stored), 1 = Jacobi fused, 2 = generic M (z computed later).
-template <int PRE>
+template <int PRE, bool F2 = false>   // F2: KB of the two-kernel iteration (workgroup 0 also advances k and rz_prev)
 __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restrict__ sc,
                                                      const double *__restrict__ part_pq, int n_part_pq,
                                                      const double *__restrict__ q, double *__restrict__ r,
@@ -532,8 +616,19 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
         if (PRE == 1) da = d2[i];
     }
     const double pq = reduce_partials(part_pq, n_part_pq, sh);
-    const double alpha = sc->rz / pq;                                   // cg.py:78
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc->alpha = alpha;         // read by K3 (a later kernel)
+    const double rz_cur = sc->rz;
+    const double alpha = rz_cur / pq;                                   // cg.py:78
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc->alpha = alpha;                                              // read by K3 / KA (a later kernel)
+        if (F2) {
+            const int k1 = sc->k + 1;                                   // this update is complete once KB has run
+            sc->rz_prev = rz_cur;                                       // read by the next KA only
+            sc->k = k1;
+            if (sc->progress)
+                __hip_atomic_store(sc->progress, (unsigned long long)k1 << 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     double a_rz = 0.0, a_rr = 0.0;
     while (have) {
         const int64_t cur = i;
@@ -576,6 +671,69 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
         part_rr[blockIdx.x] = a_rr;
         if (PRE != 2) part_rz[blockIdx.x] = PRE == 1 ? a_rz : a_rr;     // PRE 0: z = r; PRE 2: <r,z> comes later
     }
+}
+
+void launch_update_r_two_kernel(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
+                                const double *q, double *r, const double *dinv, double *z, double *part_rz,
+                                double *part_rr, int grid, hipStream_t s) {
+    if (precond_fused == 0)
+        hipLaunchKernelGGL((k_update_r<0, true>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r,
+                           dinv, z, part_rz, part_rr);
+    else if (precond_fused == 1)
+        hipLaunchKernelGGL((k_update_r<1, true>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r,
+                           dinv, z, part_rz, part_rr);
+    else
+        hipLaunchKernelGGL((k_update_r<2, true>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r,
+                           dinv, z, part_rz, part_rr);
+}
+
+// Two-kernel iteration: state before the first update (see fused_head).
+__global__ void k_fused_init(Scalars *sc) {
+    if (threadIdx.x == 0) {
+        sc->rz_prev = __builtin_huge_val();   // beta_0 = <r,z>_0 / inf = 0  =>  p_0 = z_0
+        sc->alpha = 0.0;                      // no deferred x update yet
+    }
+}
+
+void launch_fused_init(Scalars *scal, hipStream_t s) { hipLaunchKernelGGL(k_fused_init, dim3(1), dim3(64), 0, s, scal); }
+
+// End of a two-kernel solve: the deferred x += alpha_{k-1} p_{k-1} (cg.py:79) and, when the loop ran out of
+// updates, the test of the last iterate (cg.py:86-88; the status stays MAX_ITER unless it passes).
+__global__ __launch_bounds__(kBlock) void k_final_fused(int64_t n, Scalars *sc, const double *__restrict__ part_rr,
+                                                        int n_part, double *hist, int hist_cap, double *__restrict__ x,
+                                                        const double *__restrict__ p0, const double *__restrict__ p1) {
+    __shared__ double sh[4];
+    const int k = sc->k;
+    if (k >= 1) {
+        const double alpha = sc->alpha;
+        const double *__restrict__ p = ((k - 1) & 1) ? p1 : p0;
+        const int64_t stride = (int64_t)gridDim.x * kBlock;
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) x[i] = x[i] + alpha * p[i];
+    }
+    if (blockIdx.x == 0) {
+        const int done = sc->done;                         // uniform: written by an earlier kernel only
+        if (!done) {
+            const double rr = reduce_partials(part_rr, n_part, sh);
+            if (threadIdx.x == 0) {
+                if (k >= 1) {                              // iterate k has not been tested yet
+                    const double res = rr / sc->bb;
+                    const bool conv = (res < sc->rtol_sq) || (rr < sc->atol_sq);
+                    if (k < hist_cap) hist[k] = res;
+                    sc->res = res;
+                    sc->status = conv ? DPCG_OK : (!(res == res) ? DPCG_BREAKDOWN : DPCG_MAX_ITER);
+                } else {
+                    sc->status = DPCG_MAX_ITER;
+                }
+                sc->done = 1;
+            }
+        }
+    }
+}
+
+void launch_final_fused(int64_t n, Scalars *scal, const double *part_rr, int n_part, double *hist, int hist_cap,
+                        double *x, const double *p0, const double *p1, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(k_final_fused, dim3(grid), dim3(kBlock), 0, s, n, scal, part_rr, n_part, hist, hist_cap, x, p0,
+                       p1);
 }
 
 void launch_update_r(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,

@@ -333,7 +333,8 @@ class CsrSystem:
         k, pk, ll, lu = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         L.check(L.lib().dpcg_get_info(self._h, C.byref(n), C.byref(nnz), C.byref(k), C.byref(pk), C.byref(pn),
                                       C.byref(ll), C.byref(lu)))
-        return {"n": n.value, "nnz": nnz.value, "spmv_kernel": ("stream", "vector", "tile")[k.value],
+        return {"n": n.value, "nnz": nnz.value, "spmv_kernel": ("stream", "vector", "tile")[k.value & 15],
+                "two_kernel_updates": bool(k.value & 16),
                 "precond": pk.value, "precond_nnz": pn.value, "levels_lower": ll.value, "levels_upper": lu.value}
 
     def close(self) -> None:

@@ -61,10 +61,13 @@ enum dpcg_solve_flags {
     DPCG_SPMV_F32 = 2,       /* mixed precision: A@p with fp32 val and fp32 p, fp64 everywhere else */
     DPCG_NO_GRAPH = 4,       /* launch kernels one by one instead of replaying a hipGraph           */
     DPCG_NO_SMALL = 8,       /* do not use the one-workgroup whole-solve kernel for systems <= 6144 rows */
-    DPCG_VAL32_IF_LOSSLESS = 16 /* stream the matrix values as fp32 when every value survives the round trip
+    DPCG_VAL32_IF_LOSSLESS = 16, /* stream the matrix values as fp32 when every value survives the round trip
                                 fp64 -> fp32 -> fp64 unchanged (true for the reference's data, which is fp32
                                 upcast to fp64: data_set.py:121, test.py:68): 8 instead of 12 bytes per non-zero,
                                 products and sums still fp64, results bit-identical.  Ignored when lossy. */
+    DPCG_NO_FUSE = 32        /* run an update as three kernels (SpMV | r,z | x,p) instead of the default two, in
+                                which the SpMV kernel also forms p = z + beta p (cg.py:83) and the deferred
+                                x += alpha p (cg.py:79); same arithmetic, bit-identical results              */
 };
 
 /* ---- library ------------------------------------------------------------------------------- */

@@ -730,3 +730,55 @@ def test_solve_batch_general_path_interleaves_streams(D):
             assert torch.equal(o.x, s.x)
     its = [CO.pcg(A, O.rhs(A.shape[0], i), "jacobi", dinv=O.jacobi_dinv(A))[1] for i, A in enumerate(mats)]
     assert [s.iterations for s in single] == its
+
+
+# ---- two-kernel updates (SpMV kernel fused with p = z + beta p and the deferred x += alpha p) -----------------
+@pytest.mark.parametrize("make,pcs", [
+    (lambda: O.poisson2d(128), ("jacobi", "none", "ic0_multiply", "ic0_solve")),       # gather kernel, 64 row blocks
+    (lambda: O.poisson3d(60), ("jacobi", "none")),                                     # 216,000 rows, 844 row blocks
+    (lambda: O.unstructured_like(O.poisson3d(40), 1), ("jacobi", "ic0_solve")),        # scrambled: gather kernel
+])
+def test_two_kernel_updates_bit_identical_to_three_kernel_form(D, make, pcs):
+    """DPCG_NO_FUSE runs cg.py:75-86 as three kernels; the default two-kernel form regroups the same operations
+    (same expressions, same reduction orders), so iterates, histories and counts must agree to the last bit."""
+    A = make()
+    n = A.shape[0]
+    S = D.CsrSystem.from_any(A)
+    assert S.info()["two_kernel_updates"]
+    for seed, pc in enumerate(pcs):
+        S.set_preconditioner({"jacobi": D.Jacobi(), "none": None, "ic0_multiply": D.IC0(mode="multiply"),
+                              "ic0_solve": D.IC0(mode="solve")}[pc])
+        b = _dev(O.rhs(n, seed))
+        x0 = _dev(np.random.default_rng(seed).uniform(-1, 1, n)) if seed % 2 else None
+        for kw in (dict(), dict(max_iter=37), dict(max_iter=0), dict(max_iter=1), dict(flags=D._lib.NO_GRAPH)):
+            flags = kw.pop("flags", 0) | D._lib.NO_SMALL
+            two = S.solve(b, x0, flags=flags, **kw)
+            three = S.solve(b, x0, flags=flags | D._lib.NO_FUSE, **kw)
+            assert (two.iterations, two.status) == (three.iterations, three.status), (pc, kw)
+            assert np.array_equal(two.res_history, three.res_history), (pc, kw)
+            assert torch.equal(two.x, three.x), (pc, kw)
+            assert two.final_res == three.final_res
+
+
+def test_two_kernel_updates_against_oracle_and_breakdown(D):
+    A = O.poisson3d(60)
+    n = A.shape[0]
+    b = O.rhs(n, 5)
+    S = D.CsrSystem.from_any(A)
+    assert S.info()["two_kernel_updates"]
+    big = D.poisson.poisson_system(3, 80)          # 512,000 rows: past the threshold, three-kernel updates
+    assert not big.info()["two_kernel_updates"] and big.info()["spmv_kernel"] == "tile"
+    S.set_preconditioner(D.Jacobi())
+    res = S.solve(_dev(b))
+    _, it, hist, x = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A))
+    assert res.iterations == it and res.status == 0
+    np.testing.assert_allclose(res.res_history, hist, rtol=HIST_RTOL)
+    np.testing.assert_allclose(res.x.cpu().numpy(), x, rtol=1e-9, atol=1e-12)
+    # a NaN right-hand side: both forms report a breakdown after the same number of updates
+    bad = b.copy()
+    bad[n // 2] = np.nan
+    r2, r3 = S.solve(_dev(bad)), S.solve(_dev(bad), flags=D._lib.NO_FUSE)
+    assert (r2.status, r2.iterations) == (r3.status, r3.iterations)
+    # a system solved twice in a row reuses the cached graph and the second direction buffer
+    again = S.solve(_dev(b))
+    assert again.iterations == it and torch.equal(again.x, res.x)
