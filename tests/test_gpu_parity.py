@@ -234,6 +234,42 @@ def test_sptrsv_bit_exact(D, make):
     assert info["levels_lower"] >= 1 and info["levels_upper"] == info["levels_lower"]
 
 
+def _lower_factor_cases():
+    def wide2d():          # levels up to 600 rows wide: the ring kernel's two-rows-per-thread form
+        return CO.ic0(O.poisson2d(600))
+
+    def wider2d():         # levels up to 1100 rows: beyond the pipelined form, the one-level-ahead ring kernel
+        return CO.ic0(O.poisson2d(1100))
+
+    def cube3d():          # levels up to ~3000 rows: ring segment, per-level launches, ring segment that reaches back
+        return CO.ic0(O.poisson3d(64))
+
+    def chain():           # 20,000 levels of one row: more than one ring segment's worth of levels
+        return CO.ic0(sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(20000, 20000), format="csr"))
+
+    def long_rows():       # up to 6 off-diagonal entries per row: the general path inside the ring kernel
+        A = O.poisson2d(64)
+        return sp.tril(A @ A, format="csr")
+
+    return [wide2d, wider2d, cube3d, chain, long_rows]
+
+
+@pytest.mark.parametrize("make_L", _lower_factor_cases())
+def test_sptrsv_bit_exact_segment_forms(D, make_L):
+    """Every way launch_sptrsv can cut a factor into segments gives the bits of sequential substitution."""
+    Lf = make_L().tocsr()
+    Lf.sort_indices()
+    n = Lf.shape[0]
+    S = D.CsrSystem.from_any(sp.identity(n, format="csr"))
+    S.set_preconditioner(D.LLtSolve(Lf))
+    r = O.rhs(n, 9)
+    y = S.sptrsv(_dev(r), upper=False).cpu().numpy()
+    y_ref = CO.sptrsv_lower(Lf, r)
+    assert np.array_equal(y, y_ref)
+    z = S.sptrsv(_dev(y_ref), upper=True).cpu().numpy()
+    assert np.array_equal(z, CO.sptrsv_upper(CO.transpose_csr(Lf), y_ref))
+
+
 def test_pcg_llt_solve_golden(D, golden):
     A = O.poisson2d(64)
     b = _dev(O.rhs(A.shape[0], 0))
