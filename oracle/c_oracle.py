@@ -53,6 +53,10 @@ def num_threads() -> int:
     return int(lib().orc_num_threads())
 
 
+def set_num_threads(n: int) -> None:
+    lib().orc_set_num_threads(C.c_int(int(n)))
+
+
 def spmv(A: sp.csr_matrix, x: np.ndarray) -> np.ndarray:
     rp, ci, v = _csr_parts(A)
     x = np.ascontiguousarray(x, dtype=np.float64)
