@@ -380,26 +380,30 @@ void launch_tile_plan(const CsrDev &A, int nrb, int32_t *chunks, int32_t *nchunk
                        ok_and_max_dev);
 }
 
-template <bool CTL, bool DOT, int XT>   // XT: x-tile doubles staged per thread (tile_max_chunks * 64 / 256, rounded up)
+// XT: x-tile elements staged per thread (tile_max_chunks * 64 / 256, rounded up).  VT / XV: storage types of the
+// matrix values and of the staged vector (fp32 in the mixed-precision and lossless-fp32 modes; products and sums are
+// fp64 either way, and <p,Ap> always uses the fp64 vector `xdot`).
+template <bool CTL, bool DOT, int XT, typename VT, typename XV>
 __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *__restrict__ rowptr,
-                                                      const double *__restrict__ val,
+                                                      const VT *__restrict__ val,
                                                       const uint16_t *__restrict__ lidx,
                                                       const int32_t *__restrict__ chunks,
                                                       const int32_t *__restrict__ nchunks,
-                                                      const double *__restrict__ x, double *__restrict__ y, int nrb,
-                                                      int tile_doubles, double *__restrict__ part_pq, IterCtlDev ctl) {
+                                                      const XV *__restrict__ x, const double *__restrict__ xdot,
+                                                      double *__restrict__ y, int nrb, int tile_doubles,
+                                                      double *__restrict__ part_pq, IterCtlDev ctl) {
     constexpr int U = kStreamCap / kBlock;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *xs = smem;                      // the staged x chunks of this block
+    XV *xs = reinterpret_cast<XV *>(smem);  // the staged x chunks of this block (tile_doubles slots reserved)
     double *prod = smem + tile_doubles;     // products, kStreamCap doubles
     double *sh = prod + kStreamCap;         // 4 doubles for the block reduction
     const int t = threadIdx.x;
     const int v = virtual_block();
     int rb_lo, rb_hi;
     split_range(nrb, v, rb_lo, rb_hi);
-    double a[U];
+    VT a[U];
     int li[U];
-    double xt[XT];
+    XV xt[XT];
     int cnt = 0, base = 0, rs = 0, re = 0, nc = 0;
     const int lane = t & 63, wv = t >> 6;
     // Everything block `rb` needs from memory -> registers: its slice of the matrix stream AND its x chunks
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
         for (int u = 0; u < U; ++u) {
             const int k = t + u * kBlock;
             const int kk = k < cnt ? k : last;
-            a[u] = cnt > 0 ? val[base + kk] : 0.0;
+            a[u] = cnt > 0 ? val[base + kk] : (VT)0;
             li[u] = cnt > 0 ? (int)lidx[base + kk] : 0;
         }
         nc = nchunks[rb];
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
             if (ci < nc) {
                 const int chunk = __builtin_amdgcn_readfirstlane(cl[ci]);
                 const int64_t gi = (int64_t)chunk * kTileChunk + lane;
-                xt[u] = gi < n ? x[gi] : 0.0;
+                xt[u] = gi < n ? x[gi] : (XV)0;
             }
         }
     };
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = t + u * kBlock;
-            if (k < cnt_cur) prod[k] = a[u] * xs[li[u]];
+            if (k < cnt_cur) prod[k] = (double)a[u] * (double)xs[li[u]];
         }
         if (rb + 1 < rb_hi) fetch(rb + 1);   // next block's stream and x chunks are in flight from here on
         __syncthreads();
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
             double s = 0.0;
             for (int k = ks; k < ke; ++k) s += prod[k];
             y[row] = s;
-            if (DOT) acc += s * x[row];
+            if (DOT) acc += s * xdot[row];
         }
     }
     if (DOT) {
@@ -494,14 +498,13 @@ static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, 
         else if (dot) DPCG_LAUNCH_VECTOR(TPRV, false, true);  \
         else DPCG_LAUNCH_VECTOR(TPRV, false, false);          \
         break
-    if (plan.kernel == SPMV_TILE && std::is_same<VT, double>::value && std::is_same<XT, double>::value &&
-        std::is_same<YT, double>::value) {
+    if (plan.kernel == SPMV_TILE && std::is_same<YT, double>::value) {
         const int tile_doubles = plan.tile_max_chunks * kTileChunk;
         const size_t lds = (size_t)(tile_doubles + kStreamCap + 4) * sizeof(double);
 #define DPCG_LAUNCH_TILE_X(CTLV, DOTV, XTV)                                                                          \
-    hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV, XTV>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr,              \
-                       (const double *)val, plan.tile_lidx, plan.tile_chunks, plan.tile_nchunks, (const double *)x,  \
-                       (double *)y, plan.nrb, tile_doubles, part_pq, d)
+    hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV, XTV, VT, XT>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr,  \
+                       val, plan.tile_lidx, plan.tile_chunks, plan.tile_nchunks, x, xdot, (double *)y, plan.nrb,     \
+                       tile_doubles, part_pq, d)
 #define DPCG_LAUNCH_TILE(CTLV, DOTV)                                                  \
     do {                                                                              \
         if (plan.tile_max_chunks <= 20) DPCG_LAUNCH_TILE_X(CTLV, DOTV, 5);            \
@@ -555,9 +558,7 @@ void launch_spmv_f32in(const CsrDev &A, const SpmvPlan &plan, const float *x32, 
 
 void launch_spmv_val32(const CsrDev &A, const SpmvPlan &plan, const double *x, double *y, double *part_pq,
                        const IterCtl *ctl, hipStream_t s) {
-    SpmvPlan p = plan;
-    if (p.kernel == SPMV_TILE) p.kernel = SPMV_STREAM;   // the tile kernel reads fp64 values
-    spmv_dispatch<float, double, double>(A, p, A.val32, x, x, y, part_pq, ctl, s);
+    spmv_dispatch<float, double, double>(A, plan, A.val32, x, x, y, part_pq, ctl, s);
 }
 
 __global__ __launch_bounds__(kBlock) void k_val32_check(int64_t nnz, const double *__restrict__ val,
