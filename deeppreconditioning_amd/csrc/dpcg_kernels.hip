@@ -342,7 +342,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_plan(int64_t n, const int32_t *
         }
         const int cb = s_min / kTileChunk;
         const int span = s_max / kTileChunk - cb + 1;
-        if (span > kTileTableMax) {                       // columns too spread out: not tileable
+        // not tileable: columns too spread out, or no room for the alignment slot of the pair loads
+        if (span > kTileTableMax || cnt > kStreamCap - 1) {
             if (t == 0) { nchunks[rb] = 0; atomicExch(&ok_and_max[0], 0); }
             __syncthreads();
             continue;
@@ -391,42 +392,58 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
                                                       const int32_t *__restrict__ nchunks,
                                                       const XV *__restrict__ x, const double *__restrict__ xdot,
                                                       double *__restrict__ y, int nrb, int tile_doubles,
-                                                      double *__restrict__ part_pq, IterCtlDev ctl) {
+                                                      double *__restrict__ part_pq, IterCtlDev ctl, int64_t nnz) {
     constexpr int U = kStreamCap / kBlock;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     XV *xs = reinterpret_cast<XV *>(smem);  // the staged x chunks of this block (tile_doubles slots reserved)
-    double *prod = smem + tile_doubles;     // products, kStreamCap doubles
-    double *sh = prod + kStreamCap;         // 4 doubles for the block reduction
+    double *prod = smem + tile_doubles;     // products, kStreamCap + 2 doubles
+    double *sh = prod + kStreamCap + 2;     // 4 doubles for the block reduction
     const int t = threadIdx.x;
     const int v = virtual_block();
     int rb_lo, rb_hi;
     split_range(nrb, v, rb_lo, rb_hi);
-    VT a[U];
-    int li[U];
+    constexpr int UP = U / 2;               // pairs of consecutive non-zeros per thread
+    struct alignas(2 * sizeof(VT)) VPair { VT x, y; };
+    VPair a[UP];
+    uint32_t li[UP];                        // two 16-bit local indices per register
     XV xt[XT];
     int cnt = 0, base = 0, rs = 0, re = 0, nc = 0;
     const int lane = t & 63, wv = t >> 6;
     // Everything block `rb` needs from memory -> registers: its slice of the matrix stream AND its x chunks
     // (wave w stages chunks w, w+4, ...: 64 lanes x 8 B = one 512-B run; the chunk id is wave-uniform and travels
     // through the scalar unit).  Issued one block ahead, so the loads fly during the previous block's phases.
+    // The matrix slice is read as aligned PAIRS of consecutive non-zeros, lane i <-> pair i: 16-byte value loads
+    // (1 KiB per wave instruction) and 4-byte index loads instead of 8- and 2-byte ones -- the texture-address unit
+    // issues per instruction, not per byte.  Slots are counted from the even index at or below the block's first
+    // non-zero, so slot 0 may belong to the previous block (its product is never read).
     auto fetch = [&](int rb) {
         const int64_t r0 = (int64_t)rb * kStreamRows;
         const int64_t row = r0 + t;
         const int64_t rlast = (r0 + kStreamRows < n) ? r0 + kStreamRows : n;
-        base = rowptr[r0];
+        base = rowptr[r0] & ~1;
         cnt = rowptr[rlast] - base;
         rs = re = 0;
         if (row < n) {
             rs = rowptr[row];
             re = rowptr[row + 1];
         }
-        const int last = cnt > 0 ? cnt - 1 : 0;
+        const int lastp = cnt > 0 ? (cnt - 1) >> 1 : 0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = t + u * kBlock;
-            const int kk = k < cnt ? k : last;
-            a[u] = cnt > 0 ? val[base + kk] : (VT)0;
-            li[u] = cnt > 0 ? (int)lidx[base + kk] : 0;
+        for (int u = 0; u < UP; ++u) {
+            const int pr = t + u * kBlock;
+            const int64_t kabs = base + 2 * (int64_t)(pr <= lastp ? pr : lastp);
+            if (cnt > 0) {
+                if (kabs + 1 < nnz) {
+                    a[u] = *reinterpret_cast<const VPair *>(val + kabs);
+                } else {                    // the matrix's very last non-zero when nnz is odd
+                    a[u].x = val[kabs];
+                    a[u].y = (VT)0;
+                }
+                li[u] = *reinterpret_cast<const uint32_t *>(lidx + kabs);   // lidx is padded to an even length
+            } else {
+                a[u].x = a[u].y = (VT)0;
+                li[u] = 0;
+            }
         }
         nc = nchunks[rb];
         const int32_t *__restrict__ cl = chunks + (int64_t)rb * kTileMaxChunks;
@@ -455,9 +472,14 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
         }
         __syncthreads();                    // tile complete (and every thread is past the previous row sums)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = t + u * kBlock;
-            if (k < cnt_cur) prod[k] = (double)a[u] * (double)xs[li[u]];
+        for (int u = 0; u < UP; ++u) {
+            const int k = 2 * (t + u * kBlock);
+            if (k < cnt_cur) {              // one 16-byte LDS store per pair (slot cnt_cur may be written: never read)
+                double2 pp;
+                pp.x = (double)a[u].x * (double)xs[li[u] & 0xffffu];
+                pp.y = (double)a[u].y * (double)xs[li[u] >> 16];
+                *reinterpret_cast<double2 *>(prod + k) = pp;
+            }
         }
         if (rb + 1 < rb_hi) fetch(rb + 1);   // next block's stream and x chunks are in flight from here on
         __syncthreads();
@@ -500,11 +522,11 @@ static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, 
         break
     if (plan.kernel == SPMV_TILE && std::is_same<YT, double>::value) {
         const int tile_doubles = plan.tile_max_chunks * kTileChunk;
-        const size_t lds = (size_t)(tile_doubles + kStreamCap + 4) * sizeof(double);
+        const size_t lds = (size_t)(tile_doubles + kStreamCap + 6) * sizeof(double);
 #define DPCG_LAUNCH_TILE_X(CTLV, DOTV, XTV)                                                                          \
     hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV, XTV, VT, XT>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr,  \
                        val, plan.tile_lidx, plan.tile_chunks, plan.tile_nchunks, x, xdot, (double *)y, plan.nrb,     \
-                       tile_doubles, part_pq, d)
+                       tile_doubles, part_pq, d, A.nnz)
 #define DPCG_LAUNCH_TILE(CTLV, DOTV)                                                  \
     do {                                                                              \
         if (plan.tile_max_chunks <= 20) DPCG_LAUNCH_TILE_X(CTLV, DOTV, 5);            \

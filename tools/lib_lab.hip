@@ -43,7 +43,7 @@ int main(int argc, char **argv) {
         for (int g : tile_grids) { vs.push_back({"spmv+dot ctl (x-tile)", 3, g, true, b_spmv, 512}); }
         // x-tile plan
         SpmvPlan tplan; tplan.kernel = SPMV_TILE; tplan.nrb = (int)((N + 255) / 256);
-        CK(hipMalloc(&tplan.tile_chunks, (size_t)tplan.nrb * kTileMaxChunks * 4)); CK(hipMalloc(&tplan.tile_nchunks, (size_t)tplan.nrb * 4)); CK(hipMalloc(&tplan.tile_lidx, nnz * 2));
+        CK(hipMalloc(&tplan.tile_chunks, (size_t)tplan.nrb * kTileMaxChunks * 4)); CK(hipMalloc(&tplan.tile_nchunks, (size_t)tplan.nrb * 4)); CK(hipMalloc(&tplan.tile_lidx, nnz * 2 + 4));
         { int *fl; CK(hipMalloc(&fl, 8)); int hf[2] = {1, 0}; CK(hipMemcpy(fl, hf, 8, hipMemcpyHostToDevice));
           launch_tile_plan(A, tplan.nrb, tplan.tile_chunks, tplan.tile_nchunks, tplan.tile_lidx, fl, s); CK(hipStreamSynchronize(s));
           CK(hipMemcpy(hf, fl, 8, hipMemcpyDeviceToHost)); tplan.tile_max_chunks = hf[1]; printf("  tile plan: ok=%d max chunks=%d (LDS %zu B per block)\n", hf[0], hf[1], (size_t)(hf[1] * 64 + 2052) * 8); hipFree(fl); }
