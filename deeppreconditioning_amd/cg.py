@@ -50,7 +50,11 @@ def preconditioned_conjugate_gradient(A, b, M, x0=None, x_true=None, rtol=1e-8, 
     (fp64 everywhere else, BASELINE config 5); `compact_values` streams the matrix values as fp32
     when that is lossless (the reference's matrices are fp32 data upcast to fp64, test.py:68) --
     bit-identical results, 8 instead of 12 bytes per non-zero; `details=True` returns the full
-    `SolveResult`.
+    `SolveResult` (status 0 converged / 1 max_iter / 2 breakdown, residual history, x).
+
+    The plain return value follows the reference to the letter: `info` is always 0 (cg.py:90), and a NaN
+    breakdown (b = 0, NaN input, singular M), on which the reference keeps looping because `nan < rtol` is
+    false, reports `max_iter` iterations -- the library stops at the first NaN and says so in `details`.
     """
     del x_true  # unused by the reference's return value
     system = _system_and_device(A, b)
@@ -59,7 +63,8 @@ def preconditioned_conjugate_gradient(A, b, M, x0=None, x_true=None, rtol=1e-8, 
     result = system.solve(b, x0, rtol_sq=float(rtol), max_iter=int(max_iter), flags=flags)
     if details:
         return result
-    return result.seconds, result.iterations, result.status
+    iterations = int(max_iter) if result.status == L.BREAKDOWN else result.iterations
+    return result.seconds, iterations, 0
 
 
 def conjugate_gradient(A, b, x0=None, x_true=None, rtol=1e-8, max_iter=1024):

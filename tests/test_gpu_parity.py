@@ -161,6 +161,17 @@ def test_pcg_reference_signature(D, golden):
     assert iterations == int(golden["pcg_poisson2d_32_dense_jacobi_bseed3/iters"])
     with pytest.raises(TypeError):
         preconditioned_conjugate_gradient(A_t, b, object())  # unknown operator: refused, no fallback
+    # degenerate inputs, as the reference answers them (run here: (30, 0), (30, 0), (5, 0)): `info` is always 0
+    # (cg.py:90); on NaN the reference's `nan < rtol` never holds, so it reports max_iter; a capped solve reports the cap
+    A8 = O.poisson2d(8)
+    eye = sp.identity(64, format="csr")
+    assert preconditioned_conjugate_gradient(A8, torch.zeros(64, dtype=torch.float64), eye, max_iter=30)[1:] == (30, 0)
+    b_nan = O.rhs(64, 0)
+    b_nan[3] = np.nan
+    assert preconditioned_conjugate_gradient(A8, torch.from_numpy(b_nan), eye, max_iter=30)[1:] == (30, 0)
+    assert preconditioned_conjugate_gradient(A8, torch.from_numpy(O.rhs(64, 0)), eye, max_iter=5)[1:] == (5, 0)
+    full = preconditioned_conjugate_gradient(A8, torch.from_numpy(b_nan), eye, max_iter=30, details=True)
+    assert full.status == 2 and full.iterations < 30     # what the library itself saw
 
 
 def test_pcg_identity_x0_maxiter(D, golden):
