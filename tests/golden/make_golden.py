@@ -201,6 +201,29 @@ def main() -> None:
         out[f"benchmark_cg_poisson2d_{n}/jacobi"] = np.array([it1, info1], dtype=np.int64)
         print(f"benchmark_cg {n}: none {(it0, info0)} jacobi {(it1, info1)}", flush=True)
 
+    # --- edge cases of the drop-in signatures: what the reference RETURNS on degenerate arguments ----
+    A8 = O.poisson2d(8)
+    A8t, I8 = to_torch_csr(A8), to_torch_csr(sp.identity(64, format="csr"))
+    b8 = torch.from_numpy(O.rhs(64, 0))
+    b_nan = b8.clone()
+    b_nan[3] = float("nan")
+    edge = {
+        "rtol_1": ref_cg.preconditioned_conjugate_gradient(A8t, b8, I8, rtol=1.0)[1:],          # 1.0 < 1.0 is false
+        "rtol_1e9": ref_cg.preconditioned_conjugate_gradient(A8t, b8, I8, rtol=1e9)[1:],
+        "max_iter_0": ref_cg.preconditioned_conjugate_gradient(A8t, b8, I8, max_iter=0)[1:],
+        "max_iter_5": ref_cg.preconditioned_conjugate_gradient(A8t, b8, I8, max_iter=5)[1:],
+        "b_zero_max30": ref_cg.preconditioned_conjugate_gradient(A8t, torch.zeros_like(b8), I8, max_iter=30)[1:],
+        "b_nan_max30": ref_cg.preconditioned_conjugate_gradient(A8t, b_nan, I8, max_iter=30)[1:],
+    }
+    for k, v in edge.items():
+        out[f"edge_pcg/{k}"] = np.array(v, dtype=np.int64)
+    e0, x0_ = ref_cg.conjugate_gradient(A8t, b8, max_iter=0)
+    e1, _ = ref_cg.conjugate_gradient(A8t, b8, rtol=1.0)
+    out["edge_cg/max_iter_0_len"] = np.int64(len(e0))
+    out["edge_cg/max_iter_0_x"] = x0_.numpy().copy()
+    out["edge_cg/rtol_1_hist"] = np.array([float(r) for _, r in e1])
+    print("edge cases:", {k: tuple(int(t) for t in v) for k, v in edge.items()}, len(e0), out["edge_cg/rtol_1_hist"], flush=True)
+
     name = "reference_outputs_quick.npz" if args.quick else "reference_outputs.npz"
     np.savez_compressed(HERE / name, **out)
     print("wrote", HERE / name, (HERE / name).stat().st_size, "bytes")

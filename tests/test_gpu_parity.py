@@ -161,17 +161,32 @@ def test_pcg_reference_signature(D, golden):
     assert iterations == int(golden["pcg_poisson2d_32_dense_jacobi_bseed3/iters"])
     with pytest.raises(TypeError):
         preconditioned_conjugate_gradient(A_t, b, object())  # unknown operator: refused, no fallback
-    # degenerate inputs, as the reference answers them (run here: (30, 0), (30, 0), (5, 0)): `info` is always 0
-    # (cg.py:90); on NaN the reference's `nan < rtol` never holds, so it reports max_iter; a capped solve reports the cap
+
+
+def test_drop_in_signatures_on_degenerate_arguments(D, golden):
+    """What the reference RETURNS for edge arguments (fixtures `edge_*`, generated by running it): `info` is always 0
+    (cg.py:90); `rtol` is compared strictly (1.0 < 1.0 is false: one update); on NaN the reference's `nan < rtol`
+    never holds, so it reports max_iter."""
+    from deeppreconditioning_amd.cg import conjugate_gradient, preconditioned_conjugate_gradient
     A8 = O.poisson2d(8)
     eye = sp.identity(64, format="csr")
-    assert preconditioned_conjugate_gradient(A8, torch.zeros(64, dtype=torch.float64), eye, max_iter=30)[1:] == (30, 0)
-    b_nan = O.rhs(64, 0)
-    b_nan[3] = np.nan
-    assert preconditioned_conjugate_gradient(A8, torch.from_numpy(b_nan), eye, max_iter=30)[1:] == (30, 0)
-    assert preconditioned_conjugate_gradient(A8, torch.from_numpy(O.rhs(64, 0)), eye, max_iter=5)[1:] == (5, 0)
-    full = preconditioned_conjugate_gradient(A8, torch.from_numpy(b_nan), eye, max_iter=30, details=True)
+    b8 = torch.from_numpy(O.rhs(64, 0))
+    b_nan = b8.clone()
+    b_nan[3] = float("nan")
+    calls = {"rtol_1": dict(b=b8, rtol=1.0), "rtol_1e9": dict(b=b8, rtol=1e9), "max_iter_0": dict(b=b8, max_iter=0),
+             "max_iter_5": dict(b=b8, max_iter=5), "b_zero_max30": dict(b=torch.zeros_like(b8), max_iter=30),
+             "b_nan_max30": dict(b=b_nan, max_iter=30)}
+    for name, kw in calls.items():
+        b = kw.pop("b")
+        got = preconditioned_conjugate_gradient(A8, b, eye, **kw)[1:]
+        assert got == tuple(int(v) for v in golden[f"edge_pcg/{name}"]), name
+    full = preconditioned_conjugate_gradient(A8, b_nan, eye, max_iter=30, details=True)
     assert full.status == 2 and full.iterations < 30     # what the library itself saw
+    errors, x = conjugate_gradient(A8, b8, max_iter=0)
+    assert len(errors) == int(golden["edge_cg/max_iter_0_len"])
+    assert np.array_equal(x.cpu().numpy(), golden["edge_cg/max_iter_0_x"])
+    errors, _ = conjugate_gradient(A8, b8, rtol=1.0)
+    np.testing.assert_allclose([float(r) for _, r in errors], golden["edge_cg/rtol_1_hist"], rtol=HIST_RTOL)
 
 
 def test_pcg_identity_x0_maxiter(D, golden):

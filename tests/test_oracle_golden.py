@@ -167,3 +167,24 @@ def test_spmv_c_bit_exact_vs_scipy():
     for A in (O.poisson2d(37), O.poisson3d(11), O.unstructured_like(O.poisson3d(9), 4)):
         x = O.rhs(A.shape[0], 9)
         assert np.array_equal(CO.spmv(A, x), A @ x)
+
+
+def test_edge_arguments(golden):
+    """The restatements answer degenerate arguments as the reference does (fixtures `edge_*`): strict `<` against
+    rtol, max_iter 0, and a NaN that never satisfies the test (the loop runs to max_iter, cg.py:70-71)."""
+    A = O.poisson2d(8)
+    b = O.rhs(64, 0)
+    b_nan = b.copy()
+    b_nan[3] = np.nan
+    cases = {"rtol_1": dict(b=b, rtol=1.0), "rtol_1e9": dict(b=b, rtol=1e9), "max_iter_0": dict(b=b, max_iter=0),
+             "max_iter_5": dict(b=b, max_iter=5), "b_zero_max30": dict(b=np.zeros(64), max_iter=30),
+             "b_nan_max30": dict(b=b_nan, max_iter=30)}
+    for name, kw in cases.items():
+        want = int(golden[f"edge_pcg/{name}"][0])
+        rhs = kw.pop("b")
+        assert O.preconditioned_conjugate_gradient(A, rhs, O.Precond("none"), **kw)[1] == want, name
+        assert CO.pcg(A, rhs, "none", **kw)[1] == want, name
+    errors, x = O.conjugate_gradient(A, b, max_iter=0)
+    assert len(errors) == int(golden["edge_cg/max_iter_0_len"]) and np.array_equal(x, golden["edge_cg/max_iter_0_x"])
+    errors, _ = O.conjugate_gradient(A, b, rtol=1.0)
+    np.testing.assert_allclose([r for _, r in errors], golden["edge_cg/rtol_1_hist"], rtol=HIST_RTOL)
