@@ -85,15 +85,18 @@ class BenchmarkSuite:
             return LLtMultiply(lower_factor_csr(out, 0, original_size))
         raise ValueError(name)
 
-    def _density_and_kappa(self, system: CsrSystem, n: int):
-        """100 * nnz(M) / n^2 (test.py:107-109) and cond(M A) (test.py:111-113) -- reporting only, small n only."""
+    def _density_and_kappa(self, system: CsrSystem, n: int, want_spectrum: bool = False):
+        """100 * nnz(M) / n^2 (test.py:107-109), cond(M A) (test.py:111-113) and, for the first sample, the singular
+        values of M A (test.py:115-117) -- reporting only, dense N x N, small n only."""
         if n > self.kappa_max_n:
-            return float("nan"), float("nan")
+            return float("nan"), float("nan"), None
         eye = torch.eye(n, dtype=torch.float64, device=system.device)
         M = torch.stack([system.precond_apply(eye[:, j]) for j in range(n)], dim=1)
         A = torch.stack([system @ eye[:, j] for j in range(n)], dim=1)
         density = 100.0 * float((M != 0).sum()) / (n * n)
-        return density, float(torch.linalg.cond(M @ A))
+        MA = M @ A
+        spectrum = torch.linalg.svdvals(MA).tolist() if want_spectrum else None
+        return density, float(torch.linalg.cond(MA)), spectrum
 
     def run(self) -> None:
         """test.py:119-155."""
@@ -102,6 +105,7 @@ class BenchmarkSuite:
             n = int(original_size[0])
             system = self._reconstruct_system(system_tril, n)
             rhs = right_hand_side[0, :n].squeeze().to(torch.float64)
+            eigenvalues = {}
             for name in self.techniques:
                 torch.cuda.synchronize()
                 start = time.perf_counter()
@@ -109,14 +113,22 @@ class BenchmarkSuite:
                 torch.cuda.synchronize()
                 setup = time.perf_counter() - start if name != "vanilla" else 0.0      # test.py:135
                 duration, iteration, info = preconditioned_conjugate_gradient(system, rhs, system._precond)
-                density, kappa = self._density_and_kappa(system, n)
+                density, kappa, spectrum = self._density_and_kappa(system, n, want_spectrum=index == 0)
+                if spectrum is not None:
+                    eigenvalues[name] = spectrum
                 self.kappas[name].append(kappa)
                 self.densities[name].append(density)
                 self.iterations[name].append(iteration)
                 self.setups[name].append(setup)
                 self.durations[name].append(duration)
                 self.totals[name].append(setup + duration)
-                self.successes[name].append(100 * (1 if info == 0 else 0))             # test.py:149
+                self.successes[name].append(100 * (1 - info))                          # test.py:149
+            if index == 0 and eigenvalues:                                              # test.py:151-155
+                self.results_directory.mkdir(parents=True, exist_ok=True)
+                with (self.results_directory / "eigenvalues.csv").open(mode="w") as f:
+                    f.write(",".join(eigenvalues.keys()) + "\n")
+                    for row in zip(*eigenvalues.values()):
+                        f.write(",".join(str(v) for v in row) + "\n")
             system.close()
 
     def dump_csv(self) -> None:

@@ -526,6 +526,13 @@ def test_benchmark_suite_harness(D, tmp_path):
     assert [r[0] for r in rows[1:]] == list(suite.techniques)
     totals = list(csv.reader((tmp_path / "totals.csv").open()))
     assert totals[0] == list(suite.techniques) and len(totals) == 1 + len(mats)
+    eig = list(csv.reader((tmp_path / "eigenvalues.csv").open()))    # test.py:151-155: singular values of M A, sample 0
+    assert eig[0] == list(suite.techniques) and len(eig) == 1 + mats[0].shape[0]
+    sv_vanilla = np.array([float(r[0]) for r in eig[1:]])
+    low0 = sp.tril(mats[0], format="csr")
+    low0.data = low0.data.astype(np.float32).astype(np.float64)
+    A0 = (low0 + sp.tril(low0, -1).T).toarray()
+    np.testing.assert_allclose(sv_vanilla, np.linalg.svd(A0, compute_uv=False), rtol=1e-10)
 
 
 # ---- small systems: the whole solve in one launch (one workgroup per system) -------------------------------
