@@ -205,10 +205,28 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t
     double alpha = 0.0, beta = 0.0;
     const double *__restrict__ p_old = nullptr;
     double *__restrict__ p_new = nullptr;
+    // FUSE: the operands of p_k = z + beta p_{k-1} for the gathered columns and the own row.  Those of the first
+    // row block are requested BEFORE the head (whose partial reduction is two dependent round trips), so the
+    // launch-bound systems this form serves (one row block per workgroup) overlap the two latencies.
+    double zg[FUSE ? U : 1], pg[FUSE ? U : 1], zo = 0.0, po = 0.0, xo = 0.0;
+    auto gather_fused = [&](int rb) {
+        const int64_t row = (int64_t)rb * kStreamRows + t;
+        if (row < n) {
+            zo = fa.z[row];
+            po = p_old[row];
+            xo = fa.xvec[row];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            zg[u] = fa.z[c[u]];
+            pg[u] = p_old[c[u]];
+        }
+    };
     if (FUSE) {
         const int kpar = ctl.scal->k & 1;
         p_new = kpar ? fa.p1 : fa.p0;
         p_old = kpar ? fa.p0 : fa.p1;
+        if (rb_lo < rb_hi) gather_fused(rb_lo);
         if (!fused_head(ctl.scal, fa, sh, alpha, beta)) return;
     } else if (CTL) {
         if (!iteration_head(ctl)) return;
@@ -217,16 +235,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t
     for (int rb = rb_lo; rb < rb_hi; ++rb) {
         const int64_t row = (int64_t)rb * kStreamRows + t;
         const int ks = rs - base, ke = re - base;
-        double zo = 0.0, po = 0.0, xo = 0.0;
-        if (FUSE && row < n) {
-            zo = fa.z[row];
-            po = p_old[row];
-            xo = fa.xvec[row];
-        }
+        if (FUSE && rb != rb_lo) gather_fused(rb);
         double xv[U];
         if (FUSE) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) xv[u] = fa.z[c[u]] + beta * p_old[c[u]];      // = p_k[c], cg.py:83
+            for (int u = 0; u < U; ++u) xv[u] = zg[u] + beta * pg[u];                 // = p_k[c], cg.py:83
         } else {
 #pragma unroll
             for (int u = 0; u < U; ++u) xv[u] = (double)x[c[u]];

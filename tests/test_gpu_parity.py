@@ -835,7 +835,8 @@ def test_two_kernel_updates_against_oracle_and_breakdown(D):
     b = O.rhs(n, 5)
     S = D.CsrSystem.from_any(A)
     assert S.info()["two_kernel_updates"]
-    big = D.poisson.poisson_system(3, 80)          # 512,000 rows: past the threshold, three-kernel updates
+    from deeppreconditioning_amd import poisson
+    big = poisson.poisson_system(3, 80)            # 512,000 rows: past the threshold, three-kernel updates
     assert not big.info()["two_kernel_updates"] and big.info()["spmv_kernel"] == "tile"
     S.set_preconditioner(D.Jacobi())
     res = S.solve(_dev(b))
