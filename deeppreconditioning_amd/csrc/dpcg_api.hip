@@ -357,7 +357,7 @@ extern "C" int dpcg_destroy(dpcg_handle_t h) {
     return DPCG_OK;
 }
 
-// Two-kernel updates (fused_head in dpcg_kernels.hip) trade one kernel boundary and one pass over p for a second
+// Two-kernel updates (fused_head in dpcg_device.h) trade one kernel boundary and one pass over p for a second
 // gather per non-zero.  Measured with tools/fuse_probe.py (Jacobi PCG, its/s, two- vs three-kernel): 16K rows
 // +18 %, 65K +20 %, 147K +12 %, 262K +8 %, 512K -6 %, 1M -8 % (scrambled 1M: -48 %).  So: systems below the x-tile
 // threshold, where an update is launch-bound rather than bandwidth-bound.

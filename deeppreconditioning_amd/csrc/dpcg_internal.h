@@ -161,14 +161,14 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         if (_e != hipSuccess) return ::dpcg::hip_fail(_e, #call, __FILE__, __LINE__); \
     } while (0)
 
-// ---- kernel launchers (dpcg_kernels.hip) -----------------------------------------------------
+// ---- kernel launchers (dpcg_spmv.hip, dpcg_pcg.hip, dpcg_sptrsv.hip, dpcg_setup.hip) -----------------------------------------------------
 // y = A x.  If part_pq != nullptr also writes per-workgroup partials of <x, y> (plan.grid of them).
 // `ctl` (may be null): when given, the kernel is the head of a PCG update: it returns at once when
-// the device-resident `done` word is set and rotates rz_next -> rz (see dpcg_kernels.hip).
+// the device-resident `done` word is set and rotates rz_next -> rz (see dpcg_device.h).
 struct IterCtl {
     Scalars *scal;
 };
-// Extra operands of the SpMV kernels in the two-kernel iteration (see fused_head in dpcg_kernels.hip): the kernel
+// Extra operands of the SpMV kernels in the two-kernel iteration (see fused_head in dpcg_device.h): the kernel
 // first forms p_k = z + beta p_{k-1} and x += alpha_{k-1} p_{k-1} (cg.py:83,79), then q = A p_k (cg.py:75).
 struct FuseArgs {
     const double *z;          // preconditioned residual of the current iterate

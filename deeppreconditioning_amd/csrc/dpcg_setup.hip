@@ -1,0 +1,136 @@
+// Setup and utility kernels: plan analysis, on-device Poisson generators, the batched COO SpMV of utils.py:15-43.
+// Compiled with -ffp-contract=off so that a*b+c is two roundings, as in the CPU reference path (scipy/ATen CSR row
+// sums, unfused torch mul+add at cg.py:79-83); in-order sums then reproduce the oracle bit for bit.
+#include "dpcg_device.h"
+
+namespace dpcg {
+
+// ------------------------------------------------------------------------------------------------
+// Setup helpers
+// ------------------------------------------------------------------------------------------------
+// max over row-blocks of the non-zeros in `rows_per_block` consecutive rows (stream-kernel test).
+__global__ __launch_bounds__(kBlock) void k_block_nnz_max(int64_t n, const int32_t *__restrict__ rowptr,
+                                                          int rows_per_block, int *out_max) {
+    const int64_t nrb = (n + rows_per_block - 1) / rows_per_block;
+    int m = 0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t rb = (int64_t)blockIdx.x * kBlock + threadIdx.x; rb < nrb; rb += stride) {
+        const int64_t r0 = rb * rows_per_block;
+        const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+        const int c = rowptr[r1] - rowptr[r0];
+        m = c > m ? c : m;
+    }
+    atomicMax(out_max, m);
+}
+
+void launch_block_nnz_max(const CsrDev &A, int rows_per_block, int *out_max_dev, hipStream_t s) {
+    const int64_t nrb = (A.n + rows_per_block - 1) / rows_per_block;
+    int64_t g = (nrb + kBlock - 1) / kBlock;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_block_nnz_max, dim3((int)g), dim3(kBlock), 0, s, A.n, A.rowptr, rows_per_block, out_max_dev);
+}
+
+// Closed-form 5-point / 7-point Poisson CSR (kron(I,T)+kron(T,I)[+...], T = tridiag(-1,2,-1)),
+// one thread per row, columns ascending.  Generated in HBM so the 256^3 systems (1.4 GB each) never
+// cross PCIe.
+template <typename VT>
+__global__ __launch_bounds__(kBlock) void k_gen_poisson(int dim, int64_t n, int32_t *__restrict__ rowptr,
+                                                        int32_t *__restrict__ col, VT *__restrict__ val) {
+    const int64_t n2 = n * n;
+    const int64_t N = dim == 2 ? n2 : n2 * n;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= N; i += stride) {
+        // non-zeros before row i: full stencil minus the neighbours cut off by each face
+        int64_t before;
+        if (dim == 2) {
+            const int64_t lo_y = i < n ? i : n;                         // rows with iy == 0
+            const int64_t hi_y = i > n * (n - 1) ? i - n * (n - 1) : 0; // rows with iy == n-1
+            before = 5 * i - lo_y - hi_y - (i + n - 1) / n - i / n;
+        } else {
+            const int64_t lo_z = i < n2 ? i : n2;
+            const int64_t hi_z = i > n2 * (n - 1) ? i - n2 * (n - 1) : 0;
+            const int64_t planes = i / n2, rem = i % n2;
+            const int64_t lo_y = planes * n + (rem < n ? rem : n);
+            const int64_t hi_y = planes * n + (rem > n * (n - 1) ? rem - n * (n - 1) : 0);
+            before = 7 * i - lo_z - hi_z - lo_y - hi_y - (i + n - 1) / n - i / n;
+        }
+        rowptr[i] = (int32_t)before;
+        if (i == N) continue;
+        int64_t k = before;
+        const int64_t ix = i % n, iy = (i / n) % n, iz = i / n2;
+        if (dim == 3 && iz > 0) { col[k] = (int32_t)(i - n2); val[k++] = (VT)-1; }
+        if (iy > 0) { col[k] = (int32_t)(i - n); val[k++] = (VT)-1; }
+        if (ix > 0) { col[k] = (int32_t)(i - 1); val[k++] = (VT)-1; }
+        col[k] = (int32_t)i;
+        val[k++] = (VT)(dim == 2 ? 4 : 6);
+        if (ix < n - 1) { col[k] = (int32_t)(i + 1); val[k++] = (VT)-1; }
+        if (iy < n - 1) { col[k] = (int32_t)(i + n); val[k++] = (VT)-1; }
+        if (dim == 3 && iz < n - 1) { col[k] = (int32_t)(i + n2); val[k++] = (VT)-1; }
+    }
+}
+
+void launch_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void *val, int val_dtype, hipStream_t s) {
+    const int64_t N = dim == 2 ? n * n : n * n * n;
+    int64_t g = (N + 1 + kBlock - 1) / kBlock;
+    if (g > 8192) g = 8192;
+    if (val_dtype == DPCG_F32)
+        hipLaunchKernelGGL(k_gen_poisson<float>, dim3((int)g), dim3(kBlock), 0, s, dim, n, rowptr, col, (float *)val);
+    else
+        hipLaunchKernelGGL(k_gen_poisson<double>, dim3((int)g), dim3(kBlock), 0, s, dim, n, rowptr, col,
+                           (double *)val);
+}
+
+// sparse_matvec_mul (utils.py:26-41): out[b, row] += feature * vec[b, col] over COO triples.
+// One lane per triple, fp32 atomics on the output -- the same scatter-add the reference's own
+// CUDA path performs (torch scatter_reduce on a GPU tensor is an atomicAdd).
+__global__ __launch_bounds__(kBlock) void k_batched_coo_spmv(int64_t nnz, const int32_t *__restrict__ idx,
+                                                             const float *__restrict__ feat, int batch, int64_t dof,
+                                                             const float *__restrict__ vec, float *__restrict__ out,
+                                                             int transpose) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += stride) {
+        const int b = idx[3 * k];
+        const int r = idx[3 * k + (transpose ? 2 : 1)];                 // utils.py:27
+        const int c = idx[3 * k + (transpose ? 1 : 2)];                 // utils.py:28
+        if (b < 0 || b >= batch || r < 0 || r >= dof || c < 0 || c >= dof) continue;
+        atomicAdd(out + (int64_t)b * dof + r, feat[k] * vec[(int64_t)b * dof + c]);   // utils.py:32,36-41
+    }
+}
+
+// Per-triple products out[k] = a[b, row_k] * c[b, col_k]: the gradient of sparse_matvec_mul with respect to the
+// matrix entries (d/d feature_k of sum_b <g_b, A_b v_b> = g[b,row_k] * v[b,col_k]); needed to train through
+// `frobenius_loss` (metrics.py:28-29).
+__global__ __launch_bounds__(kBlock) void k_batched_coo_edge(int64_t nnz, const int32_t *__restrict__ idx, int batch,
+                                                             int64_t dof, const float *__restrict__ a,
+                                                             const float *__restrict__ c, float *__restrict__ out,
+                                                             int transpose) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += stride) {
+        const int b = idx[3 * k];
+        const int r = idx[3 * k + (transpose ? 2 : 1)];
+        const int cc = idx[3 * k + (transpose ? 1 : 2)];
+        const bool ok = b >= 0 && b < batch && r >= 0 && r < dof && cc >= 0 && cc < dof;
+        out[k] = ok ? a[(int64_t)b * dof + r] * c[(int64_t)b * dof + cc] : 0.0f;
+    }
+}
+
+void launch_batched_coo_edge(int64_t nnz, const int32_t *indices, int batch, int64_t dof, const float *a, const float *c,
+                             float *out, int transpose, hipStream_t s) {
+    int64_t g = (nnz + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_batched_coo_edge, dim3((int)g), dim3(kBlock), 0, s, nnz, indices, batch, dof, a, c, out,
+                       transpose);
+}
+
+void launch_batched_coo_spmv(int64_t nnz, const int32_t *indices, const float *features, int batch, int64_t dof,
+                             const float *vectors, float *out, int transpose, hipStream_t s) {
+    int64_t g = (nnz + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_batched_coo_spmv, dim3((int)g), dim3(kBlock), 0, s, nnz, indices, features, batch, dof,
+                       vectors, out, transpose);
+}
+
+}  // namespace dpcg

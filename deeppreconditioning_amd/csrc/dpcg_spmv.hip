@@ -1,0 +1,485 @@
+// SpMV kernels of libdpcg.so -- hand-written HIP for gfx950 (MI355X, CDNA4, wave64): CSR-stream (gather), CSR-vector
+// and x-tile kernels, the tile plan, and their dispatch.  HBM-bandwidth work: coalesced streams, LDS staging, enough
+// workgroups in flight; no MFMA (there is no dense contraction).
+// Compiled with -ffp-contract=off so that a*b+c is two roundings, as in the CPU reference path (scipy/ATen CSR row
+// sums, unfused torch mul+add at cg.py:79-83); in-order sums then reproduce the oracle bit for bit.
+#include <algorithm>
+#include <type_traits>
+
+#include "dpcg_device.h"
+
+namespace dpcg {
+
+// ------------------------------------------------------------------------------------------------
+// CSR-stream SpMV (rows with few non-zeros: 5/7-point stencils, OpenFOAM-like matrices).
+//
+// A workgroup takes 256 consecutive rows.  Their val[]/col[] segment is contiguous in CSR, so the
+// 256 threads stream it with fully coalesced loads (lane i <-> non-zero base+i), multiply by the
+// gathered x[col] (served by L1/L2: neighbouring rows share columns) and park the products in LDS.
+// After a barrier thread i adds up the products of row i IN COLUMN ORDER -- the same order and
+// rounding as a sequential CPU CSR row sum.  LDS reads are conflict-free for odd row lengths
+// (stride 5 or 7 doubles over 32 lanes).  Algorithmic bytes: nnz*(wv+4) + (n+1)*4 + 2*n*wx.
+// ------------------------------------------------------------------------------------------------
+template <typename VT, typename XT, bool CTL, bool DOT, typename YT, bool FUSE = false>
+__global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t *__restrict__ rowptr,
+                                                        const int32_t *__restrict__ col,
+                                                        const VT *__restrict__ val, const XT *__restrict__ x,
+                                                        const double *__restrict__ xdot, YT *__restrict__ y,
+                                                        int nrb, double *__restrict__ part_pq, IterCtlDev ctl,
+                                                        FuseArgs fa) {
+    constexpr int U = kStreamCap / kBlock;  // (col,val) loads per thread per row-block
+    __shared__ double prod[kStreamCap];
+    __shared__ double sh[8];
+    const int t = threadIdx.x;
+    // contiguous ranges of row-blocks per (virtual) workgroup, the remainder spread evenly over the
+    // grid (so every XCD slab carries the same load); 32-bit scalar arithmetic only
+    const int v = virtual_block();
+    int rb_lo, rb_hi;
+    split_range(nrb, v, rb_lo, rb_hi);
+    int c[U];
+    VT a[U];
+    int cnt = 0, base = 0, rs = 0, re = 0;   // rs/re stay absolute until the row-sum phase (no early wait)
+    // matrix stream of one row-block -> registers (all 2U loads of a thread in flight at once)
+    auto fetch = [&](int rb) {
+        const int64_t r0 = (int64_t)rb * kStreamRows;
+        const int64_t row = r0 + t;
+        const int64_t rlast = (r0 + kStreamRows < n) ? r0 + kStreamRows : n;
+        base = rowptr[r0];
+        cnt = rowptr[rlast] - base;
+        rs = re = 0;
+        if (row < n) {
+            rs = rowptr[row];
+            re = rowptr[row + 1];
+        }
+        const int32_t *__restrict__ cb = col + base;
+        const VT *__restrict__ vb = val + base;
+        const int last = cnt > 0 ? cnt - 1 : 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = t + u * kBlock;
+            const int kk = k < cnt ? k : last;
+            c[u] = cnt > 0 ? cb[kk] : 0;
+            a[u] = cnt > 0 ? vb[kk] : (VT)0;
+        }
+    };
+    // The first row-block's loads are issued before the `done` word is looked at.
+    if (rb_lo < rb_hi) fetch(rb_lo);
+    double alpha = 0.0, beta = 0.0;
+    const double *__restrict__ p_old = nullptr;
+    double *__restrict__ p_new = nullptr;
+    // FUSE: the operands of p_k = z + beta p_{k-1} for the gathered columns and the own row.  Those of the first
+    // row block are requested BEFORE the head (whose partial reduction is two dependent round trips), so the
+    // launch-bound systems this form serves (one row block per workgroup) overlap the two latencies.
+    double zg[FUSE ? U : 1], pg[FUSE ? U : 1], zo = 0.0, po = 0.0, xo = 0.0;
+    auto gather_fused = [&](int rb) {
+        const int64_t row = (int64_t)rb * kStreamRows + t;
+        if (row < n) {
+            zo = fa.z[row];
+            po = p_old[row];
+            xo = fa.xvec[row];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            zg[u] = fa.z[c[u]];
+            pg[u] = p_old[c[u]];
+        }
+    };
+    if (FUSE) {
+        const int kpar = ctl.scal->k & 1;
+        p_new = kpar ? fa.p1 : fa.p0;
+        p_old = kpar ? fa.p0 : fa.p1;
+        if (rb_lo < rb_hi) gather_fused(rb_lo);
+        if (!fused_head(ctl.scal, fa, sh, alpha, beta)) return;
+    } else if (CTL) {
+        if (!iteration_head(ctl)) return;
+    }
+    double acc = 0.0;
+    for (int rb = rb_lo; rb < rb_hi; ++rb) {
+        const int64_t row = (int64_t)rb * kStreamRows + t;
+        const int ks = rs - base, ke = re - base;
+        if (FUSE && rb != rb_lo) gather_fused(rb);
+        double xv[U];
+        if (FUSE) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = zg[u] + beta * pg[u];                 // = p_k[c], cg.py:83
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = (double)x[c[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = t + u * kBlock;
+            if (k < cnt) prod[k] = (double)a[u] * xv[u];
+        }
+        __syncthreads();
+        if (row < n) {
+            double s = 0.0;
+            for (int k = ks; k < ke; ++k) s += prod[k];
+            y[row] = (YT)s;
+            if (FUSE) {
+                const double pn = zo + beta * po;                                      // cg.py:83
+                p_new[row] = pn;
+                fa.xvec[row] = xo + alpha * po;                                        // cg.py:79, one update late
+                acc += s * pn;
+            } else if (DOT) {
+                acc += s * xdot[row];
+            }
+        }
+        __syncthreads();
+        if (rb + 1 < rb_hi) fetch(rb + 1);
+    }
+    if (DOT) {
+        const double tot = block_sum(acc, sh);
+        if (t == 0) part_pq[blockIdx.x] = tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR-vector SpMV (longer rows: M = L L^T, dilated learned factors).  TPR lanes share a row, each
+// strides over its non-zeros, then a shuffle tree combines them (order differs from the sequential
+// sum: parity for this kernel is tolerance-based, ~1 ulp of the row's magnitude).
+// ------------------------------------------------------------------------------------------------
+template <int TPR, typename VT, typename XT, bool CTL, bool DOT, typename YT>
+__global__ __launch_bounds__(kBlock) void k_spmv_vector(int64_t n, const int32_t *__restrict__ rowptr,
+                                                        const int32_t *__restrict__ col,
+                                                        const VT *__restrict__ val, const XT *__restrict__ x,
+                                                        const double *__restrict__ xdot, YT *__restrict__ y,
+                                                        double *__restrict__ part_pq, IterCtlDev ctl) {
+    __shared__ double sh[4];
+    if (CTL) {
+        if (!iteration_head(ctl)) return;
+    }
+    constexpr int RPB = kBlock / TPR;  // rows per workgroup step
+    const int t = threadIdx.x;
+    const int lane = t % TPR;
+    const int v = virtual_block();
+    const int ngroups = (int)((n + RPB - 1) / RPB);
+    int g_lo, g_hi;
+    split_range(ngroups, v, g_lo, g_hi);
+    double acc = 0.0;
+    for (int g = g_lo; g < g_hi; ++g) {
+        const int64_t row = (int64_t)g * RPB + t / TPR;
+        double s = 0.0;
+        if (row < n) {
+            const int rs = rowptr[row], re = rowptr[row + 1];
+            for (int k = rs + lane; k < re; k += TPR) s += (double)val[k] * (double)x[col[k]];
+        }
+#pragma unroll
+        for (int off = TPR / 2; off > 0; off >>= 1) s += __shfl_down(s, off, TPR);
+        if (lane == 0 && row < n) {
+            y[row] = (YT)s;
+            if (DOT) acc += s * xdot[row];
+        }
+    }
+    if (DOT) {
+        const double tot = block_sum(acc, sh);
+        if (t == 0) part_pq[blockIdx.x] = tot;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// CSR SpMV with the x-vector tile staged in LDS (banded / stencil-like matrices).
+//
+// The columns of a 256-row block fall into a few runs (5-point: i-n, i, i+n; 7-point: five runs).  At setup
+// (k_tile_plan) each block gets the list of 64-double chunks of x it touches and every non-zero a 16-bit
+// index into the LDS image of those chunks.  At run time the block stages its chunks with coalesced 512-B
+// wave loads, streams val[] (8 B) and the local index (2 B instead of the 4-B column) coalesced, takes
+// x from LDS instead of gathering it through L1/L2, and finishes like the CSR-stream kernel: products
+// parked in LDS, thread i adds row i in column order -- the same bits as the gather kernels and the CPU.
+// Per non-zero the matrix stream shrinks from 12 to 10 bytes and the global gathers disappear.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_tile_plan(int64_t n, const int32_t *__restrict__ rowptr,
+                                                      const int32_t *__restrict__ col, int nrb,
+                                                      int32_t *__restrict__ chunks, int32_t *__restrict__ nchunks,
+                                                      uint16_t *__restrict__ lidx, int *ok_and_max) {
+    __shared__ int s_min, s_max, s_nc;
+    __shared__ uint16_t slot_of[kTileTableMax];
+    const int t = threadIdx.x;
+    for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        const int64_t r0 = (int64_t)rb * kStreamRows;
+        const int64_t rlast = (r0 + kStreamRows < n) ? r0 + kStreamRows : n;
+        const int base = rowptr[r0], cnt = rowptr[rlast] - base;
+        if (t == 0) { s_min = 0x7fffffff; s_max = -1; s_nc = 0; }
+        __syncthreads();
+        int lo = 0x7fffffff, hi = -1;
+        for (int k = t; k < cnt; k += kBlock) {
+            const int c = col[base + k];
+            lo = c < lo ? c : lo;
+            hi = c > hi ? c : hi;
+        }
+        if (hi >= 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
+        __syncthreads();
+        if (cnt == 0) {
+            if (t == 0) nchunks[rb] = 0;
+            __syncthreads();
+            continue;
+        }
+        const int cb = s_min / kTileChunk;
+        const int span = s_max / kTileChunk - cb + 1;
+        // not tileable: columns too spread out, or no room for the alignment slot of the pair loads
+        if (span > kTileTableMax || cnt > kStreamCap - 1) {
+            if (t == 0) { nchunks[rb] = 0; atomicExch(&ok_and_max[0], 0); }
+            __syncthreads();
+            continue;
+        }
+        for (int e = t; e < span; e += kBlock) slot_of[e] = 0;
+        __syncthreads();
+        for (int k = t; k < cnt; k += kBlock) slot_of[col[base + k] / kTileChunk - cb] = 1;
+        __syncthreads();
+        if (t == 0) {                                     // ascending chunk ids -> slots 1..nc
+            int nc = 0;
+            for (int e = 0; e < span; ++e)
+                if (slot_of[e]) {
+                    if (nc < kTileMaxChunks) chunks[(int64_t)rb * kTileMaxChunks + nc] = cb + e;
+                    slot_of[e] = (uint16_t)(++nc);
+                }
+            s_nc = nc;
+            nchunks[rb] = nc <= kTileMaxChunks ? nc : 0;
+            if (nc > kTileMaxChunks) atomicExch(&ok_and_max[0], 0);
+            else atomicMax(&ok_and_max[1], nc);
+        }
+        __syncthreads();
+        if (s_nc <= kTileMaxChunks)
+            for (int k = t; k < cnt; k += kBlock) {
+                const int c = col[base + k];
+                lidx[base + k] = (uint16_t)((slot_of[c / kTileChunk - cb] - 1) * kTileChunk + c % kTileChunk);
+            }
+        __syncthreads();
+    }
+}
+
+void launch_tile_plan(const CsrDev &A, int nrb, int32_t *chunks, int32_t *nchunks, uint16_t *lidx, int *ok_and_max_dev,
+                      hipStream_t s) {
+    const int grid = nrb < 2048 ? nrb : 2048;
+    hipLaunchKernelGGL(k_tile_plan, dim3(grid), dim3(kBlock), 0, s, A.n, A.rowptr, A.col, nrb, chunks, nchunks, lidx,
+                       ok_and_max_dev);
+}
+
+// XT: x-tile elements staged per thread (tile_max_chunks * 64 / 256, rounded up).  VT / XV: storage types of the
+// matrix values and of the staged vector (fp32 in the mixed-precision and lossless-fp32 modes; products and sums are
+// fp64 either way, and <p,Ap> always uses the fp64 vector `xdot`).
+template <bool CTL, bool DOT, int XT, typename VT, typename XV>
+__global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *__restrict__ rowptr,
+                                                      const VT *__restrict__ val,
+                                                      const uint16_t *__restrict__ lidx,
+                                                      const int32_t *__restrict__ chunks,
+                                                      const int32_t *__restrict__ nchunks,
+                                                      const XV *__restrict__ x, const double *__restrict__ xdot,
+                                                      double *__restrict__ y, int nrb, int tile_doubles,
+                                                      double *__restrict__ part_pq, IterCtlDev ctl, int64_t nnz) {
+    constexpr int U = kStreamCap / kBlock;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    XV *xs = reinterpret_cast<XV *>(smem);  // the staged x chunks of this block (tile_doubles slots reserved)
+    double *prod = smem + tile_doubles;     // products, kStreamCap + 2 doubles
+    double *sh = prod + kStreamCap + 2;     // 4 doubles for the block reduction
+    const int t = threadIdx.x;
+    const int v = virtual_block();
+    int rb_lo, rb_hi;
+    split_range(nrb, v, rb_lo, rb_hi);
+    constexpr int UP = U / 2;               // pairs of consecutive non-zeros per thread
+    struct alignas(2 * sizeof(VT)) VPair { VT x, y; };
+    VPair a[UP];
+    uint32_t li[UP];                        // two 16-bit local indices per register
+    XV xt[XT];
+    int cnt = 0, base = 0, rs = 0, re = 0, nc = 0;
+    const int lane = t & 63, wv = t >> 6;
+    // Everything block `rb` needs from memory -> registers: its slice of the matrix stream AND its x chunks
+    // (wave w stages chunks w, w+4, ...: 64 lanes x 8 B = one 512-B run; the chunk id is wave-uniform and travels
+    // through the scalar unit).  Issued one block ahead, so the loads fly during the previous block's phases.
+    // The matrix slice is read as aligned PAIRS of consecutive non-zeros, lane i <-> pair i: 16-byte value loads
+    // (1 KiB per wave instruction) and 4-byte index loads instead of 8- and 2-byte ones -- the texture-address unit
+    // issues per instruction, not per byte.  Slots are counted from the even index at or below the block's first
+    // non-zero, so slot 0 may belong to the previous block (its product is never read).
+    auto fetch = [&](int rb) {
+        const int64_t r0 = (int64_t)rb * kStreamRows;
+        const int64_t row = r0 + t;
+        const int64_t rlast = (r0 + kStreamRows < n) ? r0 + kStreamRows : n;
+        base = rowptr[r0] & ~1;
+        cnt = rowptr[rlast] - base;
+        rs = re = 0;
+        if (row < n) {
+            rs = rowptr[row];
+            re = rowptr[row + 1];
+        }
+        const int lastp = cnt > 0 ? (cnt - 1) >> 1 : 0;
+#pragma unroll
+        for (int u = 0; u < UP; ++u) {
+            const int pr = t + u * kBlock;
+            const int64_t kabs = base + 2 * (int64_t)(pr <= lastp ? pr : lastp);
+            if (cnt > 0) {
+                if (kabs + 1 < nnz) {
+                    a[u] = *reinterpret_cast<const VPair *>(val + kabs);
+                } else {                    // the matrix's very last non-zero when nnz is odd
+                    a[u].x = val[kabs];
+                    a[u].y = (VT)0;
+                }
+                li[u] = *reinterpret_cast<const uint32_t *>(lidx + kabs);   // lidx is padded to an even length
+            } else {
+                a[u].x = a[u].y = (VT)0;
+                li[u] = 0;
+            }
+        }
+        nc = nchunks[rb];
+        const int32_t *__restrict__ cl = chunks + (int64_t)rb * kTileMaxChunks;
+#pragma unroll
+        for (int u = 0; u < XT; ++u) {
+            const int ci = wv + u * (kBlock / 64);
+            if (ci < nc) {
+                const int chunk = __builtin_amdgcn_readfirstlane(cl[ci]);
+                const int64_t gi = (int64_t)chunk * kTileChunk + lane;
+                xt[u] = gi < n ? x[gi] : (XV)0;
+            }
+        }
+    };
+    if (rb_lo < rb_hi) fetch(rb_lo);
+    if (CTL) {
+        if (!iteration_head(ctl)) return;
+    }
+    double acc = 0.0;
+    for (int rb = rb_lo; rb < rb_hi; ++rb) {
+        const int64_t row = (int64_t)rb * kStreamRows + t;
+        const int ks = rs - base, ke = re - base, cnt_cur = cnt;
+#pragma unroll
+        for (int u = 0; u < XT; ++u) {
+            const int ci = wv + u * (kBlock / 64);
+            if (ci < nc) xs[ci * kTileChunk + lane] = xt[u];
+        }
+        __syncthreads();                    // tile complete (and every thread is past the previous row sums)
+#pragma unroll
+        for (int u = 0; u < UP; ++u) {
+            const int k = 2 * (t + u * kBlock);
+            if (k < cnt_cur) {              // one 16-byte LDS store per pair (slot cnt_cur may be written: never read)
+                double2 pp;
+                pp.x = (double)a[u].x * (double)xs[li[u] & 0xffffu];
+                pp.y = (double)a[u].y * (double)xs[li[u] >> 16];
+                *reinterpret_cast<double2 *>(prod + k) = pp;
+            }
+        }
+        if (rb + 1 < rb_hi) fetch(rb + 1);   // next block's stream and x chunks are in flight from here on
+        __syncthreads();
+        if (row < n) {
+            double s = 0.0;
+            for (int k = ks; k < ke; ++k) s += prod[k];
+            y[row] = s;
+            if (DOT) acc += s * xdot[row];
+        }
+    }
+    if (DOT) {
+        const double tot = block_sum(acc, sh);
+        if (t == 0) part_pq[blockIdx.x] = tot;
+    }
+}
+
+static IterCtlDev to_dev(const IterCtl *c) {
+    IterCtlDev d{nullptr};
+    if (c) d = IterCtlDev{c->scal};
+    return d;
+}
+
+template <typename VT, typename XT, typename YT>
+static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, const XT *x, const double *xdot,
+                          YT *y, double *part_pq, const IterCtl *ctl, hipStream_t s) {
+    const IterCtlDev d = to_dev(ctl);
+    const bool dot = part_pq != nullptr;
+    const bool c = ctl != nullptr;
+#define DPCG_LAUNCH_STREAM(CTLV, DOTV)                                                                     \
+    hipLaunchKernelGGL((k_spmv_stream<VT, XT, CTLV, DOTV, YT>), dim3(plan.grid), dim3(kBlock), 0, s, A.n, \
+                       A.rowptr, A.col, val, x, xdot, y, plan.nrb, part_pq, d, FuseArgs{})
+#define DPCG_LAUNCH_VECTOR(TPRV, CTLV, DOTV)                                                                     \
+    hipLaunchKernelGGL((k_spmv_vector<TPRV, VT, XT, CTLV, DOTV, YT>), dim3(plan.grid), dim3(kBlock), 0, s, A.n, \
+                       A.rowptr, A.col, val, x, xdot, y, part_pq, d)
+#define DPCG_VECTOR_CASE(TPRV)                         \
+    case TPRV:                                         \
+        if (c && dot) DPCG_LAUNCH_VECTOR(TPRV, true, true);   \
+        else if (dot) DPCG_LAUNCH_VECTOR(TPRV, false, true);  \
+        else DPCG_LAUNCH_VECTOR(TPRV, false, false);          \
+        break
+    if (plan.kernel == SPMV_TILE && std::is_same<YT, double>::value) {
+        const int tile_doubles = plan.tile_max_chunks * kTileChunk;
+        const size_t lds = (size_t)(tile_doubles + kStreamCap + 6) * sizeof(double);
+#define DPCG_LAUNCH_TILE_X(CTLV, DOTV, XTV)                                                                          \
+    hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV, XTV, VT, XT>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr,  \
+                       val, plan.tile_lidx, plan.tile_chunks, plan.tile_nchunks, x, xdot, (double *)y, plan.nrb,     \
+                       tile_doubles, part_pq, d, A.nnz)
+#define DPCG_LAUNCH_TILE(CTLV, DOTV)                                                  \
+    do {                                                                              \
+        if (plan.tile_max_chunks <= 20) DPCG_LAUNCH_TILE_X(CTLV, DOTV, 5);            \
+        else DPCG_LAUNCH_TILE_X(CTLV, DOTV, (kTileMaxChunks * kTileChunk / kBlock));  \
+    } while (0)
+        if (c && dot) DPCG_LAUNCH_TILE(true, true);
+        else if (dot) DPCG_LAUNCH_TILE(false, true);
+        else DPCG_LAUNCH_TILE(false, false);
+#undef DPCG_LAUNCH_TILE
+#undef DPCG_LAUNCH_TILE_X
+    } else if (plan.kernel == SPMV_STREAM || plan.kernel == SPMV_TILE) {
+        if (c && dot) DPCG_LAUNCH_STREAM(true, true);
+        else if (dot) DPCG_LAUNCH_STREAM(false, true);
+        else DPCG_LAUNCH_STREAM(false, false);
+    } else {
+        switch (plan.tpr) {
+            DPCG_VECTOR_CASE(2);
+            DPCG_VECTOR_CASE(4);
+            DPCG_VECTOR_CASE(8);
+            DPCG_VECTOR_CASE(16);
+            DPCG_VECTOR_CASE(32);
+            default:
+                DPCG_VECTOR_CASE(64);
+        }
+    }
+#undef DPCG_VECTOR_CASE
+#undef DPCG_LAUNCH_VECTOR
+#undef DPCG_LAUNCH_STREAM
+}
+
+// KA of the two-kernel iteration (see fused_head): the gather kernel with FUSE.  A system whose plan is the x-tile
+// kernel is too large for this form to pay (dpcg_api.hip: fuse_eligible); should it be asked for anyway, the gather
+// kernel runs over the same row blocks.
+void launch_spmv_fused(const CsrDev &A, const SpmvPlan &plan, const FuseArgs &fa, double *q, double *part_pq,
+                       Scalars *scal, hipStream_t s) {
+    const IterCtlDev d{scal};
+    hipLaunchKernelGGL((k_spmv_stream<double, double, true, true, double, true>), dim3(plan.grid), dim3(kBlock), 0, s,
+                       A.n, A.rowptr, A.col, A.val, nullptr, nullptr, q, plan.nrb, part_pq, d, fa);
+}
+
+void launch_spmv(const CsrDev &A, const SpmvPlan &plan, const double *x, double *y, double *part_pq,
+                 const IterCtl *ctl, hipStream_t s) {
+    spmv_dispatch<double, double, double>(A, plan, A.val, x, x, y, part_pq, ctl, s);
+}
+
+// Mixed precision (config C5): fp32 matrix values and fp32 gathered vector, fp64 products/sums.
+void launch_spmv_f32in(const CsrDev &A, const SpmvPlan &plan, const float *x32, const double *x64, double *y,
+                       double *part_pq, const IterCtl *ctl, hipStream_t s) {
+    spmv_dispatch<float, float, double>(A, plan, A.val32, x32, x64, y, part_pq, ctl, s);
+}
+
+void launch_spmv_val32(const CsrDev &A, const SpmvPlan &plan, const double *x, double *y, double *part_pq,
+                       const IterCtl *ctl, hipStream_t s) {
+    spmv_dispatch<float, double, double>(A, plan, A.val32, x, x, y, part_pq, ctl, s);
+}
+
+__global__ __launch_bounds__(kBlock) void k_val32_check(int64_t nnz, const double *__restrict__ val,
+                                                        float *__restrict__ val32, int *lossy) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    bool bad = false;
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nnz; k += stride) {
+        const double v = val[k];
+        const float f = (float)v;
+        val32[k] = f;
+        bad = bad || ((double)f != v);
+    }
+    if (bad) atomicExch(lossy, 1);
+}
+
+void launch_val32_check(int64_t nnz, const double *val, float *val32, int *lossy_dev, hipStream_t s) {
+    int64_t g = (nnz + kBlock - 1) / kBlock;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_val32_check, dim3((int)g), dim3(kBlock), 0, s, nnz, val, val32, lossy_dev);
+}
+
+void launch_spmv_f32out(const CsrDev &A, const SpmvPlan &plan, const float *x32, float *y32, hipStream_t s) {
+    spmv_dispatch<float, float, float>(A, plan, A.val32, x32, nullptr, y32, nullptr, nullptr, s);
+}
+
+}  // namespace dpcg

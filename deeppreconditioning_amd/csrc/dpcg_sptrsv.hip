@@ -1,0 +1,444 @@
+// Level-scheduled sparse triangular solves and the IC(0) numeric factorisation.
+// Compiled with -ffp-contract=off so that a*b+c is two roundings, as in the CPU reference path (scipy/ATen CSR row
+// sums, unfused torch mul+add at cg.py:79-83); in-order sums then reproduce the oracle bit for bit.
+#include <algorithm>
+#include <cstdlib>
+
+#include "dpcg_device.h"
+
+namespace dpcg {
+
+// ------------------------------------------------------------------------------------------------
+// Level-scheduled sparse triangular solves (LLT_SOLVE: z = L^-T (L^-1 r)).
+// Rows of one level are independent; one thread owns a row and subtracts its products in column
+// order, then divides by the diagonal -- bit-identical to sequential substitution.
+// Lower factor: diagonal LAST in the row.  Upper (L^T as CSR): diagonal FIRST.
+// ------------------------------------------------------------------------------------------------
+// One wide level, CSR-stream style: a workgroup takes 256 consecutive rows of the level-ordered copy, streams
+// their contiguous val/col segment coalesced, parks v*out[col] in LDS and lets thread j subtract the products
+// of row j in column order.  The diagonal's slot is skipped (its "product" is never read).
+template <bool UPPER>
+__global__ __launch_bounds__(kBlock) void k_sptrsv_level_stream(const int32_t *__restrict__ rows, int j0, int count,
+                                                                const int32_t *__restrict__ lo_rp,
+                                                                const int32_t *__restrict__ lo_ci,
+                                                                const double *__restrict__ lo_v,
+                                                                const double *__restrict__ rhs, double *out, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
+    constexpr int U = kStreamCap / kBlock;
+    __shared__ double prod[kStreamCap];
+    const int t = threadIdx.x;
+    const int jb = j0 + blockIdx.x * kBlock;
+    const int jend = (jb + kBlock < j0 + count) ? jb + kBlock : j0 + count;
+    const int j = jb + t;
+    const int base = lo_rp[jb];
+    const int cnt = lo_rp[jend] - base;
+    int rs = 0, re = 0, i = 0;
+    double bi = 0.0;
+    if (j < jend) {
+        rs = lo_rp[j] - base;
+        re = lo_rp[j + 1] - base;
+        i = rows[j];
+        bi = rhs[i];
+    }
+    const int last = cnt > 0 ? cnt - 1 : 0;
+    int c[U];
+    double a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int k = t + u * kBlock;
+        const int kk = k < cnt ? k : last;
+        c[u] = lo_ci[base + kk];
+        a[u] = lo_v[base + kk];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int k = t + u * kBlock;
+        if (k < cnt) prod[k] = a[u] * out[c[u]];
+    }
+    __syncthreads();
+    if (j < jend) {
+        double acc = bi;
+        const int ks = UPPER ? rs + 1 : rs, ke = UPPER ? re : re - 1;
+        for (int k = ks; k < ke; ++k) acc -= prod[k];
+        out[i] = acc / lo_v[base + (UPPER ? rs : re - 1)];
+    }
+}
+
+// One level, one thread per row (rows too long for the LDS product buffer).
+template <bool UPPER>
+__global__ __launch_bounds__(kBlock) void k_sptrsv_level(const int32_t *__restrict__ rows, int j0, int count,
+                                                         const int32_t *__restrict__ lo_rp,
+                                                         const int32_t *__restrict__ lo_ci,
+                                                         const double *__restrict__ lo_v,
+                                                         const double *__restrict__ rhs, double *out, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= count) return;
+    const int j = j0 + idx, i = rows[j];
+    const int s = lo_rp[j], e = lo_rp[j + 1];
+    double acc = rhs[i];
+    const int ks = UPPER ? s + 1 : s, ke = UPPER ? e : e - 1;
+    for (int k = ks; k < ke; ++k) acc -= lo_v[k] * out[lo_ci[k]];
+    out[i] = acc / lo_v[UPPER ? s : e - 1];
+}
+
+// A run of narrow levels walked by ONE workgroup of 1024 threads with a barrier between levels
+// (cheaper than one launch per level: ~1.5 us boundary each).  Values handed from level to level
+// go through L2 with agent-scope (sc1) accesses so no wave reads a stale line from its CU's L1.
+constexpr int kMergedBlock = 1024;
+template <bool UPPER>
+__global__ __launch_bounds__(kMergedBlock) void k_sptrsv_merged(const int32_t *__restrict__ rows,
+                                                                const int32_t *__restrict__ level_ptr, int lvl_lo,
+                                                                int lvl_hi, const int32_t *__restrict__ lo_rp,
+                                                                const int32_t *__restrict__ lo_ci,
+                                                                const double *__restrict__ lo_v,
+                                                                const double *__restrict__ rhs, double *out, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
+    for (int lvl = lvl_lo; lvl < lvl_hi; ++lvl) {
+        const int lo = level_ptr[lvl], hi = level_ptr[lvl + 1];
+        for (int j = lo + (int)threadIdx.x; j < hi; j += kMergedBlock) {
+            const int i = rows[j];
+            const int s = lo_rp[j], e = lo_rp[j + 1];
+            double acc = rhs[i];
+            const int ks = UPPER ? s + 1 : s, ke = UPPER ? e : e - 1;
+            for (int k = ks; k < ke; ++k)
+                acc -= lo_v[k] * __hip_atomic_load(out + lo_ci[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double res = acc / lo_v[UPPER ? s : e - 1];
+            __hip_atomic_store(out + i, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();  // includes s_waitcnt vmcnt(0): this level's stores have reached L2
+    }
+}
+
+// The same walk with the dependencies handed over through an LDS ring instead of L2.  In level order the
+// entries a banded factor's rows depend on sit within the last W positions (for a 5-point grid: the previous
+// anti-diagonal), so y lives in a ring of W doubles indexed by position & (W-1); entries solved before this
+// segment are read from `out` (written by earlier kernels).  Everything that does not depend on y -- the row
+// id, rhs, extents and the first three entries of the NEXT level's rows -- is loaded one level ahead, so a
+// level costs an LDS round trip, a division and a barrier instead of three dependent L2 round trips.
+constexpr int kRingE = 3;   // entries per row held in registers one level ahead
+template <bool UPPER>
+__global__ __launch_bounds__(kMergedBlock) void k_sptrsv_ring(const int32_t *__restrict__ rows,
+                                                              const int32_t *__restrict__ level_ptr, int lvl_lo,
+                                                              int lvl_hi, const int32_t *__restrict__ lo_rp,
+                                                              const int32_t *__restrict__ lo_ci,
+                                                              const int32_t *__restrict__ lo_cpos,
+                                                              const double *__restrict__ lo_v,
+                                                              const double *__restrict__ rhs, double *out,
+                                                              int seg_start, int W, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
+    extern __shared__ __attribute__((aligned(16))) double ring[];
+    struct Row {
+        int j, i, s, e;
+        double b, diag;
+        int cpos[kRingE], ci[kRingE];
+        double v[kRingE];
+    };
+    const int t = threadIdx.x;
+    auto load_row = [&](Row &r, int j, int hi) {
+        r.j = j < hi ? j : -1;
+        if (r.j < 0) return;
+        r.i = rows[j];
+        r.s = lo_rp[j];
+        r.e = lo_rp[j + 1];
+        r.b = rhs[r.i];
+        r.diag = lo_v[UPPER ? r.s : r.e - 1];
+        const int ks = UPPER ? r.s + 1 : r.s, ke = UPPER ? r.e : r.e - 1;
+#pragma unroll
+        for (int m = 0; m < kRingE; ++m) {
+            const int k = ks + m < ke ? ks + m : ks;      // clamped: an unused slot re-reads a valid entry
+            r.cpos[m] = ks < ke ? lo_cpos[k] : 0;
+            r.ci[m] = ks < ke ? lo_ci[k] : 0;
+            r.v[m] = ks < ke ? lo_v[k] : 0.0;
+        }
+    };
+    auto solve_row = [&](const Row &r) {
+        if (r.j < 0) return;
+        const int ks = UPPER ? r.s + 1 : r.s, ke = UPPER ? r.e : r.e - 1;
+        double acc = r.b;
+#pragma unroll
+        for (int m = 0; m < kRingE; ++m)
+            if (ks + m < ke) {
+                const double yv = r.cpos[m] >= seg_start ? ring[r.cpos[m] & (W - 1)] : out[r.ci[m]];
+                acc -= r.v[m] * yv;
+            }
+        for (int k = ks + kRingE; k < ke; ++k) {           // longer rows: the rest straight from memory
+            const int cp = lo_cpos[k];
+            const double yv = cp >= seg_start ? ring[cp & (W - 1)] : out[lo_ci[k]];
+            acc -= lo_v[k] * yv;
+        }
+        const double y = acc / r.diag;
+        ring[r.j & (W - 1)] = y;
+        out[r.i] = y;
+    };
+    // Two register sets in ping-pong (no register moves: a move of a register with a load in flight would wait
+    // for it).  Each thread owns at most two rows of a level (levels of a merged run have <= 2048 rows).
+    auto load_level = [&](Row &a, Row &b, int lvl) {
+        if (lvl < lvl_hi) {
+            const int lo = level_ptr[lvl], hi = level_ptr[lvl + 1];
+            load_row(a, lo + t, hi);
+            load_row(b, lo + t + (int)blockDim.x, hi);
+        } else {
+            a.j = b.j = -1;
+        }
+    };
+    // LDS-only hand-off: wait for this wave's ring writes, then the workgroup barrier.  A __syncthreads() would
+    // also drain vmcnt, i.e. wait for the out[] store and for the prefetch loads that must stay in flight.
+    auto level_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    Row a0, b0, a1, b1;
+    load_level(a0, b0, lvl_lo);
+    for (int lvl = lvl_lo; lvl < lvl_hi; lvl += 2) {
+        load_level(a1, b1, lvl + 1);        // flies while level `lvl` is solved
+        solve_row(a0);
+        solve_row(b0);
+        level_barrier();
+        if (lvl + 1 >= lvl_hi) break;
+        load_level(a0, b0, lvl + 2);
+        solve_row(a1);
+        solve_row(b1);
+        level_barrier();
+    }
+}
+
+// The ring walk with a deep software pipeline.  A level of a 5-point grid's factor is ~100 rows: the LDS round
+// trip, three multiply-adds, the division and a barrier take ~0.2 us, but fetching a row's data only one level
+// ahead (k_sptrsv_ring: row id -> extents -> entries, two dependent trips to L2) costs ~1.4 us per level.  Here a
+// row's data sits in fixed-width records addressed by its level-order position alone (Levels::pk_meta / pk_val,
+// right-hand side pre-gathered into level order), four 16-byte loads per row, and is requested D levels ahead;
+// the segment's level offsets are staged in LDS up front.  Arithmetic and its order are those of every other
+// SpTRSV kernel here (ascending columns, one product and one subtraction at a time, then the division).
+__global__ __launch_bounds__(kBlock) void k_gather_lo(const int32_t *__restrict__ rows, const double *__restrict__ rhs,
+                                                      double *__restrict__ b_lo, int j0, int count, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx < count) b_lo[j0 + idx] = rhs[rows[j0 + idx]];
+}
+
+// The prefetch is chunked: while the C levels of one chunk are solved out of one register set, the records of
+// the next chunk fly into the other set; at a chunk boundary one s_waitcnt vmcnt(0) retires them (by then C levels
+// of work have covered the memory latency).  The explicit wait + register "touch" keeps the compiler from
+// inserting its own conservative vmcnt(0) at each first use, which would also wait for the loads just issued.
+template <bool UPPER, int C, int ROWS>   // ROWS rows of a level per thread, C levels per prefetch chunk
+__global__ __launch_bounds__(512) void k_sptrsv_ring_pipe(const int32_t *__restrict__ level_ptr, int lvl_lo,
+                                                          int lvl_hi, const int32_t *__restrict__ lo_rp,
+                                                          const int32_t *__restrict__ lo_ci,
+                                                          const int32_t *__restrict__ lo_cpos,
+                                                          const double *__restrict__ lo_v,
+                                                          const int4 *__restrict__ pk_meta,
+                                                          const double2 *__restrict__ pk_val,
+                                                          const double *__restrict__ b_lo, double *out, int seg_start,
+                                                          int W, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
+    extern __shared__ __attribute__((aligned(16))) double ring[];
+    int *lp = reinterpret_cast<int *>(ring + W);        // level offsets of this segment, padded with empty levels
+    const int t = threadIdx.x, T = blockDim.x;
+    const int nl = lvl_hi - lvl_lo;
+    const int nchunks = (nl + C - 1) / C;
+    const int seg_end = level_ptr[lvl_hi];
+    for (int i = t; i <= (nchunks + 2) * C; i += T) lp[i] = i <= nl ? level_ptr[lvl_lo + i] : seg_end;
+    __syncthreads();
+    const int jmax = seg_end - 1;
+    struct Row {
+        int j;           // level-order position, -1 for a lane without a row in this level 
+        int4 m;          // cpos0..2, original row
+        double2 v01, v2d;
+        double b;
+    };
+    auto load_row = [&](Row &r, int j, int hi) {
+        const int jc = j < hi ? j : jmax;                 // lanes without a row load a valid record and ignore it
+        r.j = j < hi ? j : -1;
+        r.m = pk_meta[jc];
+        r.v01 = pk_val[2 * (int64_t)jc];
+        r.v2d = pk_val[2 * (int64_t)jc + 1];
+        r.b = b_lo[jc];
+    };
+    auto load_chunk = [&](Row (&S)[C][ROWS], int chunk) {
+#pragma unroll
+        for (int d = 0; d < C; ++d) {
+            const int rel = chunk * C + d;
+            const int lo = lp[rel], hi = lp[rel + 1];
+#pragma unroll
+            for (int h = 0; h < ROWS; ++h) load_row(S[d][h], lo + t + h * T, hi);
+        }
+    };
+    // all outstanding loads have landed; tell the compiler so (the registers are "redefined" here)
+    auto retire = [&](Row (&S)[C][ROWS]) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < C; ++d)
+#pragma unroll
+            for (int h = 0; h < ROWS; ++h) {
+                Row &r = S[d][h];
+                asm volatile("" : "+v"(r.m.x), "+v"(r.m.y), "+v"(r.m.z), "+v"(r.m.w), "+v"(r.v01.x), "+v"(r.v01.y),
+                             "+v"(r.v2d.x), "+v"(r.v2d.y), "+v"(r.b));
+            }
+    };
+    auto solve_row = [&](const Row &r) {
+        const bool valid = r.j >= 0;
+        double acc = r.b;
+        if (valid && r.m.x == -2) {                       // long row, or one that reaches back before the segment
+            const int s = lo_rp[r.j], e = lo_rp[r.j + 1];
+            const int ks = UPPER ? s + 1 : s, ke = UPPER ? e : e - 1;
+            for (int k = ks; k < ke; ++k) {
+                const int cp = lo_cpos[k];
+                const double yv = cp >= seg_start ? ring[cp & (W - 1)] : out[lo_ci[k]];
+                acc -= lo_v[k] * yv;
+            }
+        } else {
+            const double y0 = ring[(r.m.x < 0 ? 0 : r.m.x) & (W - 1)];
+            const double y1 = ring[(r.m.y < 0 ? 0 : r.m.y) & (W - 1)];
+            const double y2 = ring[(r.m.z < 0 ? 0 : r.m.z) & (W - 1)];
+            if (r.m.x >= 0) acc -= r.v01.x * y0;
+            if (r.m.y >= 0) acc -= r.v01.y * y1;
+            if (r.m.z >= 0) acc -= r.v2d.x * y2;
+        }
+        const double y = acc / r.v2d.y;
+        if (valid) {
+            ring[r.j & (W - 1)] = y;
+            out[r.m.w] = y;
+        }
+    };
+    // LDS-only hand-off (see k_sptrsv_ring): no vmcnt drain, the prefetched loads stay in flight across it
+    auto level_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto solve_chunk = [&](Row (&S)[C][ROWS]) {
+#pragma unroll
+        for (int d = 0; d < C; ++d) {
+#pragma unroll
+            for (int h = 0; h < ROWS; ++h) solve_row(S[d][h]);
+            level_barrier();
+        }
+    };
+    Row S0[C][ROWS], S1[C][ROWS];
+    load_chunk(S0, 0);
+    for (int c = 0; c < nchunks; c += 2) {
+        retire(S0);
+        load_chunk(S1, c + 1);                            // flies while chunk c is solved
+        solve_chunk(S0);
+        if (c + 1 >= nchunks) break;
+        retire(S1);
+        load_chunk(S0, c + 2);
+        solve_chunk(S1);
+    }
+}
+
+constexpr int kRingChunk = 6;   // levels per prefetch chunk of k_sptrsv_ring_pipe (3 with two rows per thread)
+static bool ring_pipe_disabled() {
+    static const bool off = [] { const char *e = getenv("DPCG_RING_PIPE"); return e && e[0] == '0'; }();
+    return off;
+}
+
+void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s,
+                   const int *done) {
+    (void)T;  // the level-ordered copy in `lv` carries the factor
+    for (const auto &seg : lv.segments) {
+        if (seg.merged && seg.ring_w > 0 && lv.pk_meta && !ring_pipe_disabled() && seg.max_width <= 1024 &&
+            (size_t)seg.ring_w * sizeof(double) + (size_t)(seg.hi - seg.lo + 4 * kRingChunk) * sizeof(int) <= 64 * 1024) {
+            const int seg_start = lv.level_ptr[seg.lo], seg_rows = lv.level_ptr[seg.hi] - seg_start;
+            const size_t lds = (size_t)seg.ring_w * sizeof(double) + (size_t)(seg.hi - seg.lo + 4 * kRingChunk) * sizeof(int);
+            const int width = seg.max_width;
+            hipLaunchKernelGGL(k_gather_lo, dim3((seg_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, s, lv.rows, rhs,
+                               lv.b_lo, seg_start, seg_rows, done);
+#define DPCG_RING_PIPE(UP, CV, ROWSV, threads)                                                                      \
+    hipLaunchKernelGGL((k_sptrsv_ring_pipe<UP, CV, ROWSV>), dim3(1), dim3(threads), lds, s, lv.level_ptr_dev, seg.lo,  \
+                       seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, (const int4 *)lv.pk_meta,            \
+                       (const double2 *)lv.pk_val, lv.b_lo, out, seg_start, seg.ring_w, done)
+            if (width <= 512) {                              // one row per thread
+                int threads = (width + 63) / 64 * 64;
+                threads = threads < 64 ? 64 : threads;
+                if (upper) DPCG_RING_PIPE(true, kRingChunk, 1, threads);
+                else DPCG_RING_PIPE(false, kRingChunk, 1, threads);
+            } else {                                         // two rows per thread
+                const int threads = ((width + 1) / 2 + 63) / 64 * 64;
+                if (upper) DPCG_RING_PIPE(true, kRingChunk / 2, 2, threads);
+                else DPCG_RING_PIPE(false, kRingChunk / 2, 2, threads);
+            }
+#undef DPCG_RING_PIPE
+            continue;
+        }
+        if (seg.merged && seg.ring_w > 0) {
+            const size_t lds = (size_t)seg.ring_w * sizeof(double);
+            const int seg_start = lv.level_ptr[seg.lo];
+            // as few waves as the widest level needs (two rows per thread): a barrier among 4 waves is cheaper
+            int width = 0;
+            for (int q = seg.lo; q < seg.hi; ++q) width = std::max(width, lv.level_ptr[q + 1] - lv.level_ptr[q]);
+            int threads = ((width + 1) / 2 + 63) / 64 * 64;
+            threads = threads < 64 ? 64 : (threads > kMergedBlock ? kMergedBlock : threads);
+            if (upper)
+                hipLaunchKernelGGL(k_sptrsv_ring<true>, dim3(1), dim3(threads), lds, s, lv.rows, lv.level_ptr_dev,
+                                   seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, rhs, out, seg_start,
+                                   seg.ring_w, done);
+            else
+                hipLaunchKernelGGL(k_sptrsv_ring<false>, dim3(1), dim3(threads), lds, s, lv.rows, lv.level_ptr_dev,
+                                   seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, rhs, out, seg_start,
+                                   seg.ring_w, done);
+            continue;
+        }
+        if (seg.merged) {
+            if (upper)
+                hipLaunchKernelGGL(k_sptrsv_merged<true>, dim3(1), dim3(kMergedBlock), 0, s, lv.rows, lv.level_ptr_dev,
+                                   seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_val, rhs, out, done);
+            else
+                hipLaunchKernelGGL(k_sptrsv_merged<false>, dim3(1), dim3(kMergedBlock), 0, s, lv.rows,
+                                   lv.level_ptr_dev, seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_val, rhs, out, done);
+            continue;
+        }
+        for (int l = seg.lo; l < seg.hi; ++l) {
+            const int j0 = lv.level_ptr[l], cnt = lv.level_ptr[l + 1] - j0;
+            const int grid = (cnt + kBlock - 1) / kBlock;
+#define DPCG_TRSV(KERNEL, UP) \
+    hipLaunchKernelGGL(KERNEL<UP>, dim3(grid), dim3(kBlock), 0, s, lv.rows, j0, cnt, lv.lo_rowptr, lv.lo_col, lv.lo_val, rhs, out, done)
+            if (lv.stream_ok) {
+                if (upper) DPCG_TRSV(k_sptrsv_level_stream, true);
+                else DPCG_TRSV(k_sptrsv_level_stream, false);
+            } else {
+                if (upper) DPCG_TRSV(k_sptrsv_level, true);
+                else DPCG_TRSV(k_sptrsv_level, false);
+            }
+#undef DPCG_TRSV
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// IC(0) numeric factorisation, level by level (stands in for ilupp.ichol0, test.py:83).
+// Row i of L needs the finished rows j < i of its own pattern -- the dependency DAG of the lower
+// solve, so the same level sets apply.  One thread owns a row; every sum runs over ascending columns,
+// one product and one subtraction at a time (two roundings): the order of the CPU restatement, so the
+// factor is bit-identical to it.  lv holds tril(A) on entry and L on exit (diagonal last in a row).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_ic0_level(const int32_t *__restrict__ rows, int j0, int count,
+                                                      const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                      double *lv, int *bad) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= count) return;
+    const int i = rows[j0 + idx];
+    const int s_i = rp[i], e_i = rp[i + 1];
+    for (int k = s_i; k < e_i; ++k) {
+        const int j = ci[k];
+        const int s_j = rp[j], e_j = rp[j + 1];
+        double acc = lv[k];
+        int a = s_i, b = s_j;
+        while (a < k && b < e_j - 1) {
+            const int ca = ci[a], cb = ci[b];
+            if (ca == cb) {
+                acc -= lv[a] * lv[b];
+                ++a;
+                ++b;
+            } else if (ca < cb) ++a;
+            else ++b;
+        }
+        if (j < i) lv[k] = acc / lv[e_j - 1];
+        else {
+            if (!(acc > 0.0)) atomicExch(bad, i + 1);
+            lv[k] = sqrt(acc);
+        }
+    }
+}
+
+void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_ic0_level, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, rows, j0, count, rp, ci, lv,
+                       bad);
+}
+
+}  // namespace dpcg

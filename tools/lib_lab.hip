@@ -1,6 +1,8 @@
-// lib_lab: times the SHIPPED kernels (dpcg_kernels.hip is included verbatim) under different launch
+// lib_lab: times the SHIPPED kernels (the kernel files are included verbatim) under different launch
 // geometries, interleaved in one process.  Development tool, not part of the product.
-#include "../deeppreconditioning_amd/csrc/dpcg_kernels.hip"
+#include "../deeppreconditioning_amd/csrc/dpcg_spmv.hip"
+#include "../deeppreconditioning_amd/csrc/dpcg_pcg.hip"
+#include "../deeppreconditioning_amd/csrc/dpcg_setup.hip"
 
 #include <algorithm>
 #include <cstdio>
