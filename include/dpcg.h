@@ -82,6 +82,8 @@ int dpcg_device_info(int *cu_count, int64_t *hbm_bytes, char *name, int name_len
 int dpcg_create(dpcg_handle_t *out, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col,
                 const void *val, int val_dtype, int memspace, int copy, dpcg_stream_t stream);
 int dpcg_destroy(dpcg_handle_t h);
+/* Introspection (any out pointer may be NULL).  spmv_kernel: 0 gather (CSR-stream), 1 CSR-vector, 2 x-tile; +16 when
+ * a default solve runs two-kernel updates (see DPCG_NO_FUSE).  precond_nnz: nnz of M (CSR) or of L. */
 int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spmv_kernel, int *precond_kind,
                   int64_t *precond_nnz, int *n_levels_lower, int *n_levels_upper);
 
@@ -108,6 +110,7 @@ int dpcg_sptrsv(dpcg_handle_t h, int upper, const double *rhs, double *out, dpcg
 /* *out_host = <a,b> (torch.inner, cg.py:17,76,78,82); deterministic two-stage reduction. */
 int dpcg_dot(int64_t n, const double *a, const double *b, double *out_host, dpcg_stream_t stream);
 /* The SpMV fused with <p,Ap> exactly as launched inside the PCG iteration (for kernel timing). */
+/* (times the kernel a default solve launches: with two-kernel updates that is the SpMV fused with the vector update) */
 int dpcg_spmv_dot_bench(dpcg_handle_t h, const double *x, double *y, int repeats, float *ms_per_launch,
                         dpcg_stream_t stream);
 
