@@ -1,0 +1,491 @@
+// Host side of libdpcg.so, part 3: the PCG driver -- enqueues the iteration kernels (as replayed hipGraph chunks or
+// update by update) ahead of a progress word the GPU posts to pinned memory, the whole-solve kernel for small systems,
+// and the batch entry point.
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include "dpcg_host.h"
+
+// ------------------------------------------------------------------------------------------------
+// the solve
+// ------------------------------------------------------------------------------------------------
+static int default_chunk() {
+    const char *e = getenv("DPCG_CHUNK");
+    int c = e ? atoi(e) : 8;
+    return c < 1 ? 1 : (c > 256 ? 256 : c);
+}
+
+// One PCG update (cg.py:75-86) as kernel launches on `s`.
+static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hipStream_t s) {
+    const int64_t n = h->A.n;
+    const bool f32 = (flags & DPCG_SPMV_F32) != 0;
+    if (fuse_eligible(h, flags, x_true)) {
+        // KA: test of the current iterate, p = z + beta p, deferred x += alpha p, q = A p, partials of <p,q>
+        launch_spmv_fused(h->A, h->planA, fuse_args(h), h->q, h->part_pq, h->scal, s);          // cg.py:71,83,79,75
+        // KB: alpha; r -= alpha q; (z = M r fused); partials <r,z>, <r,r>; k += 1                cg.py:78,80-82,86
+        const int pre = h->precond == DPCG_PRECOND_NONE ? 0 : (h->precond == DPCG_PRECOND_JACOBI ? 1 : 2);
+        launch_update_r_two_kernel(pre, n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->dinv, h->z, h->part_rz,
+                                   h->part_rr, h->vec_grid, s);
+        if (pre == 2) {
+            DPCG_TRY(apply_precond(h, h->r, h->z, s, true));                                     // cg.py:81
+            launch_dot_partials(n, h->scal, h->r, h->z, h->part_rz, h->vec_grid, s);             // cg.py:82
+        }
+        return DPCG_OK;
+    }
+    IterCtl ctl{h->scal};
+    // K1: (skip when done) Ap = A p + partials of <p,Ap>           cg.py:71,75,78
+    const bool v32 = !f32 && (flags & DPCG_VAL32_IF_LOSSLESS) && h->A.val32_lossless == 1;
+    if (f32) launch_spmv_f32in(h->A, h->planA, h->p32, h->p, h->q, h->part_pq, &ctl, s);
+    else if (v32) launch_spmv_val32(h->A, h->planA, h->p, h->q, h->part_pq, &ctl, s);
+    else launch_spmv(h->A, h->planA, h->p, h->q, h->part_pq, &ctl, s);
+    // K2: alpha; r -= alpha Ap; (z = M r fused); partials <r,z>, <r,r>              cg.py:78,80-82,86
+    const int pre = h->precond == DPCG_PRECOND_NONE ? 0 : (h->precond == DPCG_PRECOND_JACOBI ? 1 : 2);
+    double *z = pre == 0 ? h->r : h->z;
+    launch_update_r(pre, n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->dinv, h->z, h->part_rz, h->part_rr,
+                    h->vec_grid, s);
+    if (pre == 2) {
+        DPCG_TRY(apply_precond(h, h->r, h->z, s, true));                             // cg.py:81
+        launch_dot_partials(n, h->scal, h->r, h->z, h->part_rz, h->vec_grid, s);     // cg.py:82
+    }
+    // K3: beta; x += alpha p; p = z + beta p; workgroup 0: stopping test of the new iterate   cg.py:79,82-83,86,71
+    launch_update_xp(n, h->scal, h->part_rz, h->part_rr, h->vec_grid, z, h->p, h->x, f32 ? h->p32 : nullptr, h->hist,
+                     h->hist_cap, h->vec_grid, s);
+    if (x_true) {                                                                    // cg.py:43-45
+        launch_anorm_err(n, h->scal, h->x, x_true, h->e, h->vec_grid, s);
+        launch_spmv(h->A, h->planA, h->e, h->t, h->part_bb, nullptr, s);
+        launch_record_err(h->scal, h->part_bb, h->planA.grid, h->err_hist, h->hist_cap, 0, s);
+    }
+    return DPCG_OK;
+}
+
+static int ensure_graph(dpcg_system *h, int flags, int chunk) {
+    const int key = (h->precond << 8) | (flags & (DPCG_SPMV_F32 | DPCG_VAL32_IF_LOSSLESS | DPCG_NO_FUSE)) |
+                    (h->A.val32_lossless == 1 ? 64 : 0) | (fuse_eligible(h, flags, nullptr) ? 128 : 0);
+    if (h->graph_exec && h->graph_key == key && h->graph_chunk == chunk) return DPCG_OK;
+    drop_graph(h);
+    HandleExtras &ex = extras()[h];
+    hipGraph_t graph = nullptr;
+    DPCG_HIP(hipStreamBeginCapture(ex.cap_stream, hipStreamCaptureModeThreadLocal));
+    int st = DPCG_OK;
+    for (int i = 0; i < chunk && st >= 0; ++i) st = enqueue_iteration(h, flags, nullptr, ex.cap_stream);
+    hipError_t e = hipStreamEndCapture(ex.cap_stream, &graph);
+    if (st < 0) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return st;
+    }
+    DPCG_HIP(e);
+    e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    DPCG_HIP(e);
+    h->graph_key = key;
+    h->graph_chunk = chunk;
+    return DPCG_OK;
+}
+
+// kernel launches one preconditioner application costs (the SpTRSVs launch once per wide level)
+static int precond_launches(const dpcg_system *h) {
+    auto trsv = [](const Levels &lv) {
+        int c = 0;
+        for (const auto &seg : lv.segments) c += seg.merged ? 2 : seg.hi - seg.lo;
+        return c;
+    };
+    switch (h->precond) {
+        case DPCG_PRECOND_CSR: return 1;
+        case DPCG_PRECOND_LLT_MULTIPLY: return 2;
+        case DPCG_PRECOND_LLT_SOLVE: return trsv(h->lvlL) + trsv(h->lvlU);
+        default: return 0;
+    }
+}
+
+namespace {
+// Host side of one solve.  The GPU never waits for the host: iterations are enqueued ahead of the
+// progress word that K3 posts to pinned memory, as a replayed hipGraph of `chunk` updates (launch-bound
+// small systems) or update by update (large systems, where one update outlasts its three launches).
+struct Solve {
+    dpcg_system *h = nullptr;
+    hipStream_t s = nullptr;
+    int max_iter = 0, flags = 0, chunk = 8;
+    const double *x_true = nullptr;
+    bool use_graph = true;
+    int enq = 0;             // updates enqueued so far
+    bool complete = false;
+    double t_iter = 0.0;     // measured seconds per update (0 = not known yet)
+    bool fused = false;           // two-kernel updates (x lags one update behind until finish())
+    bool many_launches = false;   // an update is dozens of small launches (level-scheduled SpTRSV): always replay a graph
+    std::chrono::steady_clock::time_point t0;
+
+    volatile unsigned long long *prog() { return extras()[h].prog_host; }
+
+    int enqueue_some() {
+        const bool graph_now = use_graph && (max_iter - enq) >= chunk && (many_launches || !(t_iter > 25e-6));
+        if (graph_now) {
+            DPCG_HIP(hipGraphLaunch(h->graph_exec, s));
+            enq += chunk;
+        } else {
+            DPCG_TRY(enqueue_iteration(h, flags, x_true, s));
+            enq += 1;
+        }
+        return DPCG_OK;
+    }
+
+    // how many updates to keep enqueued beyond the last one the GPU reported
+    int run_ahead() const {
+        if (t_iter <= 0.0) return 2 * chunk;
+        const double cover = 150e-6;  // host launch + scheduling latency to hide
+        int it = (int)(cover / t_iter) + 2;
+        if (t_iter > 25e-6 && !(many_launches && use_graph)) return it < 3 ? 3 : it;
+        const int chunks = (it + chunk - 1) / chunk + 1;
+        return chunks * chunk;
+    }
+
+    // Enqueue the start of the solve (cg.py:58-67); the timer starts after the initial residual /
+    // preconditioner work has drained, as the reference's does (cg.py:69).
+    int start(const double *b, const double *x0, double rtol_sq, double atol_sq) {
+        const int64_t n = h->A.n;
+        const bool f32 = (flags & DPCG_SPMV_F32) != 0;
+        HandleExtras &ex = extras()[h];
+        DPCG_TRY(ensure_work(h, max_iter, f32, x_true != nullptr));
+        if ((flags & DPCG_VAL32_IF_LOSSLESS) && h->A.val32_lossless == 0) {   // decide once per matrix
+            int *d_lossy = nullptr, lossy = 0;
+            DPCG_TRY(dev_alloc(&d_lossy, 1));
+            if (!h->A.val32) DPCG_TRY(dev_alloc(&h->A.val32, h->A.nnz));
+            DPCG_HIP(hipMemsetAsync(d_lossy, 0, sizeof(int), s));
+            launch_val32_check(h->A.nnz, h->A.val, h->A.val32, d_lossy, s);
+            DPCG_HIP(hipMemcpyAsync(&lossy, d_lossy, sizeof(int), hipMemcpyDeviceToHost, s));
+            DPCG_HIP(hipStreamSynchronize(s));
+            dev_free(d_lossy);
+            h->A.val32_lossless = lossy ? -1 : 1;
+        }
+        fused = fuse_eligible(h, flags, x_true);
+        if (fused && !h->p2) {
+            DPCG_TRY(dev_alloc(&h->p2, n));
+            drop_graph(h);
+        }
+        const int per_update = 3 + precond_launches(h);
+        many_launches = per_update >= 16;
+        if (many_launches) chunk = std::max(1, std::min(chunk, 1024 / per_update));   // keep the graph at ~1K nodes
+        use_graph = !(flags & DPCG_NO_GRAPH) && !x_true && max_iter >= chunk;
+        if (use_graph) DPCG_TRY(ensure_graph(h, flags, chunk));
+        *ex.prog_host = 0;
+        if (x0) {
+            DPCG_HIP(hipMemcpyAsync(h->x, x0, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+            launch_spmv(h->A, h->planA, h->x, h->q, nullptr, nullptr, s);
+            launch_residual(n, b, h->q, h->r, h->vec_grid, s);                       // cg.py:60
+        } else {
+            DPCG_HIP(hipMemsetAsync(h->x, 0, (size_t)n * sizeof(double), s));        // cg.py:58
+            DPCG_HIP(hipMemcpyAsync(h->r, b, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        double *z = h->precond == DPCG_PRECOND_NONE ? h->r : h->z;
+        if (h->precond != DPCG_PRECOND_NONE) DPCG_TRY(apply_precond(h, h->r, h->z, s));   // cg.py:61
+        launch_init_state(n, h->scal, b, h->r, z, h->p, f32 ? h->p32 : nullptr, h->part_bb, h->part_rz, h->part_rr,
+                          (flags & DPCG_INIT_CHECK_R) ? 1 : 0, h->vec_grid, s);
+        launch_finalize_init(h->scal, h->part_bb, h->part_rz, h->part_rr, h->vec_grid, rtol_sq, atol_sq, h->hist,
+                             h->hist_cap, ex.prog_dev, s);
+        if (fused) {
+            DPCG_HIP(hipMemsetAsync(h->p2, 0, (size_t)n * sizeof(double), s));       // "p_{-1}": multiplied by beta_0 = 0
+            launch_fused_init(h->scal, s);
+        }
+        if (x_true) {                                                                // cg.py:27-29
+            launch_anorm_err(n, h->scal, h->x, x_true, h->e, h->vec_grid, s);
+            launch_spmv(h->A, h->planA, h->e, h->t, h->part_bb, nullptr, s);
+            launch_record_err(h->scal, h->part_bb, h->planA.grid, h->err_hist, h->hist_cap, 0, s);
+        }
+        DPCG_CHECK_LAUNCH();
+        DPCG_HIP(hipStreamSynchronize(s));
+        t0 = std::chrono::steady_clock::now();                                       // cg.py:69
+        if (max_iter == 0) complete = true;
+        return DPCG_OK;
+    }
+
+    // Advance.  Returns a negative status on error, 1 when the solve is complete, 0 otherwise.
+    int step(bool blocking) {
+        if (complete) return 1;
+        for (;;) {
+            const unsigned long long v = *prog();
+            const int k = (int)(v >> 1);
+            if ((v & 1ull) || k >= max_iter) {
+                complete = true;
+                return 1;
+            }
+            if (k >= 4) t_iter = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / k;
+            const int target = run_ahead();
+            while (enq < max_iter && enq - k < target) DPCG_TRY(enqueue_some());
+            if (!blocking) return 0;
+            // wait for the progress word to move; watch the stream so that a fault cannot hang the host
+            bool moved = false;
+            for (int spin = 0; spin < 4000 && !moved; ++spin) {
+                moved = *prog() != v;
+                if (!moved) __builtin_ia32_pause();
+            }
+            if (moved) continue;
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipErrorNotReady) continue;
+            DPCG_HIP(q);
+            // stream drained: every enqueued update has run, the word is final for them
+            if (*prog() == v && enq > k) {
+                set_error("PCG driver: enqueued updates finished without reporting progress");
+                return DPCG_ERR_STATE;
+            }
+        }
+    }
+
+    int finish(double *x, int *iters, double *final_res, double *seconds, double *res_history, double *err_history) {
+        const int64_t n = h->A.n;
+        if (fused)
+            launch_final_fused(n, h->scal, h->part_rr, h->vec_grid, h->hist, h->hist_cap, h->x, h->p, h->p2, h->vec_grid,
+                               s);
+        else
+            launch_final_check(h->scal, s);
+        DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        const auto t1 = std::chrono::steady_clock::now();                            // cg.py:88
+        const Scalars sc = *h->scal_host;
+        if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+        if (iters) *iters = sc.k;                                                    // cg.py:90
+        if (final_res) *final_res = sc.res;
+        if (res_history)
+            DPCG_HIP(hipMemcpyAsync(res_history, h->hist, (size_t)(sc.k + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (err_history && x_true)
+            DPCG_HIP(hipMemcpyAsync(err_history, h->err_hist, (size_t)(sc.k + 1) * sizeof(double),
+                                    hipMemcpyDeviceToHost, s));
+        if (x) DPCG_HIP(hipMemcpyAsync(x, h->x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        DPCG_CHECK_LAUNCH();
+        return sc.status;
+    }
+};
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// small systems: the whole solve in one launch, one workgroup per system (dpcg_small.hip)
+// ------------------------------------------------------------------------------------------------
+static bool small_eligible(const dpcg_system *h, int flags, const double *x_true) {
+    static const bool enabled = [] { const char *e = getenv("DPCG_SMALL"); return !(e && e[0] == '0'); }();
+    if (!enabled || x_true || (flags & (DPCG_SPMV_F32 | DPCG_NO_SMALL))) return false;
+    if (h->A.n > kSmallMaxN) return false;
+    return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI || h->precond == DPCG_PRECOND_CSR ||
+           h->precond == DPCG_PRECOND_LLT_MULTIPLY;
+}
+
+void free_ell(SmallEll &e) {
+    dev_free(e.col);
+    dev_free(e.val);
+    e = SmallEll();
+}
+
+static int build_ell(const CsrDev &A, SmallEll &e, hipStream_t s) {
+    if (e.col) return DPCG_OK;
+    int *d_w = nullptr, w = 0;
+    DPCG_TRY(dev_alloc(&d_w, 1));
+    DPCG_HIP(hipMemsetAsync(d_w, 0, sizeof(int), s));
+    launch_max_row_len((int)A.n, A.rowptr, d_w, s);
+    DPCG_HIP(hipMemcpyAsync(&w, d_w, sizeof(int), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    dev_free(d_w);
+    const int64_t slabs = (A.n + 1023) / 1024;
+    e.W = w < 1 ? 1 : w;
+    DPCG_TRY(dev_alloc(&e.col, slabs * e.W * 1024));
+    DPCG_TRY(dev_alloc(&e.val, slabs * e.W * 1024));
+    launch_build_ell((int)A.n, A.rowptr, A.col, A.val, e.W, e.col, e.val, s);
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
+// slab-ELL copies of the matrices the small-system kernel multiplies by (built once per matrix)
+static int ensure_small(dpcg_system *h, hipStream_t s) {
+    DPCG_TRY(build_ell(h->A, h->ell_a, s));
+    if (h->precond == DPCG_PRECOND_CSR) DPCG_TRY(build_ell(h->M, h->ell_m, s));
+    if (h->precond == DPCG_PRECOND_LLT_MULTIPLY) {
+        DPCG_TRY(build_ell(h->L, h->ell_m, s));
+        DPCG_TRY(build_ell(h->Lt, h->ell_t, s));
+    }
+    return DPCG_OK;
+}
+
+static SmallDesc make_small_desc(dpcg_system *h, const double *b, const double *x0, double *x, double rtol_sq,
+                                 double atol_sq, int max_iter, int flags) {
+    SmallDesc d;
+    memset(&d, 0, sizeof(d));
+    d.n = (int)h->A.n;
+    d.precond = h->precond;
+    d.max_iter = max_iter;
+    d.init_check_r = (flags & DPCG_INIT_CHECK_R) ? 1 : 0;
+    d.hist_cap = h->hist_cap;
+    d.lds_vectors = h->precond == DPCG_PRECOND_CSR ? 2 : (h->precond == DPCG_PRECOND_LLT_MULTIPLY ? 3 : 1);
+    d.variant = small_variant((int)h->A.n, h->ell_a.W, h->precond);
+    if (d.variant % 16 != 0) d.lds_vectors = 3;   // register-matrix variants: p, x and dinv live in LDS
+    d.rp = h->A.rowptr; d.dinv = h->dinv;
+    d.ell_a = h->ell_a; d.ell_m = h->ell_m; d.ell_t = h->ell_t;
+    if (h->precond == DPCG_PRECOND_CSR) d.m_rp = h->M.rowptr;
+    if (h->precond == DPCG_PRECOND_LLT_MULTIPLY) { d.m_rp = h->L.rowptr; d.t_rp = h->Lt.rowptr; }
+    d.b = b; d.x0 = x0; d.x = x ? x : h->x; d.hist = h->hist;
+    d.rtol_sq = rtol_sq; d.atol_sq = atol_sq;
+    d.out = h->scal;
+    return d;
+}
+
+static int small_variant_bit(const SmallDesc &d) { return d.variant == 4 * 16 + 7 ? 2 : (d.variant == 6 * 16 + 5 ? 4 : 1); }
+static int small_lds_bytes(const SmallDesc &d) { return (int)(((size_t)d.lds_vectors * d.n + 64) * sizeof(double)); }
+
+static int solve_small_one(dpcg_system *h, const double *b, const double *x0, double *x, double rtol_sq, double atol_sq,
+                           int max_iter, int flags, hipStream_t s, int *iters, double *final_res, double *seconds,
+                           double *res_history) {
+    DPCG_TRY(ensure_work(h, max_iter, false, false));
+    DPCG_TRY(ensure_small(h, s));
+    if (!h->small_desc) DPCG_TRY(dev_alloc(&h->small_desc, 1));
+    const SmallDesc d = make_small_desc(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags);
+    DPCG_HIP(hipMemcpyAsync(h->small_desc, &d, sizeof(d), hipMemcpyHostToDevice, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    const auto t0 = std::chrono::steady_clock::now();                                // cg.py:69 (the launch is the loop)
+    DPCG_TRY(launch_pcg_small(h->small_desc, 1, small_lds_bytes(d), 1 << h->precond, small_variant_bit(d), s));
+    DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    const auto t1 = std::chrono::steady_clock::now();                                // cg.py:88
+    DPCG_CHECK_LAUNCH();
+    const Scalars sc = *h->scal_host;
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    if (iters) *iters = sc.k;
+    if (final_res) *final_res = sc.res;
+    if (res_history) {
+        DPCG_HIP(hipMemcpyAsync(res_history, h->hist, (size_t)(sc.k + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+    }
+    return sc.status;
+}
+
+static int check_solve_args(dpcg_handle_t h, const double *b, int max_iter, int flags, const double *x_true,
+                            double *err_history) {
+    if (!h || !b) return invalid("dpcg_solve: NULL handle or b");
+    if (max_iter < 0) return invalid("dpcg_solve: max_iter < 0");
+    if ((x_true == nullptr) != (err_history == nullptr) && x_true == nullptr)
+        return invalid("dpcg_solve: err_history needs x_true");
+    if ((flags & DPCG_SPMV_F32) && x_true) return invalid("dpcg_solve: x_true tracking is fp64 only");
+    if (h->precond == DPCG_PRECOND_JACOBI && !h->dinv) return DPCG_ERR_STATE;
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_solve(dpcg_handle_t h, const double *b, const double *x0, double *x, double rtol_sq,
+                          double atol_sq, int max_iter, int flags, dpcg_stream_t stream, int *iters,
+                          double *final_res, double *seconds, double *res_history, const double *x_true,
+                          double *err_history) {
+    DPCG_TRY(check_solve_args(h, b, max_iter, flags, x_true, err_history));
+    if (small_eligible(h, flags, x_true))
+        return solve_small_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
+                               seconds, res_history);
+    Solve sv;
+    sv.h = h;
+    sv.s = (hipStream_t)stream;
+    sv.max_iter = max_iter;
+    sv.flags = flags;
+    sv.chunk = default_chunk();
+    sv.x_true = x_true;
+    DPCG_TRY(sv.start(b, x0, rtol_sq, atol_sq));
+    for (;;) {
+        const int r = sv.step(true);
+        if (r < 0) return r;
+        if (r == 1) break;
+    }
+    return sv.finish(x, iters, final_res, seconds, res_history, err_history);
+}
+
+extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double *const *b, const double *const *x0,
+                                double *const *x, double rtol_sq, double atol_sq, int max_iter, int flags,
+                                int n_streams, int *iters, double *final_res, double *seconds, int *status) {
+    if (count <= 0 || !handles || !b) return invalid("dpcg_solve_batch: bad arguments");
+    if (n_streams < 1) n_streams = 1;
+    if (n_streams > 8) n_streams = 8;
+    if (n_streams > count) n_streams = count;
+    for (int i = 0; i < count; ++i) DPCG_TRY(check_solve_args(handles[i], b[i], max_iter, flags, nullptr, nullptr));
+    bool all_small = true;
+    for (int i = 0; i < count; ++i) all_small = all_small && small_eligible(handles[i], flags, nullptr);
+    if (all_small) {
+        // one launch, one workgroup (one CU) per system
+        std::vector<SmallDesc> descs((size_t)count);
+        int lds = 0, kinds = 0, variants = 0;
+        for (int i = 0; i < count; ++i) {
+            kinds |= 1 << handles[i]->precond;
+            DPCG_TRY(ensure_work(handles[i], max_iter, false, false));
+            DPCG_TRY(ensure_small(handles[i], nullptr));
+            descs[i] = make_small_desc(handles[i], b[i], x0 ? x0[i] : nullptr, x ? x[i] : nullptr, rtol_sq, atol_sq,
+                                       max_iter, flags);
+            lds = std::max(lds, small_lds_bytes(descs[i]));
+            variants |= small_variant_bit(descs[i]);
+        }
+        SmallDesc *d_descs = nullptr;
+        Scalars *d_out = nullptr;            // one contiguous result array: a single copy back for the whole batch
+        std::vector<Scalars> out((size_t)count);
+        DPCG_TRY(dev_alloc(&d_descs, count));
+        int st_alloc = dev_alloc(&d_out, count);
+        if (st_alloc < 0) { dev_free(d_descs); return st_alloc; }
+        for (int i = 0; i < count; ++i) descs[i].out = d_out + i;
+        hipError_t e = hipMemcpy(d_descs, descs.data(), descs.size() * sizeof(SmallDesc), hipMemcpyHostToDevice);
+        const auto t0 = std::chrono::steady_clock::now();
+        int st = e == hipSuccess ? launch_pcg_small(d_descs, count, lds, kinds, variants, nullptr) : DPCG_ERR_HIP;
+        if (e == hipSuccess) e = hipMemcpy(out.data(), d_out, out.size() * sizeof(Scalars), hipMemcpyDeviceToHost);
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        dev_free(d_descs);
+        dev_free(d_out);
+        DPCG_HIP(e);
+        if (st < 0) return st;
+        int worst_small = DPCG_OK;
+        for (int i = 0; i < count; ++i) {
+            if (iters) iters[i] = out[i].k;
+            if (final_res) final_res[i] = out[i].res;
+            if (seconds) seconds[i] = sec;   // the batch ran as one launch
+            if (status) status[i] = out[i].status;
+            worst_small = std::max(worst_small, out[i].status);
+        }
+        return worst_small;
+    }
+    std::vector<hipStream_t> streams((size_t)n_streams, nullptr);
+    for (auto &st : streams) DPCG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    std::vector<Solve> sv((size_t)count);
+    std::vector<int> state((size_t)count, 0);  // 0 = waiting, 1 = running, 2 = finished
+    std::vector<int> slot_owner((size_t)n_streams, -1);
+    int worst = DPCG_OK, next = 0, done = 0, err = 0;
+    while (done < count && !err) {
+        bool progressed = false;
+        for (int sl = 0; sl < n_streams && !err; ++sl) {
+            int i = slot_owner[sl];
+            if (i < 0) {
+                if (next >= count) continue;
+                i = next++;
+                slot_owner[sl] = i;
+                Solve &v = sv[i];
+                v.h = handles[i];
+                v.s = streams[sl];
+                v.max_iter = max_iter;
+                v.flags = flags;
+                v.chunk = default_chunk();
+                int st = v.start(b[i], x0 ? x0[i] : nullptr, rtol_sq, atol_sq);
+                if (st < 0) { err = st; break; }
+                state[i] = 1;
+                progressed = true;
+            }
+            Solve &v = sv[i];
+            const int r = v.step(false);
+            if (r < 0) { err = r; break; }
+            if (r == 1) {
+                const int st = v.finish(x ? x[i] : nullptr, iters ? &iters[i] : nullptr,
+                                        final_res ? &final_res[i] : nullptr, seconds ? &seconds[i] : nullptr, nullptr,
+                                        nullptr);
+                if (st < 0) { err = st; break; }
+                if (status) status[i] = st;
+                worst = std::max(worst, st);
+                state[i] = 2;
+                slot_owner[sl] = -1;
+                ++done;
+                progressed = true;
+            }
+        }
+        if (!progressed) std::this_thread::yield();
+    }
+    for (auto &st : streams) {
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamDestroy(st);
+    }
+    return err ? err : worst;
+}
