@@ -28,13 +28,27 @@ def solve_batch(systems: list[CsrSystem], rhs: list[torch.Tensor], x0: list | No
     if len(rhs) != count:
         raise ValueError("one right-hand side per system")
     dev = systems[0].device
-    bs = [s._vec(b) for s, b in zip(systems, rhs)]
-    x0s = None if x0 is None else [None if v is None else s._vec(v) for s, v in zip(systems, x0)]
-    xs = [torch.empty_like(b) for b in bs]
+
+    def as_vec(system, v):      # fast path: already an fp64 vector on the device (the common case in a batch)
+        if (isinstance(v, torch.Tensor) and v.dtype == torch.float64 and v.device == system.device and v.dim() == 1
+                and v.numel() == system.n and v.is_contiguous()):
+            return v
+        return system._vec(v)
+
+    bs = [as_vec(s, b) for s, b in zip(systems, rhs)]
+    x0s = None if x0 is None else [None if v is None else as_vec(s, v) for s, v in zip(systems, x0)]
+    # one allocation for all solutions; the results are views of it (the library only copies into x: 8-B alignment)
+    sizes = [s.n for s in systems]
+    flat = torch.empty(sum(sizes), dtype=torch.float64, device=dev)
+    xs = flat.split(sizes)
     PA = C.c_void_p * count
     handles = PA(*[s._h.value for s in systems])
     b_arr = PA(*[b.data_ptr() for b in bs])
-    x_arr = PA(*[x.data_ptr() for x in xs])
+    base, x_ptrs, off = flat.data_ptr(), [], 0
+    for n in sizes:
+        x_ptrs.append(base + 8 * off)
+        off += n
+    x_arr = PA(*x_ptrs)
     x0_arr = None if x0s is None else PA(*[(0 if v is None else v.data_ptr()) for v in x0s])
     iters = (C.c_int * count)()
     status = (C.c_int * count)()
@@ -44,7 +58,8 @@ def solve_batch(systems: list[CsrSystem], rhs: list[torch.Tensor], x0: list | No
     with torch.cuda.device(dev):
         L.check(L.lib().dpcg_solve_batch(count, handles, b_arr, x0_arr, x_arr, rtol_sq, atol_sq, int(max_iter),
                                          int(flags), int(n_streams), iters, res, sec, status))
-    return [SolveResult(xs[i], iters[i], status[i], res[i], sec[i], np.empty(0)) for i in range(count)]
+    no_history = np.empty(0)
+    return [SolveResult(xs[i], iters[i], status[i], res[i], sec[i], no_history) for i in range(count)]
 
 
 @dataclass

@@ -414,20 +414,34 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
             lds = std::max(lds, small_lds_bytes(descs[i]));
             variants |= small_variant_bit(descs[i]);
         }
-        SmallDesc *d_descs = nullptr;
-        Scalars *d_out = nullptr;            // one contiguous result array: a single copy back for the whole batch
+        // descriptor / result arrays live across calls (hipMalloc + hipFree cost ~0.1 ms each: as much as the launch)
+        struct BatchScratch {
+            SmallDesc *descs = nullptr;
+            Scalars *out = nullptr;
+            int cap = 0;
+            ~BatchScratch() {
+                if (descs) (void)hipFree(descs);
+                if (out) (void)hipFree(out);
+            }
+        };
+        static thread_local BatchScratch scratch;
+        if (scratch.cap < count) {
+            dev_free(scratch.descs);
+            dev_free(scratch.out);
+            scratch.cap = 0;
+            DPCG_TRY(dev_alloc(&scratch.descs, count));
+            DPCG_TRY(dev_alloc(&scratch.out, count));
+            scratch.cap = count;
+        }
+        SmallDesc *d_descs = scratch.descs;
+        Scalars *d_out = scratch.out;        // one contiguous result array: a single copy back for the whole batch
         std::vector<Scalars> out((size_t)count);
-        DPCG_TRY(dev_alloc(&d_descs, count));
-        int st_alloc = dev_alloc(&d_out, count);
-        if (st_alloc < 0) { dev_free(d_descs); return st_alloc; }
         for (int i = 0; i < count; ++i) descs[i].out = d_out + i;
         hipError_t e = hipMemcpy(d_descs, descs.data(), descs.size() * sizeof(SmallDesc), hipMemcpyHostToDevice);
         const auto t0 = std::chrono::steady_clock::now();
         int st = e == hipSuccess ? launch_pcg_small(d_descs, count, lds, kinds, variants, nullptr) : DPCG_ERR_HIP;
         if (e == hipSuccess) e = hipMemcpy(out.data(), d_out, out.size() * sizeof(Scalars), hipMemcpyDeviceToHost);
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        dev_free(d_descs);
-        dev_free(d_out);
         DPCG_HIP(e);
         if (st < 0) return st;
         int worst_small = DPCG_OK;
