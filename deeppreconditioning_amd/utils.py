@@ -87,6 +87,15 @@ class SparseBatch:
         self.spatial_shape = list(spatial_shape)
         self.batch_size = int(batch_size)
 
+    @classmethod
+    def from_dense(cls, x: torch.Tensor) -> "SparseBatch":
+        """As `SparseConvTensor.from_dense`: x is (batch, H, W, channels); a site is active where any channel is
+        non-zero; indices are int32 (batch, row, col) in row-major order (tests/test_model.py:20-23 of the reference)."""
+        active = (x != 0).any(dim=-1)
+        idx = active.nonzero().to(torch.int32)
+        feats = x[active]
+        return cls(feats, idx, x.shape[1:3], x.shape[0])
+
     def replace_feature(self, features: torch.Tensor) -> "SparseBatch":
         return SparseBatch(features, self.indices, self.spatial_shape, self.batch_size)
 

@@ -62,6 +62,12 @@ def test_forward_like_reference_test():
     assert torch.all(pre == pre.transpose(-1, -2))
     ev = torch.linalg.eigvalsh(pre.double())
     assert torch.all(ev > 0)
+    # the same input built exactly as the reference's fixture does (SparseConvTensor.from_dense of stacked identities)
+    from deeppreconditioning_amd.utils import SparseBatch
+    dense_eye = torch.eye(size).unsqueeze(0).unsqueeze(0).expand(batch, -1, -1, -1)
+    inp2 = SparseBatch.from_dense(dense_eye.permute(0, 2, 3, 1))
+    assert inp2.batch_size == batch and inp2.spatial_shape == [size, size] and inp2.indices.dtype == torch.int32
+    assert torch.equal(net(inp2).dense(), lower)
 
 
 def test_network_matches_dense_restatement_and_dilation_pattern():
