@@ -48,26 +48,31 @@ class SparseConv2d(nn.Module):
         ph, pw = self.padding
         H, W = t.spatial_shape
         Ho, Wo = H + 2 * ph - kh + 1, W + 2 * pw - kw + 1
+        w = self.weight.reshape(self.out_channels, kh * kw, self.in_channels)
+        if (kh, kw, ph, pw) == (1, 1, 0, 0):                                  # pointwise: the site set is unchanged
+            out = t.features @ w[:, 0, :].t()
+            if self.bias is not None:
+                out = out + self.bias
+            return SparseBatch(out, t.indices, [Ho, Wo], t.batch_size)
         idx = t.indices.long()
         b, y, x = idx[:, 0], idx[:, 1], idx[:, 2]
-        # rulebook: input site (y,x) feeds output site (y - ky + ph, x - kx + pw) through W[ky,kx]
-        keys, src, off = [], [], []
-        arange = torch.arange(idx.shape[0], device=idx.device)
+        nnz = idx.shape[0]
+        # rulebook: input site (y,x) feeds output site (y - ky + ph, x - kx + pw) through W[ky,kx].  No boolean
+        # compaction (each would be a host sync): a contribution that falls outside the output gets a sentinel key,
+        # which sorts last and owns one scratch row of `out` (a sentinel is always appended, so that row always exists).
+        sentinel = t.batch_size * Ho * Wo
+        keys = []
         for ky in range(kh):
             for kx in range(kw):
                 oy, ox = y - ky + ph, x - kx + pw
                 ok = (oy >= 0) & (oy < Ho) & (ox >= 0) & (ox < Wo)
-                keys.append(((b * Ho + oy) * Wo + ox)[ok])
-                src.append(arange[ok])
-                off.append(torch.full((int(ok.sum()),), ky * kw + kx, device=idx.device, dtype=torch.long))
-        keys, src, off = torch.cat(keys), torch.cat(src), torch.cat(off)
-        uniq, dst = torch.unique(keys, sorted=True, return_inverse=True)      # output sites in (batch,row,col) order
+                keys.append(torch.where(ok, (b * Ho + oy) * Wo + ox, sentinel))
+        keys.append(torch.full((1,), sentinel, device=idx.device, dtype=torch.long))
+        uniq, dst = torch.unique(torch.cat(keys), sorted=True, return_inverse=True)   # sites in (batch,row,col) order
         out = t.features.new_zeros((uniq.numel(), self.out_channels))
-        w = self.weight.reshape(self.out_channels, kh * kw, self.in_channels)
         for k in range(kh * kw):                                              # one GEMM per kernel offset
-            sel = off == k
-            if sel.any():
-                out.index_add_(0, dst[sel], t.features[src[sel]] @ w[:, k, :].t())
+            out.index_add_(0, dst[k * nnz:(k + 1) * nnz], t.features @ w[:, k, :].t())
+        uniq, out = uniq[:-1], out[:-1]                                       # drop the scratch row
         if self.bias is not None:
             out = out + self.bias
         ob = uniq // (Ho * Wo)
