@@ -37,3 +37,19 @@ with torch.no_grad():
             t = t2
         else:
             t = t.replace_feature(m(t.features))
+
+# the rest of the learned pipeline at this size: handing L to the solver (transpose, plans) and the solve
+import deeppreconditioning_amd as D
+from deeppreconditioning_amd import poisson
+s = poisson.poisson_system(2, n2, device="cuda:0")
+Lparts = mdl.lower_factor_csr(outL, 0, sizes[0])
+for mode, cls in (("multiply", D.LLtMultiply), ("solve", D.LLtSolve)):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.set_preconditioner(cls(Lparts))
+    torch.cuda.synchronize()
+    print(f"set_preconditioner(LLt{mode.capitalize()}) nnz_L {Lparts[1].numel()}: {(time.perf_counter() - t0) * 1e3:.2f} ms")
+    t0 = time.perf_counter()
+    s.set_preconditioner(cls(Lparts))
+    torch.cuda.synchronize()
+    print(f"   again: {(time.perf_counter() - t0) * 1e3:.2f} ms")
