@@ -224,6 +224,35 @@ def main() -> None:
     out["edge_cg/rtol_1_hist"] = np.array([float(r) for _, r in e1])
     print("edge cases:", {k: tuple(int(t) for t in v) for k, v in edge.items()}, len(e0), out["edge_cg/rtol_1_hist"], flush=True)
 
+    # --- dense losses of metrics.py:34-100 on a duck-typed batch (only `.dense()` is used) --------------
+    from uibk.deep_preconditioning import metrics as ref_metrics
+
+    class DenseStub:
+        def __init__(self, dense4):
+            self._d = dense4
+
+        def dense(self):
+            return self._d.clone()
+
+    gen = torch.Generator().manual_seed(123)
+    nb, nn_ = 2, 12
+    sys_low = torch.zeros(nb, 1, nn_, nn_)
+    pre_low = torch.zeros(nb, 1, nn_, nn_)
+    for bi in range(nb):
+        Ad = torch.from_numpy(sp.diags([-1.0, 2.5 + bi, -1.0], [-1, 0, 1], shape=(nn_, nn_)).toarray()).float()
+        sys_low[bi, 0] = torch.tril(Ad)
+        Lr = torch.tril(torch.rand(nn_, nn_, generator=gen) * 0.2) + torch.diag(0.5 + torch.rand(nn_, generator=gen))
+        pre_low[bi, 0] = Lr
+    out["metrics/systems_tril"] = sys_low.numpy().copy()
+    out["metrics/preconditioners_tril"] = pre_low.numpy().copy()
+    out["metrics/inverse_loss"] = np.float64(ref_metrics.inverse_loss(DenseStub(sys_low), DenseStub(pre_low)))
+    out["metrics/condition_loss"] = np.float64(ref_metrics.condition_loss(DenseStub(sys_low), DenseStub(pre_low)))
+    torch.manual_seed(7)
+    out["metrics/hutchinson_trace_seed7_cpu"] = np.float64(
+        ref_metrics.hutchinson_trace(DenseStub(sys_low), DenseStub(pre_low)))
+    print("metrics:", float(out["metrics/inverse_loss"]), float(out["metrics/condition_loss"]),
+          float(out["metrics/hutchinson_trace_seed7_cpu"]), flush=True)
+
     name = "reference_outputs_quick.npz" if args.quick else "reference_outputs.npz"
     np.savez_compressed(HERE / name, **out)
     print("wrote", HERE / name, (HERE / name).stat().st_size, "bytes")

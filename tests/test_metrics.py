@@ -1,0 +1,23 @@
+"""Dense losses of metrics.py:34-100 against values the reference itself returned (fixtures `metrics/*`, produced by
+tests/golden/make_golden.py on a duck-typed batch).  These are plain torch restatements: they run on the CPU here."""
+import numpy as np
+import torch
+
+from deeppreconditioning_amd import metrics
+from deeppreconditioning_amd.utils import SparseBatch
+
+
+def _batches(golden):
+    sys_low = torch.from_numpy(golden["metrics/systems_tril"])
+    pre_low = torch.from_numpy(golden["metrics/preconditioners_tril"])
+    to_sparse = lambda d: SparseBatch.from_dense(d.permute(0, 2, 3, 1))   # noqa: E731  (batch, H, W, channels)
+    return to_sparse(sys_low), to_sparse(pre_low)
+
+
+def test_dense_losses_match_the_reference(golden):
+    systems, pre = _batches(golden)
+    assert float(metrics.inverse_loss(systems, pre)) == np.float32(golden["metrics/inverse_loss"])
+    np.testing.assert_allclose(float(metrics.condition_loss(systems, pre)), golden["metrics/condition_loss"], rtol=1e-5)
+    torch.manual_seed(7)
+    np.testing.assert_allclose(float(metrics.hutchinson_trace(systems, pre)),
+                               golden["metrics/hutchinson_trace_seed7_cpu"], rtol=1e-6)
