@@ -852,3 +852,27 @@ def test_two_kernel_updates_against_oracle_and_breakdown(D):
     # a system solved twice in a row reuses the cached graph and the second direction buffer
     again = S.solve(_dev(b))
     assert again.iterations == it and torch.equal(again.x, res.x)
+
+
+def test_benchmark_suite_over_reference_style_folders(D, tmp_path):
+    """The harness pointed at `sludge_patterns/case_*` folders as generate_data.py writes them (f2 + f3 together)."""
+    from deeppreconditioning_amd.benchmark_suite import BenchmarkSuite
+    from deeppreconditioning_amd.data_set import SludgePatternDataSet
+    mats = [O.poisson2d(10 + i) for i in range(5)]
+    for i, m in enumerate(mats):
+        folder = tmp_path / "raw" / "sludge_patterns" / f"case_{i:04d}"
+        folder.mkdir(parents=True)
+        sp.save_npz(folder / "matrix.npz", sp.coo_matrix(m), compressed=False)
+        x = O.rhs(m.shape[0], i)
+        np.savetxt(folder / "solution.csv", x)
+        np.savetxt(folder / "right_hand_side.csv", m @ x)
+    data = SludgePatternDataSet("test", batch_size=1, shuffle=False, root=tmp_path / "raw")   # the last 20 %: case 4
+    suite = BenchmarkSuite(data, None, techniques=("vanilla", "jacobi", "incomplete_cholesky_solve"),
+                           results_directory=tmp_path / "results")
+    suite.run()
+    suite.dump_csv()
+    m = mats[4]
+    b = (m @ O.rhs(m.shape[0], 4)).astype(np.float32).astype(np.float64)          # the data set carries fp32 vectors
+    assert suite.iterations["jacobi"] == [CO.pcg(m, b, "jacobi", dinv=O.jacobi_dinv(m))[1]]
+    assert suite.iterations["incomplete_cholesky_solve"] == [CO.pcg(m, b, "llt_solve", L=CO.ic0(m))[1]]
+    assert (tmp_path / "results" / "table.csv").exists()
