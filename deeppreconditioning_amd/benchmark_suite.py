@@ -145,3 +145,29 @@ class BenchmarkSuite:
             f.write(",".join(self.techniques) + "\n")
             for index in range(len(self.totals[self.techniques[0]])):
                 f.write(",".join(str(self.totals[t][index]) for t in self.techniques) + "\n")
+
+
+def main(params_path="params.yaml", checkpoint="./assets/checkpoints/best.pt", root=None) -> BenchmarkSuite:
+    """test.py:201-221 without DVC: read `params.yaml` (keys `data`, `model`, `channels`), build the test split with
+    batch size 1, load the checkpoint when there is one (random weights otherwise), run and dump the CSVs."""
+    import yaml
+
+    from . import data_set as data_sets
+    from . import model as models
+    assert torch.cuda.is_available(), "CUDA not available"                           # test.py:203
+    torch.manual_seed(69)                                                            # test.py:205
+    params = yaml.safe_load(pathlib.Path(params_path).read_text())
+    kwargs = {} if root is None else {"root": pathlib.Path(root)}
+    data = getattr(data_sets, params["data"])(stage="test", batch_size=1, shuffle=False, **kwargs)
+    model = getattr(models, params["model"])(params["channels"])
+    if pathlib.Path(checkpoint).exists():
+        models.load_reference_state_dict(model, torch.load(checkpoint, map_location="cpu"))
+    model = model.to("cuda")
+    suite = BenchmarkSuite(data, model)
+    suite.run()
+    suite.dump_csv()
+    return suite
+
+
+if __name__ == "__main__":
+    main()

@@ -876,3 +876,15 @@ def test_benchmark_suite_over_reference_style_folders(D, tmp_path):
     assert suite.iterations["jacobi"] == [CO.pcg(m, b, "jacobi", dinv=O.jacobi_dinv(m))[1]]
     assert suite.iterations["incomplete_cholesky_solve"] == [CO.pcg(m, b, "llt_solve", L=CO.ic0(m))[1]]
     assert (tmp_path / "results" / "table.csv").exists()
+    # the reference's entry point (test.py:201-221): params.yaml names the data set, the model and its channels
+    import os
+    from deeppreconditioning_amd import benchmark_suite
+    (tmp_path / "params.yaml").write_text("model: PreconditionerNet\ndata: SludgePatternDataSet\nchannels: [1, 4, 4, 4, 1]\n")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        full = benchmark_suite.main(tmp_path / "params.yaml", checkpoint=tmp_path / "no_checkpoint.pt", root=tmp_path / "raw")
+    finally:
+        os.chdir(cwd)
+    assert full.iterations["jacobi"] == suite.iterations["jacobi"] and len(full.iterations["learned"]) == 1
+    assert (tmp_path / "assets" / "results" / "table.csv").exists()
