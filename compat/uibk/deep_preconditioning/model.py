@@ -1,2 +1,3 @@
-"""`uibk.deep_preconditioning.model` on PyTorch-ROCm without spconv (model.py:13-59)."""
-from deeppreconditioning_amd.model import PreconditionerNet, SparseConv2d, SparseSequential  # noqa: F401
+"""`uibk.deep_preconditioning.model` on PyTorch-ROCm without spconv (model.py:13-179)."""
+from deeppreconditioning_amd.model import (PreconditionerNet, PreconditionerSparseUNet, SparseConv2d,  # noqa: F401
+                                           SparseInverseConv2d, SparseSequential, SubMConv2d, sparse_add)

@@ -81,11 +81,13 @@ class SparseBatch:
     """Minimal stand-in for `spconv.pytorch.SparseConvTensor` (absent on ROCm): the attributes the
     reference's hot path touches (utils.py:26-35, data_set.py:122-125)."""
 
-    def __init__(self, features: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int):
+    def __init__(self, features: torch.Tensor, indices: torch.Tensor, spatial_shape, batch_size: int,
+                 indice_dict: dict | None = None):
         self.features = features
         self.indices = indices
         self.spatial_shape = list(spatial_shape)
         self.batch_size = int(batch_size)
+        self.indice_dict = {} if indice_dict is None else indice_dict   # rulebooks by `indice_key`, as spconv keeps them
 
     @classmethod
     def from_dense(cls, x: torch.Tensor) -> "SparseBatch":
@@ -97,7 +99,7 @@ class SparseBatch:
         return cls(feats, idx, x.shape[1:3], x.shape[0])
 
     def replace_feature(self, features: torch.Tensor) -> "SparseBatch":
-        return SparseBatch(features, self.indices, self.spatial_shape, self.batch_size)
+        return SparseBatch(features, self.indices, self.spatial_shape, self.batch_size, self.indice_dict)
 
     def dense(self) -> torch.Tensor:
         """(batch, channels, H, W) dense tensor, as `SparseConvTensor.dense()`."""

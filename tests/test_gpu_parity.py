@@ -888,3 +888,13 @@ def test_benchmark_suite_over_reference_style_folders(D, tmp_path):
         os.chdir(cwd)
     assert full.iterations["jacobi"] == suite.iterations["jacobi"] and len(full.iterations["learned"]) == 1
     assert (tmp_path / "assets" / "results" / "table.csv").exists()
+    # ... and with the U-Net variant selected the way params.yaml selects a model (model.py:62-179)
+    (tmp_path / "params.yaml").write_text("model: PreconditionerSparseUNet\ndata: SludgePatternDataSet\n"
+                                          "channels: [1, 4, 8, 8, 8, 1]\n")
+    os.chdir(tmp_path)
+    try:
+        unet = benchmark_suite.main(tmp_path / "params.yaml", checkpoint=tmp_path / "no_checkpoint.pt", root=tmp_path / "raw")
+    finally:
+        os.chdir(cwd)
+    assert len(unet.iterations["learned"]) == 1 and unet.iterations["learned"][0] > 0
+    assert unet.densities["learned"][0] > 0
