@@ -898,3 +898,32 @@ def test_benchmark_suite_over_reference_style_folders(D, tmp_path):
         os.chdir(cwd)
     assert len(unet.iterations["learned"]) == 1 and unet.iterations["learned"][0] > 0
     assert unet.densities["learned"][0] > 0
+
+
+def test_train_then_test_round_trip(D, tmp_path):
+    """train.py's loop (inverse loss, Adam, validation through the PCG solver) followed by test.py's entry point on the
+    checkpoint it wrote -- the reference's two pipeline stages, end to end on this path."""
+    import os
+    from deeppreconditioning_amd import benchmark_suite, train
+    for i in range(50):                                                               # 40 train folders -> 20 batches -> 19 / 1
+        m = O.poisson2d(5 + i % 3)
+        folder = tmp_path / "raw" / "sludge_patterns" / f"case_{i:04d}"
+        folder.mkdir(parents=True)
+        sp.save_npz(folder / "matrix.npz", sp.coo_matrix(m), compressed=False)
+        x = O.rhs(m.shape[0], i)
+        np.savetxt(folder / "solution.csv", x)
+        np.savetxt(folder / "right_hand_side.csv", m @ x)
+    (tmp_path / "params.yaml").write_text("model: PreconditionerNet\ndata: SludgePatternDataSet\nchannels: [1, 8, 8, 8, 1]\n"
+                                          "batch_size: 2\nlearning_rate: 0.01\npatience: 16\n")
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        history = train.main(tmp_path / "params.yaml", root=tmp_path / "raw", max_epochs=6)
+        losses = history["train/loss/inverse"]
+        assert len(losses) == 6 and losses[-1] < losses[0]                            # the loss goes down
+        assert all(it > 0 for it in history["val/metric/iterations"])                 # validation ran the solver
+        assert (tmp_path / "assets" / "checkpoints" / "best.pt").exists() and (tmp_path / "assets" / "metrics.csv").exists()
+        suite = benchmark_suite.main(tmp_path / "params.yaml", root=tmp_path / "raw")  # loads the checkpoint just written
+    finally:
+        os.chdir(cwd)
+    assert len(suite.iterations["learned"]) == len(suite.iterations["jacobi"]) > 0
