@@ -21,7 +21,6 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
                                                      const double *__restrict__ dinv, double *__restrict__ z,
                                                      double *__restrict__ part_rz, double *__restrict__ part_rr) {
     __shared__ double sh[8];
-    if (sc->done) return;
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -36,6 +35,9 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
         ra = r2[i];
         if (PRE == 1) da = d2[i];
     }
+    // the `done` word is looked at only now: its scalar load would otherwise sit in front of the first vector loads
+    // (~0.5 us of exposed latency per kernel); a finished solve has merely loaded a few values for nothing
+    if (sc->done) return;
     const double pq = reduce_partials(part_pq, n_part_pq, sh);
     const double rz_cur = sc->rz;
     const double alpha = rz_cur / pq;                                   // cg.py:78
@@ -199,7 +201,6 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
                                                       double *__restrict__ x, float *__restrict__ p32,
                                                       double *__restrict__ hist, int hist_cap) {
     __shared__ double sh[4];
-    if (sc->done) return;
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
         pa = p2[i];
         xa = x2[i];
     }
+    if (sc->done) return;                                               // after the first loads, as in K2
     const double rz_new = reduce_partials(part_rz, n_part, sh);
     const double beta = rz_new / sc->rz;                                // cg.py:82
     const double alpha = sc->alpha;
