@@ -927,3 +927,16 @@ def test_train_then_test_round_trip(D, tmp_path):
     finally:
         os.chdir(cwd)
     assert len(suite.iterations["learned"]) == len(suite.iterations["jacobi"]) > 0
+
+
+def test_randomised_differential_sample():
+    """A slice of tools/fuzz_parity.py: random sparse SPD systems around every kernel-selection boundary (sizes, row
+    lengths, banded or scrambled), every preconditioner kind, three launch forms, HIP path vs both oracles."""
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    proc = subprocess.run([sys.executable, str(root / "tools" / "fuzz_parity.py"), "16", "11"], capture_output=True, text=True,
+                          cwd=root, env={**__import__("os").environ, "PYTHONPATH": str(root)}, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert "fuzz: 16 cases, 0 mismatches" in proc.stdout, proc.stdout[-3000:]

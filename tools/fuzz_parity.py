@@ -1,0 +1,106 @@
+"""Randomised differential test: random sparse SPD systems (sizes around every kernel-selection boundary, row lengths
+from 1 to ~50, banded or scrambled) through every preconditioner kind, HIP path vs the C oracle.  Prints mismatches.
+
+    python tools/fuzz_parity.py [cases] [seed]
+"""
+import sys
+import numpy as np
+import scipy.sparse as sp
+import torch
+import deeppreconditioning_amd as D
+from oracle import c_oracle as CO
+from oracle import oracle as O
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+SIZES = [1, 2, 63, 64, 255, 256, 257, 1000, 3071, 3072, 3073, 4608, 4609, 6144, 6145, 9000, 20000, 70000, 400000]
+
+
+def random_spd(n, per_row, band, scramble):
+    k = max(1, per_row // 2)
+    rows = np.repeat(np.arange(n), k)
+    offs = rng.integers(1, max(2, band), size=n * k)
+    cols = rows - offs
+    keep = cols >= 0
+    vals = rng.uniform(-1, 1, size=keep.sum())
+    B = sp.coo_matrix((vals, (rows[keep], cols[keep])), shape=(n, n)).tocsr()
+    B.sum_duplicates()
+    A = B + B.T
+    A = A + sp.diags(np.asarray(abs(A).sum(axis=1)).ravel() + rng.uniform(0.1, 1.0, n))
+    A = A.tocsr()
+    if scramble:
+        p = rng.permutation(n)
+        A = A[p][:, p].tocsr()
+    A.sort_indices()
+    return A
+
+
+bad = 0
+for case in range(cases):
+    n = int(rng.choice(SIZES))
+    per_row = int(rng.choice([1, 2, 4, 6, 10, 20, 50]))
+    band = int(rng.choice([2, 8, 64, 1000, max(2, n)]))
+    scramble = bool(rng.integers(0, 2)) and n < 100000
+    if n * per_row > 6_000_000:
+        per_row = 4
+    A = random_spd(n, per_row, band, scramble)
+    b = rng.uniform(-1, 1, n)
+    tag = f"case {case}: n={n} nnz/row={A.nnz / n:.1f} band={band} scramble={scramble}"
+    S = D.CsrSystem.from_any(A)
+    x = rng.uniform(-1, 1, n)
+    y = (S @ torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = CO.spmv(A, x)
+    kern = S.info()["spmv_kernel"]
+    if kern == "vector":
+        ok = np.allclose(y, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+    else:
+        ok = np.array_equal(y, ref)
+    if not ok:
+        bad += 1
+        print("SPMV MISMATCH", tag, kern, np.abs(y - ref).max())
+    kinds = ["none", "jacobi"] + (["ic0_solve", "ic0_multiply"] if n <= 70000 else [])
+    Lf = None
+    for kind in kinds:
+        try:
+            hist_np = None          # the numpy oracle: how far two correct implementations drift apart on this system
+            if kind == "none":
+                S.set_preconditioner(None)
+                it, hist = CO.pcg(A, b, "none")[1:3]
+                hist_np = np.array(O.preconditioned_conjugate_gradient(A, b, O.Precond("none"))[2])
+            elif kind == "jacobi":
+                S.set_preconditioner(D.Jacobi())
+                it, hist = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A))[1:3]
+                hist_np = np.array(O.preconditioned_conjugate_gradient(A, b, O.Precond("jacobi", dinv=O.jacobi_dinv(A)))[2])
+            elif kind == "ic0_solve":
+                Lf = CO.ic0(A)
+                S.set_preconditioner(D.IC0("solve"))
+                it, hist = CO.pcg(A, b, "llt_solve", L=Lf)[1:3]
+            else:
+                S.set_preconditioner(D.IC0("multiply"))
+                it, hist = CO.pcg(A, b, "llt_multiply", L=Lf)[1:3]
+            for flags in (0, D._lib.NO_SMALL, D._lib.NO_SMALL | D._lib.NO_FUSE):
+                r = S.solve(torch.from_numpy(b).cuda(), flags=flags)
+                h = r.res_history
+                m = min(len(h), len(hist))
+                # M = L L^T multiplied is the reference's own "unstable" technique (test.py:45): rounding differences
+                # grow to O(1) within tens of updates, so only the first entries and a count window are comparable;
+                # residuals at round-off level (an exact factorisation converges in one update) carry no information
+                chaotic = kind == "ic0_multiply"
+                head = min(m, 8 if chaotic else m)
+                sig = np.abs(hist[:head]) > 1e-22
+                rel = np.abs(h[:head] - hist[:head])[sig] / np.abs(hist[:head])[sig]
+                tol = 1e-6 if chaotic else 1e-8
+                if hist_np is not None and len(hist_np) == len(hist):     # rounding-order sensitivity of this system
+                    drift = np.abs(hist_np[:head] - hist[:head])[sig] / np.abs(hist[:head])[sig]
+                    tol = max(tol, 10 * float(drift.max()) if drift.size else tol)
+                hist_ok = rel.size == 0 or float(rel.max()) < tol
+                count_ok = abs(r.iterations - it) <= (0.03 * it + 1 if chaotic else 0)
+                if not (hist_ok and count_ok):
+                    bad += 1
+                    print("PCG MISMATCH", tag, kind, f"flags={flags}", "iters", r.iterations, it, "status", r.status,
+                          "max rel err over the compared head", float(rel.max()) if rel.size else None)
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print("EXCEPTION", tag, kind, repr(e)[:200])
+    S.close()
+print(f"fuzz: {cases} cases, {bad} mismatches")
