@@ -44,8 +44,12 @@ for case in range(cases):
     if n * per_row > 6_000_000:
         per_row = 4
     A = random_spd(n, per_row, band, scramble)
+    fp32_values = bool(rng.integers(0, 2))
+    if fp32_values:                      # values that survive fp64 -> fp32 -> fp64: the lossless-fp32 mode must engage
+        A.data = A.data.astype(np.float32).astype(np.float64)
     b = rng.uniform(-1, 1, n)
-    tag = f"case {case}: n={n} nnz/row={A.nnz / n:.1f} band={band} scramble={scramble}"
+    x0 = rng.uniform(-1, 1, n) if rng.integers(0, 2) else None
+    tag = f"case {case}: n={n} nnz/row={A.nnz / n:.1f} band={band} scramble={scramble} fp32vals={fp32_values} x0={x0 is not None}"
     S = D.CsrSystem.from_any(A)
     x = rng.uniform(-1, 1, n)
     y = (S @ torch.from_numpy(x).cuda()).cpu().numpy()
@@ -65,21 +69,28 @@ for case in range(cases):
             hist_np = None          # the numpy oracle: how far two correct implementations drift apart on this system
             if kind == "none":
                 S.set_preconditioner(None)
-                it, hist = CO.pcg(A, b, "none")[1:3]
-                hist_np = np.array(O.preconditioned_conjugate_gradient(A, b, O.Precond("none"))[2])
+                it, hist = CO.pcg(A, b, "none", x0=x0)[1:3]
+                hist_np = np.array(O.preconditioned_conjugate_gradient(A, b, O.Precond("none"), x0=x0)[2])
             elif kind == "jacobi":
                 S.set_preconditioner(D.Jacobi())
-                it, hist = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A))[1:3]
-                hist_np = np.array(O.preconditioned_conjugate_gradient(A, b, O.Precond("jacobi", dinv=O.jacobi_dinv(A)))[2])
+                it, hist = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A), x0=x0)[1:3]
+                hist_np = np.array(O.preconditioned_conjugate_gradient(A, b, O.Precond("jacobi", dinv=O.jacobi_dinv(A)), x0=x0)[2])
             elif kind == "ic0_solve":
                 Lf = CO.ic0(A)
                 S.set_preconditioner(D.IC0("solve"))
-                it, hist = CO.pcg(A, b, "llt_solve", L=Lf)[1:3]
+                it, hist = CO.pcg(A, b, "llt_solve", L=Lf, x0=x0)[1:3]
             else:
                 S.set_preconditioner(D.IC0("multiply"))
-                it, hist = CO.pcg(A, b, "llt_multiply", L=Lf)[1:3]
+                it, hist = CO.pcg(A, b, "llt_multiply", L=Lf, x0=x0)[1:3]
+            x0_dev = None if x0 is None else torch.from_numpy(x0).cuda()
+            base = S.solve(torch.from_numpy(b).cuda(), x0_dev, flags=D._lib.NO_SMALL)
+            if fp32_values:              # lossless fp32 value storage: bit-identical by construction
+                v32 = S.solve(torch.from_numpy(b).cuda(), x0_dev, flags=D._lib.NO_SMALL | D._lib.VAL32_IF_LOSSLESS)
+                if not (np.array_equal(v32.res_history, base.res_history) and torch.equal(v32.x, base.x)):
+                    bad += 1
+                    print("LOSSLESS-FP32 MISMATCH", tag, kind, v32.iterations, base.iterations)
             for flags in (0, D._lib.NO_SMALL, D._lib.NO_SMALL | D._lib.NO_FUSE):
-                r = S.solve(torch.from_numpy(b).cuda(), flags=flags)
+                r = S.solve(torch.from_numpy(b).cuda(), x0_dev, flags=flags)
                 h = r.res_history
                 m = min(len(h), len(hist))
                 # M = L L^T multiplied is the reference's own "unstable" technique (test.py:45): rounding differences
@@ -92,7 +103,7 @@ for case in range(cases):
                 tol = 1e-6 if chaotic else 1e-8
                 if hist_np is not None and len(hist_np) == len(hist):     # rounding-order sensitivity of this system
                     drift = np.abs(hist_np[:head] - hist[:head])[sig] / np.abs(hist[:head])[sig]
-                    tol = max(tol, 10 * float(drift.max()) if drift.size else tol)
+                    tol = max(tol, 30 * float(drift.max()) if drift.size else tol)
                 hist_ok = rel.size == 0 or float(rel.max()) < tol
                 count_ok = abs(r.iterations - it) <= (0.03 * it + 1 if chaotic else 0)
                 if not (hist_ok and count_ok):
