@@ -62,6 +62,16 @@ for case in range(cases):
     if not ok:
         bad += 1
         print("SPMV MISMATCH", tag, kern, np.abs(y - ref).max())
+    # level-scheduled triangular solves on a factor with this matrix's structure: bit-exact whatever the segment forms
+    Ltri = sp.tril(A, format="csr")
+    Ltri.sort_indices()
+    S.set_preconditioner(D.LLtSolve(Ltri))
+    ylo = S.sptrsv(torch.from_numpy(x).cuda(), upper=False).cpu().numpy()
+    ref_lo = CO.sptrsv_lower(Ltri, x)
+    yup = S.sptrsv(torch.from_numpy(ref_lo).cuda(), upper=True).cpu().numpy()
+    if not (np.array_equal(ylo, ref_lo) and np.array_equal(yup, CO.sptrsv_upper(CO.transpose_csr(Ltri), ref_lo))):
+        bad += 1
+        print("SPTRSV MISMATCH", tag, S.info()["levels_lower"])
     kinds = ["none", "jacobi"] + (["ic0_solve", "ic0_multiply"] if n <= 70000 else [])
     Lf = None
     for kind in kinds:
