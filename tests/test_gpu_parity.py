@@ -600,7 +600,12 @@ def test_reference_import_lines_resolve_through_the_compat_shim(D, monkeypatch):
                                 size=(400, 400)).to_sparse_csr()
     duration, iterations, info = cg_mod.preconditioned_conjugate_gradient(torch.from_numpy(A.toarray()), b, M)
     assert iterations == CO.pcg(A, O.rhs(400, 0), "jacobi", dinv=O.jacobi_dinv(A))[1] and info == 0
-    assert hasattr(models, "PreconditionerNet")
+    assert hasattr(models, "PreconditionerNet") and hasattr(models, "PreconditionerSparseUNet")
+    for name, attrs in (("utils", ("sparse_matvec_mul", "benchmark_cg")), ("metrics", ("inverse_loss", "condition_loss")),
+                        ("data_set", ("SludgePatternDataSet", "StAnDataSet")), ("train", ("main", "EarlyStopping")),
+                        ("test", ("BenchmarkSuite", "main"))):
+        mod = importlib.import_module(f"uibk.deep_preconditioning.{name}")
+        assert all(hasattr(mod, a) for a in attrs), name
 
 
 # ---- f4: training through the sparse operators --------------------------------------------------------------
