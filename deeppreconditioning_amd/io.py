@@ -86,3 +86,28 @@ def load_case(folder, device=None):
     b = torch.from_numpy(load_vector(folder / "right_hand_side.csv")).to(system.device)
     x = torch.from_numpy(load_vector(folder / "solution.csv")).to(system.device)
     return system, b, x
+
+
+def write_case(matrix_csv, case_directory, rng=None, device=None) -> dict:
+    """The post-simulation half of generate_data.py:97-111 for one OpenFOAM dump: build the matrix (sign flip,
+    symmetry check, generate_data.py:55-81 -- the dense eigenvalue check is replaced by CG's own breakdown test), draw
+    the right-hand side from U(-1, 1), solve for the ground truth with the absolute criterion of
+    `scipy.sparse.linalg.cg(rtol=0, atol=1e-6)` (||r|| <= 1e-6, generate_data.py:107) on the GPU, and write
+    `matrix.npz` / `right_hand_side.csv` / `solution.csv` the way the data sets read them."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(69) if rng is None else rng
+    rows, cols, vals, n = load_openfoam_matrix_csv(matrix_csv)
+    matrix = sp.coo_matrix((vals, (rows, cols)), shape=(n, n))
+    assert (matrix.transpose() != matrix).nnz == 0, "Generated matrix is non-symmetric matrix"      # generate_data.py:76
+    system = system_from_coo(rows, cols, vals, n, device)
+    right_hand_side = rng.uniform(-1, 1, size=n)
+    result = system.solve(torch.from_numpy(right_hand_side).to(system.device), rtol_sq=0.0, atol_sq=1e-12,
+                          max_iter=10 * n, want_history=False)
+    assert result.status == 0, "Generated matrix is not positive definite (CG did not converge)"
+    case_directory = pathlib.Path(case_directory)
+    case_directory.mkdir(parents=True, exist_ok=True)
+    sp.save_npz(case_directory / "matrix.npz", matrix, compressed=False)                             # generate_data.py:109
+    np.savetxt(case_directory / "right_hand_side.csv", right_hand_side)
+    np.savetxt(case_directory / "solution.csv", result.x.cpu().numpy())
+    system.close()
+    return {"n": n, "iterations": result.iterations, "final_res": result.final_res}

@@ -945,3 +945,24 @@ def test_randomised_differential_sample():
                           cwd=root, env={**__import__("os").environ, "PYTHONPATH": str(root)}, timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]
     assert "fuzz: 16 cases, 0 mismatches" in proc.stdout, proc.stdout[-3000:]
+
+
+def test_write_case_from_an_openfoam_dump(D, tmp_path):
+    """generate_data.py:97-111 after the simulation: matrix.csv -> case folder with a GPU-solved ground truth."""
+    from deeppreconditioning_amd import io as dio
+    from deeppreconditioning_amd.data_set import SludgePatternDataSet
+    A = O.unstructured_like(O.poisson2d(12), 4).tocoo()
+    with (tmp_path / "matrix.csv").open("w") as f:                        # pEqn.H:98-108 writes i,j,%.32f of -A
+        for i, j, v in zip(A.row, A.col, A.data):
+            f.write(f"{i},{j},{-v:.32f}\n")
+    for k in range(5):
+        info = dio.write_case(tmp_path / "matrix.csv", tmp_path / "raw" / "sludge_patterns" / f"case_{k:04d}",
+                              rng=np.random.default_rng(k))
+    assert info["n"] == 144 and info["iterations"] > 0
+    data = SludgePatternDataSet("test", batch_size=1, shuffle=False, root=tmp_path / "raw", device="cpu")
+    tril, sol, rhs, sizes = data[0]
+    full = tril.dense()[0, 0].double().numpy()
+    full = full + np.tril(full, -1).T
+    np.testing.assert_allclose(full, A.toarray().astype(np.float32), rtol=1e-6)
+    residual = A.toarray() @ sol[0].double().numpy() - rhs[0].double().numpy()
+    assert np.linalg.norm(residual) < 1e-4                                # ||r|| <= 1e-6 in fp64, the files hold fp32 views
