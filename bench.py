@@ -155,16 +155,29 @@ def main() -> None:
         torch.cuda.synchronize()
 
     # ---- the batch: systems already resident in HBM before the timed region --------------------
+    make_pc = lambda: {"jacobi": D.Jacobi(), "none": None, "ic0": D.IC0("solve")}[args.precond]   # noqa: E731
     system = poisson.poisson_system(args.dim, args.n)
-    system.set_preconditioner({"jacobi": D.Jacobi(), "none": None, "ic0": D.IC0("solve")}[args.precond])
+    system.set_preconditioner(make_pc())
     # every rank owns systems rank, rank+world, ... of the global batch; distinct b per system
     my_ids = [rank + world * j for j in range(args.systems_per_gpu)]
     rhs = [poisson.rhs(system.n, seed=i) for i in my_ids]
+    group = [system]
+    if args.systems_per_gpu > 1:
+        # several systems per GPU: handles that share the one matrix in HBM (borrowed CSR arrays, own work vectors),
+        # up to 4 in flight at once on separate streams -- another system's kernels fill this one's launch boundaries
+        from deeppreconditioning_amd.batch import solve_batch
+        rp_, ci_, v_ = poisson.poisson_csr(args.dim, args.n)
+        group = [D.CsrSystem(rp_, ci_, v_, rp_.numel() - 1) for _ in range(min(4, args.systems_per_gpu))]
+        for g in group:
+            g.set_preconditioner(make_pc())
 
     def step() -> int:
+        if len(group) == 1:
+            return sum(system.solve(b, want_history=False).iterations for b in rhs)
         its = 0
-        for b in rhs:
-            its += system.solve(b, want_history=False).iterations
+        for lo in range(0, len(rhs), len(group)):
+            chunk = rhs[lo:lo + len(group)]
+            its += sum(r.iterations for r in solve_batch(group[:len(chunk)], chunk, n_streams=len(chunk)))
         return its
 
     for _ in range(args.warmup):
@@ -204,7 +217,9 @@ def main() -> None:
             "config": {"workload": f"poisson{args.dim}d_{args.n}_{args.precond}_pcg_fp64", "dof": n, "nnz": nnz,
                        "rtol_sq": 1e-8, "max_iter": 1024, "iterations_per_solve": check.iterations,
                        "final_res": check.final_res, "systems_per_gpu_per_step": args.systems_per_gpu,
-                       "parallelism": f"independent systems sharded one-per-rank x{world}, no data-path collective"},
+                       "parallelism": f"independent systems sharded one-per-rank x{world}, no data-path collective"
+                                      + (f"; {args.systems_per_gpu} systems per GPU, {len(group)} interleaved on streams"
+                                         if args.systems_per_gpu > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": (f"k_spmv_{info['spmv_kernel']}<FUSE> (p = z + beta p, x += alpha p, q = A p, <p,q>)"
                                     if info["two_kernel_updates"] else
                                     f"k_spmv_{info['spmv_kernel']}<CTL,DOT> (SpMV + <p,Ap>)"),
@@ -332,6 +347,30 @@ def extra_workloads(D, poisson, torch) -> dict:
                                                  "systems_per_s": round(256 / dt, 1),
                                                  "single_system_us_per_update": round(one.seconds / one.iterations * 1e6, 2)}
     del systems, rhs_b
+    # independent systems interleaved on several streams (dpcg_solve_batch, general path): another system's kernels
+    # fill the launch boundaries and ramps of this one's -- aggregate rate vs one after another
+    conc = {}
+    for label, dim_c, n_c, count in (("4x_poisson3d_100", 3, 100, 4), ("8x_poisson2d_256", 2, 256, 8)):
+        group = [poisson.poisson_system(dim_c, n_c) for _ in range(count)]
+        for sy in group:
+            sy.set_preconditioner(D.Jacobi())
+        rhs_c = [poisson.rhs(sy.n, i) for i, sy in enumerate(group)]
+        solve_batch(group, rhs_c, n_streams=4, flags=D._lib.NO_SMALL)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res_c = solve_batch(group, rhs_c, n_streams=4, flags=D._lib.NO_SMALL)
+        torch.cuda.synchronize()
+        dt_c = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        seq_its = sum(sy.solve(b_c, want_history=False, flags=D._lib.NO_SMALL).iterations for sy, b_c in zip(group, rhs_c))
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        conc[label] = {"iterations_per_s_interleaved_4_streams": round(sum(r.iterations for r in res_c) / dt_c, 1),
+                       "iterations_per_s_one_after_another": round(seq_its / dt_s, 1)}
+        for sy in group:
+            sy.close()
+        del group, rhs_c
+    out["independent_systems_interleaved"] = conc
     # config 4 (one GPU's share): 256^3 systems, 1.74 GB per SpMV, beyond the Infinity Cache -> HBM-bound
     s4 = poisson.poisson_system(3, 256)
     s4.set_preconditioner(D.Jacobi())

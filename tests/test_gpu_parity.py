@@ -966,3 +966,18 @@ def test_write_case_from_an_openfoam_dump(D, tmp_path):
     np.testing.assert_allclose(full, A.toarray().astype(np.float32), rtol=1e-6)
     residual = A.toarray() @ sol[0].double().numpy() - rhs[0].double().numpy()
     assert np.linalg.norm(residual) < 1e-4                                # ||r|| <= 1e-6 in fp64, the files hold fp32 views
+
+
+def test_solve_specs_local_concurrent_equals_sequential(D):
+    """A rank's share of a sharded batch (batch.py): systems of one size share one matrix in HBM and are solved a few at
+    a time on separate streams; the records equal those of one-after-another solves and the oracle's counts."""
+    from deeppreconditioning_amd import batch
+    specs = [batch.SystemSpec(2, 300, s) for s in range(5)] + [batch.SystemSpec(3, 44, 10 + s) for s in range(3)]
+    conc = batch.solve_specs_local(specs, concurrent=4)
+    seq = batch.solve_specs_local(specs, concurrent=1)
+    assert np.array_equal(conc[:, :3], seq[:, :3])                         # iterations, status, final residual
+    A2, A3 = O.poisson2d(300), O.poisson3d(44)
+    for i, sp_ in enumerate(specs):
+        A = A2 if sp_.dim == 2 else A3
+        assert conc[i, 0] == CO.pcg(A, O.rhs(A.shape[0], sp_.seed), "jacobi", dinv=O.jacobi_dinv(A))[1]
+        assert conc[i, 1] == 0
