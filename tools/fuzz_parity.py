@@ -125,7 +125,7 @@ for case in range(cases):
                     drift = np.abs(hist_np[:head] - hist[:head])[sig] / np.abs(hist[:head])[sig]
                     tol = max(tol, 30 * float(drift.max()) if drift.size else tol)
                 hist_ok = rel.size == 0 or float(rel.max()) < tol
-                count_ok = abs(r.iterations - it) <= (0.03 * it + 1 if chaotic else 0)
+                count_ok = abs(r.iterations - it) <= (0.06 * it + 2 if chaotic else 0)
                 if not (hist_ok and count_ok):
                     bad += 1
                     print("PCG MISMATCH", tag, kind, f"flags={flags}", "iters", r.iterations, it, "status", r.status,
