@@ -281,7 +281,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
     struct alignas(2 * sizeof(VT)) VPair { VT x, y; };
     VPair a[UP];
     uint32_t li[UP];                        // two 16-bit local indices per register
-    XV xt[XT];
+    constexpr int XP = (XT * (kBlock / 64) + 7) / 8;   // wave instructions that stage two chunks each
+    struct alignas(2 * sizeof(XV)) XPair { XV x, y; };
+    XPair xt[XP];
     int cnt = 0, base = 0, rs = 0, re = 0, nc = 0;
     const int lane = t & 63, wv = t >> 6;
     // Everything block `rb` needs from memory -> registers: its slice of the matrix stream AND its x chunks
@@ -322,13 +324,18 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
         }
         nc = nchunks[rb];
         const int32_t *__restrict__ cl = chunks + (int64_t)rb * kTileMaxChunks;
+        // two chunks per wave instruction: lanes 0-31 take chunk 2q, lanes 32-63 chunk 2q+1, two elements per lane
 #pragma unroll
-        for (int u = 0; u < XT; ++u) {
-            const int ci = wv + u * (kBlock / 64);
+        for (int u = 0; u < XP; ++u) {
+            const int ci = 2 * (wv + u * (kBlock / 64)) + (lane >> 5);
             if (ci < nc) {
-                const int chunk = __builtin_amdgcn_readfirstlane(cl[ci]);
-                const int64_t gi = (int64_t)chunk * kTileChunk + lane;
-                xt[u] = gi < n ? x[gi] : (XV)0;
+                const int64_t gi = (int64_t)cl[ci] * kTileChunk + 2 * (lane & 31);
+                if (gi + 1 < n) {
+                    xt[u] = *reinterpret_cast<const XPair *>(x + gi);
+                } else {
+                    xt[u].x = gi < n ? x[gi] : (XV)0;
+                    xt[u].y = (XV)0;
+                }
             }
         }
     };
@@ -341,9 +348,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
         const int64_t row = (int64_t)rb * kStreamRows + t;
         const int ks = rs - base, ke = re - base, cnt_cur = cnt;
 #pragma unroll
-        for (int u = 0; u < XT; ++u) {
-            const int ci = wv + u * (kBlock / 64);
-            if (ci < nc) xs[ci * kTileChunk + lane] = xt[u];
+        for (int u = 0; u < XP; ++u) {
+            const int ci = 2 * (wv + u * (kBlock / 64)) + (lane >> 5);
+            if (ci < nc) *reinterpret_cast<XPair *>(xs + ci * kTileChunk + 2 * (lane & 31)) = xt[u];
         }
         __syncthreads();                    // tile complete (and every thread is past the previous row sums)
 #pragma unroll
