@@ -324,12 +324,16 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
         }
         nc = nchunks[rb];
         const int32_t *__restrict__ cl = chunks + (int64_t)rb * kTileMaxChunks;
-        // two chunks per wave instruction: lanes 0-31 take chunk 2q, lanes 32-63 chunk 2q+1, two elements per lane
+        // two chunks per wave instruction: lanes 0-31 take chunk 2q, lanes 32-63 chunk 2q+1, two elements per lane.
+        // The block's chunk ids are read once per wave (lane l holds id l, always inside the 40-entry list) and handed
+        // to the lanes that need them through the cross-lane network: one memory instruction instead of one per pair.
+        const int my_cid = cl[lane < kTileMaxChunks ? lane : 0];
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
             const int ci = 2 * (wv + u * (kBlock / 64)) + (lane >> 5);
+            const int cid = __shfl(my_cid, ci);
             if (ci < nc) {
-                const int64_t gi = (int64_t)cl[ci] * kTileChunk + 2 * (lane & 31);
+                const int64_t gi = (int64_t)cid * kTileChunk + 2 * (lane & 31);
                 if (gi + 1 < n) {
                     xt[u] = *reinterpret_cast<const XPair *>(x + gi);
                 } else {
