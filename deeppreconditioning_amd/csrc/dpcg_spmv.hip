@@ -278,11 +278,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
     int rb_lo, rb_hi;
     split_range(nrb, v, rb_lo, rb_hi);
     constexpr int UP = U / 2;               // pairs of consecutive non-zeros per thread
-    struct alignas(2 * sizeof(VT)) VPair { VT x, y; };
+    typedef VT VPair __attribute__((ext_vector_type(2)));   // native 2-vectors: one 16- (8-) byte load, stay in registers
     VPair a[UP];
     uint32_t li[UP];                        // two 16-bit local indices per register
     constexpr int XP = (XT * (kBlock / 64) + 7) / 8;   // wave instructions that stage two chunks each
-    struct alignas(2 * sizeof(XV)) XPair { XV x, y; };
+    typedef XV XPair __attribute__((ext_vector_type(2)));
     XPair xt[XP];
     int cnt = 0, base = 0, rs = 0, re = 0, nc = 0;
     const int lane = t & 63, wv = t >> 6;
@@ -300,27 +300,22 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
         base = rowptr[r0] & ~1;
         cnt = rowptr[rlast] - base;
         rs = re = 0;
-        if (row < n) {
-            rs = rowptr[row];
-            re = rowptr[row + 1];
+        if (row < n) {                      // both extents in one 8-byte load (4-byte aligned: fine for global memory)
+            struct __attribute__((packed, aligned(4))) Ext { int32_t s, e; };
+            const Ext ext = *reinterpret_cast<const Ext *>(rowptr + row);
+            rs = ext.s;
+            re = ext.e;
         }
         const int lastp = cnt > 0 ? (cnt - 1) >> 1 : 0;
 #pragma unroll
         for (int u = 0; u < UP; ++u) {
             const int pr = t + u * kBlock;
             const int64_t kabs = base + 2 * (int64_t)(pr <= lastp ? pr : lastp);
-            if (cnt > 0) {
-                if (kabs + 1 < nnz) {
-                    a[u] = *reinterpret_cast<const VPair *>(val + kabs);
-                } else {                    // the matrix's very last non-zero when nnz is odd
-                    a[u].x = val[kabs];
-                    a[u].y = (VT)0;
-                }
-                li[u] = *reinterpret_cast<const uint32_t *>(lidx + kabs);   // lidx is padded to an even length
-            } else {
-                a[u].x = a[u].y = (VT)0;
-                li[u] = 0;
-            }
+            // Unconditional aligned pair loads.  The pair that holds the matrix's very last non-zero when nnz is odd reads
+            // 8 (4) bytes past the array: inside the same aligned 16 (8) bytes, hence the same page -- never a fault --
+            // and its product lands in a slot no row sum reads.  (The launcher checks the 16-byte alignment of val / x.)
+            a[u] = *reinterpret_cast<const VPair *>(val + (cnt > 0 ? kabs : 0));
+            li[u] = *reinterpret_cast<const uint32_t *>(lidx + (cnt > 0 ? kabs : 0));   // lidx is padded to an even length
         }
         nc = nchunks[rb];
         const int32_t *__restrict__ cl = chunks + (int64_t)rb * kTileMaxChunks;
@@ -332,15 +327,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
         for (int u = 0; u < XP; ++u) {
             const int ci = 2 * (wv + u * (kBlock / 64)) + (lane >> 5);
             const int cid = __shfl(my_cid, ci);
-            if (ci < nc) {
-                const int64_t gi = (int64_t)cid * kTileChunk + 2 * (lane & 31);
-                if (gi + 1 < n) {
-                    xt[u] = *reinterpret_cast<const XPair *>(x + gi);
-                } else {
-                    xt[u].x = gi < n ? x[gi] : (XV)0;
-                    xt[u].y = (XV)0;
-                }
-            }
+            // clamped to the last aligned pair that holds a vector element (an element past the end is never indexed)
+            const int64_t gi = (int64_t)(ci < nc ? cid : 0) * kTileChunk + 2 * (lane & 31);
+            xt[u] = *reinterpret_cast<const XPair *>(x + (gi < n ? gi : ((n - 1) & ~(int64_t)1)));
         }
     };
     if (rb_lo < rb_hi) fetch(rb_lo);
@@ -406,7 +395,11 @@ static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, 
         else if (dot) DPCG_LAUNCH_VECTOR(TPRV, false, true);  \
         else DPCG_LAUNCH_VECTOR(TPRV, false, false);          \
         break
-    if (plan.kernel == SPMV_TILE && std::is_same<YT, double>::value) {
+    // the x-tile kernel reads val and x as aligned pairs: a misaligned caller buffer takes the gather kernel
+    const bool pair_aligned = (((uintptr_t)val | (uintptr_t)x) & (2 * sizeof(double) - 1)) == 0 ||
+                              (sizeof(VT) == 4 && sizeof(XT) == 4 && (((uintptr_t)val | (uintptr_t)x) & 7) == 0) ||
+                              (sizeof(VT) == 4 && sizeof(XT) == 8 && ((uintptr_t)val & 7) == 0 && ((uintptr_t)x & 15) == 0);
+    if (plan.kernel == SPMV_TILE && std::is_same<YT, double>::value && pair_aligned) {
         const int tile_doubles = plan.tile_max_chunks * kTileChunk;
         const size_t lds = (size_t)(tile_doubles + kStreamCap + 6) * sizeof(double);
 #define DPCG_LAUNCH_TILE_X(CTLV, DOTV, XTV)                                                                          \
