@@ -101,7 +101,9 @@ int upload_csr(CsrDev &out, int64_t n, int64_t nnz, const int32_t *rowptr, const
     out.n = n;
     out.nnz = nnz;
     const hipMemcpyKind kind = memspace == DPCG_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-    const bool borrow = (memspace == DPCG_DEVICE && !copy);
+    // the SpMV kernels read col / val as aligned pairs: device arrays that are not 16-byte aligned are copied, not borrowed
+    const bool aligned16 = ((((uintptr_t)col) | ((uintptr_t)val)) & 15) == 0;
+    const bool borrow = (memspace == DPCG_DEVICE && !copy && aligned16);
     if (borrow) {
         out.owned = false;
         out.rowptr = const_cast<int32_t *>(rowptr);
@@ -166,7 +168,7 @@ int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s, bool allow_tile) {
     dev_free(d_max);
     const char *force = getenv("DPCG_SPMV_KERNEL");
     const bool force_vector = force && strcmp(force, "vector") == 0;
-    if (h_max <= kStreamCap && !force_vector) {
+    if (h_max <= kStreamCap - 1 && !force_vector) {   // - 1: the alignment slot of the pair loads
         plan.kernel = SPMV_STREAM;
         plan.nrb = (int)((A.n + kStreamRows - 1) / kStreamRows);
         // 8 workgroups per CU while the matrix stream stays in the 256 MiB Infinity Cache, 6 per CU once

@@ -27,8 +27,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t
                                                         const double *__restrict__ xdot, YT *__restrict__ y,
                                                         int nrb, double *__restrict__ part_pq, IterCtlDev ctl,
                                                         FuseArgs fa) {
-    constexpr int U = kStreamCap / kBlock;  // (col,val) loads per thread per row-block
-    __shared__ double prod[kStreamCap];
+    constexpr int U = kStreamCap / kBlock;  // non-zeros per thread per row-block, read as U/2 aligned pairs
+    __shared__ __attribute__((aligned(16))) double prod[kStreamCap + 2];
     __shared__ double sh[8];
     const int t = threadIdx.x;
     // contiguous ranges of row-blocks per (virtual) workgroup, the remainder spread evenly over the
@@ -39,27 +39,38 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t
     int c[U];
     VT a[U];
     int cnt = 0, base = 0, rs = 0, re = 0;   // rs/re stay absolute until the row-sum phase (no early wait)
-    // matrix stream of one row-block -> registers (all 2U loads of a thread in flight at once)
+    // Matrix stream of one row-block -> registers, all loads of a thread in flight at once.  The slice is read as
+    // aligned PAIRS of consecutive non-zeros, lane i <-> pair i (16-byte value loads, 8-byte column loads: the
+    // texture-address unit issues per instruction, not per byte).  Element 2u+h of a thread is slot 2 (t + 256 u) + h,
+    // slots counted from the even index at or below the block's first non-zero: slot 0 may belong to the previous
+    // block and the slot after the last non-zero to the next one or to nobody -- their columns are forced to 0 so
+    // that nothing is gathered out of range, and their products are never read.
+    typedef VT VPair __attribute__((ext_vector_type(2)));
+    typedef int IPair __attribute__((ext_vector_type(2)));
     auto fetch = [&](int rb) {
         const int64_t r0 = (int64_t)rb * kStreamRows;
         const int64_t row = r0 + t;
         const int64_t rlast = (r0 + kStreamRows < n) ? r0 + kStreamRows : n;
-        base = rowptr[r0];
+        const int first = rowptr[r0];
+        base = first & ~1;
         cnt = rowptr[rlast] - base;
         rs = re = 0;
         if (row < n) {
             rs = rowptr[row];
             re = rowptr[row + 1];
         }
-        const int32_t *__restrict__ cb = col + base;
-        const VT *__restrict__ vb = val + base;
-        const int last = cnt > 0 ? cnt - 1 : 0;
+        const int lastp = cnt > 0 ? (cnt - 1) >> 1 : 0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = t + u * kBlock;
-            const int kk = k < cnt ? k : last;
-            c[u] = cnt > 0 ? cb[kk] : 0;
-            a[u] = cnt > 0 ? vb[kk] : (VT)0;
+        for (int u = 0; u < U / 2; ++u) {
+            const int pr = t + u * kBlock;
+            const int64_t kabs = cnt > 0 ? base + 2 * (int64_t)(pr <= lastp ? pr : lastp) : 0;
+            const VPair av = *reinterpret_cast<const VPair *>(val + kabs);
+            const IPair cv = *reinterpret_cast<const IPair *>(col + kabs);
+            const int k = 2 * pr;
+            a[2 * u] = av.x;
+            a[2 * u + 1] = av.y;
+            c[2 * u] = (k < cnt && base + k >= first) ? cv.x : 0;
+            c[2 * u + 1] = (k + 1 < cnt) ? cv.y : 0;
         }
     };
     // The first row-block's loads are issued before the `done` word is looked at.
@@ -107,9 +118,14 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(int64_t n, const int32_t
             for (int u = 0; u < U; ++u) xv[u] = (double)x[c[u]];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = t + u * kBlock;
-            if (k < cnt) prod[k] = (double)a[u] * xv[u];
+        for (int u = 0; u < U / 2; ++u) {
+            const int k = 2 * (t + u * kBlock);
+            if (k < cnt) {                  // one 16-byte LDS store per pair
+                double2 pp;
+                pp.x = (double)a[2 * u] * xv[2 * u];
+                pp.y = (double)a[2 * u + 1] * xv[2 * u + 1];
+                *reinterpret_cast<double2 *>(prod + k) = pp;
+            }
         }
         __syncthreads();
         if (row < n) {
