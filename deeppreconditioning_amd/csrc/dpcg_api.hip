@@ -212,8 +212,8 @@ int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s, bool allow_tile) {
     } else {
         plan.kernel = SPMV_VECTOR;
         const double mean = A.n > 0 ? (double)A.nnz / (double)A.n : 1.0;
-        int tpr = 2;
-        while (tpr < 64 && tpr < mean) tpr *= 2;
+        int tpr = 2;                       // lanes per row; a lane takes two non-zeros per trip
+        while (tpr < 64 && 2 * tpr < mean) tpr *= 2;
         plan.tpr = tpr;
         const int64_t ngroups = (A.n + (kBlock / tpr) - 1) / (kBlock / tpr);
         int g = ngroups < kMaxSpmvGrid ? (int)ngroups : kMaxSpmvGrid;

@@ -177,8 +177,18 @@ __global__ __launch_bounds__(kBlock) void k_spmv_vector(int64_t n, const int32_t
         const int64_t row = (int64_t)g * RPB + t / TPR;
         double s = 0.0;
         if (row < n) {
+            // each lane takes aligned PAIRS of consecutive non-zeros (16-byte value, 8-byte column loads): half the
+            // lanes per row, so twice the rows in flight -- a 65K-row factor with 15 entries per row fits the chip in
+            // one pass.  A pair may start one entry before the row or end one after it: those halves are skipped.
+            typedef VT VPair __attribute__((ext_vector_type(2)));
+            typedef int IPair __attribute__((ext_vector_type(2)));
             const int rs = rowptr[row], re = rowptr[row + 1];
-            for (int k = rs + lane; k < re; k += TPR) s += (double)val[k] * (double)x[col[k]];
+            for (int k = (rs & ~1) + 2 * lane; k < re; k += 2 * TPR) {
+                const VPair av = *reinterpret_cast<const VPair *>(val + k);
+                const IPair cv = *reinterpret_cast<const IPair *>(col + k);
+                if (k >= rs) s += (double)av.x * (double)x[cv.x];
+                if (k + 1 < re) s += (double)av.y * (double)x[cv.y];
+            }
         }
 #pragma unroll
         for (int off = TPR / 2; off > 0; off >>= 1) s += __shfl_down(s, off, TPR);
