@@ -201,12 +201,12 @@ void launch_update_r_two_kernel(int precond_fused, int64_t n, Scalars *scal, con
                                 double *part_rr, int grid, hipStream_t s);
 void launch_update_r(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
                      const double *q, double *r, const double *dinv, double *z, double *part_rz, double *part_rr,
-                     int grid, hipStream_t s);
+                     int grid, hipStream_t s, int store_z = 1);
 void launch_dot_partials(int64_t n, const Scalars *scal, const double *a, const double *b, double *part, int grid,
                          hipStream_t s);
 void launch_update_xp(int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
                       const double *z, double *p, double *x, float *p32, double *hist, int hist_cap, int grid,
-                      hipStream_t s);
+                      hipStream_t s, const double *zd = nullptr);   // zd: z is not stored, K3 forms zd .* z itself
 void launch_final_check(Scalars *scal, hipStream_t s);
 void launch_init_state(int64_t n, Scalars *scal, const double *b, const double *r, const double *z, double *p,
                        float *p32, double *part_bb, double *part_rz, double *part_rr, int init_check_r, int grid,

@@ -19,7 +19,8 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
                                                      const double *__restrict__ part_pq, int n_part_pq,
                                                      const double *__restrict__ q, double *__restrict__ r,
                                                      const double *__restrict__ dinv, double *__restrict__ z,
-                                                     double *__restrict__ part_rz, double *__restrict__ part_rr) {
+                                                     double *__restrict__ part_rz, double *__restrict__ part_rr,
+                                                     int store_z) {
     __shared__ double sh[8];
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
             double2 zn;
             zn.x = dc.x * rn.x;                                         // cg.py:81 (M = diag(1/a_ii))
             zn.y = dc.y * rn.y;
-            z2[cur] = zn;
+            if (store_z) z2[cur] = zn;
             a_rz += rn.x * zn.x;                                        // cg.py:82
             a_rz += rn.y * zn.y;
         }
@@ -101,13 +102,13 @@ void launch_update_r_two_kernel(int precond_fused, int64_t n, Scalars *scal, con
                                 double *part_rr, int grid, hipStream_t s) {
     if (precond_fused == 0)
         hipLaunchKernelGGL((k_update_r<0, true>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r,
-                           dinv, z, part_rz, part_rr);
+                           dinv, z, part_rz, part_rr, 1);
     else if (precond_fused == 1)
         hipLaunchKernelGGL((k_update_r<1, true>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r,
-                           dinv, z, part_rz, part_rr);
+                           dinv, z, part_rz, part_rr, 1);
     else
         hipLaunchKernelGGL((k_update_r<2, true>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r,
-                           dinv, z, part_rz, part_rr);
+                           dinv, z, part_rz, part_rr, 1);
 }
 
 // Two-kernel iteration: state before the first update (see fused_head).
@@ -161,16 +162,16 @@ void launch_final_fused(int64_t n, Scalars *scal, const double *part_rr, int n_p
 
 void launch_update_r(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
                      const double *q, double *r, const double *dinv, double *z, double *part_rz, double *part_rr,
-                     int grid, hipStream_t s) {
+                     int grid, hipStream_t s, int store_z) {
     if (precond_fused == 0)
         hipLaunchKernelGGL(k_update_r<0>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, dinv, z,
-                           part_rz, part_rr);
+                           part_rz, part_rr, store_z);
     else if (precond_fused == 1)
         hipLaunchKernelGGL(k_update_r<1>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, dinv, z,
-                           part_rz, part_rr);
+                           part_rz, part_rr, store_z);
     else
         hipLaunchKernelGGL(k_update_r<2>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, dinv, z,
-                           part_rz, part_rr);
+                           part_rz, part_rr, store_z);
 }
 
 // part[b] = partial of <a,b>; skipped once the solve is done (scal may be null: always run).
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
                                                       const double *__restrict__ part_rr, int n_part,
                                                       const double *__restrict__ z, double *__restrict__ p,
                                                       double *__restrict__ x, float *__restrict__ p32,
-                                                      double *__restrict__ hist, int hist_cap) {
+                                                      double *__restrict__ hist, int hist_cap,
+                                                      const double *__restrict__ zd) {
     __shared__ double sh[4];
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -208,12 +210,14 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
     double2 *__restrict__ p2 = reinterpret_cast<double2 *>(p);
     double2 *__restrict__ x2 = reinterpret_cast<double2 *>(x);
     float2 *__restrict__ f2 = reinterpret_cast<float2 *>(p32);
-    double2 za = make_double2(0, 0), pa = za, xa = za;
+    const double2 *__restrict__ zd2 = reinterpret_cast<const double2 *>(zd);
+    double2 za = make_double2(0, 0), pa = za, xa = za, da = za;
     bool have = i < n2;
     if (have) {
         za = z2[i];
         pa = p2[i];
         xa = x2[i];
+        if (zd) da = zd2[i];
     }
     if (sc->done) return;                                               // after the first loads, as in K2
     const double rz_new = reduce_partials(part_rz, n_part, sh);
@@ -225,13 +229,19 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
     }
     while (have) {
         const int64_t cur = i;
-        const double2 zc = za, pc = pa, xc = xa;
+        double2 zc = za;
+        const double2 pc = pa, xc = xa, dc = da;
         i += stride;
         have = i < n2;
         if (have) {
             za = z2[i];
             pa = p2[i];
             xa = x2[i];
+            if (zd) da = zd2[i];
+        }
+        if (zd) {                                                       // z = dinv * r, recomputed (cg.py:81)
+            zc.x = dc.x * zc.x;
+            zc.y = dc.y * zc.y;
         }
         double2 xn, pn;
         xn.x = xc.x + alpha * pc.x;                                     // cg.py:79
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
         const int64_t e = n - 1;
         const double pe = p[e];
         x[e] = x[e] + alpha * pe;
-        const double pn = z[e] + beta * pe;
+        const double pn = (zd ? zd[e] * z[e] : z[e]) + beta * pe;
         p[e] = pn;
         if (P32) p32[e] = (float)pn;
     }
@@ -254,13 +264,13 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
 
 void launch_update_xp(int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
                       const double *z, double *p, double *x, float *p32, double *hist, int hist_cap, int grid,
-                      hipStream_t s) {
+                      hipStream_t s, const double *zd) {
     if (p32)
         hipLaunchKernelGGL(k_update_xp<true>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, part_rr, n_part, z, p,
-                           x, p32, hist, hist_cap);
+                           x, p32, hist, hist_cap, zd);
     else
         hipLaunchKernelGGL(k_update_xp<false>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, part_rr, n_part, z, p,
-                           x, p32, hist, hist_cap);
+                           x, p32, hist, hist_cap, zd);
 }
 
 // After the last permitted update (cg.py:70 exhausted): the test has already been recorded by K3.

@@ -43,16 +43,20 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
     else launch_spmv(h->A, h->planA, h->p, h->q, h->part_pq, &ctl, s);
     // K2: alpha; r -= alpha Ap; (z = M r fused); partials <r,z>, <r,r>              cg.py:78,80-82,86
     const int pre = h->precond == DPCG_PRECOND_NONE ? 0 : (h->precond == DPCG_PRECOND_JACOBI ? 1 : 2);
-    double *z = pre == 0 ? h->r : h->z;
+    // Jacobi: z = dinv .* r is never stored -- K2 only needs it for <r,z>, and K3 recomputes the same product from r and
+    // dinv (same rounding, same bits).  That moves 8 B per row from a write in K2 to a read in K3; writes are the dearer
+    // direction (measured: 34.9 -> 33.1 us per update at 1M DoF).
+    const bool z_on_the_fly = pre == 1;
+    const double *z = pre == 2 ? h->z : h->r;
     launch_update_r(pre, n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->dinv, h->z, h->part_rz, h->part_rr,
-                    h->vec_grid, s);
+                    h->vec_grid, s, z_on_the_fly ? 0 : 1);
     if (pre == 2) {
         DPCG_TRY(apply_precond(h, h->r, h->z, s, true));                             // cg.py:81
         launch_dot_partials(n, h->scal, h->r, h->z, h->part_rz, h->vec_grid, s);     // cg.py:82
     }
     // K3: beta; x += alpha p; p = z + beta p; workgroup 0: stopping test of the new iterate   cg.py:79,82-83,86,71
     launch_update_xp(n, h->scal, h->part_rz, h->part_rr, h->vec_grid, z, h->p, h->x, f32 ? h->p32 : nullptr, h->hist,
-                     h->hist_cap, h->vec_grid, s);
+                     h->hist_cap, h->vec_grid, s, z_on_the_fly ? h->dinv : nullptr);
     if (x_true) {                                                                    // cg.py:43-45
         launch_anorm_err(n, h->scal, h->x, x_true, h->e, h->vec_grid, s);
         launch_spmv(h->A, h->planA, h->e, h->t, h->part_bb, nullptr, s);

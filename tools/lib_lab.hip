@@ -88,10 +88,16 @@ int main(int argc, char **argv) {
                     launch_finalize_init(sc, part_rr, part_rr, part_rr, 1, 0.0, 0.0, hist, 0, nullptr, s);
                     for (double *p : {x, y, z, r, q}) CK(hipMemcpyAsync(p, dinv, N * 8, hipMemcpyDeviceToDevice, s));
                     CK(hipEventRecord(e0, s));
+                    const int vg = getenv("LAB_VEC_GRID") ? atoi(getenv("LAB_VEC_GRID")) : 512;
                     for (int i = 0; i < 40; ++i) {
                         launch_spmv(A, plan, y, q, part_pq, &ctl, s);
-                        launch_update_r(1, N, sc, part_pq, plan.grid, q, r, dinv, z, part_rz, part_rr, 512, s);
-                        launch_update_xp(N, sc, part_rz, part_rr, 512, z, y, x, nullptr, hist, 0, 512, s);
+                        if (getenv("LAB_NOZ")) {
+                            launch_update_r(1, N, sc, part_pq, plan.grid, q, r, dinv, z, part_rz, part_rr, vg, s, 0);
+                            launch_update_xp(N, sc, part_rz, part_rr, vg, r, y, x, nullptr, hist, 0, vg, s, dinv);
+                        } else {
+                            launch_update_r(1, N, sc, part_pq, plan.grid, q, r, dinv, z, part_rz, part_rr, vg, s);
+                            launch_update_xp(N, sc, part_rz, part_rr, vg, z, y, x, nullptr, hist, 0, vg, s);
+                        }
                     }
                     CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
                     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tt.push_back(ms * 1e3f / 40);
