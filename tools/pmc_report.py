@@ -53,8 +53,10 @@ lines = [f"# PMC traffic summary ({tag})", "",
          "| kernel (bytes per lane) | known read MB | 2 x FETCH_SIZE x 1024 MB | 128 x RDREQ_128B + 64 x RDREQ_64B + 32 x RDREQ_32B MB | known write MB | WRITE_SIZE x 1024 MB |",
          "|---|---|---|---|---|---|"]
 N, NNZ = SYSTEMS[2][1], SYSTEMS[2][2]
-cal = [("k_dot_partials", 2, "<b,b>, 8 B/lane loads", 8 * N, 0), ("k_update_r", 2, "16 B/lane loads and stores", 24 * N, 16 * N),
-       ("k_update_xp", 2, "16 B/lane loads and stores", 24 * N, 16 * N), ("k_convert", 3, "4 B/lane loads, 8 B/lane stores", 4 * NNZ, 8 * NNZ)]
+cal = [("k_dot_partials", 2, "<b,b>, 8 B/lane loads", 8 * N, 0),
+       ("k_update_r", 2, "16 B/lane: reads q, r, dinv, writes r", 24 * N, 8 * N),
+       ("k_update_xp", 2, "16 B/lane: reads r, dinv, p, x, writes x, p", 32 * N, 16 * N),
+       ("k_convert", 3, "4 B/lane loads, 8 B/lane stores", 4 * NNZ, 8 * NNZ)]
 for k, seg, what, rd, wr in cal:
     floor = 1000.0
     f2 = 2 * 1024 * mean(F[(seg, k, "FETCH_SIZE")], floor)
