@@ -245,18 +245,25 @@ struct Solve {
             launch_final_check(h->scal, s);
         DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
         DPCG_HIP(hipStreamSynchronize(s));
-        const auto t1 = std::chrono::steady_clock::now();                            // cg.py:88
+        const auto t1 = std::chrono::steady_clock::now();                            // cg.py:88 (the loop only)
         const Scalars sc = *h->scal_host;
         if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
         if (iters) *iters = sc.k;                                                    // cg.py:90
         if (final_res) *final_res = sc.res;
-        if (res_history)
+        bool pending = false;
+        if (res_history) {
             DPCG_HIP(hipMemcpyAsync(res_history, h->hist, (size_t)(sc.k + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
-        if (err_history && x_true)
+            pending = true;
+        }
+        if (err_history && x_true) {
             DPCG_HIP(hipMemcpyAsync(err_history, h->err_hist, (size_t)(sc.k + 1) * sizeof(double),
                                     hipMemcpyDeviceToHost, s));
+            pending = true;
+        }
+        // x is handed over in stream order: the copy is enqueued on the caller's stream, a second host sync is only
+        // needed for the host-side history buffers
         if (x) DPCG_HIP(hipMemcpyAsync(x, h->x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-        DPCG_HIP(hipStreamSynchronize(s));
+        if (pending) DPCG_HIP(hipStreamSynchronize(s));
         DPCG_CHECK_LAUNCH();
         return sc.status;
     }

@@ -116,7 +116,9 @@ int dpcg_spmv_dot_bench(dpcg_handle_t h, const double *x, double *y, int repeats
 
 /* ---- the solve: cg.py:50-90 (PCG) and cg.py:20-47 (CG = PCG with M = I, test on r) ----------- */
 /*
- * b, x0 (may be NULL = zeros, cg.py:58), x (out, may be NULL): device fp64[n].
+ * b, x0 (may be NULL = zeros, cg.py:58), x (out, may be NULL): device fp64[n].  x is written in stream order: valid for
+ * work enqueued on `stream` after the call, and for the host once `stream` is synchronised (the scalar outputs and the
+ * host-side histories are complete on return).
  * Stop when res_k = <r_k,r_k>/<b,b> < rtol_sq or <r_k,r_k> < atol_sq (cg.py:15-17,71: SQUARED
  * ratio; atol_sq = 0 for the reference, 1e-12 for generate_data.py:107), k = 0 tested on
  * <z_0,z_0>/<b,b> unless DPCG_INIT_CHECK_R (cg.py:66).  At most max_iter updates (cg.py:70).
