@@ -186,8 +186,8 @@ int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s, bool allow_tile) {
             int *d_flags = nullptr, h_flags[2] = {1, 0};
             DPCG_TRY(dev_alloc(&plan.tile_chunks, (int64_t)plan.nrb * kTileMaxChunks));
             DPCG_TRY(dev_alloc(&plan.tile_nchunks, plan.nrb));
-            DPCG_TRY(dev_alloc(&plan.tile_lidx, A.nnz + 2));                   // read in aligned pairs
-            DPCG_HIP(hipMemsetAsync(plan.tile_lidx + A.nnz, 0, 2 * sizeof(uint16_t), s));
+            DPCG_TRY(dev_alloc(&plan.tile_lidx, A.nnz + 4));                   // read in aligned groups of 2 or 4
+            DPCG_HIP(hipMemsetAsync(plan.tile_lidx + A.nnz, 0, 4 * sizeof(uint16_t), s));
             DPCG_TRY(dev_alloc(&d_flags, 2));
             DPCG_HIP(hipMemcpyAsync(d_flags, h_flags, sizeof(h_flags), hipMemcpyHostToDevice, s));
             launch_tile_plan(A, plan.nrb, plan.tile_chunks, plan.tile_nchunks, plan.tile_lidx, d_flags, s);
@@ -197,7 +197,7 @@ int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s, bool allow_tile) {
             if (h_flags[0] == 1 && h_flags[1] > 0) {
                 plan.kernel = SPMV_TILE;
                 plan.tile_max_chunks = h_flags[1];
-                const size_t lds = (size_t)(h_flags[1] * kTileChunk + kStreamCap + 6) * sizeof(double);
+                const size_t lds = (size_t)(h_flags[1] * kTileChunk + kStreamCap + 8) * sizeof(double);
                 const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
                 cap = std::min(cap, per_cu * 256);
             } else {

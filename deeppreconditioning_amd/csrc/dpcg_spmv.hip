@@ -243,8 +243,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_plan(int64_t n, const int32_t *
         }
         const int cb = s_min / kTileChunk;
         const int span = s_max / kTileChunk - cb + 1;
-        // not tileable: columns too spread out, or no room for the alignment slot of the pair loads
-        if (span > kTileTableMax || cnt > kStreamCap - 1) {
+        // not tileable: columns too spread out, or no room for the alignment slots of the grouped loads
+        if (span > kTileTableMax || cnt > kStreamCap - 3) {
             if (t == 0) { nchunks[rb] = 0; atomicExch(&ok_and_max[0], 0); }
             __syncthreads();
             continue;
@@ -297,16 +297,18 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
     constexpr int U = kStreamCap / kBlock;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     XV *xs = reinterpret_cast<XV *>(smem);  // the staged x chunks of this block (tile_doubles slots reserved)
-    double *prod = smem + tile_doubles;     // products, kStreamCap + 2 doubles
-    double *sh = prod + kStreamCap + 2;     // 4 doubles for the block reduction
+    double *prod = smem + tile_doubles;     // products, kStreamCap + 4 doubles
+    double *sh = prod + kStreamCap + 4;     // 4 doubles for the block reduction
     const int t = threadIdx.x;
     const int v = virtual_block();
     int rb_lo, rb_hi;
     split_range(nrb, v, rb_lo, rb_hi);
-    constexpr int UP = U / 2;               // pairs of consecutive non-zeros per thread
-    typedef VT VPair __attribute__((ext_vector_type(2)));   // native 2-vectors: one 16- (8-) byte load, stay in registers
+    constexpr int G = 16 / sizeof(VT);      // consecutive non-zeros per 16-byte value load: 2 (fp64) or 4 (fp32)
+    constexpr int UP = U / G;               // such groups per thread
+    typedef VT VPair __attribute__((ext_vector_type(G)));            // native vectors: one load, stay in registers
+    typedef unsigned short IPair __attribute__((ext_vector_type(G)));   // the group's 16-bit local indices (4 or 8 bytes)
     VPair a[UP];
-    uint32_t li[UP];                        // two 16-bit local indices per register
+    IPair li[UP];
     constexpr int XP = (XT * (kBlock / 64) + 7) / 8;   // wave instructions that stage two chunks each
     typedef XV XPair __attribute__((ext_vector_type(2)));
     XPair xt[XP];
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
         const int64_t r0 = (int64_t)rb * kStreamRows;
         const int64_t row = r0 + t;
         const int64_t rlast = (r0 + kStreamRows < n) ? r0 + kStreamRows : n;
-        base = rowptr[r0] & ~1;
+        base = rowptr[r0] & ~(G - 1);
         cnt = rowptr[rlast] - base;
         rs = re = 0;
         if (row < n) {                      // both extents in one 8-byte load (4-byte aligned: fine for global memory)
@@ -332,16 +334,16 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
             rs = ext.s;
             re = ext.e;
         }
-        const int lastp = cnt > 0 ? (cnt - 1) >> 1 : 0;
+        const int lastp = cnt > 0 ? (cnt - 1) / G : 0;
 #pragma unroll
         for (int u = 0; u < UP; ++u) {
             const int pr = t + u * kBlock;
-            const int64_t kabs = base + 2 * (int64_t)(pr <= lastp ? pr : lastp);
+            const int64_t kabs = base + G * (int64_t)(pr <= lastp ? pr : lastp);
             // Unconditional aligned pair loads.  The pair that holds the matrix's very last non-zero when nnz is odd reads
             // 8 (4) bytes past the array: inside the same aligned 16 (8) bytes, hence the same page -- never a fault --
             // and its product lands in a slot no row sum reads.  (The launcher checks the 16-byte alignment of val / x.)
             a[u] = *reinterpret_cast<const VPair *>(val + (cnt > 0 ? kabs : 0));
-            li[u] = *reinterpret_cast<const uint32_t *>(lidx + (cnt > 0 ? kabs : 0));   // lidx is padded to an even length
+            li[u] = *reinterpret_cast<const IPair *>(lidx + (cnt > 0 ? kabs : 0));      // lidx is padded by 4 entries
         }
         nc = nchunks[rb];
         const int32_t *__restrict__ cl = chunks + (int64_t)rb * kTileMaxChunks;
@@ -374,12 +376,15 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
         __syncthreads();                    // tile complete (and every thread is past the previous row sums)
 #pragma unroll
         for (int u = 0; u < UP; ++u) {
-            const int k = 2 * (t + u * kBlock);
-            if (k < cnt_cur) {              // one 16-byte LDS store per pair (slot cnt_cur may be written: never read)
-                double2 pp;
-                pp.x = (double)a[u].x * (double)xs[li[u] & 0xffffu];
-                pp.y = (double)a[u].y * (double)xs[li[u] >> 16];
-                *reinterpret_cast<double2 *>(prod + k) = pp;
+            const int k = G * (t + u * kBlock);
+            if (k < cnt_cur) {              // 16-byte LDS stores (slots up to cnt_cur + G - 1 may be written: never read)
+#pragma unroll
+                for (int e = 0; e < G; e += 2) {
+                    double2 pp;
+                    pp.x = (double)a[u][e] * (double)xs[li[u][e]];
+                    pp.y = (double)a[u][e + 1] * (double)xs[li[u][e + 1]];
+                    *reinterpret_cast<double2 *>(prod + k + e) = pp;
+                }
             }
         }
         if (rb + 1 < rb_hi) fetch(rb + 1);   // next block's stream and x chunks are in flight from here on
@@ -422,12 +427,10 @@ static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, 
         else DPCG_LAUNCH_VECTOR(TPRV, false, false);          \
         break
     // the x-tile kernel reads val and x as aligned pairs: a misaligned caller buffer takes the gather kernel
-    const bool pair_aligned = (((uintptr_t)val | (uintptr_t)x) & (2 * sizeof(double) - 1)) == 0 ||
-                              (sizeof(VT) == 4 && sizeof(XT) == 4 && (((uintptr_t)val | (uintptr_t)x) & 7) == 0) ||
-                              (sizeof(VT) == 4 && sizeof(XT) == 8 && ((uintptr_t)val & 7) == 0 && ((uintptr_t)x & 15) == 0);
+    const bool pair_aligned = (((uintptr_t)val) & 15) == 0 && (((uintptr_t)x) & (2 * sizeof(XT) - 1)) == 0;   // 16-byte value groups, x pairs
     if (plan.kernel == SPMV_TILE && std::is_same<YT, double>::value && pair_aligned) {
         const int tile_doubles = plan.tile_max_chunks * kTileChunk;
-        const size_t lds = (size_t)(tile_doubles + kStreamCap + 6) * sizeof(double);
+        const size_t lds = (size_t)(tile_doubles + kStreamCap + 8) * sizeof(double);
 #define DPCG_LAUNCH_TILE_X(CTLV, DOTV, XTV)                                                                          \
     hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV, XTV, VT, XT>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr,  \
                        val, plan.tile_lidx, plan.tile_chunks, plan.tile_nchunks, x, xdot, (double *)y, plan.nrb,     \
