@@ -91,7 +91,7 @@ int main(int argc, char **argv) {
                     const int vg = getenv("LAB_VEC_GRID") ? atoi(getenv("LAB_VEC_GRID")) : 512;
                     for (int i = 0; i < 40; ++i) {
                         launch_spmv(A, plan, y, q, part_pq, &ctl, s);
-                        if (getenv("LAB_NOZ")) {
+                        if (!getenv("LAB_STORE_Z")) {   // as the library runs Jacobi: z never stored (LAB_STORE_Z=1: the old form)
                             launch_update_r(1, N, sc, part_pq, plan.grid, q, r, dinv, z, part_rz, part_rr, vg, s, 0);
                             launch_update_xp(N, sc, part_rz, part_rr, vg, r, y, x, nullptr, hist, 0, vg, s, dinv);
                         } else {
