@@ -62,6 +62,7 @@ struct Scalars {
     double res;        // last tested squared relative residual
     double rtol_sq;    // cg.py:71 threshold
     double atol_sq;    // absolute threshold on <r,r> (0 for the reference)
+    double alpha_prev; // deferred-x form only: the step length of the previous update
     double rz_prev;    // two-kernel iteration only: <r,z> of the previous iterate (+inf before the first update)
     int k;             // completed updates
     int done;          // 1 once the stopping test held (kernels become no-ops)
@@ -183,6 +184,12 @@ struct FuseArgs {
 void launch_spmv_fused(const CsrDev &A, const SpmvPlan &plan, const FuseArgs &fa, double *q, double *part_pq,
                        Scalars *scal, hipStream_t s);
 void launch_fused_init(Scalars *scal, hipStream_t s);
+// K3 with the x update deferred to every second update (see k_update_xp_deferred); `odd`: this is update 1, 3, 5, ...
+void launch_update_xp_deferred(bool odd, int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
+                               const double *z, const double *p_in, double *p_out, double *x, float *p32, double *hist,
+                               int hist_cap, int grid, hipStream_t s, const double *zd);
+void launch_final_deferred(int64_t n, Scalars *scal, double *x, const double *p0, const double *p1, int grid,
+                           hipStream_t s);
 void launch_final_fused(int64_t n, Scalars *scal, const double *part_rr, int n_part, double *hist, int hist_cap,
                         double *x, const double *p0, const double *p1, int grid, hipStream_t s);
 void launch_spmv(const CsrDev &A, const SpmvPlan &plan, const double *x, double *y, double *part_pq,

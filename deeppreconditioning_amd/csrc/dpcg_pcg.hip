@@ -273,6 +273,136 @@ void launch_update_xp(int64_t n, Scalars *scal, const double *part_rz, const dou
                            x, p32, hist, hist_cap, zd);
 }
 
+// K3 with the x update deferred.  x is only an output, and every write costs more than a read here, so x is brought
+// up to date every SECOND update:  even update j  -> p_{j+1} = z + beta p_j  into the other p buffer (p_j survives);
+//                                  odd update j+1 -> x = (x + alpha_j p_j) + alpha_{j+1} p_{j+1}, then p_{j+2} over p_j.
+// Same operations in the same order as x += alpha p every update (cg.py:79): bit-identical iterates; per two updates
+// one x read and one x write are replaced by one extra read of p.  k_final_deferred applies a pending half.
+template <bool P32, bool ODD>
+__global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalars *__restrict__ sc,
+                                                               const double *__restrict__ part_rz,
+                                                               const double *__restrict__ part_rr, int n_part,
+                                                               const double *__restrict__ z, const double *p_in,
+                                                               double *p_out, double *__restrict__ x,
+                                                               float *__restrict__ p32, double *__restrict__ hist,
+                                                               int hist_cap, const double *__restrict__ zd) {
+    __shared__ double sh[4];
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const double2 *__restrict__ z2 = reinterpret_cast<const double2 *>(z);
+    const double2 *pi2 = reinterpret_cast<const double2 *>(p_in);
+    double2 *po2 = reinterpret_cast<double2 *>(p_out);          // ODD: holds p of the previous update until overwritten
+    double2 *__restrict__ x2 = reinterpret_cast<double2 *>(x);
+    float2 *__restrict__ f2 = reinterpret_cast<float2 *>(p32);
+    const double2 *__restrict__ zd2 = reinterpret_cast<const double2 *>(zd);
+    double2 za = make_double2(0, 0), pa = za, qa = za, xa = za, da = za;
+    bool have = i < n2;
+    if (have) {
+        za = z2[i];
+        pa = pi2[i];
+        if (ODD) {
+            qa = po2[i];
+            xa = x2[i];
+        }
+        if (zd) da = zd2[i];
+    }
+    if (sc->done) return;
+    const double rz_new = reduce_partials(part_rz, n_part, sh);
+    const double beta = rz_new / sc->rz;                                // cg.py:82
+    const double alpha = sc->alpha;
+    const double alpha_prev = ODD ? sc->alpha_prev : 0.0;               // written by the even update before this one
+    if (blockIdx.x == 0) {                                              // cg.py:86 + the test of cg.py:71
+        const double rr = reduce_partials(part_rr, n_part, sh);
+        if (threadIdx.x == 0) {
+            if (!ODD) sc->alpha_prev = alpha;                           // read by the next (odd) update only
+            record_and_test(sc, rr, rz_new, hist, hist_cap, sc->k + 1);
+        }
+    }
+    while (have) {
+        const int64_t cur = i;
+        double2 zc = za;
+        const double2 pc = pa, qc = qa, xc = xa, dc = da;
+        i += stride;
+        have = i < n2;
+        if (have) {
+            za = z2[i];
+            pa = pi2[i];
+            if (ODD) {
+                qa = po2[i];
+                xa = x2[i];
+            }
+            if (zd) da = zd2[i];
+        }
+        if (zd) {                                                       // z = dinv * r, recomputed (cg.py:81)
+            zc.x = dc.x * zc.x;
+            zc.y = dc.y * zc.y;
+        }
+        if (ODD) {
+            double2 xn;
+            xn.x = xc.x + alpha_prev * qc.x;                            // cg.py:79 of the previous update ...
+            xn.y = xc.y + alpha_prev * qc.y;
+            xn.x = xn.x + alpha * pc.x;                                 // ... and of this one
+            xn.y = xn.y + alpha * pc.y;
+            x2[cur] = xn;
+        }
+        double2 pn;
+        pn.x = zc.x + beta * pc.x;                                      // cg.py:83
+        pn.y = zc.y + beta * pc.y;
+        po2[cur] = pn;
+        if (P32) f2[cur] = make_float2((float)pn.x, (float)pn.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t e = n - 1;
+        const double pe = p_in[e];
+        if (ODD) {
+            const double xe = x[e] + alpha_prev * p_out[e];
+            x[e] = xe + alpha * pe;
+        }
+        const double pn = (zd ? zd[e] * z[e] : z[e]) + beta * pe;
+        p_out[e] = pn;
+        if (P32) p32[e] = (float)pn;
+    }
+}
+
+void launch_update_xp_deferred(bool odd, int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
+                               const double *z, const double *p_in, double *p_out, double *x, float *p32, double *hist,
+                               int hist_cap, int grid, hipStream_t s, const double *zd) {
+#define DPCG_K3D(P32V, ODDV)                                                                                            \
+    hipLaunchKernelGGL((k_update_xp_deferred<P32V, ODDV>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, part_rr, \
+                       n_part, z, p_in, p_out, x, p32, hist, hist_cap, zd)
+    if (p32) {
+        if (odd) DPCG_K3D(true, true);
+        else DPCG_K3D(true, false);
+    } else {
+        if (odd) DPCG_K3D(false, true);
+        else DPCG_K3D(false, false);
+    }
+#undef DPCG_K3D
+}
+
+// End of a solve in the deferred-x form: after an odd number of updates x still lacks alpha_{k-1} p_{k-1}; then the
+// status bookkeeping of k_final_check.
+__global__ __launch_bounds__(kBlock) void k_final_deferred(int64_t n, Scalars *sc, double *__restrict__ x,
+                                                           const double *__restrict__ p0, const double *__restrict__ p1) {
+    const int k = sc->k;
+    if (k & 1) {
+        const double alpha = sc->alpha;
+        const double *__restrict__ p = ((k - 1) & 1) ? p1 : p0;
+        const int64_t stride = (int64_t)gridDim.x * kBlock;
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) x[i] = x[i] + alpha * p[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !sc->done) {
+        sc->status = DPCG_MAX_ITER;
+        sc->done = 1;
+    }
+}
+
+void launch_final_deferred(int64_t n, Scalars *scal, double *x, const double *p0, const double *p1, int grid,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(k_final_deferred, dim3(grid), dim3(kBlock), 0, s, n, scal, x, p0, p1);
+}
+
 // After the last permitted update (cg.py:70 exhausted): the test has already been recorded by K3.
 __global__ void k_final_check(Scalars *sc) {
     if (threadIdx.x == 0 && !sc->done) {

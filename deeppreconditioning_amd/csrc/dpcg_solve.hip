@@ -18,8 +18,16 @@ static int default_chunk() {
     return c < 1 ? 1 : (c > 256 ? 256 : c);
 }
 
-// One PCG update (cg.py:75-86) as kernel launches on `s`.
-static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hipStream_t s) {
+// The x update is deferred to every second update (k_update_xp_deferred) in the three-kernel form; x_true tracking
+// needs x after every update.
+static bool defer_x_eligible(const dpcg_system *h, int flags, const double *x_true) {
+    static const bool enabled = [] { const char *e = getenv("DPCG_DEFER_X"); return !(e && e[0] == '0'); }();
+    return enabled && !x_true && !fuse_eligible(h, flags, x_true);
+}
+
+// One PCG update (cg.py:75-86) as kernel launches on `s`; `j` = index of this update within the solve (its parity
+// selects the p buffer in the deferred-x form: a replayed graph chunk has an even length and starts at an even j).
+static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hipStream_t s, int j) {
     const int64_t n = h->A.n;
     const bool f32 = (flags & DPCG_SPMV_F32) != 0;
     if (fuse_eligible(h, flags, x_true)) {
@@ -38,9 +46,12 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
     IterCtl ctl{h->scal};
     // K1: (skip when done) Ap = A p + partials of <p,Ap>           cg.py:71,75,78
     const bool v32 = !f32 && (flags & DPCG_VAL32_IF_LOSSLESS) && h->A.val32_lossless == 1;
-    if (f32) launch_spmv_f32in(h->A, h->planA, h->p32, h->p, h->q, h->part_pq, &ctl, s);
-    else if (v32) launch_spmv_val32(h->A, h->planA, h->p, h->q, h->part_pq, &ctl, s);
-    else launch_spmv(h->A, h->planA, h->p, h->q, h->part_pq, &ctl, s);
+    const bool defer_x = defer_x_eligible(h, flags, x_true);
+    double *p_cur = (defer_x && (j & 1)) ? h->p2 : h->p;               // p_j
+    double *p_next = (defer_x && !(j & 1)) ? h->p2 : h->p;             // where p_{j+1} goes (in place without deferral)
+    if (f32) launch_spmv_f32in(h->A, h->planA, h->p32, p_cur, h->q, h->part_pq, &ctl, s);
+    else if (v32) launch_spmv_val32(h->A, h->planA, p_cur, h->q, h->part_pq, &ctl, s);
+    else launch_spmv(h->A, h->planA, p_cur, h->q, h->part_pq, &ctl, s);
     // K2: alpha; r -= alpha Ap; (z = M r fused); partials <r,z>, <r,r>              cg.py:78,80-82,86
     const int pre = h->precond == DPCG_PRECOND_NONE ? 0 : (h->precond == DPCG_PRECOND_JACOBI ? 1 : 2);
     // Jacobi: z = dinv .* r is never stored -- K2 only needs it for <r,z>, and K3 recomputes the same product from r and
@@ -55,8 +66,13 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
         launch_dot_partials(n, h->scal, h->r, h->z, h->part_rz, h->vec_grid, s);     // cg.py:82
     }
     // K3: beta; x += alpha p; p = z + beta p; workgroup 0: stopping test of the new iterate   cg.py:79,82-83,86,71
-    launch_update_xp(n, h->scal, h->part_rz, h->part_rr, h->vec_grid, z, h->p, h->x, f32 ? h->p32 : nullptr, h->hist,
-                     h->hist_cap, h->vec_grid, s, z_on_the_fly ? h->dinv : nullptr);
+    if (defer_x)
+        launch_update_xp_deferred((j & 1) != 0, n, h->scal, h->part_rz, h->part_rr, h->vec_grid, z, p_cur, p_next, h->x,
+                                  f32 ? h->p32 : nullptr, h->hist, h->hist_cap, h->vec_grid, s,
+                                  z_on_the_fly ? h->dinv : nullptr);
+    else
+        launch_update_xp(n, h->scal, h->part_rz, h->part_rr, h->vec_grid, z, h->p, h->x, f32 ? h->p32 : nullptr, h->hist,
+                         h->hist_cap, h->vec_grid, s, z_on_the_fly ? h->dinv : nullptr);
     if (x_true) {                                                                    // cg.py:43-45
         launch_anorm_err(n, h->scal, h->x, x_true, h->e, h->vec_grid, s);
         launch_spmv(h->A, h->planA, h->e, h->t, h->part_bb, nullptr, s);
@@ -67,14 +83,15 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
 
 static int ensure_graph(dpcg_system *h, int flags, int chunk) {
     const int key = (h->precond << 8) | (flags & (DPCG_SPMV_F32 | DPCG_VAL32_IF_LOSSLESS | DPCG_NO_FUSE)) |
-                    (h->A.val32_lossless == 1 ? 64 : 0) | (fuse_eligible(h, flags, nullptr) ? 128 : 0);
+                    (h->A.val32_lossless == 1 ? 64 : 0) | (fuse_eligible(h, flags, nullptr) ? 128 : 0) |
+                    (defer_x_eligible(h, flags, nullptr) ? 1024 : 0);
     if (h->graph_exec && h->graph_key == key && h->graph_chunk == chunk) return DPCG_OK;
     drop_graph(h);
     HandleExtras &ex = extras()[h];
     hipGraph_t graph = nullptr;
     DPCG_HIP(hipStreamBeginCapture(ex.cap_stream, hipStreamCaptureModeThreadLocal));
     int st = DPCG_OK;
-    for (int i = 0; i < chunk && st >= 0; ++i) st = enqueue_iteration(h, flags, nullptr, ex.cap_stream);
+    for (int i = 0; i < chunk && st >= 0; ++i) st = enqueue_iteration(h, flags, nullptr, ex.cap_stream, i);
     hipError_t e = hipStreamEndCapture(ex.cap_stream, &graph);
     if (st < 0) {
         if (graph) (void)hipGraphDestroy(graph);
@@ -118,6 +135,7 @@ struct Solve {
     bool complete = false;
     double t_iter = 0.0;     // measured seconds per update (0 = not known yet)
     bool fused = false;           // two-kernel updates (x lags one update behind until finish())
+    bool defer_x = false;         // three-kernel updates with x brought up to date every second update
     bool many_launches = false;   // an update is dozens of small launches (level-scheduled SpTRSV): always replay a graph
     std::chrono::steady_clock::time_point t0;
 
@@ -129,7 +147,7 @@ struct Solve {
             DPCG_HIP(hipGraphLaunch(h->graph_exec, s));
             enq += chunk;
         } else {
-            DPCG_TRY(enqueue_iteration(h, flags, x_true, s));
+            DPCG_TRY(enqueue_iteration(h, flags, x_true, s, enq));
             enq += 1;
         }
         return DPCG_OK;
@@ -164,13 +182,15 @@ struct Solve {
             h->A.val32_lossless = lossy ? -1 : 1;
         }
         fused = fuse_eligible(h, flags, x_true);
-        if (fused && !h->p2) {
+        defer_x = defer_x_eligible(h, flags, x_true);
+        if ((fused || defer_x) && !h->p2) {
             DPCG_TRY(dev_alloc(&h->p2, n));
             drop_graph(h);
         }
         const int per_update = 3 + precond_launches(h);
         many_launches = per_update >= 16;
         if (many_launches) chunk = std::max(1, std::min(chunk, 1024 / per_update));   // keep the graph at ~1K nodes
+        if (defer_x && (chunk & 1)) chunk += 1;   // a replayed chunk must start at an even update (p buffer parity)
         use_graph = !(flags & DPCG_NO_GRAPH) && !x_true && max_iter >= chunk;
         if (use_graph) DPCG_TRY(ensure_graph(h, flags, chunk));
         *ex.prog_host = 0;
@@ -241,6 +261,8 @@ struct Solve {
         if (fused)
             launch_final_fused(n, h->scal, h->part_rr, h->vec_grid, h->hist, h->hist_cap, h->x, h->p, h->p2, h->vec_grid,
                                s);
+        else if (defer_x)
+            launch_final_deferred(n, h->scal, h->x, h->p, h->p2, h->vec_grid, s);
         else
             launch_final_check(h->scal, s);
         DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
