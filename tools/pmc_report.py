@@ -55,7 +55,7 @@ lines = [f"# PMC traffic summary ({tag})", "",
 N, NNZ = SYSTEMS[2][1], SYSTEMS[2][2]
 cal = [("k_dot_partials", 2, "<b,b>, 8 B/lane loads", 8 * N, 0),
        ("k_update_r", 2, "16 B/lane: reads q, r, dinv, writes r", 24 * N, 8 * N),
-       ("k_update_xp", 2, "16 B/lane: reads r, dinv, p, x, writes x, p", 32 * N, 16 * N),
+       ("k_update_xp_deferred", 2, "16 B/lane: even updates read r, dinv, p, write p; odd ones also read p', x, write x (mean)", 32 * N, 12 * N),
        ("k_convert", 3, "4 B/lane loads, 8 B/lane stores", 4 * NNZ, 8 * NNZ)]
 for k, seg, what, rd, wr in cal:
     floor = 1000.0
