@@ -66,6 +66,7 @@ def parse_args():
 def cpu_baseline(dim: int, n: int) -> dict:
     """The CPU oracle (C restatement of cg.py, oracle/pcg_oracle.c, OpenMP) timed on this box's host
     cores on the same system -- a reported baseline, not the target."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # idle OpenMP workers must not spin beside the GPU driver thread
     from oracle import c_oracle as CO
     from oracle import oracle as O
     A = O.poisson3d(n) if dim == 3 else O.poisson2d(n)
