@@ -10,8 +10,11 @@ import ctypes as C
 import pathlib
 import subprocess
 
+import os
+
 _CSRC = pathlib.Path(__file__).resolve().parent / "csrc"
-LIB_PATH = _CSRC / "libdpcg.so"
+# DPCG_LIBRARY (development): load another build of the same ABI, e.g. an older one for an A/B measurement
+LIB_PATH = pathlib.Path(os.environ["DPCG_LIBRARY"]) if os.environ.get("DPCG_LIBRARY") else _CSRC / "libdpcg.so"
 
 # status codes (include/dpcg.h)
 OK, MAX_ITER, BREAKDOWN = 0, 1, 2

@@ -147,9 +147,12 @@ class BenchmarkSuite:
                 f.write(",".join(str(self.totals[t][index]) for t in self.techniques) + "\n")
 
 
-def main(params_path="params.yaml", checkpoint="./assets/checkpoints/best.pt", root=None) -> BenchmarkSuite:
+def main(params_path="params.yaml", checkpoint="./assets/checkpoints/best.pt", root=None, *,
+         allow_random_weights: bool = False) -> BenchmarkSuite:
     """test.py:201-221 without DVC: read `params.yaml` (keys `data`, `model`, `channels`), build the test split with
-    batch size 1, load the checkpoint when there is one (random weights otherwise), run and dump the CSVs."""
+    batch size 1, load the checkpoint, run and dump the CSVs.  A missing checkpoint raises, as the reference's
+    `torch.load` does (test.py:213) -- "learned" numbers from random weights would look plausible and mean nothing;
+    `allow_random_weights=True` (tests, smoke runs without a trained model) opts into seeded random weights."""
     import yaml
 
     from . import data_set as data_sets
@@ -162,6 +165,9 @@ def main(params_path="params.yaml", checkpoint="./assets/checkpoints/best.pt", r
     model = getattr(models, params["model"])(params["channels"])
     if pathlib.Path(checkpoint).exists():
         models.load_reference_state_dict(model, torch.load(checkpoint, map_location="cpu"))
+    elif not allow_random_weights:
+        raise FileNotFoundError(f"checkpoint {checkpoint} not found (pass allow_random_weights=True to benchmark a "
+                                "randomly initialised model)")
     model = model.to("cuda")
     suite = BenchmarkSuite(data, model)
     suite.run()

@@ -30,7 +30,7 @@ __global__ void k_flag_heads(int64_t nnz, const uint64_t *__restrict__ keys, int
 __global__ void k_emit_unique(int64_t nnz, const uint64_t *__restrict__ keys, const int32_t *__restrict__ perm,
                               const int32_t *__restrict__ head, const int32_t *__restrict__ pos,
                               const double *__restrict__ vals, int32_t *__restrict__ col_out,
-                              double *__restrict__ val_out, int32_t *__restrict__ row_count) {
+                              double *__restrict__ val_out, int32_t *__restrict__ row_count, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride) {
         if (!head[k]) continue;
@@ -40,7 +40,10 @@ __global__ void k_emit_unique(int64_t nnz, const uint64_t *__restrict__ keys, co
         const int32_t p = pos[k];
         col_out[p] = (int32_t)(key & 0xffffffffu);
         val_out[p] = s;
-        atomicAdd(&row_count[(int32_t)(key >> 32) + 1], 1);
+        // an out-of-range row (flagged in `bad` by k_make_keys; the call fails after this kernel) must not be counted:
+        // row_count has n + 1 entries.  Negative rows are huge as unsigned.
+        const uint32_t row = (uint32_t)(key >> 32);
+        if (row < (uint32_t)n) atomicAdd(&row_count[row + 1], 1);
     }
 }
 
@@ -117,7 +120,7 @@ extern "C" int dpcg_coo_to_csr(int64_t n, int64_t nnz, const int32_t *rows, cons
         hipLaunchKernelGGL(k_flag_heads, dim3(grid), dim3(256), 0, s, nnz, keys_sorted, head);
         COO_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, head, pos, (int)nnz, s));
         hipLaunchKernelGGL(k_emit_unique, dim3(grid), dim3(256), 0, s, nnz, keys_sorted, perm_sorted, head, pos, vals,
-                           col_out, val_out, row_count);
+                           col_out, val_out, row_count, n);
         int32_t last_pos = 0, last_head = 0;
         int h_bad = 0;
         COO_HIP(hipMemcpyAsync(&last_pos, pos + nnz - 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));

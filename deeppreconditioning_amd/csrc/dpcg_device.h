@@ -64,8 +64,10 @@ __device__ __forceinline__ void split_range(int total, int v, int &lo, int &hi) 
 //   * the stopping test for iterate k+1 is evaluated by workgroup 0 of K3 (the last kernel of
 //     update k+1), which writes done / k / history / rz_next into the device-resident Scalars;
 //   * K1 (the SpMV, head of the next update) only reads the `done` word an EARLIER kernel wrote and
-//     workgroup 0 rotates rz_next -> rz.  No kernel reads a scalar that the same kernel writes.
-// Once `done` is set every later kernel of the replayed graph returns at once.
+//     workgroup 0 rotates rz_next -> rz; when `done` is set it latches `done_seen` for the K3 of its update.
+//   * K2 and the preconditioner kernels read `done` (written by the K3 of an earlier update); K3 reads `done_seen`.
+// No kernel reads a scalar that the same kernel writes.  Once `done` is set every later kernel of the replayed
+// graph returns at once.
 // ------------------------------------------------------------------------------------------------
 struct IterCtlDev {
     Scalars *scal;
@@ -73,7 +75,10 @@ struct IterCtlDev {
 
 __device__ __forceinline__ bool iteration_head(const IterCtlDev &c) {
     Scalars *sc = c.scal;
-    if (sc->done) return false;
+    if (sc->done) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc->done_seen = 1;    // read by the K3 of this update (a later kernel)
+        return false;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) sc->rz = sc->rz_next;     // <r,z> of the current iterate, cg.py:76
     return true;
 }

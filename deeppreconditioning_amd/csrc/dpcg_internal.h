@@ -53,7 +53,10 @@ struct SpmvPlan {
 };
 
 // Device-resident scalar state of one solve.  Only block 0 of a kernel writes it; everybody else
-// reads values written by an EARLIER kernel, so no intra-kernel hand-off is needed.
+// reads values written by an EARLIER kernel, so no intra-kernel hand-off is needed.  This holds for `done` too:
+// K3 (whose workgroup 0 sets it) never reads it -- it tests `done_seen`, the copy that the head of the same update
+// (K1, an earlier kernel) latched -- so a workgroup of K3 that is dispatched after workgroup 0 has finished cannot
+// skip its slice of x += alpha p (cg.py:79 precedes the test of cg.py:86).
 struct Scalars {
     double rz;         // <r,z> of the current iterate (cg.py:76)
     double rz_next;    // <r,z> of the iterate K3 has just produced; K1 rotates it into rz
@@ -67,7 +70,7 @@ struct Scalars {
     int k;             // completed updates
     int done;          // 1 once the stopping test held (kernels become no-ops)
     int status;        // dpcg_status of the solve
-    int pad;
+    int done_seen;     // `done` as the head (K1) of the current update saw it; what K3 tests (see above)
     // Host-visible progress word (pinned, mapped): (k << 1) | done, written by the one thread that runs
     // the stopping test.  The host steers its run-ahead from it without copies, events or syncs.
     unsigned long long *progress;

@@ -219,7 +219,9 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
         xa = x2[i];
         if (zd) da = zd2[i];
     }
-    if (sc->done) return;                                               // after the first loads, as in K2
+    // `done_seen`, not `done`: workgroup 0 of THIS launch sets `done`, and a workgroup dispatched after that must still
+    // apply x += alpha p for its rows (cg.py:79 precedes the test of cg.py:86).  Read after the first loads, as in K2.
+    if (sc->done_seen) return;
     const double rz_new = reduce_partials(part_rz, n_part, sh);
     const double beta = rz_new / sc->rz;                                // cg.py:82
     const double alpha = sc->alpha;
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalar
         }
         if (zd) da = zd2[i];
     }
-    if (sc->done) return;
+    if (sc->done_seen) return;                                          // see k_update_xp: never `done` here
     const double rz_new = reduce_partials(part_rz, n_part, sh);
     const double beta = rz_new / sc->rz;                                // cg.py:82
     const double alpha = sc->alpha;
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize_init(Scalars *sc, const dou
         sc->atol_sq = atol_sq;
         sc->done = 0;
         sc->status = DPCG_MAX_ITER;
-        sc->pad = 0;
+        sc->done_seen = 0;
         sc->progress = progress;
         record_and_test(sc, tt, rz, hist, hist_cap, 0);                 // cg.py:66-67 and the first cg.py:71
     }

@@ -137,12 +137,20 @@ struct Solve {
     bool fused = false;           // two-kernel updates (x lags one update behind until finish())
     bool defer_x = false;         // three-kernel updates with x brought up to date every second update
     bool many_launches = false;   // an update is dozens of small launches (level-scheduled SpTRSV): always replay a graph
+    bool alternate = false;       // test knob DPCG_DRIVER_ALTERNATE, see enqueue_some
+    unsigned calls = 0;
     std::chrono::steady_clock::time_point t0;
 
     volatile unsigned long long *prog() { return extras()[h].prog_host; }
 
     int enqueue_some() {
-        const bool graph_now = use_graph && (max_iter - enq) >= chunk && (many_launches || !(t_iter > 25e-6));
+        bool graph_now = use_graph && (max_iter - enq) >= chunk && (many_launches || !(t_iter > 25e-6));
+        // DPCG_DRIVER_ALTERNATE (tests): mix single updates and replayed chunks -- 1, 8, 1, 1, 8, ... -- which is what a
+        // per-update time hovering around the 25 us threshold does to the choice above
+        if (alternate) graph_now = graph_now && (calls++ % 3) != 0;
+        // Deferred-x form: the captured chunk reads p_j from h->p for even j, so a replay must start at an even update;
+        // after an odd number of single updates one more single update restores the parity.
+        if (graph_now && defer_x && (enq & 1)) graph_now = false;
         if (graph_now) {
             DPCG_HIP(hipGraphLaunch(h->graph_exec, s));
             enq += chunk;
@@ -183,6 +191,10 @@ struct Solve {
         }
         fused = fuse_eligible(h, flags, x_true);
         defer_x = defer_x_eligible(h, flags, x_true);
+        {
+            const char *e = getenv("DPCG_DRIVER_ALTERNATE");   // read per solve: tests switch it on and off
+            alternate = e && e[0] == '1';
+        }
         if ((fused || defer_x) && !h->p2) {
             DPCG_TRY(dev_alloc(&h->p2, n));
             drop_graph(h);
@@ -432,6 +444,12 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
     if (n_streams > 8) n_streams = 8;
     if (n_streams > count) n_streams = count;
     for (int i = 0; i < count; ++i) DPCG_TRY(check_solve_args(handles[i], b[i], max_iter, flags, nullptr, nullptr));
+    {   // a handle owns ONE set of work vectors: the same handle twice would share them across streams
+        std::vector<dpcg_handle_t> sorted(handles, handles + count);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+            return invalid("dpcg_solve_batch: the handles must be distinct (create one handle per system in flight)");
+    }
     bool all_small = true;
     for (int i = 0; i < count; ++i) all_small = all_small && small_eligible(handles[i], flags, nullptr);
     if (all_small) {
