@@ -381,7 +381,27 @@ def extra_workloads(D, poisson, torch) -> dict:
     ms = s4.spmv_dot_bench(50)
     gbs = loop_kernel_bytes(s4) / (ms * 1e-3) / 1e9
     out["c4_poisson3d_256_jacobi"] = {"iterations": r.iterations, "iterations_per_s": round(r.iterations / r.seconds, 2),
-                                      "spmv_gbs": round(gbs, 1), "spmv_frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+                                      "spmv_gbs": round(gbs, 1), "spmv_frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                                      "spmv_us_per_launch": round(ms * 1e3, 1)}
+    s4.close()
+    del s4, b4
+    # config 4 as ONE GPU sees it: its 8 of the 64 systems (s mod 8 == rank), full solves at the reference defaults,
+    # through the batch path the multi-GPU driver uses -- one after another and four in flight
+    from deeppreconditioning_amd.batch import SystemSpec, shard, solve_specs_local
+    specs = [SystemSpec(3, 256, sid) for sid in shard(64, 0, 8)]
+    share = {}
+    for conc in (1, 4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        recs = solve_specs_local(specs, concurrent=conc)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        share[f"concurrent_{conc}"] = {"iterations_total": int(recs[:, 0].sum()), "all_converged": bool((recs[:, 1] == 0).all()),
+                                       "wall_s_incl_generation_and_setup": round(dt, 3),
+                                       "iterations_per_s_solve_time_only": round(float(recs[:, 0].sum() / (recs[:, 3].sum() / conc)), 1),
+                                       "iterations_per_s_wall": round(float(recs[:, 0].sum() / dt), 1)}
+    share["iterations_per_system"] = [int(v) for v in recs[:, 0]]
+    out["c4_one_gpu_share_8x_poisson3d_256"] = share
     return out
 
 

@@ -148,3 +148,121 @@ def solve_specs_distributed(specs: list[SystemSpec] | None, local_solver=None, *
         idx = shard(count, r, world)
         out[idx] = gathered[r].cpu().numpy()[: len(idx)]
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Real matrices (the f3 loaders: every OpenFOAM / StAn system comes from a file on rank 0): scatter of the CSR arrays
+# and right-hand sides to their owners, optional gather of the solutions.
+# ------------------------------------------------------------------------------------------------------------------
+def _default_local_solver(items, *, precond: str = "jacobi", rtol_sq: float = 1e-8, atol_sq: float = 0.0, max_iter: int = 1024,
+                          flags: int = 0, reorder: str | None = None):
+    """Solve this rank's share one system after another on its GPU.  items: (rowptr, col, val, b) CUDA tensors.
+    Returns (records (k, 4) = [iterations, status, final_res, seconds], [x tensors])."""
+    from .operators import IC0, Jacobi
+    recs = np.zeros((len(items), 4), dtype=np.float64)
+    xs = []
+    for i, (rp, ci, v, b) in enumerate(items):
+        S = CsrSystem.from_any((rp, ci, v), reorder=reorder)
+        S.set_preconditioner(Jacobi() if precond == "jacobi" else (IC0("solve") if precond == "ic0" else None))
+        r = S.solve(b, rtol_sq=rtol_sq, atol_sq=atol_sq, max_iter=max_iter, flags=flags, want_history=False)
+        recs[i] = (r.iterations, r.status, r.final_res, r.seconds)
+        xs.append(r.x)
+        S.close()
+    return recs, xs
+
+
+def solve_systems_distributed(systems, *, gather_x: bool = False, local_solver=None, **kw):
+    """All ranks call this; rank 0 passes `systems` = [(rowptr int32, col int32, val fp64, b fp64), ...] as numpy
+    arrays or torch tensors (what `io.load_case` / `coo_to_csr_device` return), the others None.
+
+    scatter: a size table (n, nnz per system) is broadcast; then, in rounds of one system per peer, rank 0 posts
+    the four arrays of every peer's next system as ONE group of point-to-point sends (`batch_isend_irecv`: on the
+    nccl backend a ncclGroupStart / ncclSend x 4 per peer / ncclGroupEnd, i.e. one xGMI link per peer, all peers
+    at once) while each peer posts the matching receives into its own HBM.  Rank 0 keeps its own systems.
+    solve: rank r owns systems r, r + world, ... and solves them with no communication.
+    gather: fixed-size records are all-gathered; with `gather_x` every owner sends its solutions back to rank 0
+    (same grouped point-to-point form).  Returns the (count, 4) record table on every rank -- and, on rank 0 with
+    `gather_x`, `(table, [x_0, ..., x_{count-1}])` in batch order.
+    `local_solver(items, **kw) -> (records, xs)` defaults to solving on this rank's GPU (tests inject a stand-in to
+    run the exchange on CPU / gloo)."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    nccl = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    solver = local_solver or _default_local_solver
+
+    def to_dev(a, dtype):
+        t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+        return t.to(device=dev, dtype=dtype).contiguous()
+
+    meta = torch.zeros(1, dtype=torch.int64, device=dev)
+    if rank == 0:
+        meta[0] = len(systems)
+    dist.broadcast(meta, 0)
+    count = int(meta.item())
+    sizes = torch.zeros((count, 2), dtype=torch.int64, device=dev)
+    if rank == 0 and count:
+        sizes.copy_(torch.tensor([[len(s[0]) - 1, len(s[1])] for s in systems], dtype=torch.int64))
+    dist.broadcast(sizes, 0)
+    sizes_h = sizes.cpu().numpy()
+    dtypes = (torch.int32, torch.int32, torch.float64, torch.float64)
+
+    def shapes(s):
+        n, nnz = int(sizes_h[s, 0]), int(sizes_h[s, 1])
+        return (n + 1, nnz, nnz, n)
+
+    mine: dict[int, tuple] = {}
+    for base in range(0, count, world):                         # one round = one system per rank
+        ops, staged = [], []
+        for s in range(base, min(base + world, count)):
+            owner = s % world
+            if rank == 0:
+                parts = tuple(to_dev(a, dt) for a, dt in zip(systems[s], dtypes))
+                if owner == 0:
+                    mine[s] = parts
+                else:
+                    staged.append(parts)                        # keep alive until the sends have completed
+                    ops += [dist.P2POp(dist.isend, t, owner) for t in parts]
+            elif owner == rank:
+                parts = tuple(torch.empty(m, dtype=dt, device=dev) for m, dt in zip(shapes(s), dtypes))
+                mine[s] = parts
+                ops += [dist.P2POp(dist.irecv, t, 0) for t in parts]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        del staged
+    order = shard(count, rank, world)
+    recs, xs = solver([mine[s] for s in order], **kw)
+    del mine
+    per_rank = (count + world - 1) // world
+    buf = torch.full((max(per_rank, 1), 4), -1.0, dtype=torch.float64, device=dev)
+    if len(order):
+        buf[: len(order)] = torch.from_numpy(np.asarray(recs, dtype=np.float64).reshape(-1, 4)).to(dev)
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf)
+    table = np.zeros((count, 4), dtype=np.float64)
+    for r in range(world):
+        idx = shard(count, r, world)
+        table[idx] = gathered[r].cpu().numpy()[: len(idx)]
+    if not gather_x:
+        return table
+    out_x: list = [None] * count
+    for base in range(0, count, world):
+        ops, keep = [], []
+        for s in range(base, min(base + world, count)):
+            owner = s % world
+            if owner == 0:
+                if rank == 0:
+                    out_x[s] = xs[order.index(s)]
+            elif rank == owner:
+                t = xs[order.index(s)].to(device=dev, dtype=torch.float64).contiguous()
+                keep.append(t)
+                ops.append(dist.P2POp(dist.isend, t, 0))
+            elif rank == 0:
+                out_x[s] = torch.empty(int(sizes_h[s, 0]), dtype=torch.float64, device=dev)
+                ops.append(dist.P2POp(dist.irecv, out_x[s], owner))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        del keep
+    return (table, out_x) if rank == 0 else table

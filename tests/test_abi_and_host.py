@@ -18,6 +18,7 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 import deeppreconditioning_amd as D  # noqa: E402
 from deeppreconditioning_amd import _lib, batch, operators  # noqa: E402
+from oracle import oracle as O  # noqa: E402  (test input generator)
 
 
 def test_every_declared_symbol_is_exported_and_bound():
@@ -180,3 +181,61 @@ def test_distributed_scatter_shard_gather_gloo_world2(count):
     expect = _fake_local_solver([batch.SystemSpec(2 + (i % 2), 10 + i, i) for i in range(count)])
     for rank in (0, 1):  # every rank holds the full table in batch order
         np.testing.assert_array_equal(results[rank], expect)
+
+
+# ---- the same for REAL matrices: the CSR arrays and right-hand sides travel, the solutions come back -------------
+def _fake_matrix_solver(items, **kw):
+    """Stand-in for the GPU solve: x = A b computed from the arrays AS RECEIVED, so a corrupted or misrouted matrix shows
+    up in the gathered solutions; record = [n, nnz, sum(val), sum(b)]."""
+    recs, xs = [], []
+    for rp, ci, v, b in items:
+        A = sp.csr_matrix((v.numpy(), ci.numpy(), rp.numpy()), shape=(len(rp) - 1,) * 2)
+        xs.append(torch.from_numpy(A @ b.numpy()))
+        recs.append([A.shape[0], A.nnz, float(v.numpy().sum()), float(b.numpy().sum())])
+    return np.array(recs, dtype=np.float64).reshape(-1, 4), xs
+
+
+def _real_systems(count):
+    out = []
+    for i in range(count):
+        A = O.unstructured_like(O.poisson2d(5 + i), seed=i) if i % 2 else O.poisson2d(5 + i)
+        out.append((A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy(), O.rhs(A.shape[0], i)))
+    return out
+
+
+def _worker_real(rank, world, port, count, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    systems = _real_systems(count) if rank == 0 else None
+    out = batch.solve_systems_distributed(systems, gather_x=True, local_solver=_fake_matrix_solver)
+    if rank == 0:
+        table, xs = out
+        q.put((rank, table, [x.numpy() for x in xs]))
+    else:
+        q.put((rank, out, None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("count", [1, 5])
+def test_distributed_real_matrix_scatter_and_x_gather_gloo_world2(count):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_real, args=(r, 2, port, count, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {r: (t, x) for r, t, x in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    systems = _real_systems(count)
+    expect = np.array([[len(rp) - 1, len(ci), v.sum(), b.sum()] for rp, ci, v, b in systems])
+    np.testing.assert_array_equal(results[0][0], expect)            # records in batch order on every rank
+    np.testing.assert_array_equal(results[1][0], expect)
+    for (rp, ci, v, b), x in zip(systems, results[0][1]):           # x of every system is back on rank 0, bit for bit
+        A = sp.csr_matrix((v, ci, rp), shape=(len(rp) - 1,) * 2)
+        np.testing.assert_array_equal(x, A @ b)

@@ -1049,3 +1049,60 @@ def test_replayed_chunks_start_at_even_updates(D, monkeypatch, extra_flags):
     monkeypatch.delenv("DPCG_DRIVER_ALTERNATE")
     assert torch.equal(S.solve(b, flags=flags).x, S.solve(b, flags=flags | D._lib.NO_GRAPH).x)
     S.close()
+
+
+# ---- round 2: BASELINE config 4 as one GPU sees it, and the RCCL path ----------------------------------------------
+def test_config4_one_gpu_share_eight_256cubed_systems(D):
+    """Config 4 gives every GPU 8 of the 64 independent 256^3 systems (16.8M DoF, 117M non-zeros each; system s ->
+    rank s mod 8).  One rank's share through `batch.solve_specs_local`, one after another and four in flight:
+    full solves at the reference defaults, distinct right-hand sides, the same iteration counts and final residuals
+    bit for bit in both forms, every system converged."""
+    from deeppreconditioning_amd.batch import SystemSpec, shard, solve_specs_local
+    ids = shard(64, 3, 8)                                            # rank 3's systems: 3, 11, ..., 59
+    specs = [SystemSpec(3, 256, s) for s in ids]
+    seq = solve_specs_local(specs, concurrent=1)
+    par = solve_specs_local(specs, concurrent=4)
+    assert np.array_equal(seq[:, :3], par[:, :3])                    # iterations, status, final residual
+    assert (seq[:, 1] == 0).all() and (seq[:, 2] < 1e-8).all() and (seq[:, 0] < 1024).all()
+    assert len(set(seq[:, 2])) == len(ids)                           # distinct b per system
+    assert seq[:, 0].max() - seq[:, 0].min() <= 0.05 * seq[:, 0].max()
+    # the recurrence residual of one of them is the true residual
+    from deeppreconditioning_amd import poisson
+    S = poisson.poisson_system(3, 256)
+    S.set_preconditioner(D.Jacobi())
+    b = poisson.rhs(S.n, ids[0])
+    r = S.solve(b, want_history=False)
+    assert r.iterations == int(seq[0, 0]) and r.final_res == seq[0, 2]
+    t = b - S @ r.x
+    assert abs(D.dot(t, t) / D.dot(b, b) / r.final_res - 1.0) < 1e-3
+    S.close()
+
+
+def test_nccl_world1_runs_the_scatter_and_gather_on_rccl():
+    """`solve_specs_distributed` / `solve_systems_distributed` under the "nccl" backend (RCCL) with one rank, in a fresh
+    child process: broadcast, grouped point-to-point and all_gather run on RCCL, the tables and the gathered x agree
+    with direct solves and the C oracle."""
+    import json
+    import pathlib
+    import socket
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {**__import__("os").environ, "PYTHONPATH": str(root), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
+           "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
+    proc = subprocess.run([sys.executable, str(root / "tests" / "nccl_world1_child.py")], capture_output=True, text=True,
+                          cwd=root, env=env, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    out = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["backend"] == "nccl" and out["world"] == 1
+    spec_its = [int(r[0]) for r in out["spec_table"]]
+    assert spec_its[0] == 129 and spec_its[2] == 463                 # the golden counts of poisson2d 64 / 256, seed 0 ...
+    A = O.poisson3d(16)
+    assert spec_its[1] == CO.pcg(A, O.rhs(A.shape[0], 1), "jacobi", dinv=O.jacobi_dinv(A))[1]
+    mats = [O.poisson2d(40), O.unstructured_like(O.poisson3d(12), seed=1), O.poisson2d(90)]
+    for i, (A, rec) in enumerate(zip(mats, out["real_table"])):
+        assert int(rec[0]) == CO.pcg(A, O.rhs(A.shape[0], i), "jacobi", dinv=O.jacobi_dinv(A))[1] and int(rec[1]) == 0
+    assert out["x_equal_to_direct_solve"] == [True, True, True]
