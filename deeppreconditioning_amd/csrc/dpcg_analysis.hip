@@ -1,0 +1,341 @@
+// Structural analysis of triangular factors on the device (setup of LLT_SOLVE / IC(0)): validation, transpose, level
+// sets, level-ordered copies, LDS-ring records.  Integer work on data that already lives in HBM -- a factor that comes
+// "straight from the CNN" (dpcg_set_precond_llt with DEVICE pointers) never crosses PCIe.  Sort / scan come from
+// dpcg_prims.h; everything else is a plain kernel.
+#include "dpcg_device.h"
+
+namespace dpcg {
+
+namespace {
+inline int grid_rows(int64_t n, int cap = 8192) {
+    int64_t g = (n + kBlock - 1) / kBlock;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// validation: lower triangular, columns ascending, diagonal stored last and positive
+// flags[0]: bit 0 structure, bit 1 pivot
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_check_lower(int64_t n, const int32_t *__restrict__ rp,
+                                                        const int32_t *__restrict__ ci, const double *__restrict__ v,
+                                                        int *flags) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const int a = rp[i], b = rp[i + 1];
+        if (b <= a || ci[b - 1] != i) {
+            bad |= 1;
+            continue;
+        }
+        for (int k = a; k < b - 1; ++k)
+            if (ci[k] >= ci[k + 1] || ci[k] < 0) bad |= 1;
+        if (!(v[b - 1] > 0.0)) bad |= 2;
+    }
+    if (bad) atomicOr(flags, bad);
+}
+
+void launch_check_lower(const CsrDev &L, int *flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_check_lower, dim3(grid_rows(L.n)), dim3(kBlock), 0, s, L.n, L.rowptr, L.col, L.val, flags);
+}
+
+// ------------------------------------------------------------------------------------------------
+// transpose pieces
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_row_of(int64_t n, const int32_t *__restrict__ rp, int32_t *__restrict__ row_of) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        for (int k = rp[i]; k < rp[i + 1]; ++k) row_of[k] = (int32_t)i;
+}
+
+void launch_row_of(int64_t n, const int32_t *rp, int32_t *row_of, hipStream_t s) {
+    hipLaunchKernelGGL(k_row_of, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rp, row_of);
+}
+
+__global__ __launch_bounds__(kBlock) void k_iota(int64_t count, int32_t *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < count; k += stride) out[k] = (int32_t)k;
+}
+
+void launch_iota(int64_t count, int32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_iota, dim3(grid_rows(count)), dim3(kBlock), 0, s, count, out);
+}
+
+// Offsets of the groups of a SORTED key array: ptr[g] = first position with key >= g, for g = 0..groups (ptr[groups] =
+// count).  Empty groups get the offset of the next non-empty one.
+__global__ __launch_bounds__(kBlock) void k_group_offsets(int64_t count, const uint32_t *__restrict__ keys, int groups,
+                                                          int32_t *__restrict__ ptr) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k <= count; k += stride) {
+        const int64_t lo = k == 0 ? 0 : (int64_t)keys[k - 1] + 1;
+        const int64_t hi = k == count ? groups : (int64_t)keys[k];
+        for (int64_t g = lo; g <= hi; ++g) ptr[g] = (int32_t)k;
+    }
+}
+
+void launch_group_offsets(int64_t count, const uint32_t *keys_sorted, int groups, int32_t *ptr, hipStream_t s) {
+    hipLaunchKernelGGL(k_group_offsets, dim3(grid_rows(count + 1)), dim3(kBlock), 0, s, count, keys_sorted, groups, ptr);
+}
+
+// Entries of the transposed matrix from the sort permutation: tcol[d] = row_of[perm[d]], tval[d] = val[perm[d]].
+__global__ __launch_bounds__(kBlock) void k_transpose_gather(int64_t nnz, const int32_t *__restrict__ perm,
+                                                             const int32_t *__restrict__ row_of,
+                                                             const double *__restrict__ val, int32_t *__restrict__ tcol,
+                                                             double *__restrict__ tval) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t d = (int64_t)blockIdx.x * kBlock + threadIdx.x; d < nnz; d += stride) {
+        const int32_t k = perm[d];
+        tcol[d] = row_of[k];
+        tval[d] = val[k];
+    }
+}
+
+void launch_transpose_gather(int64_t nnz, const int32_t *perm, const int32_t *row_of, const double *val, int32_t *tcol,
+                             double *tval, hipStream_t s) {
+    hipLaunchKernelGGL(k_transpose_gather, dim3(grid_rows(nnz)), dim3(kBlock), 0, s, nnz, perm, row_of, val, tcol, tval);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Level sets: level(i) = 1 + max level of the rows i depends on (0 without dependencies).
+// ONE launch, no host round trip: a thread owns a row and polls the levels of its dependencies until they have been
+// written (level[] starts at -1); values travel as 4-byte agent-scope accesses, flag and payload in one word.  Rows are
+// handed out in dependency-compatible order -- ascending for a lower factor, descending for an upper one -- through a
+// ticket counter, so every row a workgroup waits for belongs to a workgroup that has already started: no deadlock
+// whatever the dispatch order.  The store sits inside the poll loop because lanes of one wave may depend on each other.
+// ------------------------------------------------------------------------------------------------
+template <bool UPPER>
+__global__ __launch_bounds__(kBlock) void k_levels_syncfree(int64_t n, const int32_t *__restrict__ rp,
+                                                            const int32_t *__restrict__ ci, int32_t *level,
+                                                            unsigned int *ticket, int *err) {
+    __shared__ unsigned int s_lb;
+    if (threadIdx.x == 0) s_lb = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int64_t idx = (int64_t)s_lb * kBlock + threadIdx.x;
+    if (idx >= n) return;
+    const int64_t i = UPPER ? n - 1 - idx : idx;
+    const int s = rp[i], e = rp[i + 1];
+    int k = UPPER ? s + 1 : s;                       // the diagonal is first (upper) or last (lower)
+    const int ke = UPPER ? e : e - 1;
+    int lvl = 0;
+    int c = k < ke ? ci[k] : 0;
+    unsigned spins = 0;
+    bool stored = false;
+    while (!stored) {
+        if (k < ke) {
+            const int l = __hip_atomic_load(level + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (l >= 0) {
+                lvl = l + 1 > lvl ? l + 1 : lvl;
+                ++k;
+                if (k < ke) c = ci[k];
+                spins = 0;
+            } else if (++spins > (1u << 24)) {       // bounded: a malformed factor must not hang the device
+                atomicExch(err, 1);
+                k = ke;
+            } else {
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (k >= ke) {
+            __hip_atomic_store(level + i, lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stored = true;
+        }
+    }
+}
+
+void launch_levels_syncfree(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int32_t *level,
+                            unsigned int *ticket_zeroed, int *err, hipStream_t s) {
+    const int grid = (int)((n + kBlock - 1) / kBlock);
+    if (upper)
+        hipLaunchKernelGGL(k_levels_syncfree<true>, dim3(grid), dim3(kBlock), 0, s, n, rp, ci, level, ticket_zeroed, err);
+    else
+        hipLaunchKernelGGL(k_levels_syncfree<false>, dim3(grid), dim3(kBlock), 0, s, n, rp, ci, level, ticket_zeroed, err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// level-ordered copy of the factor: row j of the copy = original row rows[j]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_lo_lengths(int64_t n, const int32_t *__restrict__ rows,
+                                                       const int32_t *__restrict__ rp, int32_t *__restrict__ len,
+                                                       int32_t *__restrict__ pos) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j <= n; j += stride) {
+        if (j == n) {
+            len[j] = 0;
+            continue;
+        }
+        const int i = rows[j];
+        len[j] = rp[i + 1] - rp[i];
+        pos[i] = (int32_t)j;                          // level-order position of original row i
+    }
+}
+
+void launch_lo_lengths(int64_t n, const int32_t *rows, const int32_t *rp, int32_t *len, int32_t *pos, hipStream_t s) {
+    hipLaunchKernelGGL(k_lo_lengths, dim3(grid_rows(n + 1)), dim3(kBlock), 0, s, n, rows, rp, len, pos);
+}
+
+__global__ __launch_bounds__(kBlock) void k_lo_copy(int64_t n, const int32_t *__restrict__ rows,
+                                                    const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                    const double *__restrict__ v, const int32_t *__restrict__ pos,
+                                                    const int32_t *__restrict__ lo_rp, int32_t *__restrict__ lo_ci,
+                                                    int32_t *__restrict__ lo_cp, double *__restrict__ lo_v) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        const int i = rows[j];
+        const int src = rp[i], len = rp[i + 1] - src, dst = lo_rp[j];
+        for (int k = 0; k < len; ++k) {
+            const int c = ci[src + k];
+            lo_ci[dst + k] = c;
+            lo_cp[dst + k] = pos[c];
+            lo_v[dst + k] = v[src + k];
+        }
+    }
+}
+
+void launch_lo_copy(int64_t n, const int32_t *rows, const int32_t *rp, const int32_t *ci, const double *v,
+                    const int32_t *pos, const int32_t *lo_rp, int32_t *lo_ci, int32_t *lo_cp, double *lo_v,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(k_lo_copy, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows, rp, ci, v, pos, lo_rp, lo_ci, lo_cp,
+                       lo_v);
+}
+
+// Does every 256-row block of every level fit the LDS product buffer of the stream kernels?  *flag = 1 if not.
+__global__ __launch_bounds__(kBlock) void k_stream_fit(int64_t n, const uint32_t *__restrict__ lvl_of_pos,
+                                                       const int32_t *__restrict__ level_ptr,
+                                                       const int32_t *__restrict__ lo_rp, int *flag) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        const int l = (int)lvl_of_pos[j];
+        const int lo = level_ptr[l], hi = level_ptr[l + 1];
+        if (((int)j - lo) % kStreamRows != 0) continue;
+        const int je = (int)j + kStreamRows < hi ? (int)j + kStreamRows : hi;
+        if (lo_rp[je] - lo_rp[j] > kStreamCap) atomicExch(flag, 1);
+    }
+}
+
+void launch_stream_fit(int64_t n, const uint32_t *lvl_of_pos, const int32_t *level_ptr, const int32_t *lo_rp, int *flag,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_stream_fit, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, lvl_of_pos, level_ptr, lo_rp, flag);
+}
+
+// For the rows of merged segments: how far back (in level order, within the segment) does a row reach?
+// seg_of_level[l] = index of the merged segment level l belongs to, or -1; maxdist[seg] receives the maximum.
+__global__ __launch_bounds__(kBlock) void k_ring_reach(int64_t n, const uint32_t *__restrict__ lvl_of_pos,
+                                                       const int32_t *__restrict__ seg_of_level,
+                                                       const int32_t *__restrict__ seg_start,
+                                                       const int32_t *__restrict__ lo_rp,
+                                                       const int32_t *__restrict__ lo_cp, int32_t *maxdist) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        const int sg = seg_of_level[lvl_of_pos[j]];
+        if (sg < 0) continue;
+        const int start = seg_start[sg];
+        int d = 0;
+        for (int k = lo_rp[j]; k < lo_rp[j + 1]; ++k) {
+            const int cp = lo_cp[k];
+            if (cp >= start && cp < j) d = (int)j - cp > d ? (int)j - cp : d;
+        }
+        if (d > 0) atomicMax(maxdist + sg, d);
+    }
+}
+
+void launch_ring_reach(int64_t n, const uint32_t *lvl_of_pos, const int32_t *seg_of_level, const int32_t *seg_start,
+                       const int32_t *lo_rp, const int32_t *lo_cp, int32_t *maxdist, hipStream_t s) {
+    hipLaunchKernelGGL(k_ring_reach, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, lvl_of_pos, seg_of_level, seg_start, lo_rp,
+                       lo_cp, maxdist);
+}
+
+// Fixed-width records of the rows of LDS-ring segments (Levels::pk_meta / pk_val).  ring_start_of_level[l] = first
+// level-order position of the ring segment level l belongs to, or -1 when the level is not in one.
+__global__ __launch_bounds__(kBlock) void k_ring_records(int64_t n, const uint32_t *__restrict__ lvl_of_pos,
+                                                         const int32_t *__restrict__ ring_start_of_level,
+                                                         const int32_t *__restrict__ rows,
+                                                         const int32_t *__restrict__ lo_rp,
+                                                         const int32_t *__restrict__ lo_ci,
+                                                         const int32_t *__restrict__ lo_cp,
+                                                         const double *__restrict__ lo_v, int32_t *__restrict__ meta,
+                                                         double *__restrict__ pv) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        int m[4] = {-1, -1, -1, -1};
+        double w[4] = {0.0, 0.0, 0.0, 0.0};
+        const int start = ring_start_of_level[lvl_of_pos[j]];
+        if (start >= 0) {
+            const int a = lo_rp[j], b = lo_rp[j + 1], row = rows[j];
+            // the diagonal is the first entry of a row of L^T and the last of a row of L
+            const bool diag_first = lo_ci[a] == row && (b - a == 1 || lo_ci[b - 1] != row);
+            const int ks = diag_first ? a + 1 : a, ke = diag_first ? b : b - 1;
+            m[3] = row;
+            w[3] = lo_v[diag_first ? a : b - 1];
+            bool fast = ke - ks <= 3;
+            for (int k = ks; k < ke && fast; ++k) fast = lo_cp[k] >= start;
+            if (!fast) {
+                m[0] = -2;
+            } else {
+                for (int k = ks; k < ke; ++k) {
+                    m[k - ks] = lo_cp[k];
+                    w[k - ks] = lo_v[k];
+                }
+            }
+        }
+        reinterpret_cast<int4 *>(meta)[j] = make_int4(m[0], m[1], m[2], m[3]);
+        reinterpret_cast<double2 *>(pv)[2 * j] = make_double2(w[0], w[1]);
+        reinterpret_cast<double2 *>(pv)[2 * j + 1] = make_double2(w[2], w[3]);
+    }
+}
+
+void launch_ring_records(int64_t n, const uint32_t *lvl_of_pos, const int32_t *ring_start_of_level, const int32_t *rows,
+                         const int32_t *lo_rp, const int32_t *lo_ci, const int32_t *lo_cp, const double *lo_v,
+                         int32_t *meta, double *pv, hipStream_t s) {
+    hipLaunchKernelGGL(k_ring_records, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, lvl_of_pos, ring_start_of_level, rows,
+                       lo_rp, lo_ci, lo_cp, lo_v, meta, pv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tril(A) for IC(0): count, then copy, entries with col <= row; *flag = 1 when a row's last kept entry is not its diagonal
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_tril_count(int64_t n, const int32_t *__restrict__ rp,
+                                                       const int32_t *__restrict__ ci, int32_t *__restrict__ cnt,
+                                                       int *flag) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= n; i += stride) {
+        if (i == n) {
+            cnt[i] = 0;
+            continue;
+        }
+        int c = 0, last = -1;
+        for (int k = rp[i]; k < rp[i + 1]; ++k)
+            if (ci[k] <= i) {
+                ++c;
+                last = ci[k];
+            }
+        cnt[i] = c;
+        if (last != i) atomicExch(flag, 1);
+    }
+}
+
+void launch_tril_count(int64_t n, const int32_t *rp, const int32_t *ci, int32_t *cnt, int *flag, hipStream_t s) {
+    hipLaunchKernelGGL(k_tril_count, dim3(grid_rows(n + 1)), dim3(kBlock), 0, s, n, rp, ci, cnt, flag);
+}
+
+__global__ __launch_bounds__(kBlock) void k_tril_copy(int64_t n, const int32_t *__restrict__ rp,
+                                                      const int32_t *__restrict__ ci, const double *__restrict__ v,
+                                                      const int32_t *__restrict__ lrp, int32_t *__restrict__ lci,
+                                                      double *__restrict__ lv) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        int d = lrp[i];
+        for (int k = rp[i]; k < rp[i + 1]; ++k)
+            if (ci[k] <= i) {
+                lci[d] = ci[k];
+                lv[d] = v[k];
+                ++d;
+            }
+    }
+}
+
+void launch_tril_copy(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, const int32_t *lrp, int32_t *lci,
+                      double *lv, hipStream_t s) {
+    hipLaunchKernelGGL(k_tril_copy, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rp, ci, v, lrp, lci, lv);
+}
+
+}  // namespace dpcg

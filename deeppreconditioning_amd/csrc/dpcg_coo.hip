@@ -1,9 +1,10 @@
 // COO -> CSR on the device: the on-disk formats of the reference are coordinate triplets
 // (scipy COO npz, generate_data.py:109; OpenFOAM `i,j,value` dump, pEqn.H:98-108; StAn npz, data_set.py:186-188).
 // Sort by (row, col) with a stable radix sort, add up duplicates in storage order, emit int32 CSR.
-#include <hipcub/hipcub.hpp>
+#include <algorithm>
 
 #include "dpcg_internal.h"
+#include "dpcg_prims.h"
 
 using namespace dpcg;
 
@@ -74,11 +75,10 @@ extern "C" int dpcg_coo_to_csr(int64_t n, int64_t nnz, const int32_t *rows, cons
     uint64_t *keys = nullptr, *keys_sorted = nullptr;
     int32_t *perm = nullptr, *perm_sorted = nullptr, *head = nullptr, *pos = nullptr, *row_count = nullptr;
     int *bad = nullptr;
-    void *tmp = nullptr;
     int st = DPCG_OK;
     auto cleanup = [&]() {
         for (void *p : {(void *)keys, (void *)keys_sorted, (void *)perm, (void *)perm_sorted, (void *)head, (void *)pos,
-                        (void *)row_count, (void *)bad, tmp})
+                        (void *)row_count, (void *)bad})
             if (p) (void)hipFree(p);
     };
 #define COO_TRY(expr)            \
@@ -111,14 +111,10 @@ extern "C" int dpcg_coo_to_csr(int64_t n, int64_t nnz, const int32_t *rows, cons
     if (nnz > 0) {
         const int grid = (int)std::min<int64_t>((nnz + 255) / 256, 4096);
         hipLaunchKernelGGL(k_make_keys, dim3(grid), dim3(256), 0, s, nnz, rows, cols, keys, perm, n, bad);
-        size_t tmp_bytes = 0, tmp2 = 0;
-        COO_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_sorted, perm, perm_sorted, (int)nnz, 0, 64, s));
-        COO_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, head, pos, (int)nnz, s));
-        tmp_bytes = std::max(tmp_bytes, tmp2);
-        COO_HIP(hipMalloc(&tmp, tmp_bytes));
-        COO_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_sorted, perm, perm_sorted, (int)nnz, 0, 64, s));
+        // stable sort by (row, col): duplicates keep their storage order, so their sum is reproducible
+        COO_TRY(sort_pairs_u64_i32(keys, keys_sorted, perm, perm_sorted, nnz, 32 + bits_for((uint64_t)n), s));
         hipLaunchKernelGGL(k_flag_heads, dim3(grid), dim3(256), 0, s, nnz, keys_sorted, head);
-        COO_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, head, pos, (int)nnz, s));
+        COO_TRY(exclusive_scan_i32(head, pos, nnz, s));
         hipLaunchKernelGGL(k_emit_unique, dim3(grid), dim3(256), 0, s, nnz, keys_sorted, perm_sorted, head, pos, vals,
                            col_out, val_out, row_count, n);
         int32_t last_pos = 0, last_head = 0;
@@ -135,16 +131,7 @@ extern "C" int dpcg_coo_to_csr(int64_t n, int64_t nnz, const int32_t *rows, cons
         unique = (int64_t)last_pos + last_head;
     }
     // rowptr = inclusive scan of the per-row counts (row_count[r+1] holds row r)
-    {
-        size_t need = 0;
-        COO_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, need, row_count, rowptr, (int)(n + 1), s));
-        void *t2 = nullptr;
-        COO_HIP(hipMalloc(&t2, need));
-        hipError_t e = hipcub::DeviceScan::InclusiveSum(t2, need, row_count, rowptr, (int)(n + 1), s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        (void)hipFree(t2);
-        COO_HIP(e);
-    }
+    COO_TRY(inclusive_scan_i32(row_count, rowptr, n + 1, s));
     *nnz_out = unique;
     cleanup();
     COO_HIP(hipGetLastError());

@@ -84,3 +84,4 @@ bool fuse_eligible(const dpcg_system *h, int flags, const double *x_true);
 FuseArgs fuse_args(dpcg_system *h);
 // z = M r for the handle's preconditioner (cg.py:61,81); in_loop: kernels return at once when the solve is done
 int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, bool in_loop = false);
+int check_spin_errors(dpcg_system *h, hipStream_t s);

@@ -103,7 +103,9 @@ struct Levels {
     std::vector<int32_t> level_ptr;        // host: offsets into rows, n_levels+1
     // [lo,hi) levels; merged = one workgroup walks them; ring_w > 0: the solution entries the segment's rows depend
     // on lie within the last ring_w level-order positions, so they are handed from level to level through LDS
-    struct Segment { int lo, hi; bool merged; int ring_w; int max_width; };
+    // syncfree: the segment's rows (several levels) are solved by ONE multi-workgroup launch in which a row polls the
+    // entries it depends on until they have been written (k_sptrsv_syncfree); staged: its 256-row blocks fit the LDS
+    struct Segment { int lo, hi; bool merged; int ring_w; int max_width; bool syncfree = false; bool staged = false; };
     std::vector<Segment> segments;
     int32_t *level_ptr_dev = nullptr;      // device copy of level_ptr
     // the factor once more, rows stored in level order (row j of this copy = original row rows[j]): the
@@ -121,6 +123,8 @@ struct Levels {
     int32_t *pk_meta = nullptr;
     double *pk_val = nullptr;
     double *b_lo = nullptr;                // scratch: the right-hand side gathered into level order
+    unsigned long long *tickets = nullptr; // one monotonic block-ticket counter per segment (sync-free segments use theirs)
+    int *spin_err = nullptr;               // set by a sync-free kernel whose bounded poll ran out
 };
 
 }  // namespace dpcg
@@ -251,6 +255,30 @@ int launch_pcg_small(const SmallDesc *descs_dev, int count, int lds_bytes, int k
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
                       hipStream_t s);
 void launch_block_nnz_max(const CsrDev &A, int rows_per_block, int *out_max_dev, hipStream_t s);
+void launch_block_nnz_max_raw(int64_t n, const int32_t *rowptr, int rows_per_block, int *out_max_dev, hipStream_t s);
+// ---- structural analysis of triangular factors on the device (dpcg_analysis.hip) ----
+void launch_check_lower(const CsrDev &L, int *flags, hipStream_t s);
+void launch_row_of(int64_t n, const int32_t *rp, int32_t *row_of, hipStream_t s);
+void launch_iota(int64_t count, int32_t *out, hipStream_t s);
+void launch_group_offsets(int64_t count, const uint32_t *keys_sorted, int groups, int32_t *ptr, hipStream_t s);
+void launch_transpose_gather(int64_t nnz, const int32_t *perm, const int32_t *row_of, const double *val, int32_t *tcol,
+                             double *tval, hipStream_t s);
+void launch_levels_syncfree(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int32_t *level,
+                            unsigned int *ticket_zeroed, int *err, hipStream_t s);
+void launch_lo_lengths(int64_t n, const int32_t *rows, const int32_t *rp, int32_t *len, int32_t *pos, hipStream_t s);
+void launch_lo_copy(int64_t n, const int32_t *rows, const int32_t *rp, const int32_t *ci, const double *v,
+                    const int32_t *pos, const int32_t *lo_rp, int32_t *lo_ci, int32_t *lo_cp, double *lo_v,
+                    hipStream_t s);
+void launch_stream_fit(int64_t n, const uint32_t *lvl_of_pos, const int32_t *level_ptr, const int32_t *lo_rp, int *flag,
+                       hipStream_t s);
+void launch_ring_reach(int64_t n, const uint32_t *lvl_of_pos, const int32_t *seg_of_level, const int32_t *seg_start,
+                       const int32_t *lo_rp, const int32_t *lo_cp, int32_t *maxdist, hipStream_t s);
+void launch_ring_records(int64_t n, const uint32_t *lvl_of_pos, const int32_t *ring_start_of_level, const int32_t *rows,
+                         const int32_t *lo_rp, const int32_t *lo_ci, const int32_t *lo_cp, const double *lo_v,
+                         int32_t *meta, double *pv, hipStream_t s);
+void launch_tril_count(int64_t n, const int32_t *rp, const int32_t *ci, int32_t *cnt, int *flag, hipStream_t s);
+void launch_tril_copy(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, const int32_t *lrp, int32_t *lci,
+                      double *lv, hipStream_t s);
 void launch_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void *val, int val_dtype, hipStream_t s);
 void launch_batched_coo_edge(int64_t nnz, const int32_t *indices, int batch, int64_t dof, const float *a, const float *c,
                              float *out, int transpose, hipStream_t s);

@@ -1,9 +1,12 @@
-// Host side of libdpcg.so, part 2: preconditioner setup -- Jacobi, explicit M, L L^T in multiply or solve mode (transpose,
-// level sets, level-ordered copies, ring-segment records) and IC(0) (symbolic part on the host, numeric on the device).
+// Host side of libdpcg.so, part 2: preconditioner setup -- Jacobi, explicit M, L L^T in multiply or solve mode and
+// IC(0).  The host orchestrates; the analysis itself (transpose, level sets, level-ordered copies, ring-segment
+// records, tril(A), the numeric factorisation) runs on the device.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "dpcg_host.h"
+#include "dpcg_prims.h"
 
 // ------------------------------------------------------------------------------------------------
 // preconditioners
@@ -53,78 +56,98 @@ extern "C" int dpcg_set_precond_csr(dpcg_handle_t h, int64_t nnz, const int32_t 
     return DPCG_OK;
 }
 
-// Level sets of a triangular CSR factor on the host (setup): level(i) = 1 + max level of the rows
-// it depends on.  Rows are then grouped by level; runs of narrow levels become one merged segment.
-static void build_levels_host(int64_t n, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci, bool upper,
-                              std::vector<int32_t> &rows_sorted, std::vector<int32_t> &level_ptr) {
-    std::vector<int32_t> level((size_t)n, 0);
-    int32_t max_level = 0;
-    if (!upper) {
-        for (int64_t i = 0; i < n; ++i) {
-            int32_t l = 0;
-            for (int32_t k = rp[i]; k < rp[i + 1] - 1; ++k) l = std::max(l, level[ci[k]] + 1);
-            level[i] = l;
-            max_level = std::max(max_level, l);
-        }
-    } else {
-        for (int64_t i = n - 1; i >= 0; --i) {
-            int32_t l = 0;
-            for (int32_t k = rp[i] + 1; k < rp[i + 1]; ++k) l = std::max(l, level[ci[k]] + 1);
-            level[i] = l;
-            max_level = std::max(max_level, l);
-        }
-    }
-    const int nl = max_level + 1;
-    level_ptr.assign((size_t)nl + 1, 0);
-    for (int64_t i = 0; i < n; ++i) level_ptr[level[i] + 1]++;
-    for (int l = 0; l < nl; ++l) level_ptr[l + 1] += level_ptr[l];
-    rows_sorted.resize((size_t)n);
-    std::vector<int32_t> cursor(level_ptr.begin(), level_ptr.end() - 1);
-    for (int64_t i = 0; i < n; ++i) rows_sorted[cursor[level[i]]++] = (int32_t)i;
+// ------------------------------------------------------------------------------------------------
+// L L^T preconditioners: the structural analysis (validation, transpose, level sets, level-ordered copies, ring
+// records) runs on the device on data that is already in HBM (dpcg_analysis.hip + dpcg_prims.h); the host only sees
+// the level offsets (one int per level) to plan the launches.
+// ------------------------------------------------------------------------------------------------
+namespace {
+// DPCG_SYNCFREE=0 keeps one launch per wide level (development A/B)
+bool syncfree_enabled() {
+    static const bool on = [] { const char *e = getenv("DPCG_SYNCFREE"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
-static int upload_levels(Levels &lv, const std::vector<int32_t> &rows_sorted, const std::vector<int32_t> &level_ptr,
-                         const int32_t *rp, const int32_t *ci, const double *v, hipStream_t s) {
-    constexpr int kMergeMax = 2048;  // levels this narrow are walked by one 1024-thread workgroup
-    lv.level_ptr = level_ptr;
-    lv.n_levels = (int)level_ptr.size() - 1;
-    // level-ordered copy of the factor (row j = original row rows_sorted[j])
-    const int64_t n = (int64_t)rows_sorted.size();
-    std::vector<int32_t> lo_rp((size_t)n + 1, 0);
-    for (int64_t j = 0; j < n; ++j) lo_rp[j + 1] = lo_rp[j] + (rp[rows_sorted[j] + 1] - rp[rows_sorted[j]]);
-    const int64_t nnz = lo_rp[n];
-    std::vector<int32_t> lo_ci((size_t)nnz);
-    std::vector<double> lo_v((size_t)nnz);
-    for (int64_t j = 0; j < n; ++j) {
-        const int32_t src = rp[rows_sorted[j]], len = rp[rows_sorted[j] + 1] - src, dst = lo_rp[j];
-        std::copy(ci + src, ci + src + len, lo_ci.begin() + dst);
-        std::copy(v + src, v + src + len, lo_v.begin() + dst);
+template <typename T>
+struct DevBuf {                       // scoped device allocation for the setup routines
+    T *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { dev_free(p); }
+    int alloc(int64_t count) { dev_free(p); return dev_alloc(&p, count); }
+    T *release() { T *q = p; p = nullptr; return q; }
+};
+
+// rows sorted by (level, row), the level of every sorted position, the level offsets (device and host)
+struct LevelSort {
+    DevBuf<int32_t> rows;
+    DevBuf<uint32_t> lvl_of_pos;
+    DevBuf<int32_t> level_ptr_dev;
+    std::vector<int32_t> level_ptr;
+};
+
+int compute_levels(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, LevelSort &out, hipStream_t s) {
+    DevBuf<int32_t> level, iota, ctl;
+    DPCG_TRY(level.alloc(n));
+    DPCG_TRY(iota.alloc(n));
+    DPCG_TRY(ctl.alloc(4));                                   // [0] ticket, [1] error flag, [2] max level
+    DPCG_HIP(hipMemsetAsync(level.p, 0xff, (size_t)n * sizeof(int32_t), s));   // -1 = not known yet
+    DPCG_HIP(hipMemsetAsync(ctl.p, 0, 4 * sizeof(int32_t), s));
+    launch_levels_syncfree(n, rp, ci, upper, level.p, reinterpret_cast<unsigned int *>(ctl.p), ctl.p + 1, s);
+    DPCG_CHECK_LAUNCH();
+    DPCG_TRY(reduce_max_i32(level.p, ctl.p + 2, n, s));
+    int32_t h_ctl[4] = {0, 0, 0, 0};
+    DPCG_HIP(hipMemcpyAsync(h_ctl, ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    if (h_ctl[1] || h_ctl[2] < 0) {
+        set_error("level analysis: the factor's dependency graph is not acyclic in row order");
+        return DPCG_ERR_INVALID;
     }
-    lv.stream_ok = true;
-    for (int l = 0; l < lv.n_levels && lv.stream_ok; ++l)
-        for (int32_t jb = level_ptr[l]; jb < level_ptr[l + 1]; jb += kStreamRows) {
-            const int32_t je = std::min<int32_t>(jb + kStreamRows, level_ptr[l + 1]);
-            if (lo_rp[je] - lo_rp[jb] > kStreamCap) { lv.stream_ok = false; break; }
-        }
-    // level-order position of every entry's column
-    std::vector<int32_t> pos((size_t)n), lo_cp((size_t)nnz);
-    for (int64_t j = 0; j < n; ++j) pos[rows_sorted[j]] = (int32_t)j;
-    for (int64_t k = 0; k < nnz; ++k) lo_cp[k] = pos[lo_ci[k]];
+    const int nl = h_ctl[2] + 1;
+    DPCG_TRY(out.rows.alloc(n));
+    DPCG_TRY(out.lvl_of_pos.alloc(n));
+    DPCG_TRY(out.level_ptr_dev.alloc((int64_t)nl + 1));
+    launch_iota(n, iota.p, s);
+    // stable: rows stay ascending inside a level
+    DPCG_TRY(sort_pairs_u32_i32(reinterpret_cast<const uint32_t *>(level.p), out.lvl_of_pos.p, iota.p, out.rows.p, n,
+                                bits_for((uint64_t)h_ctl[2]), s));
+    launch_group_offsets(n, out.lvl_of_pos.p, nl, out.level_ptr_dev.p, s);
+    out.level_ptr.resize((size_t)nl + 1);
+    DPCG_HIP(hipMemcpyAsync(out.level_ptr.data(), out.level_ptr_dev.p, out.level_ptr.size() * sizeof(int32_t),
+                            hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
+// Everything launch_sptrsv needs for one factor (rp/ci/v: the factor in its own row order, device).
+int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_t *rp, const int32_t *ci, const double *v,
+                 hipStream_t s) {
+    constexpr int kMergeMax = 2048;  // levels this narrow are walked by one workgroup
+    lv.level_ptr = ls.level_ptr;
+    lv.n_levels = (int)ls.level_ptr.size() - 1;
+    const std::vector<int32_t> &level_ptr = lv.level_ptr;
+    lv.rows = ls.rows.release();
+    lv.level_ptr_dev = ls.level_ptr_dev.release();
+    // level-ordered copy of the factor (row j = original row rows[j])
+    DevBuf<int32_t> len, pos, flag;
+    DPCG_TRY(len.alloc(n + 1));
+    DPCG_TRY(pos.alloc(n));
+    DPCG_TRY(flag.alloc(1));
     DPCG_TRY(dev_alloc(&lv.lo_rowptr, n + 1));
     DPCG_TRY(dev_alloc(&lv.lo_col, nnz));
     DPCG_TRY(dev_alloc(&lv.lo_cpos, nnz));
     DPCG_TRY(dev_alloc(&lv.lo_val, nnz));
-    DPCG_HIP(hipMemcpyAsync(lv.lo_cpos, lo_cp.data(), lo_cp.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    DPCG_HIP(hipMemcpyAsync(lv.lo_rowptr, lo_rp.data(), lo_rp.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    DPCG_HIP(hipMemcpyAsync(lv.lo_col, lo_ci.data(), lo_ci.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    DPCG_HIP(hipMemcpyAsync(lv.lo_val, lo_v.data(), lo_v.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    DPCG_TRY(dev_alloc(&lv.rows, (int64_t)rows_sorted.size()));
-    DPCG_TRY(dev_alloc(&lv.level_ptr_dev, (int64_t)level_ptr.size()));
-    DPCG_HIP(hipMemcpyAsync(lv.rows, rows_sorted.data(), rows_sorted.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    DPCG_HIP(hipMemcpyAsync(lv.level_ptr_dev, level_ptr.data(), level_ptr.size() * sizeof(int32_t),
-                            hipMemcpyHostToDevice, s));
-    DPCG_HIP(hipStreamSynchronize(s));
+    launch_lo_lengths(n, lv.rows, rp, len.p, pos.p, s);
+    DPCG_TRY(exclusive_scan_i32(len.p, lv.lo_rowptr, n + 1, s));
+    launch_lo_copy(n, lv.rows, rp, ci, v, pos.p, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, s);
+    DPCG_HIP(hipMemsetAsync(flag.p, 0, sizeof(int32_t), s));
+    launch_stream_fit(n, ls.lvl_of_pos.p, lv.level_ptr_dev, lv.lo_rowptr, flag.p, s);
+    // segments: runs of narrow levels are merged (one workgroup walks them), wide levels launch one by one
     lv.segments.clear();
+    std::vector<int32_t> seg_of_level((size_t)lv.n_levels, -1), seg_start;
+    std::vector<int> merged_index;                     // index into lv.segments of merged segment q
     int l = 0;
     while (l < lv.n_levels) {
         const bool narrow = (level_ptr[l + 1] - level_ptr[l]) <= kMergeMax;
@@ -140,101 +163,172 @@ static int upload_levels(Levels &lv, const std::vector<int32_t> &rows_sorted, co
         seg.max_width = 0;
         for (int q = l; q < e; ++q) seg.max_width = std::max<int>(seg.max_width, level_ptr[q + 1] - level_ptr[q]);
         if (seg.merged) {
-            // LDS ring: in level order, how far back do this segment's rows reach (within the segment)?
-            const int32_t seg_start = level_ptr[l];
-            int64_t maxdist = 0, width = 0;
-            for (int q = l; q < e; ++q) width = std::max<int64_t>(width, level_ptr[q + 1] - level_ptr[q]);
-            for (int32_t j = seg_start; j < level_ptr[e]; ++j)
-                for (int32_t k = lo_rp[j]; k < lo_rp[j + 1]; ++k)
-                    if (lo_cp[k] >= seg_start && lo_cp[k] < j) maxdist = std::max<int64_t>(maxdist, j - lo_cp[k]);
-            int64_t w = 64;
-            while (w < maxdist + width + 1) w *= 2;
-            if (w <= 8192) seg.ring_w = (int)w;            // 64 KiB of LDS at most
+            for (int q = l; q < e; ++q) seg_of_level[q] = (int32_t)seg_start.size();
+            seg_start.push_back(level_ptr[l]);
+            merged_index.push_back((int)lv.segments.size());
         }
         lv.segments.push_back(seg);
         l = e;
     }
-    // fixed-width row records for the ring segments (see Levels::pk_meta)
+    int32_t h_flag = 0;
+    DPCG_HIP(hipMemcpyAsync(&h_flag, flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     bool any_ring = false;
-    for (const auto &seg : lv.segments) any_ring = any_ring || seg.ring_w > 0;
-    if (any_ring) {
-        std::vector<int32_t> meta((size_t)n * 4, -1);
-        std::vector<double> pv((size_t)n * 4, 0.0);
-        for (const auto &seg : lv.segments) {
-            if (seg.ring_w <= 0) continue;
-            const int32_t seg_start = level_ptr[seg.lo];
-            for (int32_t j = seg_start; j < level_ptr[seg.hi]; ++j) {
-                const int32_t a = lo_rp[j], b = lo_rp[j + 1], row = rows_sorted[j];
-                // the diagonal is the first entry of a row of L^T and the last of a row of L
-                const bool diag_first = lo_ci[a] == row && (b - a == 1 || lo_ci[b - 1] != row);
-                const int32_t ks = diag_first ? a + 1 : a, ke = diag_first ? b : b - 1;
-                meta[(size_t)j * 4 + 3] = row;
-                pv[(size_t)j * 4 + 3] = lo_v[diag_first ? a : b - 1];
-                bool fast = ke - ks <= 3;
-                for (int32_t k = ks; k < ke && fast; ++k) fast = lo_cp[k] >= seg_start;
-                if (!fast) {
-                    meta[(size_t)j * 4] = -2;
-                    continue;
-                }
-                for (int32_t k = ks; k < ke; ++k) {
-                    meta[(size_t)j * 4 + (k - ks)] = lo_cp[k];
-                    pv[(size_t)j * 4 + (k - ks)] = lo_v[k];
-                }
+    DevBuf<int32_t> d_seg_of_level;
+    if (!seg_start.empty()) {
+        // LDS ring: in level order, how far back do a merged segment's rows reach (within the segment)?
+        DevBuf<int32_t> d_seg_start, d_maxdist;
+        const int64_t nseg = (int64_t)seg_start.size();
+        DPCG_TRY(d_seg_of_level.alloc(lv.n_levels));
+        DPCG_TRY(d_seg_start.alloc(nseg));
+        DPCG_TRY(d_maxdist.alloc(nseg));
+        DPCG_HIP(hipMemcpyAsync(d_seg_of_level.p, seg_of_level.data(), seg_of_level.size() * sizeof(int32_t),
+                                hipMemcpyHostToDevice, s));
+        DPCG_HIP(hipMemcpyAsync(d_seg_start.p, seg_start.data(), seg_start.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        DPCG_HIP(hipMemsetAsync(d_maxdist.p, 0, (size_t)nseg * sizeof(int32_t), s));
+        launch_ring_reach(n, ls.lvl_of_pos.p, d_seg_of_level.p, d_seg_start.p, lv.lo_rowptr, lv.lo_cpos, d_maxdist.p, s);
+        std::vector<int32_t> maxdist((size_t)nseg, 0);
+        DPCG_HIP(hipMemcpyAsync(maxdist.data(), d_maxdist.p, maxdist.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        for (int64_t q = 0; q < nseg; ++q) {
+            Levels::Segment &seg = lv.segments[(size_t)merged_index[(size_t)q]];
+            int64_t w = 64;
+            while (w < (int64_t)maxdist[(size_t)q] + seg.max_width + 1) w *= 2;
+            if (w <= 8192) {                             // 64 KiB of LDS at most
+                seg.ring_w = (int)w;
+                any_ring = true;
             }
         }
+    } else {
+        DPCG_HIP(hipStreamSynchronize(s));
+    }
+    lv.stream_ok = h_flag == 0;
+    // Everything that is not walked through an LDS ring -- wide levels, and narrow runs whose reach is too long for the
+    // ring -- goes to the sync-free multi-workgroup kernel, neighbouring such segments as ONE launch.  A single level on
+    // its own keeps the plain level kernel (nothing inside it to wait for).
+    if (syncfree_enabled()) {
+        std::vector<Levels::Segment> merged_segs;
+        for (const auto &seg : lv.segments) {
+            const bool ring = seg.merged && seg.ring_w > 0;
+            if (!ring && !merged_segs.empty() && merged_segs.back().syncfree) {
+                Levels::Segment &b = merged_segs.back();
+                b.hi = seg.hi;
+                b.max_width = std::max(b.max_width, seg.max_width);
+                continue;
+            }
+            merged_segs.push_back(seg);
+            if (!ring) {
+                merged_segs.back().syncfree = true;
+                merged_segs.back().merged = false;
+            }
+        }
+        for (auto &seg : merged_segs)
+            if (seg.syncfree && seg.hi - seg.lo < 2) seg.syncfree = false;
+        lv.segments.swap(merged_segs);
+    }
+    {
+        const int64_t nseg = (int64_t)lv.segments.size();
+        DPCG_TRY(dev_alloc(&lv.tickets, nseg));
+        DPCG_TRY(dev_alloc(&lv.spin_err, 1));
+        DPCG_HIP(hipMemsetAsync(lv.tickets, 0, (size_t)nseg * sizeof(unsigned long long), s));
+        DPCG_HIP(hipMemsetAsync(lv.spin_err, 0, sizeof(int), s));
+        DevBuf<int32_t> d_max;
+        DPCG_TRY(d_max.alloc(nseg));
+        DPCG_HIP(hipMemsetAsync(d_max.p, 0, (size_t)nseg * sizeof(int32_t), s));
+        bool any = false;
+        for (int64_t q = 0; q < nseg; ++q) {
+            const Levels::Segment &seg = lv.segments[(size_t)q];
+            if (!seg.syncfree) continue;
+            any = true;
+            const int j0 = level_ptr[seg.lo];
+            launch_block_nnz_max_raw(level_ptr[seg.hi] - j0, lv.lo_rowptr + j0, kStreamRows, reinterpret_cast<int *>(d_max.p + q), s);
+        }
+        if (any) {
+            std::vector<int32_t> h_max((size_t)nseg, 0);
+            DPCG_HIP(hipMemcpyAsync(h_max.data(), d_max.p, h_max.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            DPCG_HIP(hipStreamSynchronize(s));
+            for (int64_t q = 0; q < nseg; ++q) lv.segments[(size_t)q].staged = h_max[(size_t)q] <= kStreamCap;
+        }
+    }
+    if (any_ring) {                                      // fixed-width row records (see Levels::pk_meta)
+        std::vector<int32_t> ring_start((size_t)lv.n_levels, -1);
+        for (const auto &seg : lv.segments)
+            if (seg.ring_w > 0)
+                for (int q = seg.lo; q < seg.hi; ++q) ring_start[(size_t)q] = level_ptr[seg.lo];
+        DPCG_HIP(hipMemcpyAsync(d_seg_of_level.p, ring_start.data(), ring_start.size() * sizeof(int32_t),
+                                hipMemcpyHostToDevice, s));
         DPCG_TRY(dev_alloc(&lv.pk_meta, n * 4));
         DPCG_TRY(dev_alloc(&lv.pk_val, n * 4));
         DPCG_TRY(dev_alloc(&lv.b_lo, n));
-        DPCG_HIP(hipMemcpyAsync(lv.pk_meta, meta.data(), meta.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        DPCG_HIP(hipMemcpyAsync(lv.pk_val, pv.data(), pv.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        launch_ring_records(n, ls.lvl_of_pos.p, d_seg_of_level.p, lv.rows, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val,
+                            lv.pk_meta, lv.pk_val, s);
         DPCG_HIP(hipStreamSynchronize(s));
     }
+    DPCG_CHECK_LAUNCH();
     return DPCG_OK;
 }
 
-static int set_llt_from_host(dpcg_system *h, int mode, int64_t nnz, const int32_t *rp_in, const int32_t *ci_in,
-                             const double *v_in, hipStream_t s) {
+// L^T as CSR (columns ascending, diagonal first): stable sort of the entries by column.
+int transpose_lower(const CsrDev &L, CsrDev &Lt, hipStream_t s) {
+    const int64_t n = L.n, nnz = L.nnz;
+    DevBuf<int32_t> row_of, order_in, order;
+    DevBuf<uint32_t> cols_sorted;
+    DPCG_TRY(row_of.alloc(nnz));
+    DPCG_TRY(order_in.alloc(nnz));
+    DPCG_TRY(order.alloc(nnz));
+    DPCG_TRY(cols_sorted.alloc(nnz));
+    Lt = CsrDev();
+    Lt.n = n;
+    Lt.nnz = nnz;
+    Lt.owned = true;
+    DPCG_TRY(dev_alloc(&Lt.rowptr, n + 1));
+    DPCG_TRY(dev_alloc(&Lt.col, nnz));
+    DPCG_TRY(dev_alloc(&Lt.val, nnz));
+    launch_row_of(n, L.rowptr, row_of.p, s);
+    launch_iota(nnz, order_in.p, s);
+    DPCG_TRY(sort_pairs_u32_i32(reinterpret_cast<const uint32_t *>(L.col), cols_sorted.p, order_in.p, order.p, nnz,
+                                bits_for((uint64_t)(n - 1)), s));
+    launch_group_offsets(nnz, cols_sorted.p, (int)n, Lt.rowptr, s);
+    launch_transpose_gather(nnz, order.p, row_of.p, L.val, Lt.col, Lt.val, s);
+    DPCG_HIP(hipStreamSynchronize(s));
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
+// h->L holds a lower-triangular factor on the device (owned by the handle): validate it, build L^T, the SpMV plans and,
+// in solve mode, the level schedules.  `lower_levels`: level analysis of L when the caller already has it (IC(0)).
+int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels = nullptr) {
     const int64_t n = h->A.n;
-    // validate: lower triangular, ascending columns, diagonal last and positive
-    for (int64_t i = 0; i < n; ++i) {
-        const int32_t a = rp_in[i], b = rp_in[i + 1];
-        if (b <= a || ci_in[b - 1] != i) return invalid("L: every row needs its diagonal stored last");
-        for (int32_t k = a; k < b - 1; ++k)
-            if (ci_in[k] >= ci_in[k + 1]) return invalid("L: columns must ascend within a row (lower triangular)");
-        if (!(v_in[b - 1] > 0.0)) {
-            set_error("L: non-positive diagonal");
-            return DPCG_ERR_PIVOT;
-        }
+    DevBuf<int32_t> flags;
+    DPCG_TRY(flags.alloc(1));
+    DPCG_HIP(hipMemsetAsync(flags.p, 0, sizeof(int32_t), s));
+    launch_check_lower(h->L, reinterpret_cast<int *>(flags.p), s);
+    int32_t h_flags = 0, h_last = 0;
+    DPCG_HIP(hipMemcpyAsync(&h_flags, flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipMemcpyAsync(&h_last, h->L.rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    if (h_flags & 1) return invalid("L: lower triangular with ascending columns and the diagonal stored last in every row");
+    if (h_flags & 2) {
+        set_error("L: non-positive diagonal");
+        return DPCG_ERR_PIVOT;
     }
-    if (rp_in[n] != nnz) return invalid("L: rowptr[n] != nnz");
-    DPCG_TRY(upload_csr(h->L, n, nnz, rp_in, ci_in, v_in, DPCG_F64, DPCG_HOST, 1, s));
-    // L^T as CSR: counting transpose, stable in the row index so columns ascend and the diagonal is first
-    std::vector<int32_t> trp((size_t)n + 1, 0), tci((size_t)nnz);
-    std::vector<double> tv((size_t)nnz);
-    for (int64_t k = 0; k < nnz; ++k) trp[ci_in[k] + 1]++;
-    for (int64_t i = 0; i < n; ++i) trp[i + 1] += trp[i];
-    {
-        std::vector<int32_t> cur(trp.begin(), trp.end() - 1);
-        for (int64_t i = 0; i < n; ++i)
-            for (int32_t k = rp_in[i]; k < rp_in[i + 1]; ++k) {
-                const int32_t dst = cur[ci_in[k]]++;
-                tci[dst] = (int32_t)i;
-                tv[dst] = v_in[k];
-            }
-    }
-    DPCG_TRY(upload_csr(h->Lt, n, nnz, trp.data(), tci.data(), tv.data(), DPCG_F64, DPCG_HOST, 1, s));
+    if (h_last != h->L.nnz) return invalid("L: rowptr[n] != nnz");
+    DPCG_TRY(transpose_lower(h->L, h->Lt, s));
     DPCG_TRY(make_plan(h->L, h->planL, s));
     DPCG_TRY(make_plan(h->Lt, h->planLt, s));
     if (mode == DPCG_PRECOND_LLT_SOLVE) {
-        std::vector<int32_t> rp(rp_in, rp_in + n + 1), ci(ci_in, ci_in + nnz), rows, lptr;
-        build_levels_host(n, rp, ci, false, rows, lptr);
-        DPCG_TRY(upload_levels(h->lvlL, rows, lptr, rp_in, ci_in, v_in, s));
-        build_levels_host(n, trp, tci, true, rows, lptr);
-        DPCG_TRY(upload_levels(h->lvlU, rows, lptr, trp.data(), tci.data(), tv.data(), s));
+        LevelSort own, up;
+        if (!lower_levels) {
+            DPCG_TRY(compute_levels(n, h->L.rowptr, h->L.col, false, own, s));
+            lower_levels = &own;
+        }
+        DPCG_TRY(build_levels(h->lvlL, *lower_levels, n, h->L.nnz, h->L.rowptr, h->L.col, h->L.val, s));
+        DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s));
+        DPCG_TRY(build_levels(h->lvlU, up, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, s));
     }
     h->precond = mode;
     return DPCG_OK;
 }
+}  // namespace
 
 extern "C" int dpcg_set_precond_llt(dpcg_handle_t h, int mode, int64_t nnz, const int32_t *rowptr, const int32_t *col,
                                     const double *val, int memspace, dpcg_stream_t stream) {
@@ -243,82 +337,68 @@ extern "C" int dpcg_set_precond_llt(dpcg_handle_t h, int mode, int64_t nnz, cons
     if (nnz <= 0 || !rowptr || !col || !val) return invalid("dpcg_set_precond_llt: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     free_precond(h);
-    const int64_t n = h->A.n;
-    if (memspace == DPCG_HOST) return set_llt_from_host(h, mode, nnz, rowptr, col, val, s);
-    // device-resident factor (e.g. straight from the CNN): the structural analysis runs on the host
-    std::vector<int32_t> rp((size_t)n + 1), ci((size_t)nnz);
-    std::vector<double> v((size_t)nnz);
-    DPCG_HIP(hipMemcpyAsync(rp.data(), rowptr, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    DPCG_HIP(hipMemcpyAsync(ci.data(), col, ci.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    DPCG_HIP(hipMemcpyAsync(v.data(), val, v.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    DPCG_HIP(hipStreamSynchronize(s));
-    return set_llt_from_host(h, mode, nnz, rp.data(), ci.data(), v.data(), s);
+    // host arrays are uploaded, device arrays (a factor straight from the CNN) copied device-to-device: either way the
+    // analysis below works on HBM-resident data
+    DPCG_TRY(upload_csr(h->L, h->A.n, nnz, rowptr, col, val, DPCG_F64, memspace, 1, s));
+    const int st = finish_llt(h, mode, s);
+    if (st < 0) free_precond(h);
+    return st;
 }
 
-// IC(0) of A on its lower-triangular pattern (stands in for ilupp.ichol0, test.py:83).  The symbolic part
-// (tril pattern, level sets) is integer work on the host; the numeric factorisation runs on the device,
-// one launch per level (k_ic0_level), in the operation order of the CPU restatement (bit-identical factor).
+// IC(0) of A on its lower-triangular pattern (stands in for ilupp.ichol0, test.py:83), entirely on the device: tril(A)
+// by count / scan / copy, the level sets of its pattern, then the numeric factorisation one launch per level
+// (k_ic0_level) in the operation order of the CPU restatement (bit-identical factor).  The handle keeps its previous
+// preconditioner when the factorisation fails.
 extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t stream) {
     if (!h) return invalid("NULL handle");
     if (mode != DPCG_PRECOND_LLT_MULTIPLY && mode != DPCG_PRECOND_LLT_SOLVE) return invalid("bad LLT mode");
     hipStream_t s = (hipStream_t)stream;
-    const int64_t n = h->A.n, nnz = h->A.nnz;
-    std::vector<int32_t> rp((size_t)n + 1), ci((size_t)nnz);
-    std::vector<double> v((size_t)nnz);
-    DPCG_HIP(hipMemcpyAsync(rp.data(), h->A.rowptr, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    DPCG_HIP(hipMemcpyAsync(ci.data(), h->A.col, ci.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    DPCG_HIP(hipMemcpyAsync(v.data(), h->A.val, v.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    DPCG_HIP(hipStreamSynchronize(s));
-    std::vector<int32_t> lrp((size_t)n + 1, 0), lci;
-    std::vector<double> lv;
-    lci.reserve((size_t)nnz / 2 + n);
-    lv.reserve((size_t)nnz / 2 + n);
-    for (int64_t i = 0; i < n; ++i) {
-        for (int32_t k = rp[i]; k < rp[i + 1]; ++k)
-            if (ci[k] <= i) {
-                lci.push_back(ci[k]);
-                lv.push_back(v[k]);
-            }
-        lrp[i + 1] = (int32_t)lci.size();
-        if (lrp[i + 1] == lrp[i] || lci.back() != i) {
-            set_error("IC(0): missing diagonal entry");
-            return DPCG_ERR_PIVOT;
-        }
-    }
-    const int64_t lnnz = (int64_t)lci.size();
-    std::vector<int32_t> rows, lptr;
-    build_levels_host(n, lrp, lci, false, rows, lptr);
-    int32_t *d_rp = nullptr, *d_ci = nullptr, *d_rows = nullptr;
-    double *d_lv = nullptr;
-    int *d_bad = nullptr, h_bad = 0;
-    int st = DPCG_OK;
-    auto cleanup = [&]() { dev_free(d_rp); dev_free(d_ci); dev_free(d_rows); dev_free(d_lv); dev_free(d_bad); };
-    if ((st = dev_alloc(&d_rp, n + 1)) < 0 || (st = dev_alloc(&d_ci, lnnz)) < 0 || (st = dev_alloc(&d_rows, n)) < 0 ||
-        (st = dev_alloc(&d_lv, lnnz)) < 0 || (st = dev_alloc(&d_bad, 1)) < 0) {
-        cleanup();
+    const int64_t n = h->A.n;
+    CsrDev Lf;
+    Lf.n = n;
+    Lf.owned = true;
+    DevBuf<int32_t> cnt, flags;
+    auto fail = [&](int st) {
+        free_csr(Lf);
         return st;
-    }
-    hipError_t e = hipMemcpyAsync(d_rp, lrp.data(), lrp.size() * sizeof(int32_t), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_ci, lci.data(), lci.size() * sizeof(int32_t), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_rows, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_lv, lv.data(), lv.size() * sizeof(double), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int), s);
-    if (e == hipSuccess) {
-        const int nl = (int)lptr.size() - 1;
-        for (int l = 0; l < nl; ++l) launch_ic0_level(d_rows, lptr[l], lptr[l + 1] - lptr[l], d_rp, d_ci, d_lv, d_bad, s);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(lv.data(), d_lv, lv.size() * sizeof(double), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s);
+    };
+    int st = DPCG_OK;
+    if ((st = cnt.alloc(n + 1)) < 0 || (st = flags.alloc(2)) < 0 || (st = dev_alloc(&Lf.rowptr, n + 1)) < 0) return fail(st);
+    hipError_t e = hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), s);
+    if (e != hipSuccess) return fail(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
+    launch_tril_count(n, h->A.rowptr, h->A.col, cnt.p, reinterpret_cast<int *>(flags.p), s);
+    if ((st = exclusive_scan_i32(cnt.p, Lf.rowptr, n + 1, s)) < 0) return fail(st);
+    int32_t h_flags[2] = {0, 0}, lnnz = 0;
+    e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&lnnz, Lf.rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    cleanup();
-    DPCG_HIP(e);
-    if (h_bad) {
-        set_error("IC(0): non-positive pivot at row " + std::to_string(h_bad - 1));
-        return DPCG_ERR_PIVOT;
+    if (e != hipSuccess) return fail(hip_fail(e, "IC(0): tril(A)", __FILE__, __LINE__));
+    if (h_flags[0]) {
+        set_error("IC(0): missing diagonal entry");
+        return fail(DPCG_ERR_PIVOT);
+    }
+    Lf.nnz = lnnz;
+    if ((st = dev_alloc(&Lf.col, lnnz)) < 0 || (st = dev_alloc(&Lf.val, lnnz)) < 0) return fail(st);
+    launch_tril_copy(n, h->A.rowptr, h->A.col, h->A.val, Lf.rowptr, Lf.col, Lf.val, s);
+    LevelSort ls;
+    if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, ls, s)) < 0) return fail(st);
+    const int nl = (int)ls.level_ptr.size() - 1;
+    for (int l = 0; l < nl; ++l)
+        launch_ic0_level(ls.rows.p, ls.level_ptr[l], ls.level_ptr[l + 1] - ls.level_ptr[l], Lf.rowptr, Lf.col, Lf.val,
+                         reinterpret_cast<int *>(flags.p) + 1, s);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(hip_fail(e, "IC(0): numeric factorisation", __FILE__, __LINE__));
+    if (h_flags[1]) {
+        set_error("IC(0): non-positive pivot at row " + std::to_string(h_flags[1] - 1));
+        return fail(DPCG_ERR_PIVOT);
     }
     free_precond(h);
-    return set_llt_from_host(h, mode, lnnz, lrp.data(), lci.data(), lv.data(), s);
+    h->L = Lf;
+    st = finish_llt(h, mode, s, &ls);
+    if (st < 0) free_precond(h);
+    return st;
 }
 
 extern "C" int dpcg_get_factor(dpcg_handle_t h, int32_t *rowptr, int32_t *col, double *val) {

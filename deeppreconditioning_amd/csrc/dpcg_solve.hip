@@ -110,7 +110,7 @@ static int ensure_graph(dpcg_system *h, int flags, int chunk) {
 static int precond_launches(const dpcg_system *h) {
     auto trsv = [](const Levels &lv) {
         int c = 0;
-        for (const auto &seg : lv.segments) c += seg.merged ? 2 : seg.hi - seg.lo;
+        for (const auto &seg : lv.segments) c += (seg.merged || seg.syncfree) ? 2 : seg.hi - seg.lo;
         return c;
     };
     switch (h->precond) {
@@ -119,6 +119,24 @@ static int precond_launches(const dpcg_system *h) {
         case DPCG_PRECOND_LLT_SOLVE: return trsv(h->lvlL) + trsv(h->lvlU);
         default: return 0;
     }
+}
+
+// A sync-free triangular solve whose bounded poll ran out (cannot happen with a schedule built by this library) has
+// stored NaNs; report it instead of a silent breakdown.
+int check_spin_errors(dpcg_system *h, hipStream_t s) {
+    if (h->precond != DPCG_PRECOND_LLT_SOLVE) return DPCG_OK;
+    for (Levels *lv : {&h->lvlL, &h->lvlU}) {
+        if (!lv->spin_err) continue;
+        int e = 0;
+        DPCG_HIP(hipMemcpyAsync(&e, lv->spin_err, sizeof(int), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        if (e) {
+            (void)hipMemsetAsync(lv->spin_err, 0, sizeof(int), s);
+            set_error("sync-free triangular solve: a row waited for an entry that was never written");
+            return DPCG_ERR_STATE;
+        }
+    }
+    return DPCG_OK;
 }
 
 namespace {
@@ -280,6 +298,7 @@ struct Solve {
         DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
         DPCG_HIP(hipStreamSynchronize(s));
         const auto t1 = std::chrono::steady_clock::now();                            // cg.py:88 (the loop only)
+        DPCG_TRY(check_spin_errors(h, s));
         const Scalars sc = *h->scal_host;
         if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
         if (iters) *iters = sc.k;                                                    // cg.py:90

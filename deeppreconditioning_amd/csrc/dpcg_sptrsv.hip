@@ -321,6 +321,109 @@ __global__ __launch_bounds__(512) void k_sptrsv_ring_pipe(const int32_t *__restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Several levels in ONE multi-workgroup launch, without barriers ("sync-free" triangular solve): in level order a
+// workgroup takes 256 consecutive rows -- whatever levels they belong to -- and every row polls the solution entries it
+// depends on until they have been written.  An entry carries its own flag: `out` is filled with a reserved NaN bit
+// pattern before the launch (k_fill_pending) and an 8-byte agent-scope store of the value replaces it, so a single
+// relaxed 8-byte agent-scope load is both the test and the read (no fence, no second word).  Rows of earlier levels
+// sit at lower level-order positions, and the 256-row blocks are handed out through a ticket counter, so everything a
+// workgroup waits for belongs to a workgroup that has already started: no deadlock whatever the dispatch order; lanes
+// of one wave may depend on each other, hence the store inside the poll loop.  Against one launch per level this
+// removes (levels - 1) kernel boundaries per segment and lets consecutive levels overlap: a row starts as soon as ITS
+// entries are there.  Arithmetic as everywhere else: ascending columns, one product and one subtraction at a time,
+// then the division -- bit-identical to sequential substitution.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned long long kPendingBits = 0x7ff8dead0badbeefULL;   // a quiet NaN that no arithmetic here produces
+__device__ __forceinline__ bool is_pending(double y) { return (unsigned long long)__double_as_longlong(y) == kPendingBits; }
+
+__global__ __launch_bounds__(kBlock) void k_fill_pending(const int32_t *__restrict__ rows, int j0, int count,
+                                                         double *__restrict__ out, const int *done) {
+    if (done && *done) return;
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx < count) out[rows[j0 + idx]] = __longlong_as_double((long long)kPendingBits);
+}
+
+template <bool UPPER, bool STAGED>
+__global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree(const int32_t *__restrict__ rows, int j0, int count,
+                                                            const int32_t *__restrict__ lo_rp,
+                                                            const int32_t *__restrict__ lo_ci,
+                                                            const double *__restrict__ lo_v,
+                                                            const double *__restrict__ rhs, double *out,
+                                                            unsigned long long *ticket, int nblocks, const int *done,
+                                                            int *err) {
+    __shared__ unsigned int s_lb;
+    __shared__ double sv[STAGED ? kStreamCap : 1];
+    __shared__ int sc[STAGED ? kStreamCap : 1];
+    const int t = threadIdx.x;
+    // every workgroup draws a ticket, also when the solve is over: the counter advances by nblocks per launch
+    if (t == 0) s_lb = (unsigned int)(atomicAdd(ticket, 1ull) % (unsigned long long)nblocks);
+    __syncthreads();
+    if (done && *done) return;
+    const int jb = j0 + (int)s_lb * kBlock;
+    const int jend = (jb + kBlock < j0 + count) ? jb + kBlock : j0 + count;
+    const int j = jb + t;
+    const int base = lo_rp[jb];
+    int rs = 0, re = 0, i = 0;
+    double bi = 0.0;
+    if (j < jend) {
+        rs = lo_rp[j] - base;
+        re = lo_rp[j + 1] - base;
+        i = rows[j];
+        bi = rhs[i];
+    }
+    if (STAGED) {                                   // the block's contiguous val/col segment, coalesced, into LDS
+        const int cnt = lo_rp[jend] - base;
+        for (int k = t; k < cnt; k += kBlock) {
+            sv[k] = lo_v[base + k];
+            sc[k] = lo_ci[base + k];
+        }
+        __syncthreads();
+    }
+    if (j >= jend) return;
+    auto val_at = [&](int k) { return STAGED ? sv[k] : lo_v[base + k]; };
+    auto col_at = [&](int k) { return STAGED ? sc[k] : lo_ci[base + k]; };
+    int k = UPPER ? rs + 1 : rs;
+    const int ke = UPPER ? re : re - 1;
+    const double diag = val_at(UPPER ? rs : re - 1);
+    double acc = bi;
+    unsigned spins = 0;
+    bool stored = false;
+    while (!stored) {
+        if (k < ke) {
+            // up to four entries requested at once, consumed in column order as far as they are there
+            const int m = ke - k < 4 ? ke - k : 4;
+            double y[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                y[q] = q < m ? __hip_atomic_load(out + col_at(k + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            int used = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q == used && q < m && !is_pending(y[q])) {
+                    acc -= val_at(k + q) * y[q];
+                    ++used;
+                }
+            k += used;
+            if (used == 0) {
+                if (++spins > (1u << 22)) {          // bounded: never hang the device on a malformed schedule
+                    atomicExch(err, 1);
+                    acc = __builtin_nan("");
+                    k = ke;
+                } else {
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            } else {
+                spins = 0;
+            }
+        }
+        if (k >= ke) {
+            __hip_atomic_store(out + i, acc / diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stored = true;
+        }
+    }
+}
+
 constexpr int kRingChunk = 6;   // levels per prefetch chunk of k_sptrsv_ring_pipe (3 with two rows per thread)
 static bool ring_pipe_disabled() {
     static const bool off = [] { const char *e = getenv("DPCG_RING_PIPE"); return e && e[0] == '0'; }();
@@ -330,7 +433,26 @@ static bool ring_pipe_disabled() {
 void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s,
                    const int *done) {
     (void)T;  // the level-ordered copy in `lv` carries the factor
+    int seg_index = -1;
     for (const auto &seg : lv.segments) {
+        ++seg_index;
+        if (seg.syncfree) {
+            const int j0 = lv.level_ptr[seg.lo], cnt = lv.level_ptr[seg.hi] - j0;
+            const int nblocks = (cnt + kBlock - 1) / kBlock;
+            hipLaunchKernelGGL(k_fill_pending, dim3(nblocks), dim3(kBlock), 0, s, lv.rows, j0, cnt, out, done);
+#define DPCG_SYNCFREE(UP, ST)                                                                                          \
+    hipLaunchKernelGGL((k_sptrsv_syncfree<UP, ST>), dim3(nblocks), dim3(kBlock), 0, s, lv.rows, j0, cnt, lv.lo_rowptr,  \
+                       lv.lo_col, lv.lo_val, rhs, out, lv.tickets + seg_index, nblocks, done, lv.spin_err)
+            if (upper) {
+                if (seg.staged) DPCG_SYNCFREE(true, true);
+                else DPCG_SYNCFREE(true, false);
+            } else {
+                if (seg.staged) DPCG_SYNCFREE(false, true);
+                else DPCG_SYNCFREE(false, false);
+            }
+#undef DPCG_SYNCFREE
+            continue;
+        }
         if (seg.merged && seg.ring_w > 0 && lv.pk_meta && !ring_pipe_disabled() && seg.max_width <= 1024 &&
             (size_t)seg.ring_w * sizeof(double) + (size_t)(seg.hi - seg.lo + 4 * kRingChunk) * sizeof(int) <= 64 * 1024) {
             const int seg_start = lv.level_ptr[seg.lo], seg_rows = lv.level_ptr[seg.hi] - seg_start;
