@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_levels_syncfree(int64_t n, const int
     if (threadIdx.x == 0) s_lb = atomicAdd(ticket, 1u);
     __syncthreads();
     const int64_t idx = (int64_t)s_lb * kBlock + threadIdx.x;
-    if (idx >= n) return;
+    if (idx >= n) return;                            // (lanes past the end leave before the loop: exec-masked for good)
     const int64_t i = UPPER ? n - 1 - idx : idx;
     const int s = rp[i], e = rp[i + 1];
     int k = UPPER ? s + 1 : s;                       // the diagonal is first (upper) or last (lower)
@@ -120,8 +120,11 @@ __global__ __launch_bounds__(kBlock) void k_levels_syncfree(int64_t n, const int
     int c = k < ke ? ci[k] : 0;
     unsigned spins = 0;
     bool stored = false;
-    while (!stored) {
-        if (k < ke) {
+    // The loop is left by the whole wave at once (ballot): were lanes to leave one by one, the compiler could move the
+    // store onto the exit path, where a SIMT machine executes it only after EVERY lane has left -- a lane waiting for
+    // the level of a row owned by another lane of its own wave would then wait forever.
+    for (;;) {
+        if (!stored && k < ke) {
             const int l = __hip_atomic_load(level + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (l >= 0) {
                 lvl = l + 1 > lvl ? l + 1 : lvl;
@@ -135,10 +138,11 @@ __global__ __launch_bounds__(kBlock) void k_levels_syncfree(int64_t n, const int
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        if (k >= ke) {
+        if (!stored && k >= ke) {
             __hip_atomic_store(level + i, lvl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             stored = true;
         }
+        if (__ballot(!stored) == 0) break;
     }
 }
 

@@ -389,8 +389,10 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree(const int32_t *__res
     double acc = bi;
     unsigned spins = 0;
     bool stored = false;
-    while (!stored) {
-        if (k < ke) {
+    // left by the whole wave at once (ballot), so that the store stays INSIDE the loop: on an exit path a SIMT machine
+    // would run it only after every lane has left, and lanes of one wave may wait for each other
+    for (;;) {
+        if (!stored && k < ke) {
             // up to four entries requested at once, consumed in column order as far as they are there
             const int m = ke - k < 4 ? ke - k : 4;
             double y[4];
@@ -417,10 +419,11 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree(const int32_t *__res
                 spins = 0;
             }
         }
-        if (k >= ke) {
+        if (!stored && k >= ke) {
             __hip_atomic_store(out + i, acc / diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             stored = true;
         }
+        if (__ballot(!stored) == 0) break;
     }
 }
 
