@@ -23,6 +23,7 @@ F64, F32 = 0, 1
 DEVICE, HOST = 0, 1
 PRECOND_NONE, PRECOND_JACOBI, PRECOND_CSR, PRECOND_LLT_MULTIPLY, PRECOND_LLT_SOLVE = 0, 1, 2, 3, 4
 INIT_CHECK_R, SPMV_F32, NO_GRAPH, NO_SMALL, VAL32_IF_LOSSLESS, NO_FUSE = 1, 2, 4, 8, 16, 32
+REORDER_NONE, REORDER_AUTO, REORDER_ALWAYS = 0, 1, 2
 
 # name -> (restype, argtypes); every symbol include/dpcg.h declares
 _p = C.c_void_p
@@ -38,6 +39,8 @@ SIGNATURES = {
     "dpcg_destroy": (_int, [_p]),
     "dpcg_get_info": (_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int), C.POINTER(_int),
                              C.POINTER(_i64), C.POINTER(_int), C.POINTER(_int)]),
+    "dpcg_reorder": (_int, [_p, _int, _p, C.POINTER(_int)]),
+    "dpcg_get_permutation": (_int, [_p, C.POINTER(_int), _p, C.POINTER(_dbl)]),
     "dpcg_set_precond_none": (_int, [_p]),
     "dpcg_set_precond_jacobi": (_int, [_p, _p, _int, _p]),
     "dpcg_set_precond_csr": (_int, [_p, _i64, _p, _p, _p, _int, _p]),

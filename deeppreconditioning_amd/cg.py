@@ -19,7 +19,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
-from .operators import CsrSystem, ReorderedSystem, dot
+from .operators import CsrSystem, dot
 
 
 def stopping_criterion(_, rk, b):
@@ -32,7 +32,7 @@ def stopping_criterion(_, rk, b):
 
 
 def _system_and_device(A, b):
-    if isinstance(A, (CsrSystem, ReorderedSystem)):
+    if isinstance(A, CsrSystem):
         return A
     device = None
     if isinstance(b, torch.Tensor) and b.is_cuda:

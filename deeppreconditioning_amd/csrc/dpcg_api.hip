@@ -247,6 +247,8 @@ void free_precond(dpcg_system *h) {
     free_csr(h->M);
     free_csr(h->L);
     free_csr(h->Lt);
+    free_csr(h->Lp);
+    free_csr(h->Ltp);
     free_levels(h->lvlL);
     free_levels(h->lvlU);
     h->precond = DPCG_PRECOND_NONE;
@@ -291,6 +293,9 @@ extern "C" int dpcg_destroy(dpcg_handle_t h) {
     (void)hipDeviceSynchronize();
     free_precond(h);
     free_csr(h->A);
+    free_csr(h->A_user);
+    dev_free(h->perm); dev_free(h->iperm); dev_free(h->pb); dev_free(h->pxt); dev_free(h->pv0); dev_free(h->pv1);
+    dev_free(h->pf0); dev_free(h->pf1);
     free_plan(h->planA);
     free_ell(h->ell_a);
     dev_free(h->x); dev_free(h->r); dev_free(h->z); dev_free(h->p); dev_free(h->p2); dev_free(h->q); dev_free(h->t); dev_free(h->e);
@@ -304,6 +309,53 @@ extern "C" int dpcg_destroy(dpcg_handle_t h) {
         if (ex.prog_host) (void)hipHostFree(ex.prog_host);
     }
     delete h;
+    return DPCG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reordering (see include/dpcg.h and dpcg_reorder.hip)
+// ------------------------------------------------------------------------------------------------
+extern "C" int dpcg_reorder(dpcg_handle_t h, int mode, dpcg_stream_t stream, int *applied) {
+    if (!h) return invalid("dpcg_reorder: NULL handle");
+    if (applied) *applied = h->perm ? 1 : 0;
+    if (mode == DPCG_REORDER_NONE || h->perm) return DPCG_OK;
+    if (mode != DPCG_REORDER_AUTO && mode != DPCG_REORDER_ALWAYS) return invalid("dpcg_reorder: bad mode");
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == DPCG_REORDER_AUTO) {
+        // only where it pays: large systems whose x-tile plan failed and whose gather really is scattered
+        if (h->planA.kernel != SPMV_STREAM || h->A.n < (int64_t)kTileMinBlocks * kStreamRows) return DPCG_OK;
+        DPCG_TRY(gather_line_ratio(h->A, &h->gather_ratio, s));
+        if (h->gather_ratio <= 4.0) return DPCG_OK;
+    }
+    int32_t *perm = nullptr, *iperm = nullptr;
+    DPCG_TRY(rcm_order(h->A, &perm, &iperm, nullptr, s));
+    CsrDev B;
+    int st = permute_csr(h->A, perm, iperm, B, s);
+    if (st < 0) {
+        dev_free(perm);
+        dev_free(iperm);
+        free_csr(B);
+        return st;
+    }
+    free_precond(h);                 // an attached preconditioner referred to the old matrix
+    free_ell(h->ell_a);
+    dev_free(h->A.val32);            // recreated on demand from the reordered values
+    h->A.val32_lossless = 0;
+    h->A_user = h->A;                // ownership (or the borrow) moves with the struct
+    h->A = B;
+    h->perm = perm;
+    h->iperm = iperm;
+    DPCG_TRY(make_plan(h->A, h->planA, s, true));
+    if (applied) *applied = 1;
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_get_permutation(dpcg_handle_t h, int *reordered, int32_t *perm_host, double *gather_ratio) {
+    if (!h) return invalid("dpcg_get_permutation: NULL handle");
+    if (reordered) *reordered = h->perm ? 1 : 0;
+    if (gather_ratio) *gather_ratio = h->gather_ratio;
+    if (perm_host && h->perm)
+        DPCG_HIP(hipMemcpy(perm_host, h->perm, (size_t)h->A.n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return DPCG_OK;
 }
 
@@ -389,9 +441,28 @@ int ensure_work(dpcg_system *h, int max_iter, bool need_f32, bool need_err) {
 // ------------------------------------------------------------------------------------------------
 // standalone operators
 // ------------------------------------------------------------------------------------------------
+// scratch vectors of the standalone operators on a reordered handle (the caller's vectors keep the caller's numbering)
+static int ensure_perm_scratch(dpcg_system *h, bool f32) {
+    if (!h->pv0) DPCG_TRY(dev_alloc(&h->pv0, h->A.n));
+    if (!h->pv1) DPCG_TRY(dev_alloc(&h->pv1, h->A.n));
+    if (f32) {
+        if (!h->pf0) DPCG_TRY(dev_alloc(&h->pf0, h->A.n));
+        if (!h->pf1) DPCG_TRY(dev_alloc(&h->pf1, h->A.n));
+    }
+    return DPCG_OK;
+}
+
 extern "C" int dpcg_spmv(dpcg_handle_t h, const double *x, double *y, dpcg_stream_t stream) {
     if (!h || !x || !y) return invalid("dpcg_spmv: NULL argument");
-    launch_spmv(h->A, h->planA, x, y, nullptr, nullptr, (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    if (h->perm) {                                   // y = P^T (P A P^T) P x
+        DPCG_TRY(ensure_perm_scratch(h, false));
+        launch_gather_f64(h->A.n, h->perm, x, h->pv0, s);
+        launch_spmv(h->A, h->planA, h->pv0, h->pv1, nullptr, nullptr, s);
+        launch_scatter_f64(h->A.n, h->perm, h->pv1, y, s);
+    } else {
+        launch_spmv(h->A, h->planA, x, y, nullptr, nullptr, s);
+    }
     DPCG_CHECK_LAUNCH();
     return DPCG_OK;
 }
@@ -402,7 +473,14 @@ extern "C" int dpcg_spmv_f32(dpcg_handle_t h, const float *x, float *y, dpcg_str
         DPCG_TRY(dev_alloc(&h->A.val32, h->A.nnz));
         launch_f64_to_f32(h->A.nnz, h->A.val, h->A.val32, (hipStream_t)stream);
     }
-    launch_spmv_f32out(h->A, h->planA, x, y, (hipStream_t)stream);
+    if (h->perm) {
+        DPCG_TRY(ensure_perm_scratch(h, true));
+        launch_gather_f32(h->A.n, h->perm, x, h->pf0, (hipStream_t)stream);
+        launch_spmv_f32out(h->A, h->planA, h->pf0, h->pf1, (hipStream_t)stream);
+        launch_scatter_f32(h->A.n, h->perm, h->pf1, y, (hipStream_t)stream);
+    } else {
+        launch_spmv_f32out(h->A, h->planA, x, y, (hipStream_t)stream);
+    }
     DPCG_CHECK_LAUNCH();
     return DPCG_OK;
 }
@@ -419,9 +497,9 @@ int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, boo
         case DPCG_PRECOND_CSR:
             launch_spmv(h->M, h->planM, r, z, nullptr, nullptr, s);
             break;
-        case DPCG_PRECOND_LLT_MULTIPLY:
-            launch_spmv(h->Lt, h->planLt, r, h->t, nullptr, nullptr, s);
-            launch_spmv(h->L, h->planL, h->t, z, nullptr, nullptr, s);
+        case DPCG_PRECOND_LLT_MULTIPLY:       // on a reordered handle the SpMVs read P L^T P^T and P L P^T
+            launch_spmv(h->perm ? h->Ltp : h->Lt, h->planLt, r, h->t, nullptr, nullptr, s);
+            launch_spmv(h->perm ? h->Lp : h->L, h->planL, h->t, z, nullptr, nullptr, s);
             break;
         case DPCG_PRECOND_LLT_SOLVE:
             launch_sptrsv(h->L, h->lvlL, false, r, h->t, s, in_loop ? &h->scal->done : nullptr);
@@ -437,7 +515,15 @@ int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, boo
 extern "C" int dpcg_precond_apply(dpcg_handle_t h, const double *r, double *z, dpcg_stream_t stream) {
     if (!h || !r || !z) return invalid("dpcg_precond_apply: NULL argument");
     DPCG_TRY(ensure_work(h, 0, false, false));
-    DPCG_TRY(apply_precond(h, r, z, (hipStream_t)stream));
+    if (h->perm) {
+        hipStream_t s = (hipStream_t)stream;
+        DPCG_TRY(ensure_perm_scratch(h, false));
+        launch_gather_f64(h->A.n, h->perm, r, h->pv0, s);
+        DPCG_TRY(apply_precond(h, h->pv0, h->pv1, s));
+        launch_scatter_f64(h->A.n, h->perm, h->pv1, z, s);
+    } else {
+        DPCG_TRY(apply_precond(h, r, z, (hipStream_t)stream));
+    }
     DPCG_CHECK_LAUNCH();
     return DPCG_OK;
 }
@@ -448,8 +534,18 @@ extern "C" int dpcg_sptrsv(dpcg_handle_t h, int upper, const double *rhs, double
         set_error("dpcg_sptrsv: needs dpcg_set_precond_llt/ic0 in LLT_SOLVE mode");
         return DPCG_ERR_STATE;
     }
-    if (upper) launch_sptrsv(h->Lt, h->lvlU, true, rhs, out, (hipStream_t)stream);
-    else launch_sptrsv(h->L, h->lvlL, false, rhs, out, (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    const double *in = rhs;
+    double *res = out;
+    if (h->perm) {       // the schedules are relabelled to the handle's numbering; the factor itself is the caller's
+        DPCG_TRY(ensure_perm_scratch(h, false));
+        launch_gather_f64(h->A.n, h->perm, rhs, h->pv0, s);
+        in = h->pv0;
+        res = h->pv1;
+    }
+    if (upper) launch_sptrsv(h->Lt, h->lvlU, true, in, res, s);
+    else launch_sptrsv(h->L, h->lvlL, false, in, res, s);
+    if (h->perm) launch_scatter_f64(h->A.n, h->perm, h->pv1, out, s);
     DPCG_CHECK_LAUNCH();
     return DPCG_OK;
 }

@@ -136,8 +136,16 @@ struct dpcg_system {
     double *dinv = nullptr;
     dpcg::CsrDev M;
     dpcg::SpmvPlan planM;
-    dpcg::CsrDev L, Lt;
+    dpcg::CsrDev L, Lt;                   // the factor and its transpose in the CALLER's numbering
+    dpcg::CsrDev Lp, Ltp;                 // reordered handle, multiply mode: P L P^T and P L^T P^T (what the SpMVs read)
     dpcg::SpmvPlan planL, planLt;
+    // dpcg_reorder: the handle iterates on A = P A_user P^T; perm[new] = old, iperm[old] = new (device)
+    int32_t *perm = nullptr, *iperm = nullptr;
+    dpcg::CsrDev A_user;                  // the caller's matrix once A has been replaced by the reordered one
+    double gather_ratio = 0.0;            // measured x-gather line traffic / bytes used of the caller's matrix
+    double *pb = nullptr, *pxt = nullptr; // b / x_true gathered into the handle's numbering
+    double *pv0 = nullptr, *pv1 = nullptr;   // scratch of the standalone operators on a reordered handle
+    float *pf0 = nullptr, *pf1 = nullptr;
     dpcg::Levels lvlL, lvlU;
     // work vectors (fp64[n]) and reduction partials
     double *x = nullptr, *r = nullptr, *z = nullptr, *p = nullptr, *q = nullptr, *t = nullptr, *e = nullptr;
@@ -256,6 +264,15 @@ void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp,
                       hipStream_t s);
 void launch_block_nnz_max(const CsrDev &A, int rows_per_block, int *out_max_dev, hipStream_t s);
 void launch_block_nnz_max_raw(int64_t n, const int32_t *rowptr, int rows_per_block, int *out_max_dev, hipStream_t s);
+// ---- reordering (dpcg_reorder.hip) ----
+void launch_gather_f64(int64_t n, const int32_t *perm, const double *in, double *out, hipStream_t s);    // out[r] = in[perm[r]]
+void launch_scatter_f64(int64_t n, const int32_t *perm, const double *in, double *out, hipStream_t s);   // out[perm[r]] = in[r]
+void launch_gather_f32(int64_t n, const int32_t *perm, const float *in, float *out, hipStream_t s);
+void launch_scatter_f32(int64_t n, const int32_t *perm, const float *in, float *out, hipStream_t s);
+void launch_relabel(int64_t count, const int32_t *map, int32_t *idx, hipStream_t s);                    // idx[k] = map[idx[k]]
+int gather_line_ratio(const CsrDev &A, double *ratio, hipStream_t s);
+int permute_csr(const CsrDev &A, const int32_t *perm, const int32_t *iperm, CsrDev &B, hipStream_t s);
+int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_components, hipStream_t s);
 // ---- structural analysis of triangular factors on the device (dpcg_analysis.hip) ----
 void launch_check_lower(const CsrDev &L, int *flags, hipStream_t s);
 void launch_row_of(int64_t n, const int32_t *rp, int32_t *row_of, hipStream_t s);

@@ -22,7 +22,18 @@ extern "C" int dpcg_set_precond_jacobi(dpcg_handle_t h, const double *dinv, int 
     hipStream_t s = (hipStream_t)stream;
     free_precond(h);
     DPCG_TRY(dev_alloc(&h->dinv, h->A.n));
-    if (dinv) {
+    if (dinv && h->perm) {                           // the caller's numbering -> the handle's
+        double *tmp = nullptr;
+        const double *src = dinv;
+        if (memspace == DPCG_HOST) {
+            DPCG_TRY(dev_alloc(&tmp, h->A.n));
+            DPCG_HIP(hipMemcpyAsync(tmp, dinv, (size_t)h->A.n * sizeof(double), hipMemcpyHostToDevice, s));
+            src = tmp;
+        }
+        launch_gather_f64(h->A.n, h->perm, src, h->dinv, s);
+        DPCG_HIP(hipStreamSynchronize(s));
+        dev_free(tmp);
+    } else if (dinv) {
         DPCG_HIP(hipMemcpyAsync(h->dinv, dinv, (size_t)h->A.n * sizeof(double),
                                 memspace == DPCG_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
         DPCG_HIP(hipStreamSynchronize(s));
@@ -50,7 +61,15 @@ extern "C" int dpcg_set_precond_csr(dpcg_handle_t h, int64_t nnz, const int32_t 
     if (nnz <= 0 || !rowptr || !col || !val) return invalid("dpcg_set_precond_csr: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     free_precond(h);
-    DPCG_TRY(upload_csr(h->M, h->A.n, nnz, rowptr, col, val, DPCG_F64, memspace, 1, s));
+    if (h->perm) {                                   // M arrives in the caller's numbering: iterate with P M P^T
+        CsrDev Mu;
+        DPCG_TRY(upload_csr(Mu, h->A.n, nnz, rowptr, col, val, DPCG_F64, memspace, 1, s));
+        const int st = permute_csr(Mu, h->perm, h->iperm, h->M, s);
+        free_csr(Mu);
+        DPCG_TRY(st);
+    } else {
+        DPCG_TRY(upload_csr(h->M, h->A.n, nnz, rowptr, col, val, DPCG_F64, memspace, 1, s));
+    }
     DPCG_TRY(make_plan(h->M, h->planM, s));
     h->precond = DPCG_PRECOND_CSR;
     return DPCG_OK;
@@ -122,8 +141,11 @@ int compute_levels(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, 
 }
 
 // Everything launch_sptrsv needs for one factor (rp/ci/v: the factor in its own row order, device).
+// `relabel` (may be null): old -> new index map of a reordered handle.  The factor is the caller's; only the indices the
+// solve kernels use to address the right-hand side and the solution are mapped, so the arithmetic -- and its order --
+// is that of the factor in the caller's numbering.
 int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_t *rp, const int32_t *ci, const double *v,
-                 hipStream_t s) {
+                 hipStream_t s, const int32_t *relabel = nullptr) {
     constexpr int kMergeMax = 2048;  // levels this narrow are walked by one workgroup
     lv.level_ptr = ls.level_ptr;
     lv.n_levels = (int)ls.level_ptr.size() - 1;
@@ -142,6 +164,10 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
     launch_lo_lengths(n, lv.rows, rp, len.p, pos.p, s);
     DPCG_TRY(exclusive_scan_i32(len.p, lv.lo_rowptr, n + 1, s));
     launch_lo_copy(n, lv.rows, rp, ci, v, pos.p, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, s);
+    if (relabel) {
+        launch_relabel(n, relabel, lv.rows, s);
+        launch_relabel(nnz, relabel, lv.lo_col, s);
+    }
     DPCG_HIP(hipMemsetAsync(flag.p, 0, sizeof(int32_t), s));
     launch_stream_fit(n, ls.lvl_of_pos.p, lv.level_ptr_dev, lv.lo_rowptr, flag.p, s);
     // segments: runs of narrow levels are merged (one workgroup walks them), wide levels launch one by one
@@ -313,17 +339,24 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
     }
     if (h_last != h->L.nnz) return invalid("L: rowptr[n] != nnz");
     DPCG_TRY(transpose_lower(h->L, h->Lt, s));
-    DPCG_TRY(make_plan(h->L, h->planL, s));
-    DPCG_TRY(make_plan(h->Lt, h->planLt, s));
+    if (h->perm && mode == DPCG_PRECOND_LLT_MULTIPLY) {
+        DPCG_TRY(permute_csr(h->L, h->perm, h->iperm, h->Lp, s));
+        DPCG_TRY(permute_csr(h->Lt, h->perm, h->iperm, h->Ltp, s));
+        DPCG_TRY(make_plan(h->Lp, h->planL, s));
+        DPCG_TRY(make_plan(h->Ltp, h->planLt, s));
+    } else {
+        DPCG_TRY(make_plan(h->L, h->planL, s));
+        DPCG_TRY(make_plan(h->Lt, h->planLt, s));
+    }
     if (mode == DPCG_PRECOND_LLT_SOLVE) {
         LevelSort own, up;
         if (!lower_levels) {
             DPCG_TRY(compute_levels(n, h->L.rowptr, h->L.col, false, own, s));
             lower_levels = &own;
         }
-        DPCG_TRY(build_levels(h->lvlL, *lower_levels, n, h->L.nnz, h->L.rowptr, h->L.col, h->L.val, s));
+        DPCG_TRY(build_levels(h->lvlL, *lower_levels, n, h->L.nnz, h->L.rowptr, h->L.col, h->L.val, s, h->iperm));
         DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s));
-        DPCG_TRY(build_levels(h->lvlU, up, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, s));
+        DPCG_TRY(build_levels(h->lvlU, up, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, s, h->iperm));
     }
     h->precond = mode;
     return DPCG_OK;
@@ -354,6 +387,8 @@ extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t str
     if (mode != DPCG_PRECOND_LLT_MULTIPLY && mode != DPCG_PRECOND_LLT_SOLVE) return invalid("bad LLT mode");
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = h->A.n;
+    // the factor of the CALLER's matrix (what ilupp.ichol0 would be handed), also when the handle iterates on P A P^T
+    const CsrDev &Asrc = h->perm ? h->A_user : h->A;
     CsrDev Lf;
     Lf.n = n;
     Lf.owned = true;
@@ -366,7 +401,7 @@ extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t str
     if ((st = cnt.alloc(n + 1)) < 0 || (st = flags.alloc(2)) < 0 || (st = dev_alloc(&Lf.rowptr, n + 1)) < 0) return fail(st);
     hipError_t e = hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), s);
     if (e != hipSuccess) return fail(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
-    launch_tril_count(n, h->A.rowptr, h->A.col, cnt.p, reinterpret_cast<int *>(flags.p), s);
+    launch_tril_count(n, Asrc.rowptr, Asrc.col, cnt.p, reinterpret_cast<int *>(flags.p), s);
     if ((st = exclusive_scan_i32(cnt.p, Lf.rowptr, n + 1, s)) < 0) return fail(st);
     int32_t h_flags[2] = {0, 0}, lnnz = 0;
     e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
@@ -379,7 +414,7 @@ extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t str
     }
     Lf.nnz = lnnz;
     if ((st = dev_alloc(&Lf.col, lnnz)) < 0 || (st = dev_alloc(&Lf.val, lnnz)) < 0) return fail(st);
-    launch_tril_copy(n, h->A.rowptr, h->A.col, h->A.val, Lf.rowptr, Lf.col, Lf.val, s);
+    launch_tril_copy(n, Asrc.rowptr, Asrc.col, Asrc.val, Lf.rowptr, Lf.col, Lf.val, s);
     LevelSort ls;
     if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, ls, s)) < 0) return fail(st);
     const int nl = (int)ls.level_ptr.size() - 1;

@@ -1,0 +1,484 @@
+// Bandwidth-reducing symmetric reordering of the system matrix, computed on the device: P A P^T with P the reverse
+// Cuthill-McKee order.  A pressure matrix whose numbering scatters neighbours (an OpenFOAM mesh after refinement, the
+// scrambled stand-in of BASELINE config 3) makes every x[col] of the SpMV its own 128-byte line; in RCM order the
+// columns of a 256-row block fall into a few runs again, so the x-tile kernel applies.
+//
+//   1. breadth-first level structure from a pseudo-peripheral vertex (George-Liu: repeat the search from a
+//      minimum-degree vertex of the last level while the eccentricity grows), frontier by frontier, the frontier
+//      sizes and offsets living on the device (no host round trip per level);
+//   2. Cuthill-McKee positions inside the level structure, level by level: a vertex is keyed by the position of its
+//      first-numbered neighbour in the previous level, vertices with the same key are ranked by (degree, index);
+//      three small launches per level and no sort: children are counted per parent, the counts scanned, siblings ranked
+//      by looking at the parent's neighbour list.  The result depends only on the graph and the start vertex;
+//   3. reverse, permute the matrix (thread per row: relabel, insertion sort by the new column).
+// Further connected components are appended in the same way (at most kMaxComponents searches; whatever is left then
+// keeps its relative order at the end).
+#include <algorithm>
+#include <vector>
+
+#include "dpcg_host.h"
+#include "dpcg_prims.h"
+
+namespace dpcg {
+
+namespace {
+constexpr int kMaxComponents = 64;
+constexpr int kBfsGrid = 512;        // persistent-style grid of a frontier step
+constexpr int kBfsBatch = 64;        // frontier steps enqueued between two looks at the frontier sizes
+
+inline int rows_grid(int64_t n, int cap = 8192) {
+    int64_t g = (n + kBlock - 1) / kBlock;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+__global__ __launch_bounds__(kBlock) void k_degrees(int64_t n, const int32_t *__restrict__ rp, int32_t *__restrict__ deg) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) deg[i] = rp[i + 1] - rp[i];
+}
+
+// best = min over the vertices v of list[lo..hi) (list == nullptr: all vertices) that are still unvisited when
+// `only_unvisited`, of (deg[v] << 32 | v)
+__global__ __launch_bounds__(kBlock) void k_min_degree(const int32_t *__restrict__ list, int64_t lo, int64_t hi,
+                                                       const int32_t *__restrict__ deg, const int32_t *__restrict__ level,
+                                                       int only_unvisited, unsigned long long *best) {
+    __shared__ unsigned long long sh[kBlock / 64];
+    unsigned long long m = ~0ull;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t k = lo + (int64_t)blockIdx.x * kBlock + threadIdx.x; k < hi; k += stride) {
+        const int v = list ? list[k] : (int)k;
+        if (only_unvisited && level[v] >= 0) continue;
+        const unsigned long long key = ((unsigned long long)(unsigned)deg[v] << 32) | (unsigned)v;
+        m = key < m ? key : m;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_down(m, off);
+        m = o < m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) m = sh[w] < m ? sh[w] : m;
+        if (m != ~0ull) atomicMin(best, m);
+    }
+}
+
+// seed a search: vertex v becomes the only member of level L, stored at order[at]
+__global__ void k_bfs_seed(int v, int L, int at, int32_t *level, int32_t *order, int32_t *start, int32_t *count) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        level[v] = L;
+        order[at] = v;
+        start[L] = at;
+        count[L] = 1;
+    }
+}
+
+// One frontier step: the vertices of level L (order[start[L] .. +count[L])) claim their unvisited neighbours for level
+// L + 1 and append them behind the frontier.  start[L] and count[L] are final when this kernel runs.
+__global__ __launch_bounds__(kBlock) void k_bfs_step(const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                     int32_t *level, int32_t *order, int32_t *start, int32_t *count, int L) {
+    const int s0 = start[L], c0 = count[L];
+    if (c0 == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) start[L + 1] = s0 + c0;
+    const int stride = gridDim.x * kBlock;
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < c0; idx += stride) {
+        const int v = order[s0 + idx];
+        for (int k = rp[v]; k < rp[v + 1]; ++k) {
+            const int u = ci[k];
+            if (u != v && level[u] < 0 && atomicCAS(&level[u], -1, L + 1) == -1)
+                order[s0 + c0 + atomicAdd(&count[L + 1], 1)] = u;
+        }
+    }
+}
+
+// Cuthill-McKee, step A for level L: key[u] = position of u's first-numbered neighbour in level L - 1; that parent's
+// child counter goes up by one.
+__global__ __launch_bounds__(kBlock) void k_cm_keys(const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                    const int32_t *__restrict__ level, const int32_t *__restrict__ order,
+                                                    const int32_t *__restrict__ pos, int32_t *__restrict__ key,
+                                                    int32_t *child, int s1, int c1, int L) {
+    const int stride = gridDim.x * kBlock;
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < c1; idx += stride) {
+        const int u = order[s1 + idx];
+        int mp = 0x7fffffff;
+        for (int k = rp[u]; k < rp[u + 1]; ++k) {
+            const int v = ci[k];
+            if (level[v] == L - 1) {
+                const int p = pos[v];
+                mp = p < mp ? p : mp;
+            }
+        }
+        key[u] = mp;
+        atomicAdd(&child[mp], 1);
+    }
+}
+
+// exclusive scan of child[lo .. lo+cnt) into base[lo .. lo+cnt), one workgroup
+__global__ __launch_bounds__(1024) void k_scan_range(const int32_t *__restrict__ child, int32_t *__restrict__ base, int lo, int cnt) {
+    __shared__ int sh[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < cnt; b0 += 1024) {
+        const int i = b0 + threadIdx.x;
+        const int v = i < cnt ? child[lo + i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < cnt) base[lo + i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+}
+
+// step B: final position of u = start of its level + children of earlier parents + rank among its siblings
+__global__ __launch_bounds__(kBlock) void k_cm_place(const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                     const int32_t *__restrict__ level, const int32_t *__restrict__ order,
+                                                     const int32_t *__restrict__ deg, const int32_t *__restrict__ key,
+                                                     const int32_t *__restrict__ base, const int32_t *vertex_at_prev,
+                                                     int32_t *__restrict__ pos, int32_t *vertex_at, int s1, int c1,
+                                                     int L) {
+    const int stride = gridDim.x * kBlock;
+    for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < c1; idx += stride) {
+        const int u = order[s1 + idx];
+        const int mp = key[u];
+        const int p = vertex_at_prev[mp];
+        const int du = deg[u];
+        int rank = 0;
+        for (int k = rp[p]; k < rp[p + 1]; ++k) {
+            const int w = ci[k];
+            if (w != u && level[w] == L && key[w] == mp) {
+                const int dw = deg[w];
+                if (dw < du || (dw == du && w < u)) ++rank;
+            }
+        }
+        const int np = s1 + base[mp] + rank;
+        pos[u] = np;
+        vertex_at[np] = u;
+    }
+}
+
+__global__ void k_cm_root(const int32_t *__restrict__ order, int32_t *pos, int32_t *vertex_at, int at) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int v = order[at];
+        pos[v] = at;
+        vertex_at[at] = v;
+    }
+}
+
+// vertices no search reached: flag them (for the scan that appends them in index order)
+__global__ __launch_bounds__(kBlock) void k_flag_unvisited(int64_t n, const int32_t *__restrict__ level, int32_t *__restrict__ flag) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) flag[i] = level[i] < 0 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_place_unvisited(int64_t n, const int32_t *__restrict__ level,
+                                                            const int32_t *__restrict__ offs, int at, int32_t *__restrict__ pos) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        if (level[i] < 0) pos[i] = at + offs[i];
+}
+
+// reverse Cuthill-McKee: new index of vertex u = n - 1 - pos[u]
+__global__ __launch_bounds__(kBlock) void k_finish_perm(int64_t n, const int32_t *__restrict__ pos, int32_t *__restrict__ perm,
+                                                        int32_t *__restrict__ iperm) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x; u < n; u += stride) {
+        const int r = (int)(n - 1 - pos[u]);
+        iperm[u] = r;
+        perm[r] = (int32_t)u;
+    }
+}
+
+// ---- applying a permutation ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_perm_lengths(int64_t n, const int32_t *__restrict__ perm,
+                                                         const int32_t *__restrict__ rp, int32_t *__restrict__ len) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r <= n; r += stride)
+        len[r] = r < n ? rp[perm[r] + 1] - rp[perm[r]] : 0;
+}
+
+// row r of P A P^T = row perm[r] of A with columns relabelled through iperm, sorted ascending (insertion sort in place:
+// rows are short; the values move with their columns, so every product of a row sum is the same number as before,
+// only their order in the sum follows the new column order)
+__global__ __launch_bounds__(kBlock) void k_perm_rows(int64_t n, const int32_t *__restrict__ perm,
+                                                      const int32_t *__restrict__ iperm, const int32_t *__restrict__ rp,
+                                                      const int32_t *__restrict__ ci, const double *__restrict__ v,
+                                                      const int32_t *__restrict__ nrp, int32_t *__restrict__ nci,
+                                                      double *__restrict__ nv) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) {
+        const int old = perm[r];
+        const int src = rp[old], len = rp[old + 1] - src, dst = nrp[r];
+        for (int k = 0; k < len; ++k) {
+            const int c = iperm[ci[src + k]];
+            const double x = v[src + k];
+            int q = dst + k;
+            while (q > dst && nci[q - 1] > c) {
+                nci[q] = nci[q - 1];
+                nv[q] = nv[q - 1];
+                --q;
+            }
+            nci[q] = c;
+            nv[q] = x;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_gather_vec(int64_t n, const int32_t *__restrict__ perm, const T *__restrict__ in,
+                                                       T *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) out[r] = in[perm[r]];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_scatter_vec(int64_t n, const int32_t *__restrict__ perm, const T *__restrict__ in,
+                                                        T *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) out[perm[r]] = in[r];
+}
+
+__global__ __launch_bounds__(kBlock) void k_relabel(int64_t count, const int32_t *__restrict__ map, int32_t *__restrict__ idx) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < count; k += stride) idx[k] = map[idx[k]];
+}
+
+// Locality of the x gather: distinct 128-byte lines of x (16 doubles) that the columns of each 256-row block touch,
+// summed over the blocks.  One workgroup per block, an open-addressing set in LDS.
+constexpr int kLineSetSlots = 8192;
+__global__ __launch_bounds__(kBlock) void k_block_lines(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                        int nrb, unsigned long long *total) {
+    __shared__ int set[kLineSetSlots];
+    __shared__ int distinct;
+    for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        for (int e = threadIdx.x; e < kLineSetSlots; e += kBlock) set[e] = -1;
+        if (threadIdx.x == 0) distinct = 0;
+        __syncthreads();
+        const int64_t r0 = (int64_t)rb * kStreamRows;
+        const int64_t r1 = r0 + kStreamRows < n ? r0 + kStreamRows : n;
+        const int lo = rp[r0], hi = rp[r1];
+        int mine = 0;
+        for (int k = lo + threadIdx.x; k < hi; k += kBlock) {
+            const int line = ci[k] >> 4;
+            unsigned h = ((unsigned)line * 2654435761u) & (kLineSetSlots - 1);
+            for (int probe = 0; probe < kLineSetSlots; ++probe) {
+                const int prev = atomicCAS(&set[h], -1, line);
+                if (prev == -1) {
+                    ++mine;
+                    break;
+                }
+                if (prev == line) break;
+                h = (h + 1) & (kLineSetSlots - 1);
+            }
+        }
+        if (mine) atomicAdd(&distinct, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(total, (unsigned long long)distinct);
+        __syncthreads();
+    }
+}
+
+template <typename T>
+struct Buf {
+    T *p = nullptr;
+    Buf() = default;
+    Buf(const Buf &) = delete;
+    Buf &operator=(const Buf &) = delete;
+    ~Buf() { dev_free(p); }
+    int alloc(int64_t count) { dev_free(p); return dev_alloc(&p, count); }
+    T *release() { T *q = p; p = nullptr; return q; }
+};
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+void launch_gather_f64(int64_t n, const int32_t *perm, const double *in, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_vec<double>, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, perm, in, out);
+}
+void launch_scatter_f64(int64_t n, const int32_t *perm, const double *in, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_scatter_vec<double>, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, perm, in, out);
+}
+void launch_gather_f32(int64_t n, const int32_t *perm, const float *in, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_vec<float>, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, perm, in, out);
+}
+void launch_scatter_f32(int64_t n, const int32_t *perm, const float *in, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_scatter_vec<float>, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, perm, in, out);
+}
+void launch_relabel(int64_t count, const int32_t *map, int32_t *idx, hipStream_t s) {
+    hipLaunchKernelGGL(k_relabel, dim3(rows_grid(count)), dim3(kBlock), 0, s, count, map, idx);
+}
+
+// lines * 128 bytes fetched for the x gather per byte of x values used: ~1 for banded blocks, 16 when every column is
+// its own line
+int gather_line_ratio(const CsrDev &A, double *ratio, hipStream_t s) {
+    *ratio = 0.0;
+    if (A.nnz <= 0) return DPCG_OK;
+    Buf<unsigned long long> total;
+    DPCG_TRY(total.alloc(1));
+    DPCG_HIP(hipMemsetAsync(total.p, 0, sizeof(unsigned long long), s));
+    const int nrb = (int)((A.n + kStreamRows - 1) / kStreamRows);
+    hipLaunchKernelGGL(k_block_lines, dim3(nrb < 4096 ? nrb : 4096), dim3(kBlock), 0, s, A.n, A.rowptr, A.col, nrb, total.p);
+    unsigned long long h = 0;
+    DPCG_HIP(hipMemcpyAsync(&h, total.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    DPCG_CHECK_LAUNCH();
+    *ratio = (double)h * 128.0 / ((double)A.nnz * 8.0);
+    return DPCG_OK;
+}
+
+// B = P A P^T for perm[new] = old, iperm[old] = new (device arrays); B owns its arrays.
+int permute_csr(const CsrDev &A, const int32_t *perm, const int32_t *iperm, CsrDev &B, hipStream_t s) {
+    const int64_t n = A.n;
+    B = CsrDev();
+    B.n = n;
+    B.nnz = A.nnz;
+    B.owned = true;
+    Buf<int32_t> len;
+    DPCG_TRY(len.alloc(n + 1));
+    DPCG_TRY(dev_alloc(&B.rowptr, n + 1));
+    DPCG_TRY(dev_alloc(&B.col, A.nnz));
+    DPCG_TRY(dev_alloc(&B.val, A.nnz));
+    hipLaunchKernelGGL(k_perm_lengths, dim3(rows_grid(n + 1)), dim3(kBlock), 0, s, n, perm, A.rowptr, len.p);
+    DPCG_TRY(exclusive_scan_i32(len.p, B.rowptr, n + 1, s));
+    hipLaunchKernelGGL(k_perm_rows, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, perm, iperm, A.rowptr, A.col, A.val, B.rowptr,
+                       B.col, B.val);
+    DPCG_HIP(hipStreamSynchronize(s));
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
+namespace {
+// Breadth-first search from `root` as level L0 at order position `at`.  Returns the number of levels found and the
+// number of vertices reached; start/count (host copies) are filled for the levels of this search.
+int bfs(const CsrDev &A, int root, int L0, int at, int32_t *level, int32_t *order, int32_t *start, int32_t *count,
+        std::vector<int32_t> &h_start, std::vector<int32_t> &h_count, int *n_levels, hipStream_t s) {
+    hipLaunchKernelGGL(k_bfs_seed, dim3(1), dim3(64), 0, s, root, L0, at, level, order, start, count);
+    int L = L0;
+    for (;;) {
+        for (int b = 0; b < kBfsBatch; ++b)
+            hipLaunchKernelGGL(k_bfs_step, dim3(kBfsGrid), dim3(kBlock), 0, s, A.rowptr, A.col, level, order, start, count, L + b);
+        L += kBfsBatch;
+        int32_t last = 0;
+        DPCG_HIP(hipMemcpyAsync(&last, count + L, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        if (last == 0 || (int64_t)L >= A.n + 1) break;
+    }
+    const int span = L - L0 + 1;
+    h_start.resize((size_t)span);
+    h_count.resize((size_t)span);
+    DPCG_HIP(hipMemcpyAsync(h_count.data(), count + L0, (size_t)span * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipMemcpyAsync(h_start.data(), start + L0, (size_t)span * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    int nl = 0;
+    while (nl < span && h_count[(size_t)nl] > 0) ++nl;
+    *n_levels = nl;
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+}  // namespace
+
+// perm_out[new] = old and iperm_out[old] = new (device, n entries each, owned by the caller afterwards).
+int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_components, hipStream_t s) {
+    const int64_t n = A.n;
+    if (n + 2 + kBfsBatch > 2147483000LL) return invalid("reordering: system too large");
+    Buf<int32_t> deg, level, order, start, count, pos, vertex_at, key, child, base, perm, iperm;
+    Buf<unsigned long long> best;
+    const int64_t nlv = n + 2 + 2 * kBfsBatch;
+    DPCG_TRY(deg.alloc(n)); DPCG_TRY(level.alloc(n)); DPCG_TRY(order.alloc(n + 1)); DPCG_TRY(start.alloc(nlv));
+    DPCG_TRY(count.alloc(nlv)); DPCG_TRY(pos.alloc(n)); DPCG_TRY(vertex_at.alloc(n + 1)); DPCG_TRY(key.alloc(n));
+    DPCG_TRY(child.alloc(n + 1)); DPCG_TRY(base.alloc(n + 1)); DPCG_TRY(perm.alloc(n)); DPCG_TRY(iperm.alloc(n));
+    DPCG_TRY(best.alloc(1));
+    hipLaunchKernelGGL(k_degrees, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, A.rowptr, deg.p);
+    DPCG_HIP(hipMemsetAsync(level.p, 0xff, (size_t)n * sizeof(int32_t), s));
+    DPCG_HIP(hipMemsetAsync(count.p, 0, (size_t)nlv * sizeof(int32_t), s));
+    DPCG_HIP(hipMemsetAsync(child.p, 0, (size_t)(n + 1) * sizeof(int32_t), s));
+    auto min_degree = [&](const int32_t *list, int64_t lo, int64_t hi, int only_unvisited, int *v) -> int {
+        DPCG_HIP(hipMemsetAsync(best.p, 0xff, sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k_min_degree, dim3(rows_grid(hi - lo, 1024)), dim3(kBlock), 0, s, list, lo, hi, deg.p, level.p,
+                           only_unvisited, best.p);
+        unsigned long long h = 0;
+        DPCG_HIP(hipMemcpyAsync(&h, best.p, sizeof(h), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        *v = h == ~0ull ? -1 : (int)(h & 0xffffffffu);
+        return DPCG_OK;
+    };
+    std::vector<int32_t> h_start, h_count;
+    struct Comp { int L0, nl; std::vector<int32_t> start, count; };
+    std::vector<Comp> comps;
+    int visited = 0, next_level = 0;
+    while (visited < n && (int)comps.size() < kMaxComponents) {
+        int root = -1;
+        DPCG_TRY(min_degree(nullptr, 0, n, 1, &root));
+        if (root < 0) break;
+        int nl = 0;
+        DPCG_TRY(bfs(A, root, next_level, visited, level.p, order.p, start.p, count.p, h_start, h_count, &nl, s));
+        if (comps.empty()) {
+            // pseudo-peripheral start vertex for the first (normally the only) component
+            for (int sweep = 0; sweep < 4; ++sweep) {
+                const int last = nl - 1;
+                int cand = -1;
+                DPCG_TRY(min_degree(order.p, h_start[(size_t)last], (int64_t)h_start[(size_t)last] + h_count[(size_t)last], 0, &cand));
+                if (cand < 0 || cand == root) break;
+                // search again from the candidate: forget this component
+                DPCG_HIP(hipMemsetAsync(level.p, 0xff, (size_t)n * sizeof(int32_t), s));
+                DPCG_HIP(hipMemsetAsync(count.p, 0, (size_t)nlv * sizeof(int32_t), s));
+                int nl2 = 0;
+                std::vector<int32_t> st2, ct2;
+                DPCG_TRY(bfs(A, cand, next_level, visited, level.p, order.p, start.p, count.p, st2, ct2, &nl2, s));
+                const bool deeper = nl2 > nl;
+                root = cand;
+                nl = nl2;
+                h_start.swap(st2);
+                h_count.swap(ct2);
+                if (!deeper) break;
+            }
+        }
+        Comp c;
+        c.L0 = next_level;
+        c.nl = nl;
+        c.start.assign(h_start.begin(), h_start.begin() + nl);
+        c.count.assign(h_count.begin(), h_count.begin() + nl);
+        int reached = 0;
+        for (int l = 0; l < nl; ++l) reached += c.count[(size_t)l];
+        visited += reached;
+        next_level += nl;
+        // later searches index count[] / start[] from next_level on: clear what this search's empty tail steps touched
+        comps.push_back(std::move(c));
+    }
+    // Cuthill-McKee positions, component by component, level by level
+    for (const Comp &c : comps) {
+        hipLaunchKernelGGL(k_cm_root, dim3(1), dim3(64), 0, s, order.p, pos.p, vertex_at.p, c.start[0]);
+        for (int l = 1; l < c.nl; ++l) {
+            const int L = c.L0 + l, s1 = c.start[(size_t)l], c1 = c.count[(size_t)l];
+            const int s0 = c.start[(size_t)l - 1], c0 = c.count[(size_t)l - 1];
+            const int g = rows_grid(c1, 1024);
+            hipLaunchKernelGGL(k_cm_keys, dim3(g), dim3(kBlock), 0, s, A.rowptr, A.col, level.p, order.p, pos.p, key.p, child.p,
+                               s1, c1, L);
+            hipLaunchKernelGGL(k_scan_range, dim3(1), dim3(1024), 0, s, child.p, base.p, s0, c0);
+            hipLaunchKernelGGL(k_cm_place, dim3(g), dim3(kBlock), 0, s, A.rowptr, A.col, level.p, order.p, deg.p, key.p, base.p,
+                               vertex_at.p, pos.p, vertex_at.p, s1, c1, L);
+        }
+    }
+    if (visited < n) {   // more components than searches: the rest keeps its relative order at the end
+        Buf<int32_t> flag, offs;
+        DPCG_TRY(flag.alloc(n));
+        DPCG_TRY(offs.alloc(n));
+        hipLaunchKernelGGL(k_flag_unvisited, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, level.p, flag.p);
+        DPCG_TRY(exclusive_scan_i32(flag.p, offs.p, n, s));
+        hipLaunchKernelGGL(k_place_unvisited, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, level.p, offs.p, visited, pos.p);
+    }
+    hipLaunchKernelGGL(k_finish_perm, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, pos.p, perm.p, iperm.p);
+    DPCG_HIP(hipStreamSynchronize(s));
+    DPCG_CHECK_LAUNCH();
+    if (n_components) *n_components = (int)comps.size() + (visited < n ? 1 : 0);
+    *perm_out = perm.release();
+    *iperm_out = iperm.release();
+    return DPCG_OK;
+}
+
+}  // namespace dpcg

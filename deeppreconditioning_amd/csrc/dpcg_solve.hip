@@ -224,8 +224,19 @@ struct Solve {
         use_graph = !(flags & DPCG_NO_GRAPH) && !x_true && max_iter >= chunk;
         if (use_graph) DPCG_TRY(ensure_graph(h, flags, chunk));
         *ex.prog_host = 0;
+        if (h->perm) {                     // b, x0, x_true arrive in the caller's numbering
+            if (!h->pb) DPCG_TRY(dev_alloc(&h->pb, n));
+            launch_gather_f64(n, h->perm, b, h->pb, s);
+            b = h->pb;
+            if (x_true) {
+                if (!h->pxt) DPCG_TRY(dev_alloc(&h->pxt, n));
+                launch_gather_f64(n, h->perm, x_true, h->pxt, s);
+                x_true = h->pxt;
+            }
+        }
         if (x0) {
-            DPCG_HIP(hipMemcpyAsync(h->x, x0, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+            if (h->perm) launch_gather_f64(n, h->perm, x0, h->x, s);
+            else DPCG_HIP(hipMemcpyAsync(h->x, x0, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
             launch_spmv(h->A, h->planA, h->x, h->q, nullptr, nullptr, s);
             launch_residual(n, b, h->q, h->r, h->vec_grid, s);                       // cg.py:60
         } else {
@@ -315,7 +326,10 @@ struct Solve {
         }
         // x is handed over in stream order: the copy is enqueued on the caller's stream, a second host sync is only
         // needed for the host-side history buffers
-        if (x) DPCG_HIP(hipMemcpyAsync(x, h->x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        if (x) {
+            if (h->perm) launch_scatter_f64(n, h->perm, h->x, x, s);       // back to the caller's numbering
+            else DPCG_HIP(hipMemcpyAsync(x, h->x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
         if (pending) DPCG_HIP(hipStreamSynchronize(s));
         DPCG_CHECK_LAUNCH();
         return sc.status;
@@ -329,7 +343,7 @@ struct Solve {
 static bool small_eligible(const dpcg_system *h, int flags, const double *x_true) {
     static const bool enabled = [] { const char *e = getenv("DPCG_SMALL"); return !(e && e[0] == '0'); }();
     if (!enabled || x_true || (flags & (DPCG_SPMV_F32 | DPCG_NO_SMALL))) return false;
-    if (h->A.n > kSmallMaxN) return false;
+    if (h->A.n > kSmallMaxN || h->perm) return false;
     return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI || h->precond == DPCG_PRECOND_CSR ||
            h->precond == DPCG_PRECOND_LLT_MULTIPLY;
 }

@@ -267,13 +267,22 @@ class SolveResult:
     err_history: np.ndarray | None = None
 
 
+_REORDER_MODES = {None: L.REORDER_NONE, False: L.REORDER_NONE, "none": L.REORDER_NONE, "auto": L.REORDER_AUTO,
+                  "rcm": L.REORDER_ALWAYS, True: L.REORDER_ALWAYS}
+
+
 class CsrSystem:
     """The operator A of `A @ v` (cg.py:60,75) as a CSR matrix resident in HBM.
 
     rowptr/col int32, val float64 or float32 CUDA tensors are borrowed (kept alive here).
+
+    `reorder`: "auto" (default) lets the library iterate on P A P^T in reverse Cuthill-McKee order when the numbering
+    scatters neighbours (large system, x-tile plan failed, measured x-gather traffic > 4x the bytes used: the
+    OpenFOAM-like case of BASELINE config 3); "rcm" forces it, None / "none" never reorders.  Everything the caller
+    passes or receives -- b, x0, x, `@`, dinv, M, L -- stays in the caller's numbering (`dpcg_reorder`, include/dpcg.h).
     """
 
-    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: int):
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, n: int, reorder="auto"):
         if not (rowptr.is_cuda and col.is_cuda and val.is_cuda):
             raise ValueError("CsrSystem expects CUDA tensors; use CsrSystem.from_host / from_any for host data")
         if rowptr.dtype != torch.int32 or col.dtype != torch.int32:
@@ -292,10 +301,28 @@ class CsrSystem:
                                         _dev_ptr(self._keep[1]), _dev_ptr(self._keep[2]),
                                         L.F64 if val.dtype == torch.float64 else L.F32, L.DEVICE, 0, _stream()))
         self._precond: Preconditioner | None = None
+        self._reorder(reorder)
+
+    def _reorder(self, mode) -> None:
+        if mode not in _REORDER_MODES:
+            raise ValueError("reorder must be 'auto', 'rcm' or None")
+        applied = C.c_int(0)
+        if _REORDER_MODES[mode] != L.REORDER_NONE:
+            with torch.cuda.device(self.device):
+                L.check(L.lib().dpcg_reorder(self._h, _REORDER_MODES[mode], _stream(), C.byref(applied)))
+        self.reordered = bool(applied.value)
+
+    def permutation(self):
+        """perm (numpy int32, perm[new] = old) of a reordered system -- row `new` of the matrix the library iterates on is
+        the caller's row `old` -- or None."""
+        flag = C.c_int(0)
+        perm = np.empty(self.n, dtype=np.int32)
+        L.check(L.lib().dpcg_get_permutation(self._h, C.byref(flag), _np_ptr(perm), None))
+        return perm if flag.value else None
 
     # -- constructors ----------------------------------------------------------------------
     @classmethod
-    def from_host(cls, rowptr: np.ndarray, col: np.ndarray, val: np.ndarray, n: int, device=None) -> "CsrSystem":
+    def from_host(cls, rowptr: np.ndarray, col: np.ndarray, val: np.ndarray, n: int, device=None, reorder="auto") -> "CsrSystem":
         self = cls.__new__(cls)
         self._keep = ()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -309,19 +336,17 @@ class CsrSystem:
             L.check(L.lib().dpcg_create(C.byref(self._h), self.n, self.nnz, _np_ptr(rowptr), _np_ptr(col), _np_ptr(val),
                                         dt, L.HOST, 1, _stream()))
         self._precond = None
+        self._reorder(reorder)
         return self
 
     @classmethod
-    def from_any(cls, A, device=None, reorder: str | None = None):
-        """`reorder="rcm"` returns a `ReorderedSystem` (same `solve` / `@` / `set_preconditioner` surface)."""
-        if reorder:
-            return ReorderedSystem(A, device, reorder)
-        if isinstance(A, (CsrSystem, ReorderedSystem)):
+    def from_any(cls, A, device=None, reorder="auto"):
+        if isinstance(A, CsrSystem):
             return A
         space, rp, ci, v, n = csr_arrays(A)
         if space == "host":
-            return cls.from_host(rp, ci, v, n, device)
-        return cls(rp, ci, v, n)
+            return cls.from_host(rp, ci, v, n, device, reorder)
+        return cls(rp, ci, v, n, reorder)
 
     # -- bookkeeping -------------------------------------------------------------------------
     @property
@@ -333,8 +358,10 @@ class CsrSystem:
         k, pk, ll, lu = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         L.check(L.lib().dpcg_get_info(self._h, C.byref(n), C.byref(nnz), C.byref(k), C.byref(pk), C.byref(pn),
                                       C.byref(ll), C.byref(lu)))
+        flag, ratio = C.c_int(0), C.c_double(0.0)
+        L.check(L.lib().dpcg_get_permutation(self._h, C.byref(flag), None, C.byref(ratio)))
         return {"n": n.value, "nnz": nnz.value, "spmv_kernel": ("stream", "vector", "tile")[k.value & 15],
-                "two_kernel_updates": bool(k.value & 16),
+                "two_kernel_updates": bool(k.value & 16), "reordered": bool(flag.value), "gather_ratio": ratio.value,
                 "precond": pk.value, "precond_nnz": pn.value, "levels_lower": ll.value, "levels_upper": lu.value}
 
     def close(self) -> None:
@@ -427,63 +454,6 @@ class CsrSystem:
         k = iters.value
         return SolveResult(x, k, status, res.value, sec.value, hist[: k + 1] if hist is not None else np.empty(0),
                            err[: k + 1] if err is not None else None)
-
-
-class ReorderedSystem:
-    """A system solved in a bandwidth-reducing symmetric ordering: P A P^T (P x) = P b.
-
-    Matrices whose numbering scatters neighbours (the scrambled stand-in for OpenFOAM dumps, a mesh after
-    refinement) make every x[col] of the SpMV a separate 128-B line; reverse Cuthill-McKee brings the columns of a
-    row-block back into a few contiguous runs (and makes the x-tile kernel applicable).  The permutation is setup
-    work on the host (scipy); b is gathered and x scattered on the device around the solve.  Only preconditioners
-    that are built from A itself (None, Jacobi(), IC0(...)) can be attached: a user-supplied M or L refers to the
-    original numbering.  PCG is invariant under symmetric permutation up to the order of the floating-point sums,
-    so iteration counts match the unpermuted solve wherever the recurrence is numerically stable.
-    """
-
-    def __init__(self, A, device=None, method: str = "rcm"):
-        if method != "rcm":
-            raise ValueError("only 'rcm' is implemented")
-        import scipy.sparse as sp
-        from scipy.sparse.csgraph import reverse_cuthill_mckee
-        space, rp, ci, v, n = csr_arrays(A)
-        if space == "device":
-            rp, ci, v = rp.cpu().numpy(), ci.cpu().numpy(), v.cpu().numpy()
-        M = sp.csr_matrix((v, ci, rp), shape=(n, n))
-        perm = np.asarray(reverse_cuthill_mckee(M, symmetric_mode=True), dtype=np.int64)
-        B = M[perm][:, perm].tocsr()
-        B.sort_indices()
-        self.system = CsrSystem.from_host(B.indptr, B.indices, B.data, n, device)
-        self.device, self.n, self.nnz = self.system.device, n, self.system.nnz
-        self.perm = torch.from_numpy(perm).to(self.device)
-        self.bandwidth = int(np.abs(B.tocoo().row - B.tocoo().col).max())
-
-    def _in(self, v):
-        return None if v is None else self.system._vec(v)[self.perm]
-
-    def _out(self, v):
-        out = torch.empty_like(v)
-        out[self.perm] = v
-        return out
-
-    def info(self) -> dict:
-        return dict(self.system.info(), bandwidth=self.bandwidth, reordered="rcm")
-
-    def set_preconditioner(self, M):
-        if not (M is None or isinstance(M, (Identity, IC0)) or (isinstance(M, Jacobi) and M.dinv is None)):
-            raise TypeError("a reordered system only takes preconditioners built from A itself: None, Jacobi(), IC0(...)")
-        return self.system.set_preconditioner(M)
-
-    def __matmul__(self, v):
-        return self._out(self.system @ self._in(v))
-
-    def solve(self, b, x0=None, *, x_true=None, **kw) -> "SolveResult":
-        res = self.system.solve(self._in(b), self._in(x0), x_true=self._in(x_true), **kw)
-        res.x = self._out(res.x)
-        return res
-
-    def close(self):
-        self.system.close()
 
 
 def dot(a: torch.Tensor, b: torch.Tensor) -> float:

@@ -87,6 +87,25 @@ int dpcg_destroy(dpcg_handle_t h);
 int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spmv_kernel, int *precond_kind,
                   int64_t *precond_nnz, int *n_levels_lower, int *n_levels_upper);
 
+/* ---- bandwidth-reducing reordering (BASELINE config 3: unstructured OpenFOAM numbering) ------------------------
+ * The reference hands the solver whatever numbering the mesh generator produced (generate_data.py:67-74 reads the
+ * OpenFOAM dump as is); a numbering that scatters neighbours makes every x[col] of `A @ p` (cg.py:75) its own cache
+ * line.  dpcg_reorder computes a reverse Cuthill-McKee order ON THE DEVICE and lets the handle iterate on P A P^T.
+ * Transparent to the caller: b, x0, x, x_true, dinv, M and L keep the CALLER's numbering in every call (vectors are
+ * gathered / scattered on the device, matrices permuted at setup; an IC(0) / L factor is the factor of the caller's
+ * matrix, its level schedule merely relabelled).  Call it before attaching a preconditioner (an attached one is
+ * dropped).  mode: DPCG_REORDER_AUTO reorders only when the x-tile plan failed on a large system AND the measured
+ * x-gather traffic (distinct 128-byte lines per 256-row block) exceeds 4x the bytes used; DPCG_REORDER_ALWAYS always.
+ * *applied (may be NULL) = 1 when the handle now iterates on a reordered matrix.
+ * PCG is invariant under symmetric permutation up to the order of floating-point sums: iterates agree with the
+ * unpermuted solve to rounding, and to 1e-10 with the CPU reference run on P A P^T (dpcg_get_permutation). */
+enum dpcg_reorder_mode { DPCG_REORDER_NONE = 0, DPCG_REORDER_AUTO = 1, DPCG_REORDER_ALWAYS = 2 };
+int dpcg_reorder(dpcg_handle_t h, int mode, dpcg_stream_t stream, int *applied);
+/* *reordered = 0/1; perm_host (may be NULL): int32[n], perm[new] = old (row `new` of the iterated matrix is the
+ * caller's row `old`); gather_ratio (may be NULL): x-gather line traffic / bytes used of the caller's matrix, as
+ * measured by the last dpcg_reorder call (0 if never measured). */
+int dpcg_get_permutation(dpcg_handle_t h, int *reordered, int32_t *perm_host, double *gather_ratio);
+
 /* ---- preconditioner M (test.py:70-105) ------------------------------------------------------- */
 int dpcg_set_precond_none(dpcg_handle_t h);
 /* dinv = NULL: 1/diag(A) is extracted on the device (test.py:76). */
