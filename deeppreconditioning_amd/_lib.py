@@ -60,6 +60,8 @@ SIGNATURES = {
     "dpcg_gen_poisson": (_int, [_int, _i64, _p, _p, _p, _int, _p]),
     "dpcg_batched_coo_spmv": (_int, [_i64, _p, _p, _int, _i64, _p, _p, _int, _p]),
     "dpcg_batched_coo_edge": (_int, [_i64, _p, _int, _i64, _p, _p, _p, _int, _p]),
+    "dpcg_batched_coo_spmm": (_int, [_i64, _p, _p, _int, _i64, _int, _p, _p, _int, _p]),
+    "dpcg_batched_coo_sddmm": (_int, [_i64, _p, _int, _i64, _int, _p, _p, _p, _int, _p]),
     "dpcg_coo_to_csr": (_int, [_i64, _i64, _p, _p, _p, _p, _p, _p, C.POINTER(_i64), _p]),
 }
 

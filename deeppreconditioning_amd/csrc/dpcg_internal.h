@@ -27,6 +27,7 @@ constexpr int kTileChunk = 64;        // x is staged in LDS in chunks of 64 doub
 constexpr int kTileMaxChunks = 40;    // at most 40 chunks (20 KiB) per 256-row block
 constexpr int kRingMaxLevels = 8192;   // levels per LDS-ring segment (their offsets are staged in LDS)
 constexpr int kTileMinBlocks = 1536;   // fewest 256-row blocks for which the x-tile SpMV is chosen
+constexpr int kReorderMinRows = 65536;  // DPCG_REORDER_AUTO leaves smaller systems alone (x stays cache-resident anyway)
 constexpr int kTileTableMax = 4096;   // chunk-id span a block may cover (262,144 columns)
 
 struct CsrDev {
@@ -299,6 +300,10 @@ void launch_tril_copy(int64_t n, const int32_t *rp, const int32_t *ci, const dou
 void launch_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void *val, int val_dtype, hipStream_t s);
 void launch_batched_coo_edge(int64_t nnz, const int32_t *indices, int batch, int64_t dof, const float *a, const float *c,
                              float *out, int transpose, hipStream_t s);
+void launch_batched_coo_spmm(int64_t nnz, const int32_t *indices, const float *features, int batch, int64_t dof, int ncols,
+                             const float *B, float *out, int transpose, hipStream_t s);
+void launch_batched_coo_sddmm(int64_t nnz, const int32_t *indices, int batch, int64_t dof, int ncols, const float *G,
+                              const float *B, float *out, int transpose, hipStream_t s);
 void launch_batched_coo_spmv(int64_t nnz, const int32_t *indices, const float *features, int batch, int64_t dof,
                              const float *vectors, float *out, int transpose, hipStream_t s);
 

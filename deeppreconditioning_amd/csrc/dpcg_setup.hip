@@ -119,6 +119,69 @@ __global__ __launch_bounds__(kBlock) void k_batched_coo_edge(int64_t nnz, const 
     }
 }
 
+// The same two operators with `ncols` right-hand sides per sample (row-major panels B[b, row, c]): what the sparse form of
+// `inverse_loss` (metrics.py:34-55) is made of -- L^T (A[:, J]) and L (.) on a panel of columns J instead of dense N x N
+// products.  One lane per (triple, column): consecutive lanes take consecutive columns of a panel row (coalesced).
+__global__ __launch_bounds__(kBlock) void k_batched_coo_spmm(int64_t nnz, const int32_t *__restrict__ idx,
+                                                             const float *__restrict__ feat, int batch, int64_t dof,
+                                                             int ncols, const float *__restrict__ B,
+                                                             float *__restrict__ out, int transpose) {
+    const int64_t total = nnz * ncols;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+        const int64_t k = t / ncols;
+        const int c = (int)(t - k * ncols);
+        const int b = idx[3 * k];
+        const int r = idx[3 * k + (transpose ? 2 : 1)];
+        const int cc = idx[3 * k + (transpose ? 1 : 2)];
+        if (b < 0 || b >= batch || r < 0 || r >= dof || cc < 0 || cc >= dof) continue;
+        const float f = feat[k];
+        if (f == 0.0f) continue;                        // explicit zeros (the masked upper triangle of the network output)
+        atomicAdd(out + ((int64_t)b * dof + r) * ncols + c, f * B[((int64_t)b * dof + cc) * ncols + c]);
+    }
+}
+
+// out[k] = sum_c G[b, row_k, c] * B[b, col_k, c]: the gradient of the panel product with respect to entry k.
+// One wave per triple, lanes over the columns, fixed-order wave sum.
+__global__ __launch_bounds__(kBlock) void k_batched_coo_sddmm(int64_t nnz, const int32_t *__restrict__ idx, int batch,
+                                                              int64_t dof, int ncols, const float *__restrict__ G,
+                                                              const float *__restrict__ B, float *__restrict__ out,
+                                                              int transpose) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    for (int64_t k = wave; k < nnz; k += nwaves) {
+        const int b = idx[3 * k];
+        const int r = idx[3 * k + (transpose ? 2 : 1)];
+        const int cc = idx[3 * k + (transpose ? 1 : 2)];
+        float acc = 0.0f;
+        if (b >= 0 && b < batch && r >= 0 && r < dof && cc >= 0 && cc < dof) {
+            const float *g = G + ((int64_t)b * dof + r) * ncols, *v = B + ((int64_t)b * dof + cc) * ncols;
+            for (int c = lane; c < ncols; c += 64) acc += g[c] * v[c];
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if (lane == 0) out[k] = acc;
+    }
+}
+
+void launch_batched_coo_spmm(int64_t nnz, const int32_t *indices, const float *features, int batch, int64_t dof, int ncols,
+                             const float *B, float *out, int transpose, hipStream_t s) {
+    int64_t g = (nnz * ncols + kBlock - 1) / kBlock;
+    if (g > 16384) g = 16384;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_batched_coo_spmm, dim3((int)g), dim3(kBlock), 0, s, nnz, indices, features, batch, dof, ncols, B,
+                       out, transpose);
+}
+
+void launch_batched_coo_sddmm(int64_t nnz, const int32_t *indices, int batch, int64_t dof, int ncols, const float *G,
+                              const float *B, float *out, int transpose, hipStream_t s) {
+    int64_t g = (nnz * 64 + kBlock - 1) / kBlock;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_batched_coo_sddmm, dim3((int)g), dim3(kBlock), 0, s, nnz, indices, batch, dof, ncols, G, B, out,
+                       transpose);
+}
+
 void launch_batched_coo_edge(int64_t nnz, const int32_t *indices, int batch, int64_t dof, const float *a, const float *c,
                              float *out, int transpose, hipStream_t s) {
     int64_t g = (nnz + kBlock - 1) / kBlock;

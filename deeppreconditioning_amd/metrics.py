@@ -1,15 +1,17 @@
 """Losses of `uibk/deep_preconditioning/metrics.py` that touch the hot-path operators.
 
 `frobenius_loss` runs on the HIP batched COO SpMV and is differentiable with respect to the network output
-(`utils._SparseMatvec`); `inverse_loss` is the dense O(N^3) restatement of the reference (the loss actually
-trained, train.py:59), plain torch ops on the GPU, kept for completeness at the reference's sizes.
+(`utils._SparseMatvec`).  `inverse_loss` -- the loss the reference actually trains (train.py:59) -- never forms the
+dense N x N matrices of metrics.py:45-55: || L L^T A - I ||_F is accumulated over panels of columns J as
+L (L^T A[:, J]) - I[:, J] with the HIP panel kernels (`utils._SparseMatmat`), O(N nnz(L)) work and O(N |J|) memory, and
+is differentiable with respect to L's entries.  `inverse_loss_dense` is the reference's dense form, kept as the checker.
 """
 
 from __future__ import annotations
 
 import torch
 
-from .utils import sparse_matvec_mul
+from .utils import sparse_matmat_mul, sparse_matvec_mul
 
 
 def frobenius_loss(lower_triangular, solution: torch.Tensor, right_hand_side: torch.Tensor) -> torch.Tensor:
@@ -19,8 +21,46 @@ def frobenius_loss(lower_triangular, solution: torch.Tensor, right_hand_side: to
     return torch.linalg.vector_norm(interim - right_hand_side, ord=2, dim=1).sum()
 
 
-def inverse_loss(systems_tril, preconditioners_tril) -> torch.Tensor:
-    """mean_b || L_b L_b^T A_b - I ||_F with dense matrices (metrics.py:34-55)."""
+def inverse_loss(systems_tril, preconditioners_tril, panel_columns: int = 256) -> torch.Tensor:
+    """mean_b || L_b L_b^T A_b - I ||_F (metrics.py:34-55) on the sparse operands.
+
+    `systems_tril` holds the lower triangles of the (symmetric) systems, `preconditioners_tril` the factors L, both as
+    (batch, row, col) triples with one feature (spconv `SparseConvTensor` / `SparseBatch`).  For each panel of
+    `panel_columns` columns J the dense slice A[:, J] (mirrored across the diagonal, metrics.py:49) is scattered from
+    the triples, R = L (L^T A[:, J]) - I[:, J] is formed by two panel products and its squared entries are summed; the
+    Frobenius norm is the root of the total (torch.linalg.matrix_norm's default), then the batch mean (metrics.py:55).
+    """
+    feats = preconditioners_tril.features
+    if not feats.is_cuda:
+        raise ValueError("inverse_loss runs on the GPU (HIP panel kernels); inverse_loss_dense is the dense restatement")
+    dev = feats.device
+    batch = systems_tril.batch_size
+    dof = int(systems_tril.spatial_shape[0])
+    idx = systems_tril.indices.to(device=dev).long()
+    val = systems_tril.features.to(device=dev, dtype=torch.float32).reshape(-1)
+    b_, r_, c_ = idx[:, 0], idx[:, 1], idx[:, 2]
+    low = r_ > c_                                        # strictly lower entries are mirrored (metrics.py:49)
+    ab = torch.cat((b_, b_[low]))
+    ar = torch.cat((r_, c_[low]))
+    ac = torch.cat((c_, r_[low]))
+    av = torch.cat((val, val[low]))
+    total = torch.zeros(batch, dtype=torch.float32, device=dev)
+    for j0 in range(0, dof, panel_columns):
+        jn = min(panel_columns, dof - j0)
+        sel = (ac >= j0) & (ac < j0 + jn)
+        panel = torch.zeros((batch, dof, jn), dtype=torch.float32, device=dev)
+        panel.index_put_((ab[sel], ar[sel], ac[sel] - j0), av[sel], accumulate=True)      # A[:, J]
+        t = sparse_matmat_mul(preconditioners_tril, panel, transpose=True)               # L^T A[:, J]
+        u = sparse_matmat_mul(preconditioners_tril, t, transpose=False)                  # L (L^T A[:, J])
+        eye = torch.zeros((dof, jn), dtype=torch.float32, device=dev)
+        eye[torch.arange(j0, j0 + jn, device=dev), torch.arange(jn, device=dev)] = 1.0
+        total = total + ((u - eye.unsqueeze(0)) ** 2).sum(dim=(1, 2))
+    return total.sqrt().mean()
+
+
+def inverse_loss_dense(systems_tril, preconditioners_tril) -> torch.Tensor:
+    """The reference's form, mean_b || L_b L_b^T A_b - I ||_F with dense N x N matrices (metrics.py:34-55): O(N^3);
+    the checker of `inverse_loss`."""
     pre = preconditioners_tril.dense()[:, 0]
     pre = torch.matmul(pre, pre.transpose(-1, -2))
     systems = systems_tril.dense()[:, 0]

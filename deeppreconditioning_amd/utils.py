@@ -46,6 +46,54 @@ class _SparseMatvec(torch.autograd.Function):
         return g_feat, g_vec, None, None
 
 
+def _coo_spmm(idx, feat, panel, transpose: bool) -> torch.Tensor:
+    batch, dof, ncols = panel.shape
+    out = torch.empty_like(panel)
+    with torch.cuda.device(panel.device):
+        L.check(L.lib().dpcg_batched_coo_spmm(idx.shape[0], _dev_ptr(idx), _dev_ptr(feat), batch, dof, ncols, _dev_ptr(panel),
+                                              _dev_ptr(out), 1 if transpose else 0, _stream()))
+    return out
+
+
+class _SparseMatmat(torch.autograd.Function):
+    """Y[b] = A[b] P[b] (or A[b]^T P[b]) for a panel P of `ncols` columns per sample -- `_SparseMatvec` with several
+    right-hand sides; gradients: dL/dP = A^T G (same kernel, `transpose` flipped), dL/dfeature_k = <G[b,row_k,:],
+    P[b,col_k,:]> (dpcg_batched_coo_sddmm).  Used by `metrics.inverse_loss`."""
+
+    @staticmethod
+    def forward(ctx, feat, panel, idx, transpose):
+        ctx.save_for_backward(feat, panel, idx)
+        ctx.transpose = bool(transpose)
+        return _coo_spmm(idx, feat, panel, ctx.transpose)
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, panel, idx = ctx.saved_tensors
+        g = g.contiguous()
+        g_feat = g_panel = None
+        if ctx.needs_input_grad[0]:
+            g_feat = torch.empty_like(feat)
+            batch, dof, ncols = panel.shape
+            with torch.cuda.device(panel.device):
+                L.check(L.lib().dpcg_batched_coo_sddmm(idx.shape[0], _dev_ptr(idx), batch, dof, ncols, _dev_ptr(g),
+                                                       _dev_ptr(panel), _dev_ptr(g_feat), 1 if ctx.transpose else 0, _stream()))
+        if ctx.needs_input_grad[1]:
+            g_panel = _coo_spmm(idx, feat, g, not ctx.transpose)
+        return g_feat, g_panel, None, None
+
+
+def sparse_matmat_mul(spconv_batch, panel: torch.Tensor, transpose: bool) -> torch.Tensor:
+    """`sparse_matvec_mul` for a panel (batch, dof, ncols) of right-hand sides, differentiable."""
+    if not panel.is_cuda:
+        raise ValueError("sparse_matmat_mul runs on the GPU: the panel must be a CUDA tensor")
+    dev = panel.device
+    idx = spconv_batch.indices.to(device=dev, dtype=torch.int32).contiguous()
+    feat = spconv_batch.features.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+    if panel.shape[0] != spconv_batch.batch_size:
+        raise ValueError("batch size mismatch")
+    return _SparseMatmat.apply(feat, panel.to(torch.float32).contiguous(), idx, bool(transpose))
+
+
 def sparse_matvec_mul(spconv_batch, vector_batch: torch.Tensor, transpose: bool) -> torch.Tensor:
     """Batched sparse matrix-vector product on COO triples (utils.py:15-43), differentiable.
 

@@ -94,8 +94,9 @@ int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spmv_kernel, i
  * Transparent to the caller: b, x0, x, x_true, dinv, M and L keep the CALLER's numbering in every call (vectors are
  * gathered / scattered on the device, matrices permuted at setup; an IC(0) / L factor is the factor of the caller's
  * matrix, its level schedule merely relabelled).  Call it before attaching a preconditioner (an attached one is
- * dropped).  mode: DPCG_REORDER_AUTO reorders only when the x-tile plan failed on a large system AND the measured
- * x-gather traffic (distinct 128-byte lines per 256-row block) exceeds 4x the bytes used; DPCG_REORDER_ALWAYS always.
+ * dropped).  mode: DPCG_REORDER_AUTO reorders only when the system has >= 65536 rows, its SpMV plan is the gather
+ * kernel (no x-tile plan) AND the measured x-gather traffic (distinct 128-byte lines per 256-row block) exceeds 4x
+ * the bytes used; DPCG_REORDER_ALWAYS always.
  * *applied (may be NULL) = 1 when the handle now iterates on a reordered matrix.
  * PCG is invariant under symmetric permutation up to the order of floating-point sums: iterates agree with the
  * unpermuted solve to rounding, and to 1e-10 with the CPU reference run on P A P^T (dpcg_get_permutation). */
@@ -174,6 +175,16 @@ int dpcg_batched_coo_spmv(int64_t nnz, const int32_t *indices, const float *feat
  * out[k] = a[batch_k, row_k] * c[batch_k, col_k] with (row,col) as in dpcg_batched_coo_spmv for `transpose`. */
 int dpcg_batched_coo_edge(int64_t nnz, const int32_t *indices, int batch, int64_t dof, const float *a, const float *c,
                           float *out, int transpose, dpcg_stream_t stream);
+
+/* The same two operators on PANELS of `ncols` right-hand sides (fp32[batch*dof*ncols], row-major [b][row][c]): the
+ * building blocks of `inverse_loss` (metrics.py:34-55, the loss train.py:59 minimises) WITHOUT the reference's dense
+ * N x N products: || L L^T A - I ||_F is accumulated over panels of columns J as L (L^T A[:, J]) - I[:, J].
+ * spmm: out[b, row_k, :] += features[k] * panel[b, col_k, :]; sddmm: out[k] = <g[b, row_k, :], panel[b, col_k, :]> (the
+ * gradient of spmm with respect to features[k]).  (row, col) swap under `transpose` as in dpcg_batched_coo_spmv. */
+int dpcg_batched_coo_spmm(int64_t nnz, const int32_t *indices, const float *features, int batch, int64_t dof, int ncols,
+                          const float *panel, float *out, int transpose, dpcg_stream_t stream);
+int dpcg_batched_coo_sddmm(int64_t nnz, const int32_t *indices, int batch, int64_t dof, int ncols, const float *g,
+                           const float *panel, float *out, int transpose, dpcg_stream_t stream);
 
 /* ---- coordinate triplets -> CSR on the device (the reference's file formats are COO: scipy npz,
  * generate_data.py:109; OpenFOAM `i,j,value` dump, pEqn.H:98-108; StAn npz, data_set.py:186-188) ------------- */

@@ -290,6 +290,33 @@ def preconditioned_conjugate_gradient(A, b, M, x0=None, rtol=1e-8, max_iter=1024
     return t1 - t0, len(hist) - 1, np.array(hist), x  # cg.py:90 (+ history and x for the checker)
 
 
+def ground_truth_solve(A, b, atol=1e-6, maxiter=None):
+    """The ground-truth solve of the data generator, generate_data.py:107: `scipy.sparse.linalg.cg(matrix, rhs, rtol=0,
+    atol=1e-6)`.  The arithmetic lives in scipy (pinned 1.15.1 in the reference's uv.lock, 1.15.3 in this image; not
+    vendored), whose published algorithm is restated here: x0 = 0, stop at the top of an iteration when
+    ||r||_2 < max(atol, rtol ||b||), otherwise rho = <r,z> (z = r: no preconditioner), p = z + (rho / rho_prev) p,
+    q = A p, alpha = rho / <p,q>, x += alpha p, r -= alpha q; at most 10 n iterations.  Returns (x, iterations, info)
+    with iterations = completed updates (= callback calls) and info = 0 on convergence, maxiter otherwise.
+    Pinned by tests/golden `ground_truth/*` (outputs of the verbatim scipy call)."""
+    n = b.shape[0]
+    maxiter = 10 * n if maxiter is None else maxiter
+    x = np.zeros(n, dtype=np.float64)
+    r = np.array(b, dtype=np.float64)
+    p = None
+    rho_prev = 0.0
+    for it in range(maxiter):
+        if np.linalg.norm(r) < atol:
+            return x, it, 0
+        rho = np.dot(r, r)
+        p = r.copy() if it == 0 else r + (rho / rho_prev) * p
+        q = A @ p
+        alpha = rho / np.dot(p, q)
+        x = x + alpha * p
+        r = r - alpha * q
+        rho_prev = rho
+    return x, maxiter, maxiter
+
+
 def conjugate_gradient(A, b, x0=None, x_true=None, rtol=1e-8, max_iter=1024):
     """Restatement of cg.py:20-47.  Returns (errors, x_hat), errors[k] = (A-norm error or 0, res)."""
     x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=b.dtype)  # cg.py:22

@@ -90,11 +90,73 @@ def run_ref_pcg(A, b, M, x0=None, max_iter=1024):
     return iters, np.array(tap.values)
 
 
+def ground_truth_cases(out: dict) -> None:
+    """generate_data.py:107, the live call site of scipy's cg: `scipy.sparse.linalg.cg(matrix, rhs, rtol=0, atol=1e-6)`
+    on a COO matrix (generate_data.py:78 builds one).  `generate_data.py` itself cannot be imported (dvc, triangle, stl
+    are absent), so the call is made verbatim here; a callback only counts the iterations."""
+    import scipy.sparse.linalg
+    cases = {"unstructured2d_49_seed1": O.unstructured_like(O.poisson2d(49), seed=1), "poisson3d_20": O.poisson3d(20)}
+    for name, A in cases.items():
+        matrix = sp.coo_matrix(A)
+        right_hand_side = O.rhs(A.shape[0], 69)
+        count = [0]
+        solution, info = scipy.sparse.linalg.cg(matrix, right_hand_side, rtol=0, atol=1e-6,
+                                                callback=lambda _: count.__setitem__(0, count[0] + 1))
+        out[f"ground_truth/{name}/iters_info"] = np.array([count[0], info], dtype=np.int64)
+        out[f"ground_truth/{name}/x"] = np.asarray(solution, dtype=np.float64)
+        r = right_hand_side - A @ solution
+        print(f"ground truth {name}: {count[0]} iterations, info {info}, ||r|| = {np.linalg.norm(r):.3e}", flush=True)
+
+
+def sparse_loss_cases(out: dict) -> None:
+    """metrics.py:34-55 (`inverse_loss`) on a batch with the sparsity of real inputs: tril of 2-D Poisson matrices (fp32)
+    and lower factors on the same pattern; the reference densifies, so only `.dense()` of the batch is needed."""
+    from uibk.deep_preconditioning import metrics as ref_metrics
+
+    class DenseStub:
+        def __init__(self, dense4):
+            self._d = dense4
+
+        def dense(self):
+            return self._d.clone()
+
+    gen = torch.Generator().manual_seed(321)
+    mats = [O.poisson2d(5), O.poisson2d(6)]
+    dof = max(m.shape[0] for m in mats)
+    sys_low = torch.zeros(len(mats), 1, dof, dof)
+    pre_low = torch.zeros(len(mats), 1, dof, dof)
+    for bi, m in enumerate(mats):
+        n = m.shape[0]
+        dense = torch.from_numpy(sp.tril(m).toarray()).float()
+        sys_low[bi, 0, :n, :n] = dense
+        pattern = (dense != 0).float()
+        Lr = pattern * (torch.rand(n, n, generator=gen) * 0.3 - 0.15)
+        Lr = torch.tril(Lr, -1) + torch.diag(0.4 + torch.rand(n, generator=gen))
+        pre_low[bi, 0, :n, :n] = Lr
+        for k in range(n, dof):                      # identity padding, as the data sets pad (data_set.py:94-97)
+            sys_low[bi, 0, k, k] = 1.0
+            pre_low[bi, 0, k, k] = 1.0
+    out["metrics_sparse/systems_tril"] = sys_low.numpy().copy()
+    out["metrics_sparse/preconditioners_tril"] = pre_low.numpy().copy()
+    out["metrics_sparse/inverse_loss"] = np.float64(ref_metrics.inverse_loss(DenseStub(sys_low), DenseStub(pre_low)))
+    print("metrics_sparse/inverse_loss:", float(out["metrics_sparse/inverse_loss"]), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--add-round2", action="store_true",
+                    help="only add the ground-truth-solve and sparse-loss fixtures to the existing reference_outputs.npz")
     args = ap.parse_args()
     out: dict[str, np.ndarray] = {}
+    if args.add_round2:
+        with np.load(HERE / "reference_outputs.npz") as old:
+            out = {k: old[k] for k in old.files}
+        ground_truth_cases(out)
+        sparse_loss_cases(out)
+        np.savez_compressed(HERE / "reference_outputs.npz", **out)
+        print("updated", HERE / "reference_outputs.npz", (HERE / "reference_outputs.npz").stat().st_size, "bytes")
+        return
 
     def put(name, iters, hist):
         out[f"{name}/iters"] = np.int64(iters)
@@ -253,6 +315,8 @@ def main() -> None:
     print("metrics:", float(out["metrics/inverse_loss"]), float(out["metrics/condition_loss"]),
           float(out["metrics/hutchinson_trace_seed7_cpu"]), flush=True)
 
+    ground_truth_cases(out)
+    sparse_loss_cases(out)
     name = "reference_outputs_quick.npz" if args.quick else "reference_outputs.npz"
     np.savez_compressed(HERE / name, **out)
     print("wrote", HERE / name, (HERE / name).stat().st_size, "bytes")

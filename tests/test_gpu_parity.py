@@ -1165,3 +1165,57 @@ def test_nccl_world1_runs_the_scatter_and_gather_on_rccl():
     for i, (A, rec) in enumerate(zip(mats, out["real_table"])):
         assert int(rec[0]) == CO.pcg(A, O.rhs(A.shape[0], i), "jacobi", dinv=O.jacobi_dinv(A))[1] and int(rec[1]) == 0
     assert out["x_equal_to_direct_solve"] == [True, True, True]
+
+
+@pytest.mark.parametrize("name,make", [("unstructured2d_49_seed1", lambda: O.unstructured_like(O.poisson2d(49), seed=1)),
+                                       ("poisson3d_20", lambda: O.poisson3d(20))])
+def test_ground_truth_solve_matches_the_reference_call(D, golden, name, make):
+    """a10, generate_data.py:107: `scipy.sparse.linalg.cg(matrix, rhs, rtol=0, atol=1e-6)`.  The HIP path with the absolute
+    test <r,r> < 1e-12 (what `io.write_case` runs) against the outputs of the verbatim scipy call: same number of
+    iterations, same solution; on the small-system kernel and on the general path."""
+    A = make()
+    n = A.shape[0]
+    b = O.rhs(n, 69)
+    g_it, g_info = (int(v) for v in golden[f"ground_truth/{name}/iters_info"])
+    gx = golden[f"ground_truth/{name}/x"]
+    S = D.CsrSystem.from_any(A)
+    S.set_preconditioner(None)
+    for flags in (0, D._lib.NO_SMALL, D._lib.NO_SMALL | D._lib.NO_FUSE):
+        res = S.solve(_dev(b), rtol_sq=0.0, atol_sq=1e-12, max_iter=10 * n, flags=flags | D._lib.INIT_CHECK_R)
+        assert (res.iterations, res.status) == (g_it, g_info)
+        np.testing.assert_allclose(res.x.cpu().numpy(), gx, rtol=1e-8, atol=1e-11)
+    xo, it_o, _ = O.ground_truth_solve(A, b)
+    assert it_o == g_it
+    np.testing.assert_allclose(res.x.cpu().numpy(), xo, rtol=1e-8, atol=1e-11)
+    S.close()
+
+
+def test_inverse_loss_on_sparse_operands(D, golden):
+    """f4: `inverse_loss` (metrics.py:34-55, the loss train.py:59 minimises) accumulated panel by panel with the HIP
+    kernels instead of dense N x N products: equal to the values the reference returned on both fixtures, gradient with
+    respect to L's entries equal to autograd through the dense form, also with a panel narrower than the matrix and
+    at a size whose dense form would need 3 x 17 GB."""
+    from deeppreconditioning_amd import metrics
+    from deeppreconditioning_amd.utils import SparseBatch
+    for key in ("metrics", "metrics_sparse"):
+        to_sparse = lambda d: SparseBatch.from_dense(torch.from_numpy(d).permute(0, 2, 3, 1).cuda())   # noqa: E731
+        systems, pre = to_sparse(golden[f"{key}/systems_tril"]), to_sparse(golden[f"{key}/preconditioners_tril"])
+        for width in (256, 7):
+            np.testing.assert_allclose(float(metrics.inverse_loss(systems, pre, panel_columns=width)),
+                                       golden[f"{key}/inverse_loss"], rtol=2e-6)
+        f_sparse = pre.features.clone().requires_grad_(True)
+        metrics.inverse_loss(systems, pre.replace_feature(f_sparse), panel_columns=16).backward()
+        f_dense = pre.features.clone().requires_grad_(True)
+        metrics.inverse_loss_dense(systems, pre.replace_feature(f_dense)).backward()
+        np.testing.assert_allclose(f_sparse.grad.cpu().numpy(), f_dense.grad.cpu().numpy(), rtol=2e-4, atol=1e-6)
+    # 65 536 unknowns: tril of the 256^2 Poisson matrix, L = its Jacobi-scaled lower triangle (the dense form: 17 GB per matrix)
+    from deeppreconditioning_amd import model as mdl
+    A = sp.tril(O.poisson2d(256)).tocsr()
+    systems, _ = mdl.tril_batch_from_csr([A], device="cuda")
+    pre = systems.replace_feature(systems.features * 0.1)
+    loss = metrics.inverse_loss(systems, pre, panel_columns=2048)
+    # exact value from sparse algebra on the host: || L L^T A - I ||_F
+    Lh = (A * 0.1).astype(np.float64)
+    Af = O.poisson2d(256)
+    R = (Lh @ (Lh.T @ Af)) - sp.identity(A.shape[0])
+    np.testing.assert_allclose(float(loss), np.sqrt(R.multiply(R).sum()), rtol=1e-5)

@@ -16,8 +16,20 @@ def _batches(golden):
 
 def test_dense_losses_match_the_reference(golden):
     systems, pre = _batches(golden)
-    assert float(metrics.inverse_loss(systems, pre)) == np.float32(golden["metrics/inverse_loss"])
+    assert float(metrics.inverse_loss_dense(systems, pre)) == np.float32(golden["metrics/inverse_loss"])
     np.testing.assert_allclose(float(metrics.condition_loss(systems, pre)), golden["metrics/condition_loss"], rtol=1e-5)
     torch.manual_seed(7)
     np.testing.assert_allclose(float(metrics.hutchinson_trace(systems, pre)),
                                golden["metrics/hutchinson_trace_seed7_cpu"], rtol=1e-6)
+
+
+def _sparse_batches(golden):
+    to_sparse = lambda d: SparseBatch.from_dense(torch.from_numpy(d).permute(0, 2, 3, 1))   # noqa: E731
+    return to_sparse(golden["metrics_sparse/systems_tril"]), to_sparse(golden["metrics_sparse/preconditioners_tril"])
+
+
+def test_dense_inverse_loss_on_the_sparse_fixture(golden):
+    systems, pre = _sparse_batches(golden)
+    np.testing.assert_allclose(float(metrics.inverse_loss_dense(systems, pre)), golden["metrics_sparse/inverse_loss"], rtol=1e-6)
+    with np.testing.assert_raises(ValueError):                     # the sparse form is a GPU path: no silent CPU fallback
+        metrics.inverse_loss(systems, pre)

@@ -188,3 +188,16 @@ def test_edge_arguments(golden):
     assert len(errors) == int(golden["edge_cg/max_iter_0_len"]) and np.array_equal(x, golden["edge_cg/max_iter_0_x"])
     errors, _ = O.conjugate_gradient(A, b, rtol=1.0)
     np.testing.assert_allclose([r for _, r in errors], golden["edge_cg/rtol_1_hist"], rtol=HIST_RTOL)
+
+
+@pytest.mark.parametrize("name,make", [("unstructured2d_49_seed1", lambda: O.unstructured_like(O.poisson2d(49), seed=1)),
+                                       ("poisson3d_20", lambda: O.poisson3d(20))])
+def test_ground_truth_solve(golden, name, make):
+    """a10: the restated ground-truth solve against the outputs of the verbatim scipy call of generate_data.py:107."""
+    A = make()
+    b = O.rhs(A.shape[0], 69)
+    x, iters, info = O.ground_truth_solve(A, b)
+    g_it, g_info = (int(v) for v in golden[f"ground_truth/{name}/iters_info"])
+    assert (iters, info) == (g_it, g_info)
+    np.testing.assert_allclose(x, golden[f"ground_truth/{name}/x"], rtol=1e-9, atol=1e-12)
+    assert np.linalg.norm(b - A @ x) < 1e-6
