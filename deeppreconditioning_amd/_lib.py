@@ -21,7 +21,8 @@ OK, MAX_ITER, BREAKDOWN = 0, 1, 2
 ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_PIVOT, ERR_STATE = -1, -2, -3, -4, -5
 F64, F32 = 0, 1
 DEVICE, HOST = 0, 1
-PRECOND_NONE, PRECOND_JACOBI, PRECOND_CSR, PRECOND_LLT_MULTIPLY, PRECOND_LLT_SOLVE = 0, 1, 2, 3, 4
+PRECOND_NONE, PRECOND_JACOBI, PRECOND_CSR, PRECOND_LLT_MULTIPLY, PRECOND_LLT_SOLVE, PRECOND_CALLBACK = 0, 1, 2, 3, 4, 5
+PRECOND_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)   # dpcg_precond_fn
 INIT_CHECK_R, SPMV_F32, NO_GRAPH, NO_SMALL, VAL32_IF_LOSSLESS, NO_FUSE = 1, 2, 4, 8, 16, 32
 REORDER_NONE, REORDER_AUTO, REORDER_ALWAYS = 0, 1, 2
 
@@ -42,6 +43,7 @@ SIGNATURES = {
     "dpcg_reorder": (_int, [_p, _int, _p, C.POINTER(_int)]),
     "dpcg_get_permutation": (_int, [_p, C.POINTER(_int), _p, C.POINTER(_dbl)]),
     "dpcg_set_precond_none": (_int, [_p]),
+    "dpcg_set_precond_callback": (_int, [_p, PRECOND_FN, _p]),
     "dpcg_set_precond_jacobi": (_int, [_p, _p, _int, _p]),
     "dpcg_set_precond_csr": (_int, [_p, _i64, _p, _p, _p, _int, _p]),
     "dpcg_set_precond_llt": (_int, [_p, _int, _i64, _p, _p, _p, _int, _p]),

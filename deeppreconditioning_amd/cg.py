@@ -8,8 +8,9 @@ reference that a caller can observe:
 * `info` (third return value of PCG) is a real status -- 0 converged, 1 `max_iter` reached,
   2 breakdown -- where the reference hard-wires 0 (cg.py:90).
 * `A` may be anything `operators.csr_arrays` understands (dense / sparse torch tensors, scipy,
-  numpy) or a prepared `CsrSystem`; `M` a matrix, a `Preconditioner`, or None.  Arbitrary Python
-  objects with `__matmul__` are refused: there is no generic (non-HIP) fallback.
+  numpy) or a prepared `CsrSystem`; `M` a matrix, a `Preconditioner`, None, or -- the reference's
+  operator protocol, cg.py:61,81 -- any object with `__matmul__`, which is applied through a
+  per-update callback (`OperatorPreconditioner`: slow path, the rest of the update stays HIP).
 * `x_true` is accepted and ignored by PCG: the reference only uses it for an error history that
   it discards (cg.py:64-67,85-88,90).
 """

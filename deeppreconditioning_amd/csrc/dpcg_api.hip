@@ -251,6 +251,8 @@ void free_precond(dpcg_system *h) {
     free_csr(h->Ltp);
     free_levels(h->lvlL);
     free_levels(h->lvlU);
+    h->precond_fn = nullptr;
+    h->precond_user = nullptr;
     h->precond = DPCG_PRECOND_NONE;
 }
 
@@ -501,6 +503,15 @@ int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, boo
         case DPCG_PRECOND_LLT_MULTIPLY:       // on a reordered handle the SpMVs read P L^T P^T and P L P^T
             launch_spmv(h->perm ? h->Ltp : h->Lt, h->planLt, r, h->t, nullptr, nullptr, s);
             launch_spmv(h->perm ? h->Lp : h->L, h->planL, h->t, z, nullptr, nullptr, s);
+            break;
+        case DPCG_PRECOND_CALLBACK:
+            if (h->perm) {                        // the caller's function sees the caller's numbering; t and q (dead
+                launch_scatter_f64(h->A.n, h->perm, r, h->t, s);          // between K2 and the next K1) are the scratch
+                h->precond_fn(h->precond_user, h->t, h->q, h->A.n, (dpcg_stream_t)s);
+                launch_gather_f64(h->A.n, h->perm, h->q, z, s);
+            } else {
+                h->precond_fn(h->precond_user, r, z, h->A.n, (dpcg_stream_t)s);
+            }
             break;
         case DPCG_PRECOND_LLT_SOLVE:
             launch_sptrsv(h->L, h->lvlL, false, r, h->t, s, in_loop ? &h->scal->done : nullptr);

@@ -137,6 +137,8 @@ struct dpcg_system {
     double *dinv = nullptr;
     dpcg::CsrDev M;
     dpcg::SpmvPlan planM;
+    dpcg_precond_fn precond_fn = nullptr;   // DPCG_PRECOND_CALLBACK
+    void *precond_user = nullptr;
     dpcg::CsrDev L, Lt;                   // the factor and its transpose in the CALLER's numbering
     dpcg::CsrDev Lp, Ltp;                 // reordered handle, multiply mode: P L P^T and P L^T P^T (what the SpMVs read)
     dpcg::SpmvPlan planL, planLt;

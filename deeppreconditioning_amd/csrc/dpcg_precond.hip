@@ -17,6 +17,15 @@ extern "C" int dpcg_set_precond_none(dpcg_handle_t h) {
     return DPCG_OK;
 }
 
+extern "C" int dpcg_set_precond_callback(dpcg_handle_t h, dpcg_precond_fn fn, void *user) {
+    if (!h || !fn) return invalid("dpcg_set_precond_callback: NULL handle or function");
+    free_precond(h);
+    h->precond_fn = fn;
+    h->precond_user = user;
+    h->precond = DPCG_PRECOND_CALLBACK;
+    return DPCG_OK;
+}
+
 extern "C" int dpcg_set_precond_jacobi(dpcg_handle_t h, const double *dinv, int memspace, dpcg_stream_t stream) {
     if (!h) return invalid("NULL handle");
     hipStream_t s = (hipStream_t)stream;

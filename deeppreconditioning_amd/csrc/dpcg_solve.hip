@@ -115,6 +115,7 @@ static int precond_launches(const dpcg_system *h) {
     };
     switch (h->precond) {
         case DPCG_PRECOND_CSR: return 1;
+        case DPCG_PRECOND_CALLBACK: return 1;
         case DPCG_PRECOND_LLT_MULTIPLY: return 2;
         case DPCG_PRECOND_LLT_SOLVE: return trsv(h->lvlL) + trsv(h->lvlU);
         default: return 0;
@@ -221,7 +222,7 @@ struct Solve {
         many_launches = per_update >= 16;
         if (many_launches) chunk = std::max(1, std::min(chunk, 1024 / per_update));   // keep the graph at ~1K nodes
         if (defer_x && (chunk & 1)) chunk += 1;   // a replayed chunk must start at an even update (p buffer parity)
-        use_graph = !(flags & DPCG_NO_GRAPH) && !x_true && max_iter >= chunk;
+        use_graph = !(flags & DPCG_NO_GRAPH) && !x_true && max_iter >= chunk && h->precond != DPCG_PRECOND_CALLBACK;
         if (use_graph) DPCG_TRY(ensure_graph(h, flags, chunk));
         *ex.prog_host = 0;
         if (h->perm) {                     // b, x0, x_true arrive in the caller's numbering

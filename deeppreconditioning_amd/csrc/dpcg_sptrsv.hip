@@ -344,86 +344,101 @@ __global__ __launch_bounds__(kBlock) void k_fill_pending(const int32_t *__restri
     if (idx < count) out[rows[j0 + idx]] = __longlong_as_double((long long)kPendingBits);
 }
 
+// The grid is PERSISTENT and sized to the wavefront (about twice the widest level): a workgroup draws the next 256-row
+// block when it has finished one, so only rows near the front are resident and polling.  (With one workgroup per block
+// and the whole factor resident, thousands of waves polled entries tens of levels away; their requests saturated the
+// L2 and a hop cost 3.6 us instead of the ~0.5 us an idle chip needs -- tools/hop_lab.)  The ticket word and an exit
+// counter sit side by side; the last workgroup to leave zeroes both for the next launch.
 template <bool UPPER, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree(const int32_t *__restrict__ rows, int j0, int count,
                                                             const int32_t *__restrict__ lo_rp,
                                                             const int32_t *__restrict__ lo_ci,
                                                             const double *__restrict__ lo_v,
                                                             const double *__restrict__ rhs, double *out,
-                                                            unsigned long long *ticket, int nblocks, const int *done,
-                                                            int *err) {
+                                                            unsigned int *ticket /* [0] next block, [1] exits */,
+                                                            int nblocks, const int *done, int *err) {
     __shared__ unsigned int s_lb;
     __shared__ double sv[STAGED ? kStreamCap : 1];
     __shared__ int sc[STAGED ? kStreamCap : 1];
     const int t = threadIdx.x;
-    // every workgroup draws a ticket, also when the solve is over: the counter advances by nblocks per launch
-    if (t == 0) s_lb = (unsigned int)(atomicAdd(ticket, 1ull) % (unsigned long long)nblocks);
-    __syncthreads();
-    if (done && *done) return;
-    const int jb = j0 + (int)s_lb * kBlock;
-    const int jend = (jb + kBlock < j0 + count) ? jb + kBlock : j0 + count;
-    const int j = jb + t;
-    const int base = lo_rp[jb];
-    int rs = 0, re = 0, i = 0;
-    double bi = 0.0;
-    if (j < jend) {
-        rs = lo_rp[j] - base;
-        re = lo_rp[j + 1] - base;
-        i = rows[j];
-        bi = rhs[i];
-    }
-    if (STAGED) {                                   // the block's contiguous val/col segment, coalesced, into LDS
-        const int cnt = lo_rp[jend] - base;
-        for (int k = t; k < cnt; k += kBlock) {
-            sv[k] = lo_v[base + k];
-            sc[k] = lo_ci[base + k];
-        }
-        __syncthreads();
-    }
-    if (j >= jend) return;
-    auto val_at = [&](int k) { return STAGED ? sv[k] : lo_v[base + k]; };
-    auto col_at = [&](int k) { return STAGED ? sc[k] : lo_ci[base + k]; };
-    int k = UPPER ? rs + 1 : rs;
-    const int ke = UPPER ? re : re - 1;
-    const double diag = val_at(UPPER ? rs : re - 1);
-    double acc = bi;
-    unsigned spins = 0;
-    bool stored = false;
-    // left by the whole wave at once (ballot), so that the store stays INSIDE the loop: on an exit path a SIMT machine
-    // would run it only after every lane has left, and lanes of one wave may wait for each other
+    if (done && *done) return;                      // nothing drawn: the counters stay zero
     for (;;) {
-        if (!stored && k < ke) {
-            // up to four entries requested at once, consumed in column order as far as they are there
-            const int m = ke - k < 4 ? ke - k : 4;
-            double y[4];
+        __syncthreads();                            // everybody is done with s_lb / the LDS stage of the previous block
+        if (t == 0) s_lb = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const unsigned int lb = s_lb;
+        if (lb >= (unsigned int)nblocks) break;
+        const int jb = j0 + (int)lb * kBlock;
+        const int jend = (jb + kBlock < j0 + count) ? jb + kBlock : j0 + count;
+        const int j = jb + t;
+        const int base = lo_rp[jb];
+        int rs = 0, re = 0, i = 0;
+        double bi = 0.0;
+        if (j < jend) {
+            rs = lo_rp[j] - base;
+            re = lo_rp[j + 1] - base;
+            i = rows[j];
+            bi = rhs[i];
+        }
+        if (STAGED) {                               // the block's contiguous val/col segment, coalesced, into LDS
+            const int cnt = lo_rp[jend] - base;
+            for (int k = t; k < cnt; k += kBlock) {
+                sv[k] = lo_v[base + k];
+                sc[k] = lo_ci[base + k];
+            }
+            __syncthreads();
+        }
+        auto val_at = [&](int k) { return STAGED ? sv[k] : lo_v[base + k]; };
+        auto col_at = [&](int k) { return STAGED ? sc[k] : lo_ci[base + k]; };
+        int k = UPPER ? rs + 1 : rs;
+        const int ke = UPPER ? re : re - 1;
+        const double diag = j < jend ? val_at(UPPER ? rs : re - 1) : 1.0;
+        double acc = bi;
+        unsigned spins = 0;
+        bool stored = j >= jend;                    // lanes without a row only keep the wave company
+        // up to four entries are in flight at once; only those still pending are asked for again; they are consumed
+        // in column order.  The loop is left by the whole wave at once (ballot), so that the store stays INSIDE it: on
+        // an exit path a SIMT machine would run it only after every lane has left, and lanes of one wave may wait for
+        // each other.
+        double y[4];
+        int have = 0;                               // entries k .. k+have-1 have been requested into y[0..have)
+        for (;;) {
+            if (!stored && k < ke) {
+                const int m = ke - k < 4 ? ke - k : 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                y[q] = q < m ? __hip_atomic_load(out + col_at(k + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-            int used = 0;
+                for (int q = 0; q < 4; ++q)
+                    if (q < m && (q >= have || is_pending(y[q])))
+                        y[q] = __hip_atomic_load(out + col_at(k + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                have = m;
+                int used = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (q == used && q < m && !is_pending(y[q])) {
-                    acc -= val_at(k + q) * y[q];
-                    ++used;
-                }
-            k += used;
-            if (used == 0) {
-                if (++spins > (1u << 22)) {          // bounded: never hang the device on a malformed schedule
+                for (int q = 0; q < 4; ++q)
+                    if (q == used && q < m && !is_pending(y[q])) {
+                        acc -= val_at(k + q) * y[q];
+                        ++used;
+                    }
+                if (used > 0) {                     // the requests behind a pending entry are simply made again
+                    k += used;
+                    have = 0;
+                    spins = 0;
+                } else if (++spins > (1u << 22)) {  // bounded: never hang the device on a malformed schedule
                     atomicExch(err, 1);
                     acc = __builtin_nan("");
                     k = ke;
                 } else {
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(1);
                 }
-            } else {
-                spins = 0;
             }
+            if (!stored && k >= ke) {
+                __hip_atomic_store(out + i, acc / diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                stored = true;
+            }
+            if (__ballot(!stored) == 0) break;
         }
-        if (!stored && k >= ke) {
-            __hip_atomic_store(out + i, acc / diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            stored = true;
-        }
-        if (__ballot(!stored) == 0) break;
+    }
+    if (t == 0 && atomicAdd(ticket + 1, 1u) == gridDim.x - 1) {      // last one out: zero the counters for the next launch
+        atomicExch(ticket, 0u);
+        atomicExch(ticket + 1, 0u);
     }
 }
 
@@ -442,10 +457,16 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
         if (seg.syncfree) {
             const int j0 = lv.level_ptr[seg.lo], cnt = lv.level_ptr[seg.hi] - j0;
             const int nblocks = (cnt + kBlock - 1) / kBlock;
+            // persistent grid ~ twice the widest level: the front and the rows about to join it
+            int grid = (2 * seg.max_width + kBlock - 1) / kBlock + 4;
+            grid = grid < 16 ? 16 : grid;
+            grid = grid > nblocks ? nblocks : grid;
+            grid = grid > 1536 ? 1536 : grid;       // 6 workgroups per CU (24 KiB of LDS each): all resident
             hipLaunchKernelGGL(k_fill_pending, dim3(nblocks), dim3(kBlock), 0, s, lv.rows, j0, cnt, out, done);
 #define DPCG_SYNCFREE(UP, ST)                                                                                          \
-    hipLaunchKernelGGL((k_sptrsv_syncfree<UP, ST>), dim3(nblocks), dim3(kBlock), 0, s, lv.rows, j0, cnt, lv.lo_rowptr,  \
-                       lv.lo_col, lv.lo_val, rhs, out, lv.tickets + seg_index, nblocks, done, lv.spin_err)
+    hipLaunchKernelGGL((k_sptrsv_syncfree<UP, ST>), dim3(grid), dim3(kBlock), 0, s, lv.rows, j0, cnt, lv.lo_rowptr,     \
+                       lv.lo_col, lv.lo_val, rhs, out, reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nblocks, \
+                       done, lv.spin_err)
             if (upper) {
                 if (seg.staged) DPCG_SYNCFREE(true, true);
                 else DPCG_SYNCFREE(true, false);

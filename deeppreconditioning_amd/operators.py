@@ -230,12 +230,61 @@ class IC0(Preconditioner):
         raise TypeError("IC0 needs the system matrix: attach it with CsrSystem.set_preconditioner")
 
 
+class _DevArray:
+    """Zero-copy view of a device buffer the library hands to a callback (CUDA array interface, fp64 vector)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class OperatorPreconditioner(Preconditioner):
+    """Any object with `__matmul__` as M -- all the reference's loop asks for (`zk = M @ rk`, cg.py:61,81).
+
+    SLOW PATH, by construction: the library calls back into Python once per update (`dpcg_set_precond_callback`),
+    `op @ r` runs as whatever the object does (it receives a CUDA fp64 tensor in the caller's numbering and may
+    return a CUDA or a CPU tensor / array), and the updates cannot be replayed as a hipGraph.  SpMV, dot products and
+    vector updates remain the HIP kernels.  Prefer a matrix, a factor or one of the `Preconditioner` classes.
+    """
+
+    def __init__(self, op):
+        if not hasattr(op, "__matmul__"):
+            raise TypeError("an operator preconditioner needs __matmul__")
+        self.op = op
+        self.error: BaseException | None = None
+        self.calls = 0
+
+        def _apply(_user, r_ptr, z_ptr, n, _stream_ptr):
+            try:
+                if self.error is not None:
+                    return
+                dev = torch.device("cuda", torch.cuda.current_device())
+                r = torch.as_tensor(_DevArray(r_ptr, n), device=dev)
+                z = torch.as_tensor(_DevArray(z_ptr, n), device=dev)
+                out = self.op @ r
+                if isinstance(out, np.ndarray):
+                    out = torch.from_numpy(out)
+                z.copy_(torch.as_tensor(out).reshape(-1).to(device=dev, dtype=torch.float64))
+                self.calls += 1
+            except BaseException as exc:  # noqa: BLE001 - must not propagate through the C frame; re-raised after the solve
+                self.error = exc
+
+        self._fn = L.PRECOND_FN(_apply)      # kept alive with the object
+
+    def _attach(self, system):
+        self.error = None
+        L.check(L.lib().dpcg_set_precond_callback(system._h, self._fn, None))
+
+    def __matmul__(self, r):
+        return self.op @ r
+
+
 def as_preconditioner(M, n: int) -> Preconditioner:
     """Map whatever the reference's callers pass as `M` to an apply mode.
 
     None -> identity; a Preconditioner -> itself; a matrix (torch sparse/dense, scipy, numpy) ->
     Jacobi when it is exactly diagonal (bit-identical to the CSR product, one term per row),
-    otherwise an explicit CSR multiply.  Anything else is refused: there is no generic fallback.
+    otherwise an explicit CSR multiply; any other object with `__matmul__` -> `OperatorPreconditioner`
+    (the reference's operator protocol, honoured through a per-update callback: slow path).
     """
     if M is None:
         return Identity()
@@ -243,7 +292,12 @@ def as_preconditioner(M, n: int) -> Preconditioner:
         return M
     if isinstance(M, CsrSystem):
         raise TypeError("pass the preconditioner as a matrix or a Preconditioner, not a CsrSystem")
-    space, rp, ci, v, m = csr_arrays(M)
+    try:
+        space, rp, ci, v, m = csr_arrays(M)
+    except TypeError:
+        if hasattr(M, "__matmul__"):
+            return OperatorPreconditioner(M)
+        raise
     if m != n:
         raise ValueError("preconditioner size mismatch")
     if diagonal_only(rp, ci, n):
@@ -451,6 +505,9 @@ class CsrSystem:
             status = L.check(L.lib().dpcg_solve(
                 self._h, _dev_ptr(bv), _dev_ptr(x0v), _dev_ptr(x), rtol_sq, atol_sq, int(max_iter), int(flags),
                 _stream(), C.byref(iters), C.byref(res), C.byref(sec), _np_ptr(hist), _dev_ptr(xt), _np_ptr(err)))
+        if isinstance(self._precond, OperatorPreconditioner) and self._precond.error is not None:
+            err, self._precond.error = self._precond.error, None
+            raise err
         k = iters.value
         return SolveResult(x, k, status, res.value, sec.value, hist[: k + 1] if hist is not None else np.empty(0),
                            err[: k + 1] if err is not None else None)

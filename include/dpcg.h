@@ -51,7 +51,8 @@ enum dpcg_precond {
     DPCG_PRECOND_JACOBI = 1,       /* M = diag(1/a_ii)              test.py:74-79                   */
     DPCG_PRECOND_CSR = 2,          /* z = M r, M an explicit CSR    test.py:88,105 (M = L L^T)      */
     DPCG_PRECOND_LLT_MULTIPLY = 3, /* z = L (L^T r), same operator as test.py:102-105, never formed */
-    DPCG_PRECOND_LLT_SOLVE = 4     /* z = L^-T (L^-1 r), level-scheduled SpTRSV (north_star)        */
+    DPCG_PRECOND_LLT_SOLVE = 4,    /* z = L^-T (L^-1 r), level-scheduled SpTRSV (north_star)        */
+    DPCG_PRECOND_CALLBACK = 5      /* z = M r by a caller-supplied function (the duck-typed `M @ rk`) */
 };
 
 /* dpcg_solve flags */
@@ -119,6 +120,14 @@ int dpcg_set_precond_llt(dpcg_handle_t h, int mode, int64_t nnz, const int32_t *
                          const double *val, int memspace, dpcg_stream_t stream);
 /* IC(0) of A (stands in for ilupp.ichol0, test.py:83), then as dpcg_set_precond_llt. */
 int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t stream);
+/* The reference's operator protocol asks of M nothing but `M @ rk` (cg.py:61,81).  An M that is not a matrix this library
+ * can hold (a Python object with __matmul__, a multigrid cycle, ...) is applied through a function the caller supplies:
+ * fn(user, r, z, n, stream) must ENQUEUE z = M r on `stream` (device pointers, caller's numbering; it is called from the
+ * thread inside dpcg_solve, once per update, and keeps being called for the few updates the driver has enqueued beyond
+ * convergence).  Slow path by construction -- one host call per update, no graph replay, vectors gathered / scattered
+ * around the call on a reordered handle -- while SpMV, dots and vector updates stay the HIP kernels. */
+typedef void (*dpcg_precond_fn)(void *user, const double *r, double *z, int64_t n, dpcg_stream_t stream);
+int dpcg_set_precond_callback(dpcg_handle_t h, dpcg_precond_fn fn, void *user);
 /* Copy the current factor L out (host arrays sized from dpcg_get_info's precond_nnz). */
 int dpcg_get_factor(dpcg_handle_t h, int32_t *rowptr, int32_t *col, double *val);
 

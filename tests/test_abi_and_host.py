@@ -118,6 +118,12 @@ def test_preconditioner_mapping():
     assert operators.as_preconditioner(spec, n) is spec
     with pytest.raises(TypeError):
         operators.as_preconditioner(object(), n)
+
+    class Duck:                                    # all cg.py:61,81 ask of M: `M @ rk`
+        def __matmul__(self, r):
+            return r
+
+    assert isinstance(operators.as_preconditioner(Duck(), n), D.OperatorPreconditioner)
     with pytest.raises(ValueError):
         operators.as_preconditioner(sp.eye(n + 1, format="csr"), n)
     with pytest.raises(ValueError):

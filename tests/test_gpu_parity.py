@@ -1183,10 +1183,13 @@ def test_ground_truth_solve_matches_the_reference_call(D, golden, name, make):
     for flags in (0, D._lib.NO_SMALL, D._lib.NO_SMALL | D._lib.NO_FUSE):
         res = S.solve(_dev(b), rtol_sq=0.0, atol_sq=1e-12, max_iter=10 * n, flags=flags | D._lib.INIT_CHECK_R)
         assert (res.iterations, res.status) == (g_it, g_info)
-        np.testing.assert_allclose(res.x.cpu().numpy(), gx, rtol=1e-8, atol=1e-11)
+        # both solutions carry the solve's own error (||r|| < 1e-6 after hundreds of updates of an ill-conditioned
+        # system): they agree to that accuracy, not to rounding
+        np.testing.assert_allclose(res.x.cpu().numpy(), gx, rtol=1e-5, atol=5e-8)
+        assert np.linalg.norm(b - A @ res.x.cpu().numpy()) < 1e-6
     xo, it_o, _ = O.ground_truth_solve(A, b)
     assert it_o == g_it
-    np.testing.assert_allclose(res.x.cpu().numpy(), xo, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(res.x.cpu().numpy(), xo, rtol=1e-5, atol=5e-8)
     S.close()
 
 
@@ -1219,3 +1222,55 @@ def test_inverse_loss_on_sparse_operands(D, golden):
     Af = O.poisson2d(256)
     R = (Lh @ (Lh.T @ Af)) - sp.identity(A.shape[0])
     np.testing.assert_allclose(float(loss), np.sqrt(R.multiply(R).sum()), rtol=1e-5)
+
+
+def test_any_object_with_matmul_as_preconditioner(D):
+    """The reference's operator protocol (cg.py:61,81: `zk = M @ rk`, nothing else is asked of M): a foreign object is
+    applied through the per-update callback -- the labelled slow path -- while SpMV, dots and vector updates stay HIP.
+    Same iteration counts and histories as the oracle with the equivalent built-in operator, on the two- and the
+    three-kernel forms, on a reordered handle, with a CPU-side operator, and an exception inside `@` surfaces."""
+    from deeppreconditioning_amd.cg import preconditioned_conjugate_gradient
+    A = O.poisson2d(96)
+    n = A.shape[0]
+    b = O.rhs(n, 2)
+    dinv = O.jacobi_dinv(A) * np.linspace(0.5, 1.5, n)          # a non-trivial diagonal M
+    _, it, hist, xs = CO.pcg(A, b, "jacobi", dinv=dinv)
+
+    class GpuDiag:
+        def __init__(self):
+            self.d = _dev(dinv)
+            self.calls = 0
+
+        def __matmul__(self, r):
+            self.calls += 1
+            assert r.is_cuda and r.dtype == torch.float64
+            return self.d * r
+
+    class CpuSolve:                                              # e.g. a scipy-side operator: returns a numpy array
+        def __init__(self, L):
+            self.L = L
+
+        def __matmul__(self, r):
+            return CO.sptrsv_upper(CO.transpose_csr(self.L), CO.sptrsv_lower(self.L, r.cpu().numpy()))
+
+    for reorder in (None, "rcm"):
+        S = D.CsrSystem.from_any(A, reorder=reorder)
+        op = GpuDiag()
+        for flags in (D._lib.NO_SMALL, D._lib.NO_SMALL | D._lib.NO_FUSE):
+            S.set_preconditioner(op)
+            res = S.solve(_dev(b), flags=flags)
+            assert res.iterations == it and res.status == 0
+            np.testing.assert_allclose(res.res_history, hist, rtol=1e-9)
+            np.testing.assert_allclose(res.x.cpu().numpy(), xs, rtol=1e-8, atol=1e-11)
+        assert op.calls >= 2 * (it + 1)
+        S.close()
+    Lref = CO.ic0(A)
+    dur, its, info = preconditioned_conjugate_gradient(torch.from_numpy(A.toarray()), torch.from_numpy(b), CpuSolve(Lref))
+    assert its == CO.pcg(A, b, "llt_solve", L=Lref)[1] and info == 0
+
+    class Broken:
+        def __matmul__(self, r):
+            raise RuntimeError("boom")
+
+    with pytest.raises(RuntimeError, match="boom"):
+        preconditioned_conjugate_gradient(A, torch.from_numpy(b), Broken())
