@@ -41,6 +41,41 @@ __device__ __forceinline__ double reduce_partials(const double *__restrict__ par
     return block_sum(s, sh);
 }
 
+// The same reduction with the loads issued EARLY: a kernel whose first action depends on the reduced value (alpha, beta)
+// requests its partials together with its first vector loads and its control words, and only then looks at them -- one
+// exposed memory round trip at the head of the kernel instead of three (control word, partials, first data).  SLOTS *
+// kBlock >= n_part; absent slots hold +0.0, which leaves the sum's bits unchanged (x + 0.0 == x), so the result is
+// bit-identical to reduce_partials.
+template <int SLOTS>
+struct EarlyPartials {
+    double v[SLOTS];
+    // unconditional loads (index clamped to the last partial; n_part >= 1): a predicated load would become a branch
+    // with its own wait
+    __device__ __forceinline__ void request(const double *__restrict__ part, int n_part) {
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            const int i = (int)threadIdx.x + u * kBlock;
+            v[u] = part[i < n_part ? i : n_part - 1];
+        }
+    }
+    // Call in front of the branch on the control word: makes the values "used" there, so the compiler cannot sink the
+    // loads behind the branch (it waits for them here -- together with the first vector loads, which are older).
+    __device__ __forceinline__ void land() {
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) asm volatile("" : "+v"(v[u]));
+    }
+    __device__ __forceinline__ double reduce(int n_part, double *sh) const {
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) s += ((int)threadIdx.x + u * kBlock < n_part) ? v[u] : 0.0;
+        return block_sum(s, sh);
+    }
+};
+// pins a scalar the head has loaded in front of the `done` branch (the compiler would otherwise sink the load behind it)
+__device__ __forceinline__ void pin_scalar(double &x) { asm volatile("" : "+s"(x)); }
+constexpr int kSpmvPartSlots = kMaxSpmvGrid / kBlock;   // 8
+constexpr int kVecPartSlots = kMaxGrid / kBlock;        // 2
+
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD one contiguous slab of the
 // work so the x-vector halo of neighbouring row-blocks is shared in that XCD's 4 MiB L2.
 // Placement is a speed matter only; any mapping gives the same result.

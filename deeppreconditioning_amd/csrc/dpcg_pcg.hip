@@ -36,11 +36,17 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
         ra = r2[i];
         if (PRE == 1) da = d2[i];
     }
-    // the `done` word is looked at only now: its scalar load would otherwise sit in front of the first vector loads
-    // (~0.5 us of exposed latency per kernel); a finished solve has merely loaded a few values for nothing
-    if (sc->done) return;
-    const double pq = reduce_partials(part_pq, n_part_pq, sh);
-    const double rz_cur = sc->rz;
+    // Everything the head needs is requested before anything is looked at: the SpMV's partials of <p,Ap>, the `done`
+    // word and <r,z> travel together with the first vector loads, so the head exposes ONE memory round trip; a finished
+    // solve has merely loaded a few values for nothing.
+    EarlyPartials<kSpmvPartSlots> ep;
+    ep.request(part_pq, n_part_pq);
+    const int done = sc->done;
+    double rz_cur = sc->rz;
+    pin_scalar(rz_cur);
+    ep.land();
+    if (done) return;
+    const double pq = ep.reduce(n_part_pq, sh);
     const double alpha = rz_cur / pq;                                   // cg.py:78
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         sc->alpha = alpha;                                              // read by K3 / KA (a later kernel)
@@ -220,11 +226,17 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
         if (zd) da = zd2[i];
     }
     // `done_seen`, not `done`: workgroup 0 of THIS launch sets `done`, and a workgroup dispatched after that must still
-    // apply x += alpha p for its rows (cg.py:79 precedes the test of cg.py:86).  Read after the first loads, as in K2.
-    if (sc->done_seen) return;
-    const double rz_new = reduce_partials(part_rz, n_part, sh);
-    const double beta = rz_new / sc->rz;                                // cg.py:82
-    const double alpha = sc->alpha;
+    // apply x += alpha p for its rows (cg.py:79 precedes the test of cg.py:86).
+    EarlyPartials<kVecPartSlots> ep;                                    // as in K2: one exposed round trip at the head
+    ep.request(part_rz, n_part);
+    const int done_seen = sc->done_seen;
+    double rz_old = sc->rz, alpha = sc->alpha;
+    pin_scalar(rz_old);
+    pin_scalar(alpha);
+    ep.land();
+    if (done_seen) return;
+    const double rz_new = ep.reduce(n_part, sh);
+    const double beta = rz_new / rz_old;                                // cg.py:82
     if (blockIdx.x == 0) {                                              // cg.py:86 + the test of cg.py:71
         const double rr = reduce_partials(part_rr, n_part, sh);
         if (threadIdx.x == 0) record_and_test(sc, rr, rz_new, hist, hist_cap, sc->k + 1);
@@ -309,11 +321,18 @@ __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalar
         }
         if (zd) da = zd2[i];
     }
-    if (sc->done_seen) return;                                          // see k_update_xp: never `done` here
-    const double rz_new = reduce_partials(part_rz, n_part, sh);
-    const double beta = rz_new / sc->rz;                                // cg.py:82
-    const double alpha = sc->alpha;
-    const double alpha_prev = ODD ? sc->alpha_prev : 0.0;               // written by the even update before this one
+    EarlyPartials<kVecPartSlots> ep;                                    // as in K2: one exposed round trip at the head
+    ep.request(part_rz, n_part);
+    const int done_seen = sc->done_seen;                                // see k_update_xp: never `done` here
+    double rz_old = sc->rz, alpha = sc->alpha;
+    double alpha_prev = ODD ? sc->alpha_prev : 0.0;                     // written by the even update before this one
+    pin_scalar(rz_old);
+    pin_scalar(alpha);
+    pin_scalar(alpha_prev);
+    ep.land();
+    if (done_seen) return;
+    const double rz_new = ep.reduce(n_part, sh);
+    const double beta = rz_new / rz_old;                                // cg.py:82
     if (blockIdx.x == 0) {                                              // cg.py:86 + the test of cg.py:71
         const double rr = reduce_partials(part_rr, n_part, sh);
         if (threadIdx.x == 0) {

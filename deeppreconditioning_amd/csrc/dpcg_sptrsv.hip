@@ -457,8 +457,10 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
         if (seg.syncfree) {
             const int j0 = lv.level_ptr[seg.lo], cnt = lv.level_ptr[seg.hi] - j0;
             const int nblocks = (cnt + kBlock - 1) / kBlock;
-            // persistent grid ~ twice the widest level: the front and the rows about to join it
-            int grid = (2 * seg.max_width + kBlock - 1) / kBlock + 4;
+            // persistent grid ~ a few times the widest level: the front and the rows about to join it (DPCG_SF_FACTOR:
+            // development knob for that multiple)
+            static const int factor = [] { const char *e = getenv("DPCG_SF_FACTOR"); const int f = e ? atoi(e) : 4; return f < 1 ? 1 : f; }();
+            int grid = (factor * seg.max_width + kBlock - 1) / kBlock + 4;
             grid = grid < 16 ? 16 : grid;
             grid = grid > nblocks ? nblocks : grid;
             grid = grid > 1536 ? 1536 : grid;       // 6 workgroups per CU (24 KiB of LDS each): all resident

@@ -19,7 +19,9 @@ import sys
 fetch_dir, write_dir, rdreq_dir, tag = sys.argv[1:5]
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 SYSTEMS = [("3d_100", 1000000, 6940000), ("2d_1024", 1048576, 5238784), ("3d_256", 256 ** 3, 7 * 256 ** 3 - 6 * 256 ** 2),
-           ("3d_256_f32_create", 256 ** 3, 7 * 256 ** 3 - 6 * 256 ** 2)]
+           ("3d_256_f32_create", 256 ** 3, 7 * 256 ** 3 - 6 * 256 ** 2),
+           ("scrambled3d_100_gather", 1000000, 6940000), ("scrambled3d_100_reordered", 1000000, 6940000)]
+SPMV_ROWS = [0, 1, 2, 4, 5]
 
 
 def load(d):
@@ -68,7 +70,8 @@ lines += ["", "## SpMV + <p,Ap> kernel of the PCG loop (k_spmv_tile: the plan pi
           "| system | algorithmic MB (nnz*12 + (n+1)*4 + 16n) | read MB = 2 x FETCH_SIZE x 1024 | read MB from RDREQ sizes | write MB | traffic MB | traffic / algorithmic |",
           "|---|---|---|---|---|---|---|"]
 traffic = {}
-for seg, (name, n, nnz) in enumerate(SYSTEMS[:3]):
+for seg in SPMV_ROWS:
+    name, n, nnz = SYSTEMS[seg]
     alg = nnz * 12 + (n + 1) * 4 + 16 * n
     floor = 0.2 * alg / 2048  # FETCH_SIZE units of KiB/2: anything below is a no-op launch
     rd = 2 * 1024 * mean(F[(seg, "k_spmv", "FETCH_SIZE")], floor)
@@ -76,8 +79,10 @@ for seg, (name, n, nnz) in enumerate(SYSTEMS[:3]):
     wr = 1024 * mean(W[(seg, "k_spmv", "WRITE_SIZE")], 0.2 * 8 * n / 1024)
     tot = rd + wr
     traffic[f"spmv_{name}"] = round(tot)
-    lines.append(f"| poisson{name} | {alg / MB:.2f} | {rd / MB:.2f} | {rq / MB:.2f} | {wr / MB:.2f} | {tot / MB:.2f} | {tot / alg:.3f} |")
-lines += ["", "Reading: traffic is BELOW the algorithmic CSR bytes: the x-tile kernel reads a 2-byte local index instead of the",
+    lines.append(f"| {'poisson' if name[0].isdigit() else ''}{name} | {alg / MB:.2f} | {rd / MB:.2f} | {rq / MB:.2f} | {wr / MB:.2f} | {tot / MB:.2f} | {tot / alg:.3f} |")
+lines += ["", "scrambled3d_100_gather: the config-3 stand-in on the caller's numbering (k_spmv_stream, every x[col] its own 128-B line);",
+          "scrambled3d_100_reordered: the same system after dpcg_reorder (k_spmv_tile on P A P^T).",
+          "", "Reading: traffic is BELOW the algorithmic CSR bytes: the x-tile kernel reads a 2-byte local index instead of the",
           "4-byte column (-2 B per non-zero: -13.9 MB at 100^3, -234 MB at 256^3) and stages x in LDS; the gather kernel",
           "measured 107.2 MB at 100^3 (ratio 1.038) and 1906 MB at 256^3 (x planes at i +- n^2 re-fetched: reuse distance 6.8 MB per XCD > the 4 MiB L2).",
           "The 1M-DoF working set (~150 MB) sits in the Infinity Cache; these counters are the L2's memory-side requests",

@@ -34,3 +34,14 @@ del s
 rp, ci, v32 = poisson.poisson_csr(3, 256, dtype=torch.float32)
 s32 = D.CsrSystem(rp, ci, v32, rp.numel() - 1)
 torch.cuda.synchronize()
+del s32, rp, ci, v32
+# BASELINE config 3 stand-in (scrambled numbering of the 100^3 system): the gather SpMV on the caller's numbering, then the
+# same system as the library iterates on it after dpcg_reorder.  A k_gen_poisson dispatch marks each segment.
+A = poisson.unstructured_like_csr(3, 100, 0)
+for mode in (None, "auto"):
+    poisson.poisson_csr(2, 8)                      # segment marker
+    s = D.CsrSystem.from_any(A, reorder=mode)
+    s.set_preconditioner(D.Jacobi())
+    s.spmv_dot_bench(20)
+    s.close()
+torch.cuda.synchronize()
