@@ -48,6 +48,7 @@ SIGNATURES = {
     "dpcg_set_precond_csr": (_int, [_p, _i64, _p, _p, _p, _int, _p]),
     "dpcg_set_precond_llt": (_int, [_p, _int, _i64, _p, _p, _p, _int, _p]),
     "dpcg_set_precond_ic0": (_int, [_p, _int, _p]),
+    "dpcg_set_precond_ict": (_int, [_p, _int, _int, _dbl, _p]),
     "dpcg_get_factor": (_int, [_p, _p, _p, _p]),
     "dpcg_spmv": (_int, [_p, _p, _p, _p]),
     "dpcg_spmv_f32": (_int, [_p, _p, _p, _p]),

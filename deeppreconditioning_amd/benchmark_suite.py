@@ -18,7 +18,7 @@ import torch
 from .cg import preconditioned_conjugate_gradient
 from .io import coo_to_csr_device
 from .model import lower_factor_csr, tril_batch_from_csr
-from .operators import IC0, CsrSystem, Identity, Jacobi, LLtMultiply
+from .operators import IC0, ICT, CsrSystem, Identity, Jacobi, LLtMultiply
 
 PARAMETERS = ["kappas", "densities", "iterations", "setups", "durations", "totals", "successes"]  # test.py:180
 
@@ -75,9 +75,11 @@ class BenchmarkSuite:
             return Identity()
         if name == "jacobi":                        # test.py:74-79
             return Jacobi()
-        if name == "incomplete_cholesky":           # test.py:81-88: the factor is MULTIPLIED, as the reference does
+        if name == "incomplete_cholesky":           # test.py:81-88: icholt(add_fill_in=1, threshold=0.1) by default, and
+            return ICT("multiply", fill_in=1, threshold=0.1)      # the factor is MULTIPLIED, as the reference does
+        if name == "incomplete_cholesky_0":         # the reference's other branch (both arguments zeroed): ichol0
             return IC0("multiply")
-        if name == "incomplete_cholesky_solve":     # the same factor applied by triangular solves
+        if name == "incomplete_cholesky_solve":     # IC(0) applied by triangular solves (not in the reference)
             return IC0("solve")
         if name == "learned":                       # test.py:100-105
             with torch.no_grad():

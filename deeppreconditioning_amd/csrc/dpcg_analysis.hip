@@ -342,4 +342,134 @@ void launch_tril_copy(int64_t n, const int32_t *rp, const int32_t *ci, const dou
     hipLaunchKernelGGL(k_tril_copy, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rp, ci, v, lrp, lci, lv);
 }
 
+// ------------------------------------------------------------------------------------------------
+// ICT: thresholded incomplete Cholesky with level-1 fill (contract: oracle/oracle.py::ict; stands in for
+// ilupp.icholt(add_fill_in=1, threshold=0.1), the reference harness's default technique, test.py:81-88)
+// ------------------------------------------------------------------------------------------------
+// c[j] = || A(j:n, j) ||_1 = sum of |a_jk| over the entries of row j with column >= j (A symmetric)
+__global__ __launch_bounds__(kBlock) void k_colnorm1(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                     const double *__restrict__ v, double *__restrict__ c) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        double sum = 0.0;
+        for (int k = rp[j]; k < rp[j + 1]; ++k)
+            if (ci[k] >= j) sum += fabs(v[k]);
+        c[j] = sum;
+    }
+}
+
+void launch_colnorm1(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, double *c, hipStream_t s) {
+    hipLaunchKernelGGL(k_colnorm1, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rp, ci, v, c);
+}
+
+// Pattern of row i with level-1 fill: tril(A)_i plus every j < i that shares a neighbour k < j with i.  One thread per
+// row keeps the sorted set in a private array (rows are short; a row whose set would exceed kIctRowCap keeps tril(A)_i
+// only and raises *overflow).  WRITE = false: cnt[i] = size; WRITE = true: entries to lci / lv (a_ij, or 0 for fill).
+constexpr int kIctRowCap = 192;
+template <bool WRITE>
+__global__ __launch_bounds__(kBlock) void k_ict_pattern(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                        const double *__restrict__ v, int fill, int32_t *__restrict__ cnt,
+                                                        const int32_t *__restrict__ lrp, int32_t *__restrict__ lci,
+                                                        double *__restrict__ lv, int *flags) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= n; i += stride) {
+        if (i == n) {
+            if (!WRITE) cnt[i] = 0;
+            continue;
+        }
+        int set[kIctRowCap];
+        int m = 0, last = -1;
+        bool over = false;
+        for (int k = rp[i]; k < rp[i + 1]; ++k)
+            if (ci[k] <= i) {
+                if (m < kIctRowCap) set[m++] = ci[k];
+                else over = true;
+                last = ci[k];
+            }
+        const int base = m;                                  // tril(A)_i, ascending; re-read from A below, `set` grows
+        if (last != i) atomicOr(flags, 1);                   // missing diagonal
+        if (fill && !over) {
+            for (int p = rp[i]; p < rp[i + 1] && !over; ++p) {
+                const int k = ci[p];                         // original entries only: level-1 fill
+                if (k >= i) continue;
+                for (int q = rp[k]; q < rp[k + 1]; ++q) {
+                    const int j = ci[q];
+                    if (j <= k || j >= i) continue;
+                    int lo = 0;
+                    while (lo < m && set[lo] < j) ++lo;
+                    if (lo < m && set[lo] == j) continue;
+                    if (m >= kIctRowCap) {
+                        over = true;
+                        break;
+                    }
+                    for (int t = m; t > lo; --t) set[t] = set[t - 1];
+                    set[lo] = j;
+                    ++m;
+                }
+            }
+            if (over) {                                      // fall back to tril(A)_i for this row
+                atomicOr(flags, 2);
+                m = 0;
+                for (int k = rp[i]; k < rp[i + 1]; ++k)
+                    if (ci[k] <= i && m < kIctRowCap) set[m++] = ci[k];
+            }
+        }
+        (void)base;
+        if (!WRITE) {
+            cnt[i] = m;
+        } else {
+            const int d = lrp[i];
+            int q = rp[i];
+            for (int t = 0; t < m; ++t) {
+                while (q < rp[i + 1] && ci[q] < set[t]) ++q;
+                lci[d + t] = set[t];
+                lv[d + t] = (q < rp[i + 1] && ci[q] == set[t]) ? v[q] : 0.0;
+            }
+        }
+    }
+}
+
+void launch_ict_pattern(bool write, int64_t n, const int32_t *rp, const int32_t *ci, const double *v, int fill, int32_t *cnt,
+                        const int32_t *lrp, int32_t *lci, double *lv, int *flags, hipStream_t s) {
+    if (write)
+        hipLaunchKernelGGL(k_ict_pattern<true>, dim3(grid_rows(n + 1)), dim3(kBlock), 0, s, n, rp, ci, v, fill, cnt, lrp, lci, lv, flags);
+    else
+        hipLaunchKernelGGL(k_ict_pattern<false>, dim3(grid_rows(n + 1)), dim3(kBlock), 0, s, n, rp, ci, v, fill, cnt, lrp, lci, lv, flags);
+}
+
+// compaction after the numeric phase: dropped entries are stored zeros; the diagonal always stays
+__global__ __launch_bounds__(kBlock) void k_count_kept(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                       const double *__restrict__ v, int32_t *__restrict__ cnt) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= n; i += stride) {
+        int c = 0;
+        if (i < n)
+            for (int k = rp[i]; k < rp[i + 1]; ++k) c += (v[k] != 0.0 || ci[k] == i) ? 1 : 0;
+        cnt[i] = c;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_copy_kept(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                      const double *__restrict__ v, const int32_t *__restrict__ orp,
+                                                      int32_t *__restrict__ oci, double *__restrict__ ov) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        int d = orp[i];
+        for (int k = rp[i]; k < rp[i + 1]; ++k)
+            if (v[k] != 0.0 || ci[k] == i) {
+                oci[d] = ci[k];
+                ov[d] = v[k];
+                ++d;
+            }
+    }
+}
+
+void launch_count_kept(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, int32_t *cnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_count_kept, dim3(grid_rows(n + 1)), dim3(kBlock), 0, s, n, rp, ci, v, cnt);
+}
+void launch_copy_kept(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, const int32_t *orp, int32_t *oci,
+                      double *ov, hipStream_t s) {
+    hipLaunchKernelGGL(k_copy_kept, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rp, ci, v, orp, oci, ov);
+}
+
 }  // namespace dpcg

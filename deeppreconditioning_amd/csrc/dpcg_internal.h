@@ -264,7 +264,13 @@ int small_variant(int n, int max_row_len, int precond);
 int launch_pcg_small(const SmallDesc *descs_dev, int count, int lds_bytes, int kinds_mask, int variants_mask,
                      hipStream_t s);
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
-                      hipStream_t s);
+                      hipStream_t s, const double *colnorm = nullptr, double tau = 0.0);   // colnorm: ICT drop rule
+void launch_colnorm1(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, double *c, hipStream_t s);
+void launch_ict_pattern(bool write, int64_t n, const int32_t *rp, const int32_t *ci, const double *v, int fill, int32_t *cnt,
+                        const int32_t *lrp, int32_t *lci, double *lv, int *flags, hipStream_t s);
+void launch_count_kept(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, int32_t *cnt, hipStream_t s);
+void launch_copy_kept(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, const int32_t *orp, int32_t *oci,
+                      double *ov, hipStream_t s);
 void launch_block_nnz_max(const CsrDev &A, int rows_per_block, int *out_max_dev, hipStream_t s);
 void launch_block_nnz_max_raw(int64_t n, const int32_t *rowptr, int rows_per_block, int *out_max_dev, hipStream_t s);
 // ---- reordering (dpcg_reorder.hip) ----

@@ -2,6 +2,8 @@
 // IC(0).  The host orchestrates; the analysis itself (transpose, level sets, level-ordered copies, ring-segment
 // records, tril(A), the numeric factorisation) runs on the device.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -95,6 +97,28 @@ bool syncfree_enabled() {
     static const bool on = [] { const char *e = getenv("DPCG_SYNCFREE"); return !(e && e[0] == '0'); }();
     return on;
 }
+
+// DPCG_SETUP_TRACE=1: phase times of the preconditioner setup on stderr (development)
+struct PhaseTimer {
+    bool on;
+    hipStream_t s;
+    std::chrono::steady_clock::time_point t;
+    explicit PhaseTimer(hipStream_t stream) : s(stream) {
+        static const bool enabled = [] { const char *e = getenv("DPCG_SETUP_TRACE"); return e && e[0] == '1'; }();
+        on = enabled;
+        if (on) {
+            (void)hipStreamSynchronize(s);
+            t = std::chrono::steady_clock::now();
+        }
+    }
+    void mark(const char *what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[dpcg setup] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
 
 template <typename T>
 struct DevBuf {                       // scoped device allocation for the setup routines
@@ -256,8 +280,15 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
                 merged_segs.back().merged = false;
             }
         }
-        for (auto &seg : merged_segs)
-            if (seg.syncfree && seg.hi - seg.lo < 2) seg.syncfree = false;
+        // ... and a run of VERY wide levels stays with one launch per level too: there the bodies, not the boundaries,
+        // are the cost, and the level kernels' gathers may use the L1 / L2 where the polling loads of the sync-free
+        // kernel bypass them (measured, scrambled 1M-DoF factor, 19 levels of ~52K rows: 313 vs 372 us per apply; natural
+        // 100^3 factor, 298 levels of <= 7.5K rows: 2457 vs 1555 us)
+        constexpr int kSyncfreeMaxMeanWidth = 16384;
+        for (auto &seg : merged_segs) {
+            const int64_t rows_in_seg = (int64_t)level_ptr[seg.hi] - level_ptr[seg.lo];
+            if (seg.syncfree && (seg.hi - seg.lo < 2 || rows_in_seg / (seg.hi - seg.lo) > kSyncfreeMaxMeanWidth)) seg.syncfree = false;
+        }
         lv.segments.swap(merged_segs);
     }
     {
@@ -347,7 +378,9 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
         return DPCG_ERR_PIVOT;
     }
     if (h_last != h->L.nnz) return invalid("L: rowptr[n] != nnz");
+    PhaseTimer pt(s);
     DPCG_TRY(transpose_lower(h->L, h->Lt, s));
+    pt.mark("transpose");
     if (h->perm && mode == DPCG_PRECOND_LLT_MULTIPLY) {
         DPCG_TRY(permute_csr(h->L, h->perm, h->iperm, h->Lp, s));
         DPCG_TRY(permute_csr(h->Lt, h->perm, h->iperm, h->Ltp, s));
@@ -357,15 +390,20 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
         DPCG_TRY(make_plan(h->L, h->planL, s));
         DPCG_TRY(make_plan(h->Lt, h->planLt, s));
     }
+    pt.mark("plans");
     if (mode == DPCG_PRECOND_LLT_SOLVE) {
         LevelSort own, up;
         if (!lower_levels) {
             DPCG_TRY(compute_levels(n, h->L.rowptr, h->L.col, false, own, s));
             lower_levels = &own;
+            pt.mark("levels(L)");
         }
         DPCG_TRY(build_levels(h->lvlL, *lower_levels, n, h->L.nnz, h->L.rowptr, h->L.col, h->L.val, s, h->iperm));
+        pt.mark("schedule(L)");
         DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s));
+        pt.mark("levels(L^T)");
         DPCG_TRY(build_levels(h->lvlU, up, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, s, h->iperm));
+        pt.mark("schedule(L^T)");
     }
     h->precond = mode;
     return DPCG_OK;
@@ -423,9 +461,12 @@ extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t str
     }
     Lf.nnz = lnnz;
     if ((st = dev_alloc(&Lf.col, lnnz)) < 0 || (st = dev_alloc(&Lf.val, lnnz)) < 0) return fail(st);
+    PhaseTimer pt(s);
     launch_tril_copy(n, Asrc.rowptr, Asrc.col, Asrc.val, Lf.rowptr, Lf.col, Lf.val, s);
+    pt.mark("tril(A)");
     LevelSort ls;
     if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, ls, s)) < 0) return fail(st);
+    pt.mark("levels(tril A)");
     const int nl = (int)ls.level_ptr.size() - 1;
     for (int l = 0; l < nl; ++l)
         launch_ic0_level(ls.rows.p, ls.level_ptr[l], ls.level_ptr[l + 1] - ls.level_ptr[l], Lf.rowptr, Lf.col, Lf.val,
@@ -434,6 +475,7 @@ extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t str
     if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail(hip_fail(e, "IC(0): numeric factorisation", __FILE__, __LINE__));
+    pt.mark("numeric IC(0)");
     if (h_flags[1]) {
         set_error("IC(0): non-positive pivot at row " + std::to_string(h_flags[1] - 1));
         return fail(DPCG_ERR_PIVOT);
@@ -441,6 +483,83 @@ extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t str
     free_precond(h);
     h->L = Lf;
     st = finish_llt(h, mode, s, &ls);
+    if (st < 0) free_precond(h);
+    return st;
+}
+
+// ICT -- thresholded incomplete Cholesky with level-1 fill (contract: oracle/oracle.py::ict; stands in for
+// ilupp.icholt(add_fill_in=1, threshold=0.1), the harness's default technique, test.py:81-88; ilupp absent: unpinned).
+// Symbolic phase (pattern with level-1 fill), level sets, numeric phase (the IC(0) kernel with the drop rule) and the
+// compaction all run on the device; like IC(0) it factors the CALLER's matrix and leaves the previous preconditioner
+// in place when it fails.
+extern "C" int dpcg_set_precond_ict(dpcg_handle_t h, int mode, int fill_in, double threshold, dpcg_stream_t stream) {
+    if (!h) return invalid("NULL handle");
+    if (mode != DPCG_PRECOND_LLT_MULTIPLY && mode != DPCG_PRECOND_LLT_SOLVE) return invalid("bad LLT mode");
+    if (fill_in < 0 || !(threshold >= 0.0)) return invalid("dpcg_set_precond_ict: fill_in >= 0 and threshold >= 0");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = h->A.n;
+    const CsrDev &Asrc = h->perm ? h->A_user : h->A;
+    CsrDev S, Lf;                       // S: the pattern with fill (values: A, then the factor with stored zeros)
+    S.n = Lf.n = n;
+    S.owned = Lf.owned = true;
+    DevBuf<int32_t> cnt, flags;
+    DevBuf<double> colnorm;
+    auto fail = [&](int st) {
+        free_csr(S);
+        free_csr(Lf);
+        return st;
+    };
+    int st = DPCG_OK;
+    if ((st = cnt.alloc(n + 1)) < 0 || (st = flags.alloc(2)) < 0 || (st = colnorm.alloc(n)) < 0 ||
+        (st = dev_alloc(&S.rowptr, n + 1)) < 0 || (st = dev_alloc(&Lf.rowptr, n + 1)) < 0)
+        return fail(st);
+    hipError_t e = hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), s);
+    if (e != hipSuccess) return fail(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
+    launch_colnorm1(n, Asrc.rowptr, Asrc.col, Asrc.val, colnorm.p, s);
+    launch_ict_pattern(false, n, Asrc.rowptr, Asrc.col, Asrc.val, fill_in > 0 ? 1 : 0, cnt.p, nullptr, nullptr, nullptr,
+                       reinterpret_cast<int *>(flags.p), s);
+    if ((st = exclusive_scan_i32(cnt.p, S.rowptr, n + 1, s)) < 0) return fail(st);
+    int32_t h_flags[2] = {0, 0}, snnz = 0;
+    e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&snnz, S.rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(hip_fail(e, "ICT: symbolic phase", __FILE__, __LINE__));
+    if (h_flags[0] & 1) {
+        set_error("ICT: missing diagonal entry");
+        return fail(DPCG_ERR_PIVOT);
+    }
+    S.nnz = snnz;
+    if ((st = dev_alloc(&S.col, snnz)) < 0 || (st = dev_alloc(&S.val, snnz)) < 0) return fail(st);
+    launch_ict_pattern(true, n, Asrc.rowptr, Asrc.col, Asrc.val, fill_in > 0 ? 1 : 0, nullptr, S.rowptr, S.col, S.val,
+                       reinterpret_cast<int *>(flags.p), s);
+    LevelSort ls;
+    if ((st = compute_levels(n, S.rowptr, S.col, false, ls, s)) < 0) return fail(st);
+    const int nl = (int)ls.level_ptr.size() - 1;
+    for (int l = 0; l < nl; ++l)
+        launch_ic0_level(ls.rows.p, ls.level_ptr[l], ls.level_ptr[l + 1] - ls.level_ptr[l], S.rowptr, S.col, S.val,
+                         reinterpret_cast<int *>(flags.p) + 1, s, colnorm.p, threshold);
+    // compaction: the dropped entries are stored zeros
+    launch_count_kept(n, S.rowptr, S.col, S.val, cnt.p, s);
+    if ((st = exclusive_scan_i32(cnt.p, Lf.rowptr, n + 1, s)) < 0) return fail(st);
+    int32_t lnnz = 0;
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&lnnz, Lf.rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(hip_fail(e, "ICT: numeric factorisation", __FILE__, __LINE__));
+    if (h_flags[1]) {
+        set_error("ICT: non-positive pivot at row " + std::to_string(h_flags[1] - 1));
+        return fail(DPCG_ERR_PIVOT);
+    }
+    Lf.nnz = lnnz;
+    if ((st = dev_alloc(&Lf.col, lnnz)) < 0 || (st = dev_alloc(&Lf.val, lnnz)) < 0) return fail(st);
+    launch_copy_kept(n, S.rowptr, S.col, S.val, Lf.rowptr, Lf.col, Lf.val, s);
+    e = hipStreamSynchronize(s);
+    free_csr(S);
+    if (e != hipSuccess) return fail(hip_fail(e, "ICT: compaction", __FILE__, __LINE__));
+    free_precond(h);
+    h->L = Lf;
+    st = finish_llt(h, mode, s);
     if (st < 0) free_precond(h);
     return st;
 }

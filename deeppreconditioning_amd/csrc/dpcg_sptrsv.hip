@@ -459,7 +459,7 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
             const int nblocks = (cnt + kBlock - 1) / kBlock;
             // persistent grid ~ a few times the widest level: the front and the rows about to join it (DPCG_SF_FACTOR:
             // development knob for that multiple)
-            static const int factor = [] { const char *e = getenv("DPCG_SF_FACTOR"); const int f = e ? atoi(e) : 4; return f < 1 ? 1 : f; }();
+            static const int factor = [] { const char *e = getenv("DPCG_SF_FACTOR"); const int f = e ? atoi(e) : 2; return f < 1 ? 1 : f; }();
             int grid = (factor * seg.max_width + kBlock - 1) / kBlock + 4;
             grid = grid < 16 ? 16 : grid;
             grid = grid > nblocks ? nblocks : grid;
@@ -554,9 +554,11 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
 // one product and one subtraction at a time (two roundings): the order of the CPU restatement, so the
 // factor is bit-identical to it.  lv holds tril(A) on entry and L on exit (diagonal last in a row).
 // ------------------------------------------------------------------------------------------------
+// DROP (ICT, oracle/oracle.py::ict): an off-diagonal entry v = acc / L_jj is stored as 0 when |v| * L_jj < tau * colnorm[j].
+template <bool DROP>
 __global__ __launch_bounds__(kBlock) void k_ic0_level(const int32_t *__restrict__ rows, int j0, int count,
                                                       const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
-                                                      double *lv, int *bad) {
+                                                      double *lv, int *bad, const double *__restrict__ colnorm, double tau) {
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= count) return;
     const int i = rows[j0 + idx];
@@ -575,8 +577,12 @@ __global__ __launch_bounds__(kBlock) void k_ic0_level(const int32_t *__restrict_
             } else if (ca < cb) ++a;
             else ++b;
         }
-        if (j < i) lv[k] = acc / lv[e_j - 1];
-        else {
+        if (j < i) {
+            const double d = lv[e_j - 1];
+            double v = acc / d;
+            if (DROP && fabs(v) * d < tau * colnorm[j]) v = 0.0;
+            lv[k] = v;
+        } else {
             if (!(acc > 0.0)) atomicExch(bad, i + 1);
             lv[k] = sqrt(acc);
         }
@@ -584,9 +590,13 @@ __global__ __launch_bounds__(kBlock) void k_ic0_level(const int32_t *__restrict_
 }
 
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
-                      hipStream_t s) {
-    hipLaunchKernelGGL(k_ic0_level, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, rows, j0, count, rp, ci, lv,
-                       bad);
+                      hipStream_t s, const double *colnorm, double tau) {
+    if (colnorm)
+        hipLaunchKernelGGL(k_ic0_level<true>, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, rows, j0, count, rp, ci,
+                           lv, bad, colnorm, tau);
+    else
+        hipLaunchKernelGGL(k_ic0_level<false>, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, rows, j0, count, rp,
+                           ci, lv, bad, colnorm, tau);
 }
 
 }  // namespace dpcg

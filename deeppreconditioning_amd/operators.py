@@ -230,6 +230,28 @@ class IC0(Preconditioner):
         raise TypeError("IC0 needs the system matrix: attach it with CsrSystem.set_preconditioner")
 
 
+class ICT(Preconditioner):
+    """Thresholded incomplete Cholesky with level-1 fill computed at setup: what the reference's harness runs by default,
+    `ilupp.icholt(A, add_fill_in=1, threshold=0.1)` (test.py:81-88).  ilupp is not available: the factor follows the
+    contract of oracle/oracle.py::ict (level-1 fill, MATLAB's 'ict' drop rule), PARITY UNPINNED against ilupp itself.
+    mode="multiply" is the reference's use (it multiplies by L L^T, test.py:88), mode="solve" applies the factor by
+    triangular solves."""
+
+    def __init__(self, mode: str = "multiply", fill_in: int = 1, threshold: float = 0.1):
+        if mode not in ("solve", "multiply"):
+            raise ValueError("mode must be 'solve' or 'multiply'")
+        if fill_in < 0 or not threshold >= 0:
+            raise ValueError("fill_in >= 0 and threshold >= 0")
+        self.mode = L.PRECOND_LLT_SOLVE if mode == "solve" else L.PRECOND_LLT_MULTIPLY
+        self.fill_in, self.threshold = int(fill_in), float(threshold)
+
+    def _attach(self, system):
+        L.check(L.lib().dpcg_set_precond_ict(system._h, self.mode, self.fill_in, self.threshold, _stream()))
+
+    def __matmul__(self, r):
+        raise TypeError("ICT needs the system matrix: attach it with CsrSystem.set_preconditioner")
+
+
 class _DevArray:
     """Zero-copy view of a device buffer the library hands to a callback (CUDA array interface, fp64 vector)."""
 

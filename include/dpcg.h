@@ -120,6 +120,14 @@ int dpcg_set_precond_llt(dpcg_handle_t h, int mode, int64_t nnz, const int32_t *
                          const double *val, int memspace, dpcg_stream_t stream);
 /* IC(0) of A (stands in for ilupp.ichol0, test.py:83), then as dpcg_set_precond_llt. */
 int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t stream);
+/* ICT: thresholded incomplete Cholesky with level-1 fill, then as dpcg_set_precond_llt.  Stands in for
+ * ilupp.icholt(A, add_fill_in=1, threshold=0.1), the DEFAULT of the reference's `_construct_incomplete_cholesky`
+ * (test.py:81-88; ichol0 only when both arguments are zeroed).  ilupp is not available to pin against; the contract
+ * (oracle/oracle.py::ict) is: pattern = tril(A) plus the fill created by eliminating with original entries only
+ * (fill_in >= 1; 0 = no fill); row-wise numeric phase in the operation order of IC(0); an off-diagonal entry v = acc /
+ * L_jj is dropped when |v| * L_jj < threshold * ||A(j:n, j)||_1 (the rule MATLAB documents for ichol 'ict').
+ * fill_in = 0, threshold = 0 reproduces dpcg_set_precond_ic0 bit for bit. */
+int dpcg_set_precond_ict(dpcg_handle_t h, int mode, int fill_in, double threshold, dpcg_stream_t stream);
 /* The reference's operator protocol asks of M nothing but `M @ rk` (cg.py:61,81).  An M that is not a matrix this library
  * can hold (a Python object with __matmul__, a multigrid cycle, ...) is applied through a function the caller supplies:
  * fn(user, r, z, n, stream) must ENQUEUE z = M r on `stream` (device pointers, caller's numbering; it is called from the

@@ -148,6 +148,74 @@ def ic0(A: sp.csr_matrix) -> sp.csr_matrix:
     return sp.csr_matrix((lv, ci.copy(), rp.copy()), shape=T.shape)
 
 
+def ict(A: sp.csr_matrix, fill_in: int = 1, threshold: float = 0.1) -> sp.csr_matrix:
+    """Thresholded incomplete Cholesky with level-1 fill: the contract of `CsrSystem.set_preconditioner(ICT(...))`.
+
+    Stands in for `ilupp.icholt(A, add_fill_in=1, threshold=0.1)`, the reference harness's DEFAULT incomplete-Cholesky
+    technique (test.py:81-88).  ilupp is absent (not vendored, no network) and publishes no test vectors: PARITY
+    UNPINNED.  The algorithm restated here is the textbook one -- level-of-fill symbolic phase (Saad 2003, IC(p)) with the
+    drop rule MATLAB documents for `ichol(..., type='ict')`:
+      pattern  S_i = {j <= i : a_ij != 0}  plus, for fill_in >= 1, {j < i : there is k < j with a_ik != 0 and a_jk != 0}
+               (fill created by eliminating with ORIGINAL entries only; fill_in > 1 is treated as 1);
+      numeric  row by row, stored columns ascending:  acc = a_ij (0 for a fill position) - sum_{m<j, m in S_i & S_j} L_im L_jm
+               (ascending m, one product and one subtraction at a time);  j < i:  v = acc / L_jj, and v is DROPPED (stored as
+               0, so later sums see 0) when |v| * L_jj < threshold * ||A(j:n, j)||_1;  j = i:  L_ii = sqrt(acc) > 0;
+      result   L without the dropped entries, columns ascending, diagonal last.
+    threshold = 0 and fill_in = 0 give IC(0) exactly (same operation order as `ic0`)."""
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    n = A.shape[0]
+    arp, aci, av = A.indptr, A.indices, A.data.astype(np.float64)
+    colnorm = np.zeros(n)
+    for j in range(n):
+        for k in range(arp[j], arp[j + 1]):
+            if aci[k] >= j:
+                colnorm[j] += abs(av[k])
+    rp = [0]
+    ci, lv = [], []
+    for i in range(n):
+        row = {int(aci[k]): float(av[k]) for k in range(arp[i], arp[i + 1]) if aci[k] <= i}
+        if fill_in >= 1:
+            for k in [c for c in row if c < i]:
+                for q in range(arp[k], arp[k + 1]):
+                    j = int(aci[q])
+                    if k < j < i and j not in row:
+                        row[j] = 0.0
+        for c in sorted(row):
+            ci.append(c)
+            lv.append(row[c])
+        rp.append(len(ci))
+    rp, ci, lv = np.array(rp), np.array(ci), np.array(lv, dtype=np.float64)
+    for i in range(n):
+        s_i, e_i = rp[i], rp[i + 1]
+        for k in range(s_i, e_i):
+            j = ci[k]
+            s_j, e_j = rp[j], rp[j + 1]
+            acc = lv[k]
+            a, b = s_i, s_j
+            while a < k and b < e_j - 1:
+                ca, cb = ci[a], ci[b]
+                if ca == cb:
+                    acc = acc - lv[a] * lv[b]
+                    a += 1
+                    b += 1
+                elif ca < cb:
+                    a += 1
+                else:
+                    b += 1
+            if j < i:
+                d = lv[e_j - 1]
+                v = acc / d
+                lv[k] = 0.0 if abs(v) * d < threshold * colnorm[j] else v
+            else:
+                if not acc > 0.0:
+                    raise ValueError(f"ICT: non-positive pivot at row {i}")
+                lv[k] = np.sqrt(acc)
+    keep = (lv != 0.0) | (ci == np.repeat(np.arange(n), np.diff(rp)))
+    out_rp = np.concatenate(([0], np.cumsum(np.add.reduceat(keep.astype(np.int64), rp[:-1]))))
+    return sp.csr_matrix((lv[keep], ci[keep], out_rp), shape=A.shape)
+
+
 def learned_like_factor(A: sp.csr_matrix, seed: int = 0, scale: float = 0.05, diag_sigma: float = 1.0) -> sp.csr_matrix:
     """A seeded stand-in for the CNN output L = PreconditionerNet(tril(A)) (model.py:42-59).
 

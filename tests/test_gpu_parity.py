@@ -1275,3 +1275,39 @@ def test_any_object_with_matmul_as_preconditioner(D):
 
     with pytest.raises(RuntimeError, match="boom"):
         preconditioned_conjugate_gradient(A, torch.from_numpy(b), Broken())
+
+
+def test_ict_level1_fill_with_drop_tolerance(D):
+    """ICT, the reference harness's default incomplete-Cholesky technique (`ilupp.icholt(add_fill_in=1, threshold=0.1)`,
+    test.py:81-88).  ilupp is absent: parity is UNPINNED against it; what is checked is the stated contract -- the device
+    factor equals the CPU restatement `oracle.ict` bit for bit (pattern and values), fill_in = 0 / threshold = 0 is IC(0),
+    L has a positive diagonal (so L L^T is SPD), with threshold 0 the product L L^T matches A on the pattern of L L^T's
+    own factor (the defining property of an incomplete factorisation on a fixed pattern) and is closer to A than IC(0);
+    PCG with it matches the oracle with the same factor."""
+    for A, thr in ((O.poisson2d(24), 0.0), (O.unstructured_like(O.poisson3d(9), seed=2), 0.0),
+                   (O.unstructured_like(O.poisson3d(9), seed=2), 0.02), (O.poisson3d(10), 0.1)):
+        n = A.shape[0]
+        S = D.CsrSystem.from_any(A)
+        S.set_preconditioner(D.ICT("solve", fill_in=1, threshold=thr))
+        rp, ci, v = S.factor()
+        Lref = O.ict(A, 1, thr)
+        assert np.array_equal(rp, Lref.indptr) and np.array_equal(ci, Lref.indices) and np.array_equal(v, Lref.data)
+        L = sp.csr_matrix((v, ci, rp), shape=A.shape)
+        assert (L.diagonal() > 0).all() and sp.triu(L, 1).nnz == 0
+        R = (L @ L.T - A).tocsr()
+        if thr == 0.0:
+            pat = (L != 0).astype(np.int8)                           # on the factor's own pattern the product is exact
+            on_pattern = R.multiply(pat + pat.T)
+            assert abs(on_pattern).max() < 1e-12 * abs(A).max()
+            L0 = O.ic0(A)
+            assert sp.linalg.norm(R) < sp.linalg.norm(L0 @ L0.T - A)
+        b = O.rhs(n, 1)
+        res = S.solve(_dev(b))
+        _, it, hist, _ = CO.pcg(A, b, "llt_solve", L=Lref)
+        assert res.iterations == it and res.status == 0
+        np.testing.assert_allclose(res.res_history, hist, rtol=1e-9)
+        S.set_preconditioner(D.ICT("multiply", fill_in=0, threshold=0.0))        # IC(0)
+        assert np.array_equal(S.factor()[2], CO.ic0(A).data)
+        S.close()
+    with pytest.raises(ValueError):
+        D.ICT("solve", fill_in=-1)
