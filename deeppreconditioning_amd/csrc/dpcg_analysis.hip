@@ -294,6 +294,42 @@ void launch_ring_records(int64_t n, const uint32_t *lvl_of_pos, const int32_t *r
                        lo_rp, lo_ci, lo_cp, lo_v, meta, pv);
 }
 
+// Fixed-width records for the sync-free kernel (Levels::sf_meta / sf_val), one per level-order position j:
+//   sf_meta[j] = {c0, c1, c2, row}: the (relabelled) column indices of the first three off-diagonal entries (-1 = no
+//                such entry; c0 = -2: more than three, the row walks lo_rowptr instead) and its own row index;
+//   sf_val[4j..4j+3] = {v0, v1, v2, diagonal}.
+// Addressed by position alone, so a row's data can be requested before anything about the row is known.
+__global__ __launch_bounds__(kBlock) void k_sf_records(int64_t n, const int32_t *__restrict__ rows,
+                                                       const int32_t *__restrict__ lo_rp, const int32_t *__restrict__ lo_ci,
+                                                       const double *__restrict__ lo_v, int upper, int32_t *__restrict__ meta,
+                                                       double *__restrict__ pv) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        int m[4] = {-1, -1, -1, -1};
+        double w[4] = {0.0, 0.0, 0.0, 0.0};
+        const int a = lo_rp[j], b = lo_rp[j + 1];
+        const int ks = upper ? a + 1 : a, ke = upper ? b : b - 1;      // the diagonal is first (L^T) or last (L)
+        m[3] = rows[j];
+        w[3] = lo_v[upper ? a : b - 1];
+        if (ke - ks > 3) {
+            m[0] = -2;
+        } else {
+            for (int k = ks; k < ke; ++k) {
+                m[k - ks] = lo_ci[k];
+                w[k - ks] = lo_v[k];
+            }
+        }
+        reinterpret_cast<int4 *>(meta)[j] = make_int4(m[0], m[1], m[2], m[3]);
+        reinterpret_cast<double2 *>(pv)[2 * j] = make_double2(w[0], w[1]);
+        reinterpret_cast<double2 *>(pv)[2 * j + 1] = make_double2(w[2], w[3]);
+    }
+}
+
+void launch_sf_records(int64_t n, const int32_t *rows, const int32_t *lo_rp, const int32_t *lo_ci, const double *lo_v,
+                       bool upper, int32_t *meta, double *pv, hipStream_t s) {
+    hipLaunchKernelGGL(k_sf_records, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows, lo_rp, lo_ci, lo_v, upper ? 1 : 0, meta, pv);
+}
+
 // ------------------------------------------------------------------------------------------------
 // tril(A) for IC(0): count, then copy, entries with col <= row; *flag = 1 when a row's last kept entry is not its diagonal
 // ------------------------------------------------------------------------------------------------

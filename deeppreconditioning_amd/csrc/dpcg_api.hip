@@ -84,6 +84,8 @@ void free_levels(Levels &l) {
     dev_free(l.pk_meta);
     dev_free(l.pk_val);
     dev_free(l.b_lo);
+    dev_free(l.sf_meta);
+    dev_free(l.sf_val);
     dev_free(l.tickets);
     dev_free(l.spin_err);
     l = Levels();

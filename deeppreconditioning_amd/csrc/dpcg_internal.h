@@ -124,6 +124,8 @@ struct Levels {
     int32_t *pk_meta = nullptr;
     double *pk_val = nullptr;
     double *b_lo = nullptr;                // scratch: the right-hand side gathered into level order
+    int32_t *sf_meta = nullptr;            // records of the sync-free kernel (dpcg_analysis.hip: k_sf_records)
+    double *sf_val = nullptr;
     unsigned long long *tickets = nullptr; // one monotonic block-ticket counter per segment (sync-free segments use theirs)
     int *spin_err = nullptr;               // set by a sync-free kernel whose bounded poll ran out
 };
@@ -302,6 +304,8 @@ void launch_ring_reach(int64_t n, const uint32_t *lvl_of_pos, const int32_t *seg
 void launch_ring_records(int64_t n, const uint32_t *lvl_of_pos, const int32_t *ring_start_of_level, const int32_t *rows,
                          const int32_t *lo_rp, const int32_t *lo_ci, const int32_t *lo_cp, const double *lo_v,
                          int32_t *meta, double *pv, hipStream_t s);
+void launch_sf_records(int64_t n, const int32_t *rows, const int32_t *lo_rp, const int32_t *lo_ci, const double *lo_v,
+                       bool upper, int32_t *meta, double *pv, hipStream_t s);
 void launch_tril_count(int64_t n, const int32_t *rp, const int32_t *ci, int32_t *cnt, int *flag, hipStream_t s);
 void launch_tril_copy(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, const int32_t *lrp, int32_t *lci,
                       double *lv, hipStream_t s);

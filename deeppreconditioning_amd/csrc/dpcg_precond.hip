@@ -178,8 +178,9 @@ int compute_levels(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, 
 // solve kernels use to address the right-hand side and the solution are mapped, so the arithmetic -- and its order --
 // is that of the factor in the caller's numbering.
 int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_t *rp, const int32_t *ci, const double *v,
-                 hipStream_t s, const int32_t *relabel = nullptr) {
+                 hipStream_t s, const int32_t *relabel = nullptr, bool upper = false) {
     constexpr int kMergeMax = 2048;  // levels this narrow are walked by one workgroup
+    PhaseTimer pt(s);
     lv.level_ptr = ls.level_ptr;
     lv.n_levels = (int)ls.level_ptr.size() - 1;
     const std::vector<int32_t> &level_ptr = lv.level_ptr;
@@ -196,7 +197,9 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
     DPCG_TRY(dev_alloc(&lv.lo_val, nnz));
     launch_lo_lengths(n, lv.rows, rp, len.p, pos.p, s);
     DPCG_TRY(exclusive_scan_i32(len.p, lv.lo_rowptr, n + 1, s));
+    pt.mark("  alloc + lengths + scan");
     launch_lo_copy(n, lv.rows, rp, ci, v, pos.p, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, s);
+    pt.mark("  level-ordered copy");
     if (relabel) {
         launch_relabel(n, relabel, lv.rows, s);
         launch_relabel(nnz, relabel, lv.lo_col, s);
@@ -261,6 +264,7 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         DPCG_HIP(hipStreamSynchronize(s));
     }
     lv.stream_ok = h_flag == 0;
+    pt.mark("  segments + ring reach");
     // Everything that is not walked through an LDS ring -- wide levels, and narrow runs whose reach is too long for the
     // ring -- goes to the sync-free multi-workgroup kernel, neighbouring such segments as ONE launch.  A single level on
     // its own keeps the plain level kernel (nothing inside it to wait for).
@@ -284,7 +288,10 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         // are the cost, and the level kernels' gathers may use the L1 / L2 where the polling loads of the sync-free
         // kernel bypass them (measured, scrambled 1M-DoF factor, 19 levels of ~52K rows: 313 vs 372 us per apply; natural
         // 100^3 factor, 298 levels of <= 7.5K rows: 2457 vs 1555 us)
-        constexpr int kSyncfreeMaxMeanWidth = 16384;
+        static const int64_t kSyncfreeMaxMeanWidth = [] {
+            const char *e = getenv("DPCG_SF_MAX_MEAN_WIDTH");      // development knob
+            return e ? (int64_t)atoll(e) : (int64_t)1 << 40;
+        }();
         for (auto &seg : merged_segs) {
             const int64_t rows_in_seg = (int64_t)level_ptr[seg.hi] - level_ptr[seg.lo];
             if (seg.syncfree && (seg.hi - seg.lo < 2 || rows_in_seg / (seg.hi - seg.lo) > kSyncfreeMaxMeanWidth)) seg.syncfree = false;
@@ -309,12 +316,16 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
             launch_block_nnz_max_raw(level_ptr[seg.hi] - j0, lv.lo_rowptr + j0, kStreamRows, reinterpret_cast<int *>(d_max.p + q), s);
         }
         if (any) {
+            DPCG_TRY(dev_alloc(&lv.sf_meta, n * 4));
+            DPCG_TRY(dev_alloc(&lv.sf_val, n * 4));
+            launch_sf_records(n, lv.rows, lv.lo_rowptr, lv.lo_col, lv.lo_val, upper, lv.sf_meta, lv.sf_val, s);
             std::vector<int32_t> h_max((size_t)nseg, 0);
             DPCG_HIP(hipMemcpyAsync(h_max.data(), d_max.p, h_max.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
             DPCG_HIP(hipStreamSynchronize(s));
             for (int64_t q = 0; q < nseg; ++q) lv.segments[(size_t)q].staged = h_max[(size_t)q] <= kStreamCap;
         }
     }
+    pt.mark("  sync-free records");
     if (any_ring) {                                      // fixed-width row records (see Levels::pk_meta)
         std::vector<int32_t> ring_start((size_t)lv.n_levels, -1);
         for (const auto &seg : lv.segments)
@@ -328,6 +339,7 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         launch_ring_records(n, ls.lvl_of_pos.p, d_seg_of_level.p, lv.rows, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val,
                             lv.pk_meta, lv.pk_val, s);
         DPCG_HIP(hipStreamSynchronize(s));
+        pt.mark("  ring records");
     }
     DPCG_CHECK_LAUNCH();
     return DPCG_OK;
@@ -402,7 +414,7 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
         pt.mark("schedule(L)");
         DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s));
         pt.mark("levels(L^T)");
-        DPCG_TRY(build_levels(h->lvlU, up, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, s, h->iperm));
+        DPCG_TRY(build_levels(h->lvlU, up, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, s, h->iperm, true));
         pt.mark("schedule(L^T)");
     }
     h->precond = mode;

@@ -442,7 +442,104 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree(const int32_t *__res
     }
 }
 
+// The same protocol on fixed-width records (Levels::sf_meta / sf_val): everything a row needs -- three column indices,
+// three values, the diagonal, its own index -- comes from two 16-byte and one 32-byte load addressed by the level-order
+// position alone, issued the moment the block is drawn; no row extents to wait for, no LDS stage, no workgroup barrier
+// besides the ticket hand-out.  Rows with more than three off-diagonal entries (meta.x == -2) walk lo_rowptr.
+template <bool UPPER>
+__global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_rec(int j0, int count, const int32_t *__restrict__ lo_rp,
+                                                                const int32_t *__restrict__ lo_ci,
+                                                                const double *__restrict__ lo_v,
+                                                                const int4 *__restrict__ meta,
+                                                                const double2 *__restrict__ val,
+                                                                const double *__restrict__ rhs, double *out,
+                                                                unsigned int *ticket /* [0] next block, [1] exits */,
+                                                                int nblocks, const int *done, int *err) {
+    __shared__ unsigned int s_lb;
+    const int t = threadIdx.x;
+    if (done && *done) return;                      // nothing drawn: the counters stay zero
+    for (;;) {
+        __syncthreads();
+        if (t == 0) s_lb = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const unsigned int lb = s_lb;
+        if (lb >= (unsigned int)nblocks) break;
+        const int j = j0 + (int)lb * kBlock + t;
+        const bool valid = j < j0 + count;
+        const int jc = valid ? j : j0;              // lanes without a row load a valid record and ignore it
+        const int4 m = meta[jc];
+        const double2 v01 = val[2 * (int64_t)jc], v2d = val[2 * (int64_t)jc + 1];
+        const double bi = rhs[m.w];
+        bool stored = !valid;
+        unsigned spins = 0;
+        // ONE loop for every lane of the wave, left by the whole wave at once (lanes may wait for each other, and a
+        // store on an exit path would only run after every lane has left).  Short rows (<= 3 entries): all entries are
+        // asked for at once, the pending ones again, and consumed in column order.  Long rows (meta.x == -2) walk the
+        // level-ordered copy one entry at a time.
+        const bool longrow = m.x == -2;
+        const double pend = __longlong_as_double((long long)kPendingBits);
+        double y0 = (!longrow && m.x >= 0) ? pend : 0.0, y1 = (!longrow && m.y >= 0) ? pend : 0.0,
+               y2 = (!longrow && m.z >= 0) ? pend : 0.0;
+        int k = 0, ke = 0;
+        double acc = bi;
+        if (longrow) {
+            const int s = lo_rp[jc], e = lo_rp[jc + 1];
+            k = UPPER ? s + 1 : s;
+            ke = UPPER ? e : e - 1;
+        }
+        for (;;) {
+            if (!stored) {
+                bool ready = false, waited = false;
+                if (longrow) {
+                    if (k < ke) {
+                        const double y = __hip_atomic_load(out + lo_ci[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!is_pending(y)) {
+                            acc -= lo_v[k] * y;
+                            ++k;
+                            spins = 0;
+                        } else {
+                            waited = true;
+                        }
+                    }
+                    ready = k >= ke;
+                } else {
+                    if (is_pending(y0)) y0 = __hip_atomic_load(out + m.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (is_pending(y1)) y1 = __hip_atomic_load(out + m.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (is_pending(y2)) y2 = __hip_atomic_load(out + m.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ready = !is_pending(y0) && !is_pending(y1) && !is_pending(y2);
+                    waited = !ready;
+                    if (ready) {
+                        if (m.x >= 0) acc -= v01.x * y0;
+                        if (m.y >= 0) acc -= v01.y * y1;
+                        if (m.z >= 0) acc -= v2d.x * y2;
+                    }
+                }
+                if (waited && ++spins > (1u << 22)) {   // bounded: never hang the device on a malformed schedule
+                    atomicExch(err, 1);
+                    acc = __builtin_nan("");
+                    ready = true;
+                }
+                if (ready) {
+                    __hip_atomic_store(out + m.w, acc / v2d.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    stored = true;
+                } else if (waited) {
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (__ballot(!stored) == 0) break;
+        }
+    }
+    if (t == 0 && atomicAdd(ticket + 1, 1u) == gridDim.x - 1) {      // last one out: zero the counters for the next launch
+        atomicExch(ticket, 0u);
+        atomicExch(ticket + 1, 0u);
+    }
+}
+
 constexpr int kRingChunk = 6;   // levels per prefetch chunk of k_sptrsv_ring_pipe (3 with two rows per thread)
+static bool syncfree_staged_forced() {   // DPCG_SF_STAGED=1: the LDS-staged sync-free kernel instead of the record one (A/B)
+    static const bool on = [] { const char *e = getenv("DPCG_SF_STAGED"); return e && e[0] == '1'; }();
+    return on;
+}
 static bool ring_pipe_disabled() {
     static const bool off = [] { const char *e = getenv("DPCG_RING_PIPE"); return e && e[0] == '0'; }();
     return off;
@@ -465,6 +562,18 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
             grid = grid > nblocks ? nblocks : grid;
             grid = grid > 1536 ? 1536 : grid;       // 6 workgroups per CU (24 KiB of LDS each): all resident
             hipLaunchKernelGGL(k_fill_pending, dim3(nblocks), dim3(kBlock), 0, s, lv.rows, j0, cnt, out, done);
+            if (lv.sf_meta && !syncfree_staged_forced()) {
+                grid = grid > 2048 ? 2048 : grid;
+                if (upper)
+                    hipLaunchKernelGGL(k_sptrsv_syncfree_rec<true>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_col,
+                                       lv.lo_val, (const int4 *)lv.sf_meta, (const double2 *)lv.sf_val, rhs, out,
+                                       reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nblocks, done, lv.spin_err);
+                else
+                    hipLaunchKernelGGL(k_sptrsv_syncfree_rec<false>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_col,
+                                       lv.lo_val, (const int4 *)lv.sf_meta, (const double2 *)lv.sf_val, rhs, out,
+                                       reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nblocks, done, lv.spin_err);
+                continue;
+            }
 #define DPCG_SYNCFREE(UP, ST)                                                                                          \
     hipLaunchKernelGGL((k_sptrsv_syncfree<UP, ST>), dim3(grid), dim3(kBlock), 0, s, lv.rows, j0, cnt, lv.lo_rowptr,     \
                        lv.lo_col, lv.lo_val, rhs, out, reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nblocks, \

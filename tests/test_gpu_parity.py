@@ -1311,3 +1311,27 @@ def test_ict_level1_fill_with_drop_tolerance(D):
         S.close()
     with pytest.raises(ValueError):
         D.ICT("solve", fill_in=-1)
+
+
+def test_config4_full_size_system_against_the_oracle(D):
+    """BASELINE config 4 at FULL size against the oracle itself, not only through properties: one 256^3 system (16.8M DoF,
+    117M non-zeros, right-hand side of batch member 3) solved by the HIP path and by oracle/pcg_oracle.c on the host
+    cores (OpenMP; ~12 s on the GPU box) -- same iteration count, residual history within north_star's 1e-10, same x."""
+    import os
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    from deeppreconditioning_amd import poisson
+    S = poisson.poisson_system(3, 256)
+    S.set_preconditioner(D.Jacobi())
+    res = S.solve(poisson.rhs(S.n, 3))
+    xg = res.x.cpu().numpy()
+    S.close()
+    A = O.poisson3d(256)
+    threads = CO.num_threads()
+    CO.set_num_threads(min(32, threads))
+    try:
+        _, it, hist, x = CO.pcg(A, O.rhs(A.shape[0], 3), "jacobi", dinv=O.jacobi_dinv(A))
+    finally:
+        CO.set_num_threads(threads)
+    assert res.iterations == it and res.status == 0
+    np.testing.assert_allclose(res.res_history, hist, rtol=HIST_RTOL)
+    np.testing.assert_allclose(xg, x, rtol=1e-9, atol=1e-12)
