@@ -229,16 +229,32 @@ __global__ __launch_bounds__(kBlock) void k_ring_reach(int64_t n, const uint32_t
                                                        const int32_t *__restrict__ lo_rp,
                                                        const int32_t *__restrict__ lo_cp, int32_t *maxdist) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
-        const int sg = seg_of_level[lvl_of_pos[j]];
-        if (sg < 0) continue;
-        const int start = seg_start[sg];
-        int d = 0;
-        for (int k = lo_rp[j]; k < lo_rp[j + 1]; ++k) {
-            const int cp = lo_cp[k];
-            if (cp >= start && cp < j) d = (int)j - cp > d ? (int)j - cp : d;
+    const int64_t first = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (int64_t j0 = first - threadIdx.x % 64; j0 < n; j0 += stride) {     // whole waves stay in the loop together
+        const int64_t j = j0 + threadIdx.x % 64;
+        int sg = -1, d = 0;
+        if (j < n) {
+            sg = seg_of_level[lvl_of_pos[j]];
+            if (sg >= 0) {
+                const int start = seg_start[sg];
+                for (int k = lo_rp[j]; k < lo_rp[j + 1]; ++k) {
+                    const int cp = lo_cp[k];
+                    if (cp >= start && cp < j) d = (int)j - cp > d ? (int)j - cp : d;
+                }
+            }
         }
-        if (d > 0) atomicMax(maxdist + sg, d);
+        // positions of a segment are contiguous, so a wave almost always sits inside one segment: one atomic per wave
+        // (a million atomics on the single counter of a 2-D factor's one merged segment took 12 ms)
+        const int sg0 = __shfl(sg, 0);
+        if (__ballot(sg != sg0) == 0) {
+            for (int off = 32; off > 0; off >>= 1) {
+                const int o = __shfl_down(d, off);
+                d = o > d ? o : d;
+            }
+            if (threadIdx.x % 64 == 0 && sg0 >= 0 && d > 0) atomicMax(maxdist + sg0, d);
+        } else if (sg >= 0 && d > 0) {
+            atomicMax(maxdist + sg, d);
+        }
     }
 }
 

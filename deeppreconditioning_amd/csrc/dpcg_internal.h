@@ -105,8 +105,8 @@ struct Levels {
     // [lo,hi) levels; merged = one workgroup walks them; ring_w > 0: the solution entries the segment's rows depend
     // on lie within the last ring_w level-order positions, so they are handed from level to level through LDS
     // syncfree: the segment's rows (several levels) are solved by ONE multi-workgroup launch in which a row polls the
-    // entries it depends on until they have been written (k_sptrsv_syncfree); staged: its 256-row blocks fit the LDS
-    struct Segment { int lo, hi; bool merged; int ring_w; int max_width; bool syncfree = false; bool staged = false; };
+    // entries it depends on until they have been written (k_sptrsv_syncfree_rec)
+    struct Segment { int lo, hi; bool merged; int ring_w; int max_width; bool syncfree = false; };
     std::vector<Segment> segments;
     int32_t *level_ptr_dev = nullptr;      // device copy of level_ptr
     // the factor once more, rows stored in level order (row j of this copy = original row rows[j]): the
@@ -267,6 +267,9 @@ int launch_pcg_small(const SmallDesc *descs_dev, int count, int lds_bytes, int k
                      hipStream_t s);
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
                       hipStream_t s, const double *colnorm = nullptr, double tau = 0.0);   // colnorm: ICT drop rule
+void launch_ic0_syncfree(const int32_t *rows, int64_t n, const int32_t *rp, const int32_t *ci, double *lv, int *ready_zeroed,
+                         unsigned int *ticket_zeroed, int *bad, int *err, hipStream_t s, const double *colnorm = nullptr,
+                         double tau = 0.0);
 void launch_colnorm1(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, double *c, hipStream_t s);
 void launch_ict_pattern(bool write, int64_t n, const int32_t *rp, const int32_t *ci, const double *v, int fill, int32_t *cnt,
                         const int32_t *lrp, int32_t *lci, double *lv, int *flags, hipStream_t s);
@@ -274,7 +277,6 @@ void launch_count_kept(int64_t n, const int32_t *rp, const int32_t *ci, const do
 void launch_copy_kept(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, const int32_t *orp, int32_t *oci,
                       double *ov, hipStream_t s);
 void launch_block_nnz_max(const CsrDev &A, int rows_per_block, int *out_max_dev, hipStream_t s);
-void launch_block_nnz_max_raw(int64_t n, const int32_t *rowptr, int rows_per_block, int *out_max_dev, hipStream_t s);
 // ---- reordering (dpcg_reorder.hip) ----
 void launch_gather_f64(int64_t n, const int32_t *perm, const double *in, double *out, hipStream_t s);    // out[r] = in[perm[r]]
 void launch_scatter_f64(int64_t n, const int32_t *perm, const double *in, double *out, hipStream_t s);   // out[perm[r]] = in[r]

@@ -92,6 +92,9 @@ extern "C" int dpcg_set_precond_csr(dpcg_handle_t h, int64_t nnz, const int32_t 
 // the level offsets (one int per level) to plan the launches.
 // ------------------------------------------------------------------------------------------------
 namespace {
+struct LevelSort;
+int numeric_incomplete_cholesky(const LevelSort &ls, int64_t n, CsrDev &F, int *bad_dev, const double *colnorm, double tau,
+                                hipStream_t s);
 // DPCG_SYNCFREE=0 keeps one launch per wide level (development A/B)
 bool syncfree_enabled() {
     static const bool on = [] { const char *e = getenv("DPCG_SYNCFREE"); return !(e && e[0] == '0'); }();
@@ -170,6 +173,36 @@ int compute_levels(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, 
                             hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
     DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
+// The numeric phase of IC(0) / ICT on the pattern held in F (values: the matrix entries, zeros at fill positions): one
+// sync-free launch, or -- DPCG_SYNCFREE=0, or many levels being no issue -- one launch per level.
+int numeric_incomplete_cholesky(const LevelSort &ls, int64_t n, CsrDev &F, int *bad_dev, const double *colnorm, double tau,
+                                hipStream_t s) {
+    const int nl = (int)ls.level_ptr.size() - 1;
+    if (!syncfree_enabled() || nl <= 8) {
+        for (int l = 0; l < nl; ++l)
+            launch_ic0_level(ls.rows.p, ls.level_ptr[l], ls.level_ptr[l + 1] - ls.level_ptr[l], F.rowptr, F.col, F.val, bad_dev, s,
+                             colnorm, tau);
+        DPCG_CHECK_LAUNCH();
+        return DPCG_OK;
+    }
+    DevBuf<int32_t> ready, ctl;
+    DPCG_TRY(ready.alloc(n));
+    DPCG_TRY(ctl.alloc(2));
+    DPCG_HIP(hipMemsetAsync(ready.p, 0, (size_t)n * sizeof(int32_t), s));
+    DPCG_HIP(hipMemsetAsync(ctl.p, 0, 2 * sizeof(int32_t), s));
+    launch_ic0_syncfree(ls.rows.p, n, F.rowptr, F.col, F.val, reinterpret_cast<int *>(ready.p),
+                        reinterpret_cast<unsigned int *>(ctl.p), bad_dev, reinterpret_cast<int *>(ctl.p + 1), s, colnorm, tau);
+    int32_t h_ctl[2] = {0, 0};
+    DPCG_HIP(hipMemcpyAsync(h_ctl, ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    DPCG_CHECK_LAUNCH();
+    if (h_ctl[1]) {
+        set_error("incomplete Cholesky: a row waited for a row that was never finished");
+        return DPCG_ERR_STATE;
+    }
     return DPCG_OK;
 }
 
@@ -290,7 +323,7 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         // 100^3 factor, 298 levels of <= 7.5K rows: 2457 vs 1555 us)
         static const int64_t kSyncfreeMaxMeanWidth = [] {
             const char *e = getenv("DPCG_SF_MAX_MEAN_WIDTH");      // development knob
-            return e ? (int64_t)atoll(e) : (int64_t)1 << 40;
+            return e ? (int64_t)atoll(e) : (int64_t)16384;
         }();
         for (auto &seg : merged_segs) {
             const int64_t rows_in_seg = (int64_t)level_ptr[seg.hi] - level_ptr[seg.lo];
@@ -304,25 +337,12 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         DPCG_TRY(dev_alloc(&lv.spin_err, 1));
         DPCG_HIP(hipMemsetAsync(lv.tickets, 0, (size_t)nseg * sizeof(unsigned long long), s));
         DPCG_HIP(hipMemsetAsync(lv.spin_err, 0, sizeof(int), s));
-        DevBuf<int32_t> d_max;
-        DPCG_TRY(d_max.alloc(nseg));
-        DPCG_HIP(hipMemsetAsync(d_max.p, 0, (size_t)nseg * sizeof(int32_t), s));
         bool any = false;
-        for (int64_t q = 0; q < nseg; ++q) {
-            const Levels::Segment &seg = lv.segments[(size_t)q];
-            if (!seg.syncfree) continue;
-            any = true;
-            const int j0 = level_ptr[seg.lo];
-            launch_block_nnz_max_raw(level_ptr[seg.hi] - j0, lv.lo_rowptr + j0, kStreamRows, reinterpret_cast<int *>(d_max.p + q), s);
-        }
+        for (const auto &seg : lv.segments) any = any || seg.syncfree;
         if (any) {
             DPCG_TRY(dev_alloc(&lv.sf_meta, n * 4));
             DPCG_TRY(dev_alloc(&lv.sf_val, n * 4));
             launch_sf_records(n, lv.rows, lv.lo_rowptr, lv.lo_col, lv.lo_val, upper, lv.sf_meta, lv.sf_val, s);
-            std::vector<int32_t> h_max((size_t)nseg, 0);
-            DPCG_HIP(hipMemcpyAsync(h_max.data(), d_max.p, h_max.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            DPCG_HIP(hipStreamSynchronize(s));
-            for (int64_t q = 0; q < nseg; ++q) lv.segments[(size_t)q].staged = h_max[(size_t)q] <= kStreamCap;
         }
     }
     pt.mark("  sync-free records");
@@ -479,10 +499,7 @@ extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t str
     LevelSort ls;
     if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, ls, s)) < 0) return fail(st);
     pt.mark("levels(tril A)");
-    const int nl = (int)ls.level_ptr.size() - 1;
-    for (int l = 0; l < nl; ++l)
-        launch_ic0_level(ls.rows.p, ls.level_ptr[l], ls.level_ptr[l + 1] - ls.level_ptr[l], Lf.rowptr, Lf.col, Lf.val,
-                         reinterpret_cast<int *>(flags.p) + 1, s);
+    if ((st = numeric_incomplete_cholesky(ls, n, Lf, reinterpret_cast<int *>(flags.p) + 1, nullptr, 0.0, s)) < 0) return fail(st);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -546,10 +563,8 @@ extern "C" int dpcg_set_precond_ict(dpcg_handle_t h, int mode, int fill_in, doub
                        reinterpret_cast<int *>(flags.p), s);
     LevelSort ls;
     if ((st = compute_levels(n, S.rowptr, S.col, false, ls, s)) < 0) return fail(st);
-    const int nl = (int)ls.level_ptr.size() - 1;
-    for (int l = 0; l < nl; ++l)
-        launch_ic0_level(ls.rows.p, ls.level_ptr[l], ls.level_ptr[l + 1] - ls.level_ptr[l], S.rowptr, S.col, S.val,
-                         reinterpret_cast<int *>(flags.p) + 1, s, colnorm.p, threshold);
+    if ((st = numeric_incomplete_cholesky(ls, n, S, reinterpret_cast<int *>(flags.p) + 1, colnorm.p, threshold, s)) < 0)
+        return fail(st);
     // compaction: the dropped entries are stored zeros
     launch_count_kept(n, S.rowptr, S.col, S.val, cnt.p, s);
     if ((st = exclusive_scan_i32(cnt.p, Lf.rowptr, n + 1, s)) < 0) return fail(st);

@@ -23,16 +23,12 @@ __global__ __launch_bounds__(kBlock) void k_block_nnz_max(int64_t n, const int32
     atomicMax(out_max, m);
 }
 
-void launch_block_nnz_max_raw(int64_t n, const int32_t *rowptr, int rows_per_block, int *out_max_dev, hipStream_t s) {
-    const int64_t nrb = (n + rows_per_block - 1) / rows_per_block;
+void launch_block_nnz_max(const CsrDev &A, int rows_per_block, int *out_max_dev, hipStream_t s) {
+    const int64_t nrb = (A.n + rows_per_block - 1) / rows_per_block;
     int64_t g = (nrb + kBlock - 1) / kBlock;
     if (g > 1024) g = 1024;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_block_nnz_max, dim3((int)g), dim3(kBlock), 0, s, n, rowptr, rows_per_block, out_max_dev);
-}
-
-void launch_block_nnz_max(const CsrDev &A, int rows_per_block, int *out_max_dev, hipStream_t s) {
-    launch_block_nnz_max_raw(A.n, A.rowptr, rows_per_block, out_max_dev, s);
+    hipLaunchKernelGGL(k_block_nnz_max, dim3((int)g), dim3(kBlock), 0, s, A.n, A.rowptr, rows_per_block, out_max_dev);
 }
 
 // Closed-form 5-point / 7-point Poisson CSR (kron(I,T)+kron(T,I)[+...], T = tridiag(-1,2,-1)),

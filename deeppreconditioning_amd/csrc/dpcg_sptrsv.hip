@@ -344,108 +344,20 @@ __global__ __launch_bounds__(kBlock) void k_fill_pending(const int32_t *__restri
     if (idx < count) out[rows[j0 + idx]] = __longlong_as_double((long long)kPendingBits);
 }
 
+// The kernel works on fixed-width records (Levels::sf_meta / sf_val): everything a row needs -- three column indices,
+// three values, the diagonal, its own index -- comes from two 16-byte and one 32-byte load addressed by the level-order
+// position alone, issued the moment the block is drawn; no row extents to wait for, no LDS stage, no workgroup barrier
+// besides the ticket hand-out.  Rows with more than three off-diagonal entries (meta.x == -2) walk lo_rowptr.
 // The grid is PERSISTENT and sized to the wavefront (about twice the widest level): a workgroup draws the next 256-row
 // block when it has finished one, so only rows near the front are resident and polling.  (With one workgroup per block
 // and the whole factor resident, thousands of waves polled entries tens of levels away; their requests saturated the
 // L2 and a hop cost 3.6 us instead of the ~0.5 us an idle chip needs -- tools/hop_lab.)  The ticket word and an exit
 // counter sit side by side; the last workgroup to leave zeroes both for the next launch.
-template <bool UPPER, bool STAGED>
-__global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree(const int32_t *__restrict__ rows, int j0, int count,
-                                                            const int32_t *__restrict__ lo_rp,
-                                                            const int32_t *__restrict__ lo_ci,
-                                                            const double *__restrict__ lo_v,
-                                                            const double *__restrict__ rhs, double *out,
-                                                            unsigned int *ticket /* [0] next block, [1] exits */,
-                                                            int nblocks, const int *done, int *err) {
-    __shared__ unsigned int s_lb;
-    __shared__ double sv[STAGED ? kStreamCap : 1];
-    __shared__ int sc[STAGED ? kStreamCap : 1];
-    const int t = threadIdx.x;
-    if (done && *done) return;                      // nothing drawn: the counters stay zero
-    for (;;) {
-        __syncthreads();                            // everybody is done with s_lb / the LDS stage of the previous block
-        if (t == 0) s_lb = atomicAdd(ticket, 1u);
-        __syncthreads();
-        const unsigned int lb = s_lb;
-        if (lb >= (unsigned int)nblocks) break;
-        const int jb = j0 + (int)lb * kBlock;
-        const int jend = (jb + kBlock < j0 + count) ? jb + kBlock : j0 + count;
-        const int j = jb + t;
-        const int base = lo_rp[jb];
-        int rs = 0, re = 0, i = 0;
-        double bi = 0.0;
-        if (j < jend) {
-            rs = lo_rp[j] - base;
-            re = lo_rp[j + 1] - base;
-            i = rows[j];
-            bi = rhs[i];
-        }
-        if (STAGED) {                               // the block's contiguous val/col segment, coalesced, into LDS
-            const int cnt = lo_rp[jend] - base;
-            for (int k = t; k < cnt; k += kBlock) {
-                sv[k] = lo_v[base + k];
-                sc[k] = lo_ci[base + k];
-            }
-            __syncthreads();
-        }
-        auto val_at = [&](int k) { return STAGED ? sv[k] : lo_v[base + k]; };
-        auto col_at = [&](int k) { return STAGED ? sc[k] : lo_ci[base + k]; };
-        int k = UPPER ? rs + 1 : rs;
-        const int ke = UPPER ? re : re - 1;
-        const double diag = j < jend ? val_at(UPPER ? rs : re - 1) : 1.0;
-        double acc = bi;
-        unsigned spins = 0;
-        bool stored = j >= jend;                    // lanes without a row only keep the wave company
-        // up to four entries are in flight at once; only those still pending are asked for again; they are consumed
-        // in column order.  The loop is left by the whole wave at once (ballot), so that the store stays INSIDE it: on
-        // an exit path a SIMT machine would run it only after every lane has left, and lanes of one wave may wait for
-        // each other.
-        double y[4];
-        int have = 0;                               // entries k .. k+have-1 have been requested into y[0..have)
-        for (;;) {
-            if (!stored && k < ke) {
-                const int m = ke - k < 4 ? ke - k : 4;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q < m && (q >= have || is_pending(y[q])))
-                        y[q] = __hip_atomic_load(out + col_at(k + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                have = m;
-                int used = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (q == used && q < m && !is_pending(y[q])) {
-                        acc -= val_at(k + q) * y[q];
-                        ++used;
-                    }
-                if (used > 0) {                     // the requests behind a pending entry are simply made again
-                    k += used;
-                    have = 0;
-                    spins = 0;
-                } else if (++spins > (1u << 22)) {  // bounded: never hang the device on a malformed schedule
-                    atomicExch(err, 1);
-                    acc = __builtin_nan("");
-                    k = ke;
-                } else {
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            if (!stored && k >= ke) {
-                __hip_atomic_store(out + i, acc / diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                stored = true;
-            }
-            if (__ballot(!stored) == 0) break;
-        }
-    }
-    if (t == 0 && atomicAdd(ticket + 1, 1u) == gridDim.x - 1) {      // last one out: zero the counters for the next launch
-        atomicExch(ticket, 0u);
-        atomicExch(ticket + 1, 0u);
-    }
-}
-
-// The same protocol on fixed-width records (Levels::sf_meta / sf_val): everything a row needs -- three column indices,
-// three values, the diagonal, its own index -- comes from two 16-byte and one 32-byte load addressed by the level-order
-// position alone, issued the moment the block is drawn; no row extents to wait for, no LDS stage, no workgroup barrier
-// besides the ticket hand-out.  Rows with more than three off-diagonal entries (meta.x == -2) walk lo_rowptr.
+// Measured per apply (two solves), IC(0) of natural-order grids: 64^3 (190 levels) 1.05 ms vs 1.41 ms with one launch per
+// level; 100^3 (298 levels) 1.47 vs 2.46 ms.  A run of VERY wide levels (the scrambled 1M-DoF factor: 19 levels of ~52K
+// rows) is the other way round -- 0.43 ms vs 0.31 ms: there the level bodies, not the boundaries, are the cost, the
+// polling loads bypass the L1, and rows several levels ahead of the front poll for nothing -- so such runs keep one
+// launch per level (build_levels: mean level width > 16384).
 template <bool UPPER>
 __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_rec(int j0, int count, const int32_t *__restrict__ lo_rp,
                                                                 const int32_t *__restrict__ lo_ci,
@@ -536,10 +448,6 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_rec(int j0, int coun
 }
 
 constexpr int kRingChunk = 6;   // levels per prefetch chunk of k_sptrsv_ring_pipe (3 with two rows per thread)
-static bool syncfree_staged_forced() {   // DPCG_SF_STAGED=1: the LDS-staged sync-free kernel instead of the record one (A/B)
-    static const bool on = [] { const char *e = getenv("DPCG_SF_STAGED"); return e && e[0] == '1'; }();
-    return on;
-}
 static bool ring_pipe_disabled() {
     static const bool off = [] { const char *e = getenv("DPCG_RING_PIPE"); return e && e[0] == '0'; }();
     return off;
@@ -560,32 +468,16 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
             int grid = (factor * seg.max_width + kBlock - 1) / kBlock + 4;
             grid = grid < 16 ? 16 : grid;
             grid = grid > nblocks ? nblocks : grid;
-            grid = grid > 1536 ? 1536 : grid;       // 6 workgroups per CU (24 KiB of LDS each): all resident
+            grid = grid > 2048 ? 2048 : grid;       // 8 workgroups per CU: all resident
             hipLaunchKernelGGL(k_fill_pending, dim3(nblocks), dim3(kBlock), 0, s, lv.rows, j0, cnt, out, done);
-            if (lv.sf_meta && !syncfree_staged_forced()) {
-                grid = grid > 2048 ? 2048 : grid;
-                if (upper)
-                    hipLaunchKernelGGL(k_sptrsv_syncfree_rec<true>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_col,
-                                       lv.lo_val, (const int4 *)lv.sf_meta, (const double2 *)lv.sf_val, rhs, out,
-                                       reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nblocks, done, lv.spin_err);
-                else
-                    hipLaunchKernelGGL(k_sptrsv_syncfree_rec<false>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_col,
-                                       lv.lo_val, (const int4 *)lv.sf_meta, (const double2 *)lv.sf_val, rhs, out,
-                                       reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nblocks, done, lv.spin_err);
-                continue;
-            }
-#define DPCG_SYNCFREE(UP, ST)                                                                                          \
-    hipLaunchKernelGGL((k_sptrsv_syncfree<UP, ST>), dim3(grid), dim3(kBlock), 0, s, lv.rows, j0, cnt, lv.lo_rowptr,     \
-                       lv.lo_col, lv.lo_val, rhs, out, reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nblocks, \
-                       done, lv.spin_err)
-            if (upper) {
-                if (seg.staged) DPCG_SYNCFREE(true, true);
-                else DPCG_SYNCFREE(true, false);
-            } else {
-                if (seg.staged) DPCG_SYNCFREE(false, true);
-                else DPCG_SYNCFREE(false, false);
-            }
-#undef DPCG_SYNCFREE
+            if (upper)
+                hipLaunchKernelGGL(k_sptrsv_syncfree_rec<true>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_col,
+                                   lv.lo_val, (const int4 *)lv.sf_meta, (const double2 *)lv.sf_val, rhs, out,
+                                   reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nblocks, done, lv.spin_err);
+            else
+                hipLaunchKernelGGL(k_sptrsv_syncfree_rec<false>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_col,
+                                   lv.lo_val, (const int4 *)lv.sf_meta, (const double2 *)lv.sf_val, rhs, out,
+                                   reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nblocks, done, lv.spin_err);
             continue;
         }
         if (seg.merged && seg.ring_w > 0 && lv.pk_meta && !ring_pipe_disabled() && seg.max_width <= 1024 &&
@@ -696,6 +588,89 @@ __global__ __launch_bounds__(kBlock) void k_ic0_level(const int32_t *__restrict_
             lv[k] = sqrt(acc);
         }
     }
+}
+
+// The numeric factorisation in ONE launch (the per-level form above costs a launch per level: 2047 of them, 11 ms, for a
+// 1024^2 grid).  Rows are taken in level order through a ticket; a row that needs row j polls ready[j], which row j's
+// owner sets after its entries have been stored write-through and have drained (sc1 stores, s_waitcnt vmcnt(0), then
+// the flag: the `sc1 payload -> wait -> sc1 flag` hand-off); every read of another row's entries is an sc1 load.  The
+// arithmetic and its order are those of k_ic0_level, so the factor is the same, bit for bit.  Lanes of a wave may wait
+// for each other, hence one loop for the whole wave (left by ballot) in which a lane advances one entry per trip.
+template <bool DROP>
+__global__ __launch_bounds__(kBlock) void k_ic0_syncfree(const int32_t *__restrict__ rows, int64_t n,
+                                                         const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                         double *lv, int *ready, unsigned int *ticket, int *bad,
+                                                         const double *__restrict__ colnorm, double tau, int *err) {
+    __shared__ unsigned int s_lb;
+    if (threadIdx.x == 0) s_lb = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int64_t pos = (int64_t)s_lb * kBlock + threadIdx.x;
+    bool finished = pos >= n;
+    const int i = finished ? 0 : rows[pos];
+    const int s_i = finished ? 0 : rp[i], e_i = finished ? 0 : rp[i + 1];
+    int k = s_i;
+    unsigned spins = 0;
+    auto ld = [&](int idx) { return __hip_atomic_load(lv + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    for (;;) {
+        if (!finished) {
+            const int j = ci[k];
+            bool go = true;
+            if (j < i) {
+                go = __hip_atomic_load(ready + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                if (!go) {
+                    if (++spins > (1u << 22)) {                      // bounded
+                        atomicExch(err, 1);
+                        go = true;
+                    } else {
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+            }
+            if (go) {
+                spins = 0;
+                const int s_j = rp[j], e_j = rp[j + 1];
+                double acc = ld(k);
+                int a = s_i, b = s_j;
+                while (a < k && b < e_j - 1) {
+                    const int ca = ci[a], cb = ci[b];
+                    if (ca == cb) {
+                        acc -= ld(a) * ld(b);
+                        ++a;
+                        ++b;
+                    } else if (ca < cb) ++a;
+                    else ++b;
+                }
+                double v;
+                if (j < i) {
+                    const double d = ld(e_j - 1);
+                    v = acc / d;
+                    if (DROP && fabs(v) * d < tau * colnorm[j]) v = 0.0;
+                } else {
+                    if (!(acc > 0.0)) atomicExch(bad, i + 1);
+                    v = sqrt(acc);
+                }
+                __hip_atomic_store(lv + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ++k;
+                if (k == e_i) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row's entries have drained before its flag goes out
+                    __hip_atomic_store(ready + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    finished = true;
+                }
+            }
+        }
+        if (__ballot(!finished) == 0) break;
+    }
+}
+
+void launch_ic0_syncfree(const int32_t *rows, int64_t n, const int32_t *rp, const int32_t *ci, double *lv, int *ready_zeroed,
+                         unsigned int *ticket_zeroed, int *bad, int *err, hipStream_t s, const double *colnorm, double tau) {
+    const int grid = (int)((n + kBlock - 1) / kBlock);
+    if (colnorm)
+        hipLaunchKernelGGL(k_ic0_syncfree<true>, dim3(grid), dim3(kBlock), 0, s, rows, n, rp, ci, lv, ready_zeroed, ticket_zeroed,
+                           bad, colnorm, tau, err);
+    else
+        hipLaunchKernelGGL(k_ic0_syncfree<false>, dim3(grid), dim3(kBlock), 0, s, rows, n, rp, ci, lv, ready_zeroed, ticket_zeroed,
+                           bad, colnorm, tau, err);
 }
 
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
