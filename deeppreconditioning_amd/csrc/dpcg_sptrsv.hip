@@ -590,89 +590,6 @@ __global__ __launch_bounds__(kBlock) void k_ic0_level(const int32_t *__restrict_
     }
 }
 
-// The numeric factorisation in ONE launch (the per-level form above costs a launch per level: 2047 of them, 11 ms, for a
-// 1024^2 grid).  Rows are taken in level order through a ticket; a row that needs row j polls ready[j], which row j's
-// owner sets after its entries have been stored write-through and have drained (sc1 stores, s_waitcnt vmcnt(0), then
-// the flag: the `sc1 payload -> wait -> sc1 flag` hand-off); every read of another row's entries is an sc1 load.  The
-// arithmetic and its order are those of k_ic0_level, so the factor is the same, bit for bit.  Lanes of a wave may wait
-// for each other, hence one loop for the whole wave (left by ballot) in which a lane advances one entry per trip.
-template <bool DROP>
-__global__ __launch_bounds__(kBlock) void k_ic0_syncfree(const int32_t *__restrict__ rows, int64_t n,
-                                                         const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
-                                                         double *lv, int *ready, unsigned int *ticket, int *bad,
-                                                         const double *__restrict__ colnorm, double tau, int *err) {
-    __shared__ unsigned int s_lb;
-    if (threadIdx.x == 0) s_lb = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const int64_t pos = (int64_t)s_lb * kBlock + threadIdx.x;
-    bool finished = pos >= n;
-    const int i = finished ? 0 : rows[pos];
-    const int s_i = finished ? 0 : rp[i], e_i = finished ? 0 : rp[i + 1];
-    int k = s_i;
-    unsigned spins = 0;
-    auto ld = [&](int idx) { return __hip_atomic_load(lv + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    for (;;) {
-        if (!finished) {
-            const int j = ci[k];
-            bool go = true;
-            if (j < i) {
-                go = __hip_atomic_load(ready + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                if (!go) {
-                    if (++spins > (1u << 22)) {                      // bounded
-                        atomicExch(err, 1);
-                        go = true;
-                    } else {
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
-            }
-            if (go) {
-                spins = 0;
-                const int s_j = rp[j], e_j = rp[j + 1];
-                double acc = ld(k);
-                int a = s_i, b = s_j;
-                while (a < k && b < e_j - 1) {
-                    const int ca = ci[a], cb = ci[b];
-                    if (ca == cb) {
-                        acc -= ld(a) * ld(b);
-                        ++a;
-                        ++b;
-                    } else if (ca < cb) ++a;
-                    else ++b;
-                }
-                double v;
-                if (j < i) {
-                    const double d = ld(e_j - 1);
-                    v = acc / d;
-                    if (DROP && fabs(v) * d < tau * colnorm[j]) v = 0.0;
-                } else {
-                    if (!(acc > 0.0)) atomicExch(bad, i + 1);
-                    v = sqrt(acc);
-                }
-                __hip_atomic_store(lv + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ++k;
-                if (k == e_i) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row's entries have drained before its flag goes out
-                    __hip_atomic_store(ready + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    finished = true;
-                }
-            }
-        }
-        if (__ballot(!finished) == 0) break;
-    }
-}
-
-void launch_ic0_syncfree(const int32_t *rows, int64_t n, const int32_t *rp, const int32_t *ci, double *lv, int *ready_zeroed,
-                         unsigned int *ticket_zeroed, int *bad, int *err, hipStream_t s, const double *colnorm, double tau) {
-    const int grid = (int)((n + kBlock - 1) / kBlock);
-    if (colnorm)
-        hipLaunchKernelGGL(k_ic0_syncfree<true>, dim3(grid), dim3(kBlock), 0, s, rows, n, rp, ci, lv, ready_zeroed, ticket_zeroed,
-                           bad, colnorm, tau, err);
-    else
-        hipLaunchKernelGGL(k_ic0_syncfree<false>, dim3(grid), dim3(kBlock), 0, s, rows, n, rp, ci, lv, ready_zeroed, ticket_zeroed,
-                           bad, colnorm, tau, err);
-}
-
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
                       hipStream_t s, const double *colnorm, double tau) {
     if (colnorm)
