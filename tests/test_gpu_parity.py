@@ -1335,3 +1335,34 @@ def test_config4_full_size_system_against_the_oracle(D):
     assert res.iterations == it and res.status == 0
     np.testing.assert_allclose(res.res_history, hist, rtol=HIST_RTOL)
     np.testing.assert_allclose(xg, x, rtol=1e-9, atol=1e-12)
+
+
+def test_reordering_of_disconnected_and_degenerate_graphs(D):
+    """`dpcg_reorder` beyond the connected case: several components of different sizes, isolated (diagonal-only) rows, and
+    more components than the library searches one by one (the rest keeps its relative order at the end) -- the result must
+    always be a permutation, and the solve on it must match the oracle on P A P^T."""
+    rng = np.random.default_rng(5)
+    blocks_a = [O.unstructured_like(O.poisson2d(17), seed=1), sp.identity(5, format="csr") * 3.0,
+                O.unstructured_like(O.poisson3d(6), seed=2), O.poisson2d(9)]
+    blocks_b = [O.poisson2d(3) for _ in range(90)] + [sp.identity(7, format="csr") * 2.0]      # 97 components > 64 searches
+    for blocks in (blocks_a, blocks_b):
+        A = sp.block_diag(blocks, format="csr")
+        n = A.shape[0]
+        shuffle = rng.permutation(n)                          # interleave the components in the caller's numbering
+        A = A[shuffle][:, shuffle].tocsr()
+        A.sort_indices()
+        b = O.rhs(n, 8)
+        S = D.CsrSystem.from_any(A, reorder="rcm")
+        perm = S.permutation()
+        assert S.reordered and np.array_equal(np.sort(perm), np.arange(n))
+        B = _permuted(A, perm)
+        x = O.rhs(n, 1)
+        assert np.array_equal((S @ _dev(x)).cpu().numpy()[perm], CO.spmv(B, x[perm]))
+        S.set_preconditioner(D.Jacobi())
+        for flags in (0, D._lib.NO_SMALL | D._lib.NO_FUSE):
+            res = S.solve(_dev(b), flags=flags)
+            _, it, hist, xs = CO.pcg(B, b[perm], "jacobi", dinv=O.jacobi_dinv(B))
+            assert res.iterations == it and res.status == 0
+            np.testing.assert_allclose(res.res_history, hist, rtol=1e-9)
+            np.testing.assert_allclose(res.x.cpu().numpy()[perm], xs, rtol=1e-8, atol=1e-11)
+        S.close()
