@@ -440,6 +440,7 @@ __global__ __launch_bounds__(kBlock) void k_ict_pattern(int64_t n, const int32_t
             }
         const int base = m;                                  // tril(A)_i, ascending; re-read from A below, `set` grows
         if (last != i) atomicOr(flags, 1);                   // missing diagonal
+        if (over) atomicOr(flags, 4);                        // tril(A)_i itself does not fit the private set: refused
         if (fill && !over) {
             for (int p = rp[i]; p < rp[i + 1] && !over; ++p) {
                 const int k = ci[p];                         // original entries only: level-1 fill

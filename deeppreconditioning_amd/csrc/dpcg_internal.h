@@ -267,6 +267,8 @@ int launch_pcg_small(const SmallDesc *descs_dev, int count, int lds_bytes, int k
                      hipStream_t s);
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
                       hipStream_t s, const double *colnorm = nullptr, double tau = 0.0);   // colnorm: ICT drop rule
+void launch_ic0_merged(const int32_t *rows, const int32_t *level_ptr_dev, int lvl_lo, int lvl_hi, const int32_t *rp,
+                       const int32_t *ci, double *lv, int *bad, hipStream_t s, const double *colnorm = nullptr, double tau = 0.0);
 void launch_colnorm1(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, double *c, hipStream_t s);
 void launch_ict_pattern(bool write, int64_t n, const int32_t *rp, const int32_t *ci, const double *v, int fill, int32_t *cnt,
                         const int32_t *lrp, int32_t *lci, double *lv, int *flags, hipStream_t s);

@@ -177,16 +177,29 @@ int compute_levels(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, 
 }
 
 // The numeric phase of IC(0) / ICT on the pattern held in F (values: the matrix entries, zeros at fill positions): one
-// launch per level, one thread per row.  (A sync-free single launch, rows polling `ready` flags, was measured and
+// launch per level (one workgroup for a run of narrow levels), one thread per row.  (A sync-free single launch, rows polling `ready` flags, was measured and
 // dropped: every read of another row then has to bypass the L1, and with the whole factor resident the polling drowned
 // the front -- 1024^2: 56.6 ms vs 10.9 ms for 2047 launches; 100^3: 19.0 vs 2.7 ms.)
 int numeric_incomplete_cholesky(const LevelSort &ls, int64_t n, CsrDev &F, int *bad_dev, const double *colnorm, double tau,
                                 hipStream_t s) {
     (void)n;
+    // one launch per level; runs of >= 4 narrow levels (<= 1024 rows each) are walked by one workgroup (k_ic0_merged)
+    constexpr int kNarrow = 1024;
     const int nl = (int)ls.level_ptr.size() - 1;
-    for (int l = 0; l < nl; ++l)
-        launch_ic0_level(ls.rows.p, ls.level_ptr[l], ls.level_ptr[l + 1] - ls.level_ptr[l], F.rowptr, F.col, F.val, bad_dev, s,
-                         colnorm, tau);
+    int l = 0;
+    while (l < nl) {
+        int e = l;
+        while (e < nl && ls.level_ptr[e + 1] - ls.level_ptr[e] <= kNarrow) ++e;
+        if (e - l >= 4) {
+            launch_ic0_merged(ls.rows.p, ls.level_ptr_dev.p, l, e, F.rowptr, F.col, F.val, bad_dev, s, colnorm, tau);
+            l = e;
+            continue;
+        }
+        const int stop = e > l ? e : l + 1;
+        for (; l < stop; ++l)
+            launch_ic0_level(ls.rows.p, ls.level_ptr[l], ls.level_ptr[l + 1] - ls.level_ptr[l], F.rowptr, F.col, F.val, bad_dev, s,
+                             colnorm, tau);
+    }
     DPCG_CHECK_LAUNCH();
     return DPCG_OK;
 }
@@ -541,6 +554,10 @@ extern "C" int dpcg_set_precond_ict(dpcg_handle_t h, int mode, int fill_in, doub
     if (h_flags[0] & 1) {
         set_error("ICT: missing diagonal entry");
         return fail(DPCG_ERR_PIVOT);
+    }
+    if (h_flags[0] & 4) {
+        set_error("ICT: a row of tril(A) has more than 192 entries (use IC(0) for such matrices)");
+        return fail(DPCG_ERR_INVALID);
     }
     S.nnz = snnz;
     if ((st = dev_alloc(&S.col, snnz)) < 0 || (st = dev_alloc(&S.val, snnz)) < 0) return fail(st);

@@ -590,6 +590,62 @@ __global__ __launch_bounds__(kBlock) void k_ic0_level(const int32_t *__restrict_
     }
 }
 
+// A run of NARROW levels (each <= 1024 rows: natural-order 2-D grids have thousands of them) factored by ONE workgroup
+// with a barrier per level instead of a launch per level (2047 launches cost 10.9 ms at 1024^2, host-bound).  Entries
+// written in one level and read in the next travel through L2 with agent-scope accesses (as in k_sptrsv_merged), so no
+// wave reads a stale L1 line; the arithmetic and its order are k_ic0_level's: the same factor, bit for bit.
+template <bool DROP>
+__global__ __launch_bounds__(kMergedBlock) void k_ic0_merged(const int32_t *__restrict__ rows,
+                                                             const int32_t *__restrict__ level_ptr, int lvl_lo, int lvl_hi,
+                                                             const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                             double *lv, int *bad, const double *__restrict__ colnorm,
+                                                             double tau) {
+    auto ld = [&](int idx) { return __hip_atomic_load(lv + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    for (int lvl = lvl_lo; lvl < lvl_hi; ++lvl) {
+        const int lo = level_ptr[lvl], hi = level_ptr[lvl + 1];
+        for (int jj = lo + (int)threadIdx.x; jj < hi; jj += kMergedBlock) {
+            const int i = rows[jj];
+            const int s_i = rp[i], e_i = rp[i + 1];
+            for (int k = s_i; k < e_i; ++k) {
+                const int j = ci[k];
+                const int s_j = rp[j], e_j = rp[j + 1];
+                double acc = ld(k);
+                int a = s_i, b = s_j;
+                while (a < k && b < e_j - 1) {
+                    const int ca = ci[a], cb = ci[b];
+                    if (ca == cb) {
+                        acc -= ld(a) * ld(b);
+                        ++a;
+                        ++b;
+                    } else if (ca < cb) ++a;
+                    else ++b;
+                }
+                double v;
+                if (j < i) {
+                    const double d = ld(e_j - 1);
+                    v = acc / d;
+                    if (DROP && fabs(v) * d < tau * colnorm[j]) v = 0.0;
+                } else {
+                    if (!(acc > 0.0)) atomicExch(bad, i + 1);
+                    v = sqrt(acc);
+                }
+                __hip_atomic_store(lv + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();  // includes s_waitcnt vmcnt(0): this level's stores have reached L2
+    }
+}
+
+void launch_ic0_merged(const int32_t *rows, const int32_t *level_ptr_dev, int lvl_lo, int lvl_hi, const int32_t *rp,
+                       const int32_t *ci, double *lv, int *bad, hipStream_t s, const double *colnorm, double tau) {
+    if (colnorm)
+        hipLaunchKernelGGL(k_ic0_merged<true>, dim3(1), dim3(kMergedBlock), 0, s, rows, level_ptr_dev, lvl_lo, lvl_hi, rp, ci, lv,
+                           bad, colnorm, tau);
+    else
+        hipLaunchKernelGGL(k_ic0_merged<false>, dim3(1), dim3(kMergedBlock), 0, s, rows, level_ptr_dev, lvl_lo, lvl_hi, rp, ci,
+                           lv, bad, colnorm, tau);
+}
+
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
                       hipStream_t s, const double *colnorm, double tau) {
     if (colnorm)

@@ -148,7 +148,7 @@ def ic0(A: sp.csr_matrix) -> sp.csr_matrix:
     return sp.csr_matrix((lv, ci.copy(), rp.copy()), shape=T.shape)
 
 
-def ict(A: sp.csr_matrix, fill_in: int = 1, threshold: float = 0.1) -> sp.csr_matrix:
+def ict(A: sp.csr_matrix, fill_in: int = 1, threshold: float = 0.1, row_cap: int = 192) -> sp.csr_matrix:
     """Thresholded incomplete Cholesky with level-1 fill: the contract of `CsrSystem.set_preconditioner(ICT(...))`.
 
     Stands in for `ilupp.icholt(A, add_fill_in=1, threshold=0.1)`, the reference harness's DEFAULT incomplete-Cholesky
@@ -156,7 +156,9 @@ def ict(A: sp.csr_matrix, fill_in: int = 1, threshold: float = 0.1) -> sp.csr_ma
     UNPINNED.  The algorithm restated here is the textbook one -- level-of-fill symbolic phase (Saad 2003, IC(p)) with the
     drop rule MATLAB documents for `ichol(..., type='ict')`:
       pattern  S_i = {j <= i : a_ij != 0}  plus, for fill_in >= 1, {j < i : there is k < j with a_ik != 0 and a_jk != 0}
-               (fill created by eliminating with ORIGINAL entries only; fill_in > 1 is treated as 1);
+               (fill created by eliminating with ORIGINAL entries only; fill_in > 1 is treated as 1; a row whose
+               pattern would then exceed `row_cap` = 192 entries keeps tril(A)_i -- the bound of the device routine's
+               private per-row set, part of the contract);
       numeric  row by row, stored columns ascending:  acc = a_ij (0 for a fill position) - sum_{m<j, m in S_i & S_j} L_im L_jm
                (ascending m, one product and one subtraction at a time);  j < i:  v = acc / L_jj, and v is DROPPED (stored as
                0, so later sums see 0) when |v| * L_jj < threshold * ||A(j:n, j)||_1;  j = i:  L_ii = sqrt(acc) > 0;
@@ -175,12 +177,17 @@ def ict(A: sp.csr_matrix, fill_in: int = 1, threshold: float = 0.1) -> sp.csr_ma
     ci, lv = [], []
     for i in range(n):
         row = {int(aci[k]): float(av[k]) for k in range(arp[i], arp[i + 1]) if aci[k] <= i}
+        if len(row) > row_cap:
+            raise ValueError("ICT: a row of tril(A) has more than row_cap entries")
         if fill_in >= 1:
+            filled = dict(row)
             for k in [c for c in row if c < i]:
                 for q in range(arp[k], arp[k + 1]):
                     j = int(aci[q])
-                    if k < j < i and j not in row:
-                        row[j] = 0.0
+                    if k < j < i and j not in filled:
+                        filled[j] = 0.0
+            if len(filled) <= row_cap:
+                row = filled
         for c in sorted(row):
             ci.append(c)
             lv.append(row[c])

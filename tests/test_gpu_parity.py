@@ -1363,6 +1363,7 @@ def test_reordering_of_disconnected_and_degenerate_graphs(D):
             res = S.solve(_dev(b), flags=flags)
             _, it, hist, xs = CO.pcg(B, b[perm], "jacobi", dinv=O.jacobi_dinv(B))
             assert res.iterations == it and res.status == 0
-            np.testing.assert_allclose(res.res_history, hist, rtol=1e-9)
+            sig = hist > 1e-20           # 90 identical blocks converge in 5 updates to a residual of pure rounding noise
+            np.testing.assert_allclose(res.res_history[sig], hist[sig], rtol=1e-9)
             np.testing.assert_allclose(res.x.cpu().numpy()[perm], xs, rtol=1e-8, atol=1e-11)
         S.close()
