@@ -103,10 +103,12 @@ void launch_transpose_gather(int64_t nnz, const int32_t *perm, const int32_t *ro
 // ticket counter, so every row a workgroup waits for belongs to a workgroup that has already started: no deadlock
 // whatever the dispatch order.  The store sits inside the poll loop because lanes of one wave may depend on each other.
 // ------------------------------------------------------------------------------------------------
+// strip_rows > 0: STRIP-LOCAL levels -- dependencies on rows of another strip (strip = index / strip_rows, counted from
+// the end for an upper factor) are ignored; see the strip-pipelined solve.
 template <bool UPPER>
 __global__ __launch_bounds__(kBlock) void k_levels_syncfree(int64_t n, const int32_t *__restrict__ rp,
                                                             const int32_t *__restrict__ ci, int32_t *level,
-                                                            unsigned int *ticket, int *err) {
+                                                            unsigned int *ticket, int *err, int strip_rows) {
     __shared__ unsigned int s_lb;
     if (threadIdx.x == 0) s_lb = atomicAdd(ticket, 1u);
     __syncthreads();
@@ -120,13 +122,22 @@ __global__ __launch_bounds__(kBlock) void k_levels_syncfree(int64_t n, const int
     int c = k < ke ? ci[k] : 0;
     unsigned spins = 0;
     bool stored = false;
+    const int64_t my_strip = strip_rows > 0 ? idx / strip_rows : 0;
+    auto foreign = [&](int col) {                     // a dependency that lives in another strip does not count
+        if (strip_rows <= 0) return false;
+        const int64_t cidx = UPPER ? n - 1 - col : col;
+        return cidx / strip_rows != my_strip;
+    };
     // The loop is left by the whole wave at once (ballot): were lanes to leave one by one, the compiler could move the
     // store onto the exit path, where a SIMT machine executes it only after EVERY lane has left -- a lane waiting for
     // the level of a row owned by another lane of its own wave would then wait forever.
     for (;;) {
         if (!stored && k < ke) {
-            const int l = __hip_atomic_load(level + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (l >= 0) {
+            const int l = foreign(c) ? 0x7fffffff : __hip_atomic_load(level + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (l == 0x7fffffff) {
+                ++k;
+                if (k < ke) c = ci[k];
+            } else if (l >= 0) {
                 lvl = l + 1 > lvl ? l + 1 : lvl;
                 ++k;
                 if (k < ke) c = ci[k];
@@ -147,12 +158,85 @@ __global__ __launch_bounds__(kBlock) void k_levels_syncfree(int64_t n, const int
 }
 
 void launch_levels_syncfree(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int32_t *level,
-                            unsigned int *ticket_zeroed, int *err, hipStream_t s) {
+                            unsigned int *ticket_zeroed, int *err, hipStream_t s, int strip_rows) {
     const int grid = (int)((n + kBlock - 1) / kBlock);
     if (upper)
-        hipLaunchKernelGGL(k_levels_syncfree<true>, dim3(grid), dim3(kBlock), 0, s, n, rp, ci, level, ticket_zeroed, err);
+        hipLaunchKernelGGL(k_levels_syncfree<true>, dim3(grid), dim3(kBlock), 0, s, n, rp, ci, level, ticket_zeroed, err, strip_rows);
     else
-        hipLaunchKernelGGL(k_levels_syncfree<false>, dim3(grid), dim3(kBlock), 0, s, n, rp, ci, level, ticket_zeroed, err);
+        hipLaunchKernelGGL(k_levels_syncfree<false>, dim3(grid), dim3(kBlock), 0, s, n, rp, ci, level, ticket_zeroed, err,
+                           strip_rows);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Strip-pipelined triangular solve: setup pieces (see k_sptrsv_strips in dpcg_sptrsv.hip)
+// ------------------------------------------------------------------------------------------------
+// key[i] = strip(i) * nlev + local level(i)
+__global__ __launch_bounds__(kBlock) void k_strip_keys(int64_t n, const int32_t *__restrict__ level, int strip_rows, int nlev,
+                                                       int upper, uint32_t *__restrict__ key) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const int64_t idx = upper ? n - 1 - i : i;
+        key[i] = (uint32_t)((idx / strip_rows) * nlev + level[i]);
+    }
+}
+
+void launch_strip_keys(int64_t n, const int32_t *level, int strip_rows, int nlev, bool upper, uint32_t *key, hipStream_t s) {
+    hipLaunchKernelGGL(k_strip_keys, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, level, strip_rows, nlev, upper ? 1 : 0, key);
+}
+
+// Records of the strip solve, one per position j of the (strip, level, row) order:
+//   meta[j] = {d0, d1, d2, row};  d >= 0: position of an entry of the SAME strip (read from the LDS ring);
+//             d == -1: no such entry;  d <= -2: an entry of an EARLIER strip, column -2 - d (polled in `out`);
+//             d0 == INT_MIN: more than three off-diagonal entries, the row walks lo_rowptr;
+//   val[4j..4j+3] = {v0, v1, v2, diagonal}.
+// stats[0] = max reach (j - position of an own-strip entry), stats[1] = entries of earlier strips, stats[2] = long rows.
+__global__ __launch_bounds__(kBlock) void k_strip_records(int64_t n, const uint32_t *__restrict__ key_of_pos, int nlev,
+                                                          const int32_t *__restrict__ level_ptr,
+                                                          const int32_t *__restrict__ rows,
+                                                          const int32_t *__restrict__ lo_rp, const int32_t *__restrict__ lo_ci,
+                                                          const int32_t *__restrict__ lo_cp, const double *__restrict__ lo_v,
+                                                          int upper, int32_t *__restrict__ meta, double *__restrict__ pv,
+                                                          int *stats) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int reach = 0, ext = 0, longrows = 0;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        int m[4] = {-1, -1, -1, -1};
+        double w[4] = {0.0, 0.0, 0.0, 0.0};
+        const int strip = (int)(key_of_pos[j] / (uint32_t)nlev);
+        const int start = level_ptr[strip * nlev], end = level_ptr[(strip + 1) * nlev];
+        const int a = lo_rp[j], b = lo_rp[j + 1];
+        const int ks = upper ? a + 1 : a, ke = upper ? b : b - 1;
+        m[3] = rows[j];
+        w[3] = lo_v[upper ? a : b - 1];
+        for (int k = ks; k < ke; ++k) {
+            const int cp = lo_cp[k];
+            if (cp >= start && cp < end) reach = (int)j - cp > reach ? (int)j - cp : reach;
+            else ++ext;
+        }
+        if (ke - ks > 3) {
+            m[0] = (int)0x80000000;
+            ++longrows;
+        } else {
+            for (int k = ks; k < ke; ++k) {
+                const int cp = lo_cp[k];
+                m[k - ks] = (cp >= start && cp < end) ? cp : -2 - lo_ci[k];
+                w[k - ks] = lo_v[k];
+            }
+        }
+        reinterpret_cast<int4 *>(meta)[j] = make_int4(m[0], m[1], m[2], m[3]);
+        reinterpret_cast<double2 *>(pv)[2 * j] = make_double2(w[0], w[1]);
+        reinterpret_cast<double2 *>(pv)[2 * j + 1] = make_double2(w[2], w[3]);
+    }
+    if (reach) atomicMax(stats, reach);
+    if (ext) atomicAdd(stats + 1, ext);
+    if (longrows) atomicAdd(stats + 2, longrows);
+}
+
+void launch_strip_records(int64_t n, const uint32_t *key_of_pos, int nlev, const int32_t *level_ptr, const int32_t *rows,
+                          const int32_t *lo_rp, const int32_t *lo_ci, const int32_t *lo_cp, const double *lo_v, bool upper,
+                          int32_t *meta, double *pv, int *stats, hipStream_t s) {
+    hipLaunchKernelGGL(k_strip_records, dim3(grid_rows(n, 1024)), dim3(kBlock), 0, s, n, key_of_pos, nlev, level_ptr, rows, lo_rp,
+                       lo_ci, lo_cp, lo_v, upper ? 1 : 0, meta, pv, stats);
 }
 
 // ------------------------------------------------------------------------------------------------

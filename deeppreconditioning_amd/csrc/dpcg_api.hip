@@ -84,6 +84,9 @@ void free_levels(Levels &l) {
     dev_free(l.pk_meta);
     dev_free(l.pk_val);
     dev_free(l.b_lo);
+    dev_free(l.strips.rows); dev_free(l.strips.level_ptr_dev); dev_free(l.strips.lo_rowptr); dev_free(l.strips.lo_col);
+    dev_free(l.strips.lo_cpos); dev_free(l.strips.lo_val); dev_free(l.strips.val); dev_free(l.strips.b_lo);
+    dev_free(l.strips.meta); dev_free(l.strips.ticket);
     dev_free(l.sf_meta);
     dev_free(l.sf_val);
     dev_free(l.tickets);

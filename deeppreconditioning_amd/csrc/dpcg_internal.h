@@ -126,6 +126,15 @@ struct Levels {
     double *b_lo = nullptr;                // scratch: the right-hand side gathered into level order
     int32_t *sf_meta = nullptr;            // records of the sync-free kernel (dpcg_analysis.hip: k_sf_records)
     double *sf_val = nullptr;
+    // Strip-pipelined solve (k_sptrsv_strips): the rows once more, sorted by (strip, strip-local level, row), with their
+    // own level offsets (n_strips * nlev + 1 entries), level-ordered factor copy and records.  n_strips == 0: not used.
+    struct Strips {
+        int n_strips = 0, nlev = 0, W = 0, threads = 0, rows_per_thread = 1;
+        int32_t *rows = nullptr, *level_ptr_dev = nullptr, *lo_rowptr = nullptr, *lo_col = nullptr, *lo_cpos = nullptr;
+        double *lo_val = nullptr, *val = nullptr, *b_lo = nullptr;
+        int32_t *meta = nullptr;
+        unsigned int *ticket = nullptr;    // [0] strips handed out, [1] exits
+    } strips;
     unsigned long long *tickets = nullptr; // one monotonic block-ticket counter per segment (sync-free segments use theirs)
     int *spin_err = nullptr;               // set by a sync-free kernel whose bounded poll ran out
 };
@@ -252,6 +261,7 @@ void launch_record_err(const Scalars *scal, const double *part, int n_part, doub
                        int at_k_minus_one, hipStream_t s);
 void launch_dot_final(const double *part, int n_part, double *out_dev, hipStream_t s);
 
+void init_strip_kernels();
 // done: optional device flag (Scalars::done); when set the kernels return at once
 void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s,
                    const int *done = nullptr);
@@ -267,8 +277,6 @@ int launch_pcg_small(const SmallDesc *descs_dev, int count, int lds_bytes, int k
                      hipStream_t s);
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
                       hipStream_t s, const double *colnorm = nullptr, double tau = 0.0);   // colnorm: ICT drop rule
-void launch_ic0_merged(const int32_t *rows, const int32_t *level_ptr_dev, int lvl_lo, int lvl_hi, const int32_t *rp,
-                       const int32_t *ci, double *lv, int *bad, hipStream_t s, const double *colnorm = nullptr, double tau = 0.0);
 void launch_colnorm1(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, double *c, hipStream_t s);
 void launch_ict_pattern(bool write, int64_t n, const int32_t *rp, const int32_t *ci, const double *v, int fill, int32_t *cnt,
                         const int32_t *lrp, int32_t *lci, double *lv, int *flags, hipStream_t s);
@@ -293,7 +301,11 @@ void launch_group_offsets(int64_t count, const uint32_t *keys_sorted, int groups
 void launch_transpose_gather(int64_t nnz, const int32_t *perm, const int32_t *row_of, const double *val, int32_t *tcol,
                              double *tval, hipStream_t s);
 void launch_levels_syncfree(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int32_t *level,
-                            unsigned int *ticket_zeroed, int *err, hipStream_t s);
+                            unsigned int *ticket_zeroed, int *err, hipStream_t s, int strip_rows = 0);
+void launch_strip_keys(int64_t n, const int32_t *level, int strip_rows, int nlev, bool upper, uint32_t *key, hipStream_t s);
+void launch_strip_records(int64_t n, const uint32_t *key_of_pos, int nlev, const int32_t *level_ptr, const int32_t *rows,
+                          const int32_t *lo_rp, const int32_t *lo_ci, const int32_t *lo_cp, const double *lo_v, bool upper,
+                          int32_t *meta, double *pv, int *stats, hipStream_t s);
 void launch_lo_lengths(int64_t n, const int32_t *rows, const int32_t *rp, int32_t *len, int32_t *pos, hipStream_t s);
 void launch_lo_copy(int64_t n, const int32_t *rows, const int32_t *rp, const int32_t *ci, const double *v,
                     const int32_t *pos, const int32_t *lo_rp, int32_t *lo_ci, int32_t *lo_cp, double *lo_v,

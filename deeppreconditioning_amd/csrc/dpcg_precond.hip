@@ -177,29 +177,18 @@ int compute_levels(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, 
 }
 
 // The numeric phase of IC(0) / ICT on the pattern held in F (values: the matrix entries, zeros at fill positions): one
-// launch per level (one workgroup for a run of narrow levels), one thread per row.  (A sync-free single launch, rows polling `ready` flags, was measured and
+// launch per level, one thread per row.  (A sync-free single launch, rows polling `ready` flags, was measured and
 // dropped: every read of another row then has to bypass the L1, and with the whole factor resident the polling drowned
 // the front -- 1024^2: 56.6 ms vs 10.9 ms for 2047 launches; 100^3: 19.0 vs 2.7 ms.)
 int numeric_incomplete_cholesky(const LevelSort &ls, int64_t n, CsrDev &F, int *bad_dev, const double *colnorm, double tau,
                                 hipStream_t s) {
     (void)n;
-    // one launch per level; runs of >= 4 narrow levels (<= 1024 rows each) are walked by one workgroup (k_ic0_merged)
-    constexpr int kNarrow = 1024;
+    // (also measured and dropped: ONE workgroup walking a run of narrow levels with a barrier per level -- 1024^2: 24.2 ms, the
+    // dependent agent-scope loads of a row cost more than the launches they replace)
     const int nl = (int)ls.level_ptr.size() - 1;
-    int l = 0;
-    while (l < nl) {
-        int e = l;
-        while (e < nl && ls.level_ptr[e + 1] - ls.level_ptr[e] <= kNarrow) ++e;
-        if (e - l >= 4) {
-            launch_ic0_merged(ls.rows.p, ls.level_ptr_dev.p, l, e, F.rowptr, F.col, F.val, bad_dev, s, colnorm, tau);
-            l = e;
-            continue;
-        }
-        const int stop = e > l ? e : l + 1;
-        for (; l < stop; ++l)
-            launch_ic0_level(ls.rows.p, ls.level_ptr[l], ls.level_ptr[l + 1] - ls.level_ptr[l], F.rowptr, F.col, F.val, bad_dev, s,
-                             colnorm, tau);
-    }
+    for (int l = 0; l < nl; ++l)
+        launch_ic0_level(ls.rows.p, ls.level_ptr[l], ls.level_ptr[l + 1] - ls.level_ptr[l], F.rowptr, F.col, F.val, bad_dev, s,
+                         colnorm, tau);
     DPCG_CHECK_LAUNCH();
     return DPCG_OK;
 }
@@ -363,6 +352,92 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
     return DPCG_OK;
 }
 
+// Strip plan of a factor (see k_sptrsv_strips): tried for banded factors with many levels; kept when every strip-local level
+// fits one workgroup, the LDS ring covers the reach inside a strip and most entries stay inside their strip.  Leaves
+// lv.strips.n_strips = 0 otherwise (the level schedule built above is then what launch_sptrsv uses).
+bool strips_enabled() {
+    static const bool on = [] { const char *e = getenv("DPCG_STRIPS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const int32_t *ci, const double *v, bool upper,
+                 const int32_t *relabel, hipStream_t s) {
+    if (!strips_enabled() || lv.n_levels < 64 || n < 32768) return DPCG_OK;
+    static const int64_t target_rows = [] { const char *e = getenv("DPCG_STRIP_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)16384; }();
+    int64_t S = n / target_rows;
+    S = S < 8 ? 8 : (S > 128 ? 128 : S);
+    const int strip_rows = (int)((n + S - 1) / S);
+    S = (n + strip_rows - 1) / strip_rows;
+    PhaseTimer pt(s);
+    DevBuf<int32_t> level, iota, ctl, len, pos;
+    DevBuf<uint32_t> key, key_sorted;
+    DPCG_TRY(level.alloc(n)); DPCG_TRY(iota.alloc(n)); DPCG_TRY(ctl.alloc(8)); DPCG_TRY(key.alloc(n)); DPCG_TRY(key_sorted.alloc(n));
+    DPCG_HIP(hipMemsetAsync(level.p, 0xff, (size_t)n * sizeof(int32_t), s));
+    DPCG_HIP(hipMemsetAsync(ctl.p, 0, 8 * sizeof(int32_t), s));
+    launch_levels_syncfree(n, rp, ci, upper, level.p, reinterpret_cast<unsigned int *>(ctl.p), ctl.p + 1, s, strip_rows);
+    DPCG_TRY(reduce_max_i32(level.p, ctl.p + 2, n, s));
+    int32_t h_ctl[8] = {0};
+    DPCG_HIP(hipMemcpyAsync(h_ctl, ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    if (h_ctl[1] || h_ctl[2] < 0) return DPCG_OK;            // (cannot happen: the global analysis succeeded)
+    const int nlev = h_ctl[2] + 1;
+    if ((int64_t)S * nlev > (int64_t)1 << 24) return DPCG_OK;
+    Levels::Strips sp;
+    auto drop = [&]() {
+        dev_free(sp.rows); dev_free(sp.level_ptr_dev); dev_free(sp.lo_rowptr); dev_free(sp.lo_col); dev_free(sp.lo_cpos);
+        dev_free(sp.lo_val); dev_free(sp.val); dev_free(sp.b_lo); dev_free(sp.meta); dev_free(sp.ticket);
+        return DPCG_OK;
+    };
+    DPCG_TRY(dev_alloc(&sp.rows, n));
+    DPCG_TRY(dev_alloc(&sp.level_ptr_dev, S * nlev + 1));
+    launch_strip_keys(n, level.p, strip_rows, nlev, upper, key.p, s);
+    launch_iota(n, iota.p, s);
+    DPCG_TRY(sort_pairs_u32_i32(key.p, key_sorted.p, iota.p, sp.rows, n, bits_for((uint64_t)(S * nlev)), s));
+    launch_group_offsets(n, key_sorted.p, (int)(S * nlev), sp.level_ptr_dev, s);
+    std::vector<int32_t> lptr((size_t)(S * nlev) + 1);
+    DPCG_HIP(hipMemcpyAsync(lptr.data(), sp.level_ptr_dev, lptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    int width = 0;
+    for (size_t q = 0; q + 1 < lptr.size(); ++q) width = std::max(width, lptr[q + 1] - lptr[q]);
+    if (width > 1024) return drop();
+    // level-ordered copy in (strip, level, row) order
+    DPCG_TRY(len.alloc(n + 1)); DPCG_TRY(pos.alloc(n));
+    DPCG_TRY(dev_alloc(&sp.lo_rowptr, n + 1)); DPCG_TRY(dev_alloc(&sp.lo_col, nnz)); DPCG_TRY(dev_alloc(&sp.lo_cpos, nnz));
+    DPCG_TRY(dev_alloc(&sp.lo_val, nnz)); DPCG_TRY(dev_alloc(&sp.meta, n * 4)); DPCG_TRY(dev_alloc(&sp.val, n * 4));
+    DPCG_TRY(dev_alloc(&sp.b_lo, n)); DPCG_TRY(dev_alloc(&sp.ticket, 2));
+    launch_lo_lengths(n, sp.rows, rp, len.p, pos.p, s);
+    DPCG_TRY(exclusive_scan_i32(len.p, sp.lo_rowptr, n + 1, s));
+    launch_lo_copy(n, sp.rows, rp, ci, v, pos.p, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, s);
+    if (relabel) {
+        launch_relabel(n, relabel, sp.rows, s);
+        launch_relabel(nnz, relabel, sp.lo_col, s);
+    }
+    DPCG_HIP(hipMemsetAsync(ctl.p, 0, 8 * sizeof(int32_t), s));
+    DPCG_HIP(hipMemsetAsync(sp.ticket, 0, 2 * sizeof(unsigned int), s));
+    launch_strip_records(n, key_sorted.p, nlev, sp.level_ptr_dev, sp.rows, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, upper,
+                         sp.meta, sp.val, reinterpret_cast<int *>(ctl.p), s);
+    DPCG_HIP(hipMemcpyAsync(h_ctl, ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    DPCG_CHECK_LAUNCH();
+    const int64_t reach = h_ctl[0], external = h_ctl[1], offdiag = nnz - n;
+    int64_t W = 64;
+    while (W < reach + width + 1) W *= 2;
+    if (W > 8192 || (offdiag > 0 && external * 2 > offdiag)) return drop();      // ring too long, or mostly foreign entries
+    sp.n_strips = (int)S;
+    sp.nlev = nlev;
+    sp.W = (int)W;
+    sp.rows_per_thread = width <= 512 ? 1 : 2;
+    sp.threads = ((width + sp.rows_per_thread - 1) / sp.rows_per_thread + 63) / 64 * 64;
+    sp.threads = sp.threads < 64 ? 64 : sp.threads;
+    lv.strips = sp;
+    init_strip_kernels();
+    // the global level schedule's big arrays are not used when the strip plan is: give the memory back
+    dev_free(lv.lo_rowptr); dev_free(lv.lo_col); dev_free(lv.lo_cpos); dev_free(lv.lo_val);
+    dev_free(lv.pk_meta); dev_free(lv.pk_val); dev_free(lv.b_lo); dev_free(lv.sf_meta); dev_free(lv.sf_val);
+    pt.mark(upper ? "strip plan (L^T)" : "strip plan (L)");
+    return DPCG_OK;
+}
+
 // L^T as CSR (columns ascending, diagonal first): stable sort of the entries by column.
 int transpose_lower(const CsrDev &L, CsrDev &Lt, hipStream_t s) {
     const int64_t n = L.n, nnz = L.nnz;
@@ -430,10 +505,12 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
         }
         DPCG_TRY(build_levels(h->lvlL, *lower_levels, n, h->L.nnz, h->L.rowptr, h->L.col, h->L.val, s, h->iperm));
         pt.mark("schedule(L)");
+        DPCG_TRY(build_strips(h->lvlL, n, h->L.nnz, h->L.rowptr, h->L.col, h->L.val, false, h->iperm, s));
         DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s));
         pt.mark("levels(L^T)");
         DPCG_TRY(build_levels(h->lvlU, up, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, s, h->iperm, true));
         pt.mark("schedule(L^T)");
+        DPCG_TRY(build_strips(h->lvlU, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, true, h->iperm, s));
     }
     h->precond = mode;
     return DPCG_OK;

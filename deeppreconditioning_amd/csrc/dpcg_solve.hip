@@ -109,6 +109,7 @@ static int ensure_graph(dpcg_system *h, int flags, int chunk) {
 // kernel launches one preconditioner application costs (the SpTRSVs launch once per wide level)
 static int precond_launches(const dpcg_system *h) {
     auto trsv = [](const Levels &lv) {
+        if (lv.strips.n_strips > 0) return 2;
         int c = 0;
         for (const auto &seg : lv.segments) c += (seg.merged || seg.syncfree) ? 2 : seg.hi - seg.lo;
         return c;

@@ -447,15 +447,212 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_rec(int j0, int coun
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Strip-pipelined triangular solve (banded factors with many narrow levels: natural / RCM-ordered grids).
+// The level walk through an LDS ring (k_sptrsv_ring_pipe) costs ~0.35 us per level but runs on ONE CU; the sync-free
+// kernel uses the whole chip but pays a ~2.7 us hand-off per level.  Here the rows are cut into STRIPS of consecutive
+// row indices (for a grid: slabs of planes), one workgroup per strip, all strips in ONE launch:
+//   * inside a strip the rows are walked in strip-LOCAL level order (levels computed with the dependencies on other
+//     strips ignored); entries of the own strip are handed from level to level through the LDS ring;
+//   * an entry of an EARLIER strip is polled in `out` (reserved-NaN "pending" pattern, 8-byte agent-scope loads; the
+//     owners store with agent scope) -- the strips form a software pipeline in which strip s trails strip s - 1 by the
+//     hand-off latency ONCE, not once per level.
+// Strips are handed out through a ticket, so a strip's predecessors have always started.  Records, prefetch chunks and
+// the LDS-only level barrier are those of k_sptrsv_ring_pipe; arithmetic and its order are those of every other SpTRSV
+// kernel here -- bit-identical to sequential substitution.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_strip_prepare(const int32_t *__restrict__ rows, const double *__restrict__ rhs,
+                                                          double *__restrict__ b_lo, double *out, int count, const int *done) {
+    if (done && *done) return;
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx < count) {
+        const int i = rows[idx];
+        b_lo[idx] = rhs[i];
+        out[i] = __longlong_as_double((long long)kPendingBits);
+    }
+}
+
+template <bool UPPER, int C, int ROWS>
+__global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict__ level_ptr, int nlev,
+                                                       const int32_t *__restrict__ lo_rp, const int32_t *__restrict__ lo_ci,
+                                                       const int32_t *__restrict__ lo_cpos, const double *__restrict__ lo_v,
+                                                       const int4 *__restrict__ pk_meta, const double2 *__restrict__ pk_val,
+                                                       const double *__restrict__ b_lo, double *out, int W,
+                                                       unsigned int *ticket, const int *done, int *err) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
+    extern __shared__ __attribute__((aligned(16))) double ring[];
+    int *lp = reinterpret_cast<int *>(ring + W);        // level offsets of this strip, padded with empty levels
+    __shared__ unsigned int s_strip;
+    __shared__ int s_nl;
+    const int t = threadIdx.x, T = blockDim.x;
+    if (t == 0) s_strip = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int lvl_lo = (int)s_strip * nlev;
+    const int seg_start = level_ptr[lvl_lo], seg_end = level_ptr[lvl_lo + nlev];
+    for (int i = t; i <= nlev + 3 * C; i += T) lp[i] = i <= nlev ? level_ptr[lvl_lo + i] : seg_end;
+    __syncthreads();
+    if (t == 0) {                                       // trailing empty levels of a short strip are not walked
+        int nl = nlev;
+        while (nl > 0 && lp[nl - 1] == seg_end) --nl;
+        s_nl = nl;
+    }
+    __syncthreads();
+    const int nl = s_nl;
+    const int nchunks = (nl + C - 1) / C;
+    const int jmax = seg_end > seg_start ? seg_end - 1 : seg_start;
+    struct Row {
+        int j;           // position, -1 for a lane without a row in this level
+        int4 m;          // d0..d2, own row index
+        double2 v01, v2d;
+        double b;
+    };
+    auto load_row = [&](Row &r, int j, int hi) {
+        const int jc = j < hi ? j : jmax;                 // lanes without a row load a valid record and ignore it
+        r.j = j < hi ? j : -1;
+        r.m = pk_meta[jc];
+        r.v01 = pk_val[2 * (int64_t)jc];
+        r.v2d = pk_val[2 * (int64_t)jc + 1];
+        r.b = b_lo[jc];
+    };
+    auto load_chunk = [&](Row (&S)[C][ROWS], int chunk) {
+#pragma unroll
+        for (int d = 0; d < C; ++d) {
+            const int rel = chunk * C + d;
+            const int lo = lp[rel], hi = lp[rel + 1];
+#pragma unroll
+            for (int h = 0; h < ROWS; ++h) load_row(S[d][h], lo + t + h * T, hi);
+        }
+    };
+    auto retire = [&](Row (&S)[C][ROWS]) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < C; ++d)
+#pragma unroll
+            for (int h = 0; h < ROWS; ++h) {
+                Row &r = S[d][h];
+                asm volatile("" : "+v"(r.m.x), "+v"(r.m.y), "+v"(r.m.z), "+v"(r.m.w), "+v"(r.v01.x), "+v"(r.v01.y),
+                             "+v"(r.v2d.x), "+v"(r.v2d.y), "+v"(r.b));
+            }
+    };
+    // an entry of an earlier strip: poll until its owner has stored it (bounded)
+    auto poll = [&](int col) {
+        double y;
+        for (unsigned spins = 0;; ++spins) {
+            y = __hip_atomic_load(out + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!is_pending(y)) break;
+            if (spins > (1u << 22)) {
+                atomicExch(err, 1);
+                y = __builtin_nan("");
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return y;
+    };
+    auto solve_row = [&](const Row &r) {
+        const bool valid = r.j >= 0;
+        double acc = r.b;
+        if (valid && r.m.x == (int)0x80000000) {          // long row: entries from the level-ordered copy
+            const int s = lo_rp[r.j], e = lo_rp[r.j + 1];
+            const int ks = UPPER ? s + 1 : s, ke = UPPER ? e : e - 1;
+            for (int k = ks; k < ke; ++k) {
+                const int cp = lo_cpos[k];
+                const double yv = (cp >= seg_start && cp < seg_end) ? ring[cp & (W - 1)] : poll(lo_ci[k]);
+                acc -= lo_v[k] * yv;
+            }
+        } else {
+            double y0 = ring[(r.m.x < 0 ? 0 : r.m.x) & (W - 1)];
+            double y1 = ring[(r.m.y < 0 ? 0 : r.m.y) & (W - 1)];
+            double y2 = ring[(r.m.z < 0 ? 0 : r.m.z) & (W - 1)];
+            if (valid) {
+                if (r.m.x <= -2) y0 = poll(-2 - r.m.x);
+                if (r.m.y <= -2) y1 = poll(-2 - r.m.y);
+                if (r.m.z <= -2) y2 = poll(-2 - r.m.z);
+            }
+            if (r.m.x != -1) acc -= r.v01.x * y0;
+            if (r.m.y != -1) acc -= r.v01.y * y1;
+            if (r.m.z != -1) acc -= r.v2d.x * y2;
+        }
+        const double y = acc / r.v2d.y;
+        if (valid) {
+            ring[r.j & (W - 1)] = y;
+            __hip_atomic_store(out + r.m.w, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto level_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto solve_chunk = [&](Row (&S)[C][ROWS]) {
+#pragma unroll
+        for (int d = 0; d < C; ++d) {
+#pragma unroll
+            for (int h = 0; h < ROWS; ++h) solve_row(S[d][h]);
+            level_barrier();
+        }
+    };
+    Row S0[C][ROWS], S1[C][ROWS];
+    if (nchunks > 0) {
+        load_chunk(S0, 0);
+        for (int c = 0; c < nchunks; c += 2) {
+            retire(S0);
+            load_chunk(S1, c + 1);                            // flies while chunk c is solved
+            solve_chunk(S0);
+            if (c + 1 >= nchunks) break;
+            retire(S1);
+            load_chunk(S0, c + 2);
+            solve_chunk(S1);
+        }
+    }
+    if (t == 0 && atomicAdd(ticket + 1, 1u) == gridDim.x - 1) {      // last one out: zero the counters for the next launch
+        atomicExch(ticket, 0u);
+        atomicExch(ticket + 1, 0u);
+    }
+}
+
 constexpr int kRingChunk = 6;   // levels per prefetch chunk of k_sptrsv_ring_pipe (3 with two rows per thread)
 static bool ring_pipe_disabled() {
     static const bool off = [] { const char *e = getenv("DPCG_RING_PIPE"); return e && e[0] == '0'; }();
     return off;
 }
 
+constexpr int kStripChunk = 4;   // levels per prefetch chunk of k_sptrsv_strips (2 with two rows per thread)
+
+// The strip kernel may need more than the default 64 KiB of dynamic LDS (ring of up to 8192 doubles + level offsets):
+// raise the limit once, at setup time (never inside a stream capture).
+void init_strip_kernels() {
+    static bool done_once = false;
+    if (done_once) return;
+    done_once = true;
+    (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<true, kStripChunk, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<true, kStripChunk / 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk / 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+}
+
 void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s,
                    const int *done) {
     (void)T;  // the level-ordered copy in `lv` carries the factor
+    if (lv.strips.n_strips > 0) {
+        const Levels::Strips &sp = lv.strips;
+        const int count = (int)T.n;
+        hipLaunchKernelGGL(k_strip_prepare, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, sp.rows, rhs, sp.b_lo, out,
+                           count, done);
+        constexpr int CH = kStripChunk;
+        const size_t lds = (size_t)sp.W * sizeof(double) + (size_t)(sp.nlev + 3 * CH + 8) * sizeof(int);
+#define DPCG_STRIPS(UP, CV, ROWSV)                                                                                        \
+    do {                                                                                                                  \
+        hipLaunchKernelGGL((k_sptrsv_strips<UP, CV, ROWSV>), dim3(sp.n_strips), dim3(sp.threads), lds, s, sp.level_ptr_dev, \
+                           sp.nlev, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, (const int4 *)sp.meta,                 \
+                           (const double2 *)sp.val, sp.b_lo, out, sp.W, sp.ticket, done, lv.spin_err);                     \
+    } while (0)
+        if (sp.rows_per_thread == 1) {
+            if (upper) DPCG_STRIPS(true, CH, 1);
+            else DPCG_STRIPS(false, CH, 1);
+        } else {
+            if (upper) DPCG_STRIPS(true, CH / 2, 2);
+            else DPCG_STRIPS(false, CH / 2, 2);
+        }
+#undef DPCG_STRIPS
+        return;
+    }
     int seg_index = -1;
     for (const auto &seg : lv.segments) {
         ++seg_index;
@@ -588,62 +785,6 @@ __global__ __launch_bounds__(kBlock) void k_ic0_level(const int32_t *__restrict_
             lv[k] = sqrt(acc);
         }
     }
-}
-
-// A run of NARROW levels (each <= 1024 rows: natural-order 2-D grids have thousands of them) factored by ONE workgroup
-// with a barrier per level instead of a launch per level (2047 launches cost 10.9 ms at 1024^2, host-bound).  Entries
-// written in one level and read in the next travel through L2 with agent-scope accesses (as in k_sptrsv_merged), so no
-// wave reads a stale L1 line; the arithmetic and its order are k_ic0_level's: the same factor, bit for bit.
-template <bool DROP>
-__global__ __launch_bounds__(kMergedBlock) void k_ic0_merged(const int32_t *__restrict__ rows,
-                                                             const int32_t *__restrict__ level_ptr, int lvl_lo, int lvl_hi,
-                                                             const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
-                                                             double *lv, int *bad, const double *__restrict__ colnorm,
-                                                             double tau) {
-    auto ld = [&](int idx) { return __hip_atomic_load(lv + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    for (int lvl = lvl_lo; lvl < lvl_hi; ++lvl) {
-        const int lo = level_ptr[lvl], hi = level_ptr[lvl + 1];
-        for (int jj = lo + (int)threadIdx.x; jj < hi; jj += kMergedBlock) {
-            const int i = rows[jj];
-            const int s_i = rp[i], e_i = rp[i + 1];
-            for (int k = s_i; k < e_i; ++k) {
-                const int j = ci[k];
-                const int s_j = rp[j], e_j = rp[j + 1];
-                double acc = ld(k);
-                int a = s_i, b = s_j;
-                while (a < k && b < e_j - 1) {
-                    const int ca = ci[a], cb = ci[b];
-                    if (ca == cb) {
-                        acc -= ld(a) * ld(b);
-                        ++a;
-                        ++b;
-                    } else if (ca < cb) ++a;
-                    else ++b;
-                }
-                double v;
-                if (j < i) {
-                    const double d = ld(e_j - 1);
-                    v = acc / d;
-                    if (DROP && fabs(v) * d < tau * colnorm[j]) v = 0.0;
-                } else {
-                    if (!(acc > 0.0)) atomicExch(bad, i + 1);
-                    v = sqrt(acc);
-                }
-                __hip_atomic_store(lv + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();  // includes s_waitcnt vmcnt(0): this level's stores have reached L2
-    }
-}
-
-void launch_ic0_merged(const int32_t *rows, const int32_t *level_ptr_dev, int lvl_lo, int lvl_hi, const int32_t *rp,
-                       const int32_t *ci, double *lv, int *bad, hipStream_t s, const double *colnorm, double tau) {
-    if (colnorm)
-        hipLaunchKernelGGL(k_ic0_merged<true>, dim3(1), dim3(kMergedBlock), 0, s, rows, level_ptr_dev, lvl_lo, lvl_hi, rp, ci, lv,
-                           bad, colnorm, tau);
-    else
-        hipLaunchKernelGGL(k_ic0_merged<false>, dim3(1), dim3(kMergedBlock), 0, s, rows, level_ptr_dev, lvl_lo, lvl_hi, rp, ci,
-                           lv, bad, colnorm, tau);
 }
 
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
