@@ -399,7 +399,10 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
     DPCG_HIP(hipStreamSynchronize(s));
     int width = 0;
     for (size_t q = 0; q + 1 < lptr.size(); ++q) width = std::max(width, lptr[q + 1] - lptr[q]);
-    if (width > 1024) return drop();
+    if (width > 1024) {
+        if (pt.on) fprintf(stderr, "[dpcg setup] strip plan dropped: a strip-local level has %d rows (> 1024)\n", width);
+        return drop();
+    }
     // level-ordered copy in (strip, level, row) order
     DPCG_TRY(len.alloc(n + 1)); DPCG_TRY(pos.alloc(n));
     DPCG_TRY(dev_alloc(&sp.lo_rowptr, n + 1)); DPCG_TRY(dev_alloc(&sp.lo_col, nnz)); DPCG_TRY(dev_alloc(&sp.lo_cpos, nnz));
@@ -422,7 +425,12 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
     const int64_t reach = h_ctl[0], external = h_ctl[1], offdiag = nnz - n;
     int64_t W = 64;
     while (W < reach + width + 1) W *= 2;
-    if (W > 8192 || (offdiag > 0 && external * 2 > offdiag)) return drop();      // ring too long, or mostly foreign entries
+    if (W > 8192 || (offdiag > 0 && external * 2 > offdiag)) {                   // ring too long, or mostly foreign entries
+        if (pt.on)
+            fprintf(stderr, "[dpcg setup] strip plan dropped: reach %lld + width %d -> ring %lld, %lld of %lld entries foreign\n",
+                    (long long)reach, width, (long long)W, (long long)external, (long long)offdiag);
+        return drop();
+    }
     sp.n_strips = (int)S;
     sp.nlev = nlev;
     sp.W = (int)W;

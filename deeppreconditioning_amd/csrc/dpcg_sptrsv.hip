@@ -549,12 +549,21 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
         }
         return y;
     };
-    auto solve_row = [&](const Row &r) {
+    // Entries of EARLIER strips are asked for once per CHUNK, all at once, before the chunk's levels are walked (the records
+    // that name them have just been retired); a value that is still pending then is polled when its row is solved.  The
+    // hand-off latency is paid once per C levels instead of once per level, and the steady-state lag of a strip behind
+    // its predecessor grows accordingly.
+    struct Ext { double y0, y1, y2; };
+    const double pend = __longlong_as_double((long long)kPendingBits);
+    auto ask = [&](int d, bool valid) {
+        return (valid && d <= -2) ? __hip_atomic_load(out + (-2 - d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    };
+    auto solve_row = [&](const Row &r, const Ext &e) {
         const bool valid = r.j >= 0;
         double acc = r.b;
         if (valid && r.m.x == (int)0x80000000) {          // long row: entries from the level-ordered copy
-            const int s = lo_rp[r.j], e = lo_rp[r.j + 1];
-            const int ks = UPPER ? s + 1 : s, ke = UPPER ? e : e - 1;
+            const int s = lo_rp[r.j], e2 = lo_rp[r.j + 1];
+            const int ks = UPPER ? s + 1 : s, ke = UPPER ? e2 : e2 - 1;
             for (int k = ks; k < ke; ++k) {
                 const int cp = lo_cpos[k];
                 const double yv = (cp >= seg_start && cp < seg_end) ? ring[cp & (W - 1)] : poll(lo_ci[k]);
@@ -565,9 +574,9 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
             double y1 = ring[(r.m.y < 0 ? 0 : r.m.y) & (W - 1)];
             double y2 = ring[(r.m.z < 0 ? 0 : r.m.z) & (W - 1)];
             if (valid) {
-                if (r.m.x <= -2) y0 = poll(-2 - r.m.x);
-                if (r.m.y <= -2) y1 = poll(-2 - r.m.y);
-                if (r.m.z <= -2) y2 = poll(-2 - r.m.z);
+                if (r.m.x <= -2) y0 = is_pending(e.y0) ? poll(-2 - r.m.x) : e.y0;
+                if (r.m.y <= -2) y1 = is_pending(e.y1) ? poll(-2 - r.m.y) : e.y1;
+                if (r.m.z <= -2) y2 = is_pending(e.y2) ? poll(-2 - r.m.z) : e.y2;
             }
             if (r.m.x != -1) acc -= r.v01.x * y0;
             if (r.m.y != -1) acc -= r.v01.y * y1;
@@ -581,10 +590,22 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
     };
     auto level_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto solve_chunk = [&](Row (&S)[C][ROWS]) {
+        Ext E[C][ROWS];
+#pragma unroll
+        for (int d = 0; d < C; ++d)
+#pragma unroll
+            for (int h = 0; h < ROWS; ++h) {
+                const Row &r = S[d][h];
+                const bool v = r.j >= 0 && r.m.x != (int)0x80000000;
+                E[d][h].y0 = ask(r.m.x, v);
+                E[d][h].y1 = ask(r.m.y, v);
+                E[d][h].y2 = ask(r.m.z, v);
+            }
+        (void)pend;
 #pragma unroll
         for (int d = 0; d < C; ++d) {
 #pragma unroll
-            for (int h = 0; h < ROWS; ++h) solve_row(S[d][h]);
+            for (int h = 0; h < ROWS; ++h) solve_row(S[d][h], E[d][h]);
             level_barrier();
         }
     };
