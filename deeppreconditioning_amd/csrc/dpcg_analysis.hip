@@ -195,8 +195,8 @@ __global__ __launch_bounds__(kBlock) void k_strip_records(int64_t n, const uint3
                                                           const int32_t *__restrict__ rows,
                                                           const int32_t *__restrict__ lo_rp, const int32_t *__restrict__ lo_ci,
                                                           const int32_t *__restrict__ lo_cp, const double *__restrict__ lo_v,
-                                                          int upper, int32_t *__restrict__ meta, double *__restrict__ pv,
-                                                          int *stats) {
+                                                          int upper, int ring_reach, int32_t *__restrict__ meta,
+                                                          double *__restrict__ pv, int32_t *exported, int *stats) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     int reach = 0, ext = 0, longrows = 0;
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
@@ -208,20 +208,25 @@ __global__ __launch_bounds__(kBlock) void k_strip_records(int64_t n, const uint3
         const int ks = upper ? a + 1 : a, ke = upper ? b : b - 1;
         m[3] = rows[j];
         w[3] = lo_v[upper ? a : b - 1];
+        // through the ring: an entry of the own strip at most ring_reach positions back; everything else -- entries of
+        // earlier strips, and own entries too far back for the ring -- is read from `out`, whose owner must then publish it
         for (int k = ks; k < ke; ++k) {
             const int cp = lo_cp[k];
-            if (cp >= start && cp < end) reach = (int)j - cp > reach ? (int)j - cp : reach;
-            else ++ext;
+            const bool near = cp >= start && cp < end && (int)j - cp <= ring_reach;
+            if (near) {
+                reach = (int)j - cp > reach ? (int)j - cp : reach;
+            } else {
+                ++ext;
+                exported[lo_ci[k]] = 1;
+            }
+            if (ke - ks <= 3) {
+                m[k - ks] = near ? cp : -2 - lo_ci[k];
+                w[k - ks] = lo_v[k];
+            }
         }
         if (ke - ks > 3) {
             m[0] = (int)0x80000000;
             ++longrows;
-        } else {
-            for (int k = ks; k < ke; ++k) {
-                const int cp = lo_cp[k];
-                m[k - ks] = (cp >= start && cp < end) ? cp : -2 - lo_ci[k];
-                w[k - ks] = lo_v[k];
-            }
         }
         reinterpret_cast<int4 *>(meta)[j] = make_int4(m[0], m[1], m[2], m[3]);
         reinterpret_cast<double2 *>(pv)[2 * j] = make_double2(w[0], w[1]);
@@ -232,11 +237,44 @@ __global__ __launch_bounds__(kBlock) void k_strip_records(int64_t n, const uint3
     if (longrows) atomicAdd(stats + 2, longrows);
 }
 
+// rows some other row reads from `out` during the launch get bit 30 of their own-row field set: they are stored write-through
+__global__ __launch_bounds__(kBlock) void k_strip_mark_exported(int64_t n, const int32_t *__restrict__ exported, int32_t *meta) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        const int row = meta[4 * j + 3];
+        if (exported[row]) meta[4 * j + 3] = row | (1 << 30);
+    }
+}
+
+// max over the rows of (row - smallest column) for a lower factor, (largest column - row) for an upper one: the band
+__global__ __launch_bounds__(kBlock) void k_max_band(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                     int upper, int *out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const int a = rp[i], b = rp[i + 1];
+        if (b > a) {
+            const int d = upper ? ci[b - 1] - (int)i : (int)i - ci[a];
+            m = d > m ? d : m;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_down(m, off);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+
+void launch_max_band(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int *out_dev, hipStream_t s) {
+    hipLaunchKernelGGL(k_max_band, dim3(grid_rows(n, 1024)), dim3(kBlock), 0, s, n, rp, ci, upper ? 1 : 0, out_dev);
+}
+
 void launch_strip_records(int64_t n, const uint32_t *key_of_pos, int nlev, const int32_t *level_ptr, const int32_t *rows,
                           const int32_t *lo_rp, const int32_t *lo_ci, const int32_t *lo_cp, const double *lo_v, bool upper,
-                          int32_t *meta, double *pv, int *stats, hipStream_t s) {
+                          int ring_reach, int32_t *meta, double *pv, int32_t *exported_zeroed, int *stats, hipStream_t s) {
     hipLaunchKernelGGL(k_strip_records, dim3(grid_rows(n, 1024)), dim3(kBlock), 0, s, n, key_of_pos, nlev, level_ptr, rows, lo_rp,
-                       lo_ci, lo_cp, lo_v, upper ? 1 : 0, meta, pv, stats);
+                       lo_ci, lo_cp, lo_v, upper ? 1 : 0, ring_reach, meta, pv, exported_zeroed, stats);
+    hipLaunchKernelGGL(k_strip_mark_exported, dim3(grid_rows(n, 1024)), dim3(kBlock), 0, s, n, exported_zeroed, meta);
 }
 
 // ------------------------------------------------------------------------------------------------

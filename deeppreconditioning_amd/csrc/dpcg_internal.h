@@ -129,7 +129,7 @@ struct Levels {
     // Strip-pipelined solve (k_sptrsv_strips): the rows once more, sorted by (strip, strip-local level, row), with their
     // own level offsets (n_strips * nlev + 1 entries), level-ordered factor copy and records.  n_strips == 0: not used.
     struct Strips {
-        int n_strips = 0, nlev = 0, W = 0, threads = 0, rows_per_thread = 1;
+        int n_strips = 0, nlev = 0, W = 0, ring_reach = 0, threads = 0, rows_per_thread = 1;
         int32_t *rows = nullptr, *level_ptr_dev = nullptr, *lo_rowptr = nullptr, *lo_col = nullptr, *lo_cpos = nullptr;
         double *lo_val = nullptr, *val = nullptr, *b_lo = nullptr;
         int32_t *meta = nullptr;
@@ -305,7 +305,8 @@ void launch_levels_syncfree(int64_t n, const int32_t *rp, const int32_t *ci, boo
 void launch_strip_keys(int64_t n, const int32_t *level, int strip_rows, int nlev, bool upper, uint32_t *key, hipStream_t s);
 void launch_strip_records(int64_t n, const uint32_t *key_of_pos, int nlev, const int32_t *level_ptr, const int32_t *rows,
                           const int32_t *lo_rp, const int32_t *lo_ci, const int32_t *lo_cp, const double *lo_v, bool upper,
-                          int32_t *meta, double *pv, int *stats, hipStream_t s);
+                          int ring_reach, int32_t *meta, double *pv, int32_t *exported_zeroed, int *stats, hipStream_t s);
+void launch_max_band(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int *out_dev, hipStream_t s);
 void launch_lo_lengths(int64_t n, const int32_t *rows, const int32_t *rp, int32_t *len, int32_t *pos, hipStream_t s);
 void launch_lo_copy(int64_t n, const int32_t *rows, const int32_t *rp, const int32_t *ci, const double *v,
                     const int32_t *pos, const int32_t *lo_rp, int32_t *lo_ci, int32_t *lo_cp, double *lo_v,

@@ -364,14 +364,35 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
                  const int32_t *relabel, hipStream_t s) {
     if (!strips_enabled() || lv.n_levels < 64 || n < 32768) return DPCG_OK;
     static const int64_t target_rows = [] { const char *e = getenv("DPCG_STRIP_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)16384; }();
-    int64_t S = n / target_rows;
-    S = S < 8 ? 8 : (S > 128 ? 128 : S);
-    const int strip_rows = (int)((n + S - 1) / S);
-    S = (n + strip_rows - 1) / strip_rows;
+    if (n >= (int64_t)1 << 30) return DPCG_OK;                // bit 30 of a row index is the "published" mark
+    // a factor whose whole schedule is one LDS-ring walk and that is small enough for one CU to stream keeps that walk
+    // (measured at 256^2, 511 levels: 0.36 ms per apply on the ring, 0.66 ms in 8 strips)
+    if (n <= 131072 && lv.segments.size() == 1 && lv.segments[0].merged && lv.segments[0].ring_w > 0 && lv.pk_meta &&
+        lv.segments[0].max_width <= 1024)
+        return DPCG_OK;
     PhaseTimer pt(s);
-    DevBuf<int32_t> level, iota, ctl, len, pos;
+    DevBuf<int32_t> level, iota, ctl, len, pos, exported;
     DevBuf<uint32_t> key, key_sorted;
     DPCG_TRY(level.alloc(n)); DPCG_TRY(iota.alloc(n)); DPCG_TRY(ctl.alloc(8)); DPCG_TRY(key.alloc(n)); DPCG_TRY(key_sorted.alloc(n));
+    DPCG_TRY(exported.alloc(n));
+    DPCG_HIP(hipMemsetAsync(ctl.p, 0, 8 * sizeof(int32_t), s));
+    // strips are cut at multiples of the band (for a grid: whole planes / grid lines), so that an entry one band back sits one
+    // strip-local level back and not dozens
+    launch_max_band(n, rp, ci, upper, reinterpret_cast<int *>(ctl.p + 4), s);
+    int32_t band = 0;
+    DPCG_HIP(hipMemcpyAsync(&band, ctl.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    band = band < 1 ? 1 : band;
+    int64_t per = (target_rows + band / 2) / band;
+    per = per < 1 ? 1 : per;
+    int64_t strip_rows64 = per * band;
+    int64_t S = (n + strip_rows64 - 1) / strip_rows64;
+    if (S > 256) {                                            // keep every strip's workgroup resident
+        strip_rows64 = ((n + 255) / 256 + band - 1) / band * band;
+        S = (n + strip_rows64 - 1) / strip_rows64;
+    }
+    if (S < 4) return DPCG_OK;
+    const int strip_rows = (int)strip_rows64;
     DPCG_HIP(hipMemsetAsync(level.p, 0xff, (size_t)n * sizeof(int32_t), s));
     DPCG_HIP(hipMemsetAsync(ctl.p, 0, 8 * sizeof(int32_t), s));
     launch_levels_syncfree(n, rp, ci, upper, level.p, reinterpret_cast<unsigned int *>(ctl.p), ctl.p + 1, s, strip_rows);
@@ -417,8 +438,10 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
     }
     DPCG_HIP(hipMemsetAsync(ctl.p, 0, 8 * sizeof(int32_t), s));
     DPCG_HIP(hipMemsetAsync(sp.ticket, 0, 2 * sizeof(unsigned int), s));
+    constexpr int kRingReach = 8192 - 1024 - 1;               // what a ring of 8192 doubles covers beside the widest level
+    DPCG_HIP(hipMemsetAsync(exported.p, 0, (size_t)n * sizeof(int32_t), s));
     launch_strip_records(n, key_sorted.p, nlev, sp.level_ptr_dev, sp.rows, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, upper,
-                         sp.meta, sp.val, reinterpret_cast<int *>(ctl.p), s);
+                         kRingReach, sp.meta, sp.val, exported.p, reinterpret_cast<int *>(ctl.p), s);
     DPCG_HIP(hipMemcpyAsync(h_ctl, ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
     DPCG_CHECK_LAUNCH();
@@ -434,6 +457,7 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
     sp.n_strips = (int)S;
     sp.nlev = nlev;
     sp.W = (int)W;
+    sp.ring_reach = kRingReach;
     sp.rows_per_thread = width <= 512 ? 1 : 2;
     sp.threads = ((width + sp.rows_per_thread - 1) / sp.rows_per_thread + 63) / 64 * 64;
     sp.threads = sp.threads < 64 ? 64 : sp.threads;

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
                                                        const int32_t *__restrict__ lo_cpos, const double *__restrict__ lo_v,
                                                        const int4 *__restrict__ pk_meta, const double2 *__restrict__ pk_val,
                                                        const double *__restrict__ b_lo, double *out, int W,
-                                                       unsigned int *ticket, const int *done, int *err) {
+                                                       int ring_reach, unsigned int *ticket, const int *done, int *err) {
     if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     extern __shared__ __attribute__((aligned(16))) double ring[];
     int *lp = reinterpret_cast<int *>(ring + W);        // level offsets of this strip, padded with empty levels
@@ -566,7 +566,8 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
             const int ks = UPPER ? s + 1 : s, ke = UPPER ? e2 : e2 - 1;
             for (int k = ks; k < ke; ++k) {
                 const int cp = lo_cpos[k];
-                const double yv = (cp >= seg_start && cp < seg_end) ? ring[cp & (W - 1)] : poll(lo_ci[k]);
+                const bool near = cp >= seg_start && cp < seg_end && r.j - cp <= ring_reach;   // as k_strip_records decides
+                const double yv = near ? ring[cp & (W - 1)] : poll(lo_ci[k]);
                 acc -= lo_v[k] * yv;
             }
         } else {
@@ -585,7 +586,11 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
         const double y = acc / r.v2d.y;
         if (valid) {
             ring[r.j & (W - 1)] = y;
-            __hip_atomic_store(out + r.m.w, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // only rows that somebody reads from `out` DURING the launch are published (write-through); the rest is a plain
+            // store, visible at the kernel's end like any other
+            const int row = r.m.w & 0x3fffffff;
+            if (r.m.w & (1 << 30)) __hip_atomic_store(out + row, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else out[row] = y;
         }
     };
     auto level_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -662,7 +667,7 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
     do {                                                                                                                  \
         hipLaunchKernelGGL((k_sptrsv_strips<UP, CV, ROWSV>), dim3(sp.n_strips), dim3(sp.threads), lds, s, sp.level_ptr_dev, \
                            sp.nlev, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, (const int4 *)sp.meta,                 \
-                           (const double2 *)sp.val, sp.b_lo, out, sp.W, sp.ticket, done, lv.spin_err);                     \
+                           (const double2 *)sp.val, sp.b_lo, out, sp.W, sp.ring_reach, sp.ticket, done, lv.spin_err);      \
     } while (0)
         if (sp.rows_per_thread == 1) {
             if (upper) DPCG_STRIPS(true, CH, 1);

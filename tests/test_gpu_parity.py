@@ -1367,3 +1367,27 @@ def test_reordering_of_disconnected_and_degenerate_graphs(D):
             np.testing.assert_allclose(res.res_history[sig], hist[sig], rtol=1e-9)
             np.testing.assert_allclose(res.x.cpu().numpy()[perm], xs, rtol=1e-8, atol=1e-11)
         S.close()
+
+
+def test_strip_pipelined_triangular_solves():
+    """Banded factors with many narrow levels (natural-order 3-D / 2-D grids, an unstructured system in the library's RCM order)
+    take the strip-pipelined solve: one workgroup per strip of rows, strip-local levels through an LDS ring, entries of earlier
+    strips polled.  In a child process with DPCG_SETUP_TRACE=1 the library says which plan it kept; lower and upper solves and
+    the whole apply must equal sequential substitution BIT FOR BIT (IC(0) of the system and a factor handed over by the
+    caller, also on a reordered handle), and PCG with it the oracle's counts and histories."""
+    import json
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = {**__import__("os").environ, "PYTHONPATH": str(root), "DPCG_SETUP_TRACE": "1"}
+    proc = subprocess.run([sys.executable, str(root / "tests" / "strip_plan_child.py")], capture_output=True, text=True, cwd=root,
+                          env=env, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    assert "strip plan (L)" in proc.stderr and "strip plan (L^T)" in proc.stderr      # the path under test was taken
+    out = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][-1])
+    for name, rec in out.items():
+        for mode in ("ic0", "user_factor"):
+            r = rec[mode]
+            assert r["lower"] and r["upper"] and r["apply"], (name, mode, r)
+            assert r["iterations"][0] == r["iterations"][1] and r["hist_rel"] < 1e-9, (name, mode, r)
