@@ -428,7 +428,7 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
     DPCG_TRY(len.alloc(n + 1)); DPCG_TRY(pos.alloc(n));
     DPCG_TRY(dev_alloc(&sp.lo_rowptr, n + 1)); DPCG_TRY(dev_alloc(&sp.lo_col, nnz)); DPCG_TRY(dev_alloc(&sp.lo_cpos, nnz));
     DPCG_TRY(dev_alloc(&sp.lo_val, nnz)); DPCG_TRY(dev_alloc(&sp.meta, n * 4)); DPCG_TRY(dev_alloc(&sp.val, n * 4));
-    DPCG_TRY(dev_alloc(&sp.b_lo, n + 1)); DPCG_TRY(dev_alloc(&sp.ticket, 2));       // + the dump slot of lanes without a row
+    DPCG_TRY(dev_alloc(&sp.b_lo, n)); DPCG_TRY(dev_alloc(&sp.ticket, 2));
     launch_lo_lengths(n, sp.rows, rp, len.p, pos.p, s);
     DPCG_TRY(exclusive_scan_i32(len.p, sp.lo_rowptr, n + 1, s));
     launch_lo_copy(n, sp.rows, rp, ci, v, pos.p, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, s);

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
                                                        const int32_t *__restrict__ lo_rp, const int32_t *__restrict__ lo_ci,
                                                        const int32_t *__restrict__ lo_cpos, const double *__restrict__ lo_v,
                                                        const int4 *__restrict__ pk_meta, const double2 *__restrict__ pk_val,
-                                                       const double *__restrict__ b_lo, double *out, double *dump, int W,
+                                                       const double *__restrict__ b_lo, double *out, int W,
                                                        int ring_reach, unsigned int *ticket, const int *done, int *err) {
     if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     extern __shared__ __attribute__((aligned(16))) double ring[];
@@ -555,10 +555,8 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
     // its predecessor grows accordingly.
     struct Ext { double y0, y1, y2; };
     const double pend = __longlong_as_double((long long)kPendingBits);
-    // unconditional (a lane with nothing to ask for reads slot 0 and ignores it): a load under a branch would make the
-    // compiler's in-order counter ambiguous, and the exact s_waitcnt below relies on the number of loads issued
     auto ask = [&](int d, bool valid) {
-        return __hip_atomic_load(out + ((valid && d <= -2) ? -2 - d : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (valid && d <= -2) ? __hip_atomic_load(out + (-2 - d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     };
     auto solve_row = [&](const Row &r, const Ext &e) {
         const bool valid = r.j >= 0;
@@ -586,14 +584,18 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
             if (r.m.z != -1) acc -= r.v2d.x * y2;
         }
         const double y = acc / r.v2d.y;
-        if (valid) ring[r.j & (W - 1)] = y;
-        // one unconditional write-through store per row slot (lanes without a row write the dump slot): the number of
-        // vector-memory instructions per level is then fixed, which the exact waits of the chunk pipeline count on
-        double *dst = valid ? out + (r.m.w & 0x3fffffff) : dump;
-        __hip_atomic_store(dst, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (valid) {
+            ring[r.j & (W - 1)] = y;
+            // only rows that somebody reads from `out` DURING the launch are published (write-through); the rest is a plain
+            // store, visible at the kernel's end like any other
+            const int row = r.m.w & 0x3fffffff;
+            if (r.m.w & (1 << 30)) __hip_atomic_store(out + row, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else out[row] = y;
+        }
     };
     auto level_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    auto ask_chunk = [&](const Row (&S)[C][ROWS], Ext (&E)[C][ROWS]) {
+    auto solve_chunk = [&](Row (&S)[C][ROWS]) {
+        Ext E[C][ROWS];
 #pragma unroll
         for (int d = 0; d < C; ++d)
 #pragma unroll
@@ -604,18 +606,7 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
                 E[d][h].y1 = ask(r.m.y, v);
                 E[d][h].y2 = ask(r.m.z, v);
             }
-    };
-    // the asked-for values have landed once at most the 4 * C * ROWS record loads issued AFTER them are outstanding
-    // (vector-memory operations complete in order); tell the compiler so (the registers are "redefined" here)
-    auto land_asks = [&](Ext (&E)[C][ROWS]) {
-        static_assert(4 * C * ROWS <= 63, "s_waitcnt vmcnt takes 6 bits");
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * C * ROWS) : "memory");
-#pragma unroll
-        for (int d = 0; d < C; ++d)
-#pragma unroll
-            for (int h = 0; h < ROWS; ++h) asm volatile("" : "+v"(E[d][h].y0), "+v"(E[d][h].y1), "+v"(E[d][h].y2));
-    };
-    auto solve_chunk = [&](Row (&S)[C][ROWS], Ext (&E)[C][ROWS]) {
+        (void)pend;
 #pragma unroll
         for (int d = 0; d < C; ++d) {
 #pragma unroll
@@ -623,25 +614,17 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
             level_barrier();
         }
     };
-    // Pipeline per chunk: [records of chunk c landed] -> ask for its foreign entries -> request the records of chunk c + 1
-    // -> wait for the asked values only -> walk the C levels (stores stay in flight) -> ...
     Row S0[C][ROWS], S1[C][ROWS];
-    Ext E[C][ROWS];
-    (void)pend;
     if (nchunks > 0) {
         load_chunk(S0, 0);
         for (int c = 0; c < nchunks; c += 2) {
             retire(S0);
-            ask_chunk(S0, E);
             load_chunk(S1, c + 1);                            // flies while chunk c is solved
-            land_asks(E);
-            solve_chunk(S0, E);
+            solve_chunk(S0);
             if (c + 1 >= nchunks) break;
             retire(S1);
-            ask_chunk(S1, E);
             load_chunk(S0, c + 2);
-            land_asks(E);
-            solve_chunk(S1, E);
+            solve_chunk(S1);
         }
     }
     if (t == 0 && atomicAdd(ticket + 1, 1u) == gridDim.x - 1) {      // last one out: zero the counters for the next launch
@@ -684,8 +667,7 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
     do {                                                                                                                  \
         hipLaunchKernelGGL((k_sptrsv_strips<UP, CV, ROWSV>), dim3(sp.n_strips), dim3(sp.threads), lds, s, sp.level_ptr_dev, \
                            sp.nlev, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, (const int4 *)sp.meta,                 \
-                           (const double2 *)sp.val, sp.b_lo, out, sp.b_lo + count, sp.W, sp.ring_reach, sp.ticket, done,   \
-                           lv.spin_err);                                                                                    \
+                           (const double2 *)sp.val, sp.b_lo, out, sp.W, sp.ring_reach, sp.ticket, done, lv.spin_err);      \
     } while (0)
         if (sp.rows_per_thread == 1) {
             if (upper) DPCG_STRIPS(true, CH, 1);
