@@ -535,14 +535,29 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
             lower_levels = &own;
             pt.mark("levels(L)");
         }
-        DPCG_TRY(build_levels(h->lvlL, *lower_levels, n, h->L.nnz, h->L.rowptr, h->L.col, h->L.val, s, h->iperm));
+        // Large factors try the strip plan FIRST and build the level schedule (level-ordered copy, ring / sync-free records)
+        // only when it is not kept; small ones build the schedule first because the choice depends on it.
+        auto schedule = [&](Levels &lv, LevelSort &ls, const CsrDev &F, bool upper) -> int {
+            const bool strips_first = n > 131072;
+            if (strips_first) {
+                lv.level_ptr = ls.level_ptr;
+                lv.n_levels = (int)ls.level_ptr.size() - 1;
+                DPCG_TRY(dev_alloc(&lv.spin_err, 1));
+                DPCG_HIP(hipMemsetAsync(lv.spin_err, 0, sizeof(int), s));
+                DPCG_TRY(build_strips(lv, n, F.nnz, F.rowptr, F.col, F.val, upper, h->iperm, s));
+                if (lv.strips.n_strips > 0) return DPCG_OK;
+                dev_free(lv.spin_err);
+            }
+            DPCG_TRY(build_levels(lv, ls, n, F.nnz, F.rowptr, F.col, F.val, s, h->iperm, upper));
+            if (!strips_first) DPCG_TRY(build_strips(lv, n, F.nnz, F.rowptr, F.col, F.val, upper, h->iperm, s));
+            return DPCG_OK;
+        };
+        DPCG_TRY(schedule(h->lvlL, *lower_levels, h->L, false));
         pt.mark("schedule(L)");
-        DPCG_TRY(build_strips(h->lvlL, n, h->L.nnz, h->L.rowptr, h->L.col, h->L.val, false, h->iperm, s));
         DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s));
         pt.mark("levels(L^T)");
-        DPCG_TRY(build_levels(h->lvlU, up, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, s, h->iperm, true));
+        DPCG_TRY(schedule(h->lvlU, up, h->Lt, true));
         pt.mark("schedule(L^T)");
-        DPCG_TRY(build_strips(h->lvlU, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, true, h->iperm, s));
     }
     h->precond = mode;
     return DPCG_OK;
