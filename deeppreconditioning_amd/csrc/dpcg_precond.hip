@@ -554,9 +554,20 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
         };
         DPCG_TRY(schedule(h->lvlL, *lower_levels, h->L, false));
         pt.mark("schedule(L)");
-        DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s));
-        pt.mark("levels(L^T)");
-        DPCG_TRY(schedule(h->lvlU, up, h->Lt, true));
+        // L^T has as many levels as L (the longest dependency chain read backwards): when L took the strip plan, L^T tries it
+        // straight away and its global level sets are only computed if that fails
+        if (h->lvlL.strips.n_strips > 0) {
+            h->lvlU.n_levels = h->lvlL.n_levels;
+            DPCG_TRY(dev_alloc(&h->lvlU.spin_err, 1));
+            DPCG_HIP(hipMemsetAsync(h->lvlU.spin_err, 0, sizeof(int), s));
+            DPCG_TRY(build_strips(h->lvlU, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, true, h->iperm, s));
+            if (h->lvlU.strips.n_strips == 0) dev_free(h->lvlU.spin_err);
+        }
+        if (h->lvlU.strips.n_strips == 0) {
+            DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s));
+            pt.mark("levels(L^T)");
+            DPCG_TRY(schedule(h->lvlU, up, h->Lt, true));
+        }
         pt.mark("schedule(L^T)");
     }
     h->precond = mode;
