@@ -19,7 +19,6 @@ namespace dpcg {
 constexpr int kBlock = 256;
 constexpr int kMaxGrid = 512;         // vector kernels: 2 workgroups per CU (fewer partials to re-reduce)
 constexpr int kMaxSpmvGrid = 2048;    // SpMV: 8 workgroups per CU = 32 waves per CU (40 VGPRs, 16 KiB LDS each)
-constexpr int kVecBatch = 4;          // element pairs a thread of a vector kernel has in flight (see k_update_r)
 constexpr int kStreamCap = 2048;      // products staged in LDS per 256-row block (16 KiB)
 constexpr int kStreamRows = 256;      // rows per row-block of the CSR-stream SpMV
 

@@ -24,31 +24,20 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
     __shared__ double sh[8];
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const double2 *__restrict__ q2 = reinterpret_cast<const double2 *>(q);
     const double2 *__restrict__ d2 = reinterpret_cast<const double2 *>(dinv);
     double2 *__restrict__ r2 = reinterpret_cast<double2 *>(r);
     double2 *__restrict__ z2 = reinterpret_cast<double2 *>(z);
-    // A thread owns the element pairs i0, i0 + stride, ...: kVecBatch of them are requested AT ONCE (12 loads in flight per
-    // thread instead of 3).  At 1M rows that is a thread's whole share -- one memory round trip for the kernel's data, and
-    // it overlaps the head -- where a one-pair-ahead prefetch made four dependent round trips.  Loads are unconditional
-    // (index clamped): a lane past the end re-reads the last pair and ignores it.  Pairs are consumed in the same order
-    // as before, so every partial sum has the same bits.
-    double2 qa[kVecBatch], ra[kVecBatch], da[kVecBatch];
-    const int64_t last = n2 > 0 ? n2 - 1 : 0;
-    auto fetch = [&](int64_t base) {
-#pragma unroll
-        for (int u = 0; u < kVecBatch; ++u) {
-            const int64_t idx = base + u * stride;
-            const int64_t ic = idx < n2 ? idx : last;
-            qa[u] = q2[ic];
-            ra[u] = r2[ic];
-            da[u] = PRE == 1 ? d2[ic] : make_double2(0.0, 0.0);
-        }
-    };
-    if (n2 > 0) fetch(i0);
+    double2 qa = make_double2(0, 0), ra = qa, da = qa;
+    bool have = i < n2;
+    if (have) {
+        qa = q2[i];
+        ra = r2[i];
+        if (PRE == 1) da = d2[i];
+    }
     // Everything the head needs is requested before anything is looked at: the SpMV's partials of <p,Ap>, the `done`
-    // word and <r,z> travel together with the vector loads, so the head exposes ONE memory round trip; a finished
+    // word and <r,z> travel together with the first vector loads, so the head exposes ONE memory round trip; a finished
     // solve has merely loaded a few values for nothing.
     EarlyPartials<kSpmvPartSlots> ep;
     ep.request(part_pq, n_part_pq);
@@ -71,28 +60,29 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
         }
     }
     double a_rz = 0.0, a_rr = 0.0;
-    for (int64_t base = i0; base < n2; base += kVecBatch * stride) {
-        if (base != i0) fetch(base);
-#pragma unroll
-        for (int u = 0; u < kVecBatch; ++u) {
-            const int64_t cur = base + u * stride;
-            if (cur < n2) {
-                const double2 qc = qa[u], rc = ra[u], dc = da[u];
-                double2 rn;
-                rn.x = rc.x - alpha * qc.x;                             // cg.py:80
-                rn.y = rc.y - alpha * qc.y;
-                r2[cur] = rn;
-                a_rr += rn.x * rn.x;                                    // cg.py:86
-                a_rr += rn.y * rn.y;
-                if (PRE == 1) {
-                    double2 zn;
-                    zn.x = dc.x * rn.x;                                 // cg.py:81 (M = diag(1/a_ii))
-                    zn.y = dc.y * rn.y;
-                    if (store_z) z2[cur] = zn;
-                    a_rz += rn.x * zn.x;                                // cg.py:82
-                    a_rz += rn.y * zn.y;
-                }
-            }
+    while (have) {
+        const int64_t cur = i;
+        const double2 qc = qa, rc = ra, dc = da;
+        i += stride;
+        have = i < n2;
+        if (have) {
+            qa = q2[i];
+            ra = r2[i];
+            if (PRE == 1) da = d2[i];
+        }
+        double2 rn;
+        rn.x = rc.x - alpha * qc.x;                                     // cg.py:80
+        rn.y = rc.y - alpha * qc.y;
+        r2[cur] = rn;
+        a_rr += rn.x * rn.x;                                            // cg.py:86
+        a_rr += rn.y * rn.y;
+        if (PRE == 1) {
+            double2 zn;
+            zn.x = dc.x * rn.x;                                         // cg.py:81 (M = diag(1/a_ii))
+            zn.y = dc.y * rn.y;
+            if (store_z) z2[cur] = zn;
+            a_rz += rn.x * zn.x;                                        // cg.py:82
+            a_rz += rn.y * zn.y;
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {               // odd tail element
@@ -221,26 +211,20 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
     __shared__ double sh[4];
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const double2 *__restrict__ z2 = reinterpret_cast<const double2 *>(z);
     double2 *__restrict__ p2 = reinterpret_cast<double2 *>(p);
     double2 *__restrict__ x2 = reinterpret_cast<double2 *>(x);
     float2 *__restrict__ f2 = reinterpret_cast<float2 *>(p32);
     const double2 *__restrict__ zd2 = reinterpret_cast<const double2 *>(zd);
-    double2 za[kVecBatch], pa[kVecBatch], xa[kVecBatch], da[kVecBatch];   // kVecBatch pairs in flight, see k_update_r
-    const int64_t last = n2 > 0 ? n2 - 1 : 0;
-    auto fetch = [&](int64_t base) {
-#pragma unroll
-        for (int u = 0; u < kVecBatch; ++u) {
-            const int64_t idx = base + u * stride;
-            const int64_t ic = idx < n2 ? idx : last;
-            za[u] = z2[ic];
-            pa[u] = p2[ic];
-            xa[u] = x2[ic];
-            da[u] = zd ? zd2[ic] : make_double2(0.0, 0.0);
-        }
-    };
-    if (n2 > 0) fetch(i0);
+    double2 za = make_double2(0, 0), pa = za, xa = za, da = za;
+    bool have = i < n2;
+    if (have) {
+        za = z2[i];
+        pa = p2[i];
+        xa = x2[i];
+        if (zd) da = zd2[i];
+    }
     // `done_seen`, not `done`: workgroup 0 of THIS launch sets `done`, and a workgroup dispatched after that must still
     // apply x += alpha p for its rows (cg.py:79 precedes the test of cg.py:86).
     EarlyPartials<kVecPartSlots> ep;                                    // as in K2: one exposed round trip at the head
@@ -257,28 +241,30 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
         const double rr = reduce_partials(part_rr, n_part, sh);
         if (threadIdx.x == 0) record_and_test(sc, rr, rz_new, hist, hist_cap, sc->k + 1);
     }
-    for (int64_t base = i0; base < n2; base += kVecBatch * stride) {
-        if (base != i0) fetch(base);
-#pragma unroll
-        for (int u = 0; u < kVecBatch; ++u) {
-            const int64_t cur = base + u * stride;
-            if (cur < n2) {
-                double2 zc = za[u];
-                const double2 pc = pa[u], xc = xa[u], dc = da[u];
-                if (zd) {                                               // z = dinv * r, recomputed (cg.py:81)
-                    zc.x = dc.x * zc.x;
-                    zc.y = dc.y * zc.y;
-                }
-                double2 xn, pn;
-                xn.x = xc.x + alpha * pc.x;                             // cg.py:79
-                xn.y = xc.y + alpha * pc.y;
-                pn.x = zc.x + beta * pc.x;                              // cg.py:83
-                pn.y = zc.y + beta * pc.y;
-                x2[cur] = xn;
-                p2[cur] = pn;
-                if (P32) f2[cur] = make_float2((float)pn.x, (float)pn.y);
-            }
+    while (have) {
+        const int64_t cur = i;
+        double2 zc = za;
+        const double2 pc = pa, xc = xa, dc = da;
+        i += stride;
+        have = i < n2;
+        if (have) {
+            za = z2[i];
+            pa = p2[i];
+            xa = x2[i];
+            if (zd) da = zd2[i];
         }
+        if (zd) {                                                       // z = dinv * r, recomputed (cg.py:81)
+            zc.x = dc.x * zc.x;
+            zc.y = dc.y * zc.y;
+        }
+        double2 xn, pn;
+        xn.x = xc.x + alpha * pc.x;                                     // cg.py:79
+        xn.y = xc.y + alpha * pc.y;
+        pn.x = zc.x + beta * pc.x;                                      // cg.py:83
+        pn.y = zc.y + beta * pc.y;
+        x2[cur] = xn;
+        p2[cur] = pn;
+        if (P32) f2[cur] = make_float2((float)pn.x, (float)pn.y);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t e = n - 1;
@@ -317,30 +303,24 @@ __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalar
     __shared__ double sh[4];
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const double2 *__restrict__ z2 = reinterpret_cast<const double2 *>(z);
     const double2 *pi2 = reinterpret_cast<const double2 *>(p_in);
     double2 *po2 = reinterpret_cast<double2 *>(p_out);          // ODD: holds p of the previous update until overwritten
     double2 *__restrict__ x2 = reinterpret_cast<double2 *>(x);
     float2 *__restrict__ f2 = reinterpret_cast<float2 *>(p32);
     const double2 *__restrict__ zd2 = reinterpret_cast<const double2 *>(zd);
-    double2 za[kVecBatch], pa[kVecBatch], qa[ODD ? kVecBatch : 1], xa[ODD ? kVecBatch : 1], da[kVecBatch];   // see k_update_r
-    const int64_t last = n2 > 0 ? n2 - 1 : 0;
-    auto fetch = [&](int64_t base) {
-#pragma unroll
-        for (int u = 0; u < kVecBatch; ++u) {
-            const int64_t idx = base + u * stride;
-            const int64_t ic = idx < n2 ? idx : last;
-            za[u] = z2[ic];
-            pa[u] = pi2[ic];
-            if (ODD) {
-                qa[u] = po2[ic];
-                xa[u] = x2[ic];
-            }
-            da[u] = zd ? zd2[ic] : make_double2(0.0, 0.0);
+    double2 za = make_double2(0, 0), pa = za, qa = za, xa = za, da = za;
+    bool have = i < n2;
+    if (have) {
+        za = z2[i];
+        pa = pi2[i];
+        if (ODD) {
+            qa = po2[i];
+            xa = x2[i];
         }
-    };
-    if (n2 > 0) fetch(i0);
+        if (zd) da = zd2[i];
+    }
     EarlyPartials<kVecPartSlots> ep;                                    // as in K2: one exposed round trip at the head
     ep.request(part_rz, n_part);
     const int done_seen = sc->done_seen;                                // see k_update_xp: never `done` here
@@ -360,34 +340,38 @@ __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalar
             record_and_test(sc, rr, rz_new, hist, hist_cap, sc->k + 1);
         }
     }
-    for (int64_t base = i0; base < n2; base += kVecBatch * stride) {
-        if (base != i0) fetch(base);
-#pragma unroll
-        for (int u = 0; u < kVecBatch; ++u) {
-            const int64_t cur = base + u * stride;
-            if (cur < n2) {
-                double2 zc = za[u];
-                const double2 pc = pa[u], dc = da[u];
-                if (zd) {                                               // z = dinv * r, recomputed (cg.py:81)
-                    zc.x = dc.x * zc.x;
-                    zc.y = dc.y * zc.y;
-                }
-                if (ODD) {
-                    const double2 qc = qa[u], xc = xa[u];
-                    double2 xn;
-                    xn.x = xc.x + alpha_prev * qc.x;                    // cg.py:79 of the previous update ...
-                    xn.y = xc.y + alpha_prev * qc.y;
-                    xn.x = xn.x + alpha * pc.x;                         // ... and of this one
-                    xn.y = xn.y + alpha * pc.y;
-                    x2[cur] = xn;
-                }
-                double2 pn;
-                pn.x = zc.x + beta * pc.x;                              // cg.py:83
-                pn.y = zc.y + beta * pc.y;
-                po2[cur] = pn;
-                if (P32) f2[cur] = make_float2((float)pn.x, (float)pn.y);
+    while (have) {
+        const int64_t cur = i;
+        double2 zc = za;
+        const double2 pc = pa, qc = qa, xc = xa, dc = da;
+        i += stride;
+        have = i < n2;
+        if (have) {
+            za = z2[i];
+            pa = pi2[i];
+            if (ODD) {
+                qa = po2[i];
+                xa = x2[i];
             }
+            if (zd) da = zd2[i];
         }
+        if (zd) {                                                       // z = dinv * r, recomputed (cg.py:81)
+            zc.x = dc.x * zc.x;
+            zc.y = dc.y * zc.y;
+        }
+        if (ODD) {
+            double2 xn;
+            xn.x = xc.x + alpha_prev * qc.x;                            // cg.py:79 of the previous update ...
+            xn.y = xc.y + alpha_prev * qc.y;
+            xn.x = xn.x + alpha * pc.x;                                 // ... and of this one
+            xn.y = xn.y + alpha * pc.y;
+            x2[cur] = xn;
+        }
+        double2 pn;
+        pn.x = zc.x + beta * pc.x;                                      // cg.py:83
+        pn.y = zc.y + beta * pc.y;
+        po2[cur] = pn;
+        if (P32) f2[cur] = make_float2((float)pn.x, (float)pn.y);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t e = n - 1;
