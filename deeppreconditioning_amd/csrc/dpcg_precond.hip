@@ -289,34 +289,62 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
     // ring -- goes to the sync-free multi-workgroup kernel, neighbouring such segments as ONE launch.  A single level on
     // its own keeps the plain level kernel (nothing inside it to wait for).
     if (syncfree_enabled()) {
-        std::vector<Levels::Segment> merged_segs;
+        // Classes of segments: RING (a run of narrow levels the pipelined LDS-ring kernel can walk: reach inside the ring,
+        // levels <= 1024 rows, LDS fits), NARROW (any other run whose levels average <= kSyncfreeMaxMeanWidth rows: one
+        // sync-free launch) and WIDE (one launch per level, on records).  The old one-level-ahead ring walk
+        // (k_sptrsv_ring) is no longer chosen: on the 6-level tail of the scrambled 1M-DoF factor it took 45 us of a
+        // 205 us solve.  Neighbouring segments of the same class merge; NARROW and WIDE runs stay apart, so that the
+        // narrow tail of a wide-level factor does not fall back to a launch per level.
+        static const int64_t kSyncfreeMaxMeanWidth = [] {
+            const char *e = getenv("DPCG_SF_MAX_MEAN_WIDTH");      // development knob
+            return e ? (int64_t)atoll(e) : (int64_t)16384;
+        }();
+        auto cls = [&](const Levels::Segment &seg) {
+            const size_t lds = (size_t)seg.ring_w * sizeof(double) + (size_t)(seg.hi - seg.lo + 24) * sizeof(int);
+            if (seg.merged && seg.ring_w > 0 && seg.max_width <= 1024 && lds <= 64 * 1024) return 0;     // RING
+            const int64_t rows_in_seg = (int64_t)level_ptr[seg.hi] - level_ptr[seg.lo];
+            return rows_in_seg / (seg.hi - seg.lo) <= kSyncfreeMaxMeanWidth ? 1 : 2;                     // NARROW : WIDE
+        };
+        // first split what the width-based pass produced into per-level pieces where it is not a ring, then re-merge by class
+        std::vector<Levels::Segment> pieces;
         for (const auto &seg : lv.segments) {
-            const bool ring = seg.merged && seg.ring_w > 0;
-            if (!ring && !merged_segs.empty() && merged_segs.back().syncfree) {
+            if (cls(seg) == 0) {
+                pieces.push_back(seg);
+                continue;
+            }
+            for (int q = seg.lo; q < seg.hi; ++q) {
+                Levels::Segment one = seg;
+                one.lo = q;
+                one.hi = q + 1;
+                one.merged = false;
+                one.ring_w = 0;
+                one.max_width = level_ptr[q + 1] - level_ptr[q];
+                pieces.push_back(one);
+            }
+        }
+        std::vector<Levels::Segment> merged_segs;
+        std::vector<int> merged_cls;
+        for (const auto &seg : pieces) {
+            const int c = cls(seg);
+            if (c != 0 && !merged_segs.empty() && merged_cls.back() == c) {
                 Levels::Segment &b = merged_segs.back();
                 b.hi = seg.hi;
                 b.max_width = std::max(b.max_width, seg.max_width);
                 continue;
             }
             merged_segs.push_back(seg);
-            if (!ring) {
-                merged_segs.back().syncfree = true;
-                merged_segs.back().merged = false;
-            }
+            merged_cls.push_back(c);
         }
-        // ... and a run of VERY wide levels stays with one launch per level too: there the bodies, not the boundaries,
-        // are the cost, and the level kernels' gathers may use the L1 / L2 where the polling loads of the sync-free
-        // kernel bypass them (measured, scrambled 1M-DoF factor, 19 levels of ~52K rows: 313 vs 372 us per apply; natural
-        // 100^3 factor, 298 levels of <= 7.5K rows: 2457 vs 1555 us)
-        static const int64_t kSyncfreeMaxMeanWidth = [] {
-            const char *e = getenv("DPCG_SF_MAX_MEAN_WIDTH");      // development knob
-            return e ? (int64_t)atoll(e) : (int64_t)16384;
-        }();
-        for (auto &seg : merged_segs) {
-            const int64_t rows_in_seg = (int64_t)level_ptr[seg.hi] - level_ptr[seg.lo];
-            if (seg.syncfree && (seg.hi - seg.lo < 2 || rows_in_seg / (seg.hi - seg.lo) > kSyncfreeMaxMeanWidth)) seg.syncfree = false;
+        for (size_t q = 0; q < merged_segs.size(); ++q) {
+            Levels::Segment &seg = merged_segs[q];
+            if (merged_cls[q] == 0) continue;
+            seg.merged = false;
+            seg.ring_w = 0;
+            seg.syncfree = merged_cls[q] == 1 && seg.hi - seg.lo >= 2;   // a single level on its own: nothing to wait for inside
         }
         lv.segments.swap(merged_segs);
+        any_ring = false;
+        for (const auto &seg : lv.segments) any_ring = any_ring || (seg.merged && seg.ring_w > 0);
     }
     {
         const int64_t nseg = (int64_t)lv.segments.size();
@@ -325,8 +353,8 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         DPCG_HIP(hipMemsetAsync(lv.tickets, 0, (size_t)nseg * sizeof(unsigned long long), s));
         DPCG_HIP(hipMemsetAsync(lv.spin_err, 0, sizeof(int), s));
         bool any = false;
-        for (const auto &seg : lv.segments) any = any || seg.syncfree;
-        if (any) {
+        for (const auto &seg : lv.segments) any = any || !(seg.merged && seg.ring_w > 0);
+        if (any) {                                       // records for the sync-free and the per-level kernels
             DPCG_TRY(dev_alloc(&lv.sf_meta, n * 4));
             DPCG_TRY(dev_alloc(&lv.sf_val, n * 4));
             launch_sf_records(n, lv.rows, lv.lo_rowptr, lv.lo_col, lv.lo_val, upper, lv.sf_meta, lv.sf_val, s);

@@ -64,6 +64,38 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_level_stream(const int32_t *_
     }
 }
 
+// One wide level on the fixed-width records of the sync-free kernel (Levels::sf_meta / sf_val): a thread owns a row, and all
+// it needs -- three column indices, three values, the diagonal, its own index -- comes from loads addressed by the level-order
+// position alone; then the right-hand side and the (already final) solution entries are gathered.  Two dependent memory
+// round trips instead of the three of the LDS-staged kernel above (row extents -> entries -> gathers), no LDS and no
+// barrier, hence 8 workgroups per CU in flight.  Same arithmetic and order.  Rows with more than three off-diagonal
+// entries (meta.x == -2) walk the level-ordered copy.
+template <bool UPPER>
+__global__ __launch_bounds__(kBlock) void k_sptrsv_level_rec(int j0, int count, const int32_t *__restrict__ lo_rp,
+                                                             const int32_t *__restrict__ lo_ci,
+                                                             const double *__restrict__ lo_v, const int4 *__restrict__ meta,
+                                                             const double2 *__restrict__ val,
+                                                             const double *__restrict__ rhs, double *out, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= count) return;
+    const int j = j0 + idx;
+    const int4 m = meta[j];
+    const double2 v01 = val[2 * (int64_t)j], v2d = val[2 * (int64_t)j + 1];
+    double acc = rhs[m.w];
+    if (m.x == -2) {
+        const int s = lo_rp[j], e = lo_rp[j + 1];
+        const int ks = UPPER ? s + 1 : s, ke = UPPER ? e : e - 1;
+        for (int k = ks; k < ke; ++k) acc -= lo_v[k] * out[lo_ci[k]];
+    } else {
+        const double y0 = out[m.x < 0 ? m.w : m.x], y1 = out[m.y < 0 ? m.w : m.y], y2 = out[m.z < 0 ? m.w : m.z];
+        if (m.x >= 0) acc -= v01.x * y0;
+        if (m.y >= 0) acc -= v01.y * y1;
+        if (m.z >= 0) acc -= v2d.x * y2;
+    }
+    out[m.w] = acc / v2d.y;
+}
+
 // One level, one thread per row (rows too long for the LDS product buffer).
 template <bool UPPER>
 __global__ __launch_bounds__(kBlock) void k_sptrsv_level(const int32_t *__restrict__ rows, int j0, int count,
@@ -634,6 +666,10 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
 }
 
 constexpr int kRingChunk = 6;   // levels per prefetch chunk of k_sptrsv_ring_pipe (3 with two rows per thread)
+static bool level_rec_disabled() {   // DPCG_LEVEL_REC=0: the LDS-staged level kernel instead of the record one (A/B)
+    static const bool off = [] { const char *e = getenv("DPCG_LEVEL_REC"); return e && e[0] == '0'; }();
+    return off;
+}
 static bool ring_pipe_disabled() {
     static const bool off = [] { const char *e = getenv("DPCG_RING_PIPE"); return e && e[0] == '0'; }();
     return off;
@@ -759,7 +795,14 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
             const int grid = (cnt + kBlock - 1) / kBlock;
 #define DPCG_TRSV(KERNEL, UP) \
     hipLaunchKernelGGL(KERNEL<UP>, dim3(grid), dim3(kBlock), 0, s, lv.rows, j0, cnt, lv.lo_rowptr, lv.lo_col, lv.lo_val, rhs, out, done)
-            if (lv.stream_ok) {
+            if (lv.sf_meta && !level_rec_disabled()) {
+                if (upper)
+                    hipLaunchKernelGGL(k_sptrsv_level_rec<true>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_col,
+                                       lv.lo_val, (const int4 *)lv.sf_meta, (const double2 *)lv.sf_val, rhs, out, done);
+                else
+                    hipLaunchKernelGGL(k_sptrsv_level_rec<false>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_col,
+                                       lv.lo_val, (const int4 *)lv.sf_meta, (const double2 *)lv.sf_val, rhs, out, done);
+            } else if (lv.stream_ok) {
                 if (upper) DPCG_TRSV(k_sptrsv_level_stream, true);
                 else DPCG_TRSV(k_sptrsv_level_stream, false);
             } else {
