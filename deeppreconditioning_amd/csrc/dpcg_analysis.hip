@@ -61,6 +61,27 @@ void launch_iota(int64_t count, int32_t *out, hipStream_t s) {
     hipLaunchKernelGGL(k_iota, dim3(grid_rows(count)), dim3(kBlock), 0, s, count, out);
 }
 
+// key64[i] = level[i] << 32 | (order_by ? order_by[i] : i): rows sorted by it are grouped by level and, inside a level, ordered
+// by `order_by` (the handle's numbering on a reordered handle: the solve kernels then touch r / z in ascending addresses)
+__global__ __launch_bounds__(kBlock) void k_level_keys(int64_t n, const int32_t *__restrict__ level,
+                                                       const int32_t *__restrict__ order_by, uint64_t *__restrict__ key) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        key[i] = ((uint64_t)(uint32_t)level[i] << 32) | (uint32_t)(order_by ? order_by[i] : (int32_t)i);
+}
+
+__global__ __launch_bounds__(kBlock) void k_key_levels(int64_t n, const uint64_t *__restrict__ key, uint32_t *__restrict__ lvl) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) lvl[i] = (uint32_t)(key[i] >> 32);
+}
+
+void launch_level_keys(int64_t n, const int32_t *level, const int32_t *order_by, uint64_t *key, hipStream_t s) {
+    hipLaunchKernelGGL(k_level_keys, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, level, order_by, key);
+}
+void launch_key_levels(int64_t n, const uint64_t *key_sorted, uint32_t *lvl, hipStream_t s) {
+    hipLaunchKernelGGL(k_key_levels, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, key_sorted, lvl);
+}
+
 // Offsets of the groups of a SORTED key array: ptr[g] = first position with key >= g, for g = 0..groups (ptr[groups] =
 // count).  Empty groups get the offset of the next non-empty one.
 __global__ __launch_bounds__(kBlock) void k_group_offsets(int64_t count, const uint32_t *__restrict__ keys, int groups,

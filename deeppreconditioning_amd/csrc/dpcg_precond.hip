@@ -142,7 +142,12 @@ struct LevelSort {
     std::vector<int32_t> level_ptr;
 };
 
-int compute_levels(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, LevelSort &out, hipStream_t s) {
+// `order_by` (may be null): inside a level the rows are ordered by order_by[row] instead of by row.  On a reordered handle that
+// is the handle's (RCM) numbering: rows of a level are independent, so any order gives the same bits, and in this one the
+// solve kernels read r, write z and gather their entries at ascending, clustered addresses instead of all over the vector
+// (the caller's numbering is the scattered one -- that is why the handle was reordered).
+int compute_levels(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, LevelSort &out, hipStream_t s,
+                   const int32_t *order_by = nullptr) {
     DevBuf<int32_t> level, iota, ctl;
     DPCG_TRY(level.alloc(n));
     DPCG_TRY(iota.alloc(n));
@@ -164,9 +169,18 @@ int compute_levels(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, 
     DPCG_TRY(out.lvl_of_pos.alloc(n));
     DPCG_TRY(out.level_ptr_dev.alloc((int64_t)nl + 1));
     launch_iota(n, iota.p, s);
-    // stable: rows stay ascending inside a level
-    DPCG_TRY(sort_pairs_u32_i32(reinterpret_cast<const uint32_t *>(level.p), out.lvl_of_pos.p, iota.p, out.rows.p, n,
-                                bits_for((uint64_t)h_ctl[2]), s));
+    if (order_by) {
+        DevBuf<uint64_t> key, key_sorted;
+        DPCG_TRY(key.alloc(n));
+        DPCG_TRY(key_sorted.alloc(n));
+        launch_level_keys(n, level.p, order_by, key.p, s);
+        DPCG_TRY(sort_pairs_u64_i32(key.p, key_sorted.p, iota.p, out.rows.p, n, 32 + bits_for((uint64_t)h_ctl[2]), s));
+        launch_key_levels(n, key_sorted.p, out.lvl_of_pos.p, s);
+    } else {
+        // stable: rows stay ascending inside a level
+        DPCG_TRY(sort_pairs_u32_i32(reinterpret_cast<const uint32_t *>(level.p), out.lvl_of_pos.p, iota.p, out.rows.p, n,
+                                    bits_for((uint64_t)h_ctl[2]), s));
+    }
     launch_group_offsets(n, out.lvl_of_pos.p, nl, out.level_ptr_dev.p, s);
     out.level_ptr.resize((size_t)nl + 1);
     DPCG_HIP(hipMemcpyAsync(out.level_ptr.data(), out.level_ptr_dev.p, out.level_ptr.size() * sizeof(int32_t),
@@ -559,7 +573,7 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
     if (mode == DPCG_PRECOND_LLT_SOLVE) {
         LevelSort own, up;
         if (!lower_levels) {
-            DPCG_TRY(compute_levels(n, h->L.rowptr, h->L.col, false, own, s));
+            DPCG_TRY(compute_levels(n, h->L.rowptr, h->L.col, false, own, s, h->iperm));
             lower_levels = &own;
             pt.mark("levels(L)");
         }
@@ -592,7 +606,7 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
             if (h->lvlU.strips.n_strips == 0) dev_free(h->lvlU.spin_err);
         }
         if (h->lvlU.strips.n_strips == 0) {
-            DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s));
+            DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s, h->iperm));
             pt.mark("levels(L^T)");
             DPCG_TRY(schedule(h->lvlU, up, h->Lt, true));
         }
@@ -658,7 +672,7 @@ extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t str
     launch_tril_copy(n, Asrc.rowptr, Asrc.col, Asrc.val, Lf.rowptr, Lf.col, Lf.val, s);
     pt.mark("tril(A)");
     LevelSort ls;
-    if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, ls, s)) < 0) return fail(st);
+    if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, ls, s, h->iperm)) < 0) return fail(st);
     pt.mark("levels(tril A)");
     if ((st = numeric_incomplete_cholesky(ls, n, Lf, reinterpret_cast<int *>(flags.p) + 1, nullptr, 0.0, s)) < 0) return fail(st);
     e = hipGetLastError();
