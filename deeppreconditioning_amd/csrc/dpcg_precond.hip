@@ -445,12 +445,17 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
     if (h_ctl[1] || h_ctl[2] < 0) return DPCG_OK;            // (cannot happen: the global analysis succeeded)
     const int nlev = h_ctl[2] + 1;
     if ((int64_t)S * nlev > (int64_t)1 << 24) return DPCG_OK;
-    Levels::Strips sp;
-    auto drop = [&]() {
-        dev_free(sp.rows); dev_free(sp.level_ptr_dev); dev_free(sp.lo_rowptr); dev_free(sp.lo_col); dev_free(sp.lo_cpos);
-        dev_free(sp.lo_val); dev_free(sp.val); dev_free(sp.b_lo); dev_free(sp.meta); dev_free(sp.ticket);
-        return DPCG_OK;
-    };
+    struct Pending {                                          // the plan under construction: released unless it is kept
+        Levels::Strips sp;
+        bool keep = false;
+        ~Pending() {
+            if (keep) return;
+            dev_free(sp.rows); dev_free(sp.level_ptr_dev); dev_free(sp.lo_rowptr); dev_free(sp.lo_col); dev_free(sp.lo_cpos);
+            dev_free(sp.lo_val); dev_free(sp.val); dev_free(sp.b_lo); dev_free(sp.meta); dev_free(sp.ticket);
+        }
+    } pending;
+    Levels::Strips &sp = pending.sp;
+    auto drop = [&]() { return DPCG_OK; };                    // (~Pending frees)
     DPCG_TRY(dev_alloc(&sp.rows, n));
     DPCG_TRY(dev_alloc(&sp.level_ptr_dev, S * nlev + 1));
     launch_strip_keys(n, level.p, strip_rows, nlev, upper, key.p, s);
@@ -504,6 +509,7 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
     sp.threads = ((width + sp.rows_per_thread - 1) / sp.rows_per_thread + 63) / 64 * 64;
     sp.threads = sp.threads < 64 ? 64 : sp.threads;
     lv.strips = sp;
+    pending.keep = true;
     init_strip_kernels();
     // the global level schedule's big arrays are not used when the strip plan is: give the memory back
     dev_free(lv.lo_rowptr); dev_free(lv.lo_col); dev_free(lv.lo_cpos); dev_free(lv.lo_val);
