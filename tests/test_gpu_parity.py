@@ -1424,3 +1424,30 @@ def test_config2_cnn_emitted_factor_at_full_size(D):
     r_true = bh - A @ res.x.cpu().numpy()
     assert np.dot(r_true, r_true) / np.dot(bh, bh) < 1.5e-8
     S.close()
+
+
+def test_two_ranks_share_one_gpu_real_matrices():
+    """The N > 1 data path with the REAL solver: two ranks (gloo; a gpurun box has one GPU, both ranks use it) run
+    `solve_systems_distributed` -- rank 0's five file-like systems are scattered as CSR arrays, each rank solves its share on the
+    GPU (systems 0, 2, 4 and 1, 3), records and solutions are gathered: iteration counts equal the oracle's and every gathered x
+    is bit-identical to a direct solve."""
+    import json
+    import pathlib
+    import socket
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {**__import__("os").environ, "PYTHONPATH": str(root)}
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                           "127.0.0.1", "--master-port", str(port), str(root / "tests" / "gloo_world2_gpu_child.py")],
+                          capture_output=True, text=True, cwd=root, env=env, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    out = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["world"] == 2 and out["x_equal_to_direct_solve"] == [True] * 5
+    mats = [O.poisson2d(30), O.unstructured_like(O.poisson3d(10), seed=1), O.poisson2d(45), O.poisson3d(9),
+            O.unstructured_like(O.poisson2d(33), seed=2)]
+    for i, (A, rec) in enumerate(zip(mats, out["table"])):
+        assert int(rec[0]) == CO.pcg(A, O.rhs(A.shape[0], i), "jacobi", dinv=O.jacobi_dinv(A))[1] and int(rec[1]) == 0
