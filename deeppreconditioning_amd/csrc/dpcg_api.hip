@@ -390,7 +390,8 @@ FuseArgs fuse_args(dpcg_system *h) {
     fa.xvec = h->x;
     fa.part_rz = h->part_rz;
     fa.part_rr = h->part_rr;
-    fa.n_part = h->vec_grid;
+    fa.n_part = rz_partial_count(h);
+    fa.n_part_rr = h->vec_grid;
     fa.hist = h->hist;
     fa.hist_cap = h->hist_cap;
     return fa;
@@ -419,8 +420,8 @@ int ensure_work(dpcg_system *h, int max_iter, bool need_f32, bool need_err) {
         DPCG_TRY(dev_alloc(&h->q, n));
         DPCG_TRY(dev_alloc(&h->t, n));
         DPCG_TRY(dev_alloc(&h->part_pq, kMaxSpmvGrid));
-        DPCG_TRY(dev_alloc(&h->part_rz, kMaxGrid));
-        DPCG_TRY(dev_alloc(&h->part_rr, kMaxGrid));
+        DPCG_TRY(dev_alloc(&h->part_rz, kMaxSpmvGrid));   // an M-apply's SpMV may leave up to its grid's worth of <r,z> partials
+        DPCG_TRY(dev_alloc(&h->part_rr, kMaxSpmvGrid));
         DPCG_TRY(dev_alloc(&h->part_bb, kMaxSpmvGrid));
     }
     if (need_err && !h->e) DPCG_TRY(dev_alloc(&h->e, n));
@@ -494,7 +495,14 @@ extern "C" int dpcg_spmv_f32(dpcg_handle_t h, const float *x, float *y, dpcg_str
 }
 
 // z = M r for the handle's preconditioner (cg.py:61,81).  `t` is the handle's scratch vector.
-int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, bool in_loop) {
+int rz_partial_count(const dpcg_system *h) {
+    if (h->precond == DPCG_PRECOND_CSR) return h->planM.grid;
+    if (h->precond == DPCG_PRECOND_LLT_MULTIPLY) return h->planL.grid;
+    return h->vec_grid;
+}
+
+int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, bool in_loop, double *part_rz, int *n_part_rz) {
+    if (n_part_rz) *n_part_rz = 0;
     switch (h->precond) {
         case DPCG_PRECOND_NONE:
             if (z != r) DPCG_HIP(hipMemcpyAsync(z, r, (size_t)h->A.n * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -502,12 +510,22 @@ int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, boo
         case DPCG_PRECOND_JACOBI:
             launch_scale(h->A.n, h->dinv, r, z, h->vec_grid, s);
             break;
-        case DPCG_PRECOND_CSR:
-            launch_spmv(h->M, h->planM, r, z, nullptr, nullptr, s);
+        case DPCG_PRECOND_CSR:                 // the SpMV sums <r, M r> on the way when asked to
+            if (part_rz && n_part_rz) {
+                launch_spmv_xdot(h->M, h->planM, r, r, z, part_rz, s);
+                *n_part_rz = h->planM.grid;
+            } else {
+                launch_spmv(h->M, h->planM, r, z, nullptr, nullptr, s);
+            }
             break;
         case DPCG_PRECOND_LLT_MULTIPLY:       // on a reordered handle the SpMVs read P L^T P^T and P L P^T
             launch_spmv(h->perm ? h->Ltp : h->Lt, h->planLt, r, h->t, nullptr, nullptr, s);
-            launch_spmv(h->perm ? h->Lp : h->L, h->planL, h->t, z, nullptr, nullptr, s);
+            if (part_rz && n_part_rz) {
+                launch_spmv_xdot(h->perm ? h->Lp : h->L, h->planL, h->t, r, z, part_rz, s);
+                *n_part_rz = h->planL.grid;
+            } else {
+                launch_spmv(h->perm ? h->Lp : h->L, h->planL, h->t, z, nullptr, nullptr, s);
+            }
             break;
         case DPCG_PRECOND_CALLBACK:
             if (h->perm) {                        // the caller's function sees the caller's numbering; t and q (dead
@@ -606,7 +624,7 @@ extern "C" int dpcg_spmv_dot_bench(dpcg_handle_t h, const double *x, double *y, 
         }
         DPCG_HIP(hipMemsetAsync(h->p2, 0, (size_t)h->A.n * sizeof(double), s));
         DPCG_HIP(hipMemsetAsync(h->x, 0, (size_t)h->A.n * sizeof(double), s));
-        DPCG_HIP(hipMemsetAsync(h->part_rz, 0, kMaxGrid * sizeof(double), s));
+        DPCG_HIP(hipMemsetAsync(h->part_rz, 0, kMaxSpmvGrid * sizeof(double), s));
         launch_fused_init(h->scal, s);
         fa = fuse_args(h);
         fa.z = x;

@@ -154,10 +154,8 @@ __device__ __forceinline__ bool fused_head(Scalars *sc, const FuseArgs &f, doubl
     if (sc->done) return false;
     const int k = sc->k;                                   // updates completed (written by KB / the initial state)
     double rz = 0.0, rr = 0.0;
-    for (int i = threadIdx.x; i < f.n_part; i += kBlock) {
-        rz += f.part_rz[i];
-        rr += f.part_rr[i];
-    }
+    for (int i = threadIdx.x; i < f.n_part; i += kBlock) rz += f.part_rz[i];
+    for (int i = threadIdx.x; i < f.n_part_rr; i += kBlock) rr += f.part_rr[i];
     block_sum2(rz, rr, sh);                                // the arithmetic of reduce_partials, twice
     alpha = sc->alpha;
     beta = rz / sc->rz_prev;                               // cg.py:82

@@ -206,7 +206,8 @@ struct FuseArgs {
     double *xvec;             // the iterate, one update behind
     const double *part_rz;    // partials of <r,z> and <r,r> of the current iterate (K2 or the initial state)
     const double *part_rr;
-    int n_part;
+    int n_part;               // partials of <r,z>: vec_grid, or the grid of the SpMV that applied M and summed <r,z> on the way
+    int n_part_rr;            // partials of <r,r> (always KB's: vec_grid)
     double *hist;
     int hist_cap;
 };
@@ -216,13 +217,16 @@ void launch_fused_init(Scalars *scal, hipStream_t s);
 // K3 with the x update deferred to every second update (see k_update_xp_deferred); `odd`: this is update 1, 3, 5, ...
 void launch_update_xp_deferred(bool odd, int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
                                const double *z, const double *p_in, double *p_out, double *x, float *p32, double *hist,
-                               int hist_cap, int grid, hipStream_t s, const double *zd);
+                               int hist_cap, int grid, hipStream_t s, const double *zd, int n_part_rr);
 void launch_final_deferred(int64_t n, Scalars *scal, double *x, const double *p0, const double *p1, int grid,
                            hipStream_t s);
 void launch_final_fused(int64_t n, Scalars *scal, const double *part_rr, int n_part, double *hist, int hist_cap,
                         double *x, const double *p0, const double *p1, int grid, hipStream_t s);
 void launch_spmv(const CsrDev &A, const SpmvPlan &plan, const double *x, double *y, double *part_pq,
                  const IterCtl *ctl, hipStream_t s);
+// y = A x with per-workgroup partials of <xdot, y> (plan.grid of them): the last SpMV of an M-apply sums <r,z> on the way
+void launch_spmv_xdot(const CsrDev &A, const SpmvPlan &plan, const double *x, const double *xdot, double *y, double *part,
+                      hipStream_t s);
 void launch_spmv_f32in(const CsrDev &A, const SpmvPlan &plan, const float *x32, const double *x64, double *y,
                        double *part_pq, const IterCtl *ctl, hipStream_t s);
 // fp32-stored values, fp64 x and arithmetic (exact when the values are fp32-representable)
@@ -242,14 +246,16 @@ void launch_dot_partials(int64_t n, const Scalars *scal, const double *a, const 
                          hipStream_t s);
 void launch_update_xp(int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
                       const double *z, double *p, double *x, float *p32, double *hist, int hist_cap, int grid,
-                      hipStream_t s, const double *zd = nullptr);   // zd: z is not stored, K3 forms zd .* z itself
+                      hipStream_t s, const double *zd, int n_part_rr);   // zd: z is not stored, K3 forms zd .* z itself
 void launch_final_check(Scalars *scal, hipStream_t s);
 void launch_init_state(int64_t n, Scalars *scal, const double *b, const double *r, const double *z, double *p,
                        float *p32, double *part_bb, double *part_rz, double *part_rr, int init_check_r, int grid,
                        hipStream_t s);
-void launch_finalize_init(Scalars *scal, const double *part_bb, const double *part_rz, const double *part_t,
+// part_rz / part_t are left in canonical form (entry 0 = the sum, entries 1 .. canon_cap-1 = 0), so that the first KA may
+// read them with whatever partial count the later updates use
+void launch_finalize_init(Scalars *scal, const double *part_bb, double *part_rz, double *part_t,
                           int n_part, double rtol_sq, double atol_sq, double *hist, int hist_cap,
-                          unsigned long long *progress, hipStream_t s);
+                          unsigned long long *progress, hipStream_t s, int canon_cap = 0);
 void launch_residual(int64_t n, const double *b, const double *ax, double *r, int grid, hipStream_t s);
 void launch_scale(int64_t n, const double *dinv, const double *r, double *z, int grid, hipStream_t s);
 void launch_extract_dinv(const CsrDev &A, double *dinv, int *bad_flag, hipStream_t s);

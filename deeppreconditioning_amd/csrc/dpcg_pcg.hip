@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
                                                       const double *__restrict__ z, double *__restrict__ p,
                                                       double *__restrict__ x, float *__restrict__ p32,
                                                       double *__restrict__ hist, int hist_cap,
-                                                      const double *__restrict__ zd) {
+                                                      const double *__restrict__ zd, int n_part_rr) {
     __shared__ double sh[4];
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -227,18 +227,21 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
     }
     // `done_seen`, not `done`: workgroup 0 of THIS launch sets `done`, and a workgroup dispatched after that must still
     // apply x += alpha p for its rows (cg.py:79 precedes the test of cg.py:86).
-    EarlyPartials<kVecPartSlots> ep;                                    // as in K2: one exposed round trip at the head
-    ep.request(part_rz, n_part);
+    // as in K2: one exposed round trip at the head (more than kVecPartSlots * kBlock partials -- an M-apply's SpMV summed
+    // <r,z> -- take the loop form)
+    const bool many = n_part > kVecPartSlots * kBlock;
+    EarlyPartials<kVecPartSlots> ep;
+    ep.request(part_rz, many ? 1 : n_part);
     const int done_seen = sc->done_seen;
     double rz_old = sc->rz, alpha = sc->alpha;
     pin_scalar(rz_old);
     pin_scalar(alpha);
     ep.land();
     if (done_seen) return;
-    const double rz_new = ep.reduce(n_part, sh);
+    const double rz_new = many ? reduce_partials(part_rz, n_part, sh) : ep.reduce(n_part, sh);
     const double beta = rz_new / rz_old;                                // cg.py:82
     if (blockIdx.x == 0) {                                              // cg.py:86 + the test of cg.py:71
-        const double rr = reduce_partials(part_rr, n_part, sh);
+        const double rr = reduce_partials(part_rr, n_part_rr, sh);
         if (threadIdx.x == 0) record_and_test(sc, rr, rz_new, hist, hist_cap, sc->k + 1);
     }
     while (have) {
@@ -278,13 +281,13 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
 
 void launch_update_xp(int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
                       const double *z, double *p, double *x, float *p32, double *hist, int hist_cap, int grid,
-                      hipStream_t s, const double *zd) {
+                      hipStream_t s, const double *zd, int n_part_rr) {
     if (p32)
         hipLaunchKernelGGL(k_update_xp<true>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, part_rr, n_part, z, p,
-                           x, p32, hist, hist_cap, zd);
+                           x, p32, hist, hist_cap, zd, n_part_rr);
     else
         hipLaunchKernelGGL(k_update_xp<false>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, part_rr, n_part, z, p,
-                           x, p32, hist, hist_cap, zd);
+                           x, p32, hist, hist_cap, zd, n_part_rr);
 }
 
 // K3 with the x update deferred.  x is only an output, and every write costs more than a read here, so x is brought
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalar
                                                                const double *__restrict__ z, const double *p_in,
                                                                double *p_out, double *__restrict__ x,
                                                                float *__restrict__ p32, double *__restrict__ hist,
-                                                               int hist_cap, const double *__restrict__ zd) {
+                                                               int hist_cap, const double *__restrict__ zd, int n_part_rr) {
     __shared__ double sh[4];
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -321,8 +324,9 @@ __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalar
         }
         if (zd) da = zd2[i];
     }
+    const bool many = n_part > kVecPartSlots * kBlock;                  // see k_update_xp
     EarlyPartials<kVecPartSlots> ep;                                    // as in K2: one exposed round trip at the head
-    ep.request(part_rz, n_part);
+    ep.request(part_rz, many ? 1 : n_part);
     const int done_seen = sc->done_seen;                                // see k_update_xp: never `done` here
     double rz_old = sc->rz, alpha = sc->alpha;
     double alpha_prev = ODD ? sc->alpha_prev : 0.0;                     // written by the even update before this one
@@ -331,10 +335,10 @@ __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalar
     pin_scalar(alpha_prev);
     ep.land();
     if (done_seen) return;
-    const double rz_new = ep.reduce(n_part, sh);
+    const double rz_new = many ? reduce_partials(part_rz, n_part, sh) : ep.reduce(n_part, sh);
     const double beta = rz_new / rz_old;                                // cg.py:82
     if (blockIdx.x == 0) {                                              // cg.py:86 + the test of cg.py:71
-        const double rr = reduce_partials(part_rr, n_part, sh);
+        const double rr = reduce_partials(part_rr, n_part_rr, sh);
         if (threadIdx.x == 0) {
             if (!ODD) sc->alpha_prev = alpha;                           // read by the next (odd) update only
             record_and_test(sc, rr, rz_new, hist, hist_cap, sc->k + 1);
@@ -388,10 +392,10 @@ __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalar
 
 void launch_update_xp_deferred(bool odd, int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
                                const double *z, const double *p_in, double *p_out, double *x, float *p32, double *hist,
-                               int hist_cap, int grid, hipStream_t s, const double *zd) {
+                               int hist_cap, int grid, hipStream_t s, const double *zd, int n_part_rr) {
 #define DPCG_K3D(P32V, ODDV)                                                                                            \
     hipLaunchKernelGGL((k_update_xp_deferred<P32V, ODDV>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, part_rr, \
-                       n_part, z, p_in, p_out, x, p32, hist, hist_cap, zd)
+                       n_part, z, p_in, p_out, x, p32, hist, hist_cap, zd, n_part_rr)
     if (p32) {
         if (odd) DPCG_K3D(true, true);
         else DPCG_K3D(true, false);
@@ -477,15 +481,21 @@ void launch_init_state(int64_t n, Scalars *scal, const double *b, const double *
                            part_rr, init_check_r);
 }
 
-__global__ __launch_bounds__(kBlock) void k_finalize_init(Scalars *sc, const double *__restrict__ part_bb,
-                                                          const double *__restrict__ part_rz,
-                                                          const double *__restrict__ part_t, int n_part,
-                                                          double rtol_sq, double atol_sq, double *hist, int hist_cap,
-                                                          unsigned long long *progress) {
+__global__ __launch_bounds__(kBlock) void k_finalize_init(Scalars *sc, const double *__restrict__ part_bb, double *part_rz,
+                                                          double *part_t, int n_part, double rtol_sq, double atol_sq,
+                                                          double *hist, int hist_cap, unsigned long long *progress,
+                                                          int canon_cap) {
     __shared__ double sh[4];
     const double bb = reduce_partials(part_bb, n_part, sh);
     const double rz = reduce_partials(part_rz, n_part, sh);
     const double tt = reduce_partials(part_t, n_part, sh);             // <z0,z0> (cg.py:66) or <r0,r0>
+    // canonical form for the first KA of a two-kernel solve, which may sum a different number of partials than the
+    // initial state wrote: entry 0 = the sum (these very bits), the rest zero (x + 0.0 == x)
+    __syncthreads();
+    for (int i = threadIdx.x; i < canon_cap; i += kBlock) {
+        part_rz[i] = i == 0 ? rz : 0.0;
+        if (part_t != part_rz) part_t[i] = i == 0 ? tt : 0.0;
+    }
     if (threadIdx.x == 0) {
         sc->bb = bb;
         sc->rz = rz;
@@ -500,11 +510,11 @@ __global__ __launch_bounds__(kBlock) void k_finalize_init(Scalars *sc, const dou
     }
 }
 
-void launch_finalize_init(Scalars *scal, const double *part_bb, const double *part_rz, const double *part_t,
+void launch_finalize_init(Scalars *scal, const double *part_bb, double *part_rz, double *part_t,
                           int n_part, double rtol_sq, double atol_sq, double *hist, int hist_cap,
-                          unsigned long long *progress, hipStream_t s) {
+                          unsigned long long *progress, hipStream_t s, int canon_cap) {
     hipLaunchKernelGGL(k_finalize_init, dim3(1), dim3(kBlock), 0, s, scal, part_bb, part_rz, part_t, n_part, rtol_sq,
-                       atol_sq, hist, hist_cap, progress);
+                       atol_sq, hist, hist_cap, progress, canon_cap);
 }
 
 // r = b - A x0 (cg.py:60), ax = A x0 computed by the SpMV before.

@@ -38,8 +38,9 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
         launch_update_r_two_kernel(pre, n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->dinv, h->z, h->part_rz,
                                    h->part_rr, h->vec_grid, s);
         if (pre == 2) {
-            DPCG_TRY(apply_precond(h, h->r, h->z, s, true));                                     // cg.py:81
-            launch_dot_partials(n, h->scal, h->r, h->z, h->part_rz, h->vec_grid, s);             // cg.py:82
+            int np = 0;
+            DPCG_TRY(apply_precond(h, h->r, h->z, s, true, h->part_rz, &np));                    // cg.py:81 (+ cg.py:82 when fused)
+            if (np == 0) launch_dot_partials(n, h->scal, h->r, h->z, h->part_rz, h->vec_grid, s);   // cg.py:82
         }
         return DPCG_OK;
     }
@@ -61,18 +62,20 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
     const double *z = pre == 2 ? h->z : h->r;
     launch_update_r(pre, n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->dinv, h->z, h->part_rz, h->part_rr,
                     h->vec_grid, s, z_on_the_fly ? 0 : 1);
+    const int np_rz = pre == 2 ? rz_partial_count(h) : h->vec_grid;
     if (pre == 2) {
-        DPCG_TRY(apply_precond(h, h->r, h->z, s, true));                             // cg.py:81
-        launch_dot_partials(n, h->scal, h->r, h->z, h->part_rz, h->vec_grid, s);     // cg.py:82
+        int np = 0;
+        DPCG_TRY(apply_precond(h, h->r, h->z, s, true, h->part_rz, &np));            // cg.py:81 (+ cg.py:82 when fused)
+        if (np == 0) launch_dot_partials(n, h->scal, h->r, h->z, h->part_rz, h->vec_grid, s);   // cg.py:82
     }
     // K3: beta; x += alpha p; p = z + beta p; workgroup 0: stopping test of the new iterate   cg.py:79,82-83,86,71
     if (defer_x)
-        launch_update_xp_deferred((j & 1) != 0, n, h->scal, h->part_rz, h->part_rr, h->vec_grid, z, p_cur, p_next, h->x,
+        launch_update_xp_deferred((j & 1) != 0, n, h->scal, h->part_rz, h->part_rr, np_rz, z, p_cur, p_next, h->x,
                                   f32 ? h->p32 : nullptr, h->hist, h->hist_cap, h->vec_grid, s,
-                                  z_on_the_fly ? h->dinv : nullptr);
+                                  z_on_the_fly ? h->dinv : nullptr, h->vec_grid);
     else
-        launch_update_xp(n, h->scal, h->part_rz, h->part_rr, h->vec_grid, z, h->p, h->x, f32 ? h->p32 : nullptr, h->hist,
-                         h->hist_cap, h->vec_grid, s, z_on_the_fly ? h->dinv : nullptr);
+        launch_update_xp(n, h->scal, h->part_rz, h->part_rr, np_rz, z, h->p, h->x, f32 ? h->p32 : nullptr, h->hist,
+                         h->hist_cap, h->vec_grid, s, z_on_the_fly ? h->dinv : nullptr, h->vec_grid);
     if (x_true) {                                                                    // cg.py:43-45
         launch_anorm_err(n, h->scal, h->x, x_true, h->e, h->vec_grid, s);
         launch_spmv(h->A, h->planA, h->e, h->t, h->part_bb, nullptr, s);
@@ -250,7 +253,7 @@ struct Solve {
         launch_init_state(n, h->scal, b, h->r, z, h->p, f32 ? h->p32 : nullptr, h->part_bb, h->part_rz, h->part_rr,
                           (flags & DPCG_INIT_CHECK_R) ? 1 : 0, h->vec_grid, s);
         launch_finalize_init(h->scal, h->part_bb, h->part_rz, h->part_rr, h->vec_grid, rtol_sq, atol_sq, h->hist,
-                             h->hist_cap, ex.prog_dev, s);
+                             h->hist_cap, ex.prog_dev, s, kMaxSpmvGrid);
         if (fused) {
             DPCG_HIP(hipMemsetAsync(h->p2, 0, (size_t)n * sizeof(double), s));       // "p_{-1}": multiplied by beta_0 = 0
             launch_fused_init(h->scal, s);

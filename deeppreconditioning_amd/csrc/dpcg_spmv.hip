@@ -480,6 +480,11 @@ void launch_spmv(const CsrDev &A, const SpmvPlan &plan, const double *x, double 
     spmv_dispatch<double, double, double>(A, plan, A.val, x, x, y, part_pq, ctl, s);
 }
 
+void launch_spmv_xdot(const CsrDev &A, const SpmvPlan &plan, const double *x, const double *xdot, double *y, double *part,
+                      hipStream_t s) {
+    spmv_dispatch<double, double, double>(A, plan, A.val, x, xdot, y, part, nullptr, s);
+}
+
 // Mixed precision (config C5): fp32 matrix values and fp32 gathered vector, fp64 products/sums.
 void launch_spmv_f32in(const CsrDev &A, const SpmvPlan &plan, const float *x32, const double *x64, double *y,
                        double *part_pq, const IterCtl *ctl, hipStream_t s) {
