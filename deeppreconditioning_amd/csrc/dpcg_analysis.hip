@@ -457,20 +457,28 @@ void launch_ring_records(int64_t n, const uint32_t *lvl_of_pos, const int32_t *r
 //   sf_meta[j] = {c0, c1, c2, row}: the (relabelled) column indices of the first three off-diagonal entries (-1 = no
 //                such entry; c0 = -2: more than three, the row walks lo_rowptr instead) and its own row index;
 //   sf_val[4j..4j+3] = {v0, v1, v2, diagonal}.
+// Factors with many longer rows (an unstructured mesh in its own numbering: up to 6 lower neighbours on a 7-point graph) take
+// the width-6 form (Levels::rec_w): 8 ints {c0..c5, row, -} and 8 doubles {v0..v5, diagonal, -} per row.
 // Addressed by position alone, so a row's data can be requested before anything about the row is known.
+template <int W>   // W = 3: meta 4 ints {c0,c1,c2,row}, val 4 doubles {v0,v1,v2,diag}; W = 6: meta 8 ints {c0..c5,row,-}, val 8 doubles {v0..v5,diag,-}
 __global__ __launch_bounds__(kBlock) void k_sf_records(int64_t n, const int32_t *__restrict__ rows,
                                                        const int32_t *__restrict__ lo_rp, const int32_t *__restrict__ lo_ci,
                                                        const double *__restrict__ lo_v, int upper, int32_t *__restrict__ meta,
                                                        double *__restrict__ pv) {
+    constexpr int S = W == 3 ? 4 : 8;                                  // record stride (ints / doubles)
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
-        int m[4] = {-1, -1, -1, -1};
-        double w[4] = {0.0, 0.0, 0.0, 0.0};
+        int m[S];
+        double w[S];
+        for (int q = 0; q < S; ++q) {
+            m[q] = -1;
+            w[q] = 0.0;
+        }
         const int a = lo_rp[j], b = lo_rp[j + 1];
         const int ks = upper ? a + 1 : a, ke = upper ? b : b - 1;      // the diagonal is first (L^T) or last (L)
-        m[3] = rows[j];
-        w[3] = lo_v[upper ? a : b - 1];
-        if (ke - ks > 3) {
+        m[W] = rows ? rows[j] : (int)j;                              // rows == null: level-major records (own position)
+        w[W] = lo_v[upper ? a : b - 1];
+        if (ke - ks > W) {
             m[0] = -2;
         } else {
             for (int k = ks; k < ke; ++k) {
@@ -478,15 +486,50 @@ __global__ __launch_bounds__(kBlock) void k_sf_records(int64_t n, const int32_t 
                 w[k - ks] = lo_v[k];
             }
         }
-        reinterpret_cast<int4 *>(meta)[j] = make_int4(m[0], m[1], m[2], m[3]);
-        reinterpret_cast<double2 *>(pv)[2 * j] = make_double2(w[0], w[1]);
-        reinterpret_cast<double2 *>(pv)[2 * j + 1] = make_double2(w[2], w[3]);
+        for (int q = 0; q < S; q += 4)
+            reinterpret_cast<int4 *>(meta)[j * (S / 4) + q / 4] = make_int4(m[q], m[q + 1], m[q + 2], m[q + 3]);
+        for (int q = 0; q < S; q += 2) reinterpret_cast<double2 *>(pv)[j * (S / 2) + q / 2] = make_double2(w[q], w[q + 1]);
     }
 }
 
+__global__ __launch_bounds__(kBlock) void k_invert_positions(int64_t n, const int32_t *__restrict__ rows, int32_t *__restrict__ pos) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) pos[rows[j]] = (int32_t)j;
+}
+
+void launch_invert_positions(int64_t n, const int32_t *rows, int32_t *pos, hipStream_t s) {
+    hipLaunchKernelGGL(k_invert_positions, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows, pos);
+}
+
+__global__ __launch_bounds__(kBlock) void k_compose_positions(int64_t n, const int32_t *__restrict__ rows,
+                                                              const int32_t *__restrict__ pos, int32_t *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) out[j] = pos[rows[j]];
+}
+
+void launch_compose_positions(int64_t n, const int32_t *rows, const int32_t *pos, int32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_compose_positions, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows, pos, out);
+}
+
 void launch_sf_records(int64_t n, const int32_t *rows, const int32_t *lo_rp, const int32_t *lo_ci, const double *lo_v,
-                       bool upper, int32_t *meta, double *pv, hipStream_t s) {
-    hipLaunchKernelGGL(k_sf_records, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows, lo_rp, lo_ci, lo_v, upper ? 1 : 0, meta, pv);
+                       bool upper, int32_t *meta, double *pv, int width, hipStream_t s) {
+    if (width == 6)
+        hipLaunchKernelGGL(k_sf_records<6>, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows, lo_rp, lo_ci, lo_v, upper ? 1 : 0, meta, pv);
+    else
+        hipLaunchKernelGGL(k_sf_records<3>, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows, lo_rp, lo_ci, lo_v, upper ? 1 : 0, meta, pv);
+}
+
+// *counter += rows of the level-ordered copy with more than `limit` off-diagonal entries (one atomic per wave)
+__global__ __launch_bounds__(kBlock) void k_count_long_rows(int64_t n, const int32_t *__restrict__ lo_rp, int limit, int *counter) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int c = 0;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) c += (lo_rp[j + 1] - lo_rp[j] - 1 > limit) ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(counter, c);
+}
+
+void launch_count_long_rows(int64_t n, const int32_t *lo_rp, int limit, int *counter, hipStream_t s) {
+    hipLaunchKernelGGL(k_count_long_rows, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, lo_rp, limit, counter);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -91,6 +91,11 @@ void free_levels(Levels &l) {
     dev_free(l.sf_val);
     dev_free(l.tickets);
     dev_free(l.spin_err);
+    dev_free(l.lm_pos);
+    dev_free(l.lm_from_lower);
+    dev_free(l.lm_rhs);
+    dev_free(l.lm_out);
+    dev_free(l.lm_chunks);
     l = Levels();
 }
 
@@ -536,10 +541,22 @@ int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, boo
                 h->precond_fn(h->precond_user, r, z, h->A.n, (dpcg_stream_t)s);
             }
             break;
-        case DPCG_PRECOND_LLT_SOLVE:
-            launch_sptrsv(h->L, h->lvlL, false, r, h->t, s, in_loop ? &h->scal->done : nullptr);
-            launch_sptrsv(h->Lt, h->lvlU, true, h->t, z, s, in_loop ? &h->scal->done : nullptr);
+        case DPCG_PRECOND_LLT_SOLVE: {
+            SptrsvIo lower_io, upper_io;
+            if (h->lvlL.level_major && h->lvlU.level_major && h->lvlU.lm_from_lower) {
+                lower_io.keep_lm = true;                   // y stays in L's level-major numbering, L^T gathers it from there
+                upper_io.lm_in = h->lvlL.lm_out;
+            }
+            if (part_rz && n_part_rz) {                    // <r,z> summed by the kernel that takes z out of level-major order
+                upper_io.dot_with = r;
+                upper_io.dot_part = part_rz;
+                upper_io.dot_grid = h->vec_grid;
+            }
+            launch_sptrsv(h->L, h->lvlL, false, r, h->t, s, in_loop ? &h->scal->done : nullptr, &lower_io);
+            launch_sptrsv(h->Lt, h->lvlU, true, h->t, z, s, in_loop ? &h->scal->done : nullptr, &upper_io);
+            if (upper_io.dot_done) *n_part_rz = h->vec_grid;
             break;
+        }
         default:
             set_error("unknown preconditioner kind");
             return DPCG_ERR_STATE;

@@ -126,6 +126,7 @@ struct Levels {
     double *b_lo = nullptr;                // scratch: the right-hand side gathered into level order
     int32_t *sf_meta = nullptr;            // records of the sync-free kernel (dpcg_analysis.hip: k_sf_records)
     double *sf_val = nullptr;
+    int rec_w = 3;                         // entries a record holds (3 or 6); longer rows walk the level-ordered copy
     // Strip-pipelined solve (k_sptrsv_strips): the rows once more, sorted by (strip, strip-local level, row), with their
     // own level offsets (n_strips * nlev + 1 entries), level-ordered factor copy and records.  n_strips == 0: not used.
     struct Strips {
@@ -137,6 +138,30 @@ struct Levels {
     } strips;
     unsigned long long *tickets = nullptr; // one monotonic block-ticket counter per segment (sync-free segments use theirs)
     int *spin_err = nullptr;               // set by a sync-free kernel whose bounded poll ran out
+    // Level-major solve (few, wide levels whose rows lie all over the vector: every level would otherwise touch every
+    // line of the right-hand side, of the solution and -- through its gathers -- of the solution again).  The solve runs
+    // in the factor's OWN level-order numbering: position j holds row rows[j]; records and the level-ordered copy address
+    // columns by position (lo_cpos), so a level reads and writes one contiguous run and gathers from the runs before it.
+    // One gather brings the right-hand side in (lm_rhs), one takes the result out (through lm_pos = the inverse of rows).
+    bool level_major = false;
+    int32_t *lm_pos = nullptr;             // handle index -> level-order position
+    int32_t *lm_from_lower = nullptr;      // L^T only: position here -> position in L's numbering (lower result feeds the upper solve)
+    double *lm_rhs = nullptr, *lm_out = nullptr;
+    // way-in pass, XCD-aware: {start, count} runs of level-order positions, eight lists of lm_chunks_per_xcd entries each;
+    // list x holds the x-th eighth of EVERY level, i.e. one eighth of the handle's index range, so the lines of the vector
+    // an XCD gathers from stay in its own L2 from level to level (workgroup b takes entry b / 8 of list b % 8)
+    int32_t *lm_chunks = nullptr;
+    int lm_chunks_per_xcd = 0;
+};
+
+// Plumbing between the two solves of one preconditioner apply (all optional)
+struct SptrsvIo {
+    const double *lm_in = nullptr;         // the right-hand side is the lm_out of the lower solve: gathered through lm_from_lower
+    bool keep_lm = false;                  // leave the result in lm_out only (the next solve picks it up there)
+    const double *dot_with = nullptr;      // on the way out, also per-workgroup partials of <dot_with, result> ...
+    double *dot_part = nullptr;            // ... into dot_part[0 .. dot_grid)
+    int dot_grid = 0;
+    bool dot_done = false;                 // set by launch_sptrsv when it did sum them
 };
 
 }  // namespace dpcg
@@ -270,7 +295,9 @@ void launch_dot_final(const double *part, int n_part, double *out_dev, hipStream
 void init_strip_kernels();
 // done: optional device flag (Scalars::done); when set the kernels return at once
 void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s,
-                   const int *done = nullptr);
+                   const int *done = nullptr, SptrsvIo *io = nullptr);
+void launch_invert_positions(int64_t n, const int32_t *rows, int32_t *pos, hipStream_t s);          // pos[rows[j]] = j
+void launch_compose_positions(int64_t n, const int32_t *rows, const int32_t *pos, int32_t *out, hipStream_t s);   // out[j] = pos[rows[j]]
 
 // Builds the x-tile plan of A on the device; *ok = 1 when every block is tileable, *max_chunks its widest tile.
 void launch_tile_plan(const CsrDev &A, int nrb, int32_t *chunks, int32_t *nchunks, uint16_t *lidx, int *ok_and_max_dev,
@@ -327,7 +354,8 @@ void launch_ring_records(int64_t n, const uint32_t *lvl_of_pos, const int32_t *r
                          const int32_t *lo_rp, const int32_t *lo_ci, const int32_t *lo_cp, const double *lo_v,
                          int32_t *meta, double *pv, hipStream_t s);
 void launch_sf_records(int64_t n, const int32_t *rows, const int32_t *lo_rp, const int32_t *lo_ci, const double *lo_v,
-                       bool upper, int32_t *meta, double *pv, hipStream_t s);
+                       bool upper, int32_t *meta, double *pv, int width, hipStream_t s);
+void launch_count_long_rows(int64_t n, const int32_t *lo_rp, int limit, int *counter, hipStream_t s);
 void launch_tril_count(int64_t n, const int32_t *rp, const int32_t *ci, int32_t *cnt, int *flag, hipStream_t s);
 void launch_tril_copy(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, const int32_t *lrp, int32_t *lci,
                       double *lv, hipStream_t s);

@@ -211,12 +211,27 @@ int numeric_incomplete_cholesky(const LevelSort &ls, int64_t n, CsrDev &F, int *
 // `relabel` (may be null): old -> new index map of a reordered handle.  The factor is the caller's; only the indices the
 // solve kernels use to address the right-hand side and the solution are mapped, so the arithmetic -- and its order --
 // is that of the factor in the caller's numbering.
+// Level-major numbering (Levels::level_major) pays when there are few, wide levels: every level then touches every line
+// of three vectors once, and the two extra passes (in, out) cost about two such levels.  DPCG_LEVEL_MAJOR=0/1: off / forced.
+static bool level_major_wanted(int64_t n, int n_levels) {
+    static const int knob = [] { const char *e = getenv("DPCG_LEVEL_MAJOR"); return e ? atoi(e) : -1; }();
+    if (knob == 0 || !syncfree_enabled()) return false;
+    if (knob == 1) return true;
+    return n >= 65536 && n_levels >= 6 && n / n_levels >= 16384;
+}
+
+static bool level_major_syncfree() {              // development knob: DPCG_LM_SYNCFREE=0 keeps one launch per wide level
+    static const bool on = [] { const char *e = getenv("DPCG_LM_SYNCFREE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_t *rp, const int32_t *ci, const double *v,
                  hipStream_t s, const int32_t *relabel = nullptr, bool upper = false) {
     constexpr int kMergeMax = 2048;  // levels this narrow are walked by one workgroup
     PhaseTimer pt(s);
     lv.level_ptr = ls.level_ptr;
     lv.n_levels = (int)ls.level_ptr.size() - 1;
+    lv.level_major = level_major_wanted(n, lv.n_levels);
     const std::vector<int32_t> &level_ptr = lv.level_ptr;
     lv.rows = ls.rows.release();
     lv.level_ptr_dev = ls.level_ptr_dev.release();
@@ -315,7 +330,9 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         }();
         auto cls = [&](const Levels::Segment &seg) {
             const size_t lds = (size_t)seg.ring_w * sizeof(double) + (size_t)(seg.hi - seg.lo + 24) * sizeof(int);
-            if (seg.merged && seg.ring_w > 0 && seg.max_width <= 1024 && lds <= 64 * 1024) return 0;     // RING
+            // (a level-major factor has no ring segments: the ring kernels address the vectors by row)
+            if (!lv.level_major && seg.merged && seg.ring_w > 0 && seg.max_width <= 1024 && lds <= 64 * 1024) return 0;   // RING
+            if (lv.level_major && level_major_syncfree()) return 1;   // level-major: the whole factor as ONE sync-free launch
             const int64_t rows_in_seg = (int64_t)level_ptr[seg.hi] - level_ptr[seg.lo];
             return rows_in_seg / (seg.hi - seg.lo) <= kSyncfreeMaxMeanWidth ? 1 : 2;                     // NARROW : WIDE
         };
@@ -369,9 +386,49 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         bool any = false;
         for (const auto &seg : lv.segments) any = any || !(seg.merged && seg.ring_w > 0);
         if (any) {                                       // records for the sync-free and the per-level kernels
-            DPCG_TRY(dev_alloc(&lv.sf_meta, n * 4));
-            DPCG_TRY(dev_alloc(&lv.sf_val, n * 4));
-            launch_sf_records(n, lv.rows, lv.lo_rowptr, lv.lo_col, lv.lo_val, upper, lv.sf_meta, lv.sf_val, s);
+            // width of the records: 3 entries unless more than 2 % of the rows are longer (they would take the slow general
+            // path: three dependent loads before the first entry, then one entry at a time)
+            DevBuf<int32_t> n_long;
+            DPCG_TRY(n_long.alloc(1));
+            DPCG_HIP(hipMemsetAsync(n_long.p, 0, sizeof(int32_t), s));
+            launch_count_long_rows(n, lv.lo_rowptr, 3, n_long.p, s);
+            int32_t h_long = 0;
+            DPCG_HIP(hipMemcpyAsync(&h_long, n_long.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            DPCG_HIP(hipStreamSynchronize(s));
+            lv.rec_w = (int64_t)h_long * 50 > n ? 6 : 3;
+            const int64_t stride = lv.rec_w == 6 ? 8 : 4;
+            DPCG_TRY(dev_alloc(&lv.sf_meta, n * stride));
+            DPCG_TRY(dev_alloc(&lv.sf_val, n * stride));
+            if (lv.level_major)
+                launch_sf_records(n, nullptr, lv.lo_rowptr, lv.lo_cpos, lv.lo_val, upper, lv.sf_meta, lv.sf_val, lv.rec_w, s);
+            else
+                launch_sf_records(n, lv.rows, lv.lo_rowptr, lv.lo_col, lv.lo_val, upper, lv.sf_meta, lv.sf_val, lv.rec_w, s);
+        }
+        if (lv.level_major) {
+            DPCG_TRY(dev_alloc(&lv.lm_pos, n));
+            DPCG_TRY(dev_alloc(&lv.lm_rhs, n));
+            DPCG_TRY(dev_alloc(&lv.lm_out, n));
+            launch_invert_positions(n, lv.rows, lv.lm_pos, s);
+            // the way-in pass's work list (see Levels::lm_chunks)
+            std::vector<std::vector<int32_t>> lists(8);
+            for (int q = 0; q < lv.n_levels; ++q) {
+                const int64_t lo = level_ptr[q], w = level_ptr[q + 1] - lo;
+                for (int x = 0; x < 8; ++x) {
+                    const int64_t a = lo + w * x / 8, b = lo + w * (x + 1) / 8;
+                    for (int64_t c = a; c < b; c += kBlock) {
+                        lists[x].push_back((int32_t)c);
+                        lists[x].push_back((int32_t)std::min<int64_t>(kBlock, b - c));
+                    }
+                }
+            }
+            size_t per = 0;
+            for (const auto &l8 : lists) per = std::max(per, l8.size() / 2);
+            std::vector<int32_t> flat(per * 16, 0);
+            for (int x = 0; x < 8; ++x) std::copy(lists[x].begin(), lists[x].end(), flat.begin() + (size_t)x * per * 2);
+            DPCG_TRY(dev_alloc(&lv.lm_chunks, (int64_t)flat.size()));
+            DPCG_HIP(hipMemcpyAsync(lv.lm_chunks, flat.data(), flat.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            DPCG_HIP(hipStreamSynchronize(s));       // `flat` is pageable host memory
+            lv.lm_chunks_per_xcd = (int)per;
         }
     }
     pt.mark("  sync-free records");
@@ -598,6 +655,7 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
             }
             DPCG_TRY(build_levels(lv, ls, n, F.nnz, F.rowptr, F.col, F.val, s, h->iperm, upper));
             if (!strips_first) DPCG_TRY(build_strips(lv, n, F.nnz, F.rowptr, F.col, F.val, upper, h->iperm, s));
+            if (lv.strips.n_strips > 0) lv.level_major = false;
             return DPCG_OK;
         };
         DPCG_TRY(schedule(h->lvlL, *lower_levels, h->L, false));
@@ -617,6 +675,11 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
             DPCG_TRY(schedule(h->lvlU, up, h->Lt, true));
         }
         pt.mark("schedule(L^T)");
+        if (h->lvlL.level_major && h->lvlU.level_major) {      // the lower result feeds the upper solve without leaving level-major order
+            DPCG_TRY(dev_alloc(&h->lvlU.lm_from_lower, n));
+            launch_compose_positions(n, h->lvlU.rows, h->lvlL.lm_pos, h->lvlU.lm_from_lower, s);
+            DPCG_CHECK_LAUNCH();
+        }
     }
     h->precond = mode;
     return DPCG_OK;

@@ -70,30 +70,58 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_level_stream(const int32_t *_
 // round trips instead of the three of the LDS-staged kernel above (row extents -> entries -> gathers), no LDS and no
 // barrier, hence 8 workgroups per CU in flight.  Same arithmetic and order.  Rows with more than three off-diagonal
 // entries (meta.x == -2) walk the level-ordered copy.
-template <bool UPPER>
+// A row's fixed-width record (Levels::sf_meta / sf_val, width W = 3 or 6) in registers.
+template <int W>
+struct SfRec {
+    int col[W];
+    int own;
+    double v[W];
+    double diag;
+};
+
+template <int W>
+__device__ __forceinline__ SfRec<W> load_sf_record(const int32_t *__restrict__ meta, const double *__restrict__ val, int64_t j) {
+    SfRec<W> r;
+    if constexpr (W == 3) {
+        const int4 m = reinterpret_cast<const int4 *>(meta)[j];
+        const double2 a = reinterpret_cast<const double2 *>(val)[2 * j], b = reinterpret_cast<const double2 *>(val)[2 * j + 1];
+        r.col[0] = m.x; r.col[1] = m.y; r.col[2] = m.z; r.own = m.w;
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.diag = b.y;
+    } else {
+        const int4 m0 = reinterpret_cast<const int4 *>(meta)[2 * j], m1 = reinterpret_cast<const int4 *>(meta)[2 * j + 1];
+        const double2 *pv = reinterpret_cast<const double2 *>(val) + 4 * j;
+        const double2 a = pv[0], b = pv[1], c = pv[2], d = pv[3];
+        r.col[0] = m0.x; r.col[1] = m0.y; r.col[2] = m0.z; r.col[3] = m0.w; r.col[4] = m1.x; r.col[5] = m1.y; r.own = m1.z;
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y; r.v[4] = c.x; r.v[5] = c.y; r.diag = d.x;
+    }
+    return r;
+}
+
+template <bool UPPER, int W>
 __global__ __launch_bounds__(kBlock) void k_sptrsv_level_rec(int j0, int count, const int32_t *__restrict__ lo_rp,
                                                              const int32_t *__restrict__ lo_ci,
-                                                             const double *__restrict__ lo_v, const int4 *__restrict__ meta,
-                                                             const double2 *__restrict__ val,
+                                                             const double *__restrict__ lo_v, const int32_t *__restrict__ meta,
+                                                             const double *__restrict__ val,
                                                              const double *__restrict__ rhs, double *out, const int *done) {
     if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= count) return;
     const int j = j0 + idx;
-    const int4 m = meta[j];
-    const double2 v01 = val[2 * (int64_t)j], v2d = val[2 * (int64_t)j + 1];
-    double acc = rhs[m.w];
-    if (m.x == -2) {
+    const SfRec<W> r = load_sf_record<W>(meta, val, j);
+    double acc = rhs[r.own];
+    if (r.col[0] == -2) {
         const int s = lo_rp[j], e = lo_rp[j + 1];
         const int ks = UPPER ? s + 1 : s, ke = UPPER ? e : e - 1;
         for (int k = ks; k < ke; ++k) acc -= lo_v[k] * out[lo_ci[k]];
     } else {
-        const double y0 = out[m.x < 0 ? m.w : m.x], y1 = out[m.y < 0 ? m.w : m.y], y2 = out[m.z < 0 ? m.w : m.z];
-        if (m.x >= 0) acc -= v01.x * y0;
-        if (m.y >= 0) acc -= v01.y * y1;
-        if (m.z >= 0) acc -= v2d.x * y2;
+        double y[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) y[q] = out[r.col[q] < 0 ? r.own : r.col[q]];
+#pragma unroll
+        for (int q = 0; q < W; ++q)
+            if (r.col[q] >= 0) acc -= r.v[q] * y[q];
     }
-    out[m.w] = acc / v2d.y;
+    out[r.own] = acc / r.diag;
 }
 
 // One level, one thread per row (rows too long for the LDS product buffer).
@@ -373,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void k_fill_pending(const int32_t *__restri
                                                          double *__restrict__ out, const int *done) {
     if (done && *done) return;
     const int idx = blockIdx.x * kBlock + threadIdx.x;
-    if (idx < count) out[rows[j0 + idx]] = __longlong_as_double((long long)kPendingBits);
+    if (idx < count) out[rows ? rows[j0 + idx] : j0 + idx] = __longlong_as_double((long long)kPendingBits);
 }
 
 // The kernel works on fixed-width records (Levels::sf_meta / sf_val): everything a row needs -- three column indices,
@@ -390,15 +418,15 @@ __global__ __launch_bounds__(kBlock) void k_fill_pending(const int32_t *__restri
 // rows) is the other way round -- 0.43 ms vs 0.31 ms: there the level bodies, not the boundaries, are the cost, the
 // polling loads bypass the L1, and rows several levels ahead of the front poll for nothing -- so such runs keep one
 // launch per level (build_levels: mean level width > 16384).
-template <bool UPPER>
-__global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_rec(int j0, int count, const int32_t *__restrict__ lo_rp,
-                                                                const int32_t *__restrict__ lo_ci,
-                                                                const double *__restrict__ lo_v,
-                                                                const int4 *__restrict__ meta,
-                                                                const double2 *__restrict__ val,
-                                                                const double *__restrict__ rhs, double *out,
-                                                                unsigned int *ticket /* [0] next block, [1] exits */,
-                                                                int nblocks, const int *done, int *err) {
+template <bool UPPER, int BS, int W>   // BS rows (= threads) per ticket, records of width W
+__global__ __launch_bounds__(BS) void k_sptrsv_syncfree_rec(int j0, int count, const int32_t *__restrict__ lo_rp,
+                                                            const int32_t *__restrict__ lo_ci,
+                                                            const double *__restrict__ lo_v,
+                                                            const int32_t *__restrict__ meta,
+                                                            const double *__restrict__ val,
+                                                            const double *__restrict__ rhs, double *out,
+                                                            unsigned int *ticket /* [0] next block, [1] exits */,
+                                                            int nblocks, const int *done, int *err) {
     __shared__ unsigned int s_lb;
     const int t = threadIdx.x;
     if (done && *done) return;                      // nothing drawn: the counters stay zero
@@ -408,22 +436,22 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_rec(int j0, int coun
         __syncthreads();
         const unsigned int lb = s_lb;
         if (lb >= (unsigned int)nblocks) break;
-        const int j = j0 + (int)lb * kBlock + t;
+        const int j = j0 + (int)lb * BS + t;
         const bool valid = j < j0 + count;
         const int jc = valid ? j : j0;              // lanes without a row load a valid record and ignore it
-        const int4 m = meta[jc];
-        const double2 v01 = val[2 * (int64_t)jc], v2d = val[2 * (int64_t)jc + 1];
-        const double bi = rhs[m.w];
+        const SfRec<W> r = load_sf_record<W>(meta, val, jc);
+        const double bi = rhs[r.own];
         bool stored = !valid;
         unsigned spins = 0;
         // ONE loop for every lane of the wave, left by the whole wave at once (lanes may wait for each other, and a
-        // store on an exit path would only run after every lane has left).  Short rows (<= 3 entries): all entries are
-        // asked for at once, the pending ones again, and consumed in column order.  Long rows (meta.x == -2) walk the
-        // level-ordered copy one entry at a time.
-        const bool longrow = m.x == -2;
+        // store on an exit path would only run after every lane has left).  Rows that fit the record (<= W entries): all
+        // entries are asked for at once, the pending ones again, and consumed in column order.  Longer rows
+        // (col[0] == -2) walk the level-ordered copy one entry at a time.
+        const bool longrow = r.col[0] == -2;
         const double pend = __longlong_as_double((long long)kPendingBits);
-        double y0 = (!longrow && m.x >= 0) ? pend : 0.0, y1 = (!longrow && m.y >= 0) ? pend : 0.0,
-               y2 = (!longrow && m.z >= 0) ? pend : 0.0;
+        double y[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) y[q] = (!longrow && r.col[q] >= 0) ? pend : 0.0;
         int k = 0, ke = 0;
         double acc = bi;
         if (longrow) {
@@ -436,9 +464,9 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_rec(int j0, int coun
                 bool ready = false, waited = false;
                 if (longrow) {
                     if (k < ke) {
-                        const double y = __hip_atomic_load(out + lo_ci[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (!is_pending(y)) {
-                            acc -= lo_v[k] * y;
+                        const double yk = __hip_atomic_load(out + lo_ci[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!is_pending(yk)) {
+                            acc -= lo_v[k] * yk;
                             ++k;
                             spins = 0;
                         } else {
@@ -447,15 +475,18 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_rec(int j0, int coun
                     }
                     ready = k >= ke;
                 } else {
-                    if (is_pending(y0)) y0 = __hip_atomic_load(out + m.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (is_pending(y1)) y1 = __hip_atomic_load(out + m.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (is_pending(y2)) y2 = __hip_atomic_load(out + m.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ready = !is_pending(y0) && !is_pending(y1) && !is_pending(y2);
+                    ready = true;
+#pragma unroll
+                    for (int q = 0; q < W; ++q) {
+                        if (is_pending(y[q])) y[q] = __hip_atomic_load(out + r.col[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int q = 0; q < W; ++q) ready = ready && !is_pending(y[q]);
                     waited = !ready;
                     if (ready) {
-                        if (m.x >= 0) acc -= v01.x * y0;
-                        if (m.y >= 0) acc -= v01.y * y1;
-                        if (m.z >= 0) acc -= v2d.x * y2;
+#pragma unroll
+                        for (int q = 0; q < W; ++q)
+                            if (r.col[q] >= 0) acc -= r.v[q] * y[q];
                     }
                 }
                 if (waited && ++spins > (1u << 22)) {   // bounded: never hang the device on a malformed schedule
@@ -464,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_rec(int j0, int coun
                     ready = true;
                 }
                 if (ready) {
-                    __hip_atomic_store(out + m.w, acc / v2d.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(out + r.own, acc / r.diag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     stored = true;
                 } else if (waited) {
                     __builtin_amdgcn_s_sleep(1);
@@ -689,9 +720,75 @@ void init_strip_kernels() {
     (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk / 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 }
 
+// Level-major solve, way in: dst[j] = src[map[j]] over the XCD-aware work list (Levels::lm_chunks; the index loads do not wait
+// for the `done` word), and the solution vector preset to the sync-free kernels' "pending" pattern where such a kernel follows.
+__global__ __launch_bounds__(kBlock) void k_lm_enter(const int32_t *__restrict__ map, const double *__restrict__ src,
+                                                     double *__restrict__ dst, double *__restrict__ pending,
+                                                     const int2 *__restrict__ chunks, int per_xcd, const int *done) {
+    const int2 c = chunks[(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)];
+    const bool mine = (int)threadIdx.x < c.y;
+    const int j = c.x + (mine ? (int)threadIdx.x : 0);
+    const int a = map[j];
+    if (done && *done) return;
+    if (!mine) return;
+    dst[j] = src[a];
+    if (pending) pending[j] = __longlong_as_double((long long)kPendingBits);
+}
+
+// Level-major solve, way out: dst[i] = src[pos[i]] (the result back in the handle's numbering), optionally with the
+// per-workgroup partials of <dotv, dst> (a multiple of 8 workgroups).
+__global__ __launch_bounds__(kBlock) void k_lm_finish(int64_t n, const int32_t *__restrict__ pos, const double *__restrict__ src,
+                                                      double *__restrict__ dst, const double *__restrict__ dotv,
+                                                      double *__restrict__ part, const int *done) {
+    __shared__ double sh[4];
+    if (done && *done) return;
+    // XCD-aware: the workgroups of XCD x (b % 8 == x) share the x-th eighth of the index range, which gathers from the
+    // x-th eighth of every level -- the lines of `src` one XCD reads stay in its L2
+    const int64_t x = blockIdx.x & 7, k = blockIdx.x >> 3, per = ((int64_t)gridDim.x - x + 7) / 8;   // per: workgroups of this eighth
+    const int64_t lo = n * x / 8, hi = n * (x + 1) / 8;
+    double acc = 0.0;
+    for (int64_t i = lo + k * kBlock + threadIdx.x; i < hi; i += per * kBlock) {
+        const double v = src[pos[i]];
+        dst[i] = v;
+        if (dotv) acc += dotv[i] * v;
+    }
+    if (part) {
+        const double tot = block_sum(acc, sh);
+        if (threadIdx.x == 0) part[blockIdx.x] = tot;
+    }
+}
+
 void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s,
-                   const int *done) {
+                   const int *done, SptrsvIo *io) {
     (void)T;  // the level-ordered copy in `lv` carries the factor
+    if (io) io->dot_done = false;
+    const bool lm = lv.level_major && lv.strips.n_strips == 0;
+    const int32_t *rows = lm ? nullptr : lv.rows;             // level-major: a row's index IS its position
+    const int32_t *cols = lm ? lv.lo_cpos : lv.lo_col;
+    double *const out_user = out;
+    if (lm) {
+        const bool chained = io && io->lm_in;
+        bool any_syncfree = false;
+        for (const auto &seg : lv.segments) any_syncfree = any_syncfree || seg.syncfree;
+        hipLaunchKernelGGL(k_lm_enter, dim3(8 * lv.lm_chunks_per_xcd), dim3(kBlock), 0, s,
+                           chained ? lv.lm_from_lower : lv.rows, chained ? io->lm_in : rhs, lv.lm_rhs,
+                           any_syncfree ? lv.lm_out : nullptr, (const int2 *)lv.lm_chunks, lv.lm_chunks_per_xcd, done);
+        rhs = lv.lm_rhs;
+        out = lv.lm_out;
+    }
+    struct Finish {                                           // level-major: the result leaves through k_lm_finish
+        const Levels &lv; SptrsvIo *io; double *out_user; int64_t n; hipStream_t s; const int *done; bool lm;
+        ~Finish() {
+            if (!lm || (io && io->keep_lm)) return;
+            const bool dot = io && io->dot_with && io->dot_part && io->dot_grid > 0;
+            int grid = dot ? io->dot_grid : (int)((n + kBlock - 1) / kBlock);
+            grid = grid > 2048 ? 2048 : grid;
+            grid = dot ? grid : (grid + 7) / 8 * 8;
+            hipLaunchKernelGGL(k_lm_finish, dim3(grid), dim3(kBlock), 0, s, n, lv.lm_pos, lv.lm_out, out_user,
+                               dot ? io->dot_with : nullptr, dot ? io->dot_part : nullptr, done);
+            if (dot) io->dot_done = true;
+        }
+    } finish{lv, io, out_user, T.n, s, done, lm};
     if (lv.strips.n_strips > 0) {
         const Levels::Strips &sp = lv.strips;
         const int count = (int)T.n;
@@ -728,15 +825,41 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
             grid = grid < 16 ? 16 : grid;
             grid = grid > nblocks ? nblocks : grid;
             grid = grid > 2048 ? 2048 : grid;       // 8 workgroups per CU: all resident
-            hipLaunchKernelGGL(k_fill_pending, dim3(nblocks), dim3(kBlock), 0, s, lv.rows, j0, cnt, out, done);
-            if (upper)
-                hipLaunchKernelGGL(k_sptrsv_syncfree_rec<true>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_col,
-                                   lv.lo_val, (const int4 *)lv.sf_meta, (const double2 *)lv.sf_val, rhs, out,
-                                   reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nblocks, done, lv.spin_err);
-            else
-                hipLaunchKernelGGL(k_sptrsv_syncfree_rec<false>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_col,
-                                   lv.lo_val, (const int4 *)lv.sf_meta, (const double2 *)lv.sf_val, rhs, out,
-                                   reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nblocks, done, lv.spin_err);
+            if (lm) {                                   // (lm_out was filled with the pending pattern by the way-in pass)
+#define DPCG_SF_LM(UP, BSV, WV)                                                                                              \
+    do {                                                                                                                     \
+        const int nb = (cnt + BSV - 1) / BSV;                                                                                \
+        int g = (factor * seg.max_width + BSV - 1) / BSV + 4;                                                                \
+        g = g > nb ? nb : g;                                                                                                 \
+        g = g > 2048 * 256 / BSV ? 2048 * 256 / BSV : g;                                                                     \
+        hipLaunchKernelGGL((k_sptrsv_syncfree_rec<UP, BSV, WV>), dim3(g), dim3(BSV), 0, s, j0, cnt, lv.lo_rowptr, cols,      \
+                           lv.lo_val, lv.sf_meta, lv.sf_val, rhs, out,                                                       \
+                           reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nb, done, lv.spin_err);                 \
+    } while (0)
+                // 512 rows per ticket (measured on the scrambled 1M-DoF factor: 256 / 512 / 1024 rows: 241 / 233 / 233-254 us per apply)
+                if (lv.rec_w == 6) {
+                    if (upper) DPCG_SF_LM(true, 512, 6);
+                    else DPCG_SF_LM(false, 512, 6);
+                } else {
+                    if (upper) DPCG_SF_LM(true, 512, 3);
+                    else DPCG_SF_LM(false, 512, 3);
+                }
+#undef DPCG_SF_LM
+                continue;
+            }
+            hipLaunchKernelGGL(k_fill_pending, dim3(nblocks), dim3(kBlock), 0, s, rows, j0, cnt, out, done);
+#define DPCG_SF(UP, WV)                                                                                                      \
+    hipLaunchKernelGGL((k_sptrsv_syncfree_rec<UP, kBlock, WV>), dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, cols,  \
+                       lv.lo_val, lv.sf_meta, lv.sf_val, rhs, out, reinterpret_cast<unsigned int *>(lv.tickets + seg_index),  \
+                       nblocks, done, lv.spin_err)
+            if (lv.rec_w == 6) {
+                if (upper) DPCG_SF(true, 6);
+                else DPCG_SF(false, 6);
+            } else {
+                if (upper) DPCG_SF(true, 3);
+                else DPCG_SF(false, 3);
+            }
+#undef DPCG_SF
             continue;
         }
         if (seg.merged && seg.ring_w > 0 && lv.pk_meta && !ring_pipe_disabled() && seg.max_width <= 1024 &&
@@ -795,13 +918,18 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
             const int grid = (cnt + kBlock - 1) / kBlock;
 #define DPCG_TRSV(KERNEL, UP) \
     hipLaunchKernelGGL(KERNEL<UP>, dim3(grid), dim3(kBlock), 0, s, lv.rows, j0, cnt, lv.lo_rowptr, lv.lo_col, lv.lo_val, rhs, out, done)
-            if (lv.sf_meta && !level_rec_disabled()) {
-                if (upper)
-                    hipLaunchKernelGGL(k_sptrsv_level_rec<true>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_col,
-                                       lv.lo_val, (const int4 *)lv.sf_meta, (const double2 *)lv.sf_val, rhs, out, done);
-                else
-                    hipLaunchKernelGGL(k_sptrsv_level_rec<false>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_col,
-                                       lv.lo_val, (const int4 *)lv.sf_meta, (const double2 *)lv.sf_val, rhs, out, done);
+            if (lv.sf_meta && (lm || !level_rec_disabled())) {
+#define DPCG_LEVEL_REC(UP, WV)                                                                                            \
+    hipLaunchKernelGGL((k_sptrsv_level_rec<UP, WV>), dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, cols, lv.lo_val, \
+                       lv.sf_meta, lv.sf_val, rhs, out, done)
+                if (lv.rec_w == 6) {
+                    if (upper) DPCG_LEVEL_REC(true, 6);
+                    else DPCG_LEVEL_REC(false, 6);
+                } else {
+                    if (upper) DPCG_LEVEL_REC(true, 3);
+                    else DPCG_LEVEL_REC(false, 3);
+                }
+#undef DPCG_LEVEL_REC
             } else if (lv.stream_ok) {
                 if (upper) DPCG_TRSV(k_sptrsv_level_stream, true);
                 else DPCG_TRSV(k_sptrsv_level_stream, false);
