@@ -95,7 +95,6 @@ void free_levels(Levels &l) {
     dev_free(l.lm_from_lower);
     dev_free(l.lm_rhs);
     dev_free(l.lm_out);
-    dev_free(l.lm_chunks);
     l = Levels();
 }
 
@@ -546,6 +545,13 @@ int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, boo
             if (h->lvlL.level_major && h->lvlU.level_major && h->lvlU.lm_from_lower) {
                 lower_io.keep_lm = true;                   // y stays in L's level-major numbering, L^T gathers it from there
                 upper_io.lm_in = h->lvlL.lm_out;
+                if (single_syncfree_segment(h->lvlL) && single_syncfree_segment(h->lvlU)) {
+                    // no way-in passes: the two solve kernels gather their right-hand sides themselves; the lower solve presets
+                    // L^T's solution vector to "pending", the way-out pass does the same for L's (for the next apply)
+                    lower_io.fused_entry = upper_io.fused_entry = true;
+                    lower_io.refill = h->lvlU.lm_out;
+                    upper_io.refill = h->lvlL.lm_out;
+                }
             }
             if (part_rz && n_part_rz) {                    // <r,z> summed by the kernel that takes z out of level-major order
                 upper_io.dot_with = r;

@@ -147,11 +147,10 @@ struct Levels {
     int32_t *lm_pos = nullptr;             // handle index -> level-order position
     int32_t *lm_from_lower = nullptr;      // L^T only: position here -> position in L's numbering (lower result feeds the upper solve)
     double *lm_rhs = nullptr, *lm_out = nullptr;
-    // way-in pass, XCD-aware: {start, count} runs of level-order positions, eight lists of lm_chunks_per_xcd entries each;
-    // list x holds the x-th eighth of EVERY level, i.e. one eighth of the handle's index range, so the lines of the vector
-    // an XCD gathers from stay in its own L2 from level to level (workgroup b takes entry b / 8 of list b % 8)
-    int32_t *lm_chunks = nullptr;
-    int lm_chunks_per_xcd = 0;
+    // Invariant (factors that are one sync-free launch, single_syncfree_segment): between solves the LOWER factor's lm_out
+    // holds the sync-free kernels' "pending" pattern everywhere -- set up by build_levels, restored by whoever consumed the
+    // values (the way-out pass of a paired apply; launch_sptrsv itself after a standalone lower solve).  A solve with
+    // SptrsvIo::fused_entry relies on it.  (A host-side flag instead would be wrong under stream capture.)
 };
 
 // Plumbing between the two solves of one preconditioner apply (all optional)
@@ -162,7 +161,14 @@ struct SptrsvIo {
     double *dot_part = nullptr;            // ... into dot_part[0 .. dot_grid)
     int dot_grid = 0;
     bool dot_done = false;                 // set by launch_sptrsv when it did sum them
+    // No way-in pass: the (single, sync-free) solve kernel gathers its right-hand side through the map itself; lm_out must be
+    // all-pending (see Levels: the invariant for the lower factor; the lower solve's `refill` for the upper one).  `refill`: another vector of n entries that the
+    // kernel (lower solve) or the way-out pass (upper solve) presets to the pending pattern for whoever solves next.
+    bool fused_entry = false;
+    double *refill = nullptr;
 };
+bool single_syncfree_segment(const Levels &lv);   // level-major, the whole factor one sync-free launch
+void launch_fill_pending(double *v, int64_t n, hipStream_t s);
 
 }  // namespace dpcg
 

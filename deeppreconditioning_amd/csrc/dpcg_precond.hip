@@ -409,26 +409,7 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
             DPCG_TRY(dev_alloc(&lv.lm_rhs, n));
             DPCG_TRY(dev_alloc(&lv.lm_out, n));
             launch_invert_positions(n, lv.rows, lv.lm_pos, s);
-            // the way-in pass's work list (see Levels::lm_chunks)
-            std::vector<std::vector<int32_t>> lists(8);
-            for (int q = 0; q < lv.n_levels; ++q) {
-                const int64_t lo = level_ptr[q], w = level_ptr[q + 1] - lo;
-                for (int x = 0; x < 8; ++x) {
-                    const int64_t a = lo + w * x / 8, b = lo + w * (x + 1) / 8;
-                    for (int64_t c = a; c < b; c += kBlock) {
-                        lists[x].push_back((int32_t)c);
-                        lists[x].push_back((int32_t)std::min<int64_t>(kBlock, b - c));
-                    }
-                }
-            }
-            size_t per = 0;
-            for (const auto &l8 : lists) per = std::max(per, l8.size() / 2);
-            std::vector<int32_t> flat(per * 16, 0);
-            for (int x = 0; x < 8; ++x) std::copy(lists[x].begin(), lists[x].end(), flat.begin() + (size_t)x * per * 2);
-            DPCG_TRY(dev_alloc(&lv.lm_chunks, (int64_t)flat.size()));
-            DPCG_HIP(hipMemcpyAsync(lv.lm_chunks, flat.data(), flat.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-            DPCG_HIP(hipStreamSynchronize(s));       // `flat` is pageable host memory
-            lv.lm_chunks_per_xcd = (int)per;
+            launch_fill_pending(lv.lm_out, n, s);        // the invariant of Levels::lm_out
         }
     }
     pt.mark("  sync-free records");

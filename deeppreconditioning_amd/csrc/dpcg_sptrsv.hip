@@ -426,7 +426,9 @@ __global__ __launch_bounds__(BS) void k_sptrsv_syncfree_rec(int j0, int count, c
                                                             const double *__restrict__ val,
                                                             const double *__restrict__ rhs, double *out,
                                                             unsigned int *ticket /* [0] next block, [1] exits */,
-                                                            int nblocks, const int *done, int *err) {
+                                                            int nblocks, const int *done, int *err,
+                                                            const int32_t *__restrict__ rhs_map /* null: rhs[own] */,
+                                                            double *__restrict__ refill /* null, or preset to pending */) {
     __shared__ unsigned int s_lb;
     const int t = threadIdx.x;
     if (done && *done) return;                      // nothing drawn: the counters stay zero
@@ -439,8 +441,10 @@ __global__ __launch_bounds__(BS) void k_sptrsv_syncfree_rec(int j0, int count, c
         const int j = j0 + (int)lb * BS + t;
         const bool valid = j < j0 + count;
         const int jc = valid ? j : j0;              // lanes without a row load a valid record and ignore it
+        const int rhs_at = rhs_map ? rhs_map[jc] : -1;
         const SfRec<W> r = load_sf_record<W>(meta, val, jc);
-        const double bi = rhs[r.own];
+        const double bi = rhs[rhs_map ? rhs_at : r.own];
+        if (refill && valid) refill[j] = __longlong_as_double((long long)kPendingBits);
         bool stored = !valid;
         unsigned spins = 0;
         // ONE loop for every lane of the wave, left by the whole wave at once (lanes may wait for each other, and a
@@ -720,42 +724,79 @@ void init_strip_kernels() {
     (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk / 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 }
 
-// Level-major solve, way in: dst[j] = src[map[j]] over the XCD-aware work list (Levels::lm_chunks; the index loads do not wait
-// for the `done` word), and the solution vector preset to the sync-free kernels' "pending" pattern where such a kernel follows.
+// Level-major solve, way in: dst[j] = src[map[j]], and the solution vector preset to the sync-free kernels' "pending"
+// pattern where such a kernel follows.  kLmPerThread elements per thread, all index loads first, then all gathers: two
+// memory round trips per thread whatever the count (the index loads do not wait for the `done` word either).
+// (An XCD-aware work list -- every XCD gathering from its own eighth of every level -- was measured: no difference.)
+constexpr int kLmPerThread = 4;
 __global__ __launch_bounds__(kBlock) void k_lm_enter(const int32_t *__restrict__ map, const double *__restrict__ src,
-                                                     double *__restrict__ dst, double *__restrict__ pending,
-                                                     const int2 *__restrict__ chunks, int per_xcd, const int *done) {
-    const int2 c = chunks[(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)];
-    const bool mine = (int)threadIdx.x < c.y;
-    const int j = c.x + (mine ? (int)threadIdx.x : 0);
-    const int a = map[j];
+                                                     double *__restrict__ dst, double *__restrict__ pending, int count,
+                                                     const int *done) {
+    const int base = blockIdx.x * (kBlock * kLmPerThread) + threadIdx.x;
+    int a[kLmPerThread];
+#pragma unroll
+    for (int q = 0; q < kLmPerThread; ++q) {
+        const int j = base + q * kBlock;
+        a[q] = map[j < count ? j : 0];
+    }
     if (done && *done) return;
-    if (!mine) return;
-    dst[j] = src[a];
-    if (pending) pending[j] = __longlong_as_double((long long)kPendingBits);
+    double v[kLmPerThread];
+#pragma unroll
+    for (int q = 0; q < kLmPerThread; ++q) v[q] = src[a[q]];
+    const double pend = __longlong_as_double((long long)kPendingBits);
+#pragma unroll
+    for (int q = 0; q < kLmPerThread; ++q) {
+        const int j = base + q * kBlock;
+        if (j < count) {
+            dst[j] = v[q];
+            if (pending) pending[j] = pend;
+        }
+    }
 }
 
 // Level-major solve, way out: dst[i] = src[pos[i]] (the result back in the handle's numbering), optionally with the
-// per-workgroup partials of <dotv, dst> (a multiple of 8 workgroups).
+// per-workgroup partials of <dotv, dst>.  Same load batching as the way in.
 __global__ __launch_bounds__(kBlock) void k_lm_finish(int64_t n, const int32_t *__restrict__ pos, const double *__restrict__ src,
                                                       double *__restrict__ dst, const double *__restrict__ dotv,
-                                                      double *__restrict__ part, const int *done) {
+                                                      double *__restrict__ part, const int *done, double *__restrict__ refill) {
     __shared__ double sh[4];
     if (done && *done) return;
-    // XCD-aware: the workgroups of XCD x (b % 8 == x) share the x-th eighth of the index range, which gathers from the
-    // x-th eighth of every level -- the lines of `src` one XCD reads stay in its L2
-    const int64_t x = blockIdx.x & 7, k = blockIdx.x >> 3, per = ((int64_t)gridDim.x - x + 7) / 8;   // per: workgroups of this eighth
-    const int64_t lo = n * x / 8, hi = n * (x + 1) / 8;
     double acc = 0.0;
-    for (int64_t i = lo + k * kBlock + threadIdx.x; i < hi; i += per * kBlock) {
-        const double v = src[pos[i]];
-        dst[i] = v;
-        if (dotv) acc += dotv[i] * v;
+    const double pend = __longlong_as_double((long long)kPendingBits);
+    const int64_t step = (int64_t)gridDim.x * (kBlock * kLmPerThread);
+    for (int64_t base = (int64_t)blockIdx.x * (kBlock * kLmPerThread) + threadIdx.x; base < n; base += step) {
+        int a[kLmPerThread];
+        double v[kLmPerThread], w[kLmPerThread];
+#pragma unroll
+        for (int q = 0; q < kLmPerThread; ++q) {
+            const int64_t i = base + q * kBlock;
+            a[q] = pos[i < n ? i : 0];
+            w[q] = (dotv && i < n) ? dotv[i] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < kLmPerThread; ++q) v[q] = src[a[q]];
+#pragma unroll
+        for (int q = 0; q < kLmPerThread; ++q) {
+            const int64_t i = base + q * kBlock;
+            if (i < n) {
+                dst[i] = v[q];
+                acc += w[q] * v[q];
+                if (refill) refill[i] = pend;
+            }
+        }
     }
     if (part) {
         const double tot = block_sum(acc, sh);
         if (threadIdx.x == 0) part[blockIdx.x] = tot;
     }
+}
+
+bool single_syncfree_segment(const Levels &lv) {
+    return lv.level_major && lv.strips.n_strips == 0 && lv.segments.size() == 1 && lv.segments[0].syncfree;
+}
+
+void launch_fill_pending(double *v, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_fill_pending, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, nullptr, 0, (int)n, v, nullptr);
 }
 
 void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s,
@@ -766,29 +807,44 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
     const int32_t *rows = lm ? nullptr : lv.rows;             // level-major: a row's index IS its position
     const int32_t *cols = lm ? lv.lo_cpos : lv.lo_col;
     double *const out_user = out;
+    const bool fused_entry = lm && io && io->fused_entry && single_syncfree_segment(lv);
+    const int32_t *rhs_map = nullptr;
     if (lm) {
         const bool chained = io && io->lm_in;
-        bool any_syncfree = false;
-        for (const auto &seg : lv.segments) any_syncfree = any_syncfree || seg.syncfree;
-        hipLaunchKernelGGL(k_lm_enter, dim3(8 * lv.lm_chunks_per_xcd), dim3(kBlock), 0, s,
-                           chained ? lv.lm_from_lower : lv.rows, chained ? io->lm_in : rhs, lv.lm_rhs,
-                           any_syncfree ? lv.lm_out : nullptr, (const int2 *)lv.lm_chunks, lv.lm_chunks_per_xcd, done);
-        rhs = lv.lm_rhs;
+        const int32_t *map = chained ? lv.lm_from_lower : lv.rows;
+        const double *src = chained ? io->lm_in : rhs;
+        if (fused_entry) {                                    // the solve kernel gathers src[map[j]] itself
+            rhs_map = map;
+            rhs = src;
+        } else {
+            bool any_syncfree = false;
+            for (const auto &seg : lv.segments) any_syncfree = any_syncfree || seg.syncfree;
+            const int count = (int)T.n;
+            hipLaunchKernelGGL(k_lm_enter, dim3((count + kBlock * kLmPerThread - 1) / (kBlock * kLmPerThread)), dim3(kBlock), 0, s,
+                               map, src, lv.lm_rhs, any_syncfree ? lv.lm_out : nullptr, count, done);
+            rhs = lv.lm_rhs;
+        }
         out = lv.lm_out;
     }
+    double *const sf_refill = fused_entry && !upper ? io->refill : nullptr;   // lower solve: presets L^T's solution vector
     struct Finish {                                           // level-major: the result leaves through k_lm_finish
-        const Levels &lv; SptrsvIo *io; double *out_user; int64_t n; hipStream_t s; const int *done; bool lm;
+        const Levels &lv; SptrsvIo *io; double *out_user; int64_t n; hipStream_t s; const int *done; bool lm, upper;
         ~Finish() {
             if (!lm || (io && io->keep_lm)) return;
+            const bool restore = !upper && !(io && io->fused_entry) && single_syncfree_segment(lv);
             const bool dot = io && io->dot_with && io->dot_part && io->dot_grid > 0;
-            int grid = dot ? io->dot_grid : (int)((n + kBlock - 1) / kBlock);
+            int grid = dot ? io->dot_grid : (int)((n + kBlock * kLmPerThread - 1) / (kBlock * kLmPerThread));
             grid = grid > 2048 ? 2048 : grid;
-            grid = dot ? grid : (grid + 7) / 8 * 8;
             hipLaunchKernelGGL(k_lm_finish, dim3(grid), dim3(kBlock), 0, s, n, lv.lm_pos, lv.lm_out, out_user,
-                               dot ? io->dot_with : nullptr, dot ? io->dot_part : nullptr, done);
+                               dot ? io->dot_with : nullptr, dot ? io->dot_part : nullptr, done,
+                               (io && io->fused_entry) ? io->refill : nullptr);
             if (dot) io->dot_done = true;
+            // a standalone lower solve consumed the "pending" preset of lm_out: put it back (Levels: the invariant)
+            if (restore)
+                hipLaunchKernelGGL(k_fill_pending, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, nullptr, 0, (int)n,
+                                   lv.lm_out, done);
         }
-    } finish{lv, io, out_user, T.n, s, done, lm};
+    } finish{lv, io, out_user, T.n, s, done, lm, upper};
     if (lv.strips.n_strips > 0) {
         const Levels::Strips &sp = lv.strips;
         const int count = (int)T.n;
@@ -820,8 +876,12 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
             const int nblocks = (cnt + kBlock - 1) / kBlock;
             // persistent grid ~ a few times the widest level: the front and the rows about to join it (DPCG_SF_FACTOR:
             // development knob for that multiple)
-            static const int factor = [] { const char *e = getenv("DPCG_SF_FACTOR"); const int f = e ? atoi(e) : 2; return f < 1 ? 1 : f; }();
-            int grid = (factor * seg.max_width + kBlock - 1) / kBlock + 4;
+            static const double factor_env = [] { const char *e = getenv("DPCG_SF_FACTOR"); return e ? atof(e) : 0.0; }();
+            // (level-major factors: wide levels, where the polling loads of rows ahead of the front are what costs.  Scrambled
+            // 1M-DoF IC(0), us per apply at 0.35 / 0.5 / 0.7 / 0.85 / 1 / 1.2 / 1.5 / 2 / 3 / 4 x the widest level:
+            // 193 / 165 / 148 / 143 / 148 / 154 / 157 / 173 / 239 / 358)
+            const double factor = factor_env > 0.0 ? factor_env : (lm ? 0.85 : 2.0);
+            int grid = ((int)(factor * seg.max_width) + kBlock - 1) / kBlock + 4;
             grid = grid < 16 ? 16 : grid;
             grid = grid > nblocks ? nblocks : grid;
             grid = grid > 2048 ? 2048 : grid;       // 8 workgroups per CU: all resident
@@ -829,12 +889,13 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
 #define DPCG_SF_LM(UP, BSV, WV)                                                                                              \
     do {                                                                                                                     \
         const int nb = (cnt + BSV - 1) / BSV;                                                                                \
-        int g = (factor * seg.max_width + BSV - 1) / BSV + 4;                                                                \
+        int g = ((int)(factor * seg.max_width) + BSV - 1) / BSV + 4;                                                         \
         g = g > nb ? nb : g;                                                                                                 \
         g = g > 2048 * 256 / BSV ? 2048 * 256 / BSV : g;                                                                     \
         hipLaunchKernelGGL((k_sptrsv_syncfree_rec<UP, BSV, WV>), dim3(g), dim3(BSV), 0, s, j0, cnt, lv.lo_rowptr, cols,      \
                            lv.lo_val, lv.sf_meta, lv.sf_val, rhs, out,                                                       \
-                           reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nb, done, lv.spin_err);                 \
+                           reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nb, done, lv.spin_err, rhs_map,        \
+                           sf_refill);                                                                                       \
     } while (0)
                 // 512 rows per ticket (measured on the scrambled 1M-DoF factor: 256 / 512 / 1024 rows: 241 / 233 / 233-254 us per apply)
                 if (lv.rec_w == 6) {
@@ -851,7 +912,7 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
 #define DPCG_SF(UP, WV)                                                                                                      \
     hipLaunchKernelGGL((k_sptrsv_syncfree_rec<UP, kBlock, WV>), dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, cols,  \
                        lv.lo_val, lv.sf_meta, lv.sf_val, rhs, out, reinterpret_cast<unsigned int *>(lv.tickets + seg_index),  \
-                       nblocks, done, lv.spin_err)
+                       nblocks, done, lv.spin_err, nullptr, nullptr)
             if (lv.rec_w == 6) {
                 if (upper) DPCG_SF(true, 6);
                 else DPCG_SF(false, 6);

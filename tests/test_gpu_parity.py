@@ -1393,6 +1393,28 @@ def test_strip_pipelined_triangular_solves():
             assert r["iterations"][0] == r["iterations"][1] and r["hist_rel"] < 1e-9, (name, mode, r)
 
 
+def test_level_major_triangular_solves(D):
+    """The level-major form of the triangular solves (few wide levels: the solve runs in the factor's own level-order numbering,
+    the two solves of an apply hand the vector over without way-in passes; width-6 records) forced on small factors in a child
+    process: bit-identical to sequential substitution in every interleaving of standalone solves and applies, PCG counts and
+    histories equal to oracle/pcg_oracle.c with the same factor."""
+    import json
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = {**__import__("os").environ, "PYTHONPATH": str(root), "DPCG_LEVEL_MAJOR": "1", "DPCG_SETUP_TRACE": "1"}
+    proc = subprocess.run([sys.executable, str(root / "tests" / "level_major_child.py")], capture_output=True, text=True, cwd=root,
+                          env=env, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    out = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][-1])
+    assert len(out) == 4
+    for name, rec in out.items():
+        assert rec["apply"] and rec["lower"] and rec["upper"], (name, rec)
+        assert rec["iterations"][0] == rec["iterations"][2] == rec["iterations"][1] and rec["hist_rel"] < 1e-9, (name, rec)
+        assert rec["same_bits_without_graph"], (name, rec)
+
+
 def test_config2_cnn_emitted_factor_at_full_size(D):
     """BASELINE config 2 as stated: a single 256x256 5-point Poisson system, the L factor emitted by the PreconditionerNet
     (spconv-free forward on the GPU, seeded random weights: no checkpoint ships), fp64 PCG with z = L (L^T r) never
