@@ -217,7 +217,9 @@ static bool level_major_wanted(int64_t n, int n_levels) {
     static const int knob = [] { const char *e = getenv("DPCG_LEVEL_MAJOR"); return e ? atoi(e) : -1; }();
     if (knob == 0 || !syncfree_enabled()) return false;
     if (knob == 1) return true;
-    return n >= 65536 && n_levels >= 6 && n / n_levels >= 16384;
+    // measured, IC(0) of scrambled grids, us per PCG update without / with: 100^3 (19 levels of 53K rows on average) 270 / 146,
+    // 64^3 (18 x 14.5K) 134 / 91, 1024^2 (18 x 58K) 201 / 141, 256^2 (13 x 5K) 78 / 54, 40^3 (19 x 3.4K) 83 / 92
+    return n >= 32768 && n_levels >= 6 && n / n_levels >= 4096;
 }
 
 static bool level_major_syncfree() {              // development knob: DPCG_LM_SYNCFREE=0 keeps one launch per wide level

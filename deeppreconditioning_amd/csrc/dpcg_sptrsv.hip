@@ -799,55 +799,14 @@ void launch_fill_pending(double *v, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_fill_pending, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, nullptr, 0, (int)n, v, nullptr);
 }
 
-void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s,
-                   const int *done, SptrsvIo *io) {
-    (void)T;  // the level-ordered copy in `lv` carries the factor
-    if (io) io->dot_done = false;
-    const bool lm = lv.level_major && lv.strips.n_strips == 0;
-    const int32_t *rows = lm ? nullptr : lv.rows;             // level-major: a row's index IS its position
-    const int32_t *cols = lm ? lv.lo_cpos : lv.lo_col;
-    double *const out_user = out;
-    const bool fused_entry = lm && io && io->fused_entry && single_syncfree_segment(lv);
-    const int32_t *rhs_map = nullptr;
-    if (lm) {
-        const bool chained = io && io->lm_in;
-        const int32_t *map = chained ? lv.lm_from_lower : lv.rows;
-        const double *src = chained ? io->lm_in : rhs;
-        if (fused_entry) {                                    // the solve kernel gathers src[map[j]] itself
-            rhs_map = map;
-            rhs = src;
-        } else {
-            bool any_syncfree = false;
-            for (const auto &seg : lv.segments) any_syncfree = any_syncfree || seg.syncfree;
-            const int count = (int)T.n;
-            hipLaunchKernelGGL(k_lm_enter, dim3((count + kBlock * kLmPerThread - 1) / (kBlock * kLmPerThread)), dim3(kBlock), 0, s,
-                               map, src, lv.lm_rhs, any_syncfree ? lv.lm_out : nullptr, count, done);
-            rhs = lv.lm_rhs;
-        }
-        out = lv.lm_out;
-    }
-    double *const sf_refill = fused_entry && !upper ? io->refill : nullptr;   // lower solve: presets L^T's solution vector
-    struct Finish {                                           // level-major: the result leaves through k_lm_finish
-        const Levels &lv; SptrsvIo *io; double *out_user; int64_t n; hipStream_t s; const int *done; bool lm, upper;
-        ~Finish() {
-            if (!lm || (io && io->keep_lm)) return;
-            const bool restore = !upper && !(io && io->fused_entry) && single_syncfree_segment(lv);
-            const bool dot = io && io->dot_with && io->dot_part && io->dot_grid > 0;
-            int grid = dot ? io->dot_grid : (int)((n + kBlock * kLmPerThread - 1) / (kBlock * kLmPerThread));
-            grid = grid > 2048 ? 2048 : grid;
-            hipLaunchKernelGGL(k_lm_finish, dim3(grid), dim3(kBlock), 0, s, n, lv.lm_pos, lv.lm_out, out_user,
-                               dot ? io->dot_with : nullptr, dot ? io->dot_part : nullptr, done,
-                               (io && io->fused_entry) ? io->refill : nullptr);
-            if (dot) io->dot_done = true;
-            // a standalone lower solve consumed the "pending" preset of lm_out: put it back (Levels: the invariant)
-            if (restore)
-                hipLaunchKernelGGL(k_fill_pending, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, nullptr, 0, (int)n,
-                                   lv.lm_out, done);
-        }
-    } finish{lv, io, out_user, T.n, s, done, lm, upper};
+// The schedule proper: strips, or the segments one after another.  `rows`/`cols`: how the kernels address the vectors (by row
+// in the handle's numbering, or by level-order position for a level-major factor); rhs_map / refill: see SptrsvIo::fused_entry.
+static void launch_schedule(int64_t n, const Levels &lv, bool upper, bool lm, const int32_t *rows, const int32_t *cols,
+                            const double *rhs, double *out, hipStream_t s, const int *done, const int32_t *rhs_map,
+                            double *sf_refill) {
     if (lv.strips.n_strips > 0) {
         const Levels::Strips &sp = lv.strips;
-        const int count = (int)T.n;
+        const int count = (int)n;
         hipLaunchKernelGGL(k_strip_prepare, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, sp.rows, rhs, sp.b_lo, out,
                            count, done);
         constexpr int CH = kStripChunk;
@@ -1001,6 +960,43 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
 #undef DPCG_TRSV
         }
     }
+}
+
+void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s,
+                   const int *done, SptrsvIo *io) {
+    const int64_t n = T.n;    // the level-ordered copy in `lv` carries the factor
+    if (io) io->dot_done = false;
+    const bool lm = lv.level_major && lv.strips.n_strips == 0;
+    if (!lm) {
+        launch_schedule(n, lv, upper, false, lv.rows, lv.lo_col, rhs, out, s, done, nullptr, nullptr);
+        return;
+    }
+    // Level-major: way in (a pass, or fused into the single sync-free kernel), the schedule on positions, way out.
+    const bool fused_entry = io && io->fused_entry && single_syncfree_segment(lv);
+    const bool chained = io && io->lm_in;
+    const int32_t *map = chained ? lv.lm_from_lower : lv.rows;
+    const double *src = chained ? io->lm_in : rhs;
+    if (fused_entry) {
+        launch_schedule(n, lv, upper, true, nullptr, lv.lo_cpos, src, lv.lm_out, s, done, map, upper ? nullptr : io->refill);
+    } else {
+        bool any_syncfree = false;
+        for (const auto &seg : lv.segments) any_syncfree = any_syncfree || seg.syncfree;
+        const int count = (int)n;
+        hipLaunchKernelGGL(k_lm_enter, dim3((count + kBlock * kLmPerThread - 1) / (kBlock * kLmPerThread)), dim3(kBlock), 0, s, map,
+                           src, lv.lm_rhs, any_syncfree ? lv.lm_out : nullptr, count, done);
+        launch_schedule(n, lv, upper, true, nullptr, lv.lo_cpos, lv.lm_rhs, lv.lm_out, s, done, nullptr, nullptr);
+    }
+    if (io && io->keep_lm) return;                            // the next solve picks the result up in lm_out
+    const bool dot = io && io->dot_with && io->dot_part && io->dot_grid > 0;
+    int grid = dot ? io->dot_grid : (int)((n + kBlock * kLmPerThread - 1) / (kBlock * kLmPerThread));
+    grid = grid > 2048 ? 2048 : grid;
+    hipLaunchKernelGGL(k_lm_finish, dim3(grid), dim3(kBlock), 0, s, n, lv.lm_pos, lv.lm_out, out, dot ? io->dot_with : nullptr,
+                       dot ? io->dot_part : nullptr, done, fused_entry ? io->refill : nullptr);
+    if (dot) io->dot_done = true;
+    // a standalone lower solve consumed the "pending" preset of lm_out: put it back (Levels: the invariant)
+    if (!upper && !fused_entry && single_syncfree_segment(lv))
+        hipLaunchKernelGGL(k_fill_pending, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, nullptr, 0, (int)n,
+                           lv.lm_out, done);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -12,7 +12,11 @@ from deeppreconditioning_amd import poisson
 
 cases = [("poisson2d_256", lambda: poisson.poisson_system(2, 256)), ("poisson2d_1024", lambda: poisson.poisson_system(2, 1024)),
          ("poisson3d_64", lambda: poisson.poisson_system(3, 64)), ("poisson3d_100", lambda: poisson.poisson_system(3, 100)),
-         ("scrambled3d_100", lambda: D.CsrSystem.from_any(poisson.unstructured_like_csr(3, 100, 0)))]
+         ("scrambled3d_100", lambda: D.CsrSystem.from_any(poisson.unstructured_like_csr(3, 100, 0))),
+         ("scrambled3d_64", lambda: D.CsrSystem.from_any(poisson.unstructured_like_csr(3, 64, 0))),
+         ("scrambled3d_40", lambda: D.CsrSystem.from_any(poisson.unstructured_like_csr(3, 40, 0))),
+         ("scrambled2d_1024", lambda: D.CsrSystem.from_any(poisson.unstructured_like_csr(2, 1024, 0))),
+         ("scrambled2d_256", lambda: D.CsrSystem.from_any(poisson.unstructured_like_csr(2, 256, 0)))]
 only = sys.argv[1:] or None
 print(f"DPCG_SYNCFREE={os.environ.get('DPCG_SYNCFREE', '1')}")
 for name, make in cases:
