@@ -866,6 +866,35 @@ def test_solve_batch_general_path_interleaves_streams(D):
     assert [s.iterations for s in single] == its
 
 
+def test_solve_batch_triangular_solve_preconditioners_on_concurrent_streams(D):
+    """IC(0) applied by triangular solves on several streams at once: the sync-free kernels (persistent grids, ticket order,
+    level-major factors among them) of different handles share the chip.  Same bits as one system after the other, repeatedly,
+    and the C oracle's counts."""
+    from deeppreconditioning_amd.batch import solve_batch
+    mats = [O.unstructured_like(O.poisson2d(256), 1), O.poisson3d(40), O.unstructured_like(O.poisson3d(34), 2),
+            O.unstructured_like(O.poisson2d(200), 3), O.poisson2d(180), O.unstructured_like(O.poisson3d(40), 4)]
+    systems, rhs_list, single = [], [], []
+    for i, A in enumerate(mats):
+        S = D.CsrSystem.from_any(A)
+        S.set_preconditioner(D.IC0("solve"))
+        b = _dev(O.rhs(A.shape[0], i))
+        systems.append(S)
+        rhs_list.append(b)
+        single.append(S.solve(b, flags=D._lib.NO_SMALL))
+    for rep in range(6):
+        out = solve_batch(systems, rhs_list, n_streams=(2, 4, 6)[rep % 3])
+        for s, o in zip(single, out):
+            assert o.iterations == s.iterations and o.status == 0
+            assert torch.equal(o.x, s.x)
+    for i in (0, 2):
+        A = mats[i]
+        _, it, hist, _ = CO.pcg(A, O.rhs(A.shape[0], i), "llt_solve", L=CO.ic0(A))
+        assert single[i].iterations == it
+        # (the handle iterates on P A P^T: dot products sum in another order, so late entries drift apart in the last digits)
+        np.testing.assert_allclose(single[i].res_history[:40], hist[:40], rtol=1e-9)
+        np.testing.assert_allclose(single[i].res_history, hist, rtol=1e-6)
+
+
 # ---- two-kernel updates (SpMV kernel fused with p = z + beta p and the deferred x += alpha p) -----------------
 @pytest.mark.parametrize("make,pcs", [
     (lambda: O.poisson2d(128), ("jacobi", "none", "ic0_multiply", "ic0_solve")),       # gather kernel, 64 row blocks
