@@ -124,12 +124,12 @@ void launch_transpose_gather(int64_t nnz, const int32_t *perm, const int32_t *ro
 // ticket counter, so every row a workgroup waits for belongs to a workgroup that has already started: no deadlock
 // whatever the dispatch order.  The store sits inside the poll loop because lanes of one wave may depend on each other.
 // ------------------------------------------------------------------------------------------------
-// strip_rows > 0: STRIP-LOCAL levels -- dependencies on rows of another strip (strip = index / strip_rows, counted from
-// the end for an upper factor) are ignored; see the strip-pipelined solve.
+// map.rows > 0: STRIP-LOCAL levels -- dependencies on rows of another strip (StripMap::strip_of) are ignored; see the
+// strip-pipelined solve.
 template <bool UPPER>
 __global__ __launch_bounds__(kBlock) void k_levels_syncfree(int64_t n, const int32_t *__restrict__ rp,
                                                             const int32_t *__restrict__ ci, int32_t *level,
-                                                            unsigned int *ticket, int *err, int strip_rows) {
+                                                            unsigned int *ticket, int *err, StripMap map) {
     __shared__ unsigned int s_lb;
     if (threadIdx.x == 0) s_lb = atomicAdd(ticket, 1u);
     __syncthreads();
@@ -143,11 +143,11 @@ __global__ __launch_bounds__(kBlock) void k_levels_syncfree(int64_t n, const int
     int c = k < ke ? ci[k] : 0;
     unsigned spins = 0;
     bool stored = false;
-    const int64_t my_strip = strip_rows > 0 ? idx / strip_rows : 0;
+    const int64_t my_strip = map.rows > 0 ? map.strip_of(idx) : 0;
     auto foreign = [&](int col) {                     // a dependency that lives in another strip does not count
-        if (strip_rows <= 0) return false;
+        if (map.rows <= 0) return false;
         const int64_t cidx = UPPER ? n - 1 - col : col;
-        return cidx / strip_rows != my_strip;
+        return map.strip_of(cidx) != my_strip;
     };
     // The loop is left by the whole wave at once (ballot): were lanes to leave one by one, the compiler could move the
     // store onto the exit path, where a SIMT machine executes it only after EVERY lane has left -- a lane waiting for
@@ -179,30 +179,29 @@ __global__ __launch_bounds__(kBlock) void k_levels_syncfree(int64_t n, const int
 }
 
 void launch_levels_syncfree(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int32_t *level,
-                            unsigned int *ticket_zeroed, int *err, hipStream_t s, int strip_rows) {
+                            unsigned int *ticket_zeroed, int *err, hipStream_t s, StripMap map) {
     const int grid = (int)((n + kBlock - 1) / kBlock);
     if (upper)
-        hipLaunchKernelGGL(k_levels_syncfree<true>, dim3(grid), dim3(kBlock), 0, s, n, rp, ci, level, ticket_zeroed, err, strip_rows);
+        hipLaunchKernelGGL(k_levels_syncfree<true>, dim3(grid), dim3(kBlock), 0, s, n, rp, ci, level, ticket_zeroed, err, map);
     else
-        hipLaunchKernelGGL(k_levels_syncfree<false>, dim3(grid), dim3(kBlock), 0, s, n, rp, ci, level, ticket_zeroed, err,
-                           strip_rows);
+        hipLaunchKernelGGL(k_levels_syncfree<false>, dim3(grid), dim3(kBlock), 0, s, n, rp, ci, level, ticket_zeroed, err, map);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Strip-pipelined triangular solve: setup pieces (see k_sptrsv_strips in dpcg_sptrsv.hip)
 // ------------------------------------------------------------------------------------------------
 // key[i] = strip(i) * nlev + local level(i)
-__global__ __launch_bounds__(kBlock) void k_strip_keys(int64_t n, const int32_t *__restrict__ level, int strip_rows, int nlev,
+__global__ __launch_bounds__(kBlock) void k_strip_keys(int64_t n, const int32_t *__restrict__ level, StripMap map, int nlev,
                                                        int upper, uint32_t *__restrict__ key) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const int64_t idx = upper ? n - 1 - i : i;
-        key[i] = (uint32_t)((idx / strip_rows) * nlev + level[i]);
+        key[i] = (uint32_t)(map.strip_of(idx) * nlev + level[i]);
     }
 }
 
-void launch_strip_keys(int64_t n, const int32_t *level, int strip_rows, int nlev, bool upper, uint32_t *key, hipStream_t s) {
-    hipLaunchKernelGGL(k_strip_keys, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, level, strip_rows, nlev, upper ? 1 : 0, key);
+void launch_strip_keys(int64_t n, const int32_t *level, StripMap map, int nlev, bool upper, uint32_t *key, hipStream_t s) {
+    hipLaunchKernelGGL(k_strip_keys, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, level, map, nlev, upper ? 1 : 0, key);
 }
 
 // Records of the strip solve, one per position j of the (strip, level, row) order:
@@ -210,7 +209,9 @@ void launch_strip_keys(int64_t n, const int32_t *level, int strip_rows, int nlev
 //             d == -1: no such entry;  d <= -2: an entry of an EARLIER strip, column -2 - d (polled in `out`);
 //             d0 == INT_MIN: more than three off-diagonal entries, the row walks lo_rowptr;
 //   val[4j..4j+3] = {v0, v1, v2, diagonal}.
-// stats[0] = max reach (j - position of an own-strip entry), stats[1] = entries of earlier strips, stats[2] = long rows.
+// stats[0] = max reach (j - position of an own-strip entry), stats[1] = entries of earlier strips, stats[2] = long rows,
+// stats[3] = entries that live in a LATER strip (the plan is then not usable: strips are handed out in order, and a strip
+// may only wait for strips that have started).
 __global__ __launch_bounds__(kBlock) void k_strip_records(int64_t n, const uint32_t *__restrict__ key_of_pos, int nlev,
                                                           const int32_t *__restrict__ level_ptr,
                                                           const int32_t *__restrict__ rows,
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void k_strip_records(int64_t n, const uint3
                                                           int upper, int ring_reach, int32_t *__restrict__ meta,
                                                           double *__restrict__ pv, int32_t *exported, int *stats) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    int reach = 0, ext = 0, longrows = 0;
+    int reach = 0, ext = 0, longrows = 0, later = 0;
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
         int m[4] = {-1, -1, -1, -1};
         double w[4] = {0.0, 0.0, 0.0, 0.0};
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(kBlock) void k_strip_records(int64_t n, const uint3
             } else {
                 ++ext;
                 exported[lo_ci[k]] = 1;
+                if ((int)(key_of_pos[cp] / (uint32_t)nlev) > strip) ++later;
             }
             if (ke - ks <= 3) {
                 m[k - ks] = near ? cp : -2 - lo_ci[k];
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_strip_records(int64_t n, const uint3
     if (reach) atomicMax(stats, reach);
     if (ext) atomicAdd(stats + 1, ext);
     if (longrows) atomicAdd(stats + 2, longrows);
+    if (later) atomicAdd(stats + 3, later);
 }
 
 // rows some other row reads from `out` during the launch get bit 30 of their own-row field set: they are stored write-through
@@ -267,23 +270,33 @@ __global__ __launch_bounds__(kBlock) void k_strip_mark_exported(int64_t n, const
     }
 }
 
-// max over the rows of (row - smallest column) for a lower factor, (largest column - row) for an upper one: the band
+// out[0] = max over the rows of (row - smallest column) for a lower factor, (largest column - row) for an upper one: the band;
+// out[1] = max over the rows of the SECOND largest such distance: for a 3-D grid the length of a grid line (the band being a
+// plane), 1 for a 2-D grid -- what the parts of a two-way strip cut are aligned to.
 __global__ __launch_bounds__(kBlock) void k_max_band(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                      int upper, int *out) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    int m = 0;
+    int m = 0, m2 = 0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const int a = rp[i], b = rp[i + 1];
         if (b > a) {
             const int d = upper ? ci[b - 1] - (int)i : (int)i - ci[a];
             m = d > m ? d : m;
         }
+        if (b - a > 2) {                                  // (the diagonal is one of the entries)
+            const int d2 = upper ? ci[b - 2] - (int)i : (int)i - ci[a + 1];
+            m2 = d2 > m2 ? d2 : m2;
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
-        const int o = __shfl_down(m, off);
+        const int o = __shfl_down(m, off), o2 = __shfl_down(m2, off);
         m = o > m ? o : m;
+        m2 = o2 > m2 ? o2 : m2;
     }
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) {
+        if (m > 0) atomicMax(out, m);
+        if (m2 > 0) atomicMax(out + 1, m2);
+    }
 }
 
 void launch_max_band(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int *out_dev, hipStream_t s) {

@@ -339,9 +339,19 @@ void launch_iota(int64_t count, int32_t *out, hipStream_t s);
 void launch_group_offsets(int64_t count, const uint32_t *keys_sorted, int groups, int32_t *ptr, hipStream_t s);
 void launch_transpose_gather(int64_t nnz, const int32_t *perm, const int32_t *row_of, const double *val, int32_t *tcol,
                              double *tval, hipStream_t s);
+// Which strip of the strip-pipelined solve a row belongs to (idx = the row index, counted from the END for an upper factor).
+// Slabs of `rows` consecutive indices (a multiple of the band: whole planes / grid lines); parts > 1 cuts every slab once more
+// by the position inside the band, (idx % band) / sub_w -- for a grid: pencils instead of slabs, so that the longest
+// dependency chain crosses ~(slabs + parts) strip boundaries instead of `slabs * parts`.  rows == 0: no strips.
+struct StripMap {
+    int rows = 0, band = 1, sub_w = 1, parts = 1;
+    __host__ __device__ int64_t strip_of(int64_t idx) const {
+        return parts <= 1 ? idx / rows : (idx / rows) * parts + (idx % band) / sub_w;
+    }
+};
 void launch_levels_syncfree(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int32_t *level,
-                            unsigned int *ticket_zeroed, int *err, hipStream_t s, int strip_rows = 0);
-void launch_strip_keys(int64_t n, const int32_t *level, int strip_rows, int nlev, bool upper, uint32_t *key, hipStream_t s);
+                            unsigned int *ticket_zeroed, int *err, hipStream_t s, StripMap map = StripMap());
+void launch_strip_keys(int64_t n, const int32_t *level, StripMap map, int nlev, bool upper, uint32_t *key, hipStream_t s);
 void launch_strip_records(int64_t n, const uint32_t *key_of_pos, int nlev, const int32_t *level_ptr, const int32_t *rows,
                           const int32_t *lo_rp, const int32_t *lo_ci, const int32_t *lo_cp, const double *lo_v, bool upper,
                           int ring_reach, int32_t *meta, double *pv, int32_t *exported_zeroed, int *stats, hipStream_t s);

@@ -461,10 +461,123 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
     // strips are cut at multiples of the band (for a grid: whole planes / grid lines), so that an entry one band back sits one
     // strip-local level back and not dozens
     launch_max_band(n, rp, ci, upper, reinterpret_cast<int *>(ctl.p + 4), s);
-    int32_t band = 0;
-    DPCG_HIP(hipMemcpyAsync(&band, ctl.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    int32_t bands[2] = {0, 0};
+    DPCG_HIP(hipMemcpyAsync(bands, ctl.p + 4, sizeof(bands), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
-    band = band < 1 ? 1 : band;
+    const int32_t band = bands[0] < 1 ? 1 : bands[0], inner = bands[1] < 1 ? 1 : bands[1];
+    // One attempt at a plan for a given strip map; leaves lv.strips.n_strips = 0 when the plan is not kept.
+    auto attempt = [&](const StripMap &map, int64_t S) -> int {
+        DPCG_HIP(hipMemsetAsync(level.p, 0xff, (size_t)n * sizeof(int32_t), s));
+        DPCG_HIP(hipMemsetAsync(ctl.p, 0, 8 * sizeof(int32_t), s));
+        launch_levels_syncfree(n, rp, ci, upper, level.p, reinterpret_cast<unsigned int *>(ctl.p), ctl.p + 1, s, map);
+        DPCG_TRY(reduce_max_i32(level.p, ctl.p + 2, n, s));
+        int32_t h_ctl[8] = {0};
+        DPCG_HIP(hipMemcpyAsync(h_ctl, ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        if (h_ctl[1] || h_ctl[2] < 0) return DPCG_OK;            // (cannot happen: the global analysis succeeded)
+        const int nlev = h_ctl[2] + 1;
+        if ((int64_t)S * nlev > (int64_t)1 << 24) return DPCG_OK;
+        struct Pending {                                          // the plan under construction: released unless it is kept
+            Levels::Strips sp;
+            bool keep = false;
+            ~Pending() {
+                if (keep) return;
+                dev_free(sp.rows); dev_free(sp.level_ptr_dev); dev_free(sp.lo_rowptr); dev_free(sp.lo_col); dev_free(sp.lo_cpos);
+                dev_free(sp.lo_val); dev_free(sp.val); dev_free(sp.b_lo); dev_free(sp.meta); dev_free(sp.ticket);
+            }
+        } pending;
+        Levels::Strips &sp = pending.sp;
+        auto drop = [&]() { return DPCG_OK; };                    // (~Pending frees)
+        DPCG_TRY(dev_alloc(&sp.rows, n));
+        DPCG_TRY(dev_alloc(&sp.level_ptr_dev, S * nlev + 1));
+        launch_strip_keys(n, level.p, map, nlev, upper, key.p, s);
+        launch_iota(n, iota.p, s);
+        DPCG_TRY(sort_pairs_u32_i32(key.p, key_sorted.p, iota.p, sp.rows, n, bits_for((uint64_t)(S * nlev)), s));
+        launch_group_offsets(n, key_sorted.p, (int)(S * nlev), sp.level_ptr_dev, s);
+        std::vector<int32_t> lptr((size_t)(S * nlev) + 1);
+        DPCG_HIP(hipMemcpyAsync(lptr.data(), sp.level_ptr_dev, lptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        int width = 0;
+        for (size_t q = 0; q + 1 < lptr.size(); ++q) width = std::max(width, lptr[q + 1] - lptr[q]);
+        if (width > 1024) {
+            if (pt.on) fprintf(stderr, "[dpcg setup] strip plan dropped: a strip-local level has %d rows (> 1024)\n", width);
+            return drop();
+        }
+        // level-ordered copy in (strip, level, row) order
+        DPCG_TRY(len.alloc(n + 1)); DPCG_TRY(pos.alloc(n));
+        DPCG_TRY(dev_alloc(&sp.lo_rowptr, n + 1)); DPCG_TRY(dev_alloc(&sp.lo_col, nnz)); DPCG_TRY(dev_alloc(&sp.lo_cpos, nnz));
+        DPCG_TRY(dev_alloc(&sp.lo_val, nnz)); DPCG_TRY(dev_alloc(&sp.meta, n * 4)); DPCG_TRY(dev_alloc(&sp.val, n * 4));
+        DPCG_TRY(dev_alloc(&sp.b_lo, n)); DPCG_TRY(dev_alloc(&sp.ticket, 2));
+        launch_lo_lengths(n, sp.rows, rp, len.p, pos.p, s);
+        DPCG_TRY(exclusive_scan_i32(len.p, sp.lo_rowptr, n + 1, s));
+        launch_lo_copy(n, sp.rows, rp, ci, v, pos.p, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, s);
+        if (relabel) {
+            launch_relabel(n, relabel, sp.rows, s);
+            launch_relabel(nnz, relabel, sp.lo_col, s);
+        }
+        DPCG_HIP(hipMemsetAsync(ctl.p, 0, 8 * sizeof(int32_t), s));
+        DPCG_HIP(hipMemsetAsync(sp.ticket, 0, 2 * sizeof(unsigned int), s));
+        constexpr int kRingReach = 8192 - 1024 - 1;               // what a ring of 8192 doubles covers beside the widest level
+        DPCG_HIP(hipMemsetAsync(exported.p, 0, (size_t)n * sizeof(int32_t), s));
+        launch_strip_records(n, key_sorted.p, nlev, sp.level_ptr_dev, sp.rows, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, upper,
+                             kRingReach, sp.meta, sp.val, exported.p, reinterpret_cast<int *>(ctl.p), s);
+        DPCG_HIP(hipMemcpyAsync(h_ctl, ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        DPCG_CHECK_LAUNCH();
+        const int64_t reach = h_ctl[0], external = h_ctl[1], offdiag = nnz - n;
+        if (h_ctl[3] > 0) {                                       // an entry in a LATER strip: tickets could not guarantee progress
+            if (pt.on) fprintf(stderr, "[dpcg setup] strip plan (%d parts) dropped: %d entries live in later strips\n", map.parts, h_ctl[3]);
+            return drop();
+        }
+        int64_t W = 64;
+        while (W < reach + width + 1) W *= 2;
+        if (W > 8192 || (offdiag > 0 && external * 2 > offdiag)) {                   // ring too long, or mostly foreign entries
+            if (pt.on)
+                fprintf(stderr, "[dpcg setup] strip plan dropped: reach %lld + width %d -> ring %lld, %lld of %lld entries foreign\n",
+                        (long long)reach, width, (long long)W, (long long)external, (long long)offdiag);
+            return drop();
+        }
+        sp.n_strips = (int)S;
+        sp.nlev = nlev;
+        sp.W = (int)W;
+        sp.ring_reach = kRingReach;
+        sp.rows_per_thread = width <= 512 ? 1 : 2;
+        sp.threads = ((width + sp.rows_per_thread - 1) / sp.rows_per_thread + 63) / 64 * 64;
+        sp.threads = sp.threads < 64 ? 64 : sp.threads;
+        lv.strips = sp;
+        pending.keep = true;
+        init_strip_kernels();
+        // the global level schedule's big arrays are not used when the strip plan is: give the memory back
+        dev_free(lv.lo_rowptr); dev_free(lv.lo_col); dev_free(lv.lo_cpos); dev_free(lv.lo_val);
+        dev_free(lv.pk_meta); dev_free(lv.pk_val); dev_free(lv.b_lo); dev_free(lv.sf_meta); dev_free(lv.sf_val);
+        return DPCG_OK;
+    };
+    // First the two-way cut (slabs of whole bands x parts of a band: for a grid, pencils): the longest dependency chain then
+    // crosses about slabs + parts strip boundaries (2.7 us each) instead of slabs * parts.  Kept only if every entry lives in
+    // the own or an EARLIER strip (true for natural-order grids; checked, not assumed).
+    static const bool two_way = [] { const char *e = getenv("DPCG_STRIP_PARTS"); return !(e && e[0] == '1' && e[1] == 0); }();
+    const int64_t want = (n + target_rows - 1) / target_rows;              // strips of ~target_rows rows
+    if (two_way && band >= 128 && want >= 8) {
+        int parts = (int)std::llround(std::sqrt((double)want));
+        parts = std::max(2, std::min<int>(16, std::min<int>(parts, band / 32)));
+        StripMap map;
+        map.band = band;
+        // parts are cut at multiples of the inner band (for a 3-D grid: whole grid lines -- a part that starts in the middle of a
+        // line trails its neighbour by half a strip instead of a few levels: measured, 100^3, 72 us instead of 12 us per part)
+        map.sub_w = ((band + parts - 1) / parts + inner - 1) / inner * inner;
+        map.parts = (band + map.sub_w - 1) / map.sub_w;
+        int64_t slabs = std::max<int64_t>(1, (want + map.parts - 1) / map.parts);
+        int64_t rows64 = ((n + slabs - 1) / slabs + band - 1) / band * band;
+        slabs = (n + rows64 - 1) / rows64;
+        if (slabs * map.parts <= 256 && rows64 < ((int64_t)1 << 31)) {
+            map.rows = (int)rows64;
+            DPCG_TRY(attempt(map, slabs * map.parts));
+            if (lv.strips.n_strips > 0) {
+                pt.mark(upper ? "strip plan (L^T, two-way)" : "strip plan (L, two-way)");
+                return DPCG_OK;
+            }
+        }
+    }
     int64_t per = (target_rows + band / 2) / band;
     per = per < 1 ? 1 : per;
     int64_t strip_rows64 = per * band;
@@ -474,86 +587,10 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
         S = (n + strip_rows64 - 1) / strip_rows64;
     }
     if (S < 4) return DPCG_OK;
-    const int strip_rows = (int)strip_rows64;
-    DPCG_HIP(hipMemsetAsync(level.p, 0xff, (size_t)n * sizeof(int32_t), s));
-    DPCG_HIP(hipMemsetAsync(ctl.p, 0, 8 * sizeof(int32_t), s));
-    launch_levels_syncfree(n, rp, ci, upper, level.p, reinterpret_cast<unsigned int *>(ctl.p), ctl.p + 1, s, strip_rows);
-    DPCG_TRY(reduce_max_i32(level.p, ctl.p + 2, n, s));
-    int32_t h_ctl[8] = {0};
-    DPCG_HIP(hipMemcpyAsync(h_ctl, ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
-    DPCG_HIP(hipStreamSynchronize(s));
-    if (h_ctl[1] || h_ctl[2] < 0) return DPCG_OK;            // (cannot happen: the global analysis succeeded)
-    const int nlev = h_ctl[2] + 1;
-    if ((int64_t)S * nlev > (int64_t)1 << 24) return DPCG_OK;
-    struct Pending {                                          // the plan under construction: released unless it is kept
-        Levels::Strips sp;
-        bool keep = false;
-        ~Pending() {
-            if (keep) return;
-            dev_free(sp.rows); dev_free(sp.level_ptr_dev); dev_free(sp.lo_rowptr); dev_free(sp.lo_col); dev_free(sp.lo_cpos);
-            dev_free(sp.lo_val); dev_free(sp.val); dev_free(sp.b_lo); dev_free(sp.meta); dev_free(sp.ticket);
-        }
-    } pending;
-    Levels::Strips &sp = pending.sp;
-    auto drop = [&]() { return DPCG_OK; };                    // (~Pending frees)
-    DPCG_TRY(dev_alloc(&sp.rows, n));
-    DPCG_TRY(dev_alloc(&sp.level_ptr_dev, S * nlev + 1));
-    launch_strip_keys(n, level.p, strip_rows, nlev, upper, key.p, s);
-    launch_iota(n, iota.p, s);
-    DPCG_TRY(sort_pairs_u32_i32(key.p, key_sorted.p, iota.p, sp.rows, n, bits_for((uint64_t)(S * nlev)), s));
-    launch_group_offsets(n, key_sorted.p, (int)(S * nlev), sp.level_ptr_dev, s);
-    std::vector<int32_t> lptr((size_t)(S * nlev) + 1);
-    DPCG_HIP(hipMemcpyAsync(lptr.data(), sp.level_ptr_dev, lptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    DPCG_HIP(hipStreamSynchronize(s));
-    int width = 0;
-    for (size_t q = 0; q + 1 < lptr.size(); ++q) width = std::max(width, lptr[q + 1] - lptr[q]);
-    if (width > 1024) {
-        if (pt.on) fprintf(stderr, "[dpcg setup] strip plan dropped: a strip-local level has %d rows (> 1024)\n", width);
-        return drop();
-    }
-    // level-ordered copy in (strip, level, row) order
-    DPCG_TRY(len.alloc(n + 1)); DPCG_TRY(pos.alloc(n));
-    DPCG_TRY(dev_alloc(&sp.lo_rowptr, n + 1)); DPCG_TRY(dev_alloc(&sp.lo_col, nnz)); DPCG_TRY(dev_alloc(&sp.lo_cpos, nnz));
-    DPCG_TRY(dev_alloc(&sp.lo_val, nnz)); DPCG_TRY(dev_alloc(&sp.meta, n * 4)); DPCG_TRY(dev_alloc(&sp.val, n * 4));
-    DPCG_TRY(dev_alloc(&sp.b_lo, n)); DPCG_TRY(dev_alloc(&sp.ticket, 2));
-    launch_lo_lengths(n, sp.rows, rp, len.p, pos.p, s);
-    DPCG_TRY(exclusive_scan_i32(len.p, sp.lo_rowptr, n + 1, s));
-    launch_lo_copy(n, sp.rows, rp, ci, v, pos.p, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, s);
-    if (relabel) {
-        launch_relabel(n, relabel, sp.rows, s);
-        launch_relabel(nnz, relabel, sp.lo_col, s);
-    }
-    DPCG_HIP(hipMemsetAsync(ctl.p, 0, 8 * sizeof(int32_t), s));
-    DPCG_HIP(hipMemsetAsync(sp.ticket, 0, 2 * sizeof(unsigned int), s));
-    constexpr int kRingReach = 8192 - 1024 - 1;               // what a ring of 8192 doubles covers beside the widest level
-    DPCG_HIP(hipMemsetAsync(exported.p, 0, (size_t)n * sizeof(int32_t), s));
-    launch_strip_records(n, key_sorted.p, nlev, sp.level_ptr_dev, sp.rows, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, upper,
-                         kRingReach, sp.meta, sp.val, exported.p, reinterpret_cast<int *>(ctl.p), s);
-    DPCG_HIP(hipMemcpyAsync(h_ctl, ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
-    DPCG_HIP(hipStreamSynchronize(s));
-    DPCG_CHECK_LAUNCH();
-    const int64_t reach = h_ctl[0], external = h_ctl[1], offdiag = nnz - n;
-    int64_t W = 64;
-    while (W < reach + width + 1) W *= 2;
-    if (W > 8192 || (offdiag > 0 && external * 2 > offdiag)) {                   // ring too long, or mostly foreign entries
-        if (pt.on)
-            fprintf(stderr, "[dpcg setup] strip plan dropped: reach %lld + width %d -> ring %lld, %lld of %lld entries foreign\n",
-                    (long long)reach, width, (long long)W, (long long)external, (long long)offdiag);
-        return drop();
-    }
-    sp.n_strips = (int)S;
-    sp.nlev = nlev;
-    sp.W = (int)W;
-    sp.ring_reach = kRingReach;
-    sp.rows_per_thread = width <= 512 ? 1 : 2;
-    sp.threads = ((width + sp.rows_per_thread - 1) / sp.rows_per_thread + 63) / 64 * 64;
-    sp.threads = sp.threads < 64 ? 64 : sp.threads;
-    lv.strips = sp;
-    pending.keep = true;
-    init_strip_kernels();
-    // the global level schedule's big arrays are not used when the strip plan is: give the memory back
-    dev_free(lv.lo_rowptr); dev_free(lv.lo_col); dev_free(lv.lo_cpos); dev_free(lv.lo_val);
-    dev_free(lv.pk_meta); dev_free(lv.pk_val); dev_free(lv.b_lo); dev_free(lv.sf_meta); dev_free(lv.sf_val);
+    StripMap map;
+    map.rows = (int)strip_rows64;
+    map.band = band;
+    DPCG_TRY(attempt(map, S));
     pt.mark(upper ? "strip plan (L^T)" : "strip plan (L)");
     return DPCG_OK;
 }

@@ -545,9 +545,12 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
                                                        const int32_t *__restrict__ lo_cpos, const double *__restrict__ lo_v,
                                                        const int4 *__restrict__ pk_meta, const double2 *__restrict__ pk_val,
                                                        const double *__restrict__ b_lo, double *out, int W,
-                                                       int ring_reach, unsigned int *ticket, const int *done, int *err) {
+                                                       int ring_reach, unsigned int *ticket, const int *done, int *err,
+                                                       long long *trace /* development: per strip {start, end, polls, levels} */) {
     if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     extern __shared__ __attribute__((aligned(16))) double ring[];
+    const long long t_start = trace ? (long long)wall_clock64() : 0;
+    int n_polls = 0;
     int *lp = reinterpret_cast<int *>(ring + W);        // level offsets of this strip, padded with empty levels
     __shared__ unsigned int s_strip;
     __shared__ int s_nl;
@@ -604,6 +607,7 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
     // an entry of an earlier strip: poll until its owner has stored it (bounded)
     auto poll = [&](int col) {
         double y;
+        ++n_polls;
         for (unsigned spins = 0;; ++spins) {
             y = __hip_atomic_load(out + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!is_pending(y)) break;
@@ -692,6 +696,14 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
             retire(S1);
             load_chunk(S0, c + 2);
             solve_chunk(S1);
+        }
+    }
+    if (trace) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(trace + 4 * s_strip + 2), (unsigned long long)n_polls);
+        if (t == 0) {
+            trace[4 * s_strip] = t_start;
+            trace[4 * s_strip + 1] = (long long)wall_clock64();
+            trace[4 * s_strip + 3] = nl;
         }
     }
     if (t == 0 && atomicAdd(ticket + 1, 1u) == gridDim.x - 1) {      // last one out: zero the counters for the next launch
@@ -811,11 +823,17 @@ static void launch_schedule(int64_t n, const Levels &lv, bool upper, bool lm, co
                            count, done);
         constexpr int CH = kStripChunk;
         const size_t lds = (size_t)sp.W * sizeof(double) + (size_t)(sp.nlev + 3 * CH + 8) * sizeof(int);
+        // DPCG_STRIP_TRACE=1 (development, never under capture): the timeline of the strips of every launch on stderr
+        static const bool trace_on = [] { const char *e = getenv("DPCG_STRIP_TRACE"); return e && e[0] == '1'; }();
+        long long *trace_buf = nullptr;
+        if (trace_on && hipMalloc(&trace_buf, (size_t)sp.n_strips * 4 * sizeof(long long)) == hipSuccess)
+            (void)hipMemsetAsync(trace_buf, 0, (size_t)sp.n_strips * 4 * sizeof(long long), s);
 #define DPCG_STRIPS(UP, CV, ROWSV)                                                                                        \
     do {                                                                                                                  \
         hipLaunchKernelGGL((k_sptrsv_strips<UP, CV, ROWSV>), dim3(sp.n_strips), dim3(sp.threads), lds, s, sp.level_ptr_dev, \
                            sp.nlev, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, (const int4 *)sp.meta,                 \
-                           (const double2 *)sp.val, sp.b_lo, out, sp.W, sp.ring_reach, sp.ticket, done, lv.spin_err);      \
+                           (const double2 *)sp.val, sp.b_lo, out, sp.W, sp.ring_reach, sp.ticket, done, lv.spin_err,       \
+                           trace_buf);                                                                                     \
     } while (0)
         if (sp.rows_per_thread == 1) {
             if (upper) DPCG_STRIPS(true, CH, 1);
@@ -825,6 +843,18 @@ static void launch_schedule(int64_t n, const Levels &lv, bool upper, bool lm, co
             else DPCG_STRIPS(false, CH / 2, 2);
         }
 #undef DPCG_STRIPS
+        if (trace_buf) {
+            std::vector<long long> h((size_t)sp.n_strips * 4);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h.data(), trace_buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            (void)hipFree(trace_buf);
+            long long t0 = h[0];
+            for (int q = 0; q < sp.n_strips; ++q) t0 = std::min(t0, h[4 * (size_t)q]);
+            fprintf(stderr, "[strip trace] %s, %d strips (100 MHz clock: us)\n", upper ? "upper" : "lower", sp.n_strips);
+            for (int q = 0; q < sp.n_strips; ++q)
+                fprintf(stderr, "  strip %3d  start %8.2f  end %8.2f  levels %4lld  polls %6lld\n", q, (h[4 * (size_t)q] - t0) / 100.0,
+                        (h[4 * (size_t)q + 1] - t0) / 100.0, h[4 * (size_t)q + 3], h[4 * (size_t)q + 2]);
+        }
         return;
     }
     int seg_index = -1;

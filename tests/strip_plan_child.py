@@ -18,7 +18,8 @@ from oracle import oracle as O  # noqa: E402
 
 out = {}
 for name, A in (("poisson3d_40", O.poisson3d(40)), ("poisson2d_300", O.poisson2d(300)),
-                ("unstructured3d_36_rcm", O.unstructured_like(O.poisson3d(36), seed=3))):
+                ("unstructured3d_36_rcm", O.unstructured_like(O.poisson3d(36), seed=3)),
+                ("poisson3d_56", O.poisson3d(56)), ("poisson2d_400", O.poisson2d(400))):      # large enough for the two-way cut
     n = A.shape[0]
     S = D.CsrSystem.from_any(A, reorder="rcm" if name.endswith("rcm") else None)
     L = CO.ic0(A)

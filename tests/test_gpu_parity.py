@@ -1414,6 +1414,7 @@ def test_strip_pipelined_triangular_solves():
                           env=env, timeout=900)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
     assert "strip plan (L)" in proc.stderr and "strip plan (L^T)" in proc.stderr      # the path under test was taken
+    assert "strip plan (L, two-way)" in proc.stderr and "strip plan (L^T, two-way)" in proc.stderr   # ... in both its forms
     out = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][-1])
     for name, rec in out.items():
         for mode in ("ic0", "user_factor"):
