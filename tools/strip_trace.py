@@ -1,4 +1,4 @@
-"""DPCG_STRIP_TRACE=1 python tools/strip_trace.py dim size: the per-strip timeline of ONE lower and ONE upper strip-pipelined solve
+"""DPCG_STRIP_TRACE=1 python tools/strip_trace.py dim size [repeats]: the per-strip timeline of ONE lower and ONE upper strip-pipelined solve
 (IC(0) factor of a natural-order grid) on stderr."""
 import sys
 import torch
@@ -10,5 +10,6 @@ s = poisson.poisson_system(dim, size)
 s.set_preconditioner(D.IC0("solve"))
 r = poisson.rhs(s.n, 0)
 print("==== traced", file=sys.stderr, flush=True)
-s.sptrsv(r, False)
-torch.cuda.synchronize()
+for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):     # repeated: the later solves find their records in L2 / MALL
+    s.sptrsv(r, False)
+    torch.cuda.synchronize()
