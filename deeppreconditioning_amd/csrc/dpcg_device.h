@@ -148,10 +148,14 @@ __device__ __forceinline__ void record_and_test(Scalars *sc, double rr, double r
 // x lags one update behind; k_final_fused applies the last one.  Before the first update rz_prev = +inf and
 // alpha = 0, P[1] = 0, so update 0 degenerates to p_0 = z_0, x unchanged.  Scalars obey the same rule as in the
 // three-kernel form: nobody reads a word that the same kernel writes (`done` excepted: a workgroup that sees it
-// set early returns, which is what it would have decided anyway).
+// set early returns -- ALL its waves together --, which is what it would have decided anyway).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool fused_head(Scalars *sc, const FuseArgs &f, double *sh, double &alpha, double &beta) {
-    if (sc->done) return false;
+    // `done` may be set by workgroup 0 of THIS launch while a late workgroup starts: the waves of that workgroup must then
+    // agree on what they saw -- a wave that left alone would leave its slots of the block reduction below unwritten, the
+    // others would read stale LDS there, miss the stop and apply the deferred x += alpha p a second time (seen with several
+    // solves sharing the chip: the last increment doubled in 64-row runs).  One barrier-wide OR makes the exit uniform.
+    if (__syncthreads_or(sc->done)) return false;
     const int k = sc->k;                                   // updates completed (written by KB / the initial state)
     double rz = 0.0, rr = 0.0;
     for (int i = threadIdx.x; i < f.n_part; i += kBlock) rz += f.part_rz[i];

@@ -200,7 +200,7 @@ void launch_dot_partials(int64_t n, const Scalars *scal, const double *a, const 
 
 // x += alpha p; p = z + beta p (cg.py:79,82-83); optionally also the fp32 copy of p that the
 // mixed-precision SpMV gathers.
-template <bool P32>
+template <bool P32, bool MANY>   // MANY: more than kVecPartSlots * kBlock partials of <r,z> (an M-apply's SpMV summed them)
 __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__restrict__ sc,
                                                       const double *__restrict__ part_rz,
                                                       const double *__restrict__ part_rr, int n_part,
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
     // apply x += alpha p for its rows (cg.py:79 precedes the test of cg.py:86).
     // as in K2: one exposed round trip at the head (more than kVecPartSlots * kBlock partials -- an M-apply's SpMV summed
     // <r,z> -- take the loop form)
-    const bool many = n_part > kVecPartSlots * kBlock;
+    constexpr bool many = MANY;
     EarlyPartials<kVecPartSlots> ep;
     ep.request(part_rz, many ? 1 : n_part);
     const int done_seen = sc->done_seen;
@@ -282,12 +282,18 @@ __global__ __launch_bounds__(kBlock) void k_update_xp(int64_t n, Scalars *__rest
 void launch_update_xp(int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
                       const double *z, double *p, double *x, float *p32, double *hist, int hist_cap, int grid,
                       hipStream_t s, const double *zd, int n_part_rr) {
-    if (p32)
-        hipLaunchKernelGGL(k_update_xp<true>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, part_rr, n_part, z, p,
-                           x, p32, hist, hist_cap, zd, n_part_rr);
-    else
-        hipLaunchKernelGGL(k_update_xp<false>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, part_rr, n_part, z, p,
-                           x, p32, hist, hist_cap, zd, n_part_rr);
+    const bool many = n_part > kVecPartSlots * kBlock;
+#define DPCG_K3(P32V, MANYV)                                                                                           \
+    hipLaunchKernelGGL((k_update_xp<P32V, MANYV>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, part_rr, n_part, z, p, \
+                       x, p32, hist, hist_cap, zd, n_part_rr)
+    if (p32) {
+        if (many) DPCG_K3(true, true);
+        else DPCG_K3(true, false);
+    } else {
+        if (many) DPCG_K3(false, true);
+        else DPCG_K3(false, false);
+    }
+#undef DPCG_K3
 }
 
 // K3 with the x update deferred.  x is only an output, and every write costs more than a read here, so x is brought
@@ -295,7 +301,7 @@ void launch_update_xp(int64_t n, Scalars *scal, const double *part_rz, const dou
 //                                  odd update j+1 -> x = (x + alpha_j p_j) + alpha_{j+1} p_{j+1}, then p_{j+2} over p_j.
 // Same operations in the same order as x += alpha p every update (cg.py:79): bit-identical iterates; per two updates
 // one x read and one x write are replaced by one extra read of p.  k_final_deferred applies a pending half.
-template <bool P32, bool ODD>
+template <bool P32, bool ODD, bool MANY>
 __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalars *__restrict__ sc,
                                                                const double *__restrict__ part_rz,
                                                                const double *__restrict__ part_rr, int n_part,
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalar
         }
         if (zd) da = zd2[i];
     }
-    const bool many = n_part > kVecPartSlots * kBlock;                  // see k_update_xp
+    constexpr bool many = MANY;                                         // see k_update_xp
     EarlyPartials<kVecPartSlots> ep;                                    // as in K2: one exposed round trip at the head
     ep.request(part_rz, many ? 1 : n_part);
     const int done_seen = sc->done_seen;                                // see k_update_xp: never `done` here
@@ -393,16 +399,23 @@ __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalar
 void launch_update_xp_deferred(bool odd, int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
                                const double *z, const double *p_in, double *p_out, double *x, float *p32, double *hist,
                                int hist_cap, int grid, hipStream_t s, const double *zd, int n_part_rr) {
-#define DPCG_K3D(P32V, ODDV)                                                                                            \
-    hipLaunchKernelGGL((k_update_xp_deferred<P32V, ODDV>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, part_rr, \
-                       n_part, z, p_in, p_out, x, p32, hist, hist_cap, zd, n_part_rr)
+    const bool many = n_part > kVecPartSlots * kBlock;
+#define DPCG_K3D(P32V, ODDV, MANYV)                                                                                     \
+    hipLaunchKernelGGL((k_update_xp_deferred<P32V, ODDV, MANYV>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz,     \
+                       part_rr, n_part, z, p_in, p_out, x, p32, hist, hist_cap, zd, n_part_rr)
+#define DPCG_K3D_MANY(P32V, ODDV) \
+    do {                          \
+        if (many) DPCG_K3D(P32V, ODDV, true); \
+        else DPCG_K3D(P32V, ODDV, false);     \
+    } while (0)
     if (p32) {
-        if (odd) DPCG_K3D(true, true);
-        else DPCG_K3D(true, false);
+        if (odd) DPCG_K3D_MANY(true, true);
+        else DPCG_K3D_MANY(true, false);
     } else {
-        if (odd) DPCG_K3D(false, true);
-        else DPCG_K3D(false, false);
+        if (odd) DPCG_K3D_MANY(false, true);
+        else DPCG_K3D_MANY(false, false);
     }
+#undef DPCG_K3D_MANY
 #undef DPCG_K3D
 }
 

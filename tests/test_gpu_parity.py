@@ -1078,14 +1078,16 @@ def test_solve_specs_local_concurrent_equals_sequential(D):
 
 
 # ---- round 2: the `done` hand-off of K3 and the p-buffer parity of replayed chunks ---------------------------------
-def test_last_x_update_survives_multi_stream_contention(D):
+@pytest.mark.parametrize("form", ["three_kernel", "two_kernel"])
+def test_last_x_update_survives_multi_stream_contention(D, form):
     """cg.py:79 updates x BEFORE the test of cg.py:86.  K3 (x += alpha p, workgroup 0 runs the test) must therefore
     apply the converged update in EVERY workgroup, also in one that is dispatched after workgroup 0 has set `done` --
     which is what happens when eight solves share the GPU with a CU-saturating kernel.  32 mid-size systems on the
-    three-kernel path (NO_SMALL | NO_FUSE), 8 streams, 100 rounds, a GEMM stream running beside them: every x must
-    be bit-identical to the one-at-a-time solve and match the C oracle."""
+    three-kernel path (NO_SMALL | NO_FUSE) and on the two-kernel path (whose head must leave workgroup-uniformly when
+    it sees `done` early, or the last increment is applied twice), 8 streams, 100 rounds, a GEMM stream running beside
+    them: every x must be bit-identical to the one-at-a-time solve and match the C oracle."""
     from deeppreconditioning_amd.batch import solve_batch
-    flags = D._lib.NO_SMALL | D._lib.NO_FUSE
+    flags = D._lib.NO_SMALL | (D._lib.NO_FUSE if form == "three_kernel" else 0)
     mats = [O.poisson2d(96 + 2 * i) for i in range(32)]                         # 9 216 ... 24 964 rows
     systems = [D.CsrSystem.from_any(A) for A in mats]
     for S in systems:
