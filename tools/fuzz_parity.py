@@ -1,7 +1,7 @@
 """Randomised differential test: random sparse SPD systems (sizes around every kernel-selection boundary, row lengths
 from 1 to ~50, banded or scrambled) through every preconditioner kind, HIP path vs the C oracle.  Prints mismatches.
 
-    python tools/fuzz_parity.py [cases] [seed]
+    python tools/fuzz_parity.py [cases] [seed] [only_case]
 """
 import sys
 import numpy as np
@@ -13,6 +13,7 @@ from oracle import oracle as O
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None      # replay ONE case of a seed (same random draws), with its histories
 SIZES = [1, 2, 63, 64, 255, 256, 257, 1000, 3071, 3072, 3073, 4608, 4609, 6144, 6145, 9000, 20000, 70000, 400000]
 
 
@@ -52,6 +53,11 @@ for case in range(cases):
     reorder = str(rng.choice(["auto", "auto", "rcm"]))          # a third of the cases force the library's reordering
     tag = (f"case {case}: n={n} nnz/row={A.nnz / n:.1f} band={band} scramble={scramble} fp32vals={fp32_values} "
            f"x0={x0 is not None} reorder={reorder}")
+    if only is not None and case != only:      # consume what the case would have drawn, skip the work
+        rng.uniform(-1, 1, n)
+        if n <= 6145:
+            rng.choice([0.0, 0.01, 0.1])
+        continue
     S = D.CsrSystem.from_any(A, reorder=reorder)
     # a reordered handle iterates on B = P A P^T: that is the system the oracle is run on (vectors permuted alike); what the
     # caller hands over or gets back stays in the caller's numbering
@@ -141,6 +147,14 @@ for case in range(cases):
                     d_all = np.abs(hist_np[:mo] - hist[:mo])[big] / np.abs(hist[:mo])[big]
                     chaotic = chaotic or len(hist_np) != len(hist) or (d_all.size and float(d_all.max()) > 1e-3)
                 head = min(m, 8 if chaotic else m)
+                if hist_np is not None and not chaotic and len(hist_np) == len(hist):
+                    # superlinear end phase of a small system: rounding differences grow ~15x per update (seed 21, case 86: the
+                    # two CPU oracles drift to 2e-6, the device to 6e-4 over the last nine updates).  Entries are comparable while
+                    # the oracles still agree to 1e-13; the count is checked on all of them.
+                    dd = np.abs(hist_np[:m] - hist[:m]) / np.maximum(np.abs(hist[:m]), 1e-300)
+                    late = np.nonzero(dd > 1e-13)[0]
+                    if late.size:
+                        head = min(head, int(late[0]))
                 sig = np.abs(hist[:head]) > 1e-22
                 rel = np.abs(h[:head] - hist[:head])[sig] / np.abs(hist[:head])[sig]
                 tol = 1e-6 if chaotic else 1e-8
@@ -151,6 +165,11 @@ for case in range(cases):
                     tol = max(tol, 30 * float(drift.max()) if drift.size else tol)
                 hist_ok = rel.size == 0 or float(rel.max()) < tol
                 count_ok = abs(r.iterations - it) <= (0.06 * it + 2 if chaotic else 0)
+                if only is not None:
+                    np.set_printoptions(precision=6, linewidth=200)
+                    print(kind, "flags", flags, "GPU / C oracle - 1:", (h[:m] / hist[:m] - 1))
+                    if hist_np is not None:
+                        print(kind, "numpy oracle / C oracle - 1:", (hist_np[:min(len(hist_np), len(hist))] / hist[:min(len(hist_np), len(hist))] - 1))
                 if not (hist_ok and count_ok):
                     bad += 1
                     print("PCG MISMATCH", tag, kind, f"flags={flags}", "iters", r.iterations, it, "status", r.status,
