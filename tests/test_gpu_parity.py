@@ -1425,6 +1425,36 @@ def test_strip_pipelined_triangular_solves():
             assert r["iterations"][0] == r["iterations"][1] and r["hist_rel"] < 1e-9, (name, mode, r)
 
 
+def test_rz_partials_summed_by_the_last_spmv_of_an_m_apply(D):
+    """A CSR M (and L L^T multiplied) hands <r,z> over as the per-workgroup partials of the SpMV that applied it -- up to 2048 of
+    them: more than the vector kernels' early-partials slots hold, so K3 takes its loop form (three-kernel updates), the two-kernel
+    head its plain loop.  160 000 rows: 625 partials.  Diagonal M as an explicit CSR matrix against the C oracle ("csr") and
+    against the fused Jacobi path; IC(0) multiplied against the oracle's first entries (the reference's unstable technique)."""
+    A = O.poisson2d(400)
+    n = A.shape[0]
+    b = O.rhs(n, 3)
+    dinv = O.jacobi_dinv(A)
+    M = sp.diags(dinv).tocsr()
+    S = D.CsrSystem.from_any(A)
+    _, it, hist, xs = CO.pcg(A, b, "csr", M=M)
+    S.set_preconditioner(D.Jacobi())
+    jac = S.solve(_dev(b))
+    assert jac.iterations == it
+    S.set_preconditioner(D.CsrPreconditioner(M))
+    for flags in (0, D._lib.NO_FUSE, D._lib.NO_FUSE | D._lib.NO_GRAPH):
+        res = S.solve(_dev(b), flags=flags)
+        assert res.iterations == it and res.status == 0
+        np.testing.assert_allclose(res.res_history, hist, rtol=HIST_RTOL)
+        np.testing.assert_allclose(res.x.cpu().numpy(), xs, rtol=1e-8, atol=1e-11)
+    L = CO.ic0(A)
+    _, it2, hist2, _ = CO.pcg(A, b, "llt_multiply", L=L)
+    S.set_preconditioner(D.LLtMultiply(L))
+    for flags in (0, D._lib.NO_FUSE):
+        res = S.solve(_dev(b), flags=flags)
+        np.testing.assert_allclose(res.res_history[:8], hist2[:8], rtol=1e-9)
+    S.close()
+
+
 def test_level_major_triangular_solves(D):
     """The level-major form of the triangular solves (few wide levels: the solve runs in the factor's own level-order numbering,
     the two solves of an apply hand the vector over without way-in passes; width-6 records) forced on small factors in a child
