@@ -405,9 +405,9 @@ __global__ __launch_bounds__(kBlock) void k_fill_pending(const int32_t *__restri
 }
 
 // The kernel works on fixed-width records (Levels::sf_meta / sf_val): everything a row needs -- three column indices,
-// three values, the diagonal, its own index -- comes from two 16-byte and one 32-byte load addressed by the level-order
+// three (or six: SfRec) values, the diagonal, its own index -- comes from a few 16-byte loads addressed by the level-order
 // position alone, issued the moment the block is drawn; no row extents to wait for, no LDS stage, no workgroup barrier
-// besides the ticket hand-out.  Rows with more than three off-diagonal entries (meta.x == -2) walk lo_rowptr.
+// besides the ticket hand-out.  Rows with more entries than a record holds (col[0] == -2) walk lo_rowptr.
 // The grid is PERSISTENT and sized to the wavefront (about twice the widest level): a workgroup draws the next 256-row
 // block when it has finished one, so only rows near the front are resident and polling.  (With one workgroup per block
 // and the whole factor resident, thousands of waves polled entries tens of levels away; their requests saturated the
@@ -416,8 +416,10 @@ __global__ __launch_bounds__(kBlock) void k_fill_pending(const int32_t *__restri
 // Measured per apply (two solves), IC(0) of natural-order grids: 64^3 (190 levels) 1.05 ms vs 1.41 ms with one launch per
 // level; 100^3 (298 levels) 1.47 vs 2.46 ms.  A run of VERY wide levels (the scrambled 1M-DoF factor: 19 levels of ~52K
 // rows) is the other way round -- 0.43 ms vs 0.31 ms: there the level bodies, not the boundaries, are the cost, the
-// polling loads bypass the L1, and rows several levels ahead of the front poll for nothing -- so such runs keep one
-// launch per level (build_levels: mean level width > 16384).
+// polling loads bypass the L1, and rows several levels ahead of the front poll for nothing -- in the HANDLE's numbering such
+// runs keep one launch per level (build_levels: mean level width > 16384); a factor made of them is solved level-major instead
+// (Levels::level_major: contiguous levels, ONE launch of this kernel per solve with a window of 0.85 x the widest level and
+// 512 rows per ticket; rhs_map / refill: see SptrsvIo::fused_entry).
 template <bool UPPER, int BS, int W>   // BS rows (= threads) per ticket, records of width W
 __global__ __launch_bounds__(BS) void k_sptrsv_syncfree_rec(int j0, int count, const int32_t *__restrict__ lo_rp,
                                                             const int32_t *__restrict__ lo_ci,
