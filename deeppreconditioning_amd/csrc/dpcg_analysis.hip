@@ -471,14 +471,15 @@ void launch_ring_records(int64_t n, const uint32_t *lvl_of_pos, const int32_t *r
 //                such entry; c0 = -2: more than three, the row walks lo_rowptr instead) and its own row index;
 //   sf_val[4j..4j+3] = {v0, v1, v2, diagonal}.
 // Factors with many longer rows (an unstructured mesh in its own numbering: up to 6 lower neighbours on a 7-point graph) take
-// the width-6 form (Levels::rec_w): 8 ints {c0..c5, row, -} and 8 doubles {v0..v5, diagonal, -} per row.
+// the width-6 form (Levels::rec_w): 8 ints {c0..c5, row, -} and 8 doubles {v0..v5, diagonal, -} per row; factors with fill
+// (ICT) the width-12 form, 16 + 16.
 // Addressed by position alone, so a row's data can be requested before anything about the row is known.
-template <int W>   // W = 3: meta 4 ints {c0,c1,c2,row}, val 4 doubles {v0,v1,v2,diag}; W = 6: meta 8 ints {c0..c5,row,-}, val 8 doubles {v0..v5,diag,-}
+template <int W>   // W = 3 / 6 / 12 entries; a record is S = 4 / 8 / 16 ints {c0..c(W-1), row, -...} and S doubles {v0..v(W-1), diag, -...}
 __global__ __launch_bounds__(kBlock) void k_sf_records(int64_t n, const int32_t *__restrict__ rows,
                                                        const int32_t *__restrict__ lo_rp, const int32_t *__restrict__ lo_ci,
                                                        const double *__restrict__ lo_v, int upper, int32_t *__restrict__ meta,
                                                        double *__restrict__ pv) {
-    constexpr int S = W == 3 ? 4 : 8;                                  // record stride (ints / doubles)
+    constexpr int S = W == 3 ? 4 : (W == 6 ? 8 : 16);                  // record stride (ints / doubles)
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
         int m[S];
@@ -526,7 +527,9 @@ void launch_compose_positions(int64_t n, const int32_t *rows, const int32_t *pos
 
 void launch_sf_records(int64_t n, const int32_t *rows, const int32_t *lo_rp, const int32_t *lo_ci, const double *lo_v,
                        bool upper, int32_t *meta, double *pv, int width, hipStream_t s) {
-    if (width == 6)
+    if (width == 12)
+        hipLaunchKernelGGL(k_sf_records<12>, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows, lo_rp, lo_ci, lo_v, upper ? 1 : 0, meta, pv);
+    else if (width == 6)
         hipLaunchKernelGGL(k_sf_records<6>, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows, lo_rp, lo_ci, lo_v, upper ? 1 : 0, meta, pv);
     else
         hipLaunchKernelGGL(k_sf_records<3>, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows, lo_rp, lo_ci, lo_v, upper ? 1 : 0, meta, pv);

@@ -389,16 +389,17 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         for (const auto &seg : lv.segments) any = any || !(seg.merged && seg.ring_w > 0);
         if (any) {                                       // records for the sync-free and the per-level kernels
             // width of the records: 3 entries unless more than 2 % of the rows are longer (they would take the slow general
-            // path: three dependent loads before the first entry, then one entry at a time)
+            // path: three dependent loads before the first entry, then one entry at a time), then 6, then 12
             DevBuf<int32_t> n_long;
-            DPCG_TRY(n_long.alloc(1));
-            DPCG_HIP(hipMemsetAsync(n_long.p, 0, sizeof(int32_t), s));
+            DPCG_TRY(n_long.alloc(2));
+            DPCG_HIP(hipMemsetAsync(n_long.p, 0, 2 * sizeof(int32_t), s));
             launch_count_long_rows(n, lv.lo_rowptr, 3, n_long.p, s);
-            int32_t h_long = 0;
-            DPCG_HIP(hipMemcpyAsync(&h_long, n_long.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            launch_count_long_rows(n, lv.lo_rowptr, 6, n_long.p + 1, s);
+            int32_t h_long[2] = {0, 0};
+            DPCG_HIP(hipMemcpyAsync(h_long, n_long.p, sizeof(h_long), hipMemcpyDeviceToHost, s));
             DPCG_HIP(hipStreamSynchronize(s));
-            lv.rec_w = (int64_t)h_long * 50 > n ? 6 : 3;
-            const int64_t stride = lv.rec_w == 6 ? 8 : 4;
+            lv.rec_w = (int64_t)h_long[1] * 50 > n ? 12 : ((int64_t)h_long[0] * 50 > n ? 6 : 3);
+            const int64_t stride = lv.rec_w == 12 ? 16 : (lv.rec_w == 6 ? 8 : 4);
             DPCG_TRY(dev_alloc(&lv.sf_meta, n * stride));
             DPCG_TRY(dev_alloc(&lv.sf_val, n * stride));
             if (lv.level_major)

@@ -81,19 +81,30 @@ struct SfRec {
 
 template <int W>
 __device__ __forceinline__ SfRec<W> load_sf_record(const int32_t *__restrict__ meta, const double *__restrict__ val, int64_t j) {
-    SfRec<W> r;
-    if constexpr (W == 3) {
-        const int4 m = reinterpret_cast<const int4 *>(meta)[j];
-        const double2 a = reinterpret_cast<const double2 *>(val)[2 * j], b = reinterpret_cast<const double2 *>(val)[2 * j + 1];
-        r.col[0] = m.x; r.col[1] = m.y; r.col[2] = m.z; r.own = m.w;
-        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.diag = b.y;
-    } else {
-        const int4 m0 = reinterpret_cast<const int4 *>(meta)[2 * j], m1 = reinterpret_cast<const int4 *>(meta)[2 * j + 1];
-        const double2 *pv = reinterpret_cast<const double2 *>(val) + 4 * j;
-        const double2 a = pv[0], b = pv[1], c = pv[2], d = pv[3];
-        r.col[0] = m0.x; r.col[1] = m0.y; r.col[2] = m0.z; r.col[3] = m0.w; r.col[4] = m1.x; r.col[5] = m1.y; r.own = m1.z;
-        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y; r.v[4] = c.x; r.v[5] = c.y; r.diag = d.x;
+    constexpr int S = W == 3 ? 4 : (W == 6 ? 8 : 16);     // record stride: {c0..c(W-1), row, pad} / {v0..v(W-1), diagonal, pad}
+    int m[S];
+    double w[S];
+    const int4 *mp = reinterpret_cast<const int4 *>(meta) + j * (S / 4);
+    const double2 *vp = reinterpret_cast<const double2 *>(val) + j * (S / 2);
+#pragma unroll
+    for (int q = 0; q < S / 4; ++q) {
+        const int4 t = mp[q];
+        m[4 * q] = t.x; m[4 * q + 1] = t.y; m[4 * q + 2] = t.z; m[4 * q + 3] = t.w;
     }
+#pragma unroll
+    for (int q = 0; q < S / 2; ++q) {
+        if (2 * q > W) break;                             // (padding: not loaded)
+        const double2 t = vp[q];
+        w[2 * q] = t.x; w[2 * q + 1] = t.y;
+    }
+    SfRec<W> r;
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+        r.col[q] = m[q];
+        r.v[q] = w[q];
+    }
+    r.own = m[W];
+    r.diag = w[W];
     return r;
 }
 
@@ -889,7 +900,10 @@ static void launch_schedule(int64_t n, const Levels &lv, bool upper, bool lm, co
                            sf_refill);                                                                                       \
     } while (0)
                 // 512 rows per ticket (measured on the scrambled 1M-DoF factor: 256 / 512 / 1024 rows: 241 / 233 / 233-254 us per apply)
-                if (lv.rec_w == 6) {
+                if (lv.rec_w == 12) {
+                    if (upper) DPCG_SF_LM(true, 512, 12);
+                    else DPCG_SF_LM(false, 512, 12);
+                } else if (lv.rec_w == 6) {
                     if (upper) DPCG_SF_LM(true, 512, 6);
                     else DPCG_SF_LM(false, 512, 6);
                 } else {
@@ -904,7 +918,10 @@ static void launch_schedule(int64_t n, const Levels &lv, bool upper, bool lm, co
     hipLaunchKernelGGL((k_sptrsv_syncfree_rec<UP, kBlock, WV>), dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, cols,  \
                        lv.lo_val, lv.sf_meta, lv.sf_val, rhs, out, reinterpret_cast<unsigned int *>(lv.tickets + seg_index),  \
                        nblocks, done, lv.spin_err, nullptr, nullptr)
-            if (lv.rec_w == 6) {
+            if (lv.rec_w == 12) {
+                if (upper) DPCG_SF(true, 12);
+                else DPCG_SF(false, 12);
+            } else if (lv.rec_w == 6) {
                 if (upper) DPCG_SF(true, 6);
                 else DPCG_SF(false, 6);
             } else {
@@ -974,7 +991,10 @@ static void launch_schedule(int64_t n, const Levels &lv, bool upper, bool lm, co
 #define DPCG_LEVEL_REC(UP, WV)                                                                                            \
     hipLaunchKernelGGL((k_sptrsv_level_rec<UP, WV>), dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, cols, lv.lo_val, \
                        lv.sf_meta, lv.sf_val, rhs, out, done)
-                if (lv.rec_w == 6) {
+                if (lv.rec_w == 12) {
+                    if (upper) DPCG_LEVEL_REC(true, 12);
+                    else DPCG_LEVEL_REC(false, 12);
+                } else if (lv.rec_w == 6) {
                     if (upper) DPCG_LEVEL_REC(true, 6);
                     else DPCG_LEVEL_REC(false, 6);
                 } else {
