@@ -147,15 +147,17 @@ __device__ __forceinline__ void record_and_test(Scalars *sc, double rr, double r
 //   KB (k_update_r<PRE, true>): alpha, r, z, partials as before; workgroup 0 also advances k and rz_prev.
 // x lags one update behind; k_final_fused applies the last one.  Before the first update rz_prev = +inf and
 // alpha = 0, P[1] = 0, so update 0 degenerates to p_0 = z_0, x unchanged.  Scalars obey the same rule as in the
-// three-kernel form: nobody reads a word that the same kernel writes (`done` excepted: a workgroup that sees it
-// set early returns -- ALL its waves together --, which is what it would have decided anyway).
+// three-kernel form: nobody reads a word that the same kernel writes -- KA's head included (see fused_head).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool fused_head(Scalars *sc, const FuseArgs &f, double *sh, double &alpha, double &beta) {
-    // `done` may be set by workgroup 0 of THIS launch while a late workgroup starts: the waves of that workgroup must then
-    // agree on what they saw -- a wave that left alone would leave its slots of the block reduction below unwritten, the
-    // others would read stale LDS there, miss the stop and apply the deferred x += alpha p a second time (seen with several
-    // solves sharing the chip: the last increment doubled in 64-row runs).  One barrier-wide OR makes the exit uniform.
-    if (__syncthreads_or(sc->done)) return false;
+    // KA never reads `done`: workgroup 0 of THIS launch may be setting it while a late workgroup starts, and the waves of
+    // that workgroup would not agree on what they saw -- a wave that left alone would leave its slots of the block reduction
+    // below unwritten, the others would read stale LDS there, miss the stop and apply the deferred x += alpha p a second time
+    // (seen with several solves sharing the chip: the last increment doubled in 64-row runs).  Every workgroup derives the
+    // stop from the partials instead, which no kernel changes once the solve has stopped (KB and the preconditioner kernels
+    // are no-ops then), so the no-op launches that follow convergence decide the same way; the one case the partials cannot
+    // show -- the INITIAL iterate already passed the test (k = 0) -- travels in `done_seen`, written by k_fused_init only.
+    if (sc->done_seen) return false;
     const int k = sc->k;                                   // updates completed (written by KB / the initial state)
     double rz = 0.0, rr = 0.0;
     for (int i = threadIdx.x; i < f.n_part; i += kBlock) rz += f.part_rz[i];
@@ -173,7 +175,7 @@ __device__ __forceinline__ bool fused_head(Scalars *sc, const FuseArgs &f, doubl
             sc->res = res;
             if (stop) {
                 sc->status = conv ? DPCG_OK : DPCG_BREAKDOWN;
-                sc->done = 1;
+                sc->done = 1;                              // read by KB and the preconditioner kernels (later launches)
                 if (sc->progress)
                     __hip_atomic_store(sc->progress, ((unsigned long long)k << 1) | 1ull, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_SYSTEM);

@@ -122,6 +122,7 @@ __global__ void k_fused_init(Scalars *sc) {
     if (threadIdx.x == 0) {
         sc->rz_prev = __builtin_huge_val();   // beta_0 = <r,z>_0 / inf = 0  =>  p_0 = z_0
         sc->alpha = 0.0;                      // no deferred x update yet
+        sc->done_seen = sc->done;             // "the INITIAL iterate already passed the test": what KA's head reads (see fused_head)
     }
 }
 
