@@ -1,12 +1,10 @@
 """The reference's own call -- M handed over as an explicit sparse matrix (test.py:88,105,138) -- at config-2 size: PCG with
-M = L L^T (IC(0) factor and a 15-per-row factor like the CNN's) as ONE CSR matrix; DPCG_FUSE_KB=0 = KB, SpMV and dot apart."""
-import os
+M = L L^T (IC(0) factor and a 15-per-row factor like the CNN's) as ONE CSR matrix, per launch form."""
 import numpy as np, scipy.sparse as sp, torch
 import deeppreconditioning_amd as D
 from deeppreconditioning_amd import poisson
 from oracle import c_oracle as CO, oracle as O
 
-print("DPCG_FUSE_KB =", os.environ.get("DPCG_FUSE_KB", "1"))
 def cnn_like_factor(n2):      # the sparsity of the CNN-emitted factor (15 entries per row at 256^2), seeded random weights
     from deeppreconditioning_amd import model as mdl
     torch.manual_seed(69)
