@@ -181,6 +181,13 @@ def main() -> None:
             its += sum(r.iterations for r in solve_batch(group[:len(chunk)], chunk, n_streams=len(chunk)))
         return its
 
+    # Device wake-up, part of the setup (not a step, not timed): while torch was imported and the systems were built the GPU sat
+    # idle, and ~10 ms after load resumes its power management stalls everything once for 50-90 ms (tools/idle_probe.py: one
+    # 4.5 ms solve in six took 62 ms after 2 s of host-only work).  0.3 s of SpMV launches put that transition before the
+    # warm-up steps instead of somewhere inside the timed ones.
+    t_wake = time.perf_counter() + 0.3
+    while time.perf_counter() < t_wake:
+        system.spmv_dot_bench(repeats=50)
     for _ in range(args.warmup):
         step()
     barrier()
