@@ -1455,7 +1455,8 @@ def test_rz_partials_summed_by_the_last_spmv_of_an_m_apply(D):
     S.close()
 
 
-def test_level_major_triangular_solves(D):
+@pytest.mark.parametrize("schedule", ["one_sync_free_launch", "one_launch_per_level"])
+def test_level_major_triangular_solves(D, schedule):
     """The level-major form of the triangular solves (few wide levels: the solve runs in the factor's own level-order numbering,
     the two solves of an apply hand the vector over without way-in passes; width-6 records) forced on small factors in a child
     process: bit-identical to sequential substitution in every interleaving of standalone solves and applies, PCG counts and
@@ -1466,6 +1467,8 @@ def test_level_major_triangular_solves(D):
     import sys
     root = pathlib.Path(__file__).resolve().parent.parent
     env = {**__import__("os").environ, "PYTHONPATH": str(root), "DPCG_LEVEL_MAJOR": "1", "DPCG_SETUP_TRACE": "1"}
+    if schedule == "one_launch_per_level":          # the chained, non-fused hand-over between the two solves (way-in passes)
+        env["DPCG_LM_SYNCFREE"] = "0"
     proc = subprocess.run([sys.executable, str(root / "tests" / "level_major_child.py")], capture_output=True, text=True, cwd=root,
                           env=env, timeout=900)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
