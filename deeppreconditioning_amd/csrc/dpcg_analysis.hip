@@ -472,9 +472,9 @@ void launch_ring_records(int64_t n, const uint32_t *lvl_of_pos, const int32_t *r
 //   sf_val[4j..4j+3] = {v0, v1, v2, diagonal}.
 // Factors with many longer rows (an unstructured mesh in its own numbering: up to 6 lower neighbours on a 7-point graph) take
 // the width-6 form (Levels::rec_w): 8 ints {c0..c5, row, -} and 8 doubles {v0..v5, diagonal, -} per row; factors with fill
-// (ICT) the width-12 form, 16 + 16.
+// (ICT), or of wider stencils (27-point: 13 lower entries), the width-14 form, 16 + 16.
 // Addressed by position alone, so a row's data can be requested before anything about the row is known.
-template <int W>   // W = 3 / 6 / 12 entries; a record is S = 4 / 8 / 16 ints {c0..c(W-1), row, -...} and S doubles {v0..v(W-1), diag, -...}
+template <int W>   // W = 3 / 6 / 14 entries; a record is S = 4 / 8 / 16 ints {c0..c(W-1), row, -...} and S doubles {v0..v(W-1), diag, -...}
 __global__ __launch_bounds__(kBlock) void k_sf_records(int64_t n, const int32_t *__restrict__ rows,
                                                        const int32_t *__restrict__ lo_rp, const int32_t *__restrict__ lo_ci,
                                                        const double *__restrict__ lo_v, int upper, int32_t *__restrict__ meta,
@@ -527,8 +527,8 @@ void launch_compose_positions(int64_t n, const int32_t *rows, const int32_t *pos
 
 void launch_sf_records(int64_t n, const int32_t *rows, const int32_t *lo_rp, const int32_t *lo_ci, const double *lo_v,
                        bool upper, int32_t *meta, double *pv, int width, hipStream_t s) {
-    if (width == 12)
-        hipLaunchKernelGGL(k_sf_records<12>, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows, lo_rp, lo_ci, lo_v, upper ? 1 : 0, meta, pv);
+    if (width == 14)
+        hipLaunchKernelGGL(k_sf_records<14>, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows, lo_rp, lo_ci, lo_v, upper ? 1 : 0, meta, pv);
     else if (width == 6)
         hipLaunchKernelGGL(k_sf_records<6>, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows, lo_rp, lo_ci, lo_v, upper ? 1 : 0, meta, pv);
     else

@@ -126,7 +126,7 @@ struct Levels {
     double *b_lo = nullptr;                // scratch: the right-hand side gathered into level order
     int32_t *sf_meta = nullptr;            // records of the sync-free kernel (dpcg_analysis.hip: k_sf_records)
     double *sf_val = nullptr;
-    int rec_w = 3;                         // entries a record holds (3, 6 or 12); longer rows walk the level-ordered copy
+    int rec_w = 3;                         // entries a record holds (3, 6 or 14); longer rows walk the level-ordered copy
     // Strip-pipelined solve (k_sptrsv_strips): the rows once more, sorted by (strip, strip-local level, row), with their
     // own level offsets (n_strips * nlev + 1 entries), level-ordered factor copy and records.  n_strips == 0: not used.
     struct Strips {

@@ -227,8 +227,11 @@ static bool level_major_syncfree() {              // development knob: DPCG_LM_S
     return on;
 }
 
+// `long_rows`: most rows hold more entries than the three of the LDS-ring / strip records (a 27-point stencil, a factor with
+// fill): those kernels would walk nearly every row entry by entry, so such a factor takes the sync-free kernels with their
+// wider records instead (27-point 64^3, IC(0): 24.6 ms per update in strips, see DESIGN).
 int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_t *rp, const int32_t *ci, const double *v,
-                 hipStream_t s, const int32_t *relabel = nullptr, bool upper = false) {
+                 hipStream_t s, const int32_t *relabel = nullptr, bool upper = false, bool long_rows = false) {
     constexpr int kMergeMax = 2048;  // levels this narrow are walked by one workgroup
     PhaseTimer pt(s);
     lv.level_ptr = ls.level_ptr;
@@ -333,7 +336,8 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         auto cls = [&](const Levels::Segment &seg) {
             const size_t lds = (size_t)seg.ring_w * sizeof(double) + (size_t)(seg.hi - seg.lo + 24) * sizeof(int);
             // (a level-major factor has no ring segments: the ring kernels address the vectors by row)
-            if (!lv.level_major && seg.merged && seg.ring_w > 0 && seg.max_width <= 1024 && lds <= 64 * 1024) return 0;   // RING
+            if (!lv.level_major && !long_rows && seg.merged && seg.ring_w > 0 && seg.max_width <= 1024 && lds <= 64 * 1024)
+                return 0;                                                                                 // RING
             if (lv.level_major && level_major_syncfree()) return 1;   // level-major: the whole factor as ONE sync-free launch
             const int64_t rows_in_seg = (int64_t)level_ptr[seg.hi] - level_ptr[seg.lo];
             return rows_in_seg / (seg.hi - seg.lo) <= kSyncfreeMaxMeanWidth ? 1 : 2;                     // NARROW : WIDE
@@ -389,7 +393,7 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         for (const auto &seg : lv.segments) any = any || !(seg.merged && seg.ring_w > 0);
         if (any) {                                       // records for the sync-free and the per-level kernels
             // width of the records: 3 entries unless more than 2 % of the rows are longer (they would take the slow general
-            // path: three dependent loads before the first entry, then one entry at a time), then 6, then 12
+            // path: three dependent loads before the first entry, then one entry at a time), then 6, then 14
             DevBuf<int32_t> n_long;
             DPCG_TRY(n_long.alloc(2));
             DPCG_HIP(hipMemsetAsync(n_long.p, 0, 2 * sizeof(int32_t), s));
@@ -398,8 +402,8 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
             int32_t h_long[2] = {0, 0};
             DPCG_HIP(hipMemcpyAsync(h_long, n_long.p, sizeof(h_long), hipMemcpyDeviceToHost, s));
             DPCG_HIP(hipStreamSynchronize(s));
-            lv.rec_w = (int64_t)h_long[1] * 50 > n ? 12 : ((int64_t)h_long[0] * 50 > n ? 6 : 3);
-            const int64_t stride = lv.rec_w == 12 ? 16 : (lv.rec_w == 6 ? 8 : 4);
+            lv.rec_w = (int64_t)h_long[1] * 50 > n ? 14 : ((int64_t)h_long[0] * 50 > n ? 6 : 3);
+            const int64_t stride = lv.rec_w == 14 ? 16 : (lv.rec_w == 6 ? 8 : 4);
             DPCG_TRY(dev_alloc(&lv.sf_meta, n * stride));
             DPCG_TRY(dev_alloc(&lv.sf_val, n * stride));
             if (lv.level_major)
@@ -664,6 +668,19 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
         // Large factors try the strip plan FIRST and build the level schedule (level-ordered copy, ring / sync-free records)
         // only when it is not kept; small ones build the schedule first because the choice depends on it.
         auto schedule = [&](Levels &lv, LevelSort &ls, const CsrDev &F, bool upper) -> int {
+            // more than 2 % of the rows longer than a ring / strip record: no ring walk, no strips (see build_levels)
+            DevBuf<int32_t> n_long;
+            DPCG_TRY(n_long.alloc(1));
+            DPCG_HIP(hipMemsetAsync(n_long.p, 0, sizeof(int32_t), s));
+            launch_count_long_rows(n, F.rowptr, 3, n_long.p, s);
+            int32_t h_long = 0;
+            DPCG_HIP(hipMemcpyAsync(&h_long, n_long.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            DPCG_HIP(hipStreamSynchronize(s));
+            const bool long_rows = (int64_t)h_long * 50 > n;
+            if (long_rows) {
+                DPCG_TRY(build_levels(lv, ls, n, F.nnz, F.rowptr, F.col, F.val, s, h->iperm, upper, true));
+                return DPCG_OK;
+            }
             const bool strips_first = n > 131072;
             if (strips_first) {
                 lv.level_ptr = ls.level_ptr;

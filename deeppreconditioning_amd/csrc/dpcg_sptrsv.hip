@@ -480,15 +480,33 @@ __global__ __launch_bounds__(BS) void k_sptrsv_syncfree_rec(int j0, int count, c
             if (!stored) {
                 bool ready = false, waited = false;
                 if (longrow) {
+                    // up to four entries per turn: their columns, then their values of `out`, all at once; consumed in order as
+                    // far as they have arrived (nothing is kept across turns: the columns come from the L2 again).  One entry
+                    // per turn -- two dependent round trips each -- made a 20-entry row cost 40 trips.
                     if (k < ke) {
-                        const double yk = __hip_atomic_load(out + lo_ci[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (!is_pending(yk)) {
-                            acc -= lo_v[k] * yk;
-                            ++k;
-                            spins = 0;
-                        } else {
-                            waited = true;
+                        constexpr int CH = 4;
+                        int cc[CH];
+                        double vv[CH], yy[CH];
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) {
+                            const int kk = k + c < ke ? k + c : ke - 1;
+                            cc[c] = lo_ci[kk];
+                            vv[c] = lo_v[kk];
                         }
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) yy[c] = __hip_atomic_load(out + cc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        bool open = true;                  // still consuming the prefix that has arrived
+                        const int k_before = k;
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) {
+                            open = open && k_before + c < ke && !is_pending(yy[c]);
+                            if (open) {
+                                acc -= vv[c] * yy[c];
+                                ++k;
+                            }
+                        }
+                        if (k != k_before) spins = 0;
+                        else waited = true;
                     }
                     ready = k >= ke;
                 } else {
@@ -900,9 +918,9 @@ static void launch_schedule(int64_t n, const Levels &lv, bool upper, bool lm, co
                            sf_refill);                                                                                       \
     } while (0)
                 // 512 rows per ticket (measured on the scrambled 1M-DoF factor: 256 / 512 / 1024 rows: 241 / 233 / 233-254 us per apply)
-                if (lv.rec_w == 12) {
-                    if (upper) DPCG_SF_LM(true, 512, 12);
-                    else DPCG_SF_LM(false, 512, 12);
+                if (lv.rec_w == 14) {
+                    if (upper) DPCG_SF_LM(true, 512, 14);
+                    else DPCG_SF_LM(false, 512, 14);
                 } else if (lv.rec_w == 6) {
                     if (upper) DPCG_SF_LM(true, 512, 6);
                     else DPCG_SF_LM(false, 512, 6);
@@ -918,9 +936,9 @@ static void launch_schedule(int64_t n, const Levels &lv, bool upper, bool lm, co
     hipLaunchKernelGGL((k_sptrsv_syncfree_rec<UP, kBlock, WV>), dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, cols,  \
                        lv.lo_val, lv.sf_meta, lv.sf_val, rhs, out, reinterpret_cast<unsigned int *>(lv.tickets + seg_index),  \
                        nblocks, done, lv.spin_err, nullptr, nullptr)
-            if (lv.rec_w == 12) {
-                if (upper) DPCG_SF(true, 12);
-                else DPCG_SF(false, 12);
+            if (lv.rec_w == 14) {
+                if (upper) DPCG_SF(true, 14);
+                else DPCG_SF(false, 14);
             } else if (lv.rec_w == 6) {
                 if (upper) DPCG_SF(true, 6);
                 else DPCG_SF(false, 6);
@@ -991,9 +1009,9 @@ static void launch_schedule(int64_t n, const Levels &lv, bool upper, bool lm, co
 #define DPCG_LEVEL_REC(UP, WV)                                                                                            \
     hipLaunchKernelGGL((k_sptrsv_level_rec<UP, WV>), dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, cols, lv.lo_val, \
                        lv.sf_meta, lv.sf_val, rhs, out, done)
-                if (lv.rec_w == 12) {
-                    if (upper) DPCG_LEVEL_REC(true, 12);
-                    else DPCG_LEVEL_REC(false, 12);
+                if (lv.rec_w == 14) {
+                    if (upper) DPCG_LEVEL_REC(true, 14);
+                    else DPCG_LEVEL_REC(false, 14);
                 } else if (lv.rec_w == 6) {
                     if (upper) DPCG_LEVEL_REC(true, 6);
                     else DPCG_LEVEL_REC(false, 6);
