@@ -205,7 +205,13 @@ class LLtMultiply(_CsrBacked):
 
 
 class LLtSolve(LLtMultiply):
-    """z = L^-T (L^-1 r): a true incomplete-Cholesky apply by level-scheduled triangular solves."""
+    """z = L^-T (L^-1 r): a true incomplete-Cholesky apply by level-scheduled triangular solves.
+
+    The parallelism of a triangular solve is the width of the factor's dependency levels (`CsrSystem.info()`:
+    `levels_lower` / `levels_upper`).  The factor of a grid has n^(1/2) .. n^(2/3)-row levels; a factor whose every row
+    reaches back to its predecessor -- the sparsity the reference's CNN emits: 15 entries per row with column row-1 among
+    them -- is ONE chain of n levels and is solved row after row (256^2: 65 536 levels, ~0.1 s per apply).  That factor is
+    meant to be multiplied (`LLtMultiply`, the reference's own use, test.py:100-105)."""
 
     mode = L.PRECOND_LLT_SOLVE
 
