@@ -668,7 +668,9 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
         // Large factors try the strip plan FIRST and build the level schedule (level-ordered copy, ring / sync-free records)
         // only when it is not kept; small ones build the schedule first because the choice depends on it.
         auto schedule = [&](Levels &lv, LevelSort &ls, const CsrDev &F, bool upper) -> int {
-            // more than 2 % of the rows longer than a ring / strip record: no ring walk, no strips (see build_levels)
+            // more than 2 % of the rows longer than a ring / strip record: no ring walk, no strips (see build_levels; measured on
+            // a 48^3 grid with one extra lower neighbour on a share of the rows: 5 % such rows turn the strip plan's 263 us per
+            // update into 772, the sync-free kernels take 458 whatever the share -- tools/longrow_share_probe.py)
             DevBuf<int32_t> n_long;
             DPCG_TRY(n_long.alloc(1));
             DPCG_HIP(hipMemsetAsync(n_long.p, 0, sizeof(int32_t), s));
@@ -676,7 +678,9 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
             int32_t h_long = 0;
             DPCG_HIP(hipMemcpyAsync(&h_long, n_long.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             DPCG_HIP(hipStreamSynchronize(s));
-            const bool long_rows = (int64_t)h_long * 50 > n;
+            // (DPCG_LONG_ROW_PCT: development knob for that share, in per cent)
+            static const int64_t pct = [] { const char *e = getenv("DPCG_LONG_ROW_PCT"); return e ? (int64_t)atoll(e) : (int64_t)2; }();
+            const bool long_rows = (int64_t)h_long * 100 > n * pct;
             if (long_rows) {
                 DPCG_TRY(build_levels(lv, ls, n, F.nnz, F.rowptr, F.col, F.val, s, h->iperm, upper, true));
                 return DPCG_OK;
