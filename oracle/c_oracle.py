@@ -31,6 +31,7 @@ def lib() -> C.CDLL:
         build()
         _lib = C.CDLL(str(_LIB_PATH))
         _lib.orc_pcg.restype = C.c_double
+        _lib.orc_pcg_mixed.restype = C.c_double
         _lib.orc_dot.restype = C.c_double
         _lib.orc_ic0.restype = C.c_int64
         _lib.orc_num_threads.restype = C.c_int
@@ -71,6 +72,17 @@ def spmv_f32(A: sp.csr_matrix, x: np.ndarray) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = np.empty(A.shape[0], dtype=np.float32)
     lib().orc_spmv_f32(C.c_int64(A.shape[0]), _p(rp), _p(ci), _p(v), _p(x), _p(y))
+    return y
+
+
+def spmv_mixed(A: sp.csr_matrix, x: np.ndarray) -> np.ndarray:
+    """fp64 y = fp64(fp32(A)) fp64(fp32(x)): fp32-STORED operands, fp64 products and in-order row sums (config 5's
+    `A @ pk`).  `dpcg_spmv_f32` returns exactly fp32(y)."""
+    rp, ci, _ = _csr_parts(A)
+    v = np.ascontiguousarray(A.data, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty(A.shape[0], dtype=np.float64)
+    lib().orc_spmv_mixed(C.c_int64(A.shape[0]), _p(rp), _p(ci), _p(v), _p(x), _p(y))
     return y
 
 
@@ -115,8 +127,9 @@ def sptrsv_upper(U: sp.csr_matrix, y: np.ndarray) -> np.ndarray:
 
 
 def pcg(A: sp.csr_matrix, b: np.ndarray, kind: str = "none", *, dinv=None, M=None, L=None, x0=None, rtol=1e-8,
-        max_iter=1024, init_check="z"):
-    """Returns (seconds, iterations, residual_history, x) -- same tuple as oracle.oracle's PCG."""
+        max_iter=1024, init_check="z", mixed=False):
+    """Returns (seconds, iterations, residual_history, x) -- same tuple as oracle.oracle's PCG.
+    mixed=True: config 5, the loop's `A @ pk` on fp32-stored values and pk (orc_pcg_mixed)."""
     n = A.shape[0]
     rp, ci, v = _csr_parts(A)
     b = np.ascontiguousarray(b, dtype=np.float64)
@@ -128,9 +141,13 @@ def pcg(A: sp.csr_matrix, b: np.ndarray, kind: str = "none", *, dinv=None, M=Non
     x = np.empty(n, dtype=np.float64)
     hist = np.full(max_iter + 1, np.nan)
     iters = C.c_int(0)
-    sec = lib().orc_pcg(C.c_int64(n), _p(rp), _p(ci), _p(v), _p(b), _p(x0a), C.c_int(KINDS[kind]), _p(dinv_a),
-                        _p(m[0]), _p(m[1]), _p(m[2]), _p(l[0]), _p(l[1]), _p(l[2]), _p(lt[0]), _p(lt[1]), _p(lt[2]),
-                        C.c_double(rtol), C.c_int(max_iter), C.c_int(1 if init_check == "z" else 0),
-                        _p(x), _p(hist), C.byref(iters))
+    tail = (_p(b), _p(x0a), C.c_int(KINDS[kind]), _p(dinv_a),
+            _p(m[0]), _p(m[1]), _p(m[2]), _p(l[0]), _p(l[1]), _p(l[2]), _p(lt[0]), _p(lt[1]), _p(lt[2]),
+            C.c_double(rtol), C.c_int(max_iter), C.c_int(1 if init_check == "z" else 0), _p(x), _p(hist), C.byref(iters))
+    if mixed:
+        v32 = v.astype(np.float32)
+        sec = lib().orc_pcg_mixed(C.c_int64(n), _p(rp), _p(ci), _p(v), _p(v32), *tail)
+    else:
+        sec = lib().orc_pcg(C.c_int64(n), _p(rp), _p(ci), _p(v), *tail)
     k = iters.value
     return float(sec), k, hist[: k + 1].copy(), x

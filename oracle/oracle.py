@@ -259,6 +259,30 @@ def learned_like_factor(A: sp.csr_matrix, seed: int = 0, scale: float = 0.05, di
     return L
 
 
+def learned_like_factor_preconditioning(A: sp.csr_matrix, seed: int = 1, noise: float = 0.005) -> sp.csr_matrix:
+    """A learned-like factor that really preconditions -- the stand-in for a TRAINED PreconditionerNet output
+    (`learned_like_factor` above is the untrained, random-weight one, whose M A is so ill-conditioned that the
+    multiplied PCG is chaotic: the reference marks the technique `# unstable`, test.py:45).
+
+    L = (I + E)/2 + noise * N(0,1) on the strict-lower part of the CNN's output pattern (tril(A) dilated by
+    [-2,2]^2, model.py:33-37), rounded to fp32 and upcast (test.py:105); E = -strict_lower(A)/diag(A).
+    (I + E)(I + E^T)/4 is the first-order Neumann approximation of the symmetric Gauss-Seidel inverse of A (exact
+    orientation for matrices that are invariant under reversing the numbering, like the grid Laplacians).
+    M = L L^T multiplied gives ~half of Jacobi's iteration count and a numerically STABLE recurrence, so BASELINE
+    config 2 ("CNN-emitted L factor") gets a count-exact 1e-10 fixture from the reference's own loop."""
+    n = A.shape[0]
+    d = A.diagonal()
+    E = (-sp.tril(A, -1).tocsr()).multiply(1.0 / d[:, None]).tocsr()
+    R = learned_like_factor(A, seed=seed, scale=noise, diag_sigma=0.0)
+    R = (R - sp.diags(R.diagonal())).tocsr()
+    L = (0.5 * (sp.identity(n, format="csr") + E) + R).tocsr()
+    L.data = L.data.astype(np.float32).astype(np.float64)
+    L.sort_indices()
+    L.indices = L.indices.astype(np.int32)
+    L.indptr = L.indptr.astype(np.int32)
+    return L
+
+
 def sptrsv_lower(L: sp.csr_matrix, r: np.ndarray) -> np.ndarray:
     """Solve L y = r by forward substitution, row sums in column order, then divide by L_ii."""
     rp, ci, lv = L.indptr, L.indices, L.data
@@ -363,6 +387,21 @@ def preconditioned_conjugate_gradient(A, b, M, x0=None, rtol=1e-8, max_iter=1024
         hist.append(float(res))
     t1 = time.perf_counter()  # cg.py:88
     return t1 - t0, len(hist) - 1, np.array(hist), x  # cg.py:90 (+ history and x for the checker)
+
+
+class MixedOperator:
+    """Config 5's `A @ pk` (cg.py:75): matrix values and the vector STORED in fp32, products and row sums in fp64 --
+    y = fp64(fp32(A)) @ fp64(fp32(v)).  Handed to `preconditioned_conjugate_gradient` as A it gives the mixed-precision
+    PCG (x0 = 0, so the only `A @` that matters is the loop's; everything else stays fp64).  The same duck-typed operator,
+    on torch tensors, is what tests/golden/make_golden.py --add-round3 hands the REFERENCE's loop to pin this."""
+
+    def __init__(self, A: sp.csr_matrix):
+        A = A.tocsr()
+        self.A32 = sp.csr_matrix((A.data.astype(np.float32).astype(np.float64), A.indices, A.indptr), shape=A.shape)
+        self.shape = A.shape
+
+    def __matmul__(self, v: np.ndarray) -> np.ndarray:
+        return self.A32 @ v.astype(np.float32).astype(np.float64)
 
 
 def ground_truth_solve(A, b, atol=1e-6, maxiter=None):

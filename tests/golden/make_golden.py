@@ -142,13 +142,62 @@ def sparse_loss_cases(out: dict) -> None:
     print("metrics_sparse/inverse_loss:", float(out["metrics_sparse/inverse_loss"]), flush=True)
 
 
+class MixedTorchOperator:
+    """BASELINE config 5 as a duck-typed `A` for the REFERENCE's loop (cg.py only needs `A @ v`): matrix values and the
+    vector stored in fp32, products and row sums in fp64 -- y = fp64(fp32(A)) @ fp64(fp32(v)) by torch's own sparse-CSR
+    matvec.  With x0 = None every other use of A in cg.py (lines 60, 67, 87) multiplies zeros."""
+
+    def __init__(self, A: sp.csr_matrix):
+        A = A.tocsr()
+        self.A32 = to_torch_csr(sp.csr_matrix((A.data.astype(np.float32).astype(np.float64), A.indices, A.indptr),
+                                              shape=A.shape))
+
+    def __matmul__(self, v: torch.Tensor) -> torch.Tensor:
+        return self.A32 @ v.to(torch.float32).to(torch.float64)
+
+
+def round3_cases(out: dict) -> None:
+    """Round 3: (1) mixed-precision PCG (config 5) through the reference's own loop on systems whose values are NOT
+    fp32-representable (D A D scaling); (2) BASELINE config 2 with a well-conditioned learned-like factor at 256^2,
+    M = L L^T materialised as CSR and multiplied (test.py:100-105), so that the count is reproducible."""
+    def put(name, iters, hist):
+        out[f"{name}/iters"] = np.int64(iters)
+        out[f"{name}/hist"] = np.asarray(hist, dtype=np.float64)
+        print(f"{name}: iters={iters} res[0]={hist[0]:.17g} res[-2]={hist[-2]:.17g} res[-1]={hist[-1]:.17g}", flush=True)
+
+    for name, A in (("unstructured3d_16", O.unstructured_like(O.poisson3d(16), seed=0)),
+                    ("unstructured2d_64_seed2", O.unstructured_like(O.poisson2d(64), seed=2))):
+        b = O.rhs(A.shape[0], 0)
+        assert np.any(A.data.astype(np.float32).astype(np.float64) != A.data)          # lossy in fp32
+        iters, hist = run_ref_pcg(MixedTorchOperator(A), b, to_torch_csr(sp.diags(O.jacobi_dinv(A)).tocsr()))
+        put(f"mixed/pcg_{name}_jacobi", iters, hist)
+        iters, hist = run_ref_pcg(MixedTorchOperator(A), b, TriSolveOperator(CO.ic0(A)))
+        put(f"mixed/pcg_{name}_ic0_solve", iters, hist)
+    A = O.poisson2d(256)
+    b = O.rhs(A.shape[0], 0)
+    Lw = O.learned_like_factor_preconditioning(A, seed=1, noise=0.005)   # 15 entries per row, the CNN's output pattern
+    iters, hist = run_ref_pcg(to_torch_csr(A), b, to_torch_csr((Lw @ Lw.T).tocsr()))
+    put("pcg_poisson2d_256_learnedlike_preconditioning_multiply", iters, hist)
+    out.pop("pcg_poisson2d_256_learnedlike_wellcond_multiply/iters", None)   # first try of this round: still chaotic
+    out.pop("pcg_poisson2d_256_learnedlike_wellcond_multiply/hist", None)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--add-round3", action="store_true",
+                    help="only add the mixed-precision and config-2 well-conditioned fixtures to reference_outputs.npz")
     ap.add_argument("--add-round2", action="store_true",
                     help="only add the ground-truth-solve and sparse-loss fixtures to the existing reference_outputs.npz")
     args = ap.parse_args()
     out: dict[str, np.ndarray] = {}
+    if args.add_round3:
+        with np.load(HERE / "reference_outputs.npz") as old:
+            out = {k: old[k] for k in old.files}
+        round3_cases(out)
+        np.savez_compressed(HERE / "reference_outputs.npz", **out)
+        print("updated", HERE / "reference_outputs.npz", (HERE / "reference_outputs.npz").stat().st_size, "bytes")
+        return
     if args.add_round2:
         with np.load(HERE / "reference_outputs.npz") as old:
             out = {k: old[k] for k in old.files}
@@ -317,6 +366,7 @@ def main() -> None:
 
     ground_truth_cases(out)
     sparse_loss_cases(out)
+    round3_cases(out)
     name = "reference_outputs_quick.npz" if args.quick else "reference_outputs.npz"
     np.savez_compressed(HERE / name, **out)
     print("wrote", HERE / name, (HERE / name).stat().st_size, "bytes")

@@ -201,3 +201,62 @@ def test_ground_truth_solve(golden, name, make):
     assert (iters, info) == (g_it, g_info)
     np.testing.assert_allclose(x, golden[f"ground_truth/{name}/x"], rtol=1e-9, atol=1e-12)
     assert np.linalg.norm(b - A @ x) < 1e-6
+
+
+# ---- round 3: mixed-precision PCG (BASELINE config 5) and a count-exact config-2 fixture -------------------------
+MIXED_EARLY = 10          # entries before a float rounding of p can have flipped between implementations
+MIXED_RTOL = 2e-5         # measured: <= 1.7e-6 between the reference's run and either oracle (see the docstring)
+
+
+def _mixed_systems():
+    return (("unstructured3d_16", O.unstructured_like(O.poisson3d(16), seed=0)),
+            ("unstructured2d_64_seed2", O.unstructured_like(O.poisson2d(64), seed=2)))
+
+
+@pytest.mark.parametrize("name,A", _mixed_systems(), ids=lambda v: v if isinstance(v, str) else "A")
+def test_pcg_mixed_precision_numpy_and_c(golden, name, A):
+    """Config 5: `A @ pk` (cg.py:75) on fp32-STORED values and pk, fp64 products and sums, everything else fp64.  The
+    fixtures are the reference's own loop run with that operator (make_golden.py::MixedTorchOperator) on systems whose
+    values are NOT fp32-representable.  Rounding pk to fp32 is discontinuous: two implementations whose fp64 dot
+    products differ in the last bits round a few elements of pk to different floats, a 6e-8 relative kick that the
+    recurrence then amplifies -- measured here 1e-14 over the first entries, up to 1.7e-6 at the end (reference vs
+    either oracle, and the two oracles against each other alike).  So: counts equal, early history at 1e-12, whole
+    history at 2e-5."""
+    b = O.rhs(A.shape[0], 0)
+    assert np.any(A.data.astype(np.float32).astype(np.float64) != A.data)
+    dinv, L = O.jacobi_dinv(A), CO.ic0(A)
+    for kind, key, kw in (("jacobi", "jacobi", dict(dinv=dinv)), ("llt_solve", "ic0_solve", dict(L=L))):
+        g, gi = golden[f"mixed/pcg_{name}_{key}/hist"], int(golden[f"mixed/pcg_{name}_{key}/iters"])
+        runs = (CO.pcg(A, b, kind, mixed=True, **kw),
+                O.preconditioned_conjugate_gradient(O.MixedOperator(A), b, O.Precond(kind, **kw)))
+        for _, it, hist, x in runs:
+            assert it == gi
+            np.testing.assert_allclose(hist[:MIXED_EARLY], g[:MIXED_EARLY], rtol=1e-12)
+            np.testing.assert_allclose(hist, g, rtol=MIXED_RTOL)
+            r = b - A @ x                                   # residual-matched to the fp64 target (true fp64 residual)
+            assert np.dot(r, r) / np.dot(b, b) < 2e-8
+        # and it is NOT the fp64 solve: the fp64 history differs visibly
+        _, _, h64, _ = CO.pcg(A, b, kind, **kw)
+        m = min(len(h64), len(g))
+        assert np.max(np.abs(h64[:m] / g[:m] - 1)) > 1e-9
+
+
+def test_spmv_mixed_c_vs_numpy_bit_exact():
+    A = O.unstructured_like(O.poisson3d(12), seed=3)
+    x = O.rhs(A.shape[0], 4)
+    assert np.array_equal(CO.spmv_mixed(A, x), O.MixedOperator(A) @ x)
+    assert not np.array_equal(CO.spmv_mixed(A, x), CO.spmv(A, x))
+
+
+def test_config2_learned_like_preconditioning_factor(golden):
+    """BASELINE config 2 (256^2, "CNN-emitted L factor", multiplied as test.py:100-105 does) with a factor that really
+    preconditions: 249 iterations in the reference's loop, reproduced count-exact and within 1e-10 by both apply forms."""
+    A, b = _system("poisson2d", 256)
+    L = O.learned_like_factor_preconditioning(A)
+    assert L.nnz == O.learned_like_factor(A).nnz and np.array_equal(L.data.astype(np.float32).astype(np.float64), L.data)
+    name = "pcg_poisson2d_256_learnedlike_preconditioning_multiply"
+    assert int(golden[f"{name}/iters"]) == 249
+    _, it, hist, _ = CO.pcg(A, b, "csr", M=(L @ L.T).tocsr())
+    _check(golden, name, it, hist)
+    _, it, hist, _ = CO.pcg(A, b, "llt_multiply", L=L)
+    _check(golden, name, it, hist)
