@@ -106,20 +106,18 @@ def cpu_baseline(dim: int, n: int) -> dict:
     return out
 
 
-def measured_copy_gbs(torch) -> float:
-    """HBM ceiling as this box delivers it: device-to-device copy of 1 GiB (4x the Infinity Cache),
-    read + write bytes over the time of 10 copies."""
-    a = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
-    a.fill_(1.0)
-    b = torch.empty_like(a)
-    b.copy_(a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        b.copy_(a)
-    e1.record()
-    e1.synchronize()
-    return 10 * 2 * a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+def measured_stream_ceilings() -> dict:
+    """HBM ceiling as this box delivers it, measured with the library's own streaming kernel
+    (`dpcg_stream_bench`: 16-byte lane accesses, XCD-contiguous slabs, the SpMV's grid) on buffers far beyond the 256 MiB
+    Infinity Cache: copy (1 read : 1 write), triad (2 : 1), the read:write ratio of a 7-point CSR SpMV (11 : 1) and
+    read-only.  GB/s of reads + writes."""
+    from deeppreconditioning_amd.operators import stream_bench
+    mib = 1 << 20
+    return {"copy_1r1w": round(stream_bench(1, True, 1024 * mib, 10), 1),
+            "triad_2r1w": round(stream_bench(2, True, 512 * mib, 10), 1),
+            "spmv_like_11r1w": round(stream_bench(11, True, 128 * mib, 10), 1),
+            "read_only_3r": round(stream_bench(3, False, 512 * mib, 10), 1),
+            "method": "dpcg_stream_bench, 10 launches between HIP events, 0.5-1.5 GiB per launch"}
 
 
 def main() -> None:
@@ -215,8 +213,9 @@ def main() -> None:
         achieved = b_alg / (ms * 1e-3) / 1e9
         traffic = None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
-        if pmc.exists():
-            traffic = json.loads(pmc.read_text()).get(f"spmv_{args.dim}d_{args.n}")
+        pmc_all = json.loads(pmc.read_text()) if pmc.exists() else {}
+        traffic = pmc_all.get(f"spmv_{args.dim}d_{args.n}")
+        ceilings = measured_stream_ceilings()
         line = {
             "metric": "pcg_iterations_per_sec", "value": round(total_iters / t, 1), "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -234,9 +233,12 @@ def main() -> None:
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": b_alg, "us_per_launch": round(ms * 1e3, 3),
-                         "measured_copy_gbs": round(measured_copy_gbs(torch), 1)},
+                         # PMC counters need rocprofv3, so `traffic` comes from a tracked file: say which run made it
+                         "traffic_source": pmc_all.get("_source", "profiles/pmc_traffic.json (rocprofv3 --pmc passes of "
+                                                                  "tools/pmc_run.py, corrected as profiles/*_pmc_summary.md states)"),
+                         "measured_stream_gbs": ceilings,
+                         "frac_of_measured_ceiling": round(achieved / max(v for v in ceilings.values() if isinstance(v, float)), 4)},
         }
-        pmc_all = json.loads(pmc.read_text()) if pmc.exists() else {}
         line["roofline"]["regime"] = ("cache_resident_1M: the ~150 MB working set of the headline system lives in the 256 MiB "
                                       "Infinity Cache, so `achieved` is fabric, not DRAM, bandwidth; the HBM-bound figure is "
                                       "`hbm_bound_256cubed` below")
@@ -250,7 +252,8 @@ def main() -> None:
                 "kernel": f"k_spmv_{s4.info()['spmv_kernel']}<CTL,DOT>", "achieved": round(b4_alg / (ms4 * 1e-3) / 1e9, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b4_alg / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "traffic": pmc_all.get("spmv_3d_256"), "algorithmic_bytes_per_launch": b4_alg,
-                "us_per_launch": round(ms4 * 1e3, 2), "dof": s4.n, "nnz": s4.nnz}
+                "us_per_launch": round(ms4 * 1e3, 2), "dof": s4.n, "nnz": s4.nnz,
+                "frac_of_measured_spmv_like_stream": round(b4_alg / (ms4 * 1e-3) / 1e9 / ceilings["spmv_like_11r1w"], 4)}
             s4.close()
             del s4
         if world == 1 and not args.no_cpu_baseline:
@@ -378,6 +381,18 @@ def extra_workloads(D, poisson, torch) -> dict:
         c3[name] = {"iterations": r.iterations, "ms": round(r.seconds * 1e3, 3), "iterations_per_s": round(r.iterations / r.seconds, 1),
                     "us_per_update": round(r.seconds / r.iterations * 1e6, 1), "setup_ms": round(setup_ms, 2)}
     c3["levels"] = s3.info()["levels_lower"]
+    # config 5 AS BASELINE STATES IT: mixed fp32-SpMV / fp64 PCG on this 1M-DoF unstructured system (values not
+    # fp32-representable; the fp32 copy is made from the reordered matrix), residual-matched to the fp64 run
+    s3.set_preconditioner(D.Jacobi())
+    r64 = solve_twice(s3, b3)
+    r32 = solve_twice(s3, b3, flags=D._lib.SPMV_F32)
+    rt = b3 - s3 @ r32.x
+    out["c5_mixed_precision_unstructured3d_100"] = {
+        "iterations_fp64": r64.iterations, "iterations_mixed": r32.iterations, "final_res_fp64": r64.final_res,
+        "final_res_mixed_recurrence": r32.final_res, "final_res_mixed_true_fp64_residual": D.dot(rt, rt) / D.dot(b3, b3),
+        "iterations_per_s_fp64": round(r64.iterations / r64.seconds, 1),
+        "iterations_per_s_mixed": round(r32.iterations / r32.seconds, 1),
+        "spmv_algorithmic_bytes_mixed": spmv_bytes(s3.n, s3.nnz, wv=4, wx=4) + 4 * s3.n}   # y stays fp64: + 4 n
     ms = s3.spmv_dot_bench(100)
     c3["spmv_gbs"] = round(loop_kernel_bytes(s3) / (ms * 1e-3) / 1e9, 1)
     c3["spmv_frac_of_hbm_peak"] = round(c3["spmv_gbs"] / HBM_PEAK_GBS, 4)

@@ -673,6 +673,50 @@ extern "C" int dpcg_spmv_dot_bench(dpcg_handle_t h, const double *x, double *y, 
     return DPCG_OK;
 }
 
+// The streaming ceiling of THIS box, measured with the library's own kernel shape (16-byte lane accesses, XCD-contiguous
+// slabs, `grid` workgroups): n_read input streams of bytes_per_stream each summed into one output stream (write = 1) or into
+// per-workgroup partials (write = 0).  What an HBM-bound kernel of this library can at best reach.
+extern "C" int dpcg_stream_bench(int n_read, int write, int64_t bytes_per_stream, int repeats, float *ms_per_launch,
+                                 int64_t *bytes_per_launch, dpcg_stream_t stream) {
+    if (bytes_per_stream < 16 || repeats <= 0 || !ms_per_launch) return invalid("dpcg_stream_bench: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    double *in = nullptr, *out = nullptr, *part = nullptr;
+    const int64_t n = bytes_per_stream / 8;
+    DPCG_TRY(dev_alloc(&in, n * n_read));
+    int st = dev_alloc(&out, write ? n : 1);
+    if (st >= 0) st = dev_alloc(&part, kMaxSpmvGrid);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0.f;
+    int64_t moved = 0;
+    hipError_t e = hipSuccess;
+    if (st >= 0) {
+        e = hipMemsetAsync(in, 0, (size_t)n * n_read * sizeof(double), s);
+        if (e == hipSuccess) e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        for (int i = 0; i < 2 && e == hipSuccess; ++i)
+            moved = launch_stream_bench(n_read, write != 0, bytes_per_stream, in, out, part, kMaxSpmvGrid, s);
+        if (e == hipSuccess && moved < 0) st = invalid("dpcg_stream_bench: n_read must be 1, 2, 3 or 11");
+        if (e == hipSuccess && st >= 0) {
+            e = hipEventRecord(e0, s);
+            for (int i = 0; i < repeats; ++i) launch_stream_bench(n_read, write != 0, bytes_per_stream, in, out, part, kMaxSpmvGrid, s);
+            if (e == hipSuccess) e = hipEventRecord(e1, s);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e == hipSuccess) e = hipGetLastError();
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    dev_free(in);
+    dev_free(out);
+    dev_free(part);
+    DPCG_HIP(e);
+    if (st < 0) return st;
+    *ms_per_launch = ms / (float)repeats;
+    if (bytes_per_launch) *bytes_per_launch = moved;
+    return DPCG_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // generators and the batched COO SpMV
 // ------------------------------------------------------------------------------------------------

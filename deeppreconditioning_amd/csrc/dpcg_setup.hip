@@ -81,6 +81,64 @@ void launch_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void 
                            (double *)val);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The box's own streaming ceiling: NR read streams of 16 bytes per lane summed into one write stream
+// (NR = 1: copy, 2: triad, 11: the read:write ratio of a 7-point CSR SpMV -- 90 B read, 8 B written per row) or into
+// per-workgroup partials only (W = false: read-only).  Contiguous slab per workgroup, slabs laid out XCD by XCD like the
+// SpMV's row blocks, two 16-byte loads per stream in flight per lane.
+// ------------------------------------------------------------------------------------------------
+template <int NR, bool W>
+__global__ __launch_bounds__(kBlock) void k_stream_bench(int64_t n2, const double2 *__restrict__ in, double2 *__restrict__ out,
+                                                         double *__restrict__ part) {
+    __shared__ double sh[4];
+    const int v = virtual_block();
+    const int64_t per = (n2 + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)v * per, hi = lo + per < n2 ? lo + per : n2;
+    double acc = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 2 * kBlock) {
+        const int64_t j = i + kBlock < hi ? i + kBlock : i;
+        double2 a = {0.0, 0.0}, b = {0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const double2 u = in[(int64_t)r * n2 + i], w = in[(int64_t)r * n2 + j];
+            a.x += u.x; a.y += u.y;
+            b.x += w.x; b.y += w.y;
+        }
+        if (W) {
+            out[i] = a;
+            if (j != i) out[j] = b;
+        } else {
+            acc += (a.x + a.y) + (b.x + b.y);
+        }
+    }
+    if (!W) {
+        const double tot = block_sum(acc, sh);
+        if (threadIdx.x == 0) part[blockIdx.x] = tot;
+    }
+}
+
+// bytes_per_stream: size of each stream (rounded down to 16 B); returns the bytes one launch moves (reads + writes)
+int64_t launch_stream_bench(int n_read, bool write, int64_t bytes_per_stream, const double *in, double *out, double *part,
+                            int grid, hipStream_t s) {
+    const int64_t n2 = bytes_per_stream / 16;
+    const double2 *i2 = reinterpret_cast<const double2 *>(in);
+    double2 *o2 = reinterpret_cast<double2 *>(out);
+#define DPCG_STREAM_CASE(NRV)                                                                                        \
+    case NRV:                                                                                                        \
+        if (write) hipLaunchKernelGGL((k_stream_bench<NRV, true>), dim3(grid), dim3(kBlock), 0, s, n2, i2, o2, part);  \
+        else hipLaunchKernelGGL((k_stream_bench<NRV, false>), dim3(grid), dim3(kBlock), 0, s, n2, i2, o2, part);       \
+        break
+    switch (n_read) {
+        DPCG_STREAM_CASE(1);
+        DPCG_STREAM_CASE(2);
+        DPCG_STREAM_CASE(3);
+        DPCG_STREAM_CASE(11);
+        default: return -1;
+    }
+#undef DPCG_STREAM_CASE
+    return n2 * 16 * (n_read + (write ? 1 : 0));
+}
+
 // sparse_matvec_mul (utils.py:26-41): out[b, row] += feature * vec[b, col] over COO triples.
 // One lane per triple, fp32 atomics on the output -- the same scatter-add the reference's own
 // CUDA path performs (torch scatter_reduce on a GPU tensor is an atomicAdd).

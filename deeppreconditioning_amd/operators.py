@@ -549,3 +549,13 @@ def dot(a: torch.Tensor, b: torch.Tensor) -> float:
     with torch.cuda.device(a.device):
         L.check(L.lib().dpcg_dot(a.numel(), _dev_ptr(a), _dev_ptr(b), C.byref(out), _stream()))
     return float(out.value)
+
+
+def stream_bench(n_read: int = 2, write: bool = True, bytes_per_stream: int = 1 << 27, repeats: int = 10) -> float:
+    """GB/s (reads + writes) of the library's own streaming kernel on this box: `n_read` streams of `bytes_per_stream`
+    summed into one output stream (or only reduced) -- the measured HBM ceiling next to the 8 TB/s spec.
+    n_read = 11 with write is the read:write ratio of a 7-point CSR SpMV."""
+    ms, moved = C.c_float(), C.c_int64()
+    L.check(L.lib().dpcg_stream_bench(int(n_read), 1 if write else 0, int(bytes_per_stream), int(repeats), C.byref(ms),
+                                      C.byref(moved), _stream()))
+    return moved.value / (ms.value * 1e-3) / 1e9

@@ -151,6 +151,13 @@ int dpcg_dot(int64_t n, const double *a, const double *b, double *out_host, dpcg
 int dpcg_spmv_dot_bench(dpcg_handle_t h, const double *x, double *y, int repeats, float *ms_per_launch,
                         dpcg_stream_t stream);
 
+/* The HBM streaming ceiling of this box with the library's own access shape (SURVEY.md 8-d2 asks for a measured ceiling
+ * beside the 8 TB/s spec; nothing in the reference corresponds -- its loop runs on torch CPU/CUDA ops, cg.py:75-86):
+ * n_read (1 copy, 2 triad, 3, or 11 = the read:write ratio of a 7-point CSR SpMV) streams of bytes_per_stream summed into
+ * one output stream (write = 1) or only reduced (write = 0); `repeats` launches between HIP events on `stream`. */
+int dpcg_stream_bench(int n_read, int write, int64_t bytes_per_stream, int repeats, float *ms_per_launch,
+                      int64_t *bytes_per_launch, dpcg_stream_t stream);
+
 /* ---- the solve: cg.py:50-90 (PCG) and cg.py:20-47 (CG = PCG with M = I, test on r) ----------- */
 /*
  * b, x0 (may be NULL = zeros, cg.py:58), x (out, may be NULL): device fp64[n].  x is written in stream order: valid for

@@ -404,6 +404,22 @@ class MixedOperator:
         return self.A32 @ v.astype(np.float32).astype(np.float64)
 
 
+class MixedOperatorX0(MixedOperator):
+    """`MixedOperator` for a solve with x0 != 0: the FIRST product (the initial residual b - A x0, cg.py:60) is the plain
+    fp64 one -- only the loop's `A @ pk` (cg.py:75) is mixed, as in orc_pcg_mixed and DPCG_SPMV_F32."""
+
+    def __init__(self, A: sp.csr_matrix):
+        super().__init__(A)
+        self.A = A.tocsr()
+        self.first = True
+
+    def __matmul__(self, v: np.ndarray) -> np.ndarray:
+        if self.first:
+            self.first = False
+            return self.A @ v
+        return super().__matmul__(v)
+
+
 def ground_truth_solve(A, b, atol=1e-6, maxiter=None):
     """The ground-truth solve of the data generator, generate_data.py:107: `scipy.sparse.linalg.cg(matrix, rhs, rtol=0,
     atol=1e-6)`.  The arithmetic lives in scipy (pinned 1.15.1 in the reference's uv.lock, 1.15.3 in this image; not

@@ -414,6 +414,7 @@ def test_mixed_precision_residual_matched(D):
     np.testing.assert_allclose(r32.res_history[:m], r64.res_history[:m], rtol=1e-4)
     y32 = S.spmv_f32(_dev(b.astype(np.float32))).cpu().numpy()
     np.testing.assert_allclose(y32, CO.spmv_f32(A, b.astype(np.float32)), rtol=2e-6, atol=1e-5)
+    assert np.array_equal(y32, CO.spmv_mixed(A, b).astype(np.float32))      # the contract: fp64 sums, rounded once
 
 
 def test_solve_batch_matches_single(D):
@@ -707,19 +708,99 @@ def test_c3_unstructured_million_dof_vs_oracle(D):
     np.testing.assert_allclose(r0.res_history, hist0, rtol=HIST_RTOL)
 
 
+MIXED_EARLY, MIXED_RTOL = 6, 1e-4
+
+
+def _check_mixed(res, it, hist, tag):
+    """Mixed precision against the mixed oracle.  Rounding p to fp32 is discontinuous: implementations whose fp64 dots
+    differ in the last bits round a few elements of p to different floats, and the recurrence amplifies that kick
+    (tests/test_oracle_golden.py measures 1.7e-6 between the REFERENCE's run and either CPU oracle on 4096 rows).  So:
+    counts equal, the first entries at north_star's 1e-10, the whole history at a measured bound."""
+    assert res.iterations == it, (tag, res.iterations, it)
+    np.testing.assert_allclose(res.res_history[:MIXED_EARLY], hist[:MIXED_EARLY], rtol=HIST_RTOL, err_msg=tag)
+    np.testing.assert_allclose(res.res_history, hist, rtol=MIXED_RTOL, err_msg=tag)
+
+
 def test_c5_mixed_precision_million_dof(D, golden):
-    """fp32 SpMV operands / fp64 everything else on the 1M-DoF system: residual-matched to the fp64 reference run."""
+    """BASELINE config 5 on the system it names: mixed fp32-SpMV / fp64 PCG on the 1M-DoF unstructured (OpenFOAM
+    stand-in) system -- D A D scaled, so its values are NOT fp32-representable, and the default handle is reordered, so
+    the fp32 copy is made from the REORDERED values.  Against oracle/pcg_oracle.c::orc_pcg_mixed (fp32-stored matrix
+    values and p in `A @ pk`, fp64 products, sums and everything else; pinned to the reference's loop by the `mixed/`
+    fixtures) run on the system the library iterates on; and residual-matched to the fp64 solve."""
     from deeppreconditioning_amd import poisson
+    A = poisson.unstructured_like_csr(3, 100, 0)
+    n = A.shape[0]
+    assert np.any(A.data.astype(np.float32).astype(np.float64) != A.data)
+    b = O.rhs(n, 0)
+    x = O.rhs(n, 7)
+    for reorder in ("auto", None):
+        S = D.CsrSystem.from_any(A, reorder=reorder)
+        assert S.reordered == (reorder == "auto")
+        perm = S.permutation() if S.reordered else np.arange(n)
+        B = _permuted(A, perm) if S.reordered else A
+        # the operator itself: fp32 in, fp32 out, fp64 products and in-order sums -- bit-exact on lossy values
+        y32 = S.spmv_f32(_dev(x.astype(np.float32))).cpu().numpy()
+        assert np.array_equal(y32[perm], CO.spmv_mixed(B, x[perm]).astype(np.float32))
+        np.testing.assert_allclose(y32[perm], CO.spmv_f32(B, x[perm].astype(np.float32)), rtol=3e-6, atol=1e-5)  # all-fp32 sums
+        S.set_preconditioner(D.Jacobi())
+        r64 = S.solve(_dev(b))
+        r32 = S.solve(_dev(b), flags=D._lib.SPMV_F32)
+        _, it, hist, xs = CO.pcg(B, b[perm], "jacobi", dinv=O.jacobi_dinv(B), mixed=True)
+        _check_mixed(r32, it, hist, f"c5 reorder={reorder}")
+        np.testing.assert_allclose(r32.x.cpu().numpy()[perm], xs, rtol=1e-5, atol=1e-8)
+        # residual-matched to the fp64 reference run: same count +-1, same target met by the TRUE fp64 residual
+        assert abs(r32.iterations - r64.iterations) <= 1
+        r_true = b - A @ r32.x.cpu().numpy()
+        assert np.dot(r_true, r_true) / np.dot(b, b) < 1.5e-8
+        m = min(len(r32.res_history), len(r64.res_history))
+        np.testing.assert_allclose(r32.res_history[:m], r64.res_history[:m], rtol=5e-3)
+        assert not np.array_equal(r32.res_history[:m], r64.res_history[:m])           # and it IS a different arithmetic
+        S.close()
+    # the structured 1M-DoF system (values exact in fp32): same count window against the fp64 golden
     S = poisson.poisson_system(3, 100)
     S.set_preconditioner(D.Jacobi())
-    b = poisson.rhs(S.n, 0)
-    r32 = S.solve(b, flags=D._lib.SPMV_F32)
+    bp = poisson.rhs(S.n, 0)
+    r32 = S.solve(bp, flags=D._lib.SPMV_F32)
     g = golden["pcg_poisson3d_100_jacobi/hist"]
     assert abs(r32.iterations - int(golden["pcg_poisson3d_100_jacobi/iters"])) <= 2
     m = min(len(g), len(r32.res_history))
     np.testing.assert_allclose(r32.res_history[:m], g[:m], rtol=2e-3)   # fp32 rounding of p: ~1e-7 per update
-    r_true = b - S @ r32.x
-    assert D.dot(r_true, r_true) / D.dot(b, b) < 1.5e-8
+    r_true = bp - S @ r32.x
+    assert D.dot(r_true, r_true) / D.dot(bp, bp) < 1.5e-8
+
+
+@pytest.mark.parametrize("name,make", [("unstructured3d_16", lambda: O.unstructured_like(O.poisson3d(16), seed=0)),
+                                       ("unstructured2d_64_seed2", lambda: O.unstructured_like(O.poisson2d(64), seed=2))])
+def test_mixed_precision_against_the_reference_fixtures(D, golden, name, make):
+    """DPCG_SPMV_F32 on lossy values against what the REFERENCE's loop produced with the mixed operator
+    (tests/golden/make_golden.py::MixedTorchOperator), Jacobi and IC(0) by triangular solves; every launch form; and a
+    handle that is reordered AFTER its fp32 copy was made (the copy must be rebuilt from the reordered values)."""
+    A = make()
+    n = A.shape[0]
+    b = O.rhs(n, 0)
+    S = D.CsrSystem.from_any(A, reorder=None)
+    x = O.rhs(n, 5)
+    assert np.array_equal(S.spmv_f32(_dev(x.astype(np.float32))).cpu().numpy(), CO.spmv_mixed(A, x).astype(np.float32))
+    for pc, key in ((D.Jacobi(), "jacobi"), (D.IC0("solve"), "ic0_solve")):
+        g, gi = golden[f"mixed/pcg_{name}_{key}/hist"], int(golden[f"mixed/pcg_{name}_{key}/iters"])
+        S.set_preconditioner(pc)
+        for flags in (0, D._lib.NO_GRAPH):
+            _check_mixed(S.solve(_dev(b), flags=D._lib.SPMV_F32 | flags), gi, g, f"{name} {key} flags={flags}")
+    S._reorder("rcm")                     # fp32 copy exists by now: dpcg_reorder must drop it
+    perm = S.permutation()
+    B = _permuted(A, perm)
+    y32 = S.spmv_f32(_dev(x.astype(np.float32))).cpu().numpy()
+    assert np.array_equal(y32[perm], CO.spmv_mixed(B, x[perm]).astype(np.float32))
+    S.set_preconditioner(D.Jacobi())
+    r = S.solve(_dev(b), flags=D._lib.SPMV_F32)
+    _, it, hist, _ = CO.pcg(B, b[perm], "jacobi", dinv=O.jacobi_dinv(B), mixed=True)
+    _check_mixed(r, it, hist, f"{name} reordered after the fp32 copy")
+    _check_mixed(r, int(golden[f"mixed/pcg_{name}_jacobi/iters"]), golden[f"mixed/pcg_{name}_jacobi/hist"], name)
+    x0 = O.rhs(n, 9)                      # x0 != 0: the initial residual is the fp64 product (only cg.py:75 is mixed)
+    r = S.solve(_dev(b), x0=_dev(x0), flags=D._lib.SPMV_F32)
+    _, it, hist, _ = CO.pcg(B, b[perm], "jacobi", dinv=O.jacobi_dinv(B), x0=x0[perm], mixed=True)
+    _check_mixed(r, it, hist, f"{name} x0")
+    S.close()
 
 
 def test_library_reordering_keeps_the_callers_numbering(D):
@@ -1538,3 +1619,58 @@ def test_two_ranks_share_one_gpu_real_matrices():
             O.unstructured_like(O.poisson2d(33), seed=2)]
     for i, (A, rec) in enumerate(zip(mats, out["table"])):
         assert int(rec[0]) == CO.pcg(A, O.rhs(A.shape[0], i), "jacobi", dinv=O.jacobi_dinv(A))[1] and int(rec[1]) == 0
+
+
+# ---- round 3: the script the driver launches on 8 GPUs, exercised at N = 2 on the one GPU of a gpurun box ----------
+def _run_bench(extra_args, port_env=None):
+    import json
+    import pathlib
+    import socket
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {**__import__("os").environ, "PYTHONPATH": str(root)}
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    # exactly the driver's command line (torch.distributed.run, one rank per GPU), with --backend gloo because both
+    # ranks sit on the box's single GPU (RCCL refuses two ranks on one device)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-extra",
+           "--no-cpu-baseline"] + extra_args
+    proc = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                       # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_script_control_flow_at_two_ranks(golden):
+    """`bench.py`'s own N > 1 control flow (rendezvous, sharding, barrier + synchronize, MAX over ranks, the rank-0
+    line), launched the way the driver launches it.  Headline shape: one 1M-DoF system per rank, 187 iterations each."""
+    it = int(golden["pcg_poisson3d_100_jacobi/iters"])
+    line = _run_bench(["--steps", "2", "--warmup", "1"])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["metric"] == "pcg_iterations_per_sec" and line["unit"] == "iterations/s" and line["dtype"] == "f64"
+    assert line["config"]["iterations_per_solve"] == it == 187
+    total = line["value"] * line["ms_per_step"] * 1e-3 * line["steps"]       # iterations of all ranks in the timed region
+    assert abs(total - 2 * 2 * it) < 0.01 * 2 * 2 * it, total
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0.3 < rf["frac"] < 1.0 and rf["achieved"] > 0
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["us_per_launch"] * 1e-6) / 1e9) < 1.0
+    assert "cpu_baseline" not in line and "extra" not in line
+
+
+def test_bench_script_config4_shape_at_two_ranks(golden):
+    """Config 4's shape (8 systems per GPU, up to four in flight per rank) through the same script, at 64^3 so that it
+    runs in seconds: 2 ranks x 8 systems x 127 iterations per step."""
+    it = int(golden["pcg_poisson3d_64_jacobi/iters"])
+    line = _run_bench(["--steps", "2", "--warmup", "1", "--n", "64", "--systems-per-gpu", "8"])
+    assert line["n_gpus"] == 2 and line["config"]["systems_per_gpu_per_step"] == 8
+    assert line["config"]["iterations_per_solve"] == it == 127
+    total = line["value"] * line["ms_per_step"] * 1e-3 * line["steps"]
+    # distinct right-hand sides per system (seed = global system id): counts differ by a few around the seed-0 one
+    assert abs(total - 2 * 2 * 8 * it) < 0.05 * 2 * 2 * 8 * it, total
+    assert "roofline" in line
