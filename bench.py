@@ -53,7 +53,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--systems-per-gpu", type=int, default=1)
     ap.add_argument("--dim", type=int, default=3)
-    ap.add_argument("--n", type=int, default=100, help="grid points per side (3-D 100 -> 1,000,000 DoF)")
+    # (`--grid`, not `--n`: torch.distributed.run reads `--n` in front of the script's own arguments as an ambiguous
+    # abbreviation of its --nnodes / --nproc-per-node and refuses the command line)
+    ap.add_argument("--grid", "--n", dest="n", type=int, default=100, help="grid points per side (3-D 100 -> 1,000,000 DoF)")
     ap.add_argument("--precond", default="jacobi", choices=["jacobi", "none", "ic0"])
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,7 +129,8 @@ def main() -> None:
         # convenience: launch the one-process-per-GPU job as a child (never exec after touching the GPU)
         port = os.environ.get("MASTER_PORT", "29531")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", port, str(ROOT / "bench.py")] + sys.argv[1:]
+               "--master-addr", "127.0.0.1", "--master-port", port, str(ROOT / "bench.py")] + \
+              ["--grid" if a == "--n" else a for a in sys.argv[1:]]
         sys.exit(subprocess.run(cmd).returncode)
 
     import torch

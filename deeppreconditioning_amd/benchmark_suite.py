@@ -22,6 +22,22 @@ from .operators import IC0, ICT, CsrSystem, Identity, Jacobi, LLtMultiply
 
 PARAMETERS = ["kappas", "densities", "iterations", "setups", "durations", "totals", "successes"]  # test.py:180
 
+# How far each technique's row of `table.csv` may be compared with the reference's own table (written to `comparability.csv`
+# beside it).  `incomplete_cholesky` is NOT comparable: the reference runs `ilupp.icholt(add_fill_in=1, threshold=0.1)`
+# (test.py:81-88); ilupp is absent here (not vendored, no network), so its rule cannot be pinned -- if `add_fill_in` is a
+# per-row count of extra entries kept after a relative drop (a dual-threshold ICT, which is how we read its documentation),
+# the factor differs from this library's ICT (level-1 fill pattern + MATLAB's `ict` drop rule, oracle.ict) in pattern and
+# values, and with it the iteration, density and setup columns, by an unknown amount.
+COMPARABILITY = {
+    "vanilla": "comparable: M = I (test.py:70-72)",
+    "jacobi": "comparable: M = diag(1/a_ii) (test.py:74-79)",
+    "incomplete_cholesky": "NOT COMPARABLE: stand-in for ilupp.icholt(add_fill_in=1, threshold=0.1) with this library's own ICT "
+                           "rule (level-1 fill + 'ict' drop tolerance); ilupp's rule is unpinned, columns will differ",
+    "incomplete_cholesky_0": "algorithm comparable (textbook IC(0) = ilupp.ichol0's definition), values unpinned against ilupp",
+    "incomplete_cholesky_solve": "not in the reference: IC(0) applied by triangular solves",
+    "learned": "comparable given the same checkpoint; spconv's weight layout is assumed KRSC (unpinned)",
+}
+
 
 class ListDataSet:
     """In-memory stand-in for the reference's data sets: item = (systems_tril, solutions, right_hand_sides,
@@ -143,6 +159,10 @@ class BenchmarkSuite:
                 for parameter in PARAMETERS:
                     line += "," + str(np.mean(getattr(self, parameter)[technique], dtype=float))
                 f.write(line + "\n")
+        with (self.results_directory / "comparability.csv").open(mode="w") as f:     # not in the reference: see COMPARABILITY
+            f.write("technique,comparable_with_the_reference\n")
+            for technique in self.techniques:
+                f.write(f'{technique},"{COMPARABILITY.get(technique, "unknown technique")}"\n')
         with (self.results_directory / "totals.csv").open(mode="w") as f:
             f.write(",".join(self.techniques) + "\n")
             for index in range(len(self.totals[self.techniques[0]])):

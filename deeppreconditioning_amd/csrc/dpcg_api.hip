@@ -340,24 +340,33 @@ extern "C" int dpcg_reorder(dpcg_handle_t h, int mode, dpcg_stream_t stream, int
         if (h->gather_ratio <= 4.0) return DPCG_OK;
     }
     int32_t *perm = nullptr, *iperm = nullptr;
-    DPCG_TRY(rcm_order(h->A, &perm, &iperm, nullptr, s));
+    int st = rcm_order(h->A, &perm, &iperm, nullptr, s);
+    if (st == DPCG_ERR_INVALID && mode == DPCG_REORDER_AUTO) return DPCG_OK;   // not a symmetric pattern: AUTO leaves the handle as it is
+    if (st < 0) return st;
+    // Everything that can fail is built FIRST, into locals; the handle is switched over only when all of it exists
+    // (a failure half way would otherwise leave the old plan on the new matrix).
     CsrDev B;
-    int st = permute_csr(h->A, perm, iperm, B, s);
+    SpmvPlan planB;
+    st = permute_csr(h->A, perm, iperm, B, s);
+    if (st >= 0) st = make_plan(B, planB, s, true);
     if (st < 0) {
         dev_free(perm);
         dev_free(iperm);
         free_csr(B);
+        free_plan(planB);
         return st;
     }
     free_precond(h);                 // an attached preconditioner referred to the old matrix
     free_ell(h->ell_a);
+    drop_graph(h);
     dev_free(h->A.val32);            // recreated on demand from the reordered values
     h->A.val32_lossless = 0;
+    free_plan(h->planA);
     h->A_user = h->A;                // ownership (or the borrow) moves with the struct
     h->A = B;
+    h->planA = planB;
     h->perm = perm;
     h->iperm = iperm;
-    DPCG_TRY(make_plan(h->A, h->planA, s, true));
     if (applied) *applied = 1;
     return DPCG_OK;
 }

@@ -36,14 +36,18 @@ extern "C" int dpcg_set_precond_jacobi(dpcg_handle_t h, const double *dinv, int 
     if (dinv && h->perm) {                           // the caller's numbering -> the handle's
         double *tmp = nullptr;
         const double *src = dinv;
+        hipError_t e = hipSuccess;
         if (memspace == DPCG_HOST) {
             DPCG_TRY(dev_alloc(&tmp, h->A.n));
-            DPCG_HIP(hipMemcpyAsync(tmp, dinv, (size_t)h->A.n * sizeof(double), hipMemcpyHostToDevice, s));
+            e = hipMemcpyAsync(tmp, dinv, (size_t)h->A.n * sizeof(double), hipMemcpyHostToDevice, s);
             src = tmp;
         }
-        launch_gather_f64(h->A.n, h->perm, src, h->dinv, s);
-        DPCG_HIP(hipStreamSynchronize(s));
-        dev_free(tmp);
+        if (e == hipSuccess) {
+            launch_gather_f64(h->A.n, h->perm, src, h->dinv, s);
+            e = hipStreamSynchronize(s);
+        }
+        dev_free(tmp);                                 // on every path, error or not
+        DPCG_HIP(e);
     } else if (dinv) {
         DPCG_HIP(hipMemcpyAsync(h->dinv, dinv, (size_t)h->A.n * sizeof(double),
                                 memspace == DPCG_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
@@ -51,11 +55,14 @@ extern "C" int dpcg_set_precond_jacobi(dpcg_handle_t h, const double *dinv, int 
     } else {
         int *d_bad = nullptr, h_bad = 0;
         DPCG_TRY(dev_alloc(&d_bad, 1));
-        DPCG_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), s));
-        launch_extract_dinv(h->A, h->dinv, d_bad, s);
-        DPCG_HIP(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s));
-        DPCG_HIP(hipStreamSynchronize(s));
+        hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(int), s);
+        if (e == hipSuccess) {
+            launch_extract_dinv(h->A, h->dinv, d_bad, s);
+            e = hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
         dev_free(d_bad);
+        DPCG_HIP(e);
         if (h_bad) {
             dev_free(h->dinv);
             set_error("Jacobi: missing or non-positive diagonal entry");

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void k_bfs_step(const int32_t *__restrict__
 __global__ __launch_bounds__(kBlock) void k_cm_keys(const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                     const int32_t *__restrict__ level, const int32_t *__restrict__ order,
                                                     const int32_t *__restrict__ pos, int32_t *__restrict__ key,
-                                                    int32_t *child, int s1, int c1, int L) {
+                                                    int32_t *child, int s1, int c1, int L, int *err) {
     const int stride = gridDim.x * kBlock;
     for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < c1; idx += stride) {
         const int u = order[s1 + idx];
@@ -108,7 +108,11 @@ __global__ __launch_bounds__(kBlock) void k_cm_keys(const int32_t *__restrict__ 
             }
         }
         key[u] = mp;
-        atomicAdd(&child[mp], 1);
+        // A vertex the search reached through a PARENT's row finds no level L - 1 neighbour in its OWN row only when the
+        // pattern is not structurally symmetric (a one-sided entry, a triangle handed over by mistake): no parent to
+        // count it under -- flag it and leave it unplaced (rcm_order then reports the pattern instead of a wrong order).
+        if (mp == 0x7fffffff) atomicExch(err, 1);
+        else atomicAdd(&child[mp], 1);
     }
 }
 
@@ -147,11 +151,13 @@ __global__ __launch_bounds__(kBlock) void k_cm_place(const int32_t *__restrict__
     for (int idx = blockIdx.x * kBlock + threadIdx.x; idx < c1; idx += stride) {
         const int u = order[s1 + idx];
         const int mp = key[u];
+        if (mp == 0x7fffffff) continue;                   // no parent (flagged by k_cm_keys)
         const int p = vertex_at_prev[mp];
         const int du = deg[u];
         int rank = 0;
         for (int k = rp[p]; k < rp[p + 1]; ++k) {
             const int w = ci[k];
+            if (k > rp[p] && ci[k - 1] == w) continue;    // a duplicated entry (adjacent: columns ascend) counts once
             if (w != u && level[w] == L && key[w] == mp) {
                 const int dw = deg[w];
                 if (dw < du || (dw == du && w < u)) ++rank;
@@ -185,13 +191,29 @@ __global__ __launch_bounds__(kBlock) void k_place_unvisited(int64_t n, const int
 }
 
 // reverse Cuthill-McKee: new index of vertex u = n - 1 - pos[u]
+// perm arrives filled with -1; a position out of range is flagged, a position taken twice leaves another slot at -1
 __global__ __launch_bounds__(kBlock) void k_finish_perm(int64_t n, const int32_t *__restrict__ pos, int32_t *__restrict__ perm,
-                                                        int32_t *__restrict__ iperm) {
+                                                        int32_t *__restrict__ iperm, int *err) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x; u < n; u += stride) {
-        const int r = (int)(n - 1 - pos[u]);
+        const int64_t q = pos[u];
+        if (q < 0 || q >= n) {
+            atomicExch(err, 1);
+            continue;
+        }
+        const int r = (int)(n - 1 - q);
         iperm[u] = r;
         perm[r] = (int32_t)u;
+    }
+}
+
+// perm is a bijection iff every slot was written and maps back: perm[r] = u with iperm[u] = r
+__global__ __launch_bounds__(kBlock) void k_check_perm(int64_t n, const int32_t *__restrict__ perm, const int32_t *__restrict__ iperm,
+                                                       int *err) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) {
+        const int u = perm[r];
+        if (u < 0 || u >= n || iperm[u] != r) atomicExch(err, 1);
     }
 }
 
@@ -388,6 +410,9 @@ int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_c
     if (n + 2 + kBfsBatch > 2147483000LL) return invalid("reordering: system too large");
     Buf<int32_t> deg, level, order, start, count, pos, vertex_at, key, child, base, perm, iperm;
     Buf<unsigned long long> best;
+    Buf<int> err;
+    DPCG_TRY(err.alloc(1));
+    DPCG_HIP(hipMemsetAsync(err.p, 0, sizeof(int), s));
     const int64_t nlv = n + 2 + 2 * kBfsBatch;
     DPCG_TRY(deg.alloc(n)); DPCG_TRY(level.alloc(n)); DPCG_TRY(order.alloc(n + 1)); DPCG_TRY(start.alloc(nlv));
     DPCG_TRY(count.alloc(nlv)); DPCG_TRY(pos.alloc(n)); DPCG_TRY(vertex_at.alloc(n + 1)); DPCG_TRY(key.alloc(n));
@@ -397,6 +422,7 @@ int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_c
     DPCG_HIP(hipMemsetAsync(level.p, 0xff, (size_t)n * sizeof(int32_t), s));
     DPCG_HIP(hipMemsetAsync(count.p, 0, (size_t)nlv * sizeof(int32_t), s));
     DPCG_HIP(hipMemsetAsync(child.p, 0, (size_t)(n + 1) * sizeof(int32_t), s));
+    DPCG_HIP(hipMemsetAsync(pos.p, 0xff, (size_t)n * sizeof(int32_t), s));      // -1: not placed
     auto min_degree = [&](const int32_t *list, int64_t lo, int64_t hi, int only_unvisited, int *v) -> int {
         DPCG_HIP(hipMemsetAsync(best.p, 0xff, sizeof(unsigned long long), s));
         hipLaunchKernelGGL(k_min_degree, dim3(rows_grid(hi - lo, 1024)), dim3(kBlock), 0, s, list, lo, hi, deg.p, level.p,
@@ -458,7 +484,7 @@ int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_c
             const int s0 = c.start[(size_t)l - 1], c0 = c.count[(size_t)l - 1];
             const int g = rows_grid(c1, 1024);
             hipLaunchKernelGGL(k_cm_keys, dim3(g), dim3(kBlock), 0, s, A.rowptr, A.col, level.p, order.p, pos.p, key.p, child.p,
-                               s1, c1, L);
+                               s1, c1, L, err.p);
             hipLaunchKernelGGL(k_scan_range, dim3(1), dim3(1024), 0, s, child.p, base.p, s0, c0);
             hipLaunchKernelGGL(k_cm_place, dim3(g), dim3(kBlock), 0, s, A.rowptr, A.col, level.p, order.p, deg.p, key.p, base.p,
                                vertex_at.p, pos.p, vertex_at.p, s1, c1, L);
@@ -472,9 +498,20 @@ int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_c
         DPCG_TRY(exclusive_scan_i32(flag.p, offs.p, n, s));
         hipLaunchKernelGGL(k_place_unvisited, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, level.p, offs.p, visited, pos.p);
     }
-    hipLaunchKernelGGL(k_finish_perm, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, pos.p, perm.p, iperm.p);
+    // pos[] of a vertex that was never placed is whatever the allocation held: start from an invalid value
+    DPCG_HIP(hipMemsetAsync(perm.p, 0xff, (size_t)n * sizeof(int32_t), s));
+    DPCG_HIP(hipMemsetAsync(iperm.p, 0xff, (size_t)n * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_finish_perm, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, pos.p, perm.p, iperm.p, err.p);
+    // The construction yields a permutation for a structurally symmetric pattern without duplicate entries; it is CHECKED,
+    // not assumed: a one-sided entry leaves a vertex without a parent, a duplicated column ranks two siblings alike.
+    hipLaunchKernelGGL(k_check_perm, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, perm.p, iperm.p, err.p);
+    int bad = 0;
+    DPCG_HIP(hipMemcpyAsync(&bad, err.p, sizeof(int), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
     DPCG_CHECK_LAUNCH();
+    if (bad)
+        return invalid("reordering: the sparsity pattern is not structurally symmetric or has duplicate entries "
+                       "(reverse Cuthill-McKee needs the pattern of a symmetric matrix, columns ascending)");
     if (n_components) *n_components = (int)comps.size() + (visited < n ? 1 : 0);
     *perm_out = perm.release();
     *iperm_out = iperm.release();

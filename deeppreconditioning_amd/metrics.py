@@ -3,8 +3,11 @@
 `frobenius_loss` runs on the HIP batched COO SpMV and is differentiable with respect to the network output
 (`utils._SparseMatvec`).  `inverse_loss` -- the loss the reference actually trains (train.py:59) -- never forms the
 dense N x N matrices of metrics.py:45-55: || L L^T A - I ||_F is accumulated over panels of columns J as
-L (L^T A[:, J]) - I[:, J] with the HIP panel kernels (`utils._SparseMatmat`), O(N nnz(L)) work and O(N |J|) memory, and
-is differentiable with respect to L's entries.  `inverse_loss_dense` is the reference's dense form, kept as the checker.
+L (L^T A[:, J]) - I[:, J] with the HIP panel kernels (`utils._SparseMatmat`), O(N nnz(L)) work and O(N |J|) memory -- also
+under autograd: every panel is checkpointed (recomputed in backward), so training keeps ONE panel's intermediates alive, not
+all of them -- and is differentiable with respect to L's entries.  The panel product accumulates with fp32 atomics (as the
+reference's own CUDA `scatter_reduce` does), so the loss and its gradients vary in the last bits from run to run.
+`inverse_loss_dense` is the reference's dense form, kept as the checker.
 """
 
 from __future__ import annotations
@@ -44,17 +47,26 @@ def inverse_loss(systems_tril, preconditioners_tril, panel_columns: int = 256) -
     ar = torch.cat((r_, c_[low]))
     ac = torch.cat((c_, r_[low]))
     av = torch.cat((val, val[low]))
-    total = torch.zeros(batch, dtype=torch.float32, device=dev)
-    for j0 in range(0, dof, panel_columns):
-        jn = min(panel_columns, dof - j0)
+    def panel_sum(l_feats: torch.Tensor, j0: int, jn: int) -> torch.Tensor:
+        factor = preconditioners_tril.replace_feature(l_feats)
         sel = (ac >= j0) & (ac < j0 + jn)
         panel = torch.zeros((batch, dof, jn), dtype=torch.float32, device=dev)
         panel.index_put_((ab[sel], ar[sel], ac[sel] - j0), av[sel], accumulate=True)      # A[:, J]
-        t = sparse_matmat_mul(preconditioners_tril, panel, transpose=True)               # L^T A[:, J]
-        u = sparse_matmat_mul(preconditioners_tril, t, transpose=False)                  # L (L^T A[:, J])
+        t = sparse_matmat_mul(factor, panel, transpose=True)                             # L^T A[:, J]
+        u = sparse_matmat_mul(factor, t, transpose=False)                                # L (L^T A[:, J])
         eye = torch.zeros((dof, jn), dtype=torch.float32, device=dev)
         eye[torch.arange(j0, j0 + jn, device=dev), torch.arange(jn, device=dev)] = 1.0
-        total = total + ((u - eye.unsqueeze(0)) ** 2).sum(dim=(1, 2))
+        return ((u - eye.unsqueeze(0)) ** 2).sum(dim=(1, 2))
+
+    training = torch.is_grad_enabled() and feats.requires_grad
+    total = torch.zeros(batch, dtype=torch.float32, device=dev)
+    for j0 in range(0, dof, panel_columns):
+        jn = min(panel_columns, dof - j0)
+        if training:   # recompute the panel in backward: peak memory stays one panel (batch * N * |J| fp32 x 3), not N / |J| of them
+            from torch.utils.checkpoint import checkpoint
+            total = total + checkpoint(panel_sum, feats, j0, jn, use_reentrant=False)
+        else:
+            total = total + panel_sum(feats, j0, jn)
     return total.sqrt().mean()
 
 

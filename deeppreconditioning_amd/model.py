@@ -119,13 +119,141 @@ class PreconditionerNet(nn.Module):
         self.layers.add(SparseConv2d(channels[-2], channels[-1], 1))         # model.py:40
 
     def forward(self, input_: SparseBatch) -> SparseBatch:
-        """The `L` part of the `L @ L.T` preconditioner (model.py:42-59)."""
+        """The `L` part of the `L @ L.T` preconditioner (model.py:42-59).
+
+        Inference on the GPU (no autograd graph wanted) runs the hand-written HIP path -- `dpcg_convnet_*` in
+        include/dpcg.h: rulebooks built on the device once per sparsity pattern, gathered GEMMs on the fp32 matrix cores
+        with bias / PReLU fused, the tril mask and the softplus of model.py:53-57 fused into the last layer, L written
+        straight into a lower-triangular CSR (`output.lower_csr`, what `lower_factor_csr` / `LLtMultiply` take).  Training
+        (autograd) and CPU tensors take the torch ops below; `DPCG_CNN_TORCH=1` forces them."""
+        if _hip_forward_applies(self, input_):
+            return _hip_forward(self, input_)
         interim = self.layers(input_)
         rows, cols = interim.indices[:, 1], interim.indices[:, 2]
         feats = interim.features
         feats = torch.where((rows < cols).unsqueeze(-1), torch.zeros_like(feats), feats)          # model.py:53-54
         feats = torch.where((rows == cols).unsqueeze(-1), nn.functional.softplus(feats), feats)   # model.py:56-57
         return interim.replace_feature(feats)
+
+
+# ---- the HIP path of PreconditionerNet.forward (inference) -----------------------------------------------------------
+class _ConvnetPlan:
+    """Owner of a `dpcg_convnet_plan_t` (active sites + rulebooks of every layer for ONE sparsity pattern)."""
+
+    def __init__(self, indices: torch.Tensor, batch: int, shape, kernels, paddings):
+        import ctypes as C
+        from . import _lib as L
+        self._L, self._C = L, C
+        self.indices = indices                         # kept alive: the cache key is its storage
+        self.handle = C.c_void_p()
+        n = len(kernels)
+        k = (C.c_int32 * (2 * n))(*[v for kk in kernels for v in kk])
+        p = (C.c_int32 * (2 * n))(*[v for pp in paddings for v in pp])
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(L.lib().dpcg_convnet_plan_create(C.byref(self.handle), int(batch), int(shape[0]), int(shape[1]),
+                                                 int(indices.shape[0]), C.c_void_p(indices.data_ptr()), n, k, p, stream))
+        sites, h, w, nl = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.lib().dpcg_convnet_plan_info(self.handle, n - 1, C.byref(sites), C.byref(h), C.byref(w), C.byref(nl)))
+        self.sites, self.out_shape, self.nnz_lower, self.batch = sites.value, [h.value, w.value], nl.value, int(batch)
+        dev = indices.device
+        self.out_indices = torch.empty((self.sites, 3), dtype=torch.int32, device=dev)
+        self.lower_rowptr = torch.empty(self.batch * h.value + 1, dtype=torch.int32, device=dev)
+        self.lower_col = torch.empty(self.nnz_lower, dtype=torch.int32, device=dev)
+        L.check(L.lib().dpcg_convnet_plan_output(self.handle, C.c_void_p(self.out_indices.data_ptr()),
+                                                 C.c_void_p(self.lower_rowptr.data_ptr()), C.c_void_p(self.lower_col.data_ptr()),
+                                                 stream))
+
+    def close(self):
+        if self.handle is not None and self.handle.value:
+            self._L.lib().dpcg_convnet_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _conv_layers(net):
+    """[(conv, prelu or None)] of a PreconditionerNet, or None when a module is not one the HIP path knows."""
+    out = []
+    for m in net.layers:
+        if isinstance(m, SparseConv2d):
+            out.append([m, None])
+        elif isinstance(m, nn.PReLU) and out and out[-1][1] is None and m.weight.numel() == 1:
+            out[-1][1] = m
+        else:
+            return None
+    return out
+
+
+def _hip_forward_applies(net, t: SparseBatch) -> bool:
+    import os
+    if os.environ.get("DPCG_CNN_TORCH") == "1" or torch.is_grad_enabled():
+        return False
+    if not (t.features.is_cuda and t.features.dtype == torch.float32 and t.indices.dtype == torch.int32):
+        return False
+    layers = _conv_layers(net)
+    if not layers:
+        return False
+    for conv, _ in layers:
+        kh, kw = conv.kernel_size
+        if conv.stride != (1, 1) or kh * kw > 4 or conv.weight.dtype != torch.float32:
+            return False
+    last, last_act = layers[-1]
+    return (last.kernel_size == (1, 1) and last.padding == (0, 0) and last.out_channels == 1 and last_act is None
+            and last.in_channels in (16, 32, 64) and t.features.shape[1] == layers[0][0].in_channels)
+
+
+def _hip_forward(net, t: SparseBatch) -> SparseBatch:
+    return hip_conv_stack(_conv_layers(net), t, lower=True, cache=net.__dict__.setdefault("_hip_plans", {}))
+
+
+def hip_conv_stack(layers, t: SparseBatch, lower: bool = False, cache: dict | None = None) -> SparseBatch:
+    """Run `[(SparseConv2d, nn.PReLU | None), ...]` (stride 1, windows up to 2 x 2) on the HIP path (`dpcg_convnet_*`).
+    lower=True: the last layer is pointwise with one output channel and model.py:53-57 is fused into it (`lower_csr`)."""
+    import ctypes as C
+    from . import _lib as L
+    layers = [list(x) for x in layers]
+    cache = {} if cache is None else cache
+    indices = t.indices.contiguous()
+    feats = t.features.contiguous()
+    kernels = [tuple(c.kernel_size) for c, _ in layers]
+    paddings = [tuple(c.padding) for c, _ in layers]
+    key = (indices.data_ptr(), indices._version, indices.shape[0], tuple(t.spatial_shape), t.batch_size, tuple(kernels), tuple(paddings))
+    plan = cache.get(key)
+    with torch.cuda.device(feats.device):
+        if plan is None:
+            try:
+                plan = _ConvnetPlan(indices, t.batch_size, t.spatial_shape, kernels, paddings)
+            except L.DpcgError as exc:
+                if "sorted" not in str(exc):
+                    raise
+                # sites in another order: sort them once (spconv accepts any order; the data sets emit sorted ones)
+                H, W = t.spatial_shape
+                k = (indices[:, 0].long() * H + indices[:, 1].long()) * W + indices[:, 2].long()
+                order = torch.argsort(k)
+                return hip_conv_stack(layers, SparseBatch(feats[order], indices[order].contiguous(), t.spatial_shape, t.batch_size),
+                                      lower, cache)
+            while len(cache) >= 4:                       # a plan holds rulebooks and feature buffers: keep a few
+                cache.pop(next(iter(cache))).close()
+            cache[key] = plan
+        n = len(layers)
+        chan = (C.c_int32 * (n + 1))(*([layers[0][0].in_channels] + [c.out_channels for c, _ in layers]))
+        ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else C.c_void_p()       # noqa: E731
+        keep = [c.weight.detach().contiguous() for c, _ in layers]
+        w = (C.c_void_p * n)(*[ptr(x) for x in keep])
+        b = (C.c_void_p * n)(*[ptr(c.bias.detach() if c.bias is not None else None) for c, _ in layers])
+        a = (C.c_void_p * n)(*[ptr(act.weight.detach() if act is not None else None) for _, act in layers])
+        out_feats = torch.empty((plan.sites, layers[-1][0].out_channels), dtype=torch.float32, device=feats.device)
+        lower_val = torch.empty(plan.nnz_lower, dtype=torch.float64, device=feats.device) if lower else None
+        L.check(L.lib().dpcg_convnet_forward(plan.handle, chan, w, b, a, ptr(feats), ptr(out_feats), ptr(lower_val),
+                                             1 if lower else 0, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    out = SparseBatch(out_feats, plan.out_indices, plan.out_shape, t.batch_size)
+    if lower:
+        out.lower_csr = (plan.lower_rowptr, plan.lower_col, lower_val)  # rows = batch * height, sample b at [b * H, (b + 1) * H)
+    return out
 
 
 class SubMConv2d(nn.Module):
@@ -314,6 +442,12 @@ def lower_factor_csr(output: SparseBatch, batch_index: int, original_size: int):
     """L of one sample as CSR parts (rowptr int32, col int32, val float64) on the tensor's device: the entries
     with col <= row < original_size (test.py:102 slices `[:n,:n]`; the strict upper part is zero, model.py:54).
     Sites come out of `SparseConv2d` sorted by (batch,row,col), so the diagonal is last in each row."""
+    if getattr(output, "lower_csr", None) is not None:      # the HIP forward wrote L into a lower-triangular CSR already
+        rp, ci, v = output.lower_csr
+        H = output.spatial_shape[0]
+        lo, hi = batch_index * H, batch_index * H + original_size
+        ends = rp[[lo, hi]].tolist()                          # one small copy to size the slices
+        return (rp[lo:hi + 1] - ends[0]).contiguous(), ci[ends[0]:ends[1]].contiguous(), v[ends[0]:ends[1]].contiguous()
     idx, feats = output.indices.long(), output.features[:, 0]
     keep = (idx[:, 0] == batch_index) & (idx[:, 2] <= idx[:, 1]) & (idx[:, 1] < original_size)
     rows, cols, vals = idx[keep, 1], idx[keep, 2], feats[keep].detach().to(torch.float64)

@@ -217,6 +217,35 @@ int dpcg_batched_coo_sddmm(int64_t nnz, const int32_t *indices, int batch, int64
 int dpcg_coo_to_csr(int64_t n, int64_t nnz, const int32_t *rows, const int32_t *cols, const double *vals,
                     int32_t *rowptr, int32_t *col_out, double *val_out, int64_t *nnz_out, dpcg_stream_t stream);
 
+/* ---- the CNN that emits L: PreconditionerNet's sparse convolutions (model.py:13-59) --------------
+ * The reference runs them through spconv (CUDA only, pyproject.toml:20).  Here: a PLAN per sparsity pattern -- every
+ * layer's active sites and its rulebook, built on the device -- and a FORWARD that runs the layers as gathered GEMMs on the
+ * fp32 matrix cores with bias and PReLU (model.py:28,37) fused, the last pointwise layer fused with model.py:53-57 (strict
+ * upper part zeroed, softplus on the diagonal), L written straight into a lower-triangular CSR with fp64 values -- what
+ * dpcg_set_precond_llt takes; test.py:102-105 densifies instead.  Regular sparse convolution, stride 1, windows up to
+ * 2 x 2: an output site is active when its window holds an input site; out(y, x) = sum in(y + ky - ph, x + kx - pw) W[ky, kx].
+ *   indices: int32 (nnz, 3) rows of (batch, row, col), device, sorted by (batch, row, col) (what data_set.py:122 emits);
+ *   kernel_hw / padding_hw: host, 2 ints per layer;  weights[l]: device fp32 (C_out, kh, kw, C_in) -- spconv's KRSC layout;
+ *   biases[l] (may be NULL), prelu[l] (device, ONE slope as nn.PReLU(); NULL = no activation after layer l): device fp32. */
+typedef struct dpcg_convnet_plan *dpcg_convnet_plan_t;
+int dpcg_convnet_plan_create(dpcg_convnet_plan_t *out, int batch, int64_t height, int64_t width, int64_t nnz,
+                             const int32_t *indices, int n_layers, const int32_t *kernel_hw, const int32_t *padding_hw,
+                             dpcg_stream_t stream);
+int dpcg_convnet_plan_destroy(dpcg_convnet_plan_t plan);
+/* active sites and image size after layer `layer`; nnz_lower: entries with col <= row of the LAST layer's sites */
+int dpcg_convnet_plan_info(dpcg_convnet_plan_t plan, int layer, int64_t *sites, int64_t *height, int64_t *width,
+                           int64_t *nnz_lower);
+/* the output sites as (sites, 3) indices sorted by (batch, row, col), and the pattern of the lower-triangular CSR over
+ * batch * height rows (sample b = rows [b * height, (b + 1) * height)); device arrays, any may be NULL */
+int dpcg_convnet_plan_output(dpcg_convnet_plan_t plan, int32_t *indices_out, int32_t *lower_rowptr, int32_t *lower_col,
+                             dpcg_stream_t stream);
+/* channels: host, n_layers + 1.  features_in: device fp32 (nnz, channels[0]).  features_out: device fp32 (sites, channels[n])
+ * or NULL.  lower_val: device fp64 [nnz_lower] or NULL; lower_softplus = 1 applies model.py:53-57 (both need a pointwise last
+ * layer with one output channel).  Enqueues on `stream`; hidden features live in plan-owned buffers. */
+int dpcg_convnet_forward(dpcg_convnet_plan_t plan, const int32_t *channels, const float *const *weights,
+                         const float *const *biases, const float *const *prelu, const float *features_in,
+                         float *features_out, double *lower_val, int lower_softplus, dpcg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(str(_LIB_PATH))
         _lib.orc_pcg.restype = C.c_double
         _lib.orc_pcg_mixed.restype = C.c_double
+        _lib.orc_pcg_perm.restype = C.c_double
         _lib.orc_dot.restype = C.c_double
         _lib.orc_ic0.restype = C.c_int64
         _lib.orc_num_threads.restype = C.c_int
@@ -127,9 +128,11 @@ def sptrsv_upper(U: sp.csr_matrix, y: np.ndarray) -> np.ndarray:
 
 
 def pcg(A: sp.csr_matrix, b: np.ndarray, kind: str = "none", *, dinv=None, M=None, L=None, x0=None, rtol=1e-8,
-        max_iter=1024, init_check="z", mixed=False):
+        max_iter=1024, init_check="z", mixed=False, precond_perm=None):
     """Returns (seconds, iterations, residual_history, x) -- same tuple as oracle.oracle's PCG.
-    mixed=True: config 5, the loop's `A @ pk` on fp32-stored values and pk (orc_pcg_mixed)."""
+    mixed=True: config 5, the loop's `A @ pk` on fp32-stored values and pk (orc_pcg_mixed).
+    precond_perm: A (and b, x0, x) are the permuted system P A_c P^T, row i = the caller's row precond_perm[i], while
+    dinv / M / L stay in the caller's numbering: z' = P M P^T r' (orc_pcg_perm)."""
     n = A.shape[0]
     rp, ci, v = _csr_parts(A)
     b = np.ascontiguousarray(b, dtype=np.float64)
@@ -144,7 +147,11 @@ def pcg(A: sp.csr_matrix, b: np.ndarray, kind: str = "none", *, dinv=None, M=Non
     tail = (_p(b), _p(x0a), C.c_int(KINDS[kind]), _p(dinv_a),
             _p(m[0]), _p(m[1]), _p(m[2]), _p(l[0]), _p(l[1]), _p(l[2]), _p(lt[0]), _p(lt[1]), _p(lt[2]),
             C.c_double(rtol), C.c_int(max_iter), C.c_int(1 if init_check == "z" else 0), _p(x), _p(hist), C.byref(iters))
-    if mixed:
+    if precond_perm is not None:
+        pp = np.ascontiguousarray(precond_perm, dtype=np.int32)
+        v32 = v.astype(np.float32) if mixed else None
+        sec = lib().orc_pcg_perm(C.c_int64(n), _p(rp), _p(ci), _p(v), _p(v32), _p(pp), *tail)
+    elif mixed:
         v32 = v.astype(np.float32)
         sec = lib().orc_pcg_mixed(C.c_int64(n), _p(rp), _p(ci), _p(v), _p(v32), *tail)
     else:

@@ -346,6 +346,19 @@ class Precond:
         raise ValueError(self.kind)
 
 
+class PermutedPrecond:
+    """z' = P M P^T r' for a preconditioner M kept in the CALLER's numbering while the system is P A P^T (row i = the
+    caller's row perm[i]): what a reordered libdpcg handle does with a factor it solves with (dpcg_reorder)."""
+
+    def __init__(self, M, perm):
+        self.M, self.perm = M, np.asarray(perm)
+
+    def __matmul__(self, r: np.ndarray) -> np.ndarray:
+        rc = np.empty_like(r)
+        rc[self.perm] = r
+        return (self.M @ rc)[self.perm]
+
+
 # --------------------------------------------------------------------------------------------
 # Solvers
 # --------------------------------------------------------------------------------------------

@@ -33,7 +33,13 @@ for name, A in (("poisson3d_40", O.poisson3d(40)), ("poisson2d_300", O.poisson2d
         up = S.sptrsv(torch.from_numpy(t).cuda(), upper=True).cpu().numpy()
         ap = S.precond_apply(torch.from_numpy(b).cuda()).cpu().numpy()
         res = S.solve(torch.from_numpy(b).cuda())
-        _, it, hist, _ = CO.pcg(A, b, "llt_solve", L=L)
+        if S.reordered:      # oracle on P A P^T with the caller's factor applied as P M P^T (orc_pcg_perm): 1e-10 applies
+            perm = S.permutation()
+            Bp = A[perm][:, perm].tocsr()
+            Bp.sort_indices()
+            _, it, hist, _ = CO.pcg(Bp, b[perm], "llt_solve", L=L, precond_perm=perm)
+        else:
+            _, it, hist, _ = CO.pcg(A, b, "llt_solve", L=L)
         ok[mode] = {"lower": bool(np.array_equal(lo, t)), "upper": bool(np.array_equal(up, z)), "apply": bool(np.array_equal(ap, z)),
                     "iterations": [res.iterations, it],
                     "hist_rel": float(np.max(np.abs(res.res_history - hist) / hist)) if res.iterations == it else None}
