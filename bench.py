@@ -46,6 +46,30 @@ def loop_kernel_bytes(system) -> int:
     return spmv_bytes(system.n, system.nnz) + (fused_update_bytes(system.n) if system.info()["two_kernel_updates"] else 0)
 
 
+def sptrsv_bytes(n: int, nnz_l: int) -> int:
+    """Algorithmic bytes of ONE sparse triangular solve: nnz_L*12 + (n+1)*4 + 2*n*8 + the row list 4*n."""
+    return nnz_l * 12 + (n + 1) * 4 + 16 * n + 4 * n
+
+
+def apply_roofline(system, apply_us: float) -> dict:
+    """`roofline` object of a preconditioner apply z = L^-T (L^-1 r): two triangular solves."""
+    b = 2 * sptrsv_bytes(system.n, system.info()["precond_nnz"])
+    gbs = b / (apply_us * 1e-6) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_apply": b, "us_per_apply": round(apply_us, 1),
+            "levels": [system.info()["levels_lower"], system.info()["levels_upper"]]}
+
+
+def time_apply(system, b, torch, reps: int = 20) -> float:
+    system.precond_apply(b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        system.precond_apply(b)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e6
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,16 +134,20 @@ def cpu_baseline(dim: int, n: int) -> dict:
 
 def measured_stream_ceilings() -> dict:
     """HBM ceiling as this box delivers it, measured with the library's own streaming kernel
-    (`dpcg_stream_bench`: 16-byte lane accesses, XCD-contiguous slabs, the SpMV's grid) on buffers far beyond the 256 MiB
-    Infinity Cache: copy (1 read : 1 write), triad (2 : 1), the read:write ratio of a 7-point CSR SpMV (11 : 1) and
-    read-only.  GB/s of reads + writes."""
+    (`dpcg_stream_bench`: 16-byte lane accesses, XCD-contiguous slabs, the SpMV's grid; shapes chosen with
+    tools/stream_lab) on buffers far beyond the 256 MiB Infinity Cache: copy (1 read : 1 write), triad (2 : 1), the
+    read:write ratio of a 7-point CSR SpMV (11 : 1) and read-only, each with plain and with non-temporal accesses.
+    GB/s of reads + writes.  Any share of writes costs this memory system a fifth of its read-only rate."""
     from deeppreconditioning_amd.operators import stream_bench
     mib = 1 << 20
-    return {"copy_1r1w": round(stream_bench(1, True, 1024 * mib, 10), 1),
-            "triad_2r1w": round(stream_bench(2, True, 512 * mib, 10), 1),
-            "spmv_like_11r1w": round(stream_bench(11, True, 128 * mib, 10), 1),
-            "read_only_3r": round(stream_bench(3, False, 512 * mib, 10), 1),
-            "method": "dpcg_stream_bench, 10 launches between HIP events, 0.5-1.5 GiB per launch"}
+    out = {}
+    for tag, nt in (("", False), ("_nt", True)):
+        out["copy_1r1w" + tag] = round(stream_bench(1, True, 1024 * mib, 10, nt), 1)
+        out["triad_2r1w" + tag] = round(stream_bench(2, True, 512 * mib, 10, nt), 1)
+        out["spmv_like_11r1w" + tag] = round(stream_bench(11, True, 128 * mib, 10, nt), 1)
+        out["read_only" + tag] = round(stream_bench(4, False, 384 * mib, 10, nt), 1)
+    out["method"] = "dpcg_stream_bench, 10 launches between HIP events, 1.4-2 GiB per launch"
+    return out
 
 
 def main() -> None:
@@ -256,7 +284,9 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b4_alg / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "traffic": pmc_all.get("spmv_3d_256"), "algorithmic_bytes_per_launch": b4_alg,
                 "us_per_launch": round(ms4 * 1e3, 2), "dof": s4.n, "nnz": s4.nnz,
-                "frac_of_measured_spmv_like_stream": round(b4_alg / (ms4 * 1e-3) / 1e9 / ceilings["spmv_like_11r1w"], 4)}
+                "frac_of_measured_spmv_like_stream": round(b4_alg / (ms4 * 1e-3) / 1e9 /
+                                                           max(ceilings["spmv_like_11r1w"], ceilings["spmv_like_11r1w_nt"]), 4),
+                "non_temporal_streams": bool(s4.info().get("spmv_nt", False))}
             s4.close()
             del s4
         if world == 1 and not args.no_cpu_baseline:
@@ -290,7 +320,9 @@ def extra_workloads(D, poisson, torch) -> dict:
     s = poisson.poisson_system(2, 256)
     b = poisson.rhs(s.n, 0)
     c2 = {}
-    for name, pc in (("jacobi", D.Jacobi()), ("ic0_solve", D.IC0("solve")), ("ict_multiply_reference_default", D.ICT("multiply", 1, 0.1))):
+    for name, pc in (("jacobi", D.Jacobi()), ("ic0_solve", D.IC0("solve")),
+                     ("ic0_multicolor_solve", D.IC0("solve", ordering="multicolor")),
+                     ("ict_multiply_reference_default", D.ICT("multiply", 1, 0.1))):
         s.set_preconditioner(pc)            # first attach: module load etc.; the second one is timed (test.py:130-135 `setups`)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -300,6 +332,8 @@ def extra_workloads(D, poisson, torch) -> dict:
         r = solve_twice(s, b)
         c2[name] = {"iterations": r.iterations, "status": r.status, "ms": round(r.seconds * 1e3, 3),
                     "iterations_per_s": round(r.iterations / r.seconds, 1), "setup_ms": round(setup_ms, 2)}
+        if name in ("ic0_solve", "ic0_multicolor_solve"):
+            c2[name]["apply_roofline"] = apply_roofline(s, time_apply(s, b, torch))
         if name == "ic0_solve":
             c2["levels"] = s.info()["levels_lower"]
     # the CNN-emitted factor (seeded random weights: no checkpoint ships), applied as z = L (L^T r) without densifying
@@ -313,7 +347,8 @@ def extra_workloads(D, poisson, torch) -> dict:
     A2 = (sp.diags([np.full(n2 * n2, 4.0), np.where((idx[:-1] + 1) % n2 != 0, -1.0, 0.0), np.full(n2 * n2 - n2, -1.0)],
                    [0, -1, -n2], format="csr"))                       # tril of the 5-point matrix
     inp, sizes = mdl.tril_batch_from_csr([A2], device="cuda")
-    for _ in range(2):                                                    # second pass: library warm-up excluded
+    for _ in range(3):                                                    # last pass counts: library warm-up excluded
+        net.__dict__.get("_hip_plans", {}).clear()                        # a NEW sparsity pattern per matrix: the plan is part of it
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with torch.no_grad():
@@ -321,11 +356,25 @@ def extra_workloads(D, poisson, torch) -> dict:
         Lparts = mdl.lower_factor_csr(outL, 0, sizes[0])
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - t0) * 1e3
-    s.set_preconditioner(D.LLtMultiply(Lparts))
-    r = solve_twice(s, b)
+        s.set_preconditioner(D.LLtMultiply(Lparts))
+        torch.cuda.synchronize()
+        setup_ms = (time.perf_counter() - t0) * 1e3 - fwd_ms
+        r = s.solve(b, want_history=False)
+        total_ms = (time.perf_counter() - t0) * 1e3
+    with torch.no_grad():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            net(inp)
+        torch.cuda.synchronize()
+        fwd_cached_ms = (time.perf_counter() - t0) / 5 * 1e3
     c2["learned_random_weights_llt_multiply"] = {"iterations": r.iterations, "status": r.status, "ms": round(r.seconds * 1e3, 3),
                                                  "iterations_per_s": round(r.iterations / r.seconds, 1),
-                                                 "nnz_L": int(Lparts[1].numel()), "cnn_forward_ms": round(fwd_ms, 2)}
+                                                 "nnz_L": int(Lparts[1].numel()),
+                                                 "cnn_forward_ms": round(fwd_ms, 3), "cnn_forward_plan_cached_ms": round(fwd_cached_ms, 3),
+                                                 "cnn_path": "hip" if getattr(outL, "lower_csr", None) is not None else "torch",
+                                                 "llt_setup_ms": round(setup_ms, 3),
+                                                 "end_to_end_forward_setup_solve_ms": round(total_ms, 3)}
     out["c2_poisson2d_256"] = c2
     del s, net, outL, inp
     # IC(0) applied by triangular solves on natural-order 3-D grids: setup (factorisation + level / strip schedules, all
@@ -350,7 +399,24 @@ def extra_workloads(D, poisson, torch) -> dict:
         r = solve_twice(s_t, b_t)
         trsv[f"poisson3d_{n3}"] = {"rows": s_t.n, "levels": s_t.info()["levels_lower"], "setup_ms": round(setup_ms, 2),
                                    "apply_us": round(apply_us, 1), "pcg_iterations": r.iterations,
-                                   "pcg_us_per_update": round(r.seconds / r.iterations * 1e6, 1)}
+                                   "pcg_us_per_update": round(r.seconds / r.iterations * 1e6, 1), "pcg_ms": round(r.seconds * 1e3, 3),
+                                   "apply_roofline": apply_roofline(s_t, apply_us)}
+        # the same factorisation in multicolour (here: red-black) order: 2 levels instead of hundreds
+        s_t.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s_t.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+        torch.cuda.synchronize()
+        setup_ms = (time.perf_counter() - t0) * 1e3
+        apply_us = time_apply(s_t, b_t, torch)
+        r = solve_twice(s_t, b_t)
+        s_t.set_preconditioner(D.Jacobi())
+        rj = solve_twice(s_t, b_t)
+        trsv[f"poisson3d_{n3}_multicolor"] = {"colors": s_t.precond_ordering()[0], "setup_ms": round(setup_ms, 2),
+                                              "apply_us": round(apply_us, 1), "pcg_iterations": r.iterations,
+                                              "pcg_us_per_update": round(r.seconds / r.iterations * 1e6, 1),
+                                              "pcg_ms": round(r.seconds * 1e3, 3), "jacobi_pcg_ms": round(rj.seconds * 1e3, 3),
+                                              "jacobi_iterations": rj.iterations}
         s_t.close()
     out["ic0_triangular_solves_natural_order"] = trsv
     # 1M-DoF 2-D system: hits max_iter = 1024 like the reference (fixed-work throughput)
@@ -374,7 +440,8 @@ def extra_workloads(D, poisson, torch) -> dict:
     b3 = poisson.rhs(s3.n, 0)
     c3 = {"create_incl_upload_and_reordering_ms": round(create_s * 1e3, 1), "reordered": s3.info()["reordered"],
           "gather_ratio_before": round(s3.info()["gather_ratio"], 2), "spmv_kernel": s3.info()["spmv_kernel"]}
-    for name, pc in (("jacobi", D.Jacobi()), ("ic0_solve", D.IC0("solve"))):
+    for name, pc in (("jacobi", D.Jacobi()), ("ic0_multicolor_solve", D.IC0("solve", ordering="multicolor")),
+                     ("ic0_solve", D.IC0("solve"))):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         s3.set_preconditioner(pc)
@@ -383,6 +450,9 @@ def extra_workloads(D, poisson, torch) -> dict:
         r = solve_twice(s3, b3)
         c3[name] = {"iterations": r.iterations, "ms": round(r.seconds * 1e3, 3), "iterations_per_s": round(r.iterations / r.seconds, 1),
                     "us_per_update": round(r.seconds / r.iterations * 1e6, 1), "setup_ms": round(setup_ms, 2)}
+        if name != "jacobi":
+            c3[name]["apply_roofline"] = apply_roofline(s3, time_apply(s3, b3, torch))
+            c3[name]["levels"] = s3.info()["levels_lower"]
     c3["levels"] = s3.info()["levels_lower"]
     # config 5 AS BASELINE STATES IT: mixed fp32-SpMV / fp64 PCG on this 1M-DoF unstructured system (values not
     # fp32-representable; the fp32 copy is made from the reordered matrix), residual-matched to the fp64 run

@@ -25,6 +25,7 @@ PRECOND_NONE, PRECOND_JACOBI, PRECOND_CSR, PRECOND_LLT_MULTIPLY, PRECOND_LLT_SOL
 PRECOND_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)   # dpcg_precond_fn
 INIT_CHECK_R, SPMV_F32, NO_GRAPH, NO_SMALL, VAL32_IF_LOSSLESS, NO_FUSE = 1, 2, 4, 8, 16, 32
 REORDER_NONE, REORDER_AUTO, REORDER_ALWAYS = 0, 1, 2
+ORDER_CALLER, ORDER_MULTICOLOR = 0, 1
 
 # name -> (restype, argtypes); every symbol include/dpcg.h declares
 _p = C.c_void_p
@@ -48,6 +49,8 @@ SIGNATURES = {
     "dpcg_set_precond_csr": (_int, [_p, _i64, _p, _p, _p, _int, _p]),
     "dpcg_set_precond_llt": (_int, [_p, _int, _i64, _p, _p, _p, _int, _p]),
     "dpcg_set_precond_ic0": (_int, [_p, _int, _p]),
+    "dpcg_set_precond_ic0_ordered": (_int, [_p, _int, _int, _p]),
+    "dpcg_get_precond_ordering": (_int, [_p, C.POINTER(_int), _p]),
     "dpcg_set_precond_ict": (_int, [_p, _int, _int, _dbl, _p]),
     "dpcg_get_factor": (_int, [_p, _p, _p, _p]),
     "dpcg_spmv": (_int, [_p, _p, _p, _p]),
@@ -56,7 +59,7 @@ SIGNATURES = {
     "dpcg_sptrsv": (_int, [_p, _int, _p, _p, _p]),
     "dpcg_dot": (_int, [_i64, _p, _p, C.POINTER(_dbl), _p]),
     "dpcg_spmv_dot_bench": (_int, [_p, _p, _p, _int, C.POINTER(C.c_float), _p]),
-    "dpcg_stream_bench": (_int, [_int, _int, _i64, _int, C.POINTER(C.c_float), C.POINTER(_i64), _p]),
+    "dpcg_stream_bench": (_int, [_int, _int, _int, _i64, _int, C.POINTER(C.c_float), C.POINTER(_i64), _p]),
     "dpcg_solve": (_int, [_p, _p, _p, _p, _dbl, _dbl, _int, _int, _p, C.POINTER(_int), C.POINTER(_dbl),
                           C.POINTER(_dbl), _p, _p, _p]),
     "dpcg_solve_batch": (_int, [_int, _p, _p, _p, _p, _dbl, _dbl, _int, _int, _int, _p, _p, _p, _p]),

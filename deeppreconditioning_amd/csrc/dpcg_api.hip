@@ -208,6 +208,10 @@ int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s, bool allow_tile) {
             if (h_flags[0] == 1 && h_flags[1] > 0) {
                 plan.kernel = SPMV_TILE;
                 plan.tile_max_chunks = h_flags[1];
+                // streams that cannot stay in the 256 MiB Infinity Cache are read (and y written) non-temporally
+                // (DPCG_SPMV_NT=0/1 overrides: development knob)
+                static const int nt_knob = [] { const char *e = getenv("DPCG_SPMV_NT"); return e ? atoi(e) : -1; }();
+                plan.stream_nt = nt_knob >= 0 ? nt_knob != 0 : stream_bytes >= 512e6;
                 const size_t lds = (size_t)(h_flags[1] * kTileChunk + kStreamCap + 8) * sizeof(double);
                 const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
                 cap = std::min(cap, per_cu * 256);
@@ -260,6 +264,9 @@ void free_precond(dpcg_system *h) {
     free_csr(h->Ltp);
     free_levels(h->lvlL);
     free_levels(h->lvlU);
+    dev_free(h->fmap);
+    dev_free(h->fmap_inv);
+    h->precond_colors = 0;
     h->precond_fn = nullptr;
     h->precond_user = nullptr;
     h->precond = DPCG_PRECOND_NONE;
@@ -415,7 +422,9 @@ extern "C" int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spm
     if (!h) return invalid("dpcg_get_info: NULL handle");
     if (n) *n = h->A.n;
     if (nnz) *nnz = h->A.nnz;
-    if (spmv_kernel) *spmv_kernel = h->planA.kernel + (fuse_eligible(h, 0, nullptr) ? 16 : 0);   // +16: two-kernel updates
+    if (spmv_kernel)   // +16: two-kernel updates; +32: the x-tile kernel streams non-temporally
+        *spmv_kernel = h->planA.kernel + (fuse_eligible(h, 0, nullptr) ? 16 : 0) +
+                       (h->planA.kernel == SPMV_TILE && h->planA.stream_nt ? 32 : 0);
     if (precond_kind) *precond_kind = h->precond;
     if (precond_nnz) *precond_nnz = h->precond == DPCG_PRECOND_CSR ? h->M.nnz : h->L.nnz;
     if (n_levels_lower) *n_levels_lower = h->lvlL.n_levels;
@@ -683,31 +692,34 @@ extern "C" int dpcg_spmv_dot_bench(dpcg_handle_t h, const double *x, double *y, 
 }
 
 // The streaming ceiling of THIS box, measured with the library's own kernel shape (16-byte lane accesses, XCD-contiguous
-// slabs, `grid` workgroups): n_read input streams of bytes_per_stream each summed into one output stream (write = 1) or into
-// per-workgroup partials (write = 0).  What an HBM-bound kernel of this library can at best reach.
-extern "C" int dpcg_stream_bench(int n_read, int write, int64_t bytes_per_stream, int repeats, float *ms_per_launch,
+// slabs, 2048 workgroups): per 16 bytes written, n_read x 16 contiguous bytes are read and summed (write = 1), or the reads
+// are only reduced (write = 0, out_bytes then sizes the read stream: n_read x out_bytes).  What an HBM-bound kernel of this
+// library can at best reach on the box it runs on.
+extern "C" int dpcg_stream_bench(int n_read, int write, int nontemporal, int64_t out_bytes, int repeats, float *ms_per_launch,
                                  int64_t *bytes_per_launch, dpcg_stream_t stream) {
-    if (bytes_per_stream < 16 || repeats <= 0 || !ms_per_launch) return invalid("dpcg_stream_bench: bad argument");
+    if (out_bytes < 16 || repeats <= 0 || !ms_per_launch || n_read < 1) return invalid("dpcg_stream_bench: bad argument");
     hipStream_t s = (hipStream_t)stream;
     double *in = nullptr, *out = nullptr, *part = nullptr;
-    const int64_t n = bytes_per_stream / 8;
-    DPCG_TRY(dev_alloc(&in, n * n_read));
-    int st = dev_alloc(&out, write ? n : 1);
+    const int64_t n = out_bytes / 8;
+    const int64_t in_doubles = n * n_read + 2 * kBlock * 2 * n_read * 2;          // one tile of slack behind the last slab
+    DPCG_TRY(dev_alloc(&in, in_doubles));
+    int st = dev_alloc(&out, write ? n + 4 * kBlock : 1);
     if (st >= 0) st = dev_alloc(&part, kMaxSpmvGrid);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0.f;
     int64_t moved = 0;
     hipError_t e = hipSuccess;
     if (st >= 0) {
-        e = hipMemsetAsync(in, 0, (size_t)n * n_read * sizeof(double), s);
+        e = hipMemsetAsync(in, 0, (size_t)in_doubles * sizeof(double), s);
         if (e == hipSuccess) e = hipEventCreate(&e0);
         if (e == hipSuccess) e = hipEventCreate(&e1);
         for (int i = 0; i < 2 && e == hipSuccess; ++i)
-            moved = launch_stream_bench(n_read, write != 0, bytes_per_stream, in, out, part, kMaxSpmvGrid, s);
-        if (e == hipSuccess && moved < 0) st = invalid("dpcg_stream_bench: n_read must be 1, 2, 3 or 11");
+            moved = launch_stream_bench(n_read, write != 0, nontemporal != 0, out_bytes, in, out, part, kMaxSpmvGrid, s);
+        if (e == hipSuccess && moved < 0) st = invalid("dpcg_stream_bench: n_read must be 1, 2, 4 or 11");
         if (e == hipSuccess && st >= 0) {
             e = hipEventRecord(e0, s);
-            for (int i = 0; i < repeats; ++i) launch_stream_bench(n_read, write != 0, bytes_per_stream, in, out, part, kMaxSpmvGrid, s);
+            for (int i = 0; i < repeats; ++i)
+                launch_stream_bench(n_read, write != 0, nontemporal != 0, out_bytes, in, out, part, kMaxSpmvGrid, s);
             if (e == hipSuccess) e = hipEventRecord(e1, s);
             if (e == hipSuccess) e = hipEventSynchronize(e1);
             if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);

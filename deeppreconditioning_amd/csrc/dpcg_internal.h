@@ -51,6 +51,7 @@ struct SpmvPlan {
     int32_t *tile_nchunks = nullptr;   // [nrb]
     uint16_t *tile_lidx = nullptr;     // [nnz]
     int tile_max_chunks = 0;           // largest chunk count of any block (sizes the dynamic LDS)
+    bool stream_nt = false;            // x-tile kernel: once-read streams and y non-temporal (streams beyond the Infinity Cache)
 };
 
 // Device-resident scalar state of one solve.  Only block 0 of a kernel writes it; everybody else
@@ -183,6 +184,10 @@ struct dpcg_system {
     void *precond_user = nullptr;
     dpcg::CsrDev L, Lt;                   // the factor and its transpose in the CALLER's numbering
     dpcg::CsrDev Lp, Ltp;                 // reordered handle, multiply mode: P L P^T and P L^T P^T (what the SpMVs read)
+    // A factor that lives in a numbering of its own (IC(0) in multicolour order): fmap[factor index] = handle index,
+    // fmap_inv the inverse; owned.  Null: the factor is in the caller's numbering (handle index through iperm, if any).
+    int32_t *fmap = nullptr, *fmap_inv = nullptr;
+    int precond_colors = 0;               // colours of that ordering (0: caller's ordering)
     dpcg::SpmvPlan planL, planLt;
     // dpcg_reorder: the handle iterates on A = P A_user P^T; perm[new] = old, iperm[old] = new (device)
     int32_t *perm = nullptr, *iperm = nullptr;
@@ -332,6 +337,7 @@ void launch_relabel(int64_t count, const int32_t *map, int32_t *idx, hipStream_t
 int gather_line_ratio(const CsrDev &A, double *ratio, hipStream_t s);
 int permute_csr(const CsrDev &A, const int32_t *perm, const int32_t *iperm, CsrDev &B, hipStream_t s);
 int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_components, hipStream_t s);
+int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_colors, hipStream_t s);
 // ---- structural analysis of triangular factors on the device (dpcg_analysis.hip) ----
 void launch_check_lower(const CsrDev &L, int *flags, hipStream_t s);
 void launch_row_of(int64_t n, const int32_t *rp, int32_t *row_of, hipStream_t s);
@@ -376,7 +382,7 @@ void launch_tril_count(int64_t n, const int32_t *rp, const int32_t *ci, int32_t 
 void launch_tril_copy(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, const int32_t *lrp, int32_t *lci,
                       double *lv, hipStream_t s);
 void launch_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void *val, int val_dtype, hipStream_t s);
-int64_t launch_stream_bench(int n_read, bool write, int64_t bytes_per_stream, const double *in, double *out, double *part,
+int64_t launch_stream_bench(int n_read, bool write, bool nt, int64_t out_bytes, const double *in, double *out, double *part,
                             int grid, hipStream_t s);
 void launch_batched_coo_edge(int64_t nnz, const int32_t *indices, int batch, int64_t dof, const float *a, const float *c,
                              float *out, int transpose, hipStream_t s);

@@ -224,6 +224,8 @@ static bool level_major_wanted(int64_t n, int n_levels) {
     static const int knob = [] { const char *e = getenv("DPCG_LEVEL_MAJOR"); return e ? atoi(e) : -1; }();
     if (knob == 0 || !syncfree_enabled()) return false;
     if (knob == 1) return true;
+    // a multicolour-ordered factor has 2 .. ~8 levels of n / colours rows: the case this form is made for
+    if (n >= 32768 && n_levels >= 2 && n_levels < 6 && n / n_levels >= 4096) return true;
     // measured, IC(0) of scrambled grids, us per PCG update without / with: 100^3 (19 levels of 53K rows on average) 270 / 146,
     // 64^3 (18 x 14.5K) 134 / 91, 1024^2 (18 x 58K) 201 / 141, 256^2 (13 x 5K) 78 / 54, 40^3 (19 x 3.4K) 83 / 92
     return n >= 32768 && n_levels >= 6 && n / n_levels >= 4096;
@@ -655,6 +657,8 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
     PhaseTimer pt(s);
     DPCG_TRY(transpose_lower(h->L, h->Lt, s));
     pt.mark("transpose");
+    // factor index -> handle index: the factor's own numbering (fmap: multicolour IC(0)) or the caller's (iperm, if reordered)
+    const int32_t *fm = h->fmap ? h->fmap : h->iperm;
     if (h->perm && mode == DPCG_PRECOND_LLT_MULTIPLY) {
         DPCG_TRY(permute_csr(h->L, h->perm, h->iperm, h->Lp, s));
         DPCG_TRY(permute_csr(h->Lt, h->perm, h->iperm, h->Ltp, s));
@@ -668,7 +672,7 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
     if (mode == DPCG_PRECOND_LLT_SOLVE) {
         LevelSort own, up;
         if (!lower_levels) {
-            DPCG_TRY(compute_levels(n, h->L.rowptr, h->L.col, false, own, s, h->iperm));
+            DPCG_TRY(compute_levels(n, h->L.rowptr, h->L.col, false, own, s, fm));
             lower_levels = &own;
             pt.mark("levels(L)");
         }
@@ -689,7 +693,7 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
             static const int64_t pct = [] { const char *e = getenv("DPCG_LONG_ROW_PCT"); return e ? (int64_t)atoll(e) : (int64_t)2; }();
             const bool long_rows = (int64_t)h_long * 100 > n * pct;
             if (long_rows) {
-                DPCG_TRY(build_levels(lv, ls, n, F.nnz, F.rowptr, F.col, F.val, s, h->iperm, upper, true));
+                DPCG_TRY(build_levels(lv, ls, n, F.nnz, F.rowptr, F.col, F.val, s, fm, upper, true));
                 return DPCG_OK;
             }
             const bool strips_first = n > 131072;
@@ -698,12 +702,12 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
                 lv.n_levels = (int)ls.level_ptr.size() - 1;
                 DPCG_TRY(dev_alloc(&lv.spin_err, 1));
                 DPCG_HIP(hipMemsetAsync(lv.spin_err, 0, sizeof(int), s));
-                DPCG_TRY(build_strips(lv, n, F.nnz, F.rowptr, F.col, F.val, upper, h->iperm, s));
+                DPCG_TRY(build_strips(lv, n, F.nnz, F.rowptr, F.col, F.val, upper, fm, s));
                 if (lv.strips.n_strips > 0) return DPCG_OK;
                 dev_free(lv.spin_err);
             }
-            DPCG_TRY(build_levels(lv, ls, n, F.nnz, F.rowptr, F.col, F.val, s, h->iperm, upper));
-            if (!strips_first) DPCG_TRY(build_strips(lv, n, F.nnz, F.rowptr, F.col, F.val, upper, h->iperm, s));
+            DPCG_TRY(build_levels(lv, ls, n, F.nnz, F.rowptr, F.col, F.val, s, fm, upper));
+            if (!strips_first) DPCG_TRY(build_strips(lv, n, F.nnz, F.rowptr, F.col, F.val, upper, fm, s));
             if (lv.strips.n_strips > 0) lv.level_major = false;
             return DPCG_OK;
         };
@@ -715,11 +719,11 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
             h->lvlU.n_levels = h->lvlL.n_levels;
             DPCG_TRY(dev_alloc(&h->lvlU.spin_err, 1));
             DPCG_HIP(hipMemsetAsync(h->lvlU.spin_err, 0, sizeof(int), s));
-            DPCG_TRY(build_strips(h->lvlU, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, true, h->iperm, s));
+            DPCG_TRY(build_strips(h->lvlU, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, true, fm, s));
             if (h->lvlU.strips.n_strips == 0) dev_free(h->lvlU.spin_err);
         }
         if (h->lvlU.strips.n_strips == 0) {
-            DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s, h->iperm));
+            DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s, fm));
             pt.mark("levels(L^T)");
             DPCG_TRY(schedule(h->lvlU, up, h->Lt, true));
         }
@@ -754,19 +758,40 @@ extern "C" int dpcg_set_precond_llt(dpcg_handle_t h, int mode, int64_t nnz, cons
 // by count / scan / copy, the level sets of its pattern, then the numeric factorisation one launch per level
 // (k_ic0_level) in the operation order of the CPU restatement (bit-identical factor).  The handle keeps its previous
 // preconditioner when the factorisation fails.
-extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t stream) {
+extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int ordering, dpcg_stream_t stream) {
     if (!h) return invalid("NULL handle");
     if (mode != DPCG_PRECOND_LLT_MULTIPLY && mode != DPCG_PRECOND_LLT_SOLVE) return invalid("bad LLT mode");
+    if (ordering != DPCG_ORDER_CALLER && ordering != DPCG_ORDER_MULTICOLOR) return invalid("dpcg_set_precond_ic0_ordered: bad ordering");
+    if (ordering == DPCG_ORDER_MULTICOLOR && mode != DPCG_PRECOND_LLT_SOLVE)
+        return invalid("dpcg_set_precond_ic0_ordered: the multicolour ordering serves the triangular solves (mode LLT_SOLVE)");
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = h->A.n;
-    // the factor of the CALLER's matrix (what ilupp.ichol0 would be handed), also when the handle iterates on P A P^T
-    const CsrDev &Asrc = h->perm ? h->A_user : h->A;
+    // DPCG_ORDER_MULTICOLOR: IC(0) of Q A Q^T, Q = the handle's matrix colour by colour (dpcg_reorder.hip: multicolor_order).
+    // The permuted matrix is a temporary; the factor stays in that numbering and is addressed through fmap.
+    CsrDev Ac;
+    int32_t *cperm = nullptr, *ciperm = nullptr;
+    int n_colors = 0;
+    if (ordering == DPCG_ORDER_MULTICOLOR) {
+        DPCG_TRY(multicolor_order(h->A, &cperm, &ciperm, &n_colors, s));
+        const int stp = permute_csr(h->A, cperm, ciperm, Ac, s);
+        if (stp < 0) {
+            dev_free(cperm);
+            dev_free(ciperm);
+            free_csr(Ac);
+            return stp;
+        }
+    }
+    // otherwise the factor of the CALLER's matrix (what ilupp.ichol0 would be handed), also when the handle iterates on P A P^T
+    const CsrDev &Asrc = ordering == DPCG_ORDER_MULTICOLOR ? Ac : (h->perm ? h->A_user : h->A);
     CsrDev Lf;
     Lf.n = n;
     Lf.owned = true;
     DevBuf<int32_t> cnt, flags;
     auto fail = [&](int st) {
         free_csr(Lf);
+        free_csr(Ac);
+        dev_free(cperm);
+        dev_free(ciperm);
         return st;
     };
     int st = DPCG_OK;
@@ -790,7 +815,7 @@ extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t str
     launch_tril_copy(n, Asrc.rowptr, Asrc.col, Asrc.val, Lf.rowptr, Lf.col, Lf.val, s);
     pt.mark("tril(A)");
     LevelSort ls;
-    if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, ls, s, h->iperm)) < 0) return fail(st);
+    if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, ls, s, cperm ? cperm : h->iperm)) < 0) return fail(st);
     pt.mark("levels(tril A)");
     if ((st = numeric_incomplete_cholesky(ls, n, Lf, reinterpret_cast<int *>(flags.p) + 1, nullptr, 0.0, s)) < 0) return fail(st);
     e = hipGetLastError();
@@ -803,10 +828,37 @@ extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t str
         return fail(DPCG_ERR_PIVOT);
     }
     free_precond(h);
+    free_csr(Ac);
     h->L = Lf;
+    h->fmap = cperm;                  // factor index -> handle index (null: the caller's numbering)
+    h->fmap_inv = ciperm;
+    h->precond_colors = n_colors;
     st = finish_llt(h, mode, s, &ls);
     if (st < 0) free_precond(h);
     return st;
+}
+
+extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t stream) {
+    return dpcg_set_precond_ic0_ordered(h, mode, DPCG_ORDER_CALLER, stream);
+}
+
+// perm_host[k] = the CALLER's row that sits at position k of the factor's numbering (identity for DPCG_ORDER_CALLER)
+extern "C" int dpcg_get_precond_ordering(dpcg_handle_t h, int *n_colors, int32_t *perm_host) {
+    if (!h) return invalid("NULL handle");
+    if (n_colors) *n_colors = h->precond_colors;
+    if (!perm_host) return DPCG_OK;
+    const int64_t n = h->A.n;
+    if (!h->fmap) {
+        for (int64_t k = 0; k < n; ++k) perm_host[k] = (int32_t)k;
+        return DPCG_OK;
+    }
+    DPCG_HIP(hipMemcpy(perm_host, h->fmap, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));    // handle indices
+    if (h->perm) {                                                                                  // -> caller's rows
+        std::vector<int32_t> p((size_t)n);
+        DPCG_HIP(hipMemcpy(p.data(), h->perm, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < n; ++k) perm_host[k] = p[(size_t)perm_host[k]];
+    }
+    return DPCG_OK;
 }
 
 // ICT -- thresholded incomplete Cholesky with level-1 fill (contract: oracle/oracle.py::ict; stands in for

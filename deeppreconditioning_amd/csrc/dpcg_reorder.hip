@@ -518,4 +518,163 @@ int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_c
     return DPCG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Multicolour ordering (for IC(0) applied by triangular solves): vertices of one colour share no edge, so ordered colour
+// by colour the factor's dependency graph is only as deep as the number of colours -- 2 for a bipartite mesh graph (every
+// 5- / 7-point grid, scrambled or not), a handful in general -- instead of the hundreds of levels of a natural ordering.
+// Fewer, wider levels is what the solve kernels want; the price is a somewhat weaker preconditioner (measured with the
+// CPU oracle on the scrambled 48^3 system: 42 iterations / 19 levels in the caller's order, 51 / 2 red-black, Jacobi 102).
+//   1. two colours by breadth-first parity when that is a proper colouring (checked edge by edge);
+//   2. otherwise greedy colouring in the order of a hashed priority (Jones-Plassmann): in every round the uncoloured
+//      vertices that beat all their uncoloured neighbours take the smallest colour none of their neighbours has.  A vertex's
+//      colour depends only on its higher-priority neighbours, so the result is that of the SEQUENTIAL greedy colouring in
+//      priority order whatever the timing: deterministic.
+// perm[new] = old lists the vertices colour by colour, in ascending index order inside a colour (stable).
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ unsigned jp_priority(int v) {
+    unsigned x = (unsigned)v * 2654435761u;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(kBlock) void k_jp_round(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                     int32_t *color, int *remaining, int *err) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int left = 0;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) {
+        if (__hip_atomic_load(color + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) continue;
+        const unsigned pv = jp_priority((int)v);
+        bool top = true;
+        unsigned long long used = 0ull;
+        for (int k = rp[v]; k < rp[v + 1] && top; ++k) {
+            const int u = ci[k];
+            if (u == v) continue;
+            const int cu = __hip_atomic_load(color + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cu >= 0) used |= 1ull << cu;
+            else {
+                const unsigned pu = jp_priority(u);
+                if (pu > pv || (pu == pv && u > v)) top = false;
+            }
+        }
+        if (top) {
+            const int c = __ffsll((long long)~used) - 1;          // smallest free colour
+            if (c < 0 || c >= 63) atomicExch(err, 1);
+            else __hip_atomic_store(color + v, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            ++left;
+        }
+    }
+    if (left) atomicAdd(remaining, left);
+}
+
+__global__ __launch_bounds__(kBlock) void k_parity_colors(int64_t n, const int32_t *__restrict__ level, int32_t *__restrict__ color) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) color[v] = level[v] < 0 ? -1 : (level[v] & 1);
+}
+
+// flag = 1 when some edge joins two vertices of one colour (or a vertex has no colour)
+__global__ __launch_bounds__(kBlock) void k_check_coloring(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                           const int32_t *__restrict__ color, int *flag) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) {
+        const int cv = color[v];
+        bool bad = cv < 0;
+        for (int k = rp[v]; k < rp[v + 1]; ++k) bad = bad || (ci[k] != v && color[ci[k]] == cv);
+        if (bad) atomicExch(flag, 1);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_invert_perm(int64_t n, const int32_t *__restrict__ perm, int32_t *__restrict__ iperm) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) iperm[perm[r]] = (int32_t)r;
+}
+}  // namespace
+
+int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_colors, hipStream_t s) {
+    const int64_t n = A.n;
+    if (n + 2 + kBfsBatch > 2147483000LL) return invalid("multicolour ordering: system too large");
+    Buf<int32_t> color, perm, iperm, iota;
+    Buf<uint32_t> key_sorted;
+    Buf<int> flags;
+    DPCG_TRY(color.alloc(n)); DPCG_TRY(perm.alloc(n)); DPCG_TRY(iperm.alloc(n)); DPCG_TRY(iota.alloc(n));
+    DPCG_TRY(key_sorted.alloc(n)); DPCG_TRY(flags.alloc(4));
+    bool colored = false;
+    {   // 1. breadth-first parity, component by component
+        Buf<int32_t> deg, level, order, start, count;
+        Buf<unsigned long long> best;
+        const int64_t nlv = n + 2 + 2 * kBfsBatch;
+        DPCG_TRY(deg.alloc(n)); DPCG_TRY(level.alloc(n)); DPCG_TRY(order.alloc(n + 1)); DPCG_TRY(start.alloc(nlv));
+        DPCG_TRY(count.alloc(nlv)); DPCG_TRY(best.alloc(1));
+        hipLaunchKernelGGL(k_degrees, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, A.rowptr, deg.p);
+        DPCG_HIP(hipMemsetAsync(level.p, 0xff, (size_t)n * sizeof(int32_t), s));
+        DPCG_HIP(hipMemsetAsync(count.p, 0, (size_t)nlv * sizeof(int32_t), s));
+        std::vector<int32_t> h_start, h_count;
+        int visited = 0, next_level = 0, searches = 0;
+        while (visited < n && searches < kMaxComponents) {
+            DPCG_HIP(hipMemsetAsync(best.p, 0xff, sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(k_min_degree, dim3(rows_grid(n, 1024)), dim3(kBlock), 0, s, (const int32_t *)nullptr, (int64_t)0, n,
+                               deg.p, level.p, 1, best.p);
+            unsigned long long hb = 0;
+            DPCG_HIP(hipMemcpyAsync(&hb, best.p, sizeof(hb), hipMemcpyDeviceToHost, s));
+            DPCG_HIP(hipStreamSynchronize(s));
+            if (hb == ~0ull) break;
+            int nl = 0;
+            // every search starts at an EVEN level number, so that parity means the same in every component
+            next_level += next_level & 1;
+            DPCG_TRY(bfs(A, (int)(hb & 0xffffffffu), next_level, visited, level.p, order.p, start.p, count.p, h_start, h_count, &nl, s));
+            for (int l = 0; l < nl; ++l) visited += h_count[(size_t)l];
+            next_level += nl;
+            ++searches;
+        }
+        if (visited == n) {
+            hipLaunchKernelGGL(k_parity_colors, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, level.p, color.p);
+            DPCG_HIP(hipMemsetAsync(flags.p, 0, 4 * sizeof(int), s));
+            hipLaunchKernelGGL(k_check_coloring, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, A.rowptr, A.col, color.p, flags.p);
+            int bad = 0;
+            DPCG_HIP(hipMemcpyAsync(&bad, flags.p, sizeof(int), hipMemcpyDeviceToHost, s));
+            DPCG_HIP(hipStreamSynchronize(s));
+            colored = bad == 0;
+        }
+    }
+    if (!colored) {   // 2. Jones-Plassmann greedy colouring
+        DPCG_HIP(hipMemsetAsync(color.p, 0xff, (size_t)n * sizeof(int32_t), s));
+        DPCG_HIP(hipMemsetAsync(flags.p, 0, 4 * sizeof(int), s));
+        int rounds = 0;
+        for (;;) {
+            int h[2] = {0, 0};
+            for (int b = 0; b < 4; ++b) {
+                DPCG_HIP(hipMemsetAsync(flags.p, 0, sizeof(int), s));            // [0] remaining after this round, [1] error
+                hipLaunchKernelGGL(k_jp_round, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, color.p, flags.p,
+                                   flags.p + 1);
+                ++rounds;
+            }
+            DPCG_HIP(hipMemcpyAsync(h, flags.p, sizeof(h), hipMemcpyDeviceToHost, s));
+            DPCG_HIP(hipStreamSynchronize(s));
+            if (h[1]) return invalid("multicolour ordering: a vertex needs more than 63 colours");
+            if (h[0] == 0) break;
+            if (rounds > 4096) return invalid("multicolour ordering: the colouring did not finish");
+        }
+        hipLaunchKernelGGL(k_check_coloring, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, A.rowptr, A.col, color.p, flags.p + 2);
+        int bad = 0;
+        DPCG_HIP(hipMemcpyAsync(&bad, flags.p + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        if (bad) return invalid("multicolour ordering: improper colouring (is the pattern structurally symmetric?)");
+    }
+    int32_t cmax = 0;
+    DPCG_TRY(reduce_max_i32(color.p, reinterpret_cast<int32_t *>(flags.p + 3), n, s));
+    DPCG_HIP(hipMemcpyAsync(&cmax, flags.p + 3, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    launch_iota(n, iota.p, s);
+    // stable sort by colour: ascending vertex index inside a colour
+    DPCG_TRY(sort_pairs_u32_i32(reinterpret_cast<const uint32_t *>(color.p), key_sorted.p, iota.p, perm.p, n, bits_for((uint64_t)cmax), s));
+    hipLaunchKernelGGL(k_invert_perm, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, perm.p, iperm.p);
+    DPCG_HIP(hipStreamSynchronize(s));
+    DPCG_CHECK_LAUNCH();
+    if (n_colors) *n_colors = cmax + 1;
+    *perm_out = perm.release();
+    *iperm_out = iperm.release();
+    return DPCG_OK;
+}
+
 }  // namespace dpcg

@@ -82,60 +82,74 @@ void launch_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void 
 }
 
 // ------------------------------------------------------------------------------------------------
-// The box's own streaming ceiling: NR read streams of 16 bytes per lane summed into one write stream
-// (NR = 1: copy, 2: triad, 11: the read:write ratio of a 7-point CSR SpMV -- 90 B read, 8 B written per row) or into
-// per-workgroup partials only (W = false: read-only).  Contiguous slab per workgroup, slabs laid out XCD by XCD like the
-// SpMV's row blocks, two 16-byte loads per stream in flight per lane.
+// The box's own streaming ceiling: R read units of 16 bytes per lane for every 16 bytes written -- the
+// reads of one output element CONTIGUOUS in memory, like the val[] stream of an SpMV (R = 1: copy, 2: triad, 11: the
+// read:write ratio of a 7-point CSR SpMV -- 90 B read, 8 B written per row) -- or only reduced (W = false: read-only).
+// Contiguous slab per workgroup, slabs laid out XCD by XCD like the SpMV's row blocks, U output elements in flight per
+// lane; NT: non-temporal loads and stores.  Shapes and grid chosen with tools/stream_lab.
 // ------------------------------------------------------------------------------------------------
-template <int NR, bool W>
+template <int R, int U, bool W, bool NT>
 __global__ __launch_bounds__(kBlock) void k_stream_bench(int64_t n2, const double2 *__restrict__ in, double2 *__restrict__ out,
                                                          double *__restrict__ part) {
-    __shared__ double sh[4];
+    typedef double d2 __attribute__((ext_vector_type(2)));
     const int v = virtual_block();
     const int64_t per = (n2 + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)v * per, hi = lo + per < n2 ? lo + per : n2;
     double acc = 0.0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 2 * kBlock) {
-        const int64_t j = i + kBlock < hi ? i + kBlock : i;
-        double2 a = {0.0, 0.0}, b = {0.0, 0.0};
+    for (int64_t i0 = lo; i0 < hi; i0 += kBlock * U) {
+        d2 a[U];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const double2 u = in[(int64_t)r * n2 + i], w = in[(int64_t)r * n2 + j];
-            a.x += u.x; a.y += u.y;
-            b.x += w.x; b.y += w.y;
+        for (int u = 0; u < U; ++u) {
+            d2 sum = {0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const d2 *p = reinterpret_cast<const d2 *>(in) + ((i0 + u * kBlock) * R + (int64_t)r * kBlock + threadIdx.x);
+                sum += NT ? __builtin_nontemporal_load(p) : *p;
+            }
+            a[u] = sum;
         }
-        if (W) {
-            out[i] = a;
-            if (j != i) out[j] = b;
-        } else {
-            acc += (a.x + a.y) + (b.x + b.y);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * kBlock + threadIdx.x;
+            if (W) {
+                if (i < hi) {
+                    d2 *q = reinterpret_cast<d2 *>(out) + i;
+                    if (NT) __builtin_nontemporal_store(a[u], q);
+                    else *q = a[u];
+                }
+            } else {
+                acc += a[u].x + a[u].y;
+            }
         }
     }
-    if (!W) {
-        const double tot = block_sum(acc, sh);
-        if (threadIdx.x == 0) part[blockIdx.x] = tot;
-    }
+    if (!W && acc == 12345.678) part[blockIdx.x] = acc;      // keeps the loads alive; never true for the zero-filled input
 }
 
-// bytes_per_stream: size of each stream (rounded down to 16 B); returns the bytes one launch moves (reads + writes)
-int64_t launch_stream_bench(int n_read, bool write, int64_t bytes_per_stream, const double *in, double *out, double *part,
+// out_bytes: size of the written stream (rounded down to 16 B; the input is n_read times as long, plus one slab of slack);
+// returns the bytes one launch moves (reads + writes), or -1 for an unsupported n_read
+int64_t launch_stream_bench(int n_read, bool write, bool nt, int64_t out_bytes, const double *in, double *out, double *part,
                             int grid, hipStream_t s) {
-    const int64_t n2 = bytes_per_stream / 16;
+    const int64_t n2 = out_bytes / 16;
     const double2 *i2 = reinterpret_cast<const double2 *>(in);
     double2 *o2 = reinterpret_cast<double2 *>(out);
-#define DPCG_STREAM_CASE(NRV)                                                                                        \
-    case NRV:                                                                                                        \
-        if (write) hipLaunchKernelGGL((k_stream_bench<NRV, true>), dim3(grid), dim3(kBlock), 0, s, n2, i2, o2, part);  \
-        else hipLaunchKernelGGL((k_stream_bench<NRV, false>), dim3(grid), dim3(kBlock), 0, s, n2, i2, o2, part);       \
+#define DPCG_STREAM_LAUNCH(RV, WV, NTV) \
+    hipLaunchKernelGGL((k_stream_bench<RV, 2, WV, NTV>), dim3(grid), dim3(kBlock), 0, s, n2, i2, o2, part)
+#define DPCG_STREAM_CASE(RV)                                             \
+    case RV:                                                             \
+        if (write && nt) DPCG_STREAM_LAUNCH(RV, true, true);             \
+        else if (write) DPCG_STREAM_LAUNCH(RV, true, false);             \
+        else if (nt) DPCG_STREAM_LAUNCH(RV, false, true);                \
+        else DPCG_STREAM_LAUNCH(RV, false, false);                       \
         break
     switch (n_read) {
         DPCG_STREAM_CASE(1);
         DPCG_STREAM_CASE(2);
-        DPCG_STREAM_CASE(3);
+        DPCG_STREAM_CASE(4);
         DPCG_STREAM_CASE(11);
         default: return -1;
     }
 #undef DPCG_STREAM_CASE
+#undef DPCG_STREAM_LAUNCH
     return n2 * 16 * (n_read + (write ? 1 : 0));
 }
 

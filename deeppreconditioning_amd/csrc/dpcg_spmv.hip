@@ -285,7 +285,10 @@ void launch_tile_plan(const CsrDev &A, int nrb, int32_t *chunks, int32_t *nchunk
 // XT: x-tile elements staged per thread (tile_max_chunks * 64 / 256, rounded up).  VT / XV: storage types of the
 // matrix values and of the staged vector (fp32 in the mixed-precision and lossless-fp32 modes; products and sums are
 // fp64 either way, and <p,Ap> always uses the fp64 vector `xdot`).
-template <bool CTL, bool DOT, int XT, typename VT, typename XV>
+// NT: the once-read streams (matrix values, local indices, row extents) are loaded and y is stored NON-TEMPORALLY -- for
+// systems whose streams exceed the 256 MiB Infinity Cache, where caching them only evicts the x chunks that ARE reused
+// (tools/stream_lab on the same box: an 11-reads-per-write stream 5.05 -> 5.22 TB/s with non-temporal accesses).
+template <bool CTL, bool DOT, int XT, typename VT, typename XV, bool NT = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *__restrict__ rowptr,
                                                       const VT *__restrict__ val,
                                                       const uint16_t *__restrict__ lidx,
@@ -330,7 +333,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
         rs = re = 0;
         if (row < n) {                      // both extents in one 8-byte load (4-byte aligned: fine for global memory)
             struct __attribute__((packed, aligned(4))) Ext { int32_t s, e; };
-            const Ext ext = *reinterpret_cast<const Ext *>(rowptr + row);
+            const Ext *ep = reinterpret_cast<const Ext *>(rowptr + row);
+            const Ext ext = *ep;
             rs = ext.s;
             re = ext.e;
         }
@@ -342,8 +346,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
             // Unconditional aligned pair loads.  The pair that holds the matrix's very last non-zero when nnz is odd reads
             // 8 (4) bytes past the array: inside the same aligned 16 (8) bytes, hence the same page -- never a fault --
             // and its product lands in a slot no row sum reads.  (The launcher checks the 16-byte alignment of val / x.)
-            a[u] = *reinterpret_cast<const VPair *>(val + (cnt > 0 ? kabs : 0));
-            li[u] = *reinterpret_cast<const IPair *>(lidx + (cnt > 0 ? kabs : 0));      // lidx is padded by 4 entries
+            const VPair *vp = reinterpret_cast<const VPair *>(val + (cnt > 0 ? kabs : 0));
+            const IPair *ip = reinterpret_cast<const IPair *>(lidx + (cnt > 0 ? kabs : 0));      // lidx is padded by 4 entries
+            a[u] = NT ? __builtin_nontemporal_load(vp) : *vp;
+            li[u] = NT ? __builtin_nontemporal_load(ip) : *ip;
         }
         nc = nchunks[rb];
         const int32_t *__restrict__ cl = chunks + (int64_t)rb * kTileMaxChunks;
@@ -392,7 +398,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
         if (row < n) {
             double s = 0.0;
             for (int k = ks; k < ke; ++k) s += prod[k];
-            y[row] = s;
+            if (NT) __builtin_nontemporal_store(s, y + row);
+            else y[row] = s;
             if (DOT) acc += s * xdot[row];
         }
     }
@@ -431,14 +438,19 @@ static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, 
     if (plan.kernel == SPMV_TILE && std::is_same<YT, double>::value && pair_aligned) {
         const int tile_doubles = plan.tile_max_chunks * kTileChunk;
         const size_t lds = (size_t)(tile_doubles + kStreamCap + 8) * sizeof(double);
-#define DPCG_LAUNCH_TILE_X(CTLV, DOTV, XTV)                                                                          \
-    hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV, XTV, VT, XT>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr,  \
-                       val, plan.tile_lidx, plan.tile_chunks, plan.tile_nchunks, x, xdot, (double *)y, plan.nrb,     \
+#define DPCG_LAUNCH_TILE_X(CTLV, DOTV, XTV, NTV)                                                                         \
+    hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV, XTV, VT, XT, NTV>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr, \
+                       val, plan.tile_lidx, plan.tile_chunks, plan.tile_nchunks, x, xdot, (double *)y, plan.nrb,         \
                        tile_doubles, part_pq, d, A.nnz)
-#define DPCG_LAUNCH_TILE(CTLV, DOTV)                                                  \
-    do {                                                                              \
-        if (plan.tile_max_chunks <= 20) DPCG_LAUNCH_TILE_X(CTLV, DOTV, 5);            \
-        else DPCG_LAUNCH_TILE_X(CTLV, DOTV, (kTileMaxChunks * kTileChunk / kBlock));  \
+#define DPCG_LAUNCH_TILE(CTLV, DOTV)                                                          \
+    do {                                                                                      \
+        if (plan.stream_nt) {                                                                 \
+            if (plan.tile_max_chunks <= 20) DPCG_LAUNCH_TILE_X(CTLV, DOTV, 5, true);          \
+            else DPCG_LAUNCH_TILE_X(CTLV, DOTV, (kTileMaxChunks * kTileChunk / kBlock), true);  \
+        } else {                                                                              \
+            if (plan.tile_max_chunks <= 20) DPCG_LAUNCH_TILE_X(CTLV, DOTV, 5, false);         \
+            else DPCG_LAUNCH_TILE_X(CTLV, DOTV, (kTileMaxChunks * kTileChunk / kBlock), false); \
+        }                                                                                     \
     } while (0)
         if (c && dot) DPCG_LAUNCH_TILE(true, true);
         else if (dot) DPCG_LAUNCH_TILE(false, true);

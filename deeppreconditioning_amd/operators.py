@@ -222,15 +222,25 @@ class IC0(Preconditioner):
     mode="solve" applies it by triangular solves; mode="multiply" reproduces the reference's
     `_construct_incomplete_cholesky`, which multiplies by L L^T (test.py:88, marked unstable at
     test.py:45).
+
+    ordering="multicolor" (solve mode): IC(0) of the matrix with its unknowns listed colour by colour (red-black for
+    every 5- / 7-point grid) -- a DIFFERENT preconditioner from the reference's (another elimination order, ~+20 %
+    iterations) whose two triangular solves are a handful of wide parallel sweeps instead of hundreds of dependent
+    levels; `CsrSystem.precond_ordering()` returns the ordering.  See dpcg_set_precond_ic0_ordered in include/dpcg.h.
     """
 
-    def __init__(self, mode: str = "solve"):
+    def __init__(self, mode: str = "solve", ordering: str = "caller"):
         if mode not in ("solve", "multiply"):
             raise ValueError("mode must be 'solve' or 'multiply'")
+        if ordering not in ("caller", "multicolor"):
+            raise ValueError("ordering must be 'caller' or 'multicolor'")
+        if ordering == "multicolor" and mode != "solve":
+            raise ValueError("the multicolour ordering serves the triangular solves: mode='solve'")
         self.mode = L.PRECOND_LLT_SOLVE if mode == "solve" else L.PRECOND_LLT_MULTIPLY
+        self.ordering = L.ORDER_MULTICOLOR if ordering == "multicolor" else L.ORDER_CALLER
 
     def _attach(self, system):
-        L.check(L.lib().dpcg_set_precond_ic0(system._h, self.mode, _stream()))
+        L.check(L.lib().dpcg_set_precond_ic0_ordered(system._h, self.mode, self.ordering, _stream()))
 
     def __matmul__(self, r):
         raise TypeError("IC0 needs the system matrix: attach it with CsrSystem.set_preconditioner")
@@ -443,7 +453,8 @@ class CsrSystem:
         flag, ratio = C.c_int(0), C.c_double(0.0)
         L.check(L.lib().dpcg_get_permutation(self._h, C.byref(flag), None, C.byref(ratio)))
         return {"n": n.value, "nnz": nnz.value, "spmv_kernel": ("stream", "vector", "tile")[k.value & 15],
-                "two_kernel_updates": bool(k.value & 16), "reordered": bool(flag.value), "gather_ratio": ratio.value,
+                "two_kernel_updates": bool(k.value & 16), "spmv_nt": bool(k.value & 32), "reordered": bool(flag.value),
+                "gather_ratio": ratio.value,
                 "precond": pk.value, "precond_nnz": pn.value, "levels_lower": ll.value, "levels_upper": lu.value}
 
     def close(self) -> None:
@@ -501,8 +512,16 @@ class CsrSystem:
             L.check(L.lib().dpcg_sptrsv(self._h, 1 if upper else 0, _dev_ptr(rv), _dev_ptr(out), _stream()))
         return out
 
+    def precond_ordering(self):
+        """(n_colors, perm) of the attached factor's own numbering: perm[k] = the caller's row at factor position k
+        (identity and 0 colours unless the factor was built with ordering="multicolor")."""
+        nc = C.c_int(0)
+        perm = np.empty(self.n, dtype=np.int32)
+        L.check(L.lib().dpcg_get_precond_ordering(self._h, C.byref(nc), _np_ptr(perm)))
+        return nc.value, perm
+
     def factor(self):
-        """The attached L factor as host CSR arrays (rowptr, col, val)."""
+        """The attached L factor as host CSR arrays (rowptr, col, val), in the factor's numbering (`precond_ordering`)."""
         nnz = self.info()["precond_nnz"]
         rp = np.empty(self.n + 1, dtype=np.int32)
         ci = np.empty(nnz, dtype=np.int32)
@@ -551,11 +570,11 @@ def dot(a: torch.Tensor, b: torch.Tensor) -> float:
     return float(out.value)
 
 
-def stream_bench(n_read: int = 2, write: bool = True, bytes_per_stream: int = 1 << 27, repeats: int = 10) -> float:
-    """GB/s (reads + writes) of the library's own streaming kernel on this box: `n_read` streams of `bytes_per_stream`
-    summed into one output stream (or only reduced) -- the measured HBM ceiling next to the 8 TB/s spec.
-    n_read = 11 with write is the read:write ratio of a 7-point CSR SpMV."""
+def stream_bench(n_read: int = 2, write: bool = True, out_bytes: int = 1 << 27, repeats: int = 10, nontemporal: bool = False) -> float:
+    """GB/s (reads + writes) of the library's own streaming kernel on this box: per 16 bytes written, `n_read` x 16
+    contiguous bytes are read (or only reduced when write=False) -- the measured HBM ceiling next to the 8 TB/s spec
+    (SURVEY.md 8-d2).  n_read = 11 with write is the read:write ratio of a 7-point CSR SpMV."""
     ms, moved = C.c_float(), C.c_int64()
-    L.check(L.lib().dpcg_stream_bench(int(n_read), 1 if write else 0, int(bytes_per_stream), int(repeats), C.byref(ms),
-                                      C.byref(moved), _stream()))
+    L.check(L.lib().dpcg_stream_bench(int(n_read), 1 if write else 0, 1 if nontemporal else 0, int(out_bytes), int(repeats),
+                                      C.byref(ms), C.byref(moved), _stream()))
     return moved.value / (ms.value * 1e-3) / 1e9

@@ -84,7 +84,8 @@ int dpcg_create(dpcg_handle_t *out, int64_t n, int64_t nnz, const int32_t *rowpt
                 const void *val, int val_dtype, int memspace, int copy, dpcg_stream_t stream);
 int dpcg_destroy(dpcg_handle_t h);
 /* Introspection (any out pointer may be NULL).  spmv_kernel: 0 gather (CSR-stream), 1 CSR-vector, 2 x-tile; +16 when
- * a default solve runs two-kernel updates (see DPCG_NO_FUSE).  precond_nnz: nnz of M (CSR) or of L. */
+ * a default solve runs two-kernel updates (see DPCG_NO_FUSE), +32 when the x-tile kernel reads its once-read streams and
+ * writes y non-temporally (streams beyond the Infinity Cache).  precond_nnz: nnz of M (CSR) or of L. */
 int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spmv_kernel, int *precond_kind,
                   int64_t *precond_nnz, int *n_levels_lower, int *n_levels_upper);
 
@@ -120,6 +121,19 @@ int dpcg_set_precond_llt(dpcg_handle_t h, int mode, int64_t nnz, const int32_t *
                          const double *val, int memspace, dpcg_stream_t stream);
 /* IC(0) of A (stands in for ilupp.ichol0, test.py:83), then as dpcg_set_precond_llt. */
 int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t stream);
+/* IC(0) in an ordering of the library's choice, applied by triangular solves.  DPCG_ORDER_CALLER is dpcg_set_precond_ic0
+ * (the factor ilupp.ichol0 would return for the matrix as the caller numbered it, test.py:83).  DPCG_ORDER_MULTICOLOR factors
+ * Q A Q^T with the unknowns listed colour by colour (two colours by breadth-first parity when the mesh graph is bipartite --
+ * every 5- / 7-point grid -- otherwise a deterministic greedy colouring): the factor's dependency graph is then only as deep
+ * as the number of colours, so the two triangular solves of an apply are a handful of wide, fully parallel sweeps instead of
+ * hundreds of dependent levels.  It is a DIFFERENT preconditioner from the reference's (same algorithm, another elimination
+ * order: iteration counts differ, typically +20 % against a natural ordering), offered because on this hardware it is the
+ * form in which an incomplete-Cholesky apply beats Jacobi to the solution.  Caller-visible vectors keep the caller's numbering.
+ * dpcg_get_factor then returns L in the factor's numbering; dpcg_get_precond_ordering gives that numbering:
+ * perm_host[k] = the caller's row at factor position k (int32[n], host; identity for DPCG_ORDER_CALLER), *n_colors. */
+enum dpcg_ordering { DPCG_ORDER_CALLER = 0, DPCG_ORDER_MULTICOLOR = 1 };
+int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int ordering, dpcg_stream_t stream);
+int dpcg_get_precond_ordering(dpcg_handle_t h, int *n_colors, int32_t *perm_host);
 /* ICT: thresholded incomplete Cholesky with level-1 fill, then as dpcg_set_precond_llt.  Stands in for
  * ilupp.icholt(A, add_fill_in=1, threshold=0.1), the DEFAULT of the reference's `_construct_incomplete_cholesky`
  * (test.py:81-88; ichol0 only when both arguments are zeroed).  ilupp is not available to pin against; the contract
@@ -152,10 +166,11 @@ int dpcg_spmv_dot_bench(dpcg_handle_t h, const double *x, double *y, int repeats
                         dpcg_stream_t stream);
 
 /* The HBM streaming ceiling of this box with the library's own access shape (SURVEY.md 8-d2 asks for a measured ceiling
- * beside the 8 TB/s spec; nothing in the reference corresponds -- its loop runs on torch CPU/CUDA ops, cg.py:75-86):
- * n_read (1 copy, 2 triad, 3, or 11 = the read:write ratio of a 7-point CSR SpMV) streams of bytes_per_stream summed into
- * one output stream (write = 1) or only reduced (write = 0); `repeats` launches between HIP events on `stream`. */
-int dpcg_stream_bench(int n_read, int write, int64_t bytes_per_stream, int repeats, float *ms_per_launch,
+ * beside the 8 TB/s spec; nothing in the reference corresponds -- its loop runs on torch CPU/CUDA ops, cg.py:75-86): per 16
+ * bytes written, n_read x 16 contiguous bytes are read (n_read = 1 copy, 2 triad, 4, or 11 = the read:write ratio of a
+ * 7-point CSR SpMV); write = 0: read-only, n_read x out_bytes are only reduced.  nontemporal = 1: non-temporal loads and
+ * stores.  `repeats` launches between HIP events on `stream`; *bytes_per_launch = reads + writes of one launch. */
+int dpcg_stream_bench(int n_read, int write, int nontemporal, int64_t out_bytes, int repeats, float *ms_per_launch,
                       int64_t *bytes_per_launch, dpcg_stream_t stream);
 
 /* ---- the solve: cg.py:50-90 (PCG) and cg.py:20-47 (CG = PCG with M = I, test on r) ----------- */

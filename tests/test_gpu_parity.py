@@ -1729,7 +1729,7 @@ def test_reordering_checks_its_input_pattern(D):
     """`dpcg_reorder` needs the pattern of a symmetric matrix.  A one-sided pattern (an entry without its mirror, or a
     triangle handed over by mistake) leaves a vertex without a parent in the level structure: reorder="rcm" reports it
     (DPCG_ERR_INVALID) instead of faulting or returning a non-permutation, reorder="auto" (the default of every plain
-    call) leaves the handle un-reordered and the solve runs on the caller's numbering.  Duplicated column entries
+    call) then leaves the handle un-reordered and the solve runs on the caller's numbering.  Duplicated column entries
     (adjacent, columns ascending) are tolerated: the order is still a permutation and the operator unchanged."""
     from deeppreconditioning_amd._lib import DpcgError, ERR_INVALID
     A = O.unstructured_like(O.poisson2d(260), seed=3)            # 67 600 rows: above the AUTO threshold, scattered
@@ -1741,15 +1741,32 @@ def test_reordering_checks_its_input_pattern(D):
     one_sided = one_sided.tocsr()
     one_sided.eliminate_zeros()
     one_sided.sort_indices()
-    for bad in (one_sided, sp.tril(A, format="csr")):
-        with pytest.raises(DpcgError) as exc:
-            D.CsrSystem.from_any(bad, reorder="rcm")
-        assert exc.value.status == ERR_INVALID and "symmetric" in str(exc.value)
-        S = D.CsrSystem.from_any(bad)                              # "auto": measured as scattered, RCM refused, left alone
-        assert not S.reordered and S.info()["gather_ratio"] > 4
-        x = O.rhs(n, 1)
-        assert np.array_equal((S @ _dev(x)).cpu().numpy(), CO.spmv(bad, x))
-        S.close()
+    x = O.rhs(n, 1)
+    for bad in (one_sided, sp.tril(A, format="csr"), sp.triu(A, format="csr")):
+        # A one-sided pattern is either REPORTED (a vertex without a parent) or, when every vertex still finds a parent in
+        # its own row, ordered like any other graph -- never a fault, never a non-permutation, and the operator is intact.
+        for mode in ("rcm", "auto"):
+            try:
+                S = D.CsrSystem.from_any(bad, reorder=mode)
+            except DpcgError as exc:
+                assert mode == "rcm" and exc.status == ERR_INVALID and "symmetric" in str(exc)
+                continue
+            if S.reordered:
+                perm = S.permutation()
+                assert np.array_equal(np.sort(perm), np.arange(n))
+                np.testing.assert_allclose((S @ _dev(x)).cpu().numpy(), bad @ x, rtol=1e-13, atol=1e-13)
+            else:
+                assert np.array_equal((S @ _dev(x)).cpu().numpy(), CO.spmv(bad, x))
+            S.close()
+    # a pattern on which the check MUST fire: an upper bidiagonal matrix -- the vertex reached through its parent's row has
+    # no entry pointing back
+    chain = sp.diags([np.full(500, 2.0), np.full(499, -1.0)], [0, 1], format="csr")
+    with pytest.raises(DpcgError) as exc:
+        D.CsrSystem.from_any(chain, reorder="rcm")
+    assert exc.value.status == ERR_INVALID and "symmetric" in str(exc.value)
+    S = D.CsrSystem.from_any(chain)                               # "auto": small system, left alone
+    assert not S.reordered
+    S.close()
     # the intact matrix still reorders, and solves, through the same default call
     S = D.CsrSystem.from_any(A)
     assert S.reordered
@@ -1868,3 +1885,75 @@ def test_preconditioner_net_hip_forward_against_the_dense_restatement(D, monkeyp
             assert torch.equal(got, want)
     # autograd still takes the torch path (training)
     assert getattr(net(inp), "lower_csr", None) is None
+
+
+# ---- round 3: IC(0) in multicolour order -- shallow dependency graph for the triangular solves -------------------------
+@pytest.mark.parametrize("name,make,reorder,colors", [
+    ("poisson2d_70", lambda: O.poisson2d(70), None, 2),
+    ("poisson3d_40", lambda: O.poisson3d(40), None, 2),                               # level-major sync-free form (2 wide levels)
+    ("unstructured3d_34_rcm", lambda: O.unstructured_like(O.poisson3d(34), seed=2), "rcm", 2),
+    ("random_spd_nonbipartite", None, None, None),
+])
+def test_ic0_in_multicolour_order(D, name, make, reorder, colors):
+    """`IC0("solve", ordering="multicolor")`: IC(0) of Q A Q^T with the unknowns colour by colour (2 colours for every grid
+    graph; a deterministic greedy colouring for a graph with odd cycles).  The ordering is the library's, the arithmetic is
+    checkable: with Q from `precond_ordering()` the device factor equals oracle IC(0) of Q A Q^T BIT FOR BIT, one apply equals
+    sequential substitution bit for bit, the factor has as many levels as colours, and PCG matches oracle/pcg_oracle.c
+    (system in the handle's numbering, preconditioner applied through the permutation: orc_pcg_perm) -- counts equal,
+    history within 1e-10.  Fewer levels, somewhat more iterations than IC(0) in the caller's order."""
+    if make is None:
+        rng = np.random.default_rng(11)
+        n = 3000
+        R = sp.random(n, n, density=4.0 / n, random_state=rng, format="csr")
+        R = R + R.T
+        A = (R + sp.diags(np.asarray(abs(R).sum(axis=1)).ravel() + 1.0)).tocsr()
+        A.sort_indices()
+    else:
+        A = make()
+    n = A.shape[0]
+    b = O.rhs(n, 2)
+    S = D.CsrSystem.from_any(A, reorder=reorder)
+    S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+    nc, q = S.precond_ordering()
+    assert np.array_equal(np.sort(q), np.arange(n)) and nc >= 2
+    if colors is not None:
+        assert nc == colors
+    Bc = A[q][:, q].tocsr()
+    Bc.sort_indices()
+    Lref = CO.ic0(Bc)
+    rp, ci, v = S.factor()
+    assert np.array_equal(rp, Lref.indptr) and np.array_equal(ci, Lref.indices) and np.array_equal(v, Lref.data)
+    info = S.info()
+    assert info["levels_lower"] <= nc and info["levels_upper"] <= nc
+    zc = CO.sptrsv_upper(CO.transpose_csr(Lref), CO.sptrsv_lower(Lref, b[q]))
+    zref = np.empty(n)
+    zref[q] = zc
+    assert np.array_equal(S.precond_apply(_dev(b)).cpu().numpy(), zref)
+    assert np.array_equal(S.precond_apply(_dev(b)).cpu().numpy(), zref)          # and again (pending-pattern hand-over)
+    qinv = np.empty(n, dtype=np.int32)
+    qinv[q] = np.arange(n, dtype=np.int32)
+    if S.reordered:
+        ph = S.permutation()
+        B, bb, pperm = _permuted(A, ph), b[ph], qinv[ph]
+    else:
+        B, bb, pperm = A, b, qinv
+    _, it, hist, xs = CO.pcg(B, bb, "llt_solve", L=Lref, precond_perm=pperm)
+    for flags in (0, D._lib.NO_GRAPH):
+        res = S.solve(_dev(b), flags=flags)
+        assert res.status == 0 and res.iterations == it
+        np.testing.assert_allclose(res.res_history, hist, rtol=HIST_RTOL)
+    r_true = b - A @ res.x.cpu().numpy()
+    assert np.dot(r_true, r_true) / np.dot(b, b) < 1.01e-8
+    # against IC(0) in the caller's order: far fewer levels, a bounded loss of iterations, still ahead of Jacobi
+    S.set_preconditioner(D.IC0("solve"))
+    assert S.precond_ordering()[0] == 0 and np.array_equal(S.precond_ordering()[1], np.arange(n))
+    natural = S.solve(_dev(b))
+    if colors == 2:
+        assert S.info()["levels_lower"] > 4 * nc
+    S.set_preconditioner(D.Jacobi())
+    jac = S.solve(_dev(b))
+    if colors == 2:
+        assert natural.iterations <= res.iterations <= 1.6 * natural.iterations + 2 and res.iterations < jac.iterations
+    with pytest.raises(ValueError):
+        D.IC0("multiply", ordering="multicolor")
+    S.close()

@@ -1,0 +1,42 @@
+"""IC(0) by triangular solves in the caller's order vs in multicolour order (IC0(ordering="multicolor")) vs Jacobi:
+levels, setup, one apply, PCG iterations and time to solution.   python tools/mc_probe.py [case ...]"""
+import sys
+import time
+
+import torch
+
+import deeppreconditioning_amd as D
+from deeppreconditioning_amd import poisson
+
+cases = [("poisson2d_256", lambda: poisson.poisson_system(2, 256)), ("poisson2d_1024", lambda: poisson.poisson_system(2, 1024)),
+         ("poisson3d_64", lambda: poisson.poisson_system(3, 64)), ("poisson3d_100", lambda: poisson.poisson_system(3, 100)),
+         ("scrambled3d_100", lambda: D.CsrSystem.from_any(poisson.unstructured_like_csr(3, 100, 0))),
+         ("scrambled2d_256", lambda: D.CsrSystem.from_any(poisson.unstructured_like_csr(2, 256, 0)))]
+only = sys.argv[1:] or None
+for name, make in cases:
+    if only and name not in only:
+        continue
+    s = make()
+    r = poisson.rhs(s.n, 0)
+    for label, pc in (("jacobi", lambda: D.Jacobi()), ("ic0 caller order", lambda: D.IC0("solve")),
+                      ("ic0 multicolour", lambda: D.IC0("solve", ordering="multicolor"))):
+        s.set_preconditioner(pc())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.set_preconditioner(pc())
+        torch.cuda.synchronize()
+        setup_ms = (time.perf_counter() - t0) * 1e3
+        info = s.info()
+        s.precond_apply(r)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            s.precond_apply(r)
+        torch.cuda.synchronize()
+        apply_us = (time.perf_counter() - t0) / 20 * 1e6
+        res = s.solve(r, want_history=False)
+        res = s.solve(r, want_history=False)
+        print(f"{name:16s} {label:17s} levels {info['levels_lower']:5d}/{info['levels_upper']:5d} colours {s.precond_ordering()[0]:2d}  "
+              f"setup {setup_ms:8.2f} ms  apply {apply_us:8.1f} us  PCG {res.iterations:4d} its {res.seconds * 1e3:8.3f} ms = "
+              f"{res.seconds / max(res.iterations, 1) * 1e6:7.1f} us/update  status {res.status}", flush=True)
+    s.close()
