@@ -71,6 +71,7 @@ SIGNATURES = {
     "dpcg_batched_coo_sddmm": (_int, [_i64, _p, _int, _i64, _int, _p, _p, _p, _int, _p]),
     "dpcg_coo_to_csr": (_int, [_i64, _i64, _p, _p, _p, _p, _p, _p, C.POINTER(_i64), _p]),
     "dpcg_convnet_plan_create": (_int, [C.POINTER(_p), _int, _i64, _i64, _i64, _p, _int, _p, _p, _p]),
+    "dpcg_convnet_plan_rebuild": (_int, [_p, _int, _i64, _i64, _i64, _p, _int, _p, _p, _p]),
     "dpcg_convnet_plan_destroy": (_int, [_p]),
     "dpcg_convnet_plan_info": (_int, [_p, _int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "dpcg_convnet_plan_output": (_int, [_p, _p, _p, _p, _p]),

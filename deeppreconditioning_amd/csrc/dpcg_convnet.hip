@@ -59,10 +59,46 @@ struct dpcg_convnet_plan {
     int64_t nnz_lower = 0;
     float *buf[2] = {nullptr, nullptr};               // ping-pong feature buffers, grown on demand
     int64_t buf_cap[2] = {0, 0};
+    // Every array above lives in one of these slabs, handed out in a fixed order; dpcg_convnet_plan_rebuild draws from them
+    // again (a slab grows only when the new pattern needs more), so a stream of similar matrices -- one plan per matrix --
+    // costs no device allocations after the first (35 hipMalloc / hipFree pairs were 2.9 of a plan's 3.2 ms).
+    std::vector<std::pair<void *, size_t>> slabs;
+    size_t slab_cursor = 0;
 };
 
 namespace dpcg {
 namespace {
+
+template <typename T>
+int plan_alloc(dpcg_convnet_plan *p, T **out, int64_t count) {
+    const size_t bytes = (size_t)(count < 1 ? 1 : count) * sizeof(T);
+    *out = nullptr;
+    if (p->slab_cursor < p->slabs.size()) {
+        auto &sl = p->slabs[p->slab_cursor];
+        if (sl.second < bytes) {
+            (void)hipFree(sl.first);
+            sl = {nullptr, 0};
+            const size_t grown = bytes + bytes / 4;
+            if (hipMalloc(&sl.first, grown) != hipSuccess) {
+                set_error("dpcg_convnet: device allocation failed");
+                return DPCG_ERR_NOMEM;
+            }
+            sl.second = grown;
+        }
+        *out = reinterpret_cast<T *>(sl.first);
+        ++p->slab_cursor;
+        return DPCG_OK;
+    }
+    void *q = nullptr;
+    if (hipMalloc(&q, bytes) != hipSuccess) {
+        set_error("dpcg_convnet: device allocation failed");
+        return DPCG_ERR_NOMEM;
+    }
+    p->slabs.emplace_back(q, bytes);
+    ++p->slab_cursor;
+    *out = reinterpret_cast<T *>(q);
+    return DPCG_OK;
+}
 
 inline int grid_rows(int64_t n, int cap = 4096) {
     int64_t g = (n + kBlock - 1) / kBlock;
@@ -394,14 +430,6 @@ bool try_mfma(int cin, int cout, int64_t n_out, const int32_t *nbr, const float 
     return false;
 }
 
-void free_layer(LayerPlan &l) {
-    if (!l.same_sites) {
-        dev_free(l.rowptr);
-        dev_free(l.col);
-    }
-    dev_free(l.nbr);
-    l = LayerPlan();
-}
 
 }  // namespace
 }  // namespace dpcg
@@ -410,25 +438,18 @@ using namespace dpcg;
 
 extern "C" int dpcg_convnet_plan_destroy(dpcg_convnet_plan_t p) {
     if (!p) return DPCG_OK;
-    for (int l = 0; l < p->n_layers; ++l) free_layer(p->layers[l]);
-    dev_free(p->rowptr0);
-    dev_free(p->col0);
-    dev_free(p->site_row);
-    dev_free(p->site_batch);
-    dev_free(p->lower_rowptr);
-    dev_free(p->lower_col);
-    dev_free(p->lower_pos);
+    for (auto &sl : p->slabs)
+        if (sl.first) (void)hipFree(sl.first);
     dev_free(p->buf[0]);
     dev_free(p->buf[1]);
     delete p;
     return DPCG_OK;
 }
 
-extern "C" int dpcg_convnet_plan_create(dpcg_convnet_plan_t *out, int batch, int64_t height, int64_t width, int64_t nnz,
-                                        const int32_t *indices, int n_layers, const int32_t *kernel_hw,
-                                        const int32_t *padding_hw, dpcg_stream_t stream) {
-    if (!out) return invalid("dpcg_convnet_plan_create: NULL out");
-    *out = nullptr;
+// (Re)builds `p` for a pattern, drawing its arrays from the plan's slabs.  On failure the plan is left EMPTY (n_layers = 0)
+// but alive: its memory can serve the next rebuild.
+static int build_plan(dpcg_convnet_plan *p, int batch, int64_t height, int64_t width, int64_t nnz, const int32_t *indices,
+                      int n_layers, const int32_t *kernel_hw, const int32_t *padding_hw, dpcg_stream_t stream) {
     if (batch <= 0 || height <= 0 || width <= 0 || nnz <= 0 || !indices || n_layers <= 0 || n_layers > kConvMaxLayers ||
         !kernel_hw || !padding_hw)
         return invalid("dpcg_convnet_plan_create: bad arguments");
@@ -440,21 +461,25 @@ extern "C" int dpcg_convnet_plan_create(dpcg_convnet_plan_t *out, int batch, int
             return invalid("dpcg_convnet_plan_create: windows up to 2 x 2 (stride 1) are supported");
     }
     hipStream_t s = (hipStream_t)stream;
-    dpcg_convnet_plan *p = new dpcg_convnet_plan();
+    p->slab_cursor = 0;
     p->batch = batch;
     p->n_layers = n_layers;
     p->height = height;
     p->width = width;
     p->nnz_in = nnz;
+    p->nnz_lower = 0;
+    for (auto &L : p->layers) L = LayerPlan();
     int st = DPCG_OK;
     int *d_bad = nullptr;
     int32_t *len = nullptr;
+    void *scan_ws = nullptr;
     auto fail = [&](int code) {
-        dev_free(d_bad);
-        dev_free(len);
-        dpcg_convnet_plan_destroy(p);
+        p->n_layers = 0;
         return code;
     };
+    // one workspace for every scan of this build (the longest: batch * (height + n_layers) + 1 row counts)
+    const int64_t max_rows = (int64_t)batch * (height + 2 * n_layers) + 1;
+    const size_t scan_bytes = scan_workspace_bytes(max_rows) + 256;
 #define PLAN_TRY(expr)                     \
     do {                                   \
         st = (expr);                       \
@@ -466,9 +491,11 @@ extern "C" int dpcg_convnet_plan_create(dpcg_convnet_plan_t *out, int batch, int
         if (_e != hipSuccess) return fail(hip_fail(_e, #call, __FILE__, __LINE__)); \
     } while (0)
     const int64_t rows0 = (int64_t)batch * height;
-    PLAN_TRY(dev_alloc(&p->rowptr0, rows0 + 1));
-    PLAN_TRY(dev_alloc(&p->col0, nnz));
-    PLAN_TRY(dev_alloc(&d_bad, 1));
+    PLAN_TRY(plan_alloc(p, &p->rowptr0, rows0 + 1));
+    PLAN_TRY(plan_alloc(p, &p->col0, nnz));
+    PLAN_TRY(plan_alloc(p, &d_bad, 1));
+    PLAN_TRY(plan_alloc(p, reinterpret_cast<char **>(&scan_ws), (int64_t)scan_bytes));
+    PLAN_TRY(plan_alloc(p, &len, max_rows));
     PLAN_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_sites_to_csr, dim3(grid_rows(nnz)), dim3(kBlock), 0, s, nnz, indices, batch, height, width, p->rowptr0,
                        p->col0, d_bad);
@@ -500,12 +527,10 @@ extern "C" int dpcg_convnet_plan_create(dpcg_convnet_plan_t *out, int batch, int
         } else {
             const int64_t rows_out = (int64_t)batch * L.h_out;
             const ConvGeom g{L.kh, L.kw, L.ph, L.pw, batch, h, w, L.h_out, L.w_out};
-            dev_free(len);
-            PLAN_TRY(dev_alloc(&len, rows_out + 1));
-            PLAN_TRY(dev_alloc(&L.rowptr, rows_out + 1));
+            PLAN_TRY(plan_alloc(p, &L.rowptr, rows_out + 1));
             hipLaunchKernelGGL(k_conv_rows<false>, dim3(grid_rows(rows_out + 1)), dim3(kBlock), 0, s, g, rp_in, col_in, len,
                                (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
-            PLAN_TRY(exclusive_scan_i32(len, L.rowptr, rows_out + 1, s));
+            PLAN_TRY(exclusive_scan_i32_ws(len, L.rowptr, rows_out + 1, scan_ws, scan_bytes, s));
             int32_t total = 0;
             PLAN_HIP(hipMemcpyAsync(&total, L.rowptr + rows_out, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             PLAN_HIP(hipStreamSynchronize(s));
@@ -514,8 +539,8 @@ extern "C" int dpcg_convnet_plan_create(dpcg_convnet_plan_t *out, int batch, int
                 return fail(DPCG_ERR_INVALID);
             }
             L.sites = total;
-            PLAN_TRY(dev_alloc(&L.col, L.sites));
-            PLAN_TRY(dev_alloc(&L.nbr, L.sites * L.kh * L.kw));
+            PLAN_TRY(plan_alloc(p, &L.col, L.sites));
+            PLAN_TRY(plan_alloc(p, &L.nbr, L.sites * L.kh * L.kw));
             hipLaunchKernelGGL(k_conv_rows<true>, dim3(grid_rows(rows_out + 1)), dim3(kBlock), 0, s, g, rp_in, col_in,
                                (int32_t *)nullptr, (const int32_t *)L.rowptr, L.col, L.nbr);
         }
@@ -529,36 +554,54 @@ extern "C" int dpcg_convnet_plan_create(dpcg_convnet_plan_t *out, int batch, int
     {
         const LayerPlan &L = p->layers[n_layers - 1];
         const int64_t rows = (int64_t)batch * L.h_out;
-        dev_free(len);
-        PLAN_TRY(dev_alloc(&len, rows + 1));
-        PLAN_TRY(dev_alloc(&p->site_row, L.sites));
-        PLAN_TRY(dev_alloc(&p->site_batch, L.sites));
-        PLAN_TRY(dev_alloc(&p->lower_rowptr, rows + 1));
-        PLAN_TRY(dev_alloc(&p->lower_pos, L.sites));
+        PLAN_TRY(plan_alloc(p, &p->site_row, L.sites));
+        PLAN_TRY(plan_alloc(p, &p->site_batch, L.sites));
+        PLAN_TRY(plan_alloc(p, &p->lower_rowptr, rows + 1));
+        PLAN_TRY(plan_alloc(p, &p->lower_pos, L.sites));
         hipLaunchKernelGGL(k_lower_count, dim3(grid_rows(rows + 1)), dim3(kBlock), 0, s, rows, L.h_out, L.rowptr, L.col, len,
                            p->site_row, p->site_batch);
-        PLAN_TRY(exclusive_scan_i32(len, p->lower_rowptr, rows + 1, s));
+        PLAN_TRY(exclusive_scan_i32_ws(len, p->lower_rowptr, rows + 1, scan_ws, scan_bytes, s));
         int32_t total = 0;
         PLAN_HIP(hipMemcpyAsync(&total, p->lower_rowptr + rows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         PLAN_HIP(hipStreamSynchronize(s));
         p->nnz_lower = total;
-        PLAN_TRY(dev_alloc(&p->lower_col, p->nnz_lower));
+        PLAN_TRY(plan_alloc(p, &p->lower_col, p->nnz_lower));
         hipLaunchKernelGGL(k_lower_fill, dim3(grid_rows(rows)), dim3(kBlock), 0, s, rows, L.h_out, L.rowptr, L.col,
                            p->lower_rowptr, p->lower_col, p->lower_pos);
     }
     PLAN_HIP(hipStreamSynchronize(s));
     PLAN_HIP(hipGetLastError());
-    dev_free(d_bad);
-    dev_free(len);
 #undef PLAN_TRY
 #undef PLAN_HIP
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_convnet_plan_create(dpcg_convnet_plan_t *out, int batch, int64_t height, int64_t width, int64_t nnz,
+                                        const int32_t *indices, int n_layers, const int32_t *kernel_hw,
+                                        const int32_t *padding_hw, dpcg_stream_t stream) {
+    if (!out) return invalid("dpcg_convnet_plan_create: NULL out");
+    *out = nullptr;
+    dpcg_convnet_plan *p = new dpcg_convnet_plan();
+    const int st = build_plan(p, batch, height, width, nnz, indices, n_layers, kernel_hw, padding_hw, stream);
+    if (st < 0) {
+        dpcg_convnet_plan_destroy(p);
+        return st;
+    }
     *out = p;
     return DPCG_OK;
 }
 
+extern "C" int dpcg_convnet_plan_rebuild(dpcg_convnet_plan_t plan, int batch, int64_t height, int64_t width, int64_t nnz,
+                                         const int32_t *indices, int n_layers, const int32_t *kernel_hw,
+                                         const int32_t *padding_hw, dpcg_stream_t stream) {
+    if (!plan) return invalid("dpcg_convnet_plan_rebuild: NULL plan");
+    return build_plan(plan, batch, height, width, nnz, indices, n_layers, kernel_hw, padding_hw, stream);
+}
+
+
 extern "C" int dpcg_convnet_plan_info(dpcg_convnet_plan_t p, int layer, int64_t *sites, int64_t *height, int64_t *width,
                                       int64_t *nnz_lower) {
-    if (!p || layer < 0 || layer >= p->n_layers) return invalid("dpcg_convnet_plan_info: bad plan or layer");
+    if (!p || layer < 0 || layer >= p->n_layers) return invalid("dpcg_convnet_plan_info: bad plan or layer (or a plan whose rebuild failed)");
     const LayerPlan &L = p->layers[layer];
     if (sites) *sites = L.sites;
     if (height) *height = L.h_out;
@@ -569,7 +612,7 @@ extern "C" int dpcg_convnet_plan_info(dpcg_convnet_plan_t p, int layer, int64_t 
 
 extern "C" int dpcg_convnet_plan_output(dpcg_convnet_plan_t p, int32_t *indices_out, int32_t *lower_rowptr,
                                         int32_t *lower_col, dpcg_stream_t stream) {
-    if (!p) return invalid("dpcg_convnet_plan_output: NULL plan");
+    if (!p || p->n_layers <= 0) return invalid("dpcg_convnet_plan_output: NULL or empty plan");
     hipStream_t s = (hipStream_t)stream;
     const LayerPlan &L = p->layers[p->n_layers - 1];
     if (indices_out)
@@ -588,6 +631,7 @@ extern "C" int dpcg_convnet_forward(dpcg_convnet_plan_t p, const int32_t *channe
                                     const float *const *biases, const float *const *prelu, const float *features_in,
                                     float *features_out, double *lower_val, int lower_softplus, dpcg_stream_t stream) {
     if (!p || !channels || !weights || !biases || !prelu || !features_in) return invalid("dpcg_convnet_forward: NULL argument");
+    if (p->n_layers <= 0) return invalid("dpcg_convnet_forward: empty plan (its last rebuild failed)");
     const int n = p->n_layers;
     for (int l = 0; l <= n; ++l)
         if (channels[l] < 1 || channels[l] > 1024) return invalid("dpcg_convnet_forward: bad channel count");

@@ -16,6 +16,9 @@ int sort_pairs_u32_i32(const uint32_t *keys_in, uint32_t *keys_out, const int32_
 // out[i] = in[0] + ... + in[i-1] (exclusive) or ... + in[i] (inclusive); in == out is allowed.
 int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t count, hipStream_t s);
 int inclusive_scan_i32(const int32_t *in, int32_t *out, int64_t count, hipStream_t s);
+// exclusive scan in a caller-provided workspace of scan_workspace_bytes(count) bytes: no allocation, no synchronisation
+size_t scan_workspace_bytes(int64_t count);
+int exclusive_scan_i32_ws(const int32_t *in, int32_t *out, int64_t count, void *workspace, size_t workspace_bytes, hipStream_t s);
 // *out_dev = max(in[0..count))
 int reduce_max_i32(const int32_t *in, int32_t *out_dev, int64_t count, hipStream_t s);
 // number of bits needed to represent values in [0, max_value]

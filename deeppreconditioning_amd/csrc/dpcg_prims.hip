@@ -72,6 +72,23 @@ int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t count, hipStream
     return DPCG_OK;
 }
 
+// The same scan with the caller's workspace (scan_workspace_bytes(count) bytes): no allocation, no synchronisation.
+size_t scan_workspace_bytes(int64_t count) {
+    size_t bytes = 0;
+    if (count <= 0) return 0;
+    if (rocprim::exclusive_scan(nullptr, bytes, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t)0, (size_t)count,
+                                rocprim::plus<int32_t>(), nullptr) != hipSuccess)
+        return 0;
+    return bytes;
+}
+
+int exclusive_scan_i32_ws(const int32_t *in, int32_t *out, int64_t count, void *workspace, size_t workspace_bytes, hipStream_t s) {
+    if (count <= 0) return DPCG_OK;
+    size_t bytes = workspace_bytes;
+    PRIM_HIP(rocprim::exclusive_scan(workspace, bytes, in, out, (int32_t)0, (size_t)count, rocprim::plus<int32_t>(), s));
+    return DPCG_OK;
+}
+
 int inclusive_scan_i32(const int32_t *in, int32_t *out, int64_t count, hipStream_t s) {
     if (count <= 0) return DPCG_OK;
     size_t bytes = 0;

@@ -137,7 +137,11 @@ int check_spin_errors(dpcg_system *h, hipStream_t s) {
         DPCG_HIP(hipStreamSynchronize(s));
         if (e) {
             (void)hipMemsetAsync(lv->spin_err, 0, sizeof(int), s);
-            set_error("sync-free triangular solve: a row waited for an entry that was never written");
+            // the failed solve stored NaNs: put the "all pending between solves" invariant of the lower factor's level-major
+            // solution vector back (Levels::lm_out), so that the handle stays usable
+            if (single_syncfree_segment(h->lvlL) && h->lvlL.lm_out) launch_fill_pending(h->lvlL.lm_out, h->A.n, s);
+            (void)hipStreamSynchronize(s);
+            set_error("sync-free triangular solve: a row waited (4 s) for an entry that was never written");
             return DPCG_ERR_STATE;
         }
     }

@@ -405,6 +405,20 @@ __global__ __launch_bounds__(512) void k_sptrsv_ring_pipe(const int32_t *__restr
 // entries are there.  Arithmetic as everywhere else: ascending columns, one product and one subtraction at a time,
 // then the division -- bit-identical to sequential substitution.
 // ------------------------------------------------------------------------------------------------
+// A wait for another workgroup's entry is bounded by WALL TIME (the 100 MHz constant clock), not by a poll count: a chip
+// shared with other processes, a profiler that serialises dispatches or a pre-empted predecessor stretch a perfectly valid
+// wait; only a malformed schedule waits for seconds.  The clock is looked at every 4096 polls.
+constexpr unsigned long long kSpinTicks = 4ull * 100000000ull;     // 4 s
+__device__ __forceinline__ bool spin_expired(unsigned &spins, unsigned long long &t_start) {
+    if ((++spins & 4095u) != 0) return false;
+    const unsigned long long now = wall_clock64();
+    if (t_start == 0) {
+        t_start = now;
+        return false;
+    }
+    return now - t_start > kSpinTicks;
+}
+constexpr int kSfSub = 4;      // level-major sync-free solve: blocks of rows per ticket (see k_sptrsv_syncfree_rec)
 constexpr unsigned long long kPendingBits = 0x7ff8dead0badbeefULL;   // a quiet NaN that no arithmetic here produces
 __device__ __forceinline__ bool is_pending(double y) { return (unsigned long long)__double_as_longlong(y) == kPendingBits; }
 
@@ -431,25 +445,41 @@ __global__ __launch_bounds__(kBlock) void k_fill_pending(const int32_t *__restri
 // runs keep one launch per level (build_levels: mean level width > 16384); a factor made of them is solved level-major instead
 // (Levels::level_major: contiguous levels, ONE launch of this kernel per solve with a window of 0.85 x the widest level and
 // 512 rows per ticket; rhs_map / refill: see SptrsvIo::fused_entry).
-template <bool UPPER, int BS, int W>   // BS rows (= threads) per ticket, records of width W
+// Tickets.  Every atomic on the ticket word is served one after another (~12 ns each: 88 per us on this chip), and a solve
+// of 1M rows in 512-row tickets drew 1954 of them plus one out-of-range draw and one exit count per workgroup -- 3600
+// serialised atomics = 43 of the kernel's 49 us, whatever the number of levels (found with a 2-level factor: IC(0) in
+// red-black order ran no faster than the 19-level one).  Now a ticket is SUB consecutive blocks of BS rows, walked in order
+// by the workgroup that drew it (a block's rows depend only on earlier positions: earlier blocks of the same ticket or
+// earlier tickets, so the no-deadlock argument is unchanged), and the exit count is read off the ticket itself: every
+// workgroup draws exactly one ticket past the end, and the one that draws the LAST of those zeroes the word for the next
+// launch.  Atomics per solve: tickets + workgroups.
+template <bool UPPER, int BS, int W, int SUB = 1>   // BS rows (= threads) per block, SUB blocks per ticket, records of width W
 __global__ __launch_bounds__(BS) void k_sptrsv_syncfree_rec(int j0, int count, const int32_t *__restrict__ lo_rp,
                                                             const int32_t *__restrict__ lo_ci,
                                                             const double *__restrict__ lo_v,
                                                             const int32_t *__restrict__ meta,
                                                             const double *__restrict__ val,
                                                             const double *__restrict__ rhs, double *out,
-                                                            unsigned int *ticket /* [0] next block, [1] exits */,
+                                                            unsigned int *ticket /* next ticket; [1] unused */,
                                                             int nblocks, const int *done, int *err,
                                                             const int32_t *__restrict__ rhs_map /* null: rhs[own] */,
                                                             double *__restrict__ refill /* null, or preset to pending */) {
     __shared__ unsigned int s_lb;
     const int t = threadIdx.x;
-    if (done && *done) return;                      // nothing drawn: the counters stay zero
+    if (done && *done) return;                      // nothing drawn: the counter stays zero
+    const unsigned int ntickets = ((unsigned int)nblocks + SUB - 1) / SUB;
     for (;;) {
         __syncthreads();
         if (t == 0) s_lb = atomicAdd(ticket, 1u);
         __syncthreads();
-        const unsigned int lb = s_lb;
+        const unsigned int tk = s_lb;
+        if (tk >= ntickets) {
+            // one out-of-range draw per workgroup: the last of them leaves the word at zero for the next launch
+            if (t == 0 && tk == ntickets + gridDim.x - 1) atomicExch(ticket, 0u);
+            break;
+        }
+      for (int sub = 0; sub < SUB; ++sub) {
+        const unsigned int lb = tk * SUB + sub;
         if (lb >= (unsigned int)nblocks) break;
         const int j = j0 + (int)lb * BS + t;
         const bool valid = j < j0 + count;
@@ -460,6 +490,7 @@ __global__ __launch_bounds__(BS) void k_sptrsv_syncfree_rec(int j0, int count, c
         if (refill && valid) refill[j] = __longlong_as_double((long long)kPendingBits);
         bool stored = !valid;
         unsigned spins = 0;
+        unsigned long long t_wait = 0;
         // ONE loop for every lane of the wave, left by the whole wave at once (lanes may wait for each other, and a
         // store on an exit path would only run after every lane has left).  Rows that fit the record (<= W entries): all
         // entries are asked for at once, the pending ones again, and consumed in column order.  Longer rows
@@ -505,7 +536,7 @@ __global__ __launch_bounds__(BS) void k_sptrsv_syncfree_rec(int j0, int count, c
                                 ++k;
                             }
                         }
-                        if (k != k_before) spins = 0;
+                        if (k != k_before) { spins = 0; t_wait = 0; }
                         else waited = true;
                     }
                     ready = k >= ke;
@@ -524,7 +555,7 @@ __global__ __launch_bounds__(BS) void k_sptrsv_syncfree_rec(int j0, int count, c
                             if (r.col[q] >= 0) acc -= r.v[q] * y[q];
                     }
                 }
-                if (waited && ++spins > (1u << 22)) {   // bounded: never hang the device on a malformed schedule
+                if (waited && spin_expired(spins, t_wait)) {   // bounded: never hang the device on a malformed schedule
                     atomicExch(err, 1);
                     acc = __builtin_nan("");
                     ready = true;
@@ -538,10 +569,7 @@ __global__ __launch_bounds__(BS) void k_sptrsv_syncfree_rec(int j0, int count, c
             }
             if (__ballot(!stored) == 0) break;
         }
-    }
-    if (t == 0 && atomicAdd(ticket + 1, 1u) == gridDim.x - 1) {      // last one out: zero the counters for the next launch
-        atomicExch(ticket, 0u);
-        atomicExch(ticket + 1, 0u);
+      }
     }
 }
 
@@ -639,10 +667,12 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
     auto poll = [&](int col) {
         double y;
         ++n_polls;
-        for (unsigned spins = 0;; ++spins) {
+        unsigned spins = 0;
+        unsigned long long t_wait = 0;
+        for (;;) {
             y = __hip_atomic_load(out + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!is_pending(y)) break;
-            if (spins > (1u << 22)) {
+            if (spin_expired(spins, t_wait)) {
                 atomicExch(err, 1);
                 y = __builtin_nan("");
                 break;
@@ -910,9 +940,9 @@ static void launch_schedule(int64_t n, const Levels &lv, bool upper, bool lm, co
     do {                                                                                                                     \
         const int nb = (cnt + BSV - 1) / BSV;                                                                                \
         int g = ((int)(factor * seg.max_width) + BSV - 1) / BSV + 4;                                                         \
-        g = g > nb ? nb : g;                                                                                                 \
+        g = g > (nb + kSfSub - 1) / kSfSub ? (nb + kSfSub - 1) / kSfSub : g;                                                 \
         g = g > 2048 * 256 / BSV ? 2048 * 256 / BSV : g;                                                                     \
-        hipLaunchKernelGGL((k_sptrsv_syncfree_rec<UP, BSV, WV>), dim3(g), dim3(BSV), 0, s, j0, cnt, lv.lo_rowptr, cols,      \
+        hipLaunchKernelGGL((k_sptrsv_syncfree_rec<UP, BSV, WV, kSfSub>), dim3(g), dim3(BSV), 0, s, j0, cnt, lv.lo_rowptr, cols, \
                            lv.lo_val, lv.sf_meta, lv.sf_val, rhs, out,                                                       \
                            reinterpret_cast<unsigned int *>(lv.tickets + seg_index), nb, done, lv.spin_err, rhs_map,        \
                            sf_refill);                                                                                       \

@@ -138,24 +138,37 @@ class PreconditionerNet(nn.Module):
 
 # ---- the HIP path of PreconditionerNet.forward (inference) -----------------------------------------------------------
 class _ConvnetPlan:
-    """Owner of a `dpcg_convnet_plan_t` (active sites + rulebooks of every layer for ONE sparsity pattern)."""
+    """Owner of a `dpcg_convnet_plan_t` (active sites + rulebooks of every layer for ONE sparsity pattern).  `rebuild`
+    re-targets it at another pattern reusing its device memory (dpcg_convnet_plan_rebuild)."""
 
     def __init__(self, indices: torch.Tensor, batch: int, shape, kernels, paddings):
         import ctypes as C
-        from . import _lib as L
-        self._L, self._C = L, C
-        self.indices = indices                         # kept alive: the cache key is its storage
         self.handle = C.c_void_p()
+        self._build(indices, batch, shape, kernels, paddings, create=True)
+
+    def rebuild(self, indices: torch.Tensor, batch: int, shape, kernels, paddings) -> None:
+        self._build(indices, batch, shape, kernels, paddings, create=False)
+
+    def _build(self, indices, batch, shape, kernels, paddings, create: bool) -> None:
+        import ctypes as C
+        from . import _lib as L
+        self._L = L
+        self.indices = indices                         # kept alive: the cache key is its storage
         n = len(kernels)
         k = (C.c_int32 * (2 * n))(*[v for kk in kernels for v in kk])
         p = (C.c_int32 * (2 * n))(*[v for pp in paddings for v in pp])
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        L.check(L.lib().dpcg_convnet_plan_create(C.byref(self.handle), int(batch), int(shape[0]), int(shape[1]),
-                                                 int(indices.shape[0]), C.c_void_p(indices.data_ptr()), n, k, p, stream))
+        args = (int(batch), int(shape[0]), int(shape[1]), int(indices.shape[0]), C.c_void_p(indices.data_ptr()), n, k, p, stream)
+        if create:
+            L.check(L.lib().dpcg_convnet_plan_create(C.byref(self.handle), *args))
+        else:
+            L.check(L.lib().dpcg_convnet_plan_rebuild(self.handle, *args))
         sites, h, w, nl = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         L.check(L.lib().dpcg_convnet_plan_info(self.handle, n - 1, C.byref(sites), C.byref(h), C.byref(w), C.byref(nl)))
         self.sites, self.out_shape, self.nnz_lower, self.batch = sites.value, [h.value, w.value], nl.value, int(batch)
         dev = indices.device
+        # fresh output arrays per pattern (torch's caching allocator: no device allocation): results of an earlier pattern
+        # that the caller still holds stay valid
         self.out_indices = torch.empty((self.sites, 3), dtype=torch.int32, device=dev)
         self.lower_rowptr = torch.empty(self.batch * h.value + 1, dtype=torch.int32, device=dev)
         self.lower_col = torch.empty(self.nnz_lower, dtype=torch.int32, device=dev)
@@ -225,8 +238,19 @@ def hip_conv_stack(layers, t: SparseBatch, lower: bool = False, cache: dict | No
     plan = cache.get(key)
     with torch.cuda.device(feats.device):
         if plan is None:
+            # a plan holds rulebooks and feature buffers: keep a few, and re-target the oldest one at the new pattern
+            # (its device memory is reused: a data set of similar matrices then costs no allocations per matrix)
+            recycled_key = next(iter(cache)) if len(cache) >= 2 else None
             try:
-                plan = _ConvnetPlan(indices, t.batch_size, t.spatial_shape, kernels, paddings)
+                if recycled_key is not None:
+                    plan = cache.pop(recycled_key)
+                    try:
+                        plan.rebuild(indices, t.batch_size, t.spatial_shape, kernels, paddings)
+                    except L.DpcgError:
+                        plan.close()
+                        raise
+                else:
+                    plan = _ConvnetPlan(indices, t.batch_size, t.spatial_shape, kernels, paddings)
             except L.DpcgError as exc:
                 if "sorted" not in str(exc):
                     raise
@@ -236,8 +260,6 @@ def hip_conv_stack(layers, t: SparseBatch, lower: bool = False, cache: dict | No
                 order = torch.argsort(k)
                 return hip_conv_stack(layers, SparseBatch(feats[order], indices[order].contiguous(), t.spatial_shape, t.batch_size),
                                       lower, cache)
-            while len(cache) >= 4:                       # a plan holds rulebooks and feature buffers: keep a few
-                cache.pop(next(iter(cache))).close()
             cache[key] = plan
         n = len(layers)
         chan = (C.c_int32 * (n + 1))(*([layers[0][0].in_channels] + [c.out_channels for c, _ in layers]))

@@ -246,6 +246,11 @@ typedef struct dpcg_convnet_plan *dpcg_convnet_plan_t;
 int dpcg_convnet_plan_create(dpcg_convnet_plan_t *out, int batch, int64_t height, int64_t width, int64_t nnz,
                              const int32_t *indices, int n_layers, const int32_t *kernel_hw, const int32_t *padding_hw,
                              dpcg_stream_t stream);
+/* The same for ANOTHER pattern in an existing plan, reusing its device memory (a plan per matrix of a data set then costs
+ * no allocations after the first).  On failure the plan is left empty (usable only for another rebuild or destroy). */
+int dpcg_convnet_plan_rebuild(dpcg_convnet_plan_t plan, int batch, int64_t height, int64_t width, int64_t nnz,
+                              const int32_t *indices, int n_layers, const int32_t *kernel_hw, const int32_t *padding_hw,
+                              dpcg_stream_t stream);
 int dpcg_convnet_plan_destroy(dpcg_convnet_plan_t plan);
 /* active sites and image size after layer `layer`; nnz_lower: entries with col <= row of the LAST layer's sites */
 int dpcg_convnet_plan_info(dpcg_convnet_plan_t plan, int layer, int64_t *sites, int64_t *height, int64_t *width,
