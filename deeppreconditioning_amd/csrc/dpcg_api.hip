@@ -520,6 +520,7 @@ extern "C" int dpcg_spmv_f32(dpcg_handle_t h, const float *x, float *y, dpcg_str
 int rz_partial_count(const dpcg_system *h) {
     if (h->precond == DPCG_PRECOND_CSR) return h->planM.grid;
     if (h->precond == DPCG_PRECOND_LLT_MULTIPLY) return h->planL.grid;
+    if (h->precond == DPCG_PRECOND_LLT_SOLVE && h->lvlU.sweep) return h->lvlU.n_levels * h->lvlU.sweep_grid;   // colour sweeps
     return h->vec_grid;
 }
 
@@ -578,7 +579,7 @@ int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, boo
             }
             launch_sptrsv(h->L, h->lvlL, false, r, h->t, s, in_loop ? &h->scal->done : nullptr, &lower_io);
             launch_sptrsv(h->Lt, h->lvlU, true, h->t, z, s, in_loop ? &h->scal->done : nullptr, &upper_io);
-            if (upper_io.dot_done) *n_part_rz = h->vec_grid;
+            if (upper_io.dot_done) *n_part_rz = upper_io.dot_count;
             break;
         }
         default:

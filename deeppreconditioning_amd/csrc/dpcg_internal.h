@@ -148,6 +148,11 @@ struct Levels {
     int32_t *lm_pos = nullptr;             // handle index -> level-order position
     int32_t *lm_from_lower = nullptr;      // L^T only: position here -> position in L's numbering (lower result feeds the upper solve)
     double *lm_rhs = nullptr, *lm_out = nullptr;
+    // Colour sweeps (a level-major factor of a few very wide levels whose 256-row blocks fit the LDS product buffer --
+    // IC(0) in multicolour order): one CSR-stream launch per level that gathers its right-hand side itself, writes the
+    // result by position AND in the handle's numbering and sums <r,z> on the way (k_lm_sweep): no way-in / way-out passes.
+    bool sweep = false;
+    int sweep_grid = 0;                    // workgroups per level launch; an apply leaves n_levels * sweep_grid partials of <r,z>
     // Invariant (factors that are one sync-free launch, single_syncfree_segment): between solves the LOWER factor's lm_out
     // holds the sync-free kernels' "pending" pattern everywhere -- set up by build_levels, restored by whoever consumed the
     // values (the way-out pass of a paired apply; launch_sptrsv itself after a standalone lower solve).  A solve with
@@ -162,6 +167,7 @@ struct SptrsvIo {
     double *dot_part = nullptr;            // ... into dot_part[0 .. dot_grid)
     int dot_grid = 0;
     bool dot_done = false;                 // set by launch_sptrsv when it did sum them
+    int dot_count = 0;                     // ... and how many partials it left (dot_grid, or what the colour sweeps leave)
     // No way-in pass: the (single, sync-free) solve kernel gathers its right-hand side through the map itself; lm_out must be
     // all-pending (see Levels: the invariant for the lower factor; the lower solve's `refill` for the upper one).  `refill`: another vector of n entries that the
     // kernel (lower solve) or the way-out pass (upper solve) presets to the pending pattern for whoever solves next.

@@ -347,7 +347,13 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
             // (a level-major factor has no ring segments: the ring kernels address the vectors by row)
             if (!lv.level_major && !long_rows && seg.merged && seg.ring_w > 0 && seg.max_width <= 1024 && lds <= 64 * 1024)
                 return 0;                                                                                 // RING
-            if (lv.level_major && level_major_syncfree()) return 1;   // level-major: the whole factor as ONE sync-free launch
+            // level-major: the whole factor as ONE sync-free launch -- except a factor of a few VERY wide levels (IC(0) in
+            // multicolour order at 1M rows: 2 levels of 500K): there a launch per level on the records wins (measured per
+            // apply, 100^3 red-black: 104.7 us sync-free, 63.6 with four blocks per ticket, 59.4 one launch per level;
+            // 256^2 red-black, 2 x 32K rows: 19.8 sync-free, 30.6 per level)
+            const bool few_very_wide = lv.n_levels <= 4 && n / lv.n_levels >= 131072;
+            if (lv.level_major && level_major_syncfree() && !few_very_wide) return 1;
+            if (lv.level_major && few_very_wide) return 2;
             const int64_t rows_in_seg = (int64_t)level_ptr[seg.hi] - level_ptr[seg.lo];
             return rows_in_seg / (seg.hi - seg.lo) <= kSyncfreeMaxMeanWidth ? 1 : 2;                     // NARROW : WIDE
         };
@@ -398,9 +404,18 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         DPCG_TRY(dev_alloc(&lv.spin_err, 1));
         DPCG_HIP(hipMemsetAsync(lv.tickets, 0, (size_t)nseg * sizeof(unsigned long long), s));
         DPCG_HIP(hipMemsetAsync(lv.spin_err, 0, sizeof(int), s));
+        // colour sweeps (see Levels::sweep): a level-major factor of a few very wide levels whose blocks fit the LDS product buffer
+        static const bool sweeps_on = [] { const char *e = getenv("DPCG_SWEEPS"); return !(e && e[0] == '0'); }();
+        if (sweeps_on && lv.level_major && lv.stream_ok && lv.n_levels <= 4 && n / lv.n_levels >= 131072) {
+            lv.sweep = true;
+            int64_t widest = 0;
+            for (int l = 0; l < lv.n_levels; ++l) widest = std::max<int64_t>(widest, level_ptr[l + 1] - level_ptr[l]);
+            const int64_t blocks = (widest + kBlock - 1) / kBlock;
+            lv.sweep_grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, kMaxSpmvGrid / lv.n_levels));
+        }
         bool any = false;
         for (const auto &seg : lv.segments) any = any || !(seg.merged && seg.ring_w > 0);
-        if (any) {                                       // records for the sync-free and the per-level kernels
+        if (any && !lv.sweep) {                          // records for the sync-free and the per-level kernels
             // width of the records: 3 entries unless more than 2 % of the rows are longer (they would take the slow general
             // path: three dependent loads before the first entry, then one entry at a time), then 6, then 14
             DevBuf<int32_t> n_long;

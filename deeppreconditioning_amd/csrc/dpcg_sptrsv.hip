@@ -418,7 +418,11 @@ __device__ __forceinline__ bool spin_expired(unsigned &spins, unsigned long long
     }
     return now - t_start > kSpinTicks;
 }
-constexpr int kSfSub = 4;      // level-major sync-free solve: blocks of rows per ticket (see k_sptrsv_syncfree_rec)
+// level-major sync-free solve: blocks of rows per ticket (see k_sptrsv_syncfree_rec).  Measured with 4: a 2-level factor
+// gains (104.7 -> 63.6 us per apply at 1M rows) but a 19-level one loses badly (134 -> 301 us: the blocks of a ticket are
+// walked one after another, so a level takes four turns to complete); few-level factors of that size now take one launch
+// per level (build_levels), so one block per ticket it is.
+constexpr int kSfSub = 1;
 constexpr unsigned long long kPendingBits = 0x7ff8dead0badbeefULL;   // a quiet NaN that no arithmetic here produces
 __device__ __forceinline__ bool is_pending(double y) { return (unsigned long long)__double_as_longlong(y) == kPendingBits; }
 
@@ -1062,6 +1066,98 @@ static void launch_schedule(int64_t n, const Levels &lv, bool upper, bool lm, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Colour sweep: one VERY wide level of a level-major factor (IC(0) in multicolour order: 2 .. 4 levels of n / colours rows)
+// as ONE bandwidth-bound launch with everything an apply needs fused in, so that z = L^-T (L^-1 r) is 2 x levels launches
+// and nothing else (no way-in gather pass, no way-out pass, no dot launch):
+//   * CSR-stream on the level-ordered copy (positions as columns): a workgroup streams the contiguous val / position
+//     segment of 256 consecutive rows, parks v * out[position] in LDS, thread j subtracts row j's products in column order
+//     and divides by the diagonal -- the arithmetic and order of k_sptrsv_level_stream, bit-identical to sequential
+//     substitution; a row without off-diagonal entries (every row of the first colour) costs its 4-byte extent, not a
+//     96-byte record;
+//   * the right-hand side is gathered through `src_map` (the handle's r through the row list; the lower solve's result
+//     through lm_from_lower), the result goes to out[position] for the later levels and, when `dst` is given, to
+//     dst[rows[position]] -- the handle's numbering; with `dotv` the workgroup's share of <dotv, result> goes to
+//     part[blockIdx.x] (persistent grid: the partial count does not depend on the level's size).
+// ------------------------------------------------------------------------------------------------
+template <bool UPPER>
+__global__ __launch_bounds__(kBlock) void k_lm_sweep(int j0, int count, const int32_t *__restrict__ lo_rp,
+                                                     const int32_t *__restrict__ lo_cp, const double *__restrict__ lo_v,
+                                                     const double *__restrict__ src, const int32_t *__restrict__ src_map,
+                                                     double *out, double *__restrict__ dst, const int32_t *__restrict__ rows,
+                                                     const double *__restrict__ dotv, double *__restrict__ part, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
+    constexpr int U = kStreamCap / kBlock;
+    __shared__ double prod[kStreamCap];
+    __shared__ double sh[4];
+    const int t = threadIdx.x;
+    const int nblk = (count + kBlock - 1) / kBlock;
+    double dot = 0.0;
+    for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int jb = j0 + blk * kBlock;
+        const int jend = (jb + kBlock < j0 + count) ? jb + kBlock : j0 + count;
+        const int j = jb + t;
+        const int base = lo_rp[jb];
+        const int cnt = lo_rp[jend] - base;
+        int rs = 0, re = 0, own = 0;
+        double bi = 0.0, dv = 0.0;
+        if (j < jend) {
+            rs = lo_rp[j] - base;
+            re = lo_rp[j + 1] - base;
+            own = rows[j];
+            bi = src[src_map ? src_map[j] : j];
+            if (dotv) dv = dotv[own];
+        }
+        const int last = cnt > 0 ? cnt - 1 : 0;
+        int c[U];
+        double a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = t + u * kBlock;
+            const int kk = k < cnt ? k : last;
+            c[u] = lo_cp[base + kk];
+            a[u] = lo_v[base + kk];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = t + u * kBlock;
+            // the diagonal's slot (its column is the row itself: not solved yet) is parked too and never read
+            if (k < cnt) prod[k] = a[u] * out[c[u]];
+        }
+        __syncthreads();
+        if (j < jend) {
+            double acc = bi;
+            const int ks = UPPER ? rs + 1 : rs, ke = UPPER ? re : re - 1;
+            for (int k = ks; k < ke; ++k) acc -= prod[k];
+            const double y = acc / lo_v[base + (UPPER ? rs : re - 1)];
+            out[j] = y;
+            if (dst) dst[own] = y;
+            dot += dv * y;
+        }
+        __syncthreads();          // prod is reused by the next block
+    }
+    if (part) {
+        const double tot = block_sum(dot, sh);
+        if (t == 0) part[blockIdx.x] = tot;
+    }
+}
+
+// The whole factor as colour sweeps (Levels::sweep).  `src` / `src_map`: where the right-hand side comes from; dst: the result in
+// the handle's numbering (null: by position in lv.lm_out only).
+static void launch_sweeps(const Levels &lv, bool upper, const double *src, const int32_t *src_map, double *dst, const double *dotv,
+                          double *part, hipStream_t s, const int *done) {
+    for (int l = 0; l < lv.n_levels; ++l) {
+        const int j0 = lv.level_ptr[l], cnt = lv.level_ptr[l + 1] - j0;
+        double *pl = part ? part + (size_t)l * lv.sweep_grid : nullptr;
+        if (upper)
+            hipLaunchKernelGGL(k_lm_sweep<true>, dim3(lv.sweep_grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_cpos, lv.lo_val,
+                               src, src_map, lv.lm_out, dst, lv.rows, dotv, pl, done);
+        else
+            hipLaunchKernelGGL(k_lm_sweep<false>, dim3(lv.sweep_grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_cpos, lv.lo_val,
+                               src, src_map, lv.lm_out, dst, lv.rows, dotv, pl, done);
+    }
+}
+
 void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s,
                    const int *done, SptrsvIo *io) {
     const int64_t n = T.n;    // the level-ordered copy in `lv` carries the factor
@@ -1069,6 +1165,19 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
     const bool lm = lv.level_major && lv.strips.n_strips == 0;
     if (!lm) {
         launch_schedule(n, lv, upper, false, lv.rows, lv.lo_col, rhs, out, s, done, nullptr, nullptr);
+        return;
+    }
+    if (lv.sweep) {
+        // colour sweeps: every level one fused launch; the upper solve of a paired apply reads the lower one's result by position
+        const bool chained = io && io->lm_in;
+        const bool keep = io && io->keep_lm;
+        const bool dot = io && io->dot_with && io->dot_part;
+        launch_sweeps(lv, upper, chained ? io->lm_in : rhs, chained ? lv.lm_from_lower : lv.rows, keep ? nullptr : out,
+                      dot ? io->dot_with : nullptr, dot ? io->dot_part : nullptr, s, done);
+        if (dot) {
+            io->dot_done = true;
+            io->dot_count = lv.n_levels * lv.sweep_grid;
+        }
         return;
     }
     // Level-major: way in (a pass, or fused into the single sync-free kernel), the schedule on positions, way out.
@@ -1092,7 +1201,10 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
     grid = grid > 2048 ? 2048 : grid;
     hipLaunchKernelGGL(k_lm_finish, dim3(grid), dim3(kBlock), 0, s, n, lv.lm_pos, lv.lm_out, out, dot ? io->dot_with : nullptr,
                        dot ? io->dot_part : nullptr, done, fused_entry ? io->refill : nullptr);
-    if (dot) io->dot_done = true;
+    if (dot) {
+        io->dot_done = true;
+        io->dot_count = grid;
+    }
     // a standalone lower solve consumed the "pending" preset of lm_out: put it back (Levels: the invariant)
     if (!upper && !fused_entry && single_syncfree_segment(lv))
         hipLaunchKernelGGL(k_fill_pending, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, nullptr, 0, (int)n,

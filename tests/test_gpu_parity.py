@@ -1891,6 +1891,7 @@ def test_preconditioner_net_hip_forward_against_the_dense_restatement(D, monkeyp
 @pytest.mark.parametrize("name,make,reorder,colors", [
     ("poisson2d_70", lambda: O.poisson2d(70), None, 2),
     ("poisson3d_40", lambda: O.poisson3d(40), None, 2),                               # level-major sync-free form (2 wide levels)
+    ("poisson3d_64", lambda: O.poisson3d(64), None, 2),                               # 2 x 131 072 rows: the colour-sweep kernels
     ("unstructured3d_34_rcm", lambda: O.unstructured_like(O.poisson3d(34), seed=2), "rcm", 2),
     ("random_spd_nonbipartite", None, None, None),
 ])
@@ -1930,6 +1931,12 @@ def test_ic0_in_multicolour_order(D, name, make, reorder, colors):
     zref[q] = zc
     assert np.array_equal(S.precond_apply(_dev(b)).cpu().numpy(), zref)
     assert np.array_equal(S.precond_apply(_dev(b)).cpu().numpy(), zref)          # and again (pending-pattern hand-over)
+    # the two solves on their own (vectors in the caller's numbering): Q^T L^-1 Q b and Q^T L^-T Q t
+    t_ref = np.empty(n)
+    t_ref[q] = CO.sptrsv_lower(Lref, b[q])
+    assert np.array_equal(S.sptrsv(_dev(b), upper=False).cpu().numpy(), t_ref)
+    assert np.array_equal(S.sptrsv(_dev(t_ref), upper=True).cpu().numpy(), zref)
+    assert np.array_equal(S.precond_apply(_dev(b)).cpu().numpy(), zref)
     qinv = np.empty(n, dtype=np.int32)
     qinv[q] = np.arange(n, dtype=np.int32)
     if S.reordered:
