@@ -216,6 +216,9 @@ struct dpcg_system {
     int vec_grid = 1;
     // cached iteration graph
     dpcg::SmallDesc *small_desc = nullptr;   // device, one entry (single small solves)
+    void *team_desc = nullptr;               // device, one TeamDesc (single mid-size solves, dpcg_team.hip)
+    double *team_part = nullptr;             // the team's reduction partials (4 x 32 doubles)
+    unsigned int *team_sync = nullptr;       // [0] barrier counter, [1] error flag
     dpcg::SmallEll ell_a, ell_m, ell_t;      // slab-ELL copies of A, M (or L), L^T for the small-system kernel
     hipGraphExec_t graph_exec = nullptr;
     int graph_key = -1;
@@ -325,6 +328,25 @@ void launch_build_ell(int n, const int32_t *rp, const int32_t *ci, const double 
 int small_variant(int n, int max_row_len, int precond);
 int launch_pcg_small(const SmallDesc *descs_dev, int count, int lds_bytes, int kinds_mask, int variants_mask,
                      hipStream_t s);
+// dpcg_team.hip: whole-solve kernel for mid-size systems, a team of 32 workgroups per system
+struct TeamDesc {
+    int n, precond, max_iter, init_check_r, hist_cap, W;
+    const int32_t *rp;
+    const double *dinv;
+    const int32_t *ell_col;
+    const double *ell_val;
+    const double *b, *x0;
+    double *x, *hist;
+    double *p;                 // n doubles: the direction vector as the other workgroups see it
+    double rtol_sq, atol_sq;
+    Scalars *out;
+    unsigned int *bar;         // the team's barrier counter (zero at launch)
+    double *part;              // 4 * kTeamSize doubles: slots 0 <p,Ap> (and <b,b>), 1 <r,z>, 2 <r,r>, 3 scratch
+    int *err;
+};
+
+int team_max_rows();
+int launch_pcg_team(const TeamDesc *descs_dev, int nsys, int max_slabs_per_wg, hipStream_t s);
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
                       hipStream_t s, const double *colnorm = nullptr, double tau = 0.0);   // colnorm: ICT drop rule
 void launch_colnorm1(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, double *c, hipStream_t s);

@@ -443,6 +443,95 @@ static int solve_small_one(dpcg_system *h, const double *b, const double *x0, do
     return sc.status;
 }
 
+// ------------------------------------------------------------------------------------------------
+// mid-size systems: the whole solve in one launch, a team of 32 workgroups per system (dpcg_team.hip)
+// ------------------------------------------------------------------------------------------------
+static bool team_eligible(const dpcg_system *h, int flags, const double *x_true) {
+    static const bool enabled = [] {
+        const char *e = getenv("DPCG_TEAM");
+        if (e && e[0] == '0') return false;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        return cus >= 256;                       // eight teams of 32 workgroups, one workgroup per CU, all resident
+    }();
+    if (!enabled || x_true || (flags & (DPCG_SPMV_F32 | DPCG_NO_TEAM | DPCG_NO_FUSE | DPCG_VAL32_IF_LOSSLESS))) return false;
+    if (h->A.n <= kSmallMaxN || h->A.n > team_max_rows() || h->perm) return false;
+    if (h->planA.kernel == SPMV_VECTOR) return false;     // long rows: the multi-launch path's row-sharing kernel
+    return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI;
+}
+
+static int ensure_team(dpcg_system *h, hipStream_t s) {
+    DPCG_TRY(build_ell(h->A, h->ell_a, s));
+    if (!h->team_part) DPCG_TRY(dev_alloc(&h->team_part, 4 * 32));
+    if (!h->team_sync) DPCG_TRY(dev_alloc(&h->team_sync, 2));
+    return DPCG_OK;
+}
+
+static TeamDesc make_team_desc(dpcg_system *h, const double *b, const double *x0, double *x, double rtol_sq, double atol_sq,
+                               int max_iter, int flags) {
+    TeamDesc d;
+    memset(&d, 0, sizeof(d));
+    d.n = (int)h->A.n;
+    d.precond = h->precond;
+    d.max_iter = max_iter;
+    d.init_check_r = (flags & DPCG_INIT_CHECK_R) ? 1 : 0;
+    d.hist_cap = h->hist_cap;
+    d.W = h->ell_a.W;
+    d.rp = h->A.rowptr;
+    d.dinv = h->dinv;
+    d.ell_col = h->ell_a.col;
+    d.ell_val = h->ell_a.val;
+    d.b = b; d.x0 = x0; d.x = x ? x : h->x; d.hist = h->hist;
+    d.p = h->p;
+    d.rtol_sq = rtol_sq; d.atol_sq = atol_sq;
+    d.out = h->scal;
+    d.bar = h->team_sync;
+    d.part = h->team_part;
+    d.err = reinterpret_cast<int *>(h->team_sync + 1);
+    return d;
+}
+
+static int team_slabs_per_wg(int64_t n) {
+    const int64_t slabs = (n + 1023) / 1024;
+    return (int)((slabs + 31) / 32);
+}
+
+static int solve_team_one(dpcg_system *h, const double *b, const double *x0, double *x, double rtol_sq, double atol_sq,
+                          int max_iter, int flags, hipStream_t s, int *iters, double *final_res, double *seconds,
+                          double *res_history) {
+    DPCG_TRY(ensure_work(h, max_iter, false, false));
+    DPCG_TRY(ensure_team(h, s));
+    if (!h->team_desc) {
+        TeamDesc *td = nullptr;
+        DPCG_TRY(dev_alloc(&td, 1));
+        h->team_desc = td;
+    }
+    const TeamDesc d = make_team_desc(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags);
+    DPCG_HIP(hipMemcpyAsync(h->team_desc, &d, sizeof(d), hipMemcpyHostToDevice, s));
+    DPCG_HIP(hipMemsetAsync(h->team_sync, 0, 2 * sizeof(unsigned int), s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    const auto t0 = std::chrono::steady_clock::now();                                // cg.py:69 (the launch is the loop)
+    DPCG_TRY(launch_pcg_team(static_cast<const TeamDesc *>(h->team_desc), 1, team_slabs_per_wg(h->A.n), s));
+    DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    const auto t1 = std::chrono::steady_clock::now();                                // cg.py:88
+    DPCG_CHECK_LAUNCH();
+    const Scalars sc = *h->scal_host;
+    if (sc.status < 0) {
+        set_error("team solve: a workgroup waited (4 s) for a team member that never arrived");
+        return sc.status;
+    }
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    if (iters) *iters = sc.k;
+    if (final_res) *final_res = sc.res;
+    if (res_history) {
+        DPCG_HIP(hipMemcpyAsync(res_history, h->hist, (size_t)(sc.k + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+    }
+    return sc.status;
+}
+
 static int check_solve_args(dpcg_handle_t h, const double *b, int max_iter, int flags, const double *x_true,
                             double *err_history) {
     if (!h || !b) return invalid("dpcg_solve: NULL handle or b");
@@ -462,6 +551,9 @@ extern "C" int dpcg_solve(dpcg_handle_t h, const double *b, const double *x0, do
     if (small_eligible(h, flags, x_true))
         return solve_small_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
                                seconds, res_history);
+    if (team_eligible(h, flags, x_true))
+        return solve_team_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
+                              seconds, res_history);
     Solve sv;
     sv.h = h;
     sv.s = (hipStream_t)stream;
@@ -546,6 +638,53 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
             worst_small = std::max(worst_small, out[i].status);
         }
         return worst_small;
+    }
+    bool all_team = true;
+    for (int i = 0; i < count; ++i) all_team = all_team && team_eligible(handles[i], flags, nullptr);
+    if (all_team) {
+        // up to eight systems per launch, one team (normally: one XCD) each; the launches follow one another
+        struct TeamScratch {
+            TeamDesc *descs = nullptr;
+            ~TeamScratch() { if (descs) (void)hipFree(descs); }
+        };
+        static thread_local TeamScratch scratch;
+        if (!scratch.descs) DPCG_TRY(dev_alloc(&scratch.descs, 8));
+        int worst_team = DPCG_OK;
+        for (int g0 = 0; g0 < count; g0 += 8) {
+            const int ng = std::min(8, count - g0);
+            TeamDesc descs[8];
+            int slabs = 1;
+            for (int i = 0; i < ng; ++i) {
+                dpcg_system *hi = handles[g0 + i];
+                DPCG_TRY(ensure_work(hi, max_iter, false, false));
+                DPCG_TRY(ensure_team(hi, nullptr));
+                descs[i] = make_team_desc(hi, b[g0 + i], x0 ? x0[g0 + i] : nullptr, x ? x[g0 + i] : nullptr, rtol_sq, atol_sq,
+                                          max_iter, flags);
+                DPCG_HIP(hipMemsetAsync(hi->team_sync, 0, 2 * sizeof(unsigned int), nullptr));
+                slabs = std::max(slabs, team_slabs_per_wg(hi->A.n));
+            }
+            DPCG_HIP(hipMemcpy(scratch.descs, descs, (size_t)ng * sizeof(TeamDesc), hipMemcpyHostToDevice));
+            const auto t0 = std::chrono::steady_clock::now();
+            DPCG_TRY(launch_pcg_team(scratch.descs, ng, slabs, nullptr));
+            DPCG_HIP(hipStreamSynchronize(nullptr));
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            DPCG_CHECK_LAUNCH();
+            for (int i = 0; i < ng; ++i) {
+                dpcg_system *hi = handles[g0 + i];
+                DPCG_HIP(hipMemcpy(hi->scal_host, hi->scal, sizeof(Scalars), hipMemcpyDeviceToHost));
+                const Scalars sc = *hi->scal_host;
+                if (sc.status < 0) {
+                    set_error("team solve: a workgroup waited (4 s) for a team member that never arrived");
+                    return sc.status;
+                }
+                if (iters) iters[g0 + i] = sc.k;
+                if (final_res) final_res[g0 + i] = sc.res;
+                if (seconds) seconds[g0 + i] = sec;      // the group ran as one launch
+                if (status) status[g0 + i] = sc.status;
+                worst_team = std::max(worst_team, sc.status);
+            }
+        }
+        return worst_team;
     }
     std::vector<hipStream_t> streams((size_t)n_streams, nullptr);
     for (auto &st : streams) DPCG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));

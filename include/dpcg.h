@@ -66,9 +66,11 @@ enum dpcg_solve_flags {
                                 fp64 -> fp32 -> fp64 unchanged (true for the reference's data, which is fp32
                                 upcast to fp64: data_set.py:121, test.py:68): 8 instead of 12 bytes per non-zero,
                                 products and sums still fp64, results bit-identical.  Ignored when lossy. */
-    DPCG_NO_FUSE = 32        /* run an update as three kernels (SpMV | r,z | x,p) instead of the default two, in
+    DPCG_NO_FUSE = 32,       /* run an update as three kernels (SpMV | r,z | x,p) instead of the default two, in
                                 which the SpMV kernel also forms p = z + beta p (cg.py:83) and the deferred
                                 x += alpha p (cg.py:79); same arithmetic, bit-identical results              */
+    DPCG_NO_TEAM = 64        /* do not use the one-launch whole-solve kernel for mid-size systems (6 145 .. 65 536 rows,
+                                M = I or Jacobi: a team of 32 workgroups per system, up to eight systems per launch) */
 };
 
 /* ---- library ------------------------------------------------------------------------------- */

@@ -1964,3 +1964,63 @@ def test_ic0_in_multicolour_order(D, name, make, reorder, colors):
     with pytest.raises(ValueError):
         D.IC0("multiply", ordering="multicolor")
     S.close()
+
+
+# ---- round 3: mid-size systems, the whole solve in one launch by a team of 32 workgroups (dpcg_team.hip) --------------
+@pytest.mark.parametrize("name,make", [("poisson2d_90", lambda: O.poisson2d(90)), ("poisson2d_256", lambda: O.poisson2d(256)),
+                                       ("poisson3d_33", lambda: O.poisson3d(33)),
+                                       ("unstructured2d_150", lambda: O.unstructured_like(O.poisson2d(150), seed=4))])
+def test_team_kernel_matches_multi_launch_path_and_oracle(D, name, make):
+    """6 145 .. 65 536 rows, M = I / Jacobi: the one-launch team solve against oracle/pcg_oracle.c (counts equal, history
+    within 1e-10, x) and against the multi-launch path (DPCG_NO_TEAM): x0, max_iter caps, both stopping tests, and the
+    breakdown status.  The team path must be the one that ran (seconds of a 65 536-row solve give it away: see bench)."""
+    A = make()
+    n = A.shape[0]
+    assert 6144 < n <= 65536
+    b = O.rhs(n, 1)
+    S = D.CsrSystem.from_any(A, reorder=None)
+    for kind, pc, okw in (("jacobi", D.Jacobi(), dict(dinv=O.jacobi_dinv(A))), ("none", None, {})):
+        S.set_preconditioner(pc)
+        team = S.solve(_dev(b))
+        multi = S.solve(_dev(b), flags=D._lib.NO_TEAM)
+        _, it, hist, x = CO.pcg(A, b, kind, **okw)
+        assert team.iterations == multi.iterations == it and team.status == multi.status == 0
+        np.testing.assert_allclose(team.res_history, hist, rtol=HIST_RTOL)
+        np.testing.assert_allclose(multi.res_history, hist, rtol=HIST_RTOL)
+        np.testing.assert_allclose(team.x.cpu().numpy(), x, rtol=1e-9, atol=1e-12)
+        again = S.solve(_dev(b))
+        assert np.array_equal(again.res_history, team.res_history) and torch.equal(again.x, team.x)   # reproducible to the bit
+    x0 = O.rhs(n, 7)
+    S.set_preconditioner(D.Jacobi())
+    for max_iter in (0, 1, 25):
+        r = S.solve(_dev(b), _dev(x0), max_iter=max_iter)
+        _, it, hist, x = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A), x0=x0, max_iter=max_iter)
+        assert r.iterations == it and r.status == 1
+        np.testing.assert_allclose(r.res_history, hist, rtol=HIST_RTOL)
+        np.testing.assert_allclose(r.x.cpu().numpy(), x, rtol=1e-9, atol=1e-12)
+    r = S.solve(_dev(b), flags=D._lib.INIT_CHECK_R, rtol_sq=1e-6)
+    _, it, hist, _ = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A), rtol=1e-6, init_check="r")
+    assert r.iterations == it
+    np.testing.assert_allclose(r.res_history, hist, rtol=HIST_RTOL)
+    rz = S.solve(_dev(np.zeros(n)))                        # b = 0: <b,b> = 0 -> 0/0 -> breakdown, as on every other path
+    assert rz.status == 2 and rz.iterations == 0
+    S.close()
+
+
+def test_team_kernel_batches_of_systems(D):
+    """`solve_batch` of mid-size systems: eight per launch, one team each (11 systems = a launch of 8 and one of 3), sizes
+    and iteration counts all different; every result equals the single solve of that system bit for bit."""
+    from deeppreconditioning_amd.batch import solve_batch
+    mats = [O.poisson2d(80 + 9 * i) if i % 3 else O.unstructured_like(O.poisson3d(19 + i), seed=i) for i in range(11)]
+    systems = [D.CsrSystem.from_any(A, reorder=None) for A in mats]
+    for S in systems:
+        S.set_preconditioner(D.Jacobi())
+    rhs = [_dev(O.rhs(A.shape[0], i)) for i, A in enumerate(mats)]
+    single = [S.solve(bb) for S, bb in zip(systems, rhs)]
+    batch = solve_batch(systems, rhs)
+    for A, s1, sb, i in zip(mats, single, batch, range(11)):
+        assert 6144 < A.shape[0] <= 65536
+        assert sb.iterations == s1.iterations == CO.pcg(A, O.rhs(A.shape[0], i), "jacobi", dinv=O.jacobi_dinv(A))[1]
+        assert sb.status == 0 and sb.final_res == s1.final_res and torch.equal(sb.x, s1.x)
+    for S in systems:
+        S.close()
