@@ -551,7 +551,7 @@ extern "C" int dpcg_solve(dpcg_handle_t h, const double *b, const double *x0, do
     if (small_eligible(h, flags, x_true))
         return solve_small_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
                                seconds, res_history);
-    if (team_eligible(h, flags, x_true))
+    if ((flags & DPCG_TEAM) && team_eligible(h, flags, x_true))      // a single team: on request only (it trails the multi-launch path)
         return solve_team_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
                               seconds, res_history);
     Solve sv;
@@ -641,7 +641,7 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
     }
     bool all_team = true;
     for (int i = 0; i < count; ++i) all_team = all_team && team_eligible(handles[i], flags, nullptr);
-    if (all_team) {
+    if (all_team && (count >= 3 || (flags & DPCG_TEAM))) {
         // up to eight systems per launch, one team (normally: one XCD) each; the launches follow one another
         struct TeamScratch {
             TeamDesc *descs = nullptr;

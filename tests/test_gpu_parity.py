@@ -954,7 +954,7 @@ def test_solve_batch_general_path_interleaves_streams(D):
         b = _dev(O.rhs(A.shape[0], i))
         systems.append(S)
         rhs_list.append(b)
-        single.append(S.solve(b, flags=D._lib.NO_SMALL))
+        single.append(S.solve(b, flags=D._lib.NO_SMALL | D._lib.NO_TEAM))
     for n_streams in (1, 3, 8):
         out = solve_batch(systems, rhs_list, n_streams=n_streams)
         for s, o, A in zip(single, out, mats):
@@ -1185,7 +1185,7 @@ def test_last_x_update_survives_multi_stream_contention(D, form):
     it sees `done` early, or the last increment is applied twice), 8 streams, 100 rounds, a GEMM stream running beside
     them: every x must be bit-identical to the one-at-a-time solve and match the C oracle."""
     from deeppreconditioning_amd.batch import solve_batch
-    flags = D._lib.NO_SMALL | (D._lib.NO_FUSE if form == "three_kernel" else 0)
+    flags = D._lib.NO_SMALL | D._lib.NO_TEAM | (D._lib.NO_FUSE if form == "three_kernel" else 0)      # the multi-launch forms
     mats = [O.poisson2d(96 + 2 * i) for i in range(32)]                         # 9 216 ... 24 964 rows
     systems = [D.CsrSystem.from_any(A) for A in mats]
     for S in systems:
@@ -1971,9 +1971,9 @@ def test_ic0_in_multicolour_order(D, name, make, reorder, colors):
                                        ("poisson3d_33", lambda: O.poisson3d(33)),
                                        ("unstructured2d_150", lambda: O.unstructured_like(O.poisson2d(150), seed=4))])
 def test_team_kernel_matches_multi_launch_path_and_oracle(D, name, make):
-    """6 145 .. 65 536 rows, M = I / Jacobi: the one-launch team solve against oracle/pcg_oracle.c (counts equal, history
-    within 1e-10, x) and against the multi-launch path (DPCG_NO_TEAM): x0, max_iter caps, both stopping tests, and the
-    breakdown status.  The team path must be the one that ran (seconds of a 65 536-row solve give it away: see bench)."""
+    """6 145 .. 65 536 rows, M = I / Jacobi: the one-launch team solve (DPCG_TEAM forces it for a single system; batches of
+    three or more take it by themselves) against oracle/pcg_oracle.c (counts equal, history within 1e-10, x) and against the
+    multi-launch path: x0, max_iter caps, both stopping tests, and the breakdown status."""
     A = make()
     n = A.shape[0]
     assert 6144 < n <= 65536
@@ -1981,28 +1981,29 @@ def test_team_kernel_matches_multi_launch_path_and_oracle(D, name, make):
     S = D.CsrSystem.from_any(A, reorder=None)
     for kind, pc, okw in (("jacobi", D.Jacobi(), dict(dinv=O.jacobi_dinv(A))), ("none", None, {})):
         S.set_preconditioner(pc)
-        team = S.solve(_dev(b))
-        multi = S.solve(_dev(b), flags=D._lib.NO_TEAM)
+        team = S.solve(_dev(b), flags=D._lib.TEAM)
+        multi = S.solve(_dev(b))
         _, it, hist, x = CO.pcg(A, b, kind, **okw)
         assert team.iterations == multi.iterations == it and team.status == multi.status == 0
         np.testing.assert_allclose(team.res_history, hist, rtol=HIST_RTOL)
         np.testing.assert_allclose(multi.res_history, hist, rtol=HIST_RTOL)
         np.testing.assert_allclose(team.x.cpu().numpy(), x, rtol=1e-9, atol=1e-12)
-        again = S.solve(_dev(b))
+        again = S.solve(_dev(b), flags=D._lib.TEAM)
         assert np.array_equal(again.res_history, team.res_history) and torch.equal(again.x, team.x)   # reproducible to the bit
+        assert not np.array_equal(team.res_history, multi.res_history)        # (another summation order: it WAS the other path)
     x0 = O.rhs(n, 7)
     S.set_preconditioner(D.Jacobi())
     for max_iter in (0, 1, 25):
-        r = S.solve(_dev(b), _dev(x0), max_iter=max_iter)
+        r = S.solve(_dev(b), _dev(x0), max_iter=max_iter, flags=D._lib.TEAM)
         _, it, hist, x = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A), x0=x0, max_iter=max_iter)
         assert r.iterations == it and r.status == 1
         np.testing.assert_allclose(r.res_history, hist, rtol=HIST_RTOL)
         np.testing.assert_allclose(r.x.cpu().numpy(), x, rtol=1e-9, atol=1e-12)
-    r = S.solve(_dev(b), flags=D._lib.INIT_CHECK_R, rtol_sq=1e-6)
+    r = S.solve(_dev(b), flags=D._lib.INIT_CHECK_R | D._lib.TEAM, rtol_sq=1e-6)
     _, it, hist, _ = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A), rtol=1e-6, init_check="r")
     assert r.iterations == it
     np.testing.assert_allclose(r.res_history, hist, rtol=HIST_RTOL)
-    rz = S.solve(_dev(np.zeros(n)))                        # b = 0: <b,b> = 0 -> 0/0 -> breakdown, as on every other path
+    rz = S.solve(_dev(np.zeros(n)), flags=D._lib.TEAM)     # b = 0: <b,b> = 0 -> 0/0 -> breakdown, as on every other path
     assert rz.status == 2 and rz.iterations == 0
     S.close()
 
@@ -2016,7 +2017,7 @@ def test_team_kernel_batches_of_systems(D):
     for S in systems:
         S.set_preconditioner(D.Jacobi())
     rhs = [_dev(O.rhs(A.shape[0], i)) for i, A in enumerate(mats)]
-    single = [S.solve(bb) for S, bb in zip(systems, rhs)]
+    single = [S.solve(bb, flags=D._lib.TEAM) for S, bb in zip(systems, rhs)]
     batch = solve_batch(systems, rhs)
     for A, s1, sb, i in zip(mats, single, batch, range(11)):
         assert 6144 < A.shape[0] <= 65536

@@ -80,7 +80,12 @@ for g in range(groups):
     max_iter = int(rng.choice([40, 200, 1024]))
     # a mixed batch runs every system through the general (multi-kernel) path, a one-at-a-time solve of a small system would
     # take the whole-solve kernel (other reduction orders: equal to ~1e-15, not to the bit): compare like with like
+    # (the same for the team kernel of mid-size systems: forced for both runs when every system of the group is eligible,
+    # forbidden for both otherwise)
     flags = int(rng.choice([0, 0, D._lib.NO_FUSE, D._lib.NO_GRAPH])) | D._lib.NO_SMALL
+    team_ok = all(6144 < S.n <= 65536 and not S.reordered and S.info()["precond"] in (0, 1) and S.info()["spmv_kernel"] != "vector"
+                  for S in systems) and not (flags & D._lib.NO_FUSE)
+    flags |= D._lib.TEAM if (team_ok and rng.integers(0, 2)) else D._lib.NO_TEAM
     single = [S.solve(b, max_iter=max_iter, flags=flags, want_history=False) for S, b in zip(systems, rhs)]
     for rep in range(4):
         with torch.cuda.stream(side):

@@ -12,7 +12,7 @@ for dim, n in ((2, 100), (2, 256), (3, 40)):
     s = poisson.poisson_system(dim, n)
     s.set_preconditioner(D.Jacobi())
     b = poisson.rhs(s.n, 0)
-    for label, flags in (("team", 0), ("multi-launch", D._lib.NO_TEAM)):
+    for label, flags in (("team", D._lib.TEAM), ("multi-launch", D._lib.NO_TEAM)):
         s.solve(b, want_history=False, flags=flags)
         best = None
         for _ in range(5):
