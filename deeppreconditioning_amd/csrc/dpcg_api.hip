@@ -176,6 +176,12 @@ int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s, bool allow_tile) {
     int h_max = 0;
     DPCG_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
+    if (A.n <= 65536) {                                  // (only the team kernel of mid-size systems asks)
+        DPCG_HIP(hipMemsetAsync(d_max, 0, sizeof(int), s));
+        launch_max_row_len((int)A.n, A.rowptr, d_max, s);
+        DPCG_HIP(hipMemcpyAsync(&plan.max_row_len, d_max, sizeof(int), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+    }
     dev_free(d_max);
     const char *force = getenv("DPCG_SPMV_KERNEL");
     const bool force_vector = force && strcmp(force, "vector") == 0;

@@ -52,6 +52,7 @@ struct SpmvPlan {
     uint16_t *tile_lidx = nullptr;     // [nnz]
     int tile_max_chunks = 0;           // largest chunk count of any block (sizes the dynamic LDS)
     bool stream_nt = false;            // x-tile kernel: once-read streams and y non-temporal (streams beyond the Infinity Cache)
+    int max_row_len = 0;               // longest row (the team kernel keeps rows of <= 7 entries in registers)
 };
 
 // Device-resident scalar state of one solve.  Only block 0 of a kernel writes it; everybody else
@@ -337,7 +338,7 @@ struct TeamDesc {
     const double *ell_val;
     const double *b, *x0;
     double *x, *hist;
-    double *p;                 // n doubles: the direction vector as the other workgroups see it
+    double *z, *p0, *p1;       // n doubles each: z_k and p_k / p_{k-1} (double-buffered) as the other workgroups see them
     double rtol_sq, atol_sq;
     Scalars *out;
     unsigned int *bar;         // the team's barrier counter (zero at launch)
@@ -346,7 +347,8 @@ struct TeamDesc {
 };
 
 int team_max_rows();
-int launch_pcg_team(const TeamDesc *descs_dev, int nsys, int max_slabs_per_wg, hipStream_t s);
+int team_max_row_len();
+int launch_pcg_team(const TeamDesc *descs_dev, int nsys, int max_slabs_per_wg, int max_row_len, hipStream_t s);
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
                       hipStream_t s, const double *colnorm = nullptr, double tau = 0.0);   // colnorm: ICT drop rule
 void launch_colnorm1(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, double *c, hipStream_t s);

