@@ -342,7 +342,7 @@ struct TeamDesc {
     double rtol_sq, atol_sq;
     Scalars *out;
     unsigned int *bar;         // the team's barrier counter (zero at launch)
-    double *part;              // 4 * kTeamSize doubles: slots 0 <p,Ap> (and <b,b>), 1 <r,z>, 2 <r,r>, 3 scratch
+    double *part;              // 3 sets x 2 x kTeamSize doubles, all preset to the "pending" pattern at launch
     int *err;
 };
 

@@ -469,7 +469,7 @@ static int ensure_team(dpcg_system *h, hipStream_t s) {
         DPCG_TRY(dev_alloc(&h->p2, h->A.n));
         drop_graph(h);
     }
-    if (!h->team_part) DPCG_TRY(dev_alloc(&h->team_part, 4 * 32));
+    if (!h->team_part) DPCG_TRY(dev_alloc(&h->team_part, 3 * 2 * 32));
     if (!h->team_sync) DPCG_TRY(dev_alloc(&h->team_sync, 2));
     return DPCG_OK;
 }
@@ -516,6 +516,7 @@ static int solve_team_one(dpcg_system *h, const double *b, const double *x0, dou
     const TeamDesc d = make_team_desc(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags);
     DPCG_HIP(hipMemcpyAsync(h->team_desc, &d, sizeof(d), hipMemcpyHostToDevice, s));
     DPCG_HIP(hipMemsetAsync(h->team_sync, 0, 2 * sizeof(unsigned int), s));
+    launch_fill_pending(h->team_part, 3 * 2 * 32, s);                                // every reduction slot: "not written yet"
     DPCG_HIP(hipStreamSynchronize(s));
     const auto t0 = std::chrono::steady_clock::now();                                // cg.py:69 (the launch is the loop)
     DPCG_TRY(launch_pcg_team(static_cast<const TeamDesc *>(h->team_desc), 1, team_slabs_per_wg(h->A.n), h->ell_a.W, s));
@@ -667,6 +668,7 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
                 descs[i] = make_team_desc(hi, b[g0 + i], x0 ? x0[g0 + i] : nullptr, x ? x[g0 + i] : nullptr, rtol_sq, atol_sq,
                                           max_iter, flags);
                 DPCG_HIP(hipMemsetAsync(hi->team_sync, 0, 2 * sizeof(unsigned int), nullptr));
+                launch_fill_pending(hi->team_part, 3 * 2 * 32, nullptr);
                 slabs = std::max(slabs, team_slabs_per_wg(hi->A.n));
                 wmax = std::max(wmax, hi->ell_a.W);
             }

@@ -14,7 +14,10 @@
 //   * TWO team barriers per update (<p,Ap> partials | z, p published and <r,z>, <r,r> partials): the entries of p_k that a
 //     row gathers are recomputed as z_k[c] + beta p_{k-1}[c] from the published vectors (the owner's expression and bits), so
 //     publishing needs no barrier of its own; the matrix slice of a workgroup (rows of <= 7 entries) is read ONCE, into LDS.
-//     A barrier is one agent-scope
+//     The reductions double as the barriers: a workgroup's partial is ONE 8-byte agent-scope store into a slot that held a
+//     reserved NaN pattern, and wave 0 of every workgroup polls the 2 x 32 slots themselves -- no counter, no atomic, no second
+//     round trip for the values (three slot sets rotate; a workgroup re-arms the next set as it writes).  Only the x0 path uses
+//     the counter barrier: one agent-scope
 //     atomic add per workgroup on the team's counter after every wave has drained its stores (s_waitcnt vmcnt(0)), then a
 //     relaxed agent-scope poll by one lane; all shared data (p, the 32 partials per reduction) is stored and loaded with
 //     agent scope (sc1: served by the L2, never by a stale L1 line).  Reductions are two-stage and ordered (wave DPP tree
@@ -37,6 +40,7 @@ constexpr int kTeamMaxSlabs = 2;       // 1024-row slabs per workgroup: n <= 32 
 namespace {
 
 constexpr unsigned long long kTeamSpinTicks = 4ull * 100000000ull;     // 4 s of the 100 MHz constant clock
+constexpr unsigned long long kTeamPending = 0x7ff8dead0badbeefULL;     // a quiet NaN that no arithmetic here produces: "slot not written yet"
 
 __device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent(const double *p) {
@@ -146,20 +150,49 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
             q[k] = acc;
         }
     };
-    // two team-wide sums at once: slots s0, s1 of d.part; every workgroup returns the same bits
-    auto team_sum2 = [&](double a, double b2, int s0, int s1, double &ra, double &rb) -> bool {
-        a = team_block_sum(a, sh);
+    // Two team-wide sums at once, and a team barrier in the same breath.  The 2 x 32 partials ARE the flags: a slot holds a
+    // reserved NaN pattern until its owner stores the value (one 8-byte agent-scope store), and the readers -- lanes 0-63 of
+    // wave 0, one slot each -- poll the slots themselves: no counter, no atomic, no second round trip to fetch the values.
+    // Three slot sets rotate (generation g uses set g % 3; writing generation g a workgroup re-arms its slots of set (g + 1) % 3,
+    // which everybody finished reading before anybody could write generation g - 1).  `publish`: the workgroup's stores of z and p
+    // must be visible to whoever passes this point, so every wave drains them first.  Every workgroup returns the same bits.
+    unsigned int gen = 0;
+    auto team_sum2 = [&](double a, double b2, bool publish, double &ra, double &rb) -> bool {
+        if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        a = team_block_sum(a, sh);                                 // (two workgroup barriers inside: behind every wave's drain)
         b2 = team_block_sum(b2, sh);
+        const double pend = __longlong_as_double((long long)kTeamPending);
+        double *cur = d.part + (gen % 3) * (2 * kTeamSize), *nxt = d.part + ((gen + 1) % 3) * (2 * kTeamSize);
+        ++gen;
         if (t == 0) {
-            st_agent(d.part + s0 * kTeamSize + rank, a);
-            st_agent(d.part + s1 * kTeamSize + rank, b2);
+            st_agent(nxt + rank, pend);
+            st_agent(nxt + kTeamSize + rank, pend);
+            st_agent(cur + rank, a);
+            st_agent(cur + kTeamSize + rank, b2);
         }
-        if (!team_barrier(d.bar, target, d.err, &s_flag)) return false;
-        if (t < kTeamSize) {
-            s_part[t] = ld_agent(d.part + s0 * kTeamSize + t);
-            s_part[kTeamSize + t] = ld_agent(d.part + s1 * kTeamSize + t);
+        if (t < 2 * kTeamSize) {                                  // wave 0: lane l polls slot l
+            double v = ld_agent(cur + t);
+            unsigned spins = 0;
+            unsigned long long t0 = 0;
+            int ok = 1;
+            while (__ballot((unsigned long long)__double_as_longlong(v) == kTeamPending) != 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((unsigned long long)__double_as_longlong(v) == kTeamPending) v = ld_agent(cur + t);
+                if ((++spins & 1023u) == 0) {
+                    const unsigned long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    else if (now - t0 > kTeamSpinTicks || __hip_atomic_load(d.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        atomicExch(d.err, 1);
+                        ok = 0;
+                        break;
+                    }
+                }
+            }
+            s_part[t] = v;
+            if (t == 0) s_flag = ok;
         }
         __syncthreads();
+        if (!s_flag) return false;
         ra = rb = 0.0;
 #pragma unroll
         for (int w = 0; w < kTeamSize; ++w) {
@@ -208,10 +241,8 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
         }
     }
     double bb = 0.0, dummy = 0.0, rz = 0.0, tt = 0.0;
-    // (a slot is written again only after a barrier that every workgroup reaches AFTER its reads of the slot; the
-    // second operand of a one-value sum goes to slot 3, which nobody looks at)
-    if (alive) alive = team_sum2(bb_loc, rz_loc, 0, 1, bb, rz);
-    if (alive) alive = team_sum2(t0_loc, 0.0, 2, 3, tt, dummy);
+    if (alive) alive = team_sum2(bb_loc, rz_loc, true, bb, rz);    // z_0 and p_{-1} = 0 are published behind this point
+    if (alive) alive = team_sum2(t0_loc, 0.0, false, tt, dummy);
     double res = tt / bb, beta = 0.0;
     int k_done = 0, status = DPCG_MAX_ITER;
     bool stop = false;
@@ -231,7 +262,7 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
         for (int k = 0; k < RPT; ++k)
             if (row[k] >= 0) pq_loc += q[k] * p[k];
         double pq = 0.0;
-        if (!(alive = team_sum2(pq_loc, 0.0, 0, 3, pq, dummy))) break;      // barrier A: every SpMV of this update is done
+        if (!(alive = team_sum2(pq_loc, 0.0, false, pq, dummy))) break;     // barrier A: every SpMV of this update is done
         const double alpha = rz / pq;                             // cg.py:78
         double rz_new_loc = 0.0, rr_loc = 0.0;
 #pragma unroll
@@ -247,7 +278,7 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
             }
         }
         double rz_new = 0.0, rr = 0.0;
-        if (!(alive = team_sum2(rz_new_loc, rr_loc, 1, 2, rz_new, rr))) break;   // barrier B: z, p published and <r,z>, <r,r> known
+        if (!(alive = team_sum2(rz_new_loc, rr_loc, true, rz_new, rr))) break;   // barrier B: z, p published and <r,z>, <r,r> known
         beta = rz_new / rz;                                       // cg.py:82
 #pragma unroll
         for (int k = 0; k < RPT; ++k) p[k] = z[k] + beta * p[k];  // cg.py:83
