@@ -530,18 +530,24 @@ def extra_workloads(D, poisson, torch) -> dict:
         for sy in group:
             sy.set_preconditioner(D.Jacobi())
         rhs_c = [poisson.rhs(sy.n, i) for i, sy in enumerate(group)]
-        solve_batch(group, rhs_c, n_streams=4, flags=D._lib.NO_SMALL)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        res_c = solve_batch(group, rhs_c, n_streams=4, flags=D._lib.NO_SMALL)
-        torch.cuda.synchronize()
-        dt_c = time.perf_counter() - t0
+        entry = {}
+        # multi-launch path interleaved on 4 streams; for the mid-size systems also the default of a batch: one launch, one
+        # team of 32 workgroups per system (dpcg_team.hip)
+        for tag, fl in (("interleaved_4_streams", D._lib.NO_SMALL | D._lib.NO_TEAM), ("default_batch", 0)):
+            solve_batch(group, rhs_c, n_streams=4, flags=fl)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res_c = solve_batch(group, rhs_c, n_streams=4, flags=fl)
+            torch.cuda.synchronize()
+            dt_c = time.perf_counter() - t0
+            entry[f"iterations_per_s_{tag}"] = round(sum(r.iterations for r in res_c) / dt_c, 1)
+        entry["default_batch_is"] = "team kernel (one launch)" if group[0].n <= 65536 else "multi-launch path, interleaved"
         t0 = time.perf_counter()
         seq_its = sum(sy.solve(b_c, want_history=False, flags=D._lib.NO_SMALL).iterations for sy, b_c in zip(group, rhs_c))
         torch.cuda.synchronize()
         dt_s = time.perf_counter() - t0
-        conc[label] = {"iterations_per_s_interleaved_4_streams": round(sum(r.iterations for r in res_c) / dt_c, 1),
-                       "iterations_per_s_one_after_another": round(seq_its / dt_s, 1)}
+        entry["iterations_per_s_one_after_another"] = round(seq_its / dt_s, 1)
+        conc[label] = entry
         for sy in group:
             sy.close()
         del group, rhs_c

@@ -13,7 +13,8 @@ from deeppreconditioning_amd import poisson  # noqa: E402
 torch.cuda.set_device(0)
 A = poisson.unstructured_like_csr(3, 100, 0)
 s = D.CsrSystem.from_any(A)
-s.set_preconditioner(D.IC0("solve"))
+# `multicolor`: IC(0) of the same system in multicolour order (2 levels: colour-sweep kernels) instead of the caller's order
+s.set_preconditioner(D.IC0("solve", ordering="multicolor") if "multicolor" in sys.argv[1:] else D.IC0("solve"))
 b = poisson.rhs(s.n, 0)
 s.solve(b, max_iter=4, want_history=False)
 s.solve(b, max_iter=24, want_history=False, flags=D._lib.NO_GRAPH)
