@@ -410,10 +410,11 @@ def extra_workloads(D, poisson, torch) -> dict:
         torch.cuda.synchronize()
         setup_ms = (time.perf_counter() - t0) * 1e3
         apply_us = time_apply(s_t, b_t, torch)
+        n_colors = s_t.precond_ordering()[0]
         r = solve_twice(s_t, b_t)
         s_t.set_preconditioner(D.Jacobi())
         rj = solve_twice(s_t, b_t)
-        trsv[f"poisson3d_{n3}_multicolor"] = {"colors": s_t.precond_ordering()[0], "setup_ms": round(setup_ms, 2),
+        trsv[f"poisson3d_{n3}_multicolor"] = {"colors": n_colors, "setup_ms": round(setup_ms, 2),
                                               "apply_us": round(apply_us, 1), "pcg_iterations": r.iterations,
                                               "pcg_us_per_update": round(r.seconds / r.iterations * 1e6, 1),
                                               "pcg_ms": round(r.seconds * 1e3, 3), "jacobi_pcg_ms": round(rj.seconds * 1e3, 3),

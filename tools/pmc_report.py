@@ -17,6 +17,7 @@ import pathlib
 import sys
 
 fetch_dir, write_dir, rdreq_dir, tag = sys.argv[1:5]
+source = sys.argv[5] if len(sys.argv) > 5 else f"rocprofv3 --pmc passes of tools/pmc_run.py ({tag}); corrected as profiles/{tag}_pmc_summary.md states"
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 SYSTEMS = [("3d_100", 1000000, 6940000), ("2d_1024", 1048576, 5238784), ("3d_256", 256 ** 3, 7 * 256 ** 3 - 6 * 256 ** 2),
            ("3d_256_f32_create", 256 ** 3, 7 * 256 ** 3 - 6 * 256 ** 2),
@@ -69,7 +70,7 @@ for k, seg, what, rd, wr in cal:
 lines += ["", "## SpMV + <p,Ap> kernel of the PCG loop (k_spmv_tile: the plan picks the x-tile kernel for all three systems): bytes per launch", "",
           "| system | algorithmic MB (nnz*12 + (n+1)*4 + 16n) | read MB = 2 x FETCH_SIZE x 1024 | read MB from RDREQ sizes | write MB | traffic MB | traffic / algorithmic |",
           "|---|---|---|---|---|---|---|"]
-traffic = {}
+traffic = {"_source": source}           # bench.py reports it as roofline.traffic_source
 for seg in SPMV_ROWS:
     name, n, nnz = SYSTEMS[seg]
     alg = nnz * 12 + (n + 1) * 4 + 16 * n
