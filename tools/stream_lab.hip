@@ -136,5 +136,12 @@ int main() {
     for (int g : {2048, 4096}) { RATIO(4, 2, false, false, g, n2 * 3); RATIO(4, 4, false, false, g, n2 * 3); }
     RATIO(4, 2, false, true, 2048, n2 * 3);
     STREAMS(3, 2, false, 2048, n2 * 4);
+    // cache-resident footprints (the 1M-DoF systems: ~100-150 MB per kernel, inside the 256 MiB Infinity Cache)
+    printf("-- Infinity-Cache-resident footprints --\n");
+    for (int g : {1536, 2048, 4096}) { RATIO(11, 1, true, false, g, n2 / 16); RATIO(11, 2, true, false, g, n2 / 16); }   // 88 MiB in, 8 MiB out
+    RATIO(11, 2, true, true, 2048, n2 / 16);
+    for (int g : {512, 1024, 2048}) { RATIO(2, 2, true, false, g, n2 / 16); RATIO(2, 4, true, false, g, n2 / 16); }     // K2/K3-like: 16 + 8 MiB
+    for (int g : {512, 1024, 2048}) { RATIO(4, 2, false, false, g, n2 / 16); }                                          // read only 32 MiB
+    RATIO(1, 4, true, false, 2048, n2 / 2);                                                                            // copy 64 + 64 MiB
     return 0;
 }
