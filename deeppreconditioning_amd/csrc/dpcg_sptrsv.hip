@@ -457,6 +457,11 @@ __global__ __launch_bounds__(kBlock) void k_fill_pending(const int32_t *__restri
 // earlier tickets, so the no-deadlock argument is unchanged), and the exit count is read off the ticket itself: every
 // workgroup draws exactly one ticket past the end, and the one that draws the LAST of those zeroes the word for the next
 // launch.  Atomics per solve: tickets + workgroups.
+// Two more variants measured on the scrambled 1M-DoF IC(0) factor (19 levels; 132.5 us per apply as is) and dropped: two / four
+// rows per LANE polled in one loop (half / a quarter of the tickets): 176 / 271 us; a second ticket per workgroup whose
+// records are loaded while the current block polls, the third drawn meanwhile (ticket and record latency off the chain):
+// 138 us.  Neither the tickets nor the per-block load latency bound that solve: its two kernels move 2 x 112 MB of records
+// (about 2 x 28 us at the rate the colour sweeps reach) and pay ~1.1 us for each of the 19 hand-offs.
 template <bool UPPER, int BS, int W, int SUB = 1>   // BS rows (= threads) per block, SUB blocks per ticket, records of width W
 __global__ __launch_bounds__(BS) void k_sptrsv_syncfree_rec(int j0, int count, const int32_t *__restrict__ lo_rp,
                                                             const int32_t *__restrict__ lo_ci,
