@@ -299,6 +299,33 @@ __global__ __launch_bounds__(kBlock) void k_max_band(int64_t n, const int32_t *_
     }
 }
 
+// Can IC(0) on this lower pattern (diagonal last in a row) run as a recurrence on the diagonals alone?  flags |= 1: two
+// off-diagonal entries (i, a), (i, b), a < b, of some row are joined by an entry (b, a) -- a cross term L_ia * L_ba in
+// the update of L_ib; flags |= 2: a row with more than three off-diagonal entries (longer than a strip record).
+__global__ __launch_bounds__(kBlock) void k_ic0_cross_terms(int64_t n, const int32_t *__restrict__ rp,
+                                                            const int32_t *__restrict__ ci, int *flags) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int f = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const int a = rp[i], b = rp[i + 1] - 1;               // off-diagonals [a, b)
+        if (b - a > 3) f |= 2;
+        for (int q = a + 1; q < b; ++q) {
+            const int cq = ci[q];
+            const int sa = rp[cq], sb = rp[cq + 1] - 1;
+            for (int p = a; p < q; ++p) {
+                const int cp = ci[p];
+                for (int k = sa; k < sb; ++k)
+                    if (ci[k] == cp) f |= 1;
+            }
+        }
+    }
+    if (f) atomicOr(flags, f);
+}
+
+void launch_ic0_cross_terms(int64_t n, const int32_t *rp, const int32_t *ci, int *flags_zeroed, hipStream_t s) {
+    hipLaunchKernelGGL(k_ic0_cross_terms, dim3(grid_rows(n, 1024)), dim3(kBlock), 0, s, n, rp, ci, flags_zeroed);
+}
+
 void launch_max_band(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int *out_dev, hipStream_t s) {
     hipLaunchKernelGGL(k_max_band, dim3(grid_rows(n, 1024)), dim3(kBlock), 0, s, n, rp, ci, upper ? 1 : 0, out_dev);
 }

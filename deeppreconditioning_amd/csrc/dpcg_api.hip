@@ -292,6 +292,7 @@ extern "C" int dpcg_create(dpcg_handle_t *out, int64_t n, int64_t nnz, const int
         return DPCG_ERR_HIP;
     }
     hipStream_t s = (hipStream_t)stream;
+    SetupScope scope(s);
     dpcg_system *h = new dpcg_system();
     int st = upload_csr(h->A, n, nnz, rowptr, col, val, val_dtype, memspace, copy, s);
     if (st >= 0) st = make_plan(h->A, h->planA, s, true);
@@ -314,7 +315,7 @@ extern "C" int dpcg_create(dpcg_handle_t *out, int64_t n, int64_t nnz, const int
 
 extern "C" int dpcg_destroy(dpcg_handle_t h) {
     if (!h) return DPCG_OK;
-    (void)hipDeviceSynchronize();
+    SetupScope scope(nullptr, true);                      // (waits for the device: the arrays may be in use on any stream)
     free_precond(h);
     free_csr(h->A);
     free_csr(h->A_user);
@@ -346,6 +347,7 @@ extern "C" int dpcg_reorder(dpcg_handle_t h, int mode, dpcg_stream_t stream, int
     if (mode == DPCG_REORDER_NONE || h->perm) return DPCG_OK;
     if (mode != DPCG_REORDER_AUTO && mode != DPCG_REORDER_ALWAYS) return invalid("dpcg_reorder: bad mode");
     hipStream_t s = (hipStream_t)stream;
+    SetupScope scope(s, true);
     if (mode == DPCG_REORDER_AUTO) {
         // only where it pays: systems beyond one XCD's L2 reach whose plan is the gather kernel (no x-tile plan, or too
         // few row blocks for one) and whose gather really is scattered (measured 64^3 scrambled: 31K -> 55K it/s)
@@ -434,6 +436,7 @@ extern "C" int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spm
                        (h->planA.kernel == SPMV_TILE && h->planA.stream_nt ? 32 : 0);
     if (precond_kind) *precond_kind = h->precond;
     if (precond_nnz) *precond_nnz = h->precond == DPCG_PRECOND_CSR ? h->M.nnz : h->L.nnz;
+    if ((n_levels_lower || n_levels_upper) && h->lvlL.n_levels < 0) DPCG_TRY(count_levels_on_demand(h));
     if (n_levels_lower) *n_levels_lower = h->lvlL.n_levels;
     if (n_levels_upper) *n_levels_upper = h->lvlU.n_levels;
     return DPCG_OK;

@@ -51,7 +51,7 @@ __global__ void k_emit_unique(int64_t nnz, const uint64_t *__restrict__ keys, co
 template <typename T>
 int alloc(T **p, int64_t count) {
     *p = nullptr;
-    if (hipMalloc((void **)p, (size_t)(count > 0 ? count : 1) * sizeof(T)) != hipSuccess) {
+    if (cached_alloc((void **)p, (size_t)(count > 0 ? count : 1) * sizeof(T)) != hipSuccess) {
         set_error("dpcg_coo_to_csr: hipMalloc failed");
         return DPCG_ERR_NOMEM;
     }
@@ -72,6 +72,7 @@ extern "C" int dpcg_coo_to_csr(int64_t n, int64_t nnz, const int32_t *rows, cons
         return DPCG_ERR_INVALID;
     }
     hipStream_t s = (hipStream_t)stream;
+    SetupScope scope(s);
     uint64_t *keys = nullptr, *keys_sorted = nullptr;
     int32_t *perm = nullptr, *perm_sorted = nullptr, *head = nullptr, *pos = nullptr, *row_count = nullptr;
     int *bad = nullptr;
@@ -79,7 +80,7 @@ extern "C" int dpcg_coo_to_csr(int64_t n, int64_t nnz, const int32_t *rows, cons
     auto cleanup = [&]() {
         for (void *p : {(void *)keys, (void *)keys_sorted, (void *)perm, (void *)perm_sorted, (void *)head, (void *)pos,
                         (void *)row_count, (void *)bad})
-            if (p) (void)hipFree(p);
+            if (p) cached_free(p);
     };
 #define COO_TRY(expr)            \
     do {                         \

@@ -26,7 +26,7 @@ template <typename T>
 inline int dev_alloc(T **p, int64_t count) {
     *p = nullptr;
     if (count <= 0) count = 1;
-    hipError_t e = hipMalloc((void **)p, (size_t)count * sizeof(T));
+    hipError_t e = cached_alloc((void **)p, (size_t)count * sizeof(T));
     if (e != hipSuccess) {
         set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? DPCG_ERR_NOMEM : DPCG_ERR_HIP;
@@ -36,12 +36,13 @@ inline int dev_alloc(T **p, int64_t count) {
 
 template <typename T>
 inline void dev_free(T *&p) {
-    if (p) (void)hipFree(p);
+    if (p) cached_free(p);
     p = nullptr;
 }
 
 void free_csr(CsrDev &c);
 void free_levels(Levels &l);
+int count_levels_on_demand(dpcg_system *h);   // dpcg_precond.hip
 void free_plan(SpmvPlan &plan);
 void free_ell(SmallEll &e);
 int grid_for(int64_t n);

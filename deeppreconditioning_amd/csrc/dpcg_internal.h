@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -132,7 +133,7 @@ struct Levels {
     // Strip-pipelined solve (k_sptrsv_strips): the rows once more, sorted by (strip, strip-local level, row), with their
     // own level offsets (n_strips * nlev + 1 entries), level-ordered factor copy and records.  n_strips == 0: not used.
     struct Strips {
-        int n_strips = 0, nlev = 0, W = 0, ring_reach = 0, threads = 0, rows_per_thread = 1;
+        int n_strips = 0, nlev = 0, W = 0, ring_reach = 0, threads = 0, rows_per_thread = 1, long_rows = 0;
         int32_t *rows = nullptr, *level_ptr_dev = nullptr, *lo_rowptr = nullptr, *lo_col = nullptr, *lo_cpos = nullptr;
         double *lo_val = nullptr, *val = nullptr, *b_lo = nullptr;
         int32_t *meta = nullptr;
@@ -230,6 +231,24 @@ namespace dpcg {
 
 // ---- error plumbing ------------------------------------------------------------------------
 void set_error(const std::string &msg);
+// ---- device memory with a block cache (dpcg_mem.hip) ----
+hipError_t cached_alloc(void **out, size_t bytes);
+void cached_free(void *p);
+void release_cached_memory();
+size_t cached_memory_bytes();
+// Opened by the ABI entry points that build something on a stream: blocks freed inside are reusable at once by the same
+// scope (one stream: ordered), and go to the process-wide pool when the scope ends -- after the stream has been waited
+// for, so a setup call's results are complete when it returns.  wait_for_device: the blocks about to be freed may be in
+// use on other streams (dpcg_destroy).
+struct SetupScope {
+    hipStream_t stream;
+    bool owner = false;
+    std::multimap<size_t, void *> idle;
+    explicit SetupScope(hipStream_t s, bool wait_for_device = false);
+    ~SetupScope();
+    SetupScope(const SetupScope &) = delete;
+    SetupScope &operator=(const SetupScope &) = delete;
+};
 int hip_fail(hipError_t e, const char *what, const char *file, int line);
 #define DPCG_HIP(call)                                                         \
     do {                                                                       \
@@ -314,6 +333,10 @@ void launch_record_err(const Scalars *scal, const double *part, int n_part, doub
 void launch_dot_final(const double *part, int n_part, double *out_dev, hipStream_t s);
 
 void init_strip_kernels();
+// IC(0) through a strip plan (dpcg_sptrsv.hip: k_sptrsv_strips<..., FACTOR>)
+void launch_strip_factor(const Levels &lv, double *diag, double *fac, int64_t n, hipStream_t s);
+void launch_strip_factor_scatter(int64_t n, const int32_t *frow, const int32_t *rp, const double *fac, double *fval,
+                                 const int32_t *lo_rp, double *lo_val, int *bad, hipStream_t s);
 // done: optional device flag (Scalars::done); when set the kernels return at once
 void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *rhs, double *out, hipStream_t s,
                    const int *done = nullptr, SptrsvIo *io = nullptr);
@@ -392,6 +415,7 @@ void launch_strip_records(int64_t n, const uint32_t *key_of_pos, int nlev, const
                           const int32_t *lo_rp, const int32_t *lo_ci, const int32_t *lo_cp, const double *lo_v, bool upper,
                           int ring_reach, int32_t *meta, double *pv, int32_t *exported_zeroed, int *stats, hipStream_t s);
 void launch_max_band(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int *out_dev, hipStream_t s);
+void launch_ic0_cross_terms(int64_t n, const int32_t *rp, const int32_t *ci, int *flags_zeroed, hipStream_t s);
 void launch_level_keys(int64_t n, const int32_t *level, const int32_t *order_by, uint64_t *key, hipStream_t s);
 void launch_key_levels(int64_t n, const uint64_t *key_sorted, uint32_t *lvl, hipStream_t s);
 void launch_lo_lengths(int64_t n, const int32_t *rows, const int32_t *rp, int32_t *len, int32_t *pos, hipStream_t s);

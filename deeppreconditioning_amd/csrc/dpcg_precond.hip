@@ -15,12 +15,14 @@
 // ------------------------------------------------------------------------------------------------
 extern "C" int dpcg_set_precond_none(dpcg_handle_t h) {
     if (!h) return invalid("NULL handle");
+    SetupScope scope(nullptr, true);
     free_precond(h);
     return DPCG_OK;
 }
 
 extern "C" int dpcg_set_precond_callback(dpcg_handle_t h, dpcg_precond_fn fn, void *user) {
     if (!h || !fn) return invalid("dpcg_set_precond_callback: NULL handle or function");
+    SetupScope scope(nullptr, true);
     free_precond(h);
     h->precond_fn = fn;
     h->precond_user = user;
@@ -31,6 +33,7 @@ extern "C" int dpcg_set_precond_callback(dpcg_handle_t h, dpcg_precond_fn fn, vo
 extern "C" int dpcg_set_precond_jacobi(dpcg_handle_t h, const double *dinv, int memspace, dpcg_stream_t stream) {
     if (!h) return invalid("NULL handle");
     hipStream_t s = (hipStream_t)stream;
+    SetupScope scope(s, true);          // (the preconditioner being replaced may be in use on another stream)
     free_precond(h);
     DPCG_TRY(dev_alloc(&h->dinv, h->A.n));
     if (dinv && h->perm) {                           // the caller's numbering -> the handle's
@@ -78,6 +81,7 @@ extern "C" int dpcg_set_precond_csr(dpcg_handle_t h, int64_t nnz, const int32_t 
     if (!h) return invalid("NULL handle");
     if (nnz <= 0 || !rowptr || !col || !val) return invalid("dpcg_set_precond_csr: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    SetupScope scope(s, true);          // (the preconditioner being replaced may be in use on another stream)
     free_precond(h);
     if (h->perm) {                                   // M arrives in the caller's numbering: iterate with P M P^T
         CsrDev Mu;
@@ -471,9 +475,12 @@ bool strips_enabled() {
     return on;
 }
 
+// `levels_known` false: the global level sets have not been computed (IC(0) by strips builds the plan BEFORE anything else);
+// the plan is then tried for a banded pattern (band <= n / 32) and kept only with >= 32 strip-local levels.
+// `factor_rows` (may be null): receives the factor's row at every position (sp.rows holds the handle's index after relabelling).
 int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const int32_t *ci, const double *v, bool upper,
-                 const int32_t *relabel, hipStream_t s) {
-    if (!strips_enabled() || lv.n_levels < 64 || n < 32768) return DPCG_OK;
+                 const int32_t *relabel, hipStream_t s, bool levels_known = true, DevBuf<int32_t> *factor_rows = nullptr) {
+    if (!strips_enabled() || (levels_known && lv.n_levels < 64) || n < 32768) return DPCG_OK;
     static const int64_t target_rows = [] { const char *e = getenv("DPCG_STRIP_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)16384; }();
     if (n >= (int64_t)1 << 30) return DPCG_OK;                // bit 30 of a row index is the "published" mark
     // a factor whose whole schedule is one LDS-ring walk and that is small enough for one CU to stream keeps that walk
@@ -494,6 +501,7 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
     DPCG_HIP(hipMemcpyAsync(bands, ctl.p + 4, sizeof(bands), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
     const int32_t band = bands[0] < 1 ? 1 : bands[0], inner = bands[1] < 1 ? 1 : bands[1];
+    if (!levels_known && (int64_t)band * 32 > n) return DPCG_OK;
     // One attempt at a plan for a given strip map; leaves lv.strips.n_strips = 0 when the plan is not kept.
     auto attempt = [&](const StripMap &map, int64_t S) -> int {
         DPCG_HIP(hipMemsetAsync(level.p, 0xff, (size_t)n * sizeof(int32_t), s));
@@ -506,6 +514,7 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
         if (h_ctl[1] || h_ctl[2] < 0) return DPCG_OK;            // (cannot happen: the global analysis succeeded)
         const int nlev = h_ctl[2] + 1;
         if ((int64_t)S * nlev > (int64_t)1 << 24) return DPCG_OK;
+        if (!levels_known && nlev < 32) return DPCG_OK;
         struct Pending {                                          // the plan under construction: released unless it is kept
             Levels::Strips sp;
             bool keep = false;
@@ -540,6 +549,10 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
         launch_lo_lengths(n, sp.rows, rp, len.p, pos.p, s);
         DPCG_TRY(exclusive_scan_i32(len.p, sp.lo_rowptr, n + 1, s));
         launch_lo_copy(n, sp.rows, rp, ci, v, pos.p, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, s);
+        if (factor_rows) {
+            DPCG_TRY(factor_rows->alloc(n));
+            DPCG_HIP(hipMemcpyAsync(factor_rows->p, sp.rows, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        }
         if (relabel) {
             launch_relabel(n, relabel, sp.rows, s);
             launch_relabel(nnz, relabel, sp.lo_col, s);
@@ -566,6 +579,7 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
                         (long long)reach, width, (long long)W, (long long)external, (long long)offdiag);
             return drop();
         }
+        sp.long_rows = h_ctl[2];
         sp.n_strips = (int)S;
         sp.nlev = nlev;
         sp.W = (int)W;
@@ -653,7 +667,9 @@ int transpose_lower(const CsrDev &L, CsrDev &Lt, hipStream_t s) {
 
 // h->L holds a lower-triangular factor on the device (owned by the handle): validate it, build L^T, the SpMV plans and,
 // in solve mode, the level schedules.  `lower_levels`: level analysis of L when the caller already has it (IC(0)).
-int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels = nullptr) {
+// `lower_strips`: a kept strip plan of L (IC(0) by strips factored through it); its global level sets were never computed
+// (n_levels = -1: counted when dpcg_get_info asks).
+int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels = nullptr, Levels *lower_strips = nullptr) {
     const int64_t n = h->A.n;
     DevBuf<int32_t> flags;
     DPCG_TRY(flags.alloc(1));
@@ -684,7 +700,22 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
         DPCG_TRY(make_plan(h->Lt, h->planLt, s));
     }
     pt.mark("plans");
-    if (mode == DPCG_PRECOND_LLT_SOLVE) {
+    if (mode == DPCG_PRECOND_LLT_SOLVE && lower_strips) {
+        h->lvlL = *lower_strips;                          // (the handle owns the plan from here on)
+        *lower_strips = Levels();
+        h->lvlL.n_levels = -1;
+        h->lvlU.n_levels = -1;
+        DPCG_TRY(dev_alloc(&h->lvlU.spin_err, 1));
+        DPCG_HIP(hipMemsetAsync(h->lvlU.spin_err, 0, sizeof(int), s));
+        DPCG_TRY(build_strips(h->lvlU, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, true, fm, s, false));
+        if (h->lvlU.strips.n_strips == 0) {               // (not seen: L^T of a banded factor is banded) -- the level schedule then
+            LevelSort up;
+            dev_free(h->lvlU.spin_err);
+            DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s, fm));
+            DPCG_TRY(build_levels(h->lvlU, up, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, s, fm, true));
+        }
+        pt.mark("schedule(L^T)");
+    } else if (mode == DPCG_PRECOND_LLT_SOLVE) {
         LevelSort own, up;
         if (!lower_levels) {
             DPCG_TRY(compute_levels(n, h->L.rowptr, h->L.col, false, own, s, fm));
@@ -760,6 +791,7 @@ extern "C" int dpcg_set_precond_llt(dpcg_handle_t h, int mode, int64_t nnz, cons
     if (mode != DPCG_PRECOND_LLT_MULTIPLY && mode != DPCG_PRECOND_LLT_SOLVE) return invalid("bad LLT mode");
     if (nnz <= 0 || !rowptr || !col || !val) return invalid("dpcg_set_precond_llt: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    SetupScope scope(s, true);          // (the preconditioner being replaced may be in use on another stream)
     free_precond(h);
     // host arrays are uploaded, device arrays (a factor straight from the CNN) copied device-to-device: either way the
     // analysis below works on HBM-resident data
@@ -780,6 +812,7 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
     if (ordering == DPCG_ORDER_MULTICOLOR && mode != DPCG_PRECOND_LLT_SOLVE)
         return invalid("dpcg_set_precond_ic0_ordered: the multicolour ordering serves the triangular solves (mode LLT_SOLVE)");
     hipStream_t s = (hipStream_t)stream;
+    SetupScope scope(s, true);          // (the preconditioner being replaced may be in use on another stream)
     const int64_t n = h->A.n;
     // DPCG_ORDER_MULTICOLOR: IC(0) of Q A Q^T, Q = the handle's matrix colour by colour (dpcg_reorder.hip: multicolor_order).
     // The permuted matrix is a temporary; the factor stays in that numbering and is addressed through fmap.
@@ -829,18 +862,74 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
     PhaseTimer pt(s);
     launch_tril_copy(n, Asrc.rowptr, Asrc.col, Asrc.val, Lf.rowptr, Lf.col, Lf.val, s);
     pt.mark("tril(A)");
+    // A large banded pattern without cross terms (natural-order / RCM-ordered grids: thousands of narrow levels) is factored
+    // through the strip plan of its own pattern -- the walk the solves use, one launch -- and that plan then IS the plan of L
+    // (measured at 1024^2, 2047 levels: 10.9 ms of level-by-level launches + 3.6 ms of level analysis before).
+    Levels pre;                       // strip plan on tril(A); becomes the handle's when kept
+    auto fail2 = [&](int st2) {
+        free_levels(pre);
+        return fail(st2);
+    };
+    bool by_strips = false;
+    static const bool strip_factor_on = [] { const char *ev = getenv("DPCG_IC0_STRIPS"); return !(ev && ev[0] == '0'); }();
+    if (strip_factor_on && n > 131072 && ordering == DPCG_ORDER_CALLER) {
+        e = hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), s);
+        if (e != hipSuccess) return fail(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
+        launch_ic0_cross_terms(n, Lf.rowptr, Lf.col, reinterpret_cast<int *>(flags.p), s);
+        e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(hip_fail(e, "IC(0): pattern check", __FILE__, __LINE__));
+        if (h_flags[0] == 0) {
+            DevBuf<int32_t> frows;
+            DevBuf<double> diag, fac;
+            if ((st = dev_alloc(&pre.spin_err, 1)) < 0) return fail2(st);
+            e = hipMemsetAsync(pre.spin_err, 0, sizeof(int), s);
+            if (e != hipSuccess) return fail2(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
+            if ((st = build_strips(pre, n, Lf.nnz, Lf.rowptr, Lf.col, Lf.val, false, h->iperm, s, false, &frows)) < 0) return fail2(st);
+            if (pre.strips.n_strips > 0 && pre.strips.long_rows == 0) {
+                pt.mark("strip plan (tril A)");
+                if ((st = diag.alloc(n)) < 0 || (st = fac.alloc(4 * n)) < 0) return fail2(st);
+                launch_strip_factor(pre, diag.p, fac.p, n, s);
+                launch_strip_factor_scatter(n, frows.p, Lf.rowptr, fac.p, Lf.val, pre.strips.lo_rowptr, pre.strips.lo_val,
+                                            reinterpret_cast<int *>(flags.p) + 1, s);
+                int32_t h_spin = 0;
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess) e = hipMemcpyAsync(&h_spin, pre.spin_err, sizeof(int), hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess) e = hipStreamSynchronize(s);
+                if (e != hipSuccess) return fail2(hip_fail(e, "IC(0): numeric factorisation (strips)", __FILE__, __LINE__));
+                if (h_spin) {
+                    set_error("IC(0) by strips: a bounded wait ran out");
+                    return fail2(DPCG_ERR_HIP);
+                }
+                if (h_flags[1]) h_flags[1] = (0x7fffffff - h_flags[1]) + 1;      // (row + 1, as the level kernels report it)
+                // the records of the plan now hold L: swap the value arrays
+                std::swap(pre.strips.val, fac.p);
+                by_strips = true;
+                pt.mark("numeric IC(0) by strips");
+            } else {
+                free_levels(pre);
+            }
+        }
+        if (!by_strips) {
+            e = hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), s);
+            if (e != hipSuccess) return fail2(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
+        }
+    }
     LevelSort ls;
-    if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, ls, s, cperm ? cperm : h->iperm)) < 0) return fail(st);
-    pt.mark("levels(tril A)");
-    if ((st = numeric_incomplete_cholesky(ls, n, Lf, reinterpret_cast<int *>(flags.p) + 1, nullptr, 0.0, s)) < 0) return fail(st);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return fail(hip_fail(e, "IC(0): numeric factorisation", __FILE__, __LINE__));
-    pt.mark("numeric IC(0)");
+    if (!by_strips) {
+        if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, ls, s, cperm ? cperm : h->iperm)) < 0) return fail2(st);
+        pt.mark("levels(tril A)");
+        if ((st = numeric_incomplete_cholesky(ls, n, Lf, reinterpret_cast<int *>(flags.p) + 1, nullptr, 0.0, s)) < 0) return fail2(st);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail2(hip_fail(e, "IC(0): numeric factorisation", __FILE__, __LINE__));
+        pt.mark("numeric IC(0)");
+    }
     if (h_flags[1]) {
         set_error("IC(0): non-positive pivot at row " + std::to_string(h_flags[1] - 1));
-        return fail(DPCG_ERR_PIVOT);
+        return fail2(DPCG_ERR_PIVOT);
     }
     free_precond(h);
     free_csr(Ac);
@@ -848,9 +937,24 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
     h->fmap = cperm;                  // factor index -> handle index (null: the caller's numbering)
     h->fmap_inv = ciperm;
     h->precond_colors = n_colors;
-    st = finish_llt(h, mode, s, &ls);
+    const bool keep_plan = by_strips && mode == DPCG_PRECOND_LLT_SOLVE;
+    st = finish_llt(h, mode, s, by_strips ? nullptr : &ls, keep_plan ? &pre : nullptr);
+    free_levels(pre);                 // (multiply mode: the plan only served the factorisation)
     if (st < 0) free_precond(h);
     return st;
+}
+
+// The number of levels of a factor whose schedule never needed them (strip plans built before the level analysis): counted
+// on the first request, for dpcg_get_info.
+int count_levels_on_demand(dpcg_system *h) {
+    if (h->precond != DPCG_PRECOND_LLT_SOLVE || h->lvlL.n_levels >= 0) return DPCG_OK;
+    const int32_t *fm = h->fmap ? h->fmap : h->iperm;
+    SetupScope scope(nullptr);
+    LevelSort ls;
+    DPCG_TRY(compute_levels(h->A.n, h->L.rowptr, h->L.col, false, ls, nullptr, fm));
+    h->lvlL.n_levels = (int)ls.level_ptr.size() - 1;
+    h->lvlU.n_levels = h->lvlL.n_levels;   // (the longest dependency chain of L, read backwards)
+    return DPCG_OK;
 }
 
 extern "C" int dpcg_set_precond_ic0(dpcg_handle_t h, int mode, dpcg_stream_t stream) {
@@ -886,6 +990,7 @@ extern "C" int dpcg_set_precond_ict(dpcg_handle_t h, int mode, int fill_in, doub
     if (mode != DPCG_PRECOND_LLT_MULTIPLY && mode != DPCG_PRECOND_LLT_SOLVE) return invalid("bad LLT mode");
     if (fill_in < 0 || !(threshold >= 0.0)) return invalid("dpcg_set_precond_ict: fill_in >= 0 and threshold >= 0");
     hipStream_t s = (hipStream_t)stream;
+    SetupScope scope(s, true);          // (the preconditioner being replaced may be in use on another stream)
     const int64_t n = h->A.n;
     const CsrDev &Asrc = h->perm ? h->A_user : h->A;
     CsrDev S, Lf;                       // S: the pattern with fill (values: A, then the factor with stored zeros)

@@ -15,10 +15,10 @@ namespace {
 struct Scratch {
     void *p = nullptr;
     ~Scratch() {
-        if (p) (void)hipFree(p);
+        if (p) cached_free(p);
     }
     int reserve(size_t bytes) {
-        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        if (cached_alloc(&p, bytes ? bytes : 1) != hipSuccess) {
             p = nullptr;
             set_error("device primitive: scratch allocation failed");
             return DPCG_ERR_NOMEM;

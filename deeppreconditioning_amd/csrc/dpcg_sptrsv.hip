@@ -607,14 +607,22 @@ __global__ __launch_bounds__(kBlock) void k_strip_prepare(const int32_t *__restr
     }
 }
 
-template <bool UPPER, int C, int ROWS>
+// FACTOR: the same walk computes IC(0) instead of a solve, for a pattern WITHOUT cross terms (no two lower entries of a row
+// are themselves joined by an entry: every 5- / 7-point grid in any numbering -- checked by k_ic0_cross_terms, not assumed)
+// and rows of at most three off-diagonal entries.  Then L_ik = A_ik / L_kk and L_ii = sqrt(A_ii - sum_k L_ik^2): the only
+// thing a row needs of an earlier row is its DIAGONAL, one number per dependency -- the data flow of the lower solve, with
+// the records holding the entries of tril(A) and `out` / the ring the diagonals of L.  Operation order as k_ic0_level:
+// ascending columns, the quotient, then one product and one subtraction at a time, then the root.  The factor's values go
+// to fac (the records of the SAME plan, which thereby becomes the plan of L) and are scattered to CSR by k_strip_factor_scatter.
+template <bool UPPER, int C, int ROWS, bool FACTOR = false>
 __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict__ level_ptr, int nlev,
                                                        const int32_t *__restrict__ lo_rp, const int32_t *__restrict__ lo_ci,
                                                        const int32_t *__restrict__ lo_cpos, const double *__restrict__ lo_v,
                                                        const int4 *__restrict__ pk_meta, const double2 *__restrict__ pk_val,
                                                        const double *__restrict__ b_lo, double *out, int W,
                                                        int ring_reach, unsigned int *ticket, const int *done, int *err,
-                                                       long long *trace /* development: per strip {start, end, polls, levels} */) {
+                                                       long long *trace /* development: per strip {start, end, polls, levels} */,
+                                                       double2 *__restrict__ fac = nullptr /* FACTOR: records of L, by position */) {
     if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     extern __shared__ __attribute__((aligned(16))) double ring[];
     const long long t_start = trace ? (long long)wall_clock64() : 0;
@@ -650,7 +658,7 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
         r.m = pk_meta[jc];
         r.v01 = pk_val[2 * (int64_t)jc];
         r.v2d = pk_val[2 * (int64_t)jc + 1];
-        r.b = b_lo[jc];
+        r.b = FACTOR ? 0.0 : b_lo[jc];
     };
     auto load_chunk = [&](Row (&S)[C][ROWS], int chunk) {
 #pragma unroll
@@ -720,11 +728,24 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
                 if (r.m.y <= -2) y1 = is_pending(e.y1) ? poll(-2 - r.m.y) : e.y1;
                 if (r.m.z <= -2) y2 = is_pending(e.y2) ? poll(-2 - r.m.z) : e.y2;
             }
-            if (r.m.x != -1) acc -= r.v01.x * y0;
-            if (r.m.y != -1) acc -= r.v01.y * y1;
-            if (r.m.z != -1) acc -= r.v2d.x * y2;
+            if (FACTOR) {
+                double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+                acc = r.v2d.y;                               // A_ii
+                if (r.m.x != -1) { l0 = r.v01.x / y0; acc -= l0 * l0; }
+                if (r.m.y != -1) { l1 = r.v01.y / y1; acc -= l1 * l1; }
+                if (r.m.z != -1) { l2 = r.v2d.x / y2; acc -= l2 * l2; }
+                acc = sqrt(acc);                             // (a non-positive pivot: NaN or 0, found by the scatter pass)
+                if (valid) {
+                    fac[2 * (int64_t)r.j] = make_double2(l0, l1);
+                    fac[2 * (int64_t)r.j + 1] = make_double2(l2, acc);
+                }
+            } else {
+                if (r.m.x != -1) acc -= r.v01.x * y0;
+                if (r.m.y != -1) acc -= r.v01.y * y1;
+                if (r.m.z != -1) acc -= r.v2d.x * y2;
+            }
         }
-        const double y = acc / r.v2d.y;
+        const double y = FACTOR ? acc : acc / r.v2d.y;
         if (valid) {
             ring[r.j & (W - 1)] = y;
             // only rows that somebody reads from `out` DURING the launch are published (write-through); the rest is a plain
@@ -804,6 +825,57 @@ void init_strip_kernels() {
     (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<true, kStripChunk / 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk / 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk / 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+}
+
+// IC(0) through a strip plan built on the pattern of tril(A) (k_sptrsv_strips<..., FACTOR>): diag[] (n doubles, by the index
+// the plan addresses its vectors with) receives the diagonal of L, fac the records {l0, l1, l2, diagonal} by position.
+void launch_strip_factor(const Levels &lv, double *diag, double *fac, int64_t n, hipStream_t s) {
+    const Levels::Strips &sp = lv.strips;
+    hipLaunchKernelGGL(k_fill_pending, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, nullptr, 0, (int)n, diag,
+                       nullptr);
+    constexpr int CH = kStripChunk;
+    const size_t lds = (size_t)sp.W * sizeof(double) + (size_t)(sp.nlev + 3 * CH + 8) * sizeof(int);
+    if (sp.rows_per_thread == 1)
+        hipLaunchKernelGGL((k_sptrsv_strips<false, CH, 1, true>), dim3(sp.n_strips), dim3(sp.threads), lds, s, sp.level_ptr_dev,
+                           sp.nlev, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, (const int4 *)sp.meta, (const double2 *)sp.val,
+                           nullptr, diag, sp.W, sp.ring_reach, sp.ticket, nullptr, lv.spin_err, nullptr, (double2 *)fac);
+    else
+        hipLaunchKernelGGL((k_sptrsv_strips<false, CH / 2, 2, true>), dim3(sp.n_strips), dim3(sp.threads), lds, s,
+                           sp.level_ptr_dev, sp.nlev, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, (const int4 *)sp.meta,
+                           (const double2 *)sp.val, nullptr, diag, sp.W, sp.ring_reach, sp.ticket, nullptr, lv.spin_err, nullptr,
+                           (double2 *)fac);
+}
+
+// fac (records by position) -> the factor's CSR values and the plan's level-ordered copy; frow[j] = the factor row at position
+// j.  bad: the smallest row with a non-positive pivot, as INT_MAX - row (0: none).
+__global__ __launch_bounds__(kBlock) void k_strip_factor_scatter(int64_t n, const int32_t *__restrict__ frow,
+                                                                 const int32_t *__restrict__ rp, const double2 *__restrict__ fac,
+                                                                 double *__restrict__ fval, const int32_t *__restrict__ lo_rp,
+                                                                 double *__restrict__ lo_val, int *bad) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        const int i = frow[j];
+        const int a = rp[i], b = rp[i + 1], la = lo_rp[j];
+        const double2 f01 = fac[2 * j], f2d = fac[2 * j + 1];
+        const double l[3] = {f01.x, f01.y, f2d.x};
+        for (int q = 0; q < b - a - 1 && q < 3; ++q) {
+            fval[a + q] = l[q];
+            lo_val[la + q] = l[q];
+        }
+        fval[b - 1] = f2d.y;
+        lo_val[la + (b - a - 1)] = f2d.y;
+        if (!(f2d.y > 0.0)) atomicMax(bad, 0x7fffffff - i);
+    }
+}
+
+void launch_strip_factor_scatter(int64_t n, const int32_t *frow, const int32_t *rp, const double *fac, double *fval,
+                                 const int32_t *lo_rp, double *lo_val, int *bad, hipStream_t s) {
+    int grid = (int)((n + kBlock - 1) / kBlock);
+    grid = grid > 4096 ? 4096 : grid;
+    hipLaunchKernelGGL(k_strip_factor_scatter, dim3(grid), dim3(kBlock), 0, s, n, frow, rp, (const double2 *)fac, fval, lo_rp,
+                       lo_val, bad);
 }
 
 // Level-major solve, way in: dst[j] = src[map[j]], and the solution vector preset to the sync-free kernels' "pending"

@@ -578,3 +578,8 @@ def stream_bench(n_read: int = 2, write: bool = True, out_bytes: int = 1 << 27, 
     L.check(L.lib().dpcg_stream_bench(int(n_read), 1 if write else 0, 1 if nontemporal else 0, int(out_bytes), int(repeats),
                                       C.byref(ms), C.byref(moved), _stream()))
     return moved.value / (ms.value * 1e-3) / 1e9
+
+
+def release_cached_memory() -> None:
+    """Return the device blocks the library keeps between setups (see include/dpcg.h) to the driver."""
+    L.check(L.lib().dpcg_release_cached_memory())

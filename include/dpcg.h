@@ -82,6 +82,10 @@ const char *dpcg_status_string(int status);
 const char *dpcg_last_error(void);
 /* Device facts for the roofline report: CU count, HBM bytes, gcnArchName into name[name_len]. */
 int dpcg_device_info(int *cu_count, int64_t *hbm_bytes, char *name, int name_len);
+/* Device blocks freed by the setup routines are kept for the next setup (hipFree costs ~0.14 ms a block and a
+ * preconditioner setup frees dozens; the cache is bounded by DPCG_CACHE_MB, default 1024, 0 = off).  This returns them
+ * to the driver.  No reference counterpart: the reference's setups run in ilupp / scipy on the host (test.py:81-88). */
+int dpcg_release_cached_memory(void);
 
 /* ---- system handle: the operator A (test.py:61-68 / train.py:93-95 pass it dense; here CSR) -- */
 /* copy = 0 with DEVICE pointers borrows the arrays (caller keeps them alive); otherwise copied. */

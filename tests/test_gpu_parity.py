@@ -241,6 +241,61 @@ def test_ic0_factor_bit_exact(D):
         assert np.array_equal(v, Lref.data)
 
 
+def _scaled(A, seed):
+    """D A D with a random positive diagonal D: the pattern and the ordering of A, values that are not round numbers."""
+    d = np.random.default_rng(seed).uniform(0.5, 2.0, A.shape[0])
+    B = (sp.diags(d) @ A @ sp.diags(d)).tocsr()
+    B.sort_indices()
+    return B
+
+
+def _nine_point(m):
+    T = sp.diags([-1.0, -1.0, -1.0], [-1, 0, 1], shape=(m, m))
+    A = (sp.kron(T, T) * -1.0).tolil()          # all eight neighbours -1 ...
+    A.setdiag(8.5)                               # ... and a dominant diagonal
+    A = A.tocsr()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("name", ["poisson2d_600_scaled", "poisson3d_64_scaled", "nine_point_400_cross_terms"])
+def test_ic0_factor_bit_exact_large_banded(D, name):
+    """IC(0) of large banded patterns: without cross terms (5- / 7-point grids) the factorisation runs through the strip plan
+    of tril(A) (one launch, a recurrence on the diagonals), a 9-point grid has cross terms and keeps one launch per level.
+    Either way the factor equals the sequential restatement bit for bit, and so do the solves on the plan that was kept."""
+    A = {"poisson2d_600_scaled": lambda: _scaled(O.poisson2d(600), 3), "poisson3d_64_scaled": lambda: _scaled(O.poisson3d(64), 4),
+         "nine_point_400_cross_terms": lambda: _scaled(_nine_point(400), 5)}[name]()
+    S = D.CsrSystem.from_any(A, reorder=None)
+    S.set_preconditioner(D.IC0("solve"))
+    rp, ci, v = S.factor()
+    Lref = CO.ic0(A)
+    assert np.array_equal(rp, Lref.indptr) and np.array_equal(ci, Lref.indices)
+    assert np.array_equal(v, Lref.data)
+    r = O.rhs(A.shape[0], 2)
+    y_ref = CO.sptrsv_lower(Lref, r)
+    assert np.array_equal(S.sptrsv(_dev(r), upper=False).cpu().numpy(), y_ref)
+    z_ref = CO.sptrsv_upper(CO.transpose_csr(Lref), y_ref)
+    assert np.array_equal(S.sptrsv(_dev(y_ref), upper=True).cpu().numpy(), z_ref)
+    assert np.array_equal(S.precond_apply(_dev(r)).cpu().numpy(), z_ref)
+    info = S.info()                              # (the level count of a strip-factored system is computed on this request)
+    assert info["levels_lower"] == info["levels_upper"] >= 64
+    if name == "poisson2d_600_scaled":
+        assert info["levels_lower"] == 2 * 600 - 1
+        # multiply mode factors through the same plan and drops it
+        S.set_preconditioner(D.IC0("multiply"))
+        assert np.array_equal(S.factor()[2], Lref.data)
+        # a non-positive pivot is found and reported; the previous preconditioner stays
+        from deeppreconditioning_amd._lib import DpcgError, ERR_PIVOT
+        B = A.copy()
+        B[200000, 200000] = -1.0                 # (an existing entry: the pattern is unchanged)
+        Sb = D.CsrSystem.from_any(B, reorder=None)
+        with pytest.raises(DpcgError) as e:
+            Sb.set_preconditioner(D.IC0("solve"))
+        assert e.value.status == ERR_PIVOT and "row 200000" in str(e.value)
+        Sb.close()
+    S.close()
+
+
 @pytest.mark.parametrize("make", [lambda: O.poisson2d(64), lambda: O.poisson3d(16),
                                   lambda: O.unstructured_like(O.poisson3d(16), 0), lambda: O.poisson2d(80)])
 def test_sptrsv_bit_exact(D, make):
