@@ -667,9 +667,9 @@ int transpose_lower(const CsrDev &L, CsrDev &Lt, hipStream_t s) {
 
 // h->L holds a lower-triangular factor on the device (owned by the handle): validate it, build L^T, the SpMV plans and,
 // in solve mode, the level schedules.  `lower_levels`: level analysis of L when the caller already has it (IC(0)).
-// `lower_strips`: a kept strip plan of L (IC(0) by strips factored through it); its global level sets were never computed
-// (n_levels = -1: counted when dpcg_get_info asks).
-int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels = nullptr, Levels *lower_strips = nullptr) {
+// `lower_prebuilt`: the schedule of L when IC(0) was factored THROUGH it (a strip plan -- its global level sets were never
+// computed, n_levels = -1: counted when dpcg_get_info asks -- or a one-segment LDS-ring schedule).
+int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels = nullptr, Levels *lower_prebuilt = nullptr) {
     const int64_t n = h->A.n;
     DevBuf<int32_t> flags;
     DPCG_TRY(flags.alloc(1));
@@ -700,28 +700,8 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
         DPCG_TRY(make_plan(h->Lt, h->planLt, s));
     }
     pt.mark("plans");
-    if (mode == DPCG_PRECOND_LLT_SOLVE && lower_strips) {
-        h->lvlL = *lower_strips;                          // (the handle owns the plan from here on)
-        *lower_strips = Levels();
-        h->lvlL.n_levels = -1;
-        h->lvlU.n_levels = -1;
-        DPCG_TRY(dev_alloc(&h->lvlU.spin_err, 1));
-        DPCG_HIP(hipMemsetAsync(h->lvlU.spin_err, 0, sizeof(int), s));
-        DPCG_TRY(build_strips(h->lvlU, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, true, fm, s, false));
-        if (h->lvlU.strips.n_strips == 0) {               // (not seen: L^T of a banded factor is banded) -- the level schedule then
-            LevelSort up;
-            dev_free(h->lvlU.spin_err);
-            DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s, fm));
-            DPCG_TRY(build_levels(h->lvlU, up, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, s, fm, true));
-        }
-        pt.mark("schedule(L^T)");
-    } else if (mode == DPCG_PRECOND_LLT_SOLVE) {
+    if (mode == DPCG_PRECOND_LLT_SOLVE) {
         LevelSort own, up;
-        if (!lower_levels) {
-            DPCG_TRY(compute_levels(n, h->L.rowptr, h->L.col, false, own, s, fm));
-            lower_levels = &own;
-            pt.mark("levels(L)");
-        }
         // Large factors try the strip plan FIRST and build the level schedule (level-ordered copy, ring / sync-free records)
         // only when it is not kept; small ones build the schedule first because the choice depends on it.
         auto schedule = [&](Levels &lv, LevelSort &ls, const CsrDev &F, bool upper) -> int {
@@ -757,15 +737,26 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
             if (lv.strips.n_strips > 0) lv.level_major = false;
             return DPCG_OK;
         };
-        DPCG_TRY(schedule(h->lvlL, *lower_levels, h->L, false));
-        pt.mark("schedule(L)");
+        if (lower_prebuilt) {                                 // (the handle owns the schedule from here on)
+            h->lvlL = *lower_prebuilt;
+            *lower_prebuilt = Levels();
+            if (h->lvlL.strips.n_strips > 0) h->lvlL.n_levels = -1;
+        } else {
+            if (!lower_levels) {
+                DPCG_TRY(compute_levels(n, h->L.rowptr, h->L.col, false, own, s, fm));
+                lower_levels = &own;
+                pt.mark("levels(L)");
+            }
+            DPCG_TRY(schedule(h->lvlL, *lower_levels, h->L, false));
+            pt.mark("schedule(L)");
+        }
         // L^T has as many levels as L (the longest dependency chain read backwards): when L took the strip plan, L^T tries it
         // straight away and its global level sets are only computed if that fails
         if (h->lvlL.strips.n_strips > 0) {
             h->lvlU.n_levels = h->lvlL.n_levels;
             DPCG_TRY(dev_alloc(&h->lvlU.spin_err, 1));
             DPCG_HIP(hipMemsetAsync(h->lvlU.spin_err, 0, sizeof(int), s));
-            DPCG_TRY(build_strips(h->lvlU, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, true, fm, s));
+            DPCG_TRY(build_strips(h->lvlU, n, h->Lt.nnz, h->Lt.rowptr, h->Lt.col, h->Lt.val, true, fm, s, h->lvlL.n_levels >= 0));
             if (h->lvlU.strips.n_strips == 0) dev_free(h->lvlU.spin_err);
         }
         if (h->lvlU.strips.n_strips == 0) {
@@ -862,65 +853,89 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
     PhaseTimer pt(s);
     launch_tril_copy(n, Asrc.rowptr, Asrc.col, Asrc.val, Lf.rowptr, Lf.col, Lf.val, s);
     pt.mark("tril(A)");
-    // A large banded pattern without cross terms (natural-order / RCM-ordered grids: thousands of narrow levels) is factored
-    // through the strip plan of its own pattern -- the walk the solves use, one launch -- and that plan then IS the plan of L
-    // (measured at 1024^2, 2047 levels: 10.9 ms of level-by-level launches + 3.6 ms of level analysis before).
-    Levels pre;                       // strip plan on tril(A); becomes the handle's when kept
+    // A pattern without cross terms whose schedule is a walk of many narrow levels (natural-order / RCM-ordered grids) is factored
+    // THROUGH that schedule, built on the pattern of tril(A) -- one launch -- and the schedule then is L's:
+    //   * n > 131 072, banded: the strip plan (measured at 1024^2, 2047 levels: 10.9 ms of level-by-level launches and 3.6 ms
+    //     of level analysis before);
+    //   * smaller, one LDS-ring segment (2-D grids up to 362^2): the one-workgroup ring walk (256^2: 511 launches, 2.3 ms).
+    Levels pre;                       // the schedule built on tril(A); becomes the handle's when kept
     auto fail2 = [&](int st2) {
         free_levels(pre);
         return fail(st2);
     };
-    bool by_strips = false;
-    static const bool strip_factor_on = [] { const char *ev = getenv("DPCG_IC0_STRIPS"); return !(ev && ev[0] == '0'); }();
-    if (strip_factor_on && n > 131072 && ordering == DPCG_ORDER_CALLER) {
+    bool through_schedule = false, plain = false;
+    static const bool schedule_factor_on = [] { const char *ev = getenv("DPCG_IC0_STRIPS"); return !(ev && ev[0] == '0'); }();
+    DevBuf<double> diag, fac;
+    // records of L by position -> CSR values + the schedule's own copies; pivot check; the records' value array is swapped in
+    auto harvest = [&](const int32_t *frows, const int32_t *lo_rp, double *lo_val, double **rec_val, const char *what) -> int {
+        launch_strip_factor_scatter(n, frows, Lf.rowptr, fac.p, Lf.val, lo_rp, lo_val, reinterpret_cast<int *>(flags.p) + 1, s);
+        int32_t h_spin = 0;
+        hipError_t e2 = hipGetLastError();
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(&h_spin, pre.spin_err, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(s);
+        if (e2 != hipSuccess) return hip_fail(e2, what, __FILE__, __LINE__);
+        if (h_spin) {
+            set_error("IC(0) through the schedule: a bounded wait ran out");
+            return DPCG_ERR_HIP;
+        }
+        if (h_flags[1]) h_flags[1] = (0x7fffffff - h_flags[1]) + 1;      // (row + 1, as the level kernels report it)
+        std::swap(*rec_val, fac.p);
+        return DPCG_OK;
+    };
+    if (schedule_factor_on && n >= 4096 && ordering == DPCG_ORDER_CALLER) {
         e = hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), s);
         if (e != hipSuccess) return fail(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
         launch_ic0_cross_terms(n, Lf.rowptr, Lf.col, reinterpret_cast<int *>(flags.p), s);
         e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return fail(hip_fail(e, "IC(0): pattern check", __FILE__, __LINE__));
-        if (h_flags[0] == 0) {
-            DevBuf<int32_t> frows;
-            DevBuf<double> diag, fac;
-            if ((st = dev_alloc(&pre.spin_err, 1)) < 0) return fail2(st);
-            e = hipMemsetAsync(pre.spin_err, 0, sizeof(int), s);
-            if (e != hipSuccess) return fail2(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
-            if ((st = build_strips(pre, n, Lf.nnz, Lf.rowptr, Lf.col, Lf.val, false, h->iperm, s, false, &frows)) < 0) return fail2(st);
-            if (pre.strips.n_strips > 0 && pre.strips.long_rows == 0) {
-                pt.mark("strip plan (tril A)");
-                if ((st = diag.alloc(n)) < 0 || (st = fac.alloc(4 * n)) < 0) return fail2(st);
-                launch_strip_factor(pre, diag.p, fac.p, n, s);
-                launch_strip_factor_scatter(n, frows.p, Lf.rowptr, fac.p, Lf.val, pre.strips.lo_rowptr, pre.strips.lo_val,
-                                            reinterpret_cast<int *>(flags.p) + 1, s);
-                int32_t h_spin = 0;
-                e = hipGetLastError();
-                if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
-                if (e == hipSuccess) e = hipMemcpyAsync(&h_spin, pre.spin_err, sizeof(int), hipMemcpyDeviceToHost, s);
-                if (e == hipSuccess) e = hipStreamSynchronize(s);
-                if (e != hipSuccess) return fail2(hip_fail(e, "IC(0): numeric factorisation (strips)", __FILE__, __LINE__));
-                if (h_spin) {
-                    set_error("IC(0) by strips: a bounded wait ran out");
-                    return fail2(DPCG_ERR_HIP);
-                }
-                if (h_flags[1]) h_flags[1] = (0x7fffffff - h_flags[1]) + 1;      // (row + 1, as the level kernels report it)
-                // the records of the plan now hold L: swap the value arrays
-                std::swap(pre.strips.val, fac.p);
-                by_strips = true;
-                pt.mark("numeric IC(0) by strips");
-            } else {
-                free_levels(pre);
-            }
-        }
-        if (!by_strips) {
-            e = hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), s);
-            if (e != hipSuccess) return fail2(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
+        plain = h_flags[0] == 0;
+        e = hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), s);
+        if (e != hipSuccess) return fail(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
+        h_flags[0] = h_flags[1] = 0;
+    }
+    if (plain && n > 131072) {
+        DevBuf<int32_t> frows;
+        if ((st = dev_alloc(&pre.spin_err, 1)) < 0) return fail2(st);
+        e = hipMemsetAsync(pre.spin_err, 0, sizeof(int), s);
+        if (e != hipSuccess) return fail2(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
+        if ((st = build_strips(pre, n, Lf.nnz, Lf.rowptr, Lf.col, Lf.val, false, h->iperm, s, false, &frows)) < 0) return fail2(st);
+        if (pre.strips.n_strips > 0 && pre.strips.long_rows == 0) {
+            pt.mark("strip plan (tril A)");
+            if ((st = diag.alloc(n)) < 0 || (st = fac.alloc(4 * n)) < 0) return fail2(st);
+            launch_strip_factor(pre, diag.p, fac.p, n, s);
+            if ((st = harvest(frows.p, pre.strips.lo_rowptr, pre.strips.lo_val, &pre.strips.val, "IC(0) through the strip plan")) < 0)
+                return fail2(st);
+            through_schedule = true;
+            pt.mark("numeric IC(0) by strips");
+        } else {
+            free_levels(pre);
         }
     }
-    LevelSort ls;
-    if (!by_strips) {
-        if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, ls, s, cperm ? cperm : h->iperm)) < 0) return fail2(st);
+    LevelSort ls_first, ls_again;
+    LevelSort *ls = &ls_first;
+    if (!through_schedule) {
+        if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, *ls, s, cperm ? cperm : h->iperm)) < 0) return fail2(st);
         pt.mark("levels(tril A)");
-        if ((st = numeric_incomplete_cholesky(ls, n, Lf, reinterpret_cast<int *>(flags.p) + 1, nullptr, 0.0, s)) < 0) return fail2(st);
+        const int nl = (int)ls->level_ptr.size() - 1;
+        if (plain && !h->perm && n <= 131072 && nl >= 64) {
+            // (build_levels takes the level sets over: if the schedule turns out not to be one ring walk, they are computed again)
+            if ((st = build_levels(pre, *ls, n, Lf.nnz, Lf.rowptr, Lf.col, Lf.val, s, nullptr, false)) < 0) return fail2(st);
+            if ((st = diag.alloc(n)) < 0 || (st = fac.alloc(4 * n)) < 0) return fail2(st);
+            if (launch_ring_factor(pre, diag.p, fac.p, s)) {
+                if ((st = harvest(pre.rows, pre.lo_rowptr, pre.lo_val, &pre.pk_val, "IC(0) through the ring walk")) < 0) return fail2(st);
+                through_schedule = true;
+                pt.mark("numeric IC(0) by the ring walk");
+            } else {
+                free_levels(pre);
+                ls = &ls_again;
+                if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, *ls, s, cperm ? cperm : h->iperm)) < 0) return fail2(st);
+            }
+        }
+    }
+    if (!through_schedule) {
+        if ((st = numeric_incomplete_cholesky(*ls, n, Lf, reinterpret_cast<int *>(flags.p) + 1, nullptr, 0.0, s)) < 0) return fail2(st);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -937,9 +952,9 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
     h->fmap = cperm;                  // factor index -> handle index (null: the caller's numbering)
     h->fmap_inv = ciperm;
     h->precond_colors = n_colors;
-    const bool keep_plan = by_strips && mode == DPCG_PRECOND_LLT_SOLVE;
-    st = finish_llt(h, mode, s, by_strips ? nullptr : &ls, keep_plan ? &pre : nullptr);
-    free_levels(pre);                 // (multiply mode: the plan only served the factorisation)
+    const bool keep_schedule = through_schedule && mode == DPCG_PRECOND_LLT_SOLVE;
+    st = finish_llt(h, mode, s, through_schedule ? nullptr : ls, keep_schedule ? &pre : nullptr);
+    free_levels(pre);                 // (multiply mode: the schedule only served the factorisation)
     if (st < 0) free_precond(h);
     return st;
 }

@@ -289,7 +289,9 @@ __global__ __launch_bounds__(kBlock) void k_gather_lo(const int32_t *__restrict_
 // the next chunk fly into the other set; at a chunk boundary one s_waitcnt vmcnt(0) retires them (by then C levels
 // of work have covered the memory latency).  The explicit wait + register "touch" keeps the compiler from
 // inserting its own conservative vmcnt(0) at each first use, which would also wait for the loads just issued.
-template <bool UPPER, int C, int ROWS>   // ROWS rows of a level per thread, C levels per prefetch chunk
+// FACTOR: IC(0) of a cross-term-free pattern as a recurrence on the diagonals (see k_sptrsv_strips), for a factor whose whole
+// schedule is this one walk: records = the entries of tril(A), ring / out = the diagonals of L, fac = the records of L.
+template <bool UPPER, int C, int ROWS, bool FACTOR = false>   // ROWS rows of a level per thread, C levels per prefetch chunk
 __global__ __launch_bounds__(512) void k_sptrsv_ring_pipe(const int32_t *__restrict__ level_ptr, int lvl_lo,
                                                           int lvl_hi, const int32_t *__restrict__ lo_rp,
                                                           const int32_t *__restrict__ lo_ci,
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(512) void k_sptrsv_ring_pipe(const int32_t *__restr
                                                           const int4 *__restrict__ pk_meta,
                                                           const double2 *__restrict__ pk_val,
                                                           const double *__restrict__ b_lo, double *out, int seg_start,
-                                                          int W, const int *done) {
+                                                          int W, const int *done, double2 *__restrict__ fac = nullptr) {
     if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     extern __shared__ __attribute__((aligned(16))) double ring[];
     int *lp = reinterpret_cast<int *>(ring + W);        // level offsets of this segment, padded with empty levels
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(512) void k_sptrsv_ring_pipe(const int32_t *__restr
         r.m = pk_meta[jc];
         r.v01 = pk_val[2 * (int64_t)jc];
         r.v2d = pk_val[2 * (int64_t)jc + 1];
-        r.b = b_lo[jc];
+        r.b = FACTOR ? 0.0 : b_lo[jc];
     };
     auto load_chunk = [&](Row (&S)[C][ROWS], int chunk) {
 #pragma unroll
@@ -359,11 +361,24 @@ __global__ __launch_bounds__(512) void k_sptrsv_ring_pipe(const int32_t *__restr
             const double y0 = ring[(r.m.x < 0 ? 0 : r.m.x) & (W - 1)];
             const double y1 = ring[(r.m.y < 0 ? 0 : r.m.y) & (W - 1)];
             const double y2 = ring[(r.m.z < 0 ? 0 : r.m.z) & (W - 1)];
-            if (r.m.x >= 0) acc -= r.v01.x * y0;
-            if (r.m.y >= 0) acc -= r.v01.y * y1;
-            if (r.m.z >= 0) acc -= r.v2d.x * y2;
+            if (FACTOR) {
+                double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+                acc = r.v2d.y;                               // A_ii
+                if (r.m.x >= 0) { l0 = r.v01.x / y0; acc -= l0 * l0; }
+                if (r.m.y >= 0) { l1 = r.v01.y / y1; acc -= l1 * l1; }
+                if (r.m.z >= 0) { l2 = r.v2d.x / y2; acc -= l2 * l2; }
+                acc = sqrt(acc);
+                if (valid) {
+                    fac[2 * (int64_t)r.j] = make_double2(l0, l1);
+                    fac[2 * (int64_t)r.j + 1] = make_double2(l2, acc);
+                }
+            } else {
+                if (r.m.x >= 0) acc -= r.v01.x * y0;
+                if (r.m.y >= 0) acc -= r.v01.y * y1;
+                if (r.m.z >= 0) acc -= r.v2d.x * y2;
+            }
         }
-        const double y = acc / r.v2d.y;
+        const double y = FACTOR ? acc : acc / r.v2d.y;
         if (valid) {
             ring[r.j & (W - 1)] = y;
             out[r.m.w] = y;
@@ -846,6 +861,29 @@ void launch_strip_factor(const Levels &lv, double *diag, double *fac, int64_t n,
                            sp.level_ptr_dev, sp.nlev, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, (const int4 *)sp.meta,
                            (const double2 *)sp.val, nullptr, diag, sp.W, sp.ring_reach, sp.ticket, nullptr, lv.spin_err, nullptr,
                            (double2 *)fac);
+}
+
+// The same through the one-workgroup LDS-ring walk (a factor of <= 131 072 rows whose schedule is ONE ring segment: 2-D grids).
+// Returns false when the schedule is not of that form.
+bool launch_ring_factor(const Levels &lv, double *diag, double *fac, hipStream_t s) {
+    if (lv.segments.size() != 1 || lv.strips.n_strips > 0 || !lv.pk_meta) return false;
+    const Levels::Segment &seg = lv.segments[0];
+    const size_t lds = (size_t)seg.ring_w * sizeof(double) + (size_t)(seg.hi - seg.lo + 4 * kRingChunk) * sizeof(int);
+    if (!(seg.merged && seg.ring_w > 0) || ring_pipe_disabled() || seg.max_width > 1024 || lds > 64 * 1024) return false;
+    const int seg_start = lv.level_ptr[seg.lo], width = seg.max_width;
+    if (width <= 512) {
+        int threads = (width + 63) / 64 * 64;
+        threads = threads < 64 ? 64 : threads;
+        hipLaunchKernelGGL((k_sptrsv_ring_pipe<false, kRingChunk, 1, true>), dim3(1), dim3(threads), lds, s, lv.level_ptr_dev, seg.lo,
+                           seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, (const int4 *)lv.pk_meta,
+                           (const double2 *)lv.pk_val, nullptr, diag, seg_start, seg.ring_w, nullptr, (double2 *)fac);
+    } else {
+        const int threads = ((width + 1) / 2 + 63) / 64 * 64;
+        hipLaunchKernelGGL((k_sptrsv_ring_pipe<false, kRingChunk / 2, 2, true>), dim3(1), dim3(threads), lds, s, lv.level_ptr_dev,
+                           seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, (const int4 *)lv.pk_meta,
+                           (const double2 *)lv.pk_val, nullptr, diag, seg_start, seg.ring_w, nullptr, (double2 *)fac);
+    }
+    return true;
 }
 
 // fac (records by position) -> the factor's CSR values and the plan's level-ordered copy; frow[j] = the factor row at position

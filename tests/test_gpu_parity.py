@@ -258,13 +258,18 @@ def _nine_point(m):
     return A
 
 
-@pytest.mark.parametrize("name", ["poisson2d_600_scaled", "poisson3d_64_scaled", "nine_point_400_cross_terms"])
+@pytest.mark.parametrize("name", ["poisson2d_600_scaled", "poisson3d_64_scaled", "nine_point_400_cross_terms",
+                                  "poisson2d_256_scaled_ring_walk", "poisson3d_40_scaled_mixed_schedule"])
 def test_ic0_factor_bit_exact_large_banded(D, name):
-    """IC(0) of large banded patterns: without cross terms (5- / 7-point grids) the factorisation runs through the strip plan
-    of tril(A) (one launch, a recurrence on the diagonals), a 9-point grid has cross terms and keeps one launch per level.
-    Either way the factor equals the sequential restatement bit for bit, and so do the solves on the plan that was kept."""
+    """IC(0) of banded patterns: without cross terms (5- / 7-point grids) the factorisation runs through the schedule built on
+    tril(A) -- the strip plan beyond 131 072 rows, the one-workgroup ring walk for a C2-size 2-D grid -- in one launch, a
+    recurrence on the diagonals; a 9-point grid has cross terms and a small 3-D grid a schedule of several segments: those keep
+    one launch per level.  Either way the factor equals the sequential restatement bit for bit, and so do the solves on the
+    schedule that was kept."""
     A = {"poisson2d_600_scaled": lambda: _scaled(O.poisson2d(600), 3), "poisson3d_64_scaled": lambda: _scaled(O.poisson3d(64), 4),
-         "nine_point_400_cross_terms": lambda: _scaled(_nine_point(400), 5)}[name]()
+         "nine_point_400_cross_terms": lambda: _scaled(_nine_point(400), 5),
+         "poisson2d_256_scaled_ring_walk": lambda: _scaled(O.poisson2d(256), 6),
+         "poisson3d_40_scaled_mixed_schedule": lambda: _scaled(O.poisson3d(40), 7)}[name]()
     S = D.CsrSystem.from_any(A, reorder=None)
     S.set_preconditioner(D.IC0("solve"))
     rp, ci, v = S.factor()
