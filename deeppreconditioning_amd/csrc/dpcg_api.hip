@@ -724,13 +724,17 @@ extern "C" int dpcg_stream_bench(int n_read, int write, int nontemporal, int64_t
         e = hipMemsetAsync(in, 0, (size_t)in_doubles * sizeof(double), s);
         if (e == hipSuccess) e = hipEventCreate(&e0);
         if (e == hipSuccess) e = hipEventCreate(&e1);
+        // a footprint inside the Infinity Cache (256 MiB) streams best with one element in flight per lane and 6 workgroups
+        // per CU, one beyond it with two and 8 (tools/stream_lab; profiles/r03_stream_lab.txt)
+        const bool resident = (int64_t)(n_read + (write ? 1 : 0)) * out_bytes < ((int64_t)200 << 20);
+        const int grid = resident ? 1536 : kMaxSpmvGrid, in_flight = resident ? 1 : 2;
         for (int i = 0; i < 2 && e == hipSuccess; ++i)
-            moved = launch_stream_bench(n_read, write != 0, nontemporal != 0, out_bytes, in, out, part, kMaxSpmvGrid, s);
+            moved = launch_stream_bench(n_read, write != 0, nontemporal != 0, out_bytes, in, out, part, grid, s, in_flight);
         if (e == hipSuccess && moved < 0) st = invalid("dpcg_stream_bench: n_read must be 1, 2, 4 or 11");
         if (e == hipSuccess && st >= 0) {
             e = hipEventRecord(e0, s);
             for (int i = 0; i < repeats; ++i)
-                launch_stream_bench(n_read, write != 0, nontemporal != 0, out_bytes, in, out, part, kMaxSpmvGrid, s);
+                launch_stream_bench(n_read, write != 0, nontemporal != 0, out_bytes, in, out, part, grid, s, in_flight);
             if (e == hipSuccess) e = hipEventRecord(e1, s);
             if (e == hipSuccess) e = hipEventSynchronize(e1);
             if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);

@@ -438,7 +438,7 @@ void launch_tril_copy(int64_t n, const int32_t *rp, const int32_t *ci, const dou
                       double *lv, hipStream_t s);
 void launch_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void *val, int val_dtype, hipStream_t s);
 int64_t launch_stream_bench(int n_read, bool write, bool nt, int64_t out_bytes, const double *in, double *out, double *part,
-                            int grid, hipStream_t s);
+                            int grid, hipStream_t s, int in_flight = 2);
 void launch_batched_coo_edge(int64_t nnz, const int32_t *indices, int batch, int64_t dof, const float *a, const float *c,
                              float *out, int transpose, hipStream_t s);
 void launch_batched_coo_spmm(int64_t nnz, const int32_t *indices, const float *features, int batch, int64_t dof, int ncols,

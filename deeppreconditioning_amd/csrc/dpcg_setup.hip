@@ -127,13 +127,19 @@ __global__ __launch_bounds__(kBlock) void k_stream_bench(int64_t n2, const doubl
 
 // out_bytes: size of the written stream (rounded down to 16 B; the input is n_read times as long, plus one slab of slack);
 // returns the bytes one launch moves (reads + writes), or -1 for an unsupported n_read
+// `in_flight`: output elements in flight per lane (2 suits streams from HBM, 1 footprints inside the Infinity Cache -- tools/stream_lab)
 int64_t launch_stream_bench(int n_read, bool write, bool nt, int64_t out_bytes, const double *in, double *out, double *part,
-                            int grid, hipStream_t s) {
+                            int grid, hipStream_t s, int in_flight) {
     const int64_t n2 = out_bytes / 16;
     const double2 *i2 = reinterpret_cast<const double2 *>(in);
     double2 *o2 = reinterpret_cast<double2 *>(out);
-#define DPCG_STREAM_LAUNCH(RV, WV, NTV) \
-    hipLaunchKernelGGL((k_stream_bench<RV, 2, WV, NTV>), dim3(grid), dim3(kBlock), 0, s, n2, i2, o2, part)
+#define DPCG_STREAM_LAUNCH(RV, WV, NTV)                                                                                     \
+    do {                                                                                                                    \
+        if (in_flight == 1)                                                                                                 \
+            hipLaunchKernelGGL((k_stream_bench<RV, 1, WV, NTV>), dim3(grid), dim3(kBlock), 0, s, n2, i2, o2, part);         \
+        else                                                                                                                \
+            hipLaunchKernelGGL((k_stream_bench<RV, 2, WV, NTV>), dim3(grid), dim3(kBlock), 0, s, n2, i2, o2, part);         \
+    } while (0)
 #define DPCG_STREAM_CASE(RV)                                             \
     case RV:                                                             \
         if (write && nt) DPCG_STREAM_LAUNCH(RV, true, true);             \

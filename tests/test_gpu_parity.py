@@ -1199,6 +1199,40 @@ def test_randomised_differential_sample():
     assert "fuzz: 16 cases, 0 mismatches" in proc.stdout, proc.stdout[-3000:]
 
 
+def test_device_block_cache_is_bounded_and_optional(D):
+    """Setup routines keep freed device blocks for the next setup (dpcg_mem.hip).  The blocks can be handed back, the
+    cache can be switched off (DPCG_CACHE_MB=0: the fuzz slice again, every free a hipFree), and a cached block never
+    carries results over: two setups of different preconditioners on recycled blocks reproduce the first solve bit for bit."""
+    import pathlib
+    import subprocess
+    import sys
+    import torch
+    from deeppreconditioning_amd.operators import release_cached_memory
+    A = O.unstructured_like(O.poisson3d(24), 2)
+    b = _dev(O.rhs(A.shape[0], 1))
+    S = D.CsrSystem.from_any(A)
+    S.set_preconditioner(D.IC0("solve"))
+    first = S.solve(b)
+    S.set_preconditioner(D.ICT("multiply"))             # frees IC(0)'s arrays into the cache, builds on recycled blocks
+    S.solve(b)
+    S.set_preconditioner(D.IC0("solve"))
+    again = S.solve(b)
+    assert first.iterations == again.iterations and torch.equal(first.x, again.x)
+    S.close()
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    release_cached_memory()
+    assert torch.cuda.mem_get_info()[0] > free_before
+    free_released = torch.cuda.mem_get_info()[0]
+    release_cached_memory()                             # nothing left: a no-op
+    assert torch.cuda.mem_get_info()[0] == free_released
+    root = pathlib.Path(__file__).resolve().parent.parent
+    proc = subprocess.run([sys.executable, str(root / "tools" / "fuzz_parity.py"), "6", "5"], capture_output=True, text=True,
+                          cwd=root, env={**__import__("os").environ, "PYTHONPATH": str(root), "DPCG_CACHE_MB": "0"}, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert "fuzz: 6 cases, 0 mismatches" in proc.stdout, proc.stdout[-3000:]
+
+
 def test_write_case_from_an_openfoam_dump(D, tmp_path):
     """generate_data.py:97-111 after the simulation: matrix.csv -> case folder with a GPU-solved ground truth."""
     from deeppreconditioning_amd import io as dio
