@@ -219,7 +219,8 @@ int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s, bool allow_tile) {
                 static const int nt_knob = [] { const char *e = getenv("DPCG_SPMV_NT"); return e ? atoi(e) : -1; }();
                 plan.stream_nt = nt_knob >= 0 ? nt_knob != 0 : stream_bytes >= 512e6;
                 const size_t lds = (size_t)(h_flags[1] * kTileChunk + kStreamCap + 8) * sizeof(double);
-                const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+                static const int wg_knob = [] { const char *e = getenv("DPCG_SPMV_WG_PER_CU"); return e ? atoi(e) : 8; }();   // development
+                const int per_cu = (int)std::min<size_t>((size_t)(wg_knob < 1 ? 1 : wg_knob), (160 * 1024) / lds);
                 cap = std::min(cap, per_cu * 256);
             } else {
                 dev_free(plan.tile_chunks);
