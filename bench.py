@@ -452,6 +452,16 @@ def extra_workloads(D, poisson, torch) -> dict:
     b3 = poisson.rhs(s3.n, 0)
     c3 = {"create_incl_upload_and_reordering_ms": round(create_s * 1e3, 1), "reordered": s3.info()["reordered"],
           "gather_ratio_before": round(s3.info()["gather_ratio"], 2), "spmv_kernel": s3.info()["spmv_kernel"]}
+    # the NEXT pressure system of the same mesh: new values on the same pattern keep the plan and the reordering
+    vals_dev = torch.from_numpy(A.data).cuda()
+    for tag, v in (("update_values_from_host_ms", A.data), ("update_values_from_device_ms", vals_dev)):
+        s3.update_values(v)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s3.update_values(v)
+        torch.cuda.synchronize()
+        c3[tag] = round((time.perf_counter() - t0) * 1e3, 2)
+    del vals_dev
     for name, pc in (("jacobi", D.Jacobi()), ("ic0_multicolor_solve", D.IC0("solve", ordering="multicolor")),
                      ("ic0_solve", D.IC0("solve"))):
         torch.cuda.synchronize()

@@ -60,6 +60,7 @@ SIGNATURES = {
     "dpcg_dot": (_int, [_i64, _p, _p, C.POINTER(_dbl), _p]),
     "dpcg_spmv_dot_bench": (_int, [_p, _p, _p, _int, C.POINTER(C.c_float), _p]),
     "dpcg_release_cached_memory": (_int, []),
+    "dpcg_update_values": (_int, [_p, _p, _int, _int, _p]),
     "dpcg_stream_bench": (_int, [_int, _int, _int, _i64, _int, C.POINTER(C.c_float), C.POINTER(_i64), _p]),
     "dpcg_solve": (_int, [_p, _p, _p, _p, _dbl, _dbl, _int, _int, _p, C.POINTER(_int), C.POINTER(_dbl),
                           C.POINTER(_dbl), _p, _p, _p]),

@@ -388,6 +388,58 @@ extern "C" int dpcg_reorder(dpcg_handle_t h, int mode, dpcg_stream_t stream, int
     return DPCG_OK;
 }
 
+// New values on the pattern the handle was created with (the next pressure system of the same mesh): everything that
+// depends only on the pattern stays -- the SpMV plan with its x-tile lists, the reordering -- and everything that holds
+// values is refreshed or dropped (the permuted copy, the fp32 copy, the slab-ELL slices, the captured graphs, the
+// preconditioner: attach one again).
+extern "C" int dpcg_update_values(dpcg_handle_t h, const void *val, int val_dtype, int memspace, dpcg_stream_t stream) {
+    if (!h || !val) return invalid("dpcg_update_values: NULL handle or values");
+    if (val_dtype != DPCG_F64 && val_dtype != DPCG_F32) return invalid("dpcg_update_values: bad val_dtype");
+    if (memspace != DPCG_HOST && memspace != DPCG_DEVICE) return invalid("dpcg_update_values: bad memspace");
+    hipStream_t s = (hipStream_t)stream;
+    SetupScope scope(s, true);           // (the old values may be in use on another stream)
+    CsrDev &U = h->perm ? h->A_user : h->A;      // the matrix in the caller's numbering
+    const int64_t nnz = U.nnz;
+    bool val32_fresh = false;                    // U.val32 holds the NEW values in fp32
+    if (!U.owned) {
+        // borrowed arrays (dpcg_create with copy = 0): the new values are borrowed the same way -- possibly the same buffer,
+        // rewritten in place
+        if (memspace != DPCG_DEVICE || val_dtype != DPCG_F64 || (((uintptr_t)val) & 15) != 0)
+            return invalid("dpcg_update_values: a handle that borrows its arrays takes 16-byte aligned fp64 device values");
+        U.val = const_cast<double *>((const double *)val);
+    } else {
+        const hipMemcpyKind kind = memspace == DPCG_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+        if (val_dtype == DPCG_F64) {
+            DPCG_HIP(hipMemcpyAsync(U.val, val, (size_t)nnz * sizeof(double), kind, s));
+        } else {
+            if (!U.val32) DPCG_TRY(dev_alloc(&U.val32, nnz));
+            DPCG_HIP(hipMemcpyAsync(U.val32, val, (size_t)nnz * sizeof(float), kind, s));
+            launch_f32_to_f64(nnz, U.val32, U.val, s);
+            val32_fresh = true;
+        }
+        DPCG_HIP(hipStreamSynchronize(s));       // a host source buffer may be released by the caller
+    }
+    if (h->perm) {                               // P A P^T again: same pattern, so the plan of the old one fits
+        CsrDev B;
+        const int st = permute_csr(h->A_user, h->perm, h->iperm, B, s);
+        if (st < 0) {
+            free_csr(B);
+            return st;
+        }
+        free_csr(h->A);                          // (with its fp32 copy)
+        h->A = B;
+        if (!val32_fresh) dev_free(h->A_user.val32);
+    } else if (!val32_fresh) {
+        dev_free(h->A.val32);                    // an fp32 original or copy of the OLD values: made again on demand
+    }
+    h->A.val32_lossless = 0;                     // decided again on demand
+    free_precond(h);
+    free_ell(h->ell_a);
+    drop_graph(h);
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
 extern "C" int dpcg_get_permutation(dpcg_handle_t h, int *reordered, int32_t *perm_host, double *gather_ratio) {
     if (!h) return invalid("dpcg_get_permutation: NULL handle");
     if (reordered) *reordered = h->perm ? 1 : 0;

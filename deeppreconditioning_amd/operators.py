@@ -404,6 +404,35 @@ class CsrSystem:
                 L.check(L.lib().dpcg_reorder(self._h, _REORDER_MODES[mode], _stream(), C.byref(applied)))
         self.reordered = bool(applied.value)
 
+    def update_values(self, values) -> None:
+        """New matrix values on the SAME sparsity pattern (the next pressure system of one mesh), in the order of the arrays
+        the system was created from.  The SpMV plan and the reordering are kept; the preconditioner is dropped -- attach one
+        again.  (No reference counterpart: the reference builds a tensor per sample, test.py:61-68.)"""
+        if isinstance(values, torch.Tensor) and values.is_cuda:
+            v = values.detach().contiguous()
+            if v.dtype not in (torch.float32, torch.float64):
+                v = v.to(torch.float64)
+            if v.numel() != self.nnz:
+                raise ValueError(f"expected {self.nnz} values")
+            if self._keep:                      # a system created from device arrays borrows them: borrow the new ones likewise
+                if v.dtype != torch.float64 or v.data_ptr() % 16:
+                    v = v.to(torch.float64).clone()
+                self._keep = (self._keep[0], self._keep[1], v)
+            with torch.cuda.device(self.device):
+                L.check(L.lib().dpcg_update_values(self._h, _dev_ptr(v), L.F64 if v.dtype == torch.float64 else L.F32,
+                                                   L.DEVICE, _stream()))
+        else:
+            a = values.detach().cpu().numpy() if isinstance(values, torch.Tensor) else np.asarray(values)
+            dt = L.F32 if a.dtype == np.float32 else L.F64
+            a = np.ascontiguousarray(a, dtype=np.float32 if dt == L.F32 else np.float64)
+            if a.size != self.nnz:
+                raise ValueError(f"expected {self.nnz} values")
+            if self._keep:                      # borrowed device arrays: the new values must live on the device too
+                return self.update_values(torch.from_numpy(a.astype(np.float64)).to(self.device))
+            with torch.cuda.device(self.device):
+                L.check(L.lib().dpcg_update_values(self._h, _np_ptr(a), dt, L.HOST, _stream()))
+        self._precond = None
+
     def permutation(self):
         """perm (numpy int32, perm[new] = old) of a reordered system -- row `new` of the matrix the library iterates on is
         the caller's row `old` -- or None."""

@@ -112,6 +112,14 @@ int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spmv_kernel, i
  * PCG is invariant under symmetric permutation up to the order of floating-point sums: iterates agree with the
  * unpermuted solve to rounding, and to 1e-10 with the CPU reference run on P A P^T (dpcg_get_permutation). */
 enum dpcg_reorder_mode { DPCG_REORDER_NONE = 0, DPCG_REORDER_AUTO = 1, DPCG_REORDER_ALWAYS = 2 };
+/* New values on the SAME sparsity pattern: val[nnz] in the order of the arrays dpcg_create was given (the caller's
+ * promise -- only values are passed).  The reference builds a fresh tensor per sample (data_set.py / test.py:61-68);
+ * the pressure systems of one mesh share their pattern, and the SpMV plan and the reordering depend on nothing else,
+ * so the next system costs an upload and a value permutation instead of a create (1M-DoF unstructured system: ~21 ms
+ * with reordering).  The preconditioner is dropped (it was computed from the old values): attach one again.  A handle
+ * that borrows its arrays (copy = 0) borrows `val` likewise: fp64, device, 16-byte aligned; it may be the same buffer
+ * rewritten in place. */
+int dpcg_update_values(dpcg_handle_t h, const void *val, int val_dtype, int memspace, dpcg_stream_t stream);
 int dpcg_reorder(dpcg_handle_t h, int mode, dpcg_stream_t stream, int *applied);
 /* *reordered = 0/1; perm_host (may be NULL): int32[n], perm[new] = old (row `new` of the iterated matrix is the
  * caller's row `old`); gather_ratio (may be NULL): x-gather line traffic / bytes used of the caller's matrix, as

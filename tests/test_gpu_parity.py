@@ -1199,6 +1199,68 @@ def test_randomised_differential_sample():
     assert "fuzz: 16 cases, 0 mismatches" in proc.stdout, proc.stdout[-3000:]
 
 
+@pytest.mark.parametrize("case", ["scrambled_reordered_64k", "natural_owned_host_upload", "borrowed_device_arrays", "small_whole_solve_kernel",
+                                  "fp32_values"])
+def test_update_values_on_the_same_pattern(D, case):
+    """dpcg_update_values: the next system of the same mesh keeps the plan and the reordering; every solve after it is the
+    solve of a handle created from the new matrix, bit for bit (SpMV, Jacobi / IC(0) PCG, the mixed-precision mode)."""
+    import torch
+    if case == "scrambled_reordered_64k":
+        A0 = O.unstructured_like(O.poisson3d(42), 3)
+        kw = dict(reorder="rcm")
+    elif case == "small_whole_solve_kernel":
+        A0 = O.poisson2d(40)
+        kw = dict(reorder=None)
+    else:
+        A0 = O.poisson3d(30)
+        kw = dict(reorder=None)
+    A1 = _scaled(A0, 11)                                   # same pattern, other values
+    assert np.array_equal(A0.indptr, A1.indptr) and np.array_equal(A0.indices, A1.indices)
+    if case == "fp32_values":
+        A0 = A0.astype(np.float32)
+        A1 = A1.astype(np.float32)
+    b = _dev(O.rhs(A0.shape[0], 5))
+    if case == "borrowed_device_arrays":
+        rp = torch.from_numpy(A0.indptr.astype(np.int32)).cuda()
+        ci = torch.from_numpy(A0.indices.astype(np.int32)).cuda()
+        v = torch.from_numpy(A0.data.copy()).cuda()
+        S = D.CsrSystem(rp, ci, v, A0.shape[0], **kw)
+    else:
+        S = D.CsrSystem.from_any(A0, **kw)
+    S.set_preconditioner(D.IC0("solve"))
+    S.solve(b)
+    S.solve(b, flags=D._lib.SPMV_F32)                      # (makes the fp32 copy of the OLD values)
+    if case == "borrowed_device_arrays":
+        v.copy_(torch.from_numpy(A1.data))                 # rewritten in place ...
+        S.update_values(v)                                 # ... and announced
+    else:
+        S.update_values(A1.data)
+    assert S.info()["precond"] == 0                        # the preconditioner was computed from the old values: dropped
+    F = D.CsrSystem.from_any(A1, **kw)                     # a handle created from the new matrix
+    assert S.reordered == F.reordered
+    x = _dev(O.rhs(A0.shape[0], 6))
+    assert torch.equal(S @ x, F @ x)
+    for pc, flags in ((D.Jacobi(), 0), (D.IC0("solve"), 0), (D.Jacobi(), D._lib.SPMV_F32), (D.Jacobi(), D._lib.NO_SMALL | D._lib.NO_TEAM)):
+        S.set_preconditioner(pc)
+        F.set_preconditioner(pc)
+        rs, rf = S.solve(b, flags=flags), F.solve(b, flags=flags)
+        assert rs.iterations == rf.iterations and torch.equal(rs.x, rf.x) and np.array_equal(rs.res_history, rf.res_history)
+    # and against the oracle on the new matrix
+    S.set_preconditioner(D.Jacobi())
+    A1d = A1.astype(np.float64)
+    perm = S.permutation()
+    B = A1d if perm is None else A1d[perm][:, perm].tocsr()
+    bo = b.cpu().numpy() if perm is None else b.cpu().numpy()[perm]
+    it, hist = CO.pcg(B, bo, "jacobi", dinv=O.jacobi_dinv(B))[1:3]
+    r = S.solve(b, flags=D._lib.NO_SMALL)
+    assert r.iterations == it
+    np.testing.assert_allclose(r.res_history, hist[:len(r.res_history)], rtol=HIST_RTOL)
+    with pytest.raises(ValueError):
+        S.update_values(A1.data[:-1])
+    S.close()
+    F.close()
+
+
 def test_device_block_cache_is_bounded_and_optional(D):
     """Setup routines keep freed device blocks for the next setup (dpcg_mem.hip).  The blocks can be handed back, the
     cache can be switched off (DPCG_CACHE_MB=0: the fuzz slice again, every free a hipFree), and a cached block never
