@@ -242,6 +242,7 @@ size_t cached_memory_bytes();
 // use on other streams (dpcg_destroy).
 struct SetupScope {
     hipStream_t stream;
+    int device = 0;
     bool owner = false;
     std::multimap<size_t, void *> idle;
     explicit SetupScope(hipStream_t s, bool wait_for_device = false);

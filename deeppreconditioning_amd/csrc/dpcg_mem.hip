@@ -6,8 +6,10 @@
 //     the SAME scope at once -- everything the scope enqueues goes to its one stream, so the reuse is ordered behind the
 //     last use -- and moves to the process-wide pool when the scope ends, after the stream has been waited for;
 //   * outside a scope a free waits for the device (what hipFree does) before the block goes to the pool.
-// So a block in the pool is never in use by the device, and any stream may take it.  The pool is bounded (DPCG_CACHE_MB,
-// default 1024; 0 switches the cache off); dpcg_release_cached_memory() returns it to the driver.
+// So a block in the pool is never in use by the device, and any stream may take it.  Blocks are kept per DEVICE (a process
+// may hold handles on several GPUs): a block serves requests made with its own device current, and a free that happens
+// with another device current waits for the block's device.  The pool is bounded (DPCG_CACHE_MB, default 1024, over all
+// devices; 0 switches the cache off); dpcg_release_cached_memory() returns it to the driver.
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -18,11 +20,15 @@
 namespace dpcg {
 
 namespace {
+struct Block {
+    size_t size;
+    int device;
+};
 struct Pool {
     std::mutex mu;
-    std::unordered_map<void *, size_t> size_of;          // every block handed out by cached_alloc and not yet returned to the driver
-    std::multimap<size_t, void *> free_blocks;           // idle, not in use by the device
-    size_t free_bytes = 0;
+    std::unordered_map<void *, Block> info;              // every block handed out by cached_alloc and not yet returned to the driver
+    std::map<int, std::multimap<size_t, void *>> free_blocks;   // per device: idle, not in use by the device
+    size_t free_bytes = 0;                               // over all devices
     size_t cap = 0;
     Pool() {
         const char *e = getenv("DPCG_CACHE_MB");
@@ -49,22 +55,32 @@ bool take_from(std::multimap<size_t, void *> &m, size_t want, void **out, size_t
     m.erase(it);
     return true;
 }
-void pool_insert(void *p, size_t size) {
+int current_device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+}
+void pool_insert(void *p, size_t size, int device) {
     Pool &P = pool();
     std::vector<void *> evict;
     {
         std::lock_guard<std::mutex> lock(P.mu);
-        P.free_blocks.emplace(size, p);
+        P.free_blocks[device].emplace(size, p);
         P.free_bytes += size;
-        while (P.free_bytes > P.cap && !P.free_blocks.empty()) {     // over the bound: the largest blocks go back to the driver
-            auto it = std::prev(P.free_blocks.end());
+        while (P.free_bytes > P.cap) {                   // over the bound: the largest blocks go back to the driver
+            std::multimap<size_t, void *> *largest = nullptr;
+            for (auto &kv : P.free_blocks)
+                if (!kv.second.empty() && (!largest || std::prev(kv.second.end())->first > std::prev(largest->end())->first))
+                    largest = &kv.second;
+            if (!largest) break;
+            auto it = std::prev(largest->end());
             P.free_bytes -= it->first;
-            P.size_of.erase(it->second);
+            P.info.erase(it->second);
             evict.push_back(it->second);
-            P.free_blocks.erase(it);
+            largest->erase(it);
         }
     }
-    for (void *q : evict) (void)hipFree(q);
+    for (void *q : evict) (void)hipFree(q);              // (hipFree finds the block's device itself)
 }
 }  // namespace
 
@@ -73,10 +89,11 @@ void release_cached_memory() {
     std::vector<void *> all;
     {
         std::lock_guard<std::mutex> lock(P.mu);
-        for (auto &kv : P.free_blocks) {
-            P.size_of.erase(kv.second);
-            all.push_back(kv.second);
-        }
+        for (auto &dev : P.free_blocks)
+            for (auto &kv : dev.second) {
+                P.info.erase(kv.second);
+                all.push_back(kv.second);
+            }
         P.free_blocks.clear();
         P.free_bytes = 0;
     }
@@ -94,11 +111,13 @@ hipError_t cached_alloc(void **out, size_t bytes) {
     *out = nullptr;
     if (P.cap == 0) return hipMalloc(out, bytes ? bytes : 1);
     const size_t want = rounded(bytes);
+    const int device = current_device();                 // a block serves requests on the device it was allocated on only
     size_t got = 0;
-    if (tl_scope && take_from(tl_scope->idle, want, out, &got)) return hipSuccess;
+    if (tl_scope && tl_scope->device == device && take_from(tl_scope->idle, want, out, &got)) return hipSuccess;
     {
         std::lock_guard<std::mutex> lock(P.mu);
-        if (take_from(P.free_blocks, want, out, &got)) {
+        auto dev = P.free_blocks.find(device);
+        if (dev != P.free_blocks.end() && take_from(dev->second, want, out, &got)) {
             P.free_bytes -= got;
             return hipSuccess;
         }
@@ -114,7 +133,7 @@ hipError_t cached_alloc(void **out, size_t bytes) {
         return e;
     }
     std::lock_guard<std::mutex> lock(P.mu);
-    P.size_of[*out] = want;
+    P.info[*out] = Block{want, device};
     return hipSuccess;
 }
 
@@ -122,13 +141,15 @@ void cached_free(void *p) {
     if (!p) return;
     Pool &P = pool();
     size_t size = 0;
+    int device = 0;
     {
         std::lock_guard<std::mutex> lock(P.mu);
-        auto it = P.size_of.find(p);
-        if (it != P.size_of.end()) {
-            size = it->second;
+        auto it = P.info.find(p);
+        if (it != P.info.end()) {
+            size = it->second.size;
+            device = it->second.device;
             if (P.cap == 0 || size > P.cap / 4) {        // too large to keep
-                P.size_of.erase(it);
+                P.info.erase(it);
                 size = 0;
             }
         }
@@ -137,17 +158,22 @@ void cached_free(void *p) {
         (void)hipFree(p);
         return;
     }
-    if (tl_scope) {
+    if (tl_scope && tl_scope->device == device) {
         tl_scope->idle.emplace(size, p);
         return;
     }
-    (void)hipDeviceSynchronize();                        // what hipFree would have waited for
-    pool_insert(p, size);
+    // what hipFree would have waited for: the device the block lives on
+    const int here = current_device();
+    if (here != device) (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    if (here != device) (void)hipSetDevice(here);
+    pool_insert(p, size, device);
 }
 
 SetupScope::SetupScope(hipStream_t s, bool wait_for_device) : stream(s) {
     if (tl_scope) return;                                // nested: the outer scope (same thread, same call) keeps the blocks
     owner = true;
+    device = current_device();                           // (the stream's device: the caller made it current)
     if (wait_for_device) (void)hipDeviceSynchronize();
     tl_scope = this;
 }
@@ -157,7 +183,7 @@ SetupScope::~SetupScope() {
     tl_scope = nullptr;
     // everything the scope enqueued has run when this returns: the blocks are idle, and the call's results are complete
     if (hipStreamSynchronize(stream) != hipSuccess) (void)hipDeviceSynchronize();
-    for (auto &kv : idle) pool_insert(kv.second, kv.first);
+    for (auto &kv : idle) pool_insert(kv.second, kv.first, device);
     idle.clear();
 }
 
