@@ -295,8 +295,11 @@ extern "C" int dpcg_create(dpcg_handle_t *out, int64_t n, int64_t nnz, const int
     hipStream_t s = (hipStream_t)stream;
     SetupScope scope(s);
     dpcg_system *h = new dpcg_system();
+    PhaseTimer pt(s);
     int st = upload_csr(h->A, n, nnz, rowptr, col, val, val_dtype, memspace, copy, s);
+    pt.mark("create: upload");
     if (st >= 0) st = make_plan(h->A, h->planA, s, true);
+    pt.mark("create: plan");
     HandleExtras ex;
     if (st >= 0 && hipStreamCreateWithFlags(&ex.cap_stream, hipStreamNonBlocking) != hipSuccess) st = DPCG_ERR_HIP;
     if (st >= 0 && hipHostMalloc((void **)&ex.prog_host, 64, hipHostMallocMapped) != hipSuccess) st = DPCG_ERR_HIP;
@@ -353,11 +356,15 @@ extern "C" int dpcg_reorder(dpcg_handle_t h, int mode, dpcg_stream_t stream, int
         // only where it pays: systems beyond one XCD's L2 reach whose plan is the gather kernel (no x-tile plan, or too
         // few row blocks for one) and whose gather really is scattered (measured 64^3 scrambled: 31K -> 55K it/s)
         if (h->planA.kernel != SPMV_STREAM || h->A.n < kReorderMinRows) return DPCG_OK;
+        PhaseTimer ptg(s);
         DPCG_TRY(gather_line_ratio(h->A, &h->gather_ratio, s));
+        ptg.mark("reorder: gather ratio");
         if (h->gather_ratio <= 4.0) return DPCG_OK;
     }
+    PhaseTimer pt(s);
     int32_t *perm = nullptr, *iperm = nullptr;
     int st = rcm_order(h->A, &perm, &iperm, nullptr, s);
+    pt.mark("reorder: RCM");
     if (st == DPCG_ERR_INVALID && mode == DPCG_REORDER_AUTO) return DPCG_OK;   // not a symmetric pattern: AUTO leaves the handle as it is
     if (st < 0) return st;
     // Everything that can fail is built FIRST, into locals; the handle is switched over only when all of it exists
@@ -365,7 +372,9 @@ extern "C" int dpcg_reorder(dpcg_handle_t h, int mode, dpcg_stream_t stream, int
     CsrDev B;
     SpmvPlan planB;
     st = permute_csr(h->A, perm, iperm, B, s);
+    pt.mark("reorder: permute");
     if (st >= 0) st = make_plan(B, planB, s, true);
+    pt.mark("reorder: plan");
     if (st < 0) {
         dev_free(perm);
         dev_free(iperm);

@@ -1,6 +1,9 @@
 // Host-side internals shared by dpcg_api.hip, dpcg_precond.hip and dpcg_solve.hip (not part of the ABI).
 #pragma once
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -20,6 +23,28 @@ using namespace dpcg;
 
 // sets dpcg_last_error() and returns DPCG_ERR_INVALID
 int invalid(const char *msg);
+
+// DPCG_SETUP_TRACE=1: phase times of the setup routines on stderr (development)
+struct PhaseTimer {
+    bool on;
+    hipStream_t s;
+    std::chrono::steady_clock::time_point t;
+    explicit PhaseTimer(hipStream_t stream) : s(stream) {
+        static const bool enabled = [] { const char *e = getenv("DPCG_SETUP_TRACE"); return e && e[0] == '1'; }();
+        on = enabled;
+        if (on) {
+            (void)hipStreamSynchronize(s);
+            t = std::chrono::steady_clock::now();
+        }
+    }
+    void mark(const char *what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[dpcg setup] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
 
 // ---- device memory ---------------------------------------------------------------------------------------
 template <typename T>

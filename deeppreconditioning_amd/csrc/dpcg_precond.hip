@@ -112,28 +112,6 @@ bool syncfree_enabled() {
     return on;
 }
 
-// DPCG_SETUP_TRACE=1: phase times of the preconditioner setup on stderr (development)
-struct PhaseTimer {
-    bool on;
-    hipStream_t s;
-    std::chrono::steady_clock::time_point t;
-    explicit PhaseTimer(hipStream_t stream) : s(stream) {
-        static const bool enabled = [] { const char *e = getenv("DPCG_SETUP_TRACE"); return e && e[0] == '1'; }();
-        on = enabled;
-        if (on) {
-            (void)hipStreamSynchronize(s);
-            t = std::chrono::steady_clock::now();
-        }
-    }
-    void mark(const char *what) {
-        if (!on) return;
-        (void)hipStreamSynchronize(s);
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[dpcg setup] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
-        t = now;
-    }
-};
-
 template <typename T>
 struct DevBuf {                       // scoped device allocation for the setup routines
     T *p = nullptr;

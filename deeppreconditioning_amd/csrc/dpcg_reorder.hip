@@ -433,6 +433,8 @@ int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_c
         *v = h == ~0ull ? -1 : (int)(h & 0xffffffffu);
         return DPCG_OK;
     };
+    PhaseTimer pt(s);
+    int n_bfs = 0;
     std::vector<int32_t> h_start, h_count;
     struct Comp { int L0, nl; std::vector<int32_t> start, count; };
     std::vector<Comp> comps;
@@ -443,6 +445,7 @@ int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_c
         if (root < 0) break;
         int nl = 0;
         DPCG_TRY(bfs(A, root, next_level, visited, level.p, order.p, start.p, count.p, h_start, h_count, &nl, s));
+        ++n_bfs;
         if (comps.empty()) {
             // pseudo-peripheral start vertex for the first (normally the only) component
             for (int sweep = 0; sweep < 4; ++sweep) {
@@ -456,6 +459,7 @@ int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_c
                 int nl2 = 0;
                 std::vector<int32_t> st2, ct2;
                 DPCG_TRY(bfs(A, cand, next_level, visited, level.p, order.p, start.p, count.p, st2, ct2, &nl2, s));
+                ++n_bfs;
                 const bool deeper = nl2 > nl;
                 root = cand;
                 nl = nl2;
@@ -476,7 +480,11 @@ int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_c
         // later searches index count[] / start[] from next_level on: clear what this search's empty tail steps touched
         comps.push_back(std::move(c));
     }
-    // Cuthill-McKee positions, component by component, level by level
+    if (pt.on) fprintf(stderr, "[dpcg setup]   %d breadth-first searches, %d levels\n", n_bfs, next_level);
+    pt.mark("  RCM: searches");
+    // Cuthill-McKee positions, component by component, level by level.  (Both level loops were also tried as ONE persistent launch
+    // each -- 64 workgroups, a grid barrier per phase, agent-scope accesses for what crosses workgroups: 23 / 56 us per level at 1M
+    // rows (3-D) against 14 / 29 us for the launches below; with release / acquire fences instead, which write the L2 back, 39 / 100 us.)
     for (const Comp &c : comps) {
         hipLaunchKernelGGL(k_cm_root, dim3(1), dim3(64), 0, s, order.p, pos.p, vertex_at.p, c.start[0]);
         for (int l = 1; l < c.nl; ++l) {
@@ -490,6 +498,7 @@ int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_c
                                vertex_at.p, pos.p, vertex_at.p, s1, c1, L);
         }
     }
+    pt.mark("  RCM: positions");
     if (visited < n) {   // more components than searches: the rest keeps its relative order at the end
         Buf<int32_t> flag, offs;
         DPCG_TRY(flag.alloc(n));
