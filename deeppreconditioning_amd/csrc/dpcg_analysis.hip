@@ -326,6 +326,48 @@ void launch_ic0_cross_terms(int64_t n, const int32_t *rp, const int32_t *ci, int
     hipLaunchKernelGGL(k_ic0_cross_terms, dim3(grid_rows(n, 1024)), dim3(kBlock), 0, s, n, rp, ci, flags_zeroed);
 }
 
+// Descriptors of the general factorisation through the ring walk (k_sptrsv_ring_pipe, FACTOR = 2), per level-order position j
+// of a lower pattern whose rows hold at most three off-diagonal entries (lo_*: the level-ordered copy, diagonal last):
+//   xdesc[j]: 2 bits for each of the entry pairs (p, q) = (0,1), (0,2), (1,2): 1 + the slot of column c_p among the
+//             off-diagonal entries of row c_q, 0 when row c_q has no such entry (no cross term);
+//   thr[4j + q] = tau * colnorm[c_q] (the drop threshold of entry q; thr == nullptr: nothing is dropped).
+__global__ __launch_bounds__(kBlock) void k_ring_factor_desc(int64_t n, const int32_t *__restrict__ lo_rp,
+                                                             const int32_t *__restrict__ lo_ci, const int32_t *__restrict__ lo_cp,
+                                                             const double *__restrict__ colnorm, double tau,
+                                                             int32_t *__restrict__ xdesc, double *__restrict__ thr) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        const int a = lo_rp[j], b = lo_rp[j + 1] - 1;                 // off-diagonals [a, b)
+        const int m = b - a < 3 ? b - a : 3;
+        int desc = 0;
+        for (int q = 1; q < m; ++q) {
+            const int pq = lo_cp[a + q];                               // position of row c_q
+            const int sa = lo_rp[pq], sb = lo_rp[pq + 1] - 1;
+            for (int p = 0; p < q; ++p) {
+                const int cp = lo_ci[a + p];
+                int slot = 0;
+                for (int k = sa; k < sb && k < sa + 3; ++k)
+                    if (lo_ci[k] == cp) slot = 1 + (k - sa);
+                const int pair = q == 1 ? 0 : 1 + p;                   // (0,1) -> 0, (0,2) -> 1, (1,2) -> 2
+                desc |= slot << (2 * pair);
+            }
+        }
+        xdesc[j] = desc;
+        if (thr) {
+            double t[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int q = 0; q < m; ++q) t[q] = tau * colnorm[lo_ci[a + q]];
+            reinterpret_cast<double2 *>(thr)[2 * j] = make_double2(t[0], t[1]);
+            reinterpret_cast<double2 *>(thr)[2 * j + 1] = make_double2(t[2], t[3]);
+        }
+    }
+}
+
+void launch_ring_factor_desc(int64_t n, const int32_t *lo_rp, const int32_t *lo_ci, const int32_t *lo_cp, const double *colnorm,
+                             double tau, int32_t *xdesc, double *thr, hipStream_t s) {
+    hipLaunchKernelGGL(k_ring_factor_desc, dim3(grid_rows(n, 1024)), dim3(kBlock), 0, s, n, lo_rp, lo_ci, lo_cp, colnorm, tau, xdesc,
+                       colnorm ? thr : nullptr);
+}
+
 void launch_max_band(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int *out_dev, hipStream_t s) {
     hipLaunchKernelGGL(k_max_band, dim3(grid_rows(n, 1024)), dim3(kBlock), 0, s, n, rp, ci, upper ? 1 : 0, out_dev);
 }

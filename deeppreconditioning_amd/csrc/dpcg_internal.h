@@ -336,7 +336,10 @@ void launch_dot_final(const double *part, int n_part, double *out_dev, hipStream
 void init_strip_kernels();
 // IC(0) through a strip plan (dpcg_sptrsv.hip: k_sptrsv_strips<..., FACTOR>)
 void launch_strip_factor(const Levels &lv, double *diag, double *fac, int64_t n, hipStream_t s);
-bool launch_ring_factor(const Levels &lv, double *diag, double *fac, hipStream_t s);
+bool launch_ring_factor(const Levels &lv, double *diag, double *fac, hipStream_t s, const int32_t *xdesc = nullptr,
+                        const double *thr = nullptr);
+void launch_ring_factor_desc(int64_t n, const int32_t *lo_rp, const int32_t *lo_ci, const int32_t *lo_cp, const double *colnorm,
+                             double tau, int32_t *xdesc, double *thr, hipStream_t s);
 void launch_strip_factor_scatter(int64_t n, const int32_t *frow, const int32_t *rp, const double *fac, double *fval,
                                  const int32_t *lo_rp, double *lo_val, int *bad, hipStream_t s);
 // done: optional device flag (Scalars::done); when set the kernels return at once

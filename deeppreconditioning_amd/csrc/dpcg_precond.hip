@@ -841,7 +841,7 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
         free_levels(pre);
         return fail(st2);
     };
-    bool through_schedule = false, plain = false;
+    bool through_schedule = false, plain = false, short_rows = false;   // plain: no cross terms, rows of <= 3 off-diagonal entries
     static const bool schedule_factor_on = [] { const char *ev = getenv("DPCG_IC0_STRIPS"); return !(ev && ev[0] == '0'); }();
     DevBuf<double> diag, fac;
     // records of L by position -> CSR values + the schedule's own copies; pivot check; the records' value array is swapped in
@@ -869,6 +869,7 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return fail(hip_fail(e, "IC(0): pattern check", __FILE__, __LINE__));
         plain = h_flags[0] == 0;
+        short_rows = (h_flags[0] & 2) == 0;
         e = hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), s);
         if (e != hipSuccess) return fail(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
         h_flags[0] = h_flags[1] = 0;
@@ -897,11 +898,16 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
         if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, *ls, s, cperm ? cperm : h->iperm)) < 0) return fail2(st);
         pt.mark("levels(tril A)");
         const int nl = (int)ls->level_ptr.size() - 1;
-        if (plain && !h->perm && n <= 131072 && nl >= 64) {
+        if (short_rows && !h->perm && n <= 131072 && nl >= 64) {
             // (build_levels takes the level sets over: if the schedule turns out not to be one ring walk, they are computed again)
             if ((st = build_levels(pre, *ls, n, Lf.nnz, Lf.rowptr, Lf.col, Lf.val, s, nullptr, false)) < 0) return fail2(st);
             if ((st = diag.alloc(n)) < 0 || (st = fac.alloc(4 * n)) < 0) return fail2(st);
-            if (launch_ring_factor(pre, diag.p, fac.p, s)) {
+            DevBuf<int32_t> xdesc;                          // a pattern with cross terms: the general form of the walk
+            if (!plain) {
+                if ((st = xdesc.alloc(n)) < 0) return fail2(st);
+                launch_ring_factor_desc(n, pre.lo_rowptr, pre.lo_col, pre.lo_cpos, nullptr, 0.0, xdesc.p, nullptr, s);
+            }
+            if (launch_ring_factor(pre, diag.p, fac.p, s, plain ? nullptr : xdesc.p, nullptr)) {
                 if ((st = harvest(pre.rows, pre.lo_rowptr, pre.lo_val, &pre.pk_val, "IC(0) through the ring walk")) < 0) return fail2(st);
                 through_schedule = true;
                 pt.mark("numeric IC(0) by the ring walk");
@@ -997,11 +1003,13 @@ extern "C" int dpcg_set_precond_ict(dpcg_handle_t h, int mode, int fill_in, doub
         return st;
     };
     int st = DPCG_OK;
-    if ((st = cnt.alloc(n + 1)) < 0 || (st = flags.alloc(2)) < 0 || (st = colnorm.alloc(n)) < 0 ||
+    if ((st = cnt.alloc(n + 1)) < 0 || (st = flags.alloc(4)) < 0 || (st = colnorm.alloc(n)) < 0 ||
         (st = dev_alloc(&S.rowptr, n + 1)) < 0 || (st = dev_alloc(&Lf.rowptr, n + 1)) < 0)
         return fail(st);
-    hipError_t e = hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), s);
+    // flags: [0] symbolic phase, [1] pivot (row + 1) of the level kernels, [2] pattern check, [3] pivot of the ring walk
+    hipError_t e = hipMemsetAsync(flags.p, 0, 4 * sizeof(int32_t), s);
     if (e != hipSuccess) return fail(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
+    PhaseTimer pt(s);
     launch_colnorm1(n, Asrc.rowptr, Asrc.col, Asrc.val, colnorm.p, s);
     launch_ict_pattern(false, n, Asrc.rowptr, Asrc.col, Asrc.val, fill_in > 0 ? 1 : 0, cnt.p, nullptr, nullptr, nullptr,
                        reinterpret_cast<int *>(flags.p), s);
@@ -1023,11 +1031,52 @@ extern "C" int dpcg_set_precond_ict(dpcg_handle_t h, int mode, int fill_in, doub
     if ((st = dev_alloc(&S.col, snnz)) < 0 || (st = dev_alloc(&S.val, snnz)) < 0) return fail(st);
     launch_ict_pattern(true, n, Asrc.rowptr, Asrc.col, Asrc.val, fill_in > 0 ? 1 : 0, nullptr, S.rowptr, S.col, S.val,
                        reinterpret_cast<int *>(flags.p), s);
-    LevelSort ls;
-    if ((st = compute_levels(n, S.rowptr, S.col, false, ls, s)) < 0) return fail(st);
-    if ((st = numeric_incomplete_cholesky(ls, n, S, reinterpret_cast<int *>(flags.p) + 1, colnorm.p, threshold, s)) < 0)
+    LevelSort ls_first, ls_again;
+    LevelSort *ls = &ls_first;
+    pt.mark("ICT: pattern with fill");
+    if ((st = compute_levels(n, S.rowptr, S.col, false, *ls, s)) < 0) return fail(st);
+    pt.mark("ICT: levels");
+    // A C2-size factor whose rows hold at most three off-diagonal entries (level-1 fill on a 5-point grid) and whose schedule is ONE
+    // LDS-ring segment is factored by the one-workgroup walk -- cross terms and the drop rule included (k_sptrsv_ring_pipe, FACTOR = 2)
+    // -- instead of one launch per level (256^2: 766 launches, 4.8 of the setup's 6.2 ms).  The schedule built for that is a
+    // temporary: dropping changes the pattern, and L gets its own below.
+    bool through_ring = false;
+    static const bool ring_factor_on = [] { const char *ev = getenv("DPCG_IC0_STRIPS"); return !(ev && ev[0] == '0'); }();
+    if (ring_factor_on && n >= 4096 && n <= 131072 && (int)ls->level_ptr.size() - 1 >= 64) {
+        launch_ic0_cross_terms(n, S.rowptr, S.col, reinterpret_cast<int *>(flags.p) + 2, s);
+        int32_t h_pat = 0;
+        e = hipMemcpyAsync(&h_pat, flags.p + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(hip_fail(e, "ICT: pattern check", __FILE__, __LINE__));
+        if (!(h_pat & 2)) {
+            Levels tmp;
+            DevBuf<int32_t> xdesc;
+            DevBuf<double> thr, diag, fac;
+            auto fail_tmp = [&](int st2) {
+                free_levels(tmp);
+                return fail(st2);
+            };
+            if ((st = build_levels(tmp, *ls, n, S.nnz, S.rowptr, S.col, S.val, s, nullptr, false)) < 0) return fail_tmp(st);
+            if ((st = xdesc.alloc(n)) < 0 || (st = thr.alloc(4 * n)) < 0 || (st = diag.alloc(n)) < 0 || (st = fac.alloc(4 * n)) < 0)
+                return fail_tmp(st);
+            launch_ring_factor_desc(n, tmp.lo_rowptr, tmp.lo_col, tmp.lo_cpos, colnorm.p, threshold, xdesc.p, thr.p, s);
+            if (launch_ring_factor(tmp, diag.p, fac.p, s, xdesc.p, thr.p)) {
+                launch_strip_factor_scatter(n, tmp.rows, S.rowptr, fac.p, S.val, tmp.lo_rowptr, tmp.lo_val,
+                                            reinterpret_cast<int *>(flags.p) + 3, s);
+                through_ring = true;
+            }
+            free_levels(tmp);
+            if (!through_ring) {                                   // (build_levels took the level sets over)
+                ls = &ls_again;
+                if ((st = compute_levels(n, S.rowptr, S.col, false, *ls, s)) < 0) return fail(st);
+            }
+        }
+    }
+    if (!through_ring &&
+        (st = numeric_incomplete_cholesky(*ls, n, S, reinterpret_cast<int *>(flags.p) + 1, colnorm.p, threshold, s)) < 0)
         return fail(st);
     // compaction: the dropped entries are stored zeros
+    pt.mark(through_ring ? "ICT: numeric (ring walk)" : "ICT: numeric (launch per level)");
     launch_count_kept(n, S.rowptr, S.col, S.val, cnt.p, s);
     if ((st = exclusive_scan_i32(cnt.p, Lf.rowptr, n + 1, s)) < 0) return fail(st);
     int32_t lnnz = 0;
@@ -1035,7 +1084,13 @@ extern "C" int dpcg_set_precond_ict(dpcg_handle_t h, int mode, int fill_in, doub
     if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(&lnnz, Lf.rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
+    int32_t h_ring_pivot = 0;
+    if (e == hipSuccess && through_ring) {
+        e = hipMemcpyAsync(&h_ring_pivot, flags.p + 3, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
     if (e != hipSuccess) return fail(hip_fail(e, "ICT: numeric factorisation", __FILE__, __LINE__));
+    if (h_ring_pivot) h_flags[1] = (0x7fffffff - h_ring_pivot) + 1;          // (row + 1, as the level kernels report it)
     if (h_flags[1]) {
         set_error("ICT: non-positive pivot at row " + std::to_string(h_flags[1] - 1));
         return fail(DPCG_ERR_PIVOT);
@@ -1048,6 +1103,7 @@ extern "C" int dpcg_set_precond_ict(dpcg_handle_t h, int mode, int fill_in, doub
     if (e != hipSuccess) return fail(hip_fail(e, "ICT: compaction", __FILE__, __LINE__));
     free_precond(h);
     h->L = Lf;
+    pt.mark("ICT: compaction");
     st = finish_llt(h, mode, s);
     if (st < 0) free_precond(h);
     return st;

@@ -289,9 +289,16 @@ __global__ __launch_bounds__(kBlock) void k_gather_lo(const int32_t *__restrict_
 // the next chunk fly into the other set; at a chunk boundary one s_waitcnt vmcnt(0) retires them (by then C levels
 // of work have covered the memory latency).  The explicit wait + register "touch" keeps the compiler from
 // inserting its own conservative vmcnt(0) at each first use, which would also wait for the loads just issued.
-// FACTOR: IC(0) of a cross-term-free pattern as a recurrence on the diagonals (see k_sptrsv_strips), for a factor whose whole
-// schedule is this one walk: records = the entries of tril(A), ring / out = the diagonals of L, fac = the records of L.
-template <bool UPPER, int C, int ROWS, bool FACTOR = false>   // ROWS rows of a level per thread, C levels per prefetch chunk
+// FACTOR = 1: IC(0) of a cross-term-free pattern as a recurrence on the diagonals (see k_sptrsv_strips), for a factor whose
+// whole schedule is this one walk: records = the entries of tril(A), ring / out = the diagonals of L, fac = the records of L.
+// FACTOR = 2: the general incomplete factorisation on rows of at most three off-diagonal entries -- cross terms and ICT's
+// drop rule included (the pattern with level-1 fill of a 5-point grid: the harness's default technique at its own size).
+// The ring then holds a row's WHOLE record {l0, l1, l2, diagonal} (4 doubles per position); xdesc[j] names, for the entry
+// pairs (0,1), (0,2), (1,2) of row j, the slot of column c_p in row c_q's record (2 bits each, 0 = no such entry: no cross
+// term), thr[4j + q] = threshold * ||A(c_q:n, c_q)||_1 (null: nothing is dropped).  Operation order as k_ic0_level: entries
+// in ascending columns; per entry the cross terms in ascending common column, one product and one subtraction at a time; the
+// quotient; the drop test |v| * d < thr; the diagonal minus the squares of the KEPT values in order; the root.
+template <bool UPPER, int C, int ROWS, int FACTOR = 0>   // ROWS rows of a level per thread, C levels per prefetch chunk
 __global__ __launch_bounds__(512) void k_sptrsv_ring_pipe(const int32_t *__restrict__ level_ptr, int lvl_lo,
                                                           int lvl_hi, const int32_t *__restrict__ lo_rp,
                                                           const int32_t *__restrict__ lo_ci,
@@ -300,10 +307,12 @@ __global__ __launch_bounds__(512) void k_sptrsv_ring_pipe(const int32_t *__restr
                                                           const int4 *__restrict__ pk_meta,
                                                           const double2 *__restrict__ pk_val,
                                                           const double *__restrict__ b_lo, double *out, int seg_start,
-                                                          int W, const int *done, double2 *__restrict__ fac = nullptr) {
+                                                          int W, const int *done, double2 *__restrict__ fac = nullptr,
+                                                          const int32_t *__restrict__ xdesc = nullptr,
+                                                          const double2 *__restrict__ thr = nullptr) {
     if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     extern __shared__ __attribute__((aligned(16))) double ring[];
-    int *lp = reinterpret_cast<int *>(ring + W);        // level offsets of this segment, padded with empty levels
+    int *lp = reinterpret_cast<int *>(ring + (FACTOR == 2 ? 4 * W : W));   // level offsets of this segment, padded with empty levels
     const int t = threadIdx.x, T = blockDim.x;
     const int nl = lvl_hi - lvl_lo;
     const int nchunks = (nl + C - 1) / C;
@@ -316,6 +325,9 @@ __global__ __launch_bounds__(512) void k_sptrsv_ring_pipe(const int32_t *__restr
         int4 m;          // cpos0..2, original row
         double2 v01, v2d;
         double b;
+        int xd;          // FACTOR 2: cross-term slots
+        double2 t01;     // FACTOR 2 with a drop rule: thresholds of entries 0, 1
+        double t2;       //                            ... and 2
     };
     auto load_row = [&](Row &r, int j, int hi) {
         const int jc = j < hi ? j : jmax;                 // lanes without a row load a valid record and ignore it
@@ -324,6 +336,16 @@ __global__ __launch_bounds__(512) void k_sptrsv_ring_pipe(const int32_t *__restr
         r.v01 = pk_val[2 * (int64_t)jc];
         r.v2d = pk_val[2 * (int64_t)jc + 1];
         r.b = FACTOR ? 0.0 : b_lo[jc];
+        r.xd = 0;
+        r.t01 = make_double2(0.0, 0.0);
+        r.t2 = 0.0;
+        if (FACTOR == 2) {
+            r.xd = xdesc[jc];
+            if (thr) {
+                r.t01 = thr[2 * (int64_t)jc];
+                r.t2 = thr[2 * (int64_t)jc + 1].x;
+            }
+        }
     };
     auto load_chunk = [&](Row (&S)[C][ROWS], int chunk) {
 #pragma unroll
@@ -344,6 +366,7 @@ __global__ __launch_bounds__(512) void k_sptrsv_ring_pipe(const int32_t *__restr
                 Row &r = S[d][h];
                 asm volatile("" : "+v"(r.m.x), "+v"(r.m.y), "+v"(r.m.z), "+v"(r.m.w), "+v"(r.v01.x), "+v"(r.v01.y),
                              "+v"(r.v2d.x), "+v"(r.v2d.y), "+v"(r.b));
+                if (FACTOR == 2) asm volatile("" : "+v"(r.xd), "+v"(r.t01.x), "+v"(r.t01.y), "+v"(r.t2));
             }
     };
     auto solve_row = [&](const Row &r) {
@@ -357,6 +380,46 @@ __global__ __launch_bounds__(512) void k_sptrsv_ring_pipe(const int32_t *__restr
                 const double yv = cp >= seg_start ? ring[cp & (W - 1)] : out[lo_ci[k]];
                 acc -= lo_v[k] * yv;
             }
+        } else if (FACTOR == 2) {
+            // positions of the three dependency rows in the ring of records
+            const int p0 = 4 * ((r.m.x < 0 ? 0 : r.m.x) & (W - 1)), p1 = 4 * ((r.m.y < 0 ? 0 : r.m.y) & (W - 1)),
+                      p2 = 4 * ((r.m.z < 0 ? 0 : r.m.z) & (W - 1));
+            const int s01 = (r.xd & 3) - 1, s02 = ((r.xd >> 2) & 3) - 1, s12 = ((r.xd >> 4) & 3) - 1;
+            const double d0 = ring[p0 + 3], d1 = ring[p1 + 3], d2 = ring[p2 + 3];
+            // the cross operands (slot 0 read when there is none: never used)
+            const double c01 = ring[p1 + (s01 < 0 ? 0 : s01)], c02 = ring[p2 + (s02 < 0 ? 0 : s02)],
+                         c12 = ring[p2 + (s12 < 0 ? 0 : s12)];
+            double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+            if (r.m.x >= 0) {
+                l0 = r.v01.x / d0;
+                if (thr && fabs(l0) * d0 < r.t01.x) l0 = 0.0;
+            }
+            if (r.m.y >= 0) {
+                double a1 = r.v01.y;
+                if (s01 >= 0) a1 -= l0 * c01;
+                l1 = a1 / d1;
+                if (thr && fabs(l1) * d1 < r.t01.y) l1 = 0.0;
+            }
+            if (r.m.z >= 0) {
+                double a2 = r.v2d.x;
+                if (s02 >= 0) a2 -= l0 * c02;
+                if (s12 >= 0) a2 -= l1 * c12;
+                l2 = a2 / d2;
+                if (thr && fabs(l2) * d2 < r.t2) l2 = 0.0;
+            }
+            acc = r.v2d.y;                                   // A_ii
+            if (r.m.x >= 0) acc -= l0 * l0;
+            if (r.m.y >= 0) acc -= l1 * l1;
+            if (r.m.z >= 0) acc -= l2 * l2;
+            acc = sqrt(acc);
+            if (valid) {
+                fac[2 * (int64_t)r.j] = make_double2(l0, l1);
+                fac[2 * (int64_t)r.j + 1] = make_double2(l2, acc);
+                double *slot = ring + 4 * (r.j & (W - 1));
+                slot[0] = l0; slot[1] = l1; slot[2] = l2; slot[3] = acc;
+                out[r.m.w] = acc;
+            }
+            return;
         } else {
             const double y0 = ring[(r.m.x < 0 ? 0 : r.m.x) & (W - 1)];
             const double y1 = ring[(r.m.y < 0 ? 0 : r.m.y) & (W - 1)];
@@ -865,24 +928,30 @@ void launch_strip_factor(const Levels &lv, double *diag, double *fac, int64_t n,
 
 // The same through the one-workgroup LDS-ring walk (a factor of <= 131 072 rows whose schedule is ONE ring segment: 2-D grids).
 // Returns false when the schedule is not of that form.
-bool launch_ring_factor(const Levels &lv, double *diag, double *fac, hipStream_t s) {
+// xdesc != null: the general form (cross terms; thr != null: with the drop rule) -- see k_sptrsv_ring_pipe, FACTOR = 2.
+bool launch_ring_factor(const Levels &lv, double *diag, double *fac, hipStream_t s, const int32_t *xdesc, const double *thr) {
     if (lv.segments.size() != 1 || lv.strips.n_strips > 0 || !lv.pk_meta) return false;
     const Levels::Segment &seg = lv.segments[0];
-    const size_t lds = (size_t)seg.ring_w * sizeof(double) + (size_t)(seg.hi - seg.lo + 4 * kRingChunk) * sizeof(int);
+    const size_t ring_doubles = (size_t)seg.ring_w * (xdesc ? 4 : 1);
+    const size_t lds = ring_doubles * sizeof(double) + (size_t)(seg.hi - seg.lo + 4 * kRingChunk) * sizeof(int);
     if (!(seg.merged && seg.ring_w > 0) || ring_pipe_disabled() || seg.max_width > 1024 || lds > 64 * 1024) return false;
     const int seg_start = lv.level_ptr[seg.lo], width = seg.max_width;
+#define DPCG_RING_FACTOR(CV, ROWSV, FV, threads)                                                                              \
+    hipLaunchKernelGGL((k_sptrsv_ring_pipe<false, CV, ROWSV, FV>), dim3(1), dim3(threads), lds, s, lv.level_ptr_dev, seg.lo,   \
+                       seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, (const int4 *)lv.pk_meta,                      \
+                       (const double2 *)lv.pk_val, nullptr, diag, seg_start, seg.ring_w, nullptr, (double2 *)fac, xdesc,      \
+                       (const double2 *)thr)
     if (width <= 512) {
         int threads = (width + 63) / 64 * 64;
         threads = threads < 64 ? 64 : threads;
-        hipLaunchKernelGGL((k_sptrsv_ring_pipe<false, kRingChunk, 1, true>), dim3(1), dim3(threads), lds, s, lv.level_ptr_dev, seg.lo,
-                           seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, (const int4 *)lv.pk_meta,
-                           (const double2 *)lv.pk_val, nullptr, diag, seg_start, seg.ring_w, nullptr, (double2 *)fac);
+        if (xdesc) DPCG_RING_FACTOR(kRingChunk, 1, 2, threads);
+        else DPCG_RING_FACTOR(kRingChunk, 1, 1, threads);
     } else {
         const int threads = ((width + 1) / 2 + 63) / 64 * 64;
-        hipLaunchKernelGGL((k_sptrsv_ring_pipe<false, kRingChunk / 2, 2, true>), dim3(1), dim3(threads), lds, s, lv.level_ptr_dev,
-                           seg.lo, seg.hi, lv.lo_rowptr, lv.lo_col, lv.lo_cpos, lv.lo_val, (const int4 *)lv.pk_meta,
-                           (const double2 *)lv.pk_val, nullptr, diag, seg_start, seg.ring_w, nullptr, (double2 *)fac);
+        if (xdesc) DPCG_RING_FACTOR(kRingChunk / 2, 2, 2, threads);
+        else DPCG_RING_FACTOR(kRingChunk / 2, 2, 1, threads);
     }
+#undef DPCG_RING_FACTOR
     return true;
 }
 

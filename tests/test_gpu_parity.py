@@ -1599,6 +1599,47 @@ def test_ict_level1_fill_with_drop_tolerance(D):
         D.ICT("solve", fill_in=-1)
 
 
+def _six_point(m):
+    """5-point grid plus the south-west / north-east diagonal: three lower entries a row, two of the three pairs joined."""
+    idx = np.arange(m * m).reshape(m, m)
+    pairs = [(idx[:, 1:], idx[:, :-1]), (idx[1:, :], idx[:-1, :]), (idx[1:, 1:], idx[:-1, :-1])]
+    r = np.concatenate([a.ravel() for a, _ in pairs])
+    c = np.concatenate([b.ravel() for _, b in pairs])
+    off = sp.coo_matrix((-np.ones(r.size), (r, c)), shape=(m * m, m * m)).tocsr()
+    A = (off + off.T + sp.diags(np.full(m * m, 6.5))).tocsr()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("case", ["ict_poisson2d_100_thr0.1", "ict_scaled_2d_100_thr0.02", "ict_scaled_2d_100_thr0", "ict_poisson2d_256_thr0.1",
+                                  "ic0_six_point_128_cross_terms"])
+def test_incomplete_factorisations_through_the_ring_walk(D, case):
+    """C2-size factors with rows of at most three off-diagonal entries are factored by ONE workgroup walking the LDS-ring
+    schedule, cross terms and ICT's drop rule included (k_sptrsv_ring_pipe, FACTOR = 2), instead of one launch per level:
+    the harness's default technique ICT(1, 0.1) at its own size, and IC(0) on a pattern with triangles.  The factor must be
+    the CPU restatement's bit for bit -- pattern after dropping and values."""
+    if case.startswith("ict"):
+        A = {"ict_poisson2d_100_thr0.1": lambda: O.poisson2d(100), "ict_scaled_2d_100_thr0.02": lambda: _scaled(O.poisson2d(100), 8),
+             "ict_scaled_2d_100_thr0": lambda: _scaled(O.poisson2d(100), 9), "ict_poisson2d_256_thr0.1": lambda: O.poisson2d(256)}[case]()
+        thr = float(case.split("thr")[1])
+        S = D.CsrSystem.from_any(A, reorder=None)
+        S.set_preconditioner(D.ICT("solve", fill_in=1, threshold=thr))
+        Lref = O.ict(A, 1, thr)
+    else:
+        A = _scaled(_six_point(128), 10)
+        S = D.CsrSystem.from_any(A, reorder=None)
+        S.set_preconditioner(D.IC0("solve"))
+        Lref = CO.ic0(A)
+    rp, ci, v = S.factor()
+    assert np.array_equal(rp, Lref.indptr) and np.array_equal(ci, Lref.indices)
+    assert np.array_equal(v, Lref.data)
+    r = O.rhs(A.shape[0], 3)
+    y_ref = CO.sptrsv_lower(Lref, r)
+    assert np.array_equal(S.sptrsv(_dev(r), upper=False).cpu().numpy(), y_ref)
+    assert np.array_equal(S.sptrsv(_dev(y_ref), upper=True).cpu().numpy(), CO.sptrsv_upper(CO.transpose_csr(Lref), y_ref))
+    S.close()
+
+
 def test_config4_full_size_system_against_the_oracle(D):
     """BASELINE config 4 at FULL size against the oracle itself, not only through properties: one 256^3 system (16.8M DoF,
     117M non-zeros, right-hand side of batch member 3) solved by the HIP path and by oracle/pcg_oracle.c on the host
