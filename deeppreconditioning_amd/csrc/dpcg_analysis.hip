@@ -75,6 +75,29 @@ __global__ __launch_bounds__(kBlock) void k_key_levels(int64_t n, const uint64_t
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) lvl[i] = (uint32_t)(key[i] >> 32);
 }
 
+// The level sets of a lower factor, read backwards, are level sets of its transpose: all dependencies of the upper solve run from
+// a higher lower-level to a lower one, and the rows of one lower level do not depend on each other in either direction.  Position
+// j of lower level l (range [p0, p1)) becomes position (n - p1) + (j - p0) of upper level nl - 1 - l: the rows of a level keep
+// their order.  lvl_lo[j] = lower level of position j.
+__global__ __launch_bounds__(kBlock) void k_reverse_levels(int64_t n, const int32_t *__restrict__ rows_lo,
+                                                           const uint32_t *__restrict__ lvl_lo,
+                                                           const int32_t *__restrict__ level_ptr_lo, int nl,
+                                                           int32_t *__restrict__ rows_up, uint32_t *__restrict__ lvl_up) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        const int l = (int)lvl_lo[j];
+        const int p0 = level_ptr_lo[l], p1 = level_ptr_lo[l + 1];
+        const int64_t ju = (n - p1) + (j - p0);
+        rows_up[ju] = rows_lo[j];
+        lvl_up[ju] = (uint32_t)(nl - 1 - l);
+    }
+}
+
+void launch_reverse_levels(int64_t n, const int32_t *rows_lo, const uint32_t *lvl_lo, const int32_t *level_ptr_lo, int nl,
+                           int32_t *rows_up, uint32_t *lvl_up, hipStream_t s) {
+    hipLaunchKernelGGL(k_reverse_levels, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows_lo, lvl_lo, level_ptr_lo, nl, rows_up, lvl_up);
+}
+
 void launch_level_keys(int64_t n, const int32_t *level, const int32_t *order_by, uint64_t *key, hipStream_t s) {
     hipLaunchKernelGGL(k_level_keys, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, level, order_by, key);
 }

@@ -179,6 +179,22 @@ int compute_levels(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, 
     return DPCG_OK;
 }
 
+// Level sets of L^T from those of L (k_reverse_levels): no second level analysis -- a chain of n_levels dependent hand-offs,
+// 0.4-0.9 ms for the factors of 65K-1M rows.  `lo` must still own its arrays (build_levels takes them over).
+int reversed_levels(int64_t n, const LevelSort &lo, LevelSort &up, hipStream_t s) {
+    const int nl = (int)lo.level_ptr.size() - 1;
+    DPCG_TRY(up.rows.alloc(n));
+    DPCG_TRY(up.lvl_of_pos.alloc(n));
+    DPCG_TRY(up.level_ptr_dev.alloc((int64_t)nl + 1));
+    launch_reverse_levels(n, lo.rows.p, lo.lvl_of_pos.p, lo.level_ptr_dev.p, nl, up.rows.p, up.lvl_of_pos.p, s);
+    up.level_ptr.resize((size_t)nl + 1);
+    for (int l = 0; l <= nl; ++l) up.level_ptr[(size_t)l] = (int32_t)(n - lo.level_ptr[(size_t)(nl - l)]);
+    DPCG_HIP(hipMemcpyAsync(up.level_ptr_dev.p, up.level_ptr.data(), up.level_ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    DPCG_HIP(hipStreamSynchronize(s));     // (the host vector is the source of an asynchronous copy)
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
 // The numeric phase of IC(0) / ICT on the pattern held in F (values: the matrix entries, zeros at fill positions): one
 // launch per level, one thread per row.  (A sync-free single launch, rows polling `ready` flags, was measured and
 // dropped: every read of another row then has to bypass the L1, and with the whole factor resident the polling drowned
@@ -647,7 +663,10 @@ int transpose_lower(const CsrDev &L, CsrDev &Lt, hipStream_t s) {
 // in solve mode, the level schedules.  `lower_levels`: level analysis of L when the caller already has it (IC(0)).
 // `lower_prebuilt`: the schedule of L when IC(0) was factored THROUGH it (a strip plan -- its global level sets were never
 // computed, n_levels = -1: counted when dpcg_get_info asks -- or a one-segment LDS-ring schedule).
-int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels = nullptr, Levels *lower_prebuilt = nullptr) {
+// `upper_levels`: level sets of L^T the caller already has (the reversed level sets of L, taken before a prebuilt schedule took
+// those over).
+int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels = nullptr, Levels *lower_prebuilt = nullptr,
+               LevelSort *upper_levels = nullptr) {
     const int64_t n = h->A.n;
     DevBuf<int32_t> flags;
     DPCG_TRY(flags.alloc(1));
@@ -679,7 +698,9 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
     }
     pt.mark("plans");
     if (mode == DPCG_PRECOND_LLT_SOLVE) {
-        LevelSort own, up;
+        LevelSort own, up_own;
+        LevelSort &up = upper_levels ? *upper_levels : up_own;
+        bool have_up = upper_levels != nullptr;
         // Large factors try the strip plan FIRST and build the level schedule (level-ordered copy, ring / sync-free records)
         // only when it is not kept; small ones build the schedule first because the choice depends on it.
         auto schedule = [&](Levels &lv, LevelSort &ls, const CsrDev &F, bool upper) -> int {
@@ -725,6 +746,12 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
                 lower_levels = &own;
                 pt.mark("levels(L)");
             }
+            // the level sets of L^T are those of L read backwards (taken before the schedule of L takes the arrays over)
+            static const bool reverse_on = [] { const char *e = getenv("DPCG_REVERSE_LEVELS"); return !(e && e[0] == '0'); }();
+            if (reverse_on) {
+                DPCG_TRY(reversed_levels(n, *lower_levels, up, s));
+                have_up = true;
+            }
             DPCG_TRY(schedule(h->lvlL, *lower_levels, h->L, false));
             pt.mark("schedule(L)");
         }
@@ -738,8 +765,10 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
             if (h->lvlU.strips.n_strips == 0) dev_free(h->lvlU.spin_err);
         }
         if (h->lvlU.strips.n_strips == 0) {
-            DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s, fm));
-            pt.mark("levels(L^T)");
+            if (!have_up) {
+                DPCG_TRY(compute_levels(n, h->Lt.rowptr, h->Lt.col, true, up, s, fm));
+                pt.mark("levels(L^T)");
+            }
             DPCG_TRY(schedule(h->lvlU, up, h->Lt, true));
         }
         pt.mark("schedule(L^T)");
@@ -892,14 +921,16 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
             free_levels(pre);
         }
     }
-    LevelSort ls_first, ls_again;
+    LevelSort ls_first, ls_again, up_from_lower;
     LevelSort *ls = &ls_first;
+    bool have_upper = false;
     if (!through_schedule) {
         if ((st = compute_levels(n, Lf.rowptr, Lf.col, false, *ls, s, cperm ? cperm : h->iperm)) < 0) return fail2(st);
         pt.mark("levels(tril A)");
         const int nl = (int)ls->level_ptr.size() - 1;
         if (short_rows && !h->perm && n <= 131072 && nl >= 64) {
             // (build_levels takes the level sets over: if the schedule turns out not to be one ring walk, they are computed again)
+            if (mode == DPCG_PRECOND_LLT_SOLVE && (st = reversed_levels(n, *ls, up_from_lower, s)) < 0) return fail2(st);
             if ((st = build_levels(pre, *ls, n, Lf.nnz, Lf.rowptr, Lf.col, Lf.val, s, nullptr, false)) < 0) return fail2(st);
             if ((st = diag.alloc(n)) < 0 || (st = fac.alloc(4 * n)) < 0) return fail2(st);
             DevBuf<int32_t> xdesc;                          // a pattern with cross terms: the general form of the walk
@@ -910,6 +941,7 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
             if (launch_ring_factor(pre, diag.p, fac.p, s, plain ? nullptr : xdesc.p, nullptr)) {
                 if ((st = harvest(pre.rows, pre.lo_rowptr, pre.lo_val, &pre.pk_val, "IC(0) through the ring walk")) < 0) return fail2(st);
                 through_schedule = true;
+                have_upper = mode == DPCG_PRECOND_LLT_SOLVE;
                 pt.mark("numeric IC(0) by the ring walk");
             } else {
                 free_levels(pre);
@@ -937,7 +969,7 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
     h->fmap_inv = ciperm;
     h->precond_colors = n_colors;
     const bool keep_schedule = through_schedule && mode == DPCG_PRECOND_LLT_SOLVE;
-    st = finish_llt(h, mode, s, through_schedule ? nullptr : ls, keep_schedule ? &pre : nullptr);
+    st = finish_llt(h, mode, s, through_schedule ? nullptr : ls, keep_schedule ? &pre : nullptr, have_upper ? &up_from_lower : nullptr);
     free_levels(pre);                 // (multiply mode: the schedule only served the factorisation)
     if (st < 0) free_precond(h);
     return st;
