@@ -1118,7 +1118,12 @@ static void launch_schedule(int64_t n, const Levels &lv, bool upper, bool lm, co
             // (level-major factors: wide levels, where the polling loads of rows ahead of the front are what costs.  Scrambled
             // 1M-DoF IC(0), us per apply at 0.35 / 0.5 / 0.7 / 0.85 / 1 / 1.2 / 1.5 / 2 / 3 / 4 x the widest level:
             // 193 / 165 / 148 / 143 / 148 / 154 / 157 / 173 / 239 / 358)
-            const double factor = factor_env > 0.0 ? factor_env : (lm ? 0.85 : 2.0);
+            // The best window shrinks, relative to the level, as the levels widen (PCG update at 0.85 / 1.7 / 3 / 6 x the widest level:
+            // 64^3, 14.5K rows a level: 85.6 / 72.2 / 70.9 / 102 us; 256^2, 5K: 50.9 / 45.2 / 44.8 / 46.0; 40^3, 3.4K: 84.1 / 76.7 /
+            // 78.7 / 85.0; 1024^2, 58K: 130 / 146 / 153 / 154; 100^3, 53K: 136 / 153 (1.7)): 2.5 x up to a MEAN width of 16K rows, 0.85 x from 40K.
+            const double w_lm = (double)cnt / (double)(seg.hi - seg.lo);          // mean level width of the segment
+            const double factor_lm = w_lm <= 16000.0 ? 2.5 : (w_lm >= 40000.0 ? 0.85 : 2.5 - (w_lm - 16000.0) / 24000.0 * 1.65);
+            const double factor = factor_env > 0.0 ? factor_env : (lm ? factor_lm : 2.0);
             int grid = ((int)(factor * seg.max_width) + kBlock - 1) / kBlock + 4;
             grid = grid < 16 ? 16 : grid;
             grid = grid > nblocks ? nblocks : grid;
