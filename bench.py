@@ -280,6 +280,14 @@ def main() -> None:
                                                                       max(v for k, v in ceilings.items() if isinstance(v, float)
                                                                           and not k.startswith("cache_resident"))), 4)},
         }
+        if args.precond == "jacobi" and not info["two_kernel_updates"]:
+            # the whole PCG update of the timed solve against the same peak: K1 + K2 (q, r, dinv read; r written) + K3 (r, dinv, p read;
+            # p written; every other update also p', x read and x written) = B_spmv + 9.5 n x 8 bytes, over wall time per update
+            b_upd = b_alg + int(9.5 * 8 * n)
+            us_upd = t / max(total_iters, 1.0) * world * 1e6
+            line["roofline"]["whole_update"] = {"algorithmic_bytes": b_upd, "us": round(us_upd, 2),
+                                                "achieved": round(b_upd / (us_upd * 1e-6) / 1e9, 1),
+                                                "frac": round(b_upd / (us_upd * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         line["roofline"]["regime"] = ("cache_resident_1M: the ~150 MB working set of the headline system lives in the 256 MiB "
                                       "Infinity Cache, so `achieved` is fabric, not DRAM, bandwidth; the HBM-bound figure is "
                                       "`hbm_bound_256cubed` below")
