@@ -335,7 +335,8 @@ void launch_dot_final(const double *part, int n_part, double *out_dev, hipStream
 
 void init_strip_kernels();
 // IC(0) through a strip plan (dpcg_sptrsv.hip: k_sptrsv_strips<..., FACTOR>)
-void launch_strip_factor(const Levels &lv, double *diag, double *fac, int64_t n, hipStream_t s);
+bool launch_strip_factor(const Levels &lv, double *diag, double *fac, int64_t n, hipStream_t s, const int32_t *xdesc = nullptr,
+                         const double *thr = nullptr, double *offd = nullptr);
 bool launch_ring_factor(const Levels &lv, double *diag, double *fac, hipStream_t s, const int32_t *xdesc = nullptr,
                         const double *thr = nullptr);
 void launch_ring_factor_desc(int64_t n, const int32_t *lo_rp, const int32_t *lo_ci, const int32_t *lo_cp, const double *colnorm,

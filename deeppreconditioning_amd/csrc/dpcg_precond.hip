@@ -903,16 +903,24 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
         if (e != hipSuccess) return fail(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
         h_flags[0] = h_flags[1] = 0;
     }
-    if (plain && n > 131072) {
-        DevBuf<int32_t> frows;
+    if (short_rows && n > 131072) {
+        DevBuf<int32_t> frows, xdesc;
+        DevBuf<double> offd;
         if ((st = dev_alloc(&pre.spin_err, 1)) < 0) return fail2(st);
         e = hipMemsetAsync(pre.spin_err, 0, sizeof(int), s);
         if (e != hipSuccess) return fail2(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
         if ((st = build_strips(pre, n, Lf.nnz, Lf.rowptr, Lf.col, Lf.val, false, h->iperm, s, false, &frows)) < 0) return fail2(st);
+        bool launched = false;
         if (pre.strips.n_strips > 0 && pre.strips.long_rows == 0) {
             pt.mark("strip plan (tril A)");
             if ((st = diag.alloc(n)) < 0 || (st = fac.alloc(4 * n)) < 0) return fail2(st);
-            launch_strip_factor(pre, diag.p, fac.p, n, s);
+            if (!plain) {                                   // cross terms: the general form of the walk
+                if ((st = xdesc.alloc(n)) < 0 || (st = offd.alloc(3 * n)) < 0) return fail2(st);
+                launch_ring_factor_desc(n, pre.strips.lo_rowptr, pre.strips.lo_col, pre.strips.lo_cpos, nullptr, 0.0, xdesc.p, nullptr, s);
+            }
+            launched = launch_strip_factor(pre, diag.p, fac.p, n, s, plain ? nullptr : xdesc.p, nullptr, plain ? nullptr : offd.p);
+        }
+        if (launched) {
             if ((st = harvest(frows.p, pre.strips.lo_rowptr, pre.strips.lo_val, &pre.strips.val, "IC(0) through the strip plan")) < 0)
                 return fail2(st);
             through_schedule = true;
@@ -1066,20 +1074,59 @@ extern "C" int dpcg_set_precond_ict(dpcg_handle_t h, int mode, int fill_in, doub
     LevelSort ls_first, ls_again;
     LevelSort *ls = &ls_first;
     pt.mark("ICT: pattern with fill");
-    if ((st = compute_levels(n, S.rowptr, S.col, false, *ls, s)) < 0) return fail(st);
-    pt.mark("ICT: levels");
+    bool through_ring = false;       // (the numeric phase ran through a schedule: the ring walk or the strips)
+    static const bool ring_factor_on = [] { const char *ev = getenv("DPCG_IC0_STRIPS"); return !(ev && ev[0] == '0'); }();
+    int32_t h_pat = 2;               // pattern check: bit 1 = a row with more than three off-diagonal entries
+    if (ring_factor_on && n >= 4096) {
+        launch_ic0_cross_terms(n, S.rowptr, S.col, reinterpret_cast<int *>(flags.p) + 2, s);
+        e = hipMemcpyAsync(&h_pat, flags.p + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(hip_fail(e, "ICT: pattern check", __FILE__, __LINE__));
+    }
+    // Beyond 131 072 rows a banded pattern takes the strip walk (general form), before any level analysis
+    if (!(h_pat & 2) && n > 131072) {
+        Levels tmp;
+        DevBuf<int32_t> frows, xdesc;
+        DevBuf<double> thr, diag, fac, offd;
+        auto fail_tmp = [&](int st2) {
+            free_levels(tmp);
+            return fail(st2);
+        };
+        if ((st = dev_alloc(&tmp.spin_err, 1)) < 0) return fail_tmp(st);
+        e = hipMemsetAsync(tmp.spin_err, 0, sizeof(int), s);
+        if (e != hipSuccess) return fail_tmp(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
+        if ((st = build_strips(tmp, n, S.nnz, S.rowptr, S.col, S.val, false, nullptr, s, false, &frows)) < 0) return fail_tmp(st);
+        if (tmp.strips.n_strips > 0 && tmp.strips.long_rows == 0) {
+            if ((st = xdesc.alloc(n)) < 0 || (st = thr.alloc(4 * n)) < 0 || (st = diag.alloc(n)) < 0 || (st = fac.alloc(4 * n)) < 0 ||
+                (st = offd.alloc(3 * n)) < 0)
+                return fail_tmp(st);
+            launch_ring_factor_desc(n, tmp.strips.lo_rowptr, tmp.strips.lo_col, tmp.strips.lo_cpos, colnorm.p, threshold, xdesc.p, thr.p, s);
+            if (launch_strip_factor(tmp, diag.p, fac.p, n, s, xdesc.p, thr.p, offd.p)) {
+                launch_strip_factor_scatter(n, frows.p, S.rowptr, fac.p, S.val, tmp.strips.lo_rowptr, tmp.strips.lo_val,
+                                            reinterpret_cast<int *>(flags.p) + 3, s);
+                int32_t h_spin = 0;
+                e = hipMemcpyAsync(&h_spin, tmp.spin_err, sizeof(int), hipMemcpyDeviceToHost, s);
+                if (e == hipSuccess) e = hipStreamSynchronize(s);
+                if (e != hipSuccess) return fail_tmp(hip_fail(e, "ICT through the strip plan", __FILE__, __LINE__));
+                if (h_spin) {
+                    set_error("ICT through the strip plan: a bounded wait ran out");
+                    return fail_tmp(DPCG_ERR_HIP);
+                }
+                through_ring = true;
+                pt.mark("ICT: numeric (strips)");
+            }
+        }
+        free_levels(tmp);
+    }
+    if (!through_ring) {
+        if ((st = compute_levels(n, S.rowptr, S.col, false, *ls, s)) < 0) return fail(st);
+        pt.mark("ICT: levels");
+    }
     // A C2-size factor whose rows hold at most three off-diagonal entries (level-1 fill on a 5-point grid) and whose schedule is ONE
     // LDS-ring segment is factored by the one-workgroup walk -- cross terms and the drop rule included (k_sptrsv_ring_pipe, FACTOR = 2)
     // -- instead of one launch per level (256^2: 766 launches, 4.8 of the setup's 6.2 ms).  The schedule built for that is a
     // temporary: dropping changes the pattern, and L gets its own below.
-    bool through_ring = false;
-    static const bool ring_factor_on = [] { const char *ev = getenv("DPCG_IC0_STRIPS"); return !(ev && ev[0] == '0'); }();
-    if (ring_factor_on && n >= 4096 && n <= 131072 && (int)ls->level_ptr.size() - 1 >= 64) {
-        launch_ic0_cross_terms(n, S.rowptr, S.col, reinterpret_cast<int *>(flags.p) + 2, s);
-        int32_t h_pat = 0;
-        e = hipMemcpyAsync(&h_pat, flags.p + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return fail(hip_fail(e, "ICT: pattern check", __FILE__, __LINE__));
+    if (!through_ring && n <= 131072 && (int)ls->level_ptr.size() - 1 >= 64) {
         if (!(h_pat & 2)) {
             Levels tmp;
             DevBuf<int32_t> xdesc;
@@ -1108,7 +1155,7 @@ extern "C" int dpcg_set_precond_ict(dpcg_handle_t h, int mode, int fill_in, doub
         (st = numeric_incomplete_cholesky(*ls, n, S, reinterpret_cast<int *>(flags.p) + 1, colnorm.p, threshold, s)) < 0)
         return fail(st);
     // compaction: the dropped entries are stored zeros
-    pt.mark(through_ring ? "ICT: numeric (ring walk)" : "ICT: numeric (launch per level)");
+    pt.mark(through_ring ? "ICT: numeric (through the schedule)" : "ICT: numeric (launch per level)");
     launch_count_kept(n, S.rowptr, S.col, S.val, cnt.p, s);
     if ((st = exclusive_scan_i32(cnt.p, Lf.rowptr, n + 1, s)) < 0) return fail(st);
     int32_t lnnz = 0;

@@ -692,7 +692,11 @@ __global__ __launch_bounds__(kBlock) void k_strip_prepare(const int32_t *__restr
 // the records holding the entries of tril(A) and `out` / the ring the diagonals of L.  Operation order as k_ic0_level:
 // ascending columns, the quotient, then one product and one subtraction at a time, then the root.  The factor's values go
 // to fac (the records of the SAME plan, which thereby becomes the plan of L) and are scattered to CSR by k_strip_factor_scatter.
-template <bool UPPER, int C, int ROWS, bool FACTOR = false>
+// FACTOR = 2: the general form (cross terms, ICT's drop rule) for rows of at most three off-diagonal entries, as in
+// k_sptrsv_ring_pipe: the ring holds whole records {l0, l1, l2, diagonal}, xdesc names the cross-term slots, thr the drop thresholds;
+// what another strip needs of a row -- its diagonal AND its off-diagonal values -- is published in out (diagonals) and out3
+// (3 values per row), every value self-validating ("pending" until stored), asked for per chunk and polled per value.
+template <bool UPPER, int C, int ROWS, int FACTOR = 0>
 __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict__ level_ptr, int nlev,
                                                        const int32_t *__restrict__ lo_rp, const int32_t *__restrict__ lo_ci,
                                                        const int32_t *__restrict__ lo_cpos, const double *__restrict__ lo_v,
@@ -700,12 +704,14 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
                                                        const double *__restrict__ b_lo, double *out, int W,
                                                        int ring_reach, unsigned int *ticket, const int *done, int *err,
                                                        long long *trace /* development: per strip {start, end, polls, levels} */,
-                                                       double2 *__restrict__ fac = nullptr /* FACTOR: records of L, by position */) {
+                                                       double2 *__restrict__ fac = nullptr /* FACTOR: records of L, by position */,
+                                                       const int32_t *__restrict__ xdesc = nullptr,
+                                                       const double2 *__restrict__ thr = nullptr, double *out3 = nullptr) {
     if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     extern __shared__ __attribute__((aligned(16))) double ring[];
     const long long t_start = trace ? (long long)wall_clock64() : 0;
     int n_polls = 0;
-    int *lp = reinterpret_cast<int *>(ring + W);        // level offsets of this strip, padded with empty levels
+    int *lp = reinterpret_cast<int *>(ring + (FACTOR == 2 ? 4 * W : W));   // level offsets of this strip, padded with empty levels
     __shared__ unsigned int s_strip;
     __shared__ int s_nl;
     const int t = threadIdx.x, T = blockDim.x;
@@ -729,6 +735,9 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
         int4 m;          // d0..d2, own row index
         double2 v01, v2d;
         double b;
+        int xd;          // FACTOR 2: cross-term slots
+        double2 t01;     // FACTOR 2 with a drop rule: thresholds of entries 0, 1
+        double t2;       //                            ... and 2
     };
     auto load_row = [&](Row &r, int j, int hi) {
         const int jc = j < hi ? j : jmax;                 // lanes without a row load a valid record and ignore it
@@ -737,6 +746,16 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
         r.v01 = pk_val[2 * (int64_t)jc];
         r.v2d = pk_val[2 * (int64_t)jc + 1];
         r.b = FACTOR ? 0.0 : b_lo[jc];
+        r.xd = 0;
+        r.t01 = make_double2(0.0, 0.0);
+        r.t2 = 0.0;
+        if (FACTOR == 2) {
+            r.xd = xdesc[jc];
+            if (thr) {
+                r.t01 = thr[2 * (int64_t)jc];
+                r.t2 = thr[2 * (int64_t)jc + 1].x;
+            }
+        }
     };
     auto load_chunk = [&](Row (&S)[C][ROWS], int chunk) {
 #pragma unroll
@@ -756,6 +775,7 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
                 Row &r = S[d][h];
                 asm volatile("" : "+v"(r.m.x), "+v"(r.m.y), "+v"(r.m.z), "+v"(r.m.w), "+v"(r.v01.x), "+v"(r.v01.y),
                              "+v"(r.v2d.x), "+v"(r.v2d.y), "+v"(r.b));
+                if (FACTOR == 2) asm volatile("" : "+v"(r.xd), "+v"(r.t01.x), "+v"(r.t01.y), "+v"(r.t2));
             }
     };
     // an entry of an earlier strip: poll until its owner has stored it (bounded)
@@ -780,10 +800,32 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
     // that name them have just been retired); a value that is still pending then is polled when its row is solved.  The
     // hand-off latency is paid once per C levels instead of once per level, and the steady-state lag of a strip behind
     // its predecessor grows accordingly.
-    struct Ext { double y0, y1, y2; };
+    struct Ext { double y0, y1, y2, c01, c02, c12; };
     const double pend = __longlong_as_double((long long)kPendingBits);
     auto ask = [&](int d, bool valid) {
         return (valid && d <= -2) ? __hip_atomic_load(out + (-2 - d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    };
+    // FACTOR 2: off-diagonal value `slot` of the row of an EARLIER strip (column -2 - d), asked for / polled like a diagonal
+    auto ask3 = [&](int d, int slot, bool valid) {
+        return (valid && d <= -2 && slot >= 0)
+                   ? __hip_atomic_load(out3 + 3 * (int64_t)(-2 - d) + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    };
+    auto poll3 = [&](int col, int slot) {
+        double y;
+        ++n_polls;
+        unsigned spins = 0;
+        unsigned long long t_wait = 0;
+        for (;;) {
+            y = __hip_atomic_load(out3 + 3 * (int64_t)col + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!is_pending(y)) break;
+            if (spin_expired(spins, t_wait)) {
+                atomicExch(err, 1);
+                y = __builtin_nan("");
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return y;
     };
     auto solve_row = [&](const Row &r, const Ext &e) {
         const bool valid = r.j >= 0;
@@ -797,6 +839,64 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
                 const double yv = near ? ring[cp & (W - 1)] : poll(lo_ci[k]);
                 acc -= lo_v[k] * yv;
             }
+        } else if (FACTOR == 2) {
+            const int p0 = 4 * ((r.m.x < 0 ? 0 : r.m.x) & (W - 1)), p1 = 4 * ((r.m.y < 0 ? 0 : r.m.y) & (W - 1)),
+                      p2 = 4 * ((r.m.z < 0 ? 0 : r.m.z) & (W - 1));
+            const int s01 = (r.xd & 3) - 1, s02 = ((r.xd >> 2) & 3) - 1, s12 = ((r.xd >> 4) & 3) - 1;
+            // diagonals and cross operands of the dependency rows: from the ring (own strip) or published by an earlier strip
+            double d0 = ring[p0 + 3], d1 = ring[p1 + 3], d2 = ring[p2 + 3];
+            double c01 = ring[p1 + (s01 < 0 ? 0 : s01)], c02 = ring[p2 + (s02 < 0 ? 0 : s02)], c12 = ring[p2 + (s12 < 0 ? 0 : s12)];
+            if (valid) {
+                if (r.m.x <= -2) d0 = is_pending(e.y0) ? poll(-2 - r.m.x) : e.y0;
+                if (r.m.y <= -2) {
+                    d1 = is_pending(e.y1) ? poll(-2 - r.m.y) : e.y1;
+                    if (s01 >= 0) c01 = is_pending(e.c01) ? poll3(-2 - r.m.y, s01) : e.c01;
+                }
+                if (r.m.z <= -2) {
+                    d2 = is_pending(e.y2) ? poll(-2 - r.m.z) : e.y2;
+                    if (s02 >= 0) c02 = is_pending(e.c02) ? poll3(-2 - r.m.z, s02) : e.c02;
+                    if (s12 >= 0) c12 = is_pending(e.c12) ? poll3(-2 - r.m.z, s12) : e.c12;
+                }
+            }
+            double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+            if (r.m.x != -1) {
+                l0 = r.v01.x / d0;
+                if (thr && fabs(l0) * d0 < r.t01.x) l0 = 0.0;
+            }
+            if (r.m.y != -1) {
+                double a1 = r.v01.y;
+                if (s01 >= 0) a1 -= l0 * c01;
+                l1 = a1 / d1;
+                if (thr && fabs(l1) * d1 < r.t01.y) l1 = 0.0;
+            }
+            if (r.m.z != -1) {
+                double a2 = r.v2d.x;
+                if (s02 >= 0) a2 -= l0 * c02;
+                if (s12 >= 0) a2 -= l1 * c12;
+                l2 = a2 / d2;
+                if (thr && fabs(l2) * d2 < r.t2) l2 = 0.0;
+            }
+            acc = r.v2d.y;                                   // A_ii
+            if (r.m.x != -1) acc -= l0 * l0;
+            if (r.m.y != -1) acc -= l1 * l1;
+            if (r.m.z != -1) acc -= l2 * l2;
+            acc = sqrt(acc);
+            if (valid) {
+                fac[2 * (int64_t)r.j] = make_double2(l0, l1);
+                fac[2 * (int64_t)r.j + 1] = make_double2(l2, acc);
+                double *slot = ring + 4 * (r.j & (W - 1));
+                slot[0] = l0; slot[1] = l1; slot[2] = l2; slot[3] = acc;
+                const int row = r.m.w & 0x3fffffff;
+                if (r.m.w & (1 << 30)) {
+                    __hip_atomic_store(out3 + 3 * (int64_t)row, l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(out3 + 3 * (int64_t)row + 1, l1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(out3 + 3 * (int64_t)row + 2, l2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(out + row, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    out[row] = acc;
+                }
+            }
+            return;
         } else {
             double y0 = ring[(r.m.x < 0 ? 0 : r.m.x) & (W - 1)];
             double y1 = ring[(r.m.y < 0 ? 0 : r.m.y) & (W - 1)];
@@ -845,6 +945,12 @@ __global__ __launch_bounds__(512) void k_sptrsv_strips(const int32_t *__restrict
                 E[d][h].y0 = ask(r.m.x, v);
                 E[d][h].y1 = ask(r.m.y, v);
                 E[d][h].y2 = ask(r.m.z, v);
+                E[d][h].c01 = E[d][h].c02 = E[d][h].c12 = 0.0;
+                if (FACTOR == 2) {
+                    E[d][h].c01 = ask3(r.m.y, (r.xd & 3) - 1, v);
+                    E[d][h].c02 = ask3(r.m.z, ((r.xd >> 2) & 3) - 1, v);
+                    E[d][h].c12 = ask3(r.m.z, ((r.xd >> 4) & 3) - 1, v);
+                }
             }
         (void)pend;
 #pragma unroll
@@ -903,27 +1009,42 @@ void init_strip_kernels() {
     (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<true, kStripChunk / 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk / 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk / 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk / 2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk / 2, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_sptrsv_strips<false, kStripChunk / 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
 }
 
 // IC(0) through a strip plan built on the pattern of tril(A) (k_sptrsv_strips<..., FACTOR>): diag[] (n doubles, by the index
 // the plan addresses its vectors with) receives the diagonal of L, fac the records {l0, l1, l2, diagonal} by position.
-void launch_strip_factor(const Levels &lv, double *diag, double *fac, int64_t n, hipStream_t s) {
+// xdesc != null: the general form (cross terms; thr != null: with the drop rule); offd: 3 n doubles, the published off-diagonal values.
+// Returns false when the ring of whole records does not fit the LDS.
+bool launch_strip_factor(const Levels &lv, double *diag, double *fac, int64_t n, hipStream_t s, const int32_t *xdesc, const double *thr,
+                         double *offd) {
     const Levels::Strips &sp = lv.strips;
+    constexpr int CH = kStripChunk;
+    const size_t lds = (size_t)sp.W * (xdesc ? 4 : 1) * sizeof(double) + (size_t)(sp.nlev + 3 * CH + 8) * sizeof(int);
+    if (lds > (xdesc ? 144 : 128) * 1024) return false;
     hipLaunchKernelGGL(k_fill_pending, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, nullptr, 0, (int)n, diag,
                        nullptr);
-    constexpr int CH = kStripChunk;
-    const size_t lds = (size_t)sp.W * sizeof(double) + (size_t)(sp.nlev + 3 * CH + 8) * sizeof(int);
-    if (sp.rows_per_thread == 1)
-        hipLaunchKernelGGL((k_sptrsv_strips<false, CH, 1, true>), dim3(sp.n_strips), dim3(sp.threads), lds, s, sp.level_ptr_dev,
-                           sp.nlev, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, (const int4 *)sp.meta, (const double2 *)sp.val,
-                           nullptr, diag, sp.W, sp.ring_reach, sp.ticket, nullptr, lv.spin_err, nullptr, (double2 *)fac);
-    else
-        hipLaunchKernelGGL((k_sptrsv_strips<false, CH / 2, 2, true>), dim3(sp.n_strips), dim3(sp.threads), lds, s,
-                           sp.level_ptr_dev, sp.nlev, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, (const int4 *)sp.meta,
-                           (const double2 *)sp.val, nullptr, diag, sp.W, sp.ring_reach, sp.ticket, nullptr, lv.spin_err, nullptr,
-                           (double2 *)fac);
+    if (xdesc)
+        hipLaunchKernelGGL(k_fill_pending, dim3((unsigned)((3 * n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, nullptr, 0, (int)(3 * n),
+                           offd, nullptr);
+#define DPCG_STRIP_FACTOR(CV, ROWSV, FV)                                                                                       \
+    hipLaunchKernelGGL((k_sptrsv_strips<false, CV, ROWSV, FV>), dim3(sp.n_strips), dim3(sp.threads), lds, s, sp.level_ptr_dev,   \
+                       sp.nlev, sp.lo_rowptr, sp.lo_col, sp.lo_cpos, sp.lo_val, (const int4 *)sp.meta, (const double2 *)sp.val, \
+                       nullptr, diag, sp.W, sp.ring_reach, sp.ticket, nullptr, lv.spin_err, nullptr, (double2 *)fac, xdesc,   \
+                       (const double2 *)thr, offd)
+    // (the general form holds twice the state per row: half the prefetch chunk keeps it in registers)
+    if (sp.rows_per_thread == 1) {
+        if (xdesc) DPCG_STRIP_FACTOR(CH / 2, 1, 2);
+        else DPCG_STRIP_FACTOR(CH, 1, 1);
+    } else {
+        if (xdesc) DPCG_STRIP_FACTOR(CH / 4, 2, 2);
+        else DPCG_STRIP_FACTOR(CH / 2, 2, 1);
+    }
+#undef DPCG_STRIP_FACTOR
+    return true;
 }
 
 // The same through the one-workgroup LDS-ring walk (a factor of <= 131 072 rows whose schedule is ONE ring segment: 2-D grids).

@@ -1612,21 +1612,24 @@ def _six_point(m):
 
 
 @pytest.mark.parametrize("case", ["ict_poisson2d_100_thr0.1", "ict_scaled_2d_100_thr0.02", "ict_scaled_2d_100_thr0", "ict_poisson2d_256_thr0.1",
-                                  "ic0_six_point_128_cross_terms"])
+                                  "ic0_six_point_128_cross_terms", "ict_scaled_2d_400_strips_thr0.1", "ict_scaled_2d_400_strips_thr0",
+                                  "ic0_six_point_400_strips_cross_terms"])
 def test_incomplete_factorisations_through_the_ring_walk(D, case):
-    """C2-size factors with rows of at most three off-diagonal entries are factored by ONE workgroup walking the LDS-ring
-    schedule, cross terms and ICT's drop rule included (k_sptrsv_ring_pipe, FACTOR = 2), instead of one launch per level:
-    the harness's default technique ICT(1, 0.1) at its own size, and IC(0) on a pattern with triangles.  The factor must be
-    the CPU restatement's bit for bit -- pattern after dropping and values."""
+    """Factors with rows of at most three off-diagonal entries are factored THROUGH a schedule built on their pattern, cross
+    terms and ICT's drop rule included (FACTOR = 2): by ONE workgroup walking the LDS ring at C2 size, by the strip walk
+    beyond 131 072 rows -- instead of one launch per level: the harness's default technique ICT(1, 0.1), and IC(0) on a
+    pattern with triangles.  The factor must be the CPU restatement's bit for bit -- pattern after dropping and values."""
     if case.startswith("ict"):
         A = {"ict_poisson2d_100_thr0.1": lambda: O.poisson2d(100), "ict_scaled_2d_100_thr0.02": lambda: _scaled(O.poisson2d(100), 8),
-             "ict_scaled_2d_100_thr0": lambda: _scaled(O.poisson2d(100), 9), "ict_poisson2d_256_thr0.1": lambda: O.poisson2d(256)}[case]()
+             "ict_scaled_2d_100_thr0": lambda: _scaled(O.poisson2d(100), 9), "ict_poisson2d_256_thr0.1": lambda: O.poisson2d(256),
+             "ict_scaled_2d_400_strips_thr0.1": lambda: _scaled(O.poisson2d(400), 12),       # > 131 072 rows: the strip walk, general form
+             "ict_scaled_2d_400_strips_thr0": lambda: _scaled(O.poisson2d(400), 13)}[case]()
         thr = float(case.split("thr")[1])
         S = D.CsrSystem.from_any(A, reorder=None)
         S.set_preconditioner(D.ICT("solve", fill_in=1, threshold=thr))
         Lref = O.ict(A, 1, thr)
     else:
-        A = _scaled(_six_point(128), 10)
+        A = _scaled(_six_point(400 if "400" in case else 128), 10)
         S = D.CsrSystem.from_any(A, reorder=None)
         S.set_preconditioner(D.IC0("solve"))
         Lref = CO.ic0(A)

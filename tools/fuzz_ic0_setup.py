@@ -67,7 +67,7 @@ for case in range(cases):
     reorder = None if reorder == "None" else reorder
     mode = str(rng.choice(["solve", "solve", "multiply"]))
     # a share of the smaller cases run ICT (level-1 fill, drop rule) against the Python restatement instead of IC(0)
-    ict_thr = float(rng.choice([0.0, 0.02, 0.1])) if (n <= 70000 and rng.integers(0, 2) == 0) else None
+    ict_thr = float(rng.choice([0.0, 0.02, 0.1])) if ((n <= 70000 and rng.integers(0, 2) == 0) or (n <= 310000 and rng.integers(0, 4) == 0)) else None
     tag = (f"case {case}: shape={shape} n={n} drop={drop} diagonal={diagonal} scramble={scramble} reorder={reorder} mode={mode} "
            f"{'ict thr ' + str(ict_thr) if ict_thr is not None else 'ic0'}")
     S = D.CsrSystem.from_any(A, reorder=reorder)
