@@ -391,6 +391,29 @@ void launch_ring_factor_desc(int64_t n, const int32_t *lo_rp, const int32_t *lo_
                        colnorm ? thr : nullptr);
 }
 
+// flag[0] = 1 when some off-diagonal entry sits FURTHER along the band than its row (column mod band > row mod band for a lower
+// factor, < for an upper one): in a two-way strip cut it would live in a later part of an earlier slab -- e.g. the level-1 fill
+// entry (i, i - nx + 1) of a 5-point grid.  Such a pattern takes slabs straight away.
+__global__ __launch_bounds__(kBlock) void k_points_along_band(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                              int upper, int band, int *flag) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int f = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const int im = (int)(i % band);
+        for (int k = rp[i]; k < rp[i + 1]; ++k) {
+            const int c = ci[k];
+            if (c == (int)i) continue;
+            const int cm = c % band;
+            if (upper ? cm < im && c - (int)i >= band - im : cm > im && (int)i - c >= im + 1) f = 1;
+        }
+    }
+    if (f) atomicExch(flag, 1);
+}
+
+void launch_points_along_band(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int band, int *flag_zeroed, hipStream_t s) {
+    hipLaunchKernelGGL(k_points_along_band, dim3(grid_rows(n, 1024)), dim3(kBlock), 0, s, n, rp, ci, upper ? 1 : 0, band, flag_zeroed);
+}
+
 void launch_max_band(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int *out_dev, hipStream_t s) {
     hipLaunchKernelGGL(k_max_band, dim3(grid_rows(n, 1024)), dim3(kBlock), 0, s, n, rp, ci, upper ? 1 : 0, out_dev);
 }

@@ -423,6 +423,7 @@ void launch_strip_records(int64_t n, const uint32_t *key_of_pos, int nlev, const
 void launch_max_band(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int *out_dev, hipStream_t s);
 void launch_reverse_levels(int64_t n, const int32_t *rows_lo, const uint32_t *lvl_lo, const int32_t *level_ptr_lo, int nl,
                            int32_t *rows_up, uint32_t *lvl_up, hipStream_t s);
+void launch_points_along_band(int64_t n, const int32_t *rp, const int32_t *ci, bool upper, int band, int *flag_zeroed, hipStream_t s);
 void launch_ic0_cross_terms(int64_t n, const int32_t *rp, const int32_t *ci, int *flags_zeroed, hipStream_t s);
 void launch_level_keys(int64_t n, const int32_t *level, const int32_t *order_by, uint64_t *key, hipStream_t s);
 void launch_key_levels(int64_t n, const uint64_t *key_sorted, uint32_t *lvl, hipStream_t s);

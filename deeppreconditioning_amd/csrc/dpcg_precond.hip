@@ -594,7 +594,15 @@ int build_strips(Levels &lv, int64_t n, int64_t nnz, const int32_t *rp, const in
     // the own or an EARLIER strip (true for natural-order grids; checked, not assumed).
     static const bool two_way = [] { const char *e = getenv("DPCG_STRIP_PARTS"); return !(e && e[0] == '1' && e[1] == 0); }();
     const int64_t want = (n + target_rows - 1) / target_rows;              // strips of ~target_rows rows
+    // (a pattern whose entries point further along the band -- ICT's fill entry (i, i - nx + 1) -- cannot be cut two ways)
+    int32_t along = 0;
     if (two_way && band >= 128 && want >= 8) {
+        DPCG_HIP(hipMemsetAsync(ctl.p + 6, 0, sizeof(int32_t), s));
+        launch_points_along_band(n, rp, ci, upper, band, reinterpret_cast<int *>(ctl.p + 6), s);
+        DPCG_HIP(hipMemcpyAsync(&along, ctl.p + 6, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+    }
+    if (two_way && band >= 128 && want >= 8 && !along) {
         int parts = (int)std::llround(std::sqrt((double)want));
         parts = std::max(2, std::min<int>(16, std::min<int>(parts, band / 32)));
         StripMap map;
