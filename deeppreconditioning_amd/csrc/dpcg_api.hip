@@ -527,7 +527,7 @@ int ensure_work(dpcg_system *h, int max_iter, bool need_f32, bool need_err) {
         if (!h->A.val32) {
             DPCG_TRY(dev_alloc(&h->A.val32, h->A.nnz));
             launch_f64_to_f32(h->A.nnz, h->A.val, h->A.val32, nullptr);
-            DPCG_HIP(hipDeviceSynchronize());
+            DPCG_HIP(device_wide_wait());
         }
     }
     if (h->hist_cap < max_iter + 1) {

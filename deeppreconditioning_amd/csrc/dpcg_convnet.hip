@@ -76,7 +76,7 @@ int plan_alloc(dpcg_convnet_plan *p, T **out, int64_t count) {
     if (p->slab_cursor < p->slabs.size()) {
         auto &sl = p->slabs[p->slab_cursor];
         if (sl.second < bytes) {
-            (void)hipFree(sl.first);
+            (void)device_free(sl.first);
             sl = {nullptr, 0};
             const size_t grown = bytes + bytes / 4;
             if (hipMalloc(&sl.first, grown) != hipSuccess) {
@@ -439,7 +439,7 @@ using namespace dpcg;
 extern "C" int dpcg_convnet_plan_destroy(dpcg_convnet_plan_t p) {
     if (!p) return DPCG_OK;
     for (auto &sl : p->slabs)
-        if (sl.first) (void)hipFree(sl.first);
+        if (sl.first) (void)device_free(sl.first);
     dev_free(p->buf[0]);
     dev_free(p->buf[1]);
     delete p;

@@ -231,6 +231,18 @@ namespace dpcg {
 
 // ---- error plumbing ------------------------------------------------------------------------
 void set_error(const std::string &msg);
+// ---- stream captures vs device-wide waits (dpcg_mem.hip) ----
+// A device-wide wait (hipDeviceSynchronize, the implicit one of hipFree) issued while ANOTHER host thread is capturing a stream
+// invalidates that capture ("operation failed due to a previous error during capture": four threads setting up and solving at
+// once, tools/thread_probe.py).  Captures hold this lock shared, device-wide waits hold it exclusively -- they wait for the
+// captures in progress (a few hundred microseconds) and keep new ones out while they run.
+struct CaptureGuard {              // around hipStreamBeginCapture .. hipStreamEndCapture
+    CaptureGuard();
+    ~CaptureGuard();
+};
+hipError_t device_wide_wait();     // hipDeviceSynchronize under the exclusive lock
+hipError_t device_free(void *p);   // hipFree under the exclusive lock
+
 // ---- device memory with a block cache (dpcg_mem.hip) ----
 hipError_t cached_alloc(void **out, size_t bytes);
 void cached_free(void *p);

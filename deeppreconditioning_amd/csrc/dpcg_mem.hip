@@ -12,12 +12,33 @@
 // devices; 0 switches the cache off); dpcg_release_cached_memory() returns it to the driver.
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <unordered_map>
 #include <vector>
 
 #include "dpcg_host.h"
 
 namespace dpcg {
+
+namespace {
+std::shared_mutex &capture_lock() {
+    static std::shared_mutex *m = new std::shared_mutex();
+    return *m;
+}
+}  // namespace
+
+CaptureGuard::CaptureGuard() { capture_lock().lock_shared(); }
+CaptureGuard::~CaptureGuard() { capture_lock().unlock_shared(); }
+
+hipError_t device_wide_wait() {
+    std::unique_lock<std::shared_mutex> lock(capture_lock());
+    return hipDeviceSynchronize();
+}
+
+hipError_t device_free(void *p) {
+    std::unique_lock<std::shared_mutex> lock(capture_lock());
+    return hipFree(p);
+}
 
 namespace {
 struct Block {
@@ -80,7 +101,7 @@ void pool_insert(void *p, size_t size, int device) {
             largest->erase(it);
         }
     }
-    for (void *q : evict) (void)hipFree(q);              // (hipFree finds the block's device itself)
+    for (void *q : evict) (void)device_free(q);          // (hipFree finds the block's device itself)
 }
 }  // namespace
 
@@ -97,7 +118,7 @@ void release_cached_memory() {
         P.free_blocks.clear();
         P.free_bytes = 0;
     }
-    for (void *q : all) (void)hipFree(q);
+    for (void *q : all) (void)device_free(q);
 }
 
 size_t cached_memory_bytes() {
@@ -155,7 +176,7 @@ void cached_free(void *p) {
         }
     }
     if (size == 0) {                                     // not ours to keep (or the cache is off)
-        (void)hipFree(p);
+        (void)device_free(p);
         return;
     }
     if (tl_scope && tl_scope->device == device) {
@@ -165,7 +186,7 @@ void cached_free(void *p) {
     // what hipFree would have waited for: the device the block lives on
     const int here = current_device();
     if (here != device) (void)hipSetDevice(device);
-    (void)hipDeviceSynchronize();
+    (void)device_wide_wait();
     if (here != device) (void)hipSetDevice(here);
     pool_insert(p, size, device);
 }
@@ -174,7 +195,7 @@ SetupScope::SetupScope(hipStream_t s, bool wait_for_device) : stream(s) {
     if (tl_scope) return;                                // nested: the outer scope (same thread, same call) keeps the blocks
     owner = true;
     device = current_device();                           // (the stream's device: the caller made it current)
-    if (wait_for_device) (void)hipDeviceSynchronize();
+    if (wait_for_device) (void)device_wide_wait();
     tl_scope = this;
 }
 
@@ -182,7 +203,7 @@ SetupScope::~SetupScope() {
     if (!owner) return;
     tl_scope = nullptr;
     // everything the scope enqueued has run when this returns: the blocks are idle, and the call's results are complete
-    if (hipStreamSynchronize(stream) != hipSuccess) (void)hipDeviceSynchronize();
+    if (hipStreamSynchronize(stream) != hipSuccess) (void)device_wide_wait();
     for (auto &kv : idle) pool_insert(kv.second, kv.first, device);
     idle.clear();
 }

@@ -92,10 +92,14 @@ static int ensure_graph(dpcg_system *h, int flags, int chunk) {
     drop_graph(h);
     HandleExtras &ex = extras()[h];
     hipGraph_t graph = nullptr;
-    DPCG_HIP(hipStreamBeginCapture(ex.cap_stream, hipStreamCaptureModeThreadLocal));
     int st = DPCG_OK;
-    for (int i = 0; i < chunk && st >= 0; ++i) st = enqueue_iteration(h, flags, nullptr, ex.cap_stream, i);
-    hipError_t e = hipStreamEndCapture(ex.cap_stream, &graph);
+    hipError_t e = hipSuccess;
+    {
+        CaptureGuard no_device_wide_waits_meanwhile;          // (another host thread's hipFree / hipDeviceSynchronize would void the capture)
+        DPCG_HIP(hipStreamBeginCapture(ex.cap_stream, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < chunk && st >= 0; ++i) st = enqueue_iteration(h, flags, nullptr, ex.cap_stream, i);
+        e = hipStreamEndCapture(ex.cap_stream, &graph);
+    }
     if (st < 0) {
         if (graph) (void)hipGraphDestroy(graph);
         return st;
@@ -612,8 +616,8 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
             Scalars *out = nullptr;
             int cap = 0;
             ~BatchScratch() {
-                if (descs) (void)hipFree(descs);
-                if (out) (void)hipFree(out);
+                if (descs) (void)device_free(descs);
+                if (out) (void)device_free(out);
             }
         };
         static thread_local BatchScratch scratch;
@@ -652,7 +656,7 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
         // up to eight systems per launch, one team (normally: one XCD) each; the launches follow one another
         struct TeamScratch {
             TeamDesc *descs = nullptr;
-            ~TeamScratch() { if (descs) (void)hipFree(descs); }
+            ~TeamScratch() { if (descs) (void)device_free(descs); }
         };
         static thread_local TeamScratch scratch;
         if (!scratch.descs) DPCG_TRY(dev_alloc(&scratch.descs, 8));
