@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 
 #include "dpcg_host.h"
@@ -466,6 +467,11 @@ static bool team_eligible(const dpcg_system *h, int flags, const double *x_true)
     return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI;
 }
 
+static std::mutex &team_launch_mutex() {
+    static std::mutex *m = new std::mutex();
+    return *m;
+}
+
 static int ensure_team(dpcg_system *h, hipStream_t s) {
     DPCG_TRY(build_ell(h->A, h->ell_a, s));
     if (h->ell_a.W > team_max_row_len()) return invalid("team solve: a row has more than 7 entries");
@@ -522,6 +528,9 @@ static int solve_team_one(dpcg_system *h, const double *b, const double *x0, dou
     DPCG_HIP(hipMemsetAsync(h->team_sync, 0, 2 * sizeof(unsigned int), s));
     launch_fill_pending(h->team_part, 3 * 2 * 32, s);                                // every reduction slot: "not written yet"
     DPCG_HIP(hipStreamSynchronize(s));
+    // one team launch at a time per process: the workgroups of a team wait for each other, and two such launches dispatched at
+    // once from two host threads could each hold part of the chip waiting for the rest of it (the 4 s bound would end that)
+    std::lock_guard<std::mutex> one_team_launch(team_launch_mutex());
     const auto t0 = std::chrono::steady_clock::now();                                // cg.py:69 (the launch is the loop)
     DPCG_TRY(launch_pcg_team(static_cast<const TeamDesc *>(h->team_desc), 1, team_slabs_per_wg(h->A.n), h->ell_a.W, s));
     DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
@@ -677,6 +686,7 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
                 wmax = std::max(wmax, hi->ell_a.W);
             }
             DPCG_HIP(hipMemcpy(scratch.descs, descs, (size_t)ng * sizeof(TeamDesc), hipMemcpyHostToDevice));
+            std::lock_guard<std::mutex> one_team_launch(team_launch_mutex());        // (see solve_team_one)
             const auto t0 = std::chrono::steady_clock::now();
             DPCG_TRY(launch_pcg_team(scratch.descs, ng, slabs, wmax, nullptr));
             DPCG_HIP(hipStreamSynchronize(nullptr));

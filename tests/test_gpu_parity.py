@@ -1263,7 +1263,8 @@ def test_update_values_on_the_same_pattern(D, case):
 
 def test_host_threads_set_up_and_solve_concurrently():
     """tools/thread_probe.py: four host threads on their own streams create systems, attach IC(0) / ICT / Jacobi and solve, 48
-    times in all; every result equals the one computed alone.  (Found with it: a device-wide wait -- hipFree, hipDeviceSynchronize
+    times in all, then each solves its own batch (one-launch team form) between `update_values` calls, 72 solves more; every
+    result equals the one computed alone.  (Found with it: a device-wide wait -- hipFree, hipDeviceSynchronize
     -- issued while another thread captured its update graph voided that capture; captures and device-wide waits now exclude each
     other, dpcg_mem.hip.)"""
     import pathlib
@@ -1273,7 +1274,7 @@ def test_host_threads_set_up_and_solve_concurrently():
     proc = subprocess.run([sys.executable, str(root / "tools" / "thread_probe.py")], capture_output=True, text=True, cwd=root,
                           env={**__import__("os").environ, "PYTHONPATH": str(root)}, timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]
-    assert "48 solves on 4 threads, 0 mismatches" in proc.stdout, proc.stdout[-2000:]
+    assert "48 solves on 4 threads, 0 mismatches (72 more in concurrent batches with update_values)" in proc.stdout, proc.stdout[-2000:]
 
 
 def test_device_block_cache_is_bounded_and_optional(D):

@@ -45,5 +45,57 @@ for i in range(4):
         if it != alone[(a, p)][0] or not np.array_equal(x, alone[(a, p)][1]):
             bad += 1
             print("MISMATCH thread", i, "case", a, "precond", p, it, alone[(a, p)][0])
-print(f"thread_probe: {sum(len(v) for v in out.values())} solves on 4 threads, {bad} mismatches")
+# phase 2: every thread solves its own batch (team / whole-solve launch forms), updates the values of its systems and solves again
+from deeppreconditioning_amd.batch import solve_batch
+import scipy.sparse as sp
+
+bA = [O.poisson2d(120), O.poisson2d(48), O.poisson3d(20)]
+bA2 = []
+for q, A in enumerate(bA):
+    d = np.random.default_rng(q).uniform(0.5, 2.0, A.shape[0])
+    B = (sp.diags(d) @ A @ sp.diags(d)).tocsr()
+    B.sort_indices()
+    bA2.append(B)
+brhs = [O.rhs(A.shape[0], 7 + q) for q, A in enumerate(bA)]
+
+
+def batch_run(i, rounds, out):
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        S = [D.CsrSystem.from_any(A, reorder=None) for A in bA]
+        b = [torch.from_numpy(v).cuda() for v in brhs]
+        res = []
+        for r in range(rounds):
+            mats = bA if r % 2 == 0 else bA2
+            for s_, A in zip(S, mats):
+                s_.update_values(A.data)
+                s_.set_preconditioner(D.Jacobi())
+            res.append([(x.iterations, x.x.cpu().numpy()) for x in solve_batch(S, b)])
+        for s_ in S:
+            s_.close()
+        stream.synchronize()
+    out[i] = res
+
+
+ref = {}
+for parity, mats in ((0, bA), (1, bA2)):
+    S = [D.CsrSystem.from_any(A, reorder=None) for A in mats]
+    for s_ in S:
+        s_.set_preconditioner(D.Jacobi())
+    ref[parity] = [(x.iterations, x.x.cpu().numpy()) for x in solve_batch(S, [torch.from_numpy(v).cuda() for v in brhs])]
+    for s_ in S:
+        s_.close()
+out2 = {}
+threads = [threading.Thread(target=batch_run, args=(i, 6, out2)) for i in range(4)]
+[t.start() for t in threads]
+[t.join() for t in threads]
+n2 = 0
+for i in range(4):
+    for r, res in enumerate(out2[i]):
+        for (it, x), (it0, x0) in zip(res, ref[r % 2]):
+            n2 += 1
+            if it != it0 or not np.array_equal(x, x0):
+                bad += 1
+                print("BATCH MISMATCH thread", i, "round", r, it, it0)
+print(f"thread_probe: {sum(len(v) for v in out.values())} solves on 4 threads, {bad} mismatches ({n2} more in concurrent batches with update_values)")
 raise SystemExit(1 if bad else 0)
