@@ -54,7 +54,9 @@ def solve_batch(systems: list[CsrSystem], rhs: list[torch.Tensor], x0: list | No
     status = (C.c_int * count)()
     res = (C.c_double * count)()
     sec = (C.c_double * count)()
-    torch.cuda.synchronize(dev)  # inputs were produced on torch's stream; the batch runs on its own
+    # inputs were produced on torch's stream; the batch runs on its own.  (The STREAM is waited for, not the device: a device-wide
+    # wait from this host thread would void a graph capture in progress on another one.)
+    torch.cuda.current_stream(dev).synchronize()
     with torch.cuda.device(dev):
         L.check(L.lib().dpcg_solve_batch(count, handles, b_arr, x0_arr, x_arr, rtol_sq, atol_sq, int(max_iter),
                                          int(flags), int(n_streams), iters, res, sec, status))

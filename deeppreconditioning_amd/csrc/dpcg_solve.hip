@@ -97,15 +97,24 @@ static int ensure_graph(dpcg_system *h, int flags, int chunk) {
     hipError_t e = hipSuccess;
     {
         CaptureGuard no_device_wide_waits_meanwhile;          // (another host thread's hipFree / hipDeviceSynchronize would void the capture)
-        DPCG_HIP(hipStreamBeginCapture(ex.cap_stream, hipStreamCaptureModeThreadLocal));
+        // (relaxed mode: what OTHER host threads call meanwhile -- torch allocating or synchronising -- is their business; the
+        // capture stream itself is private to this handle)
+        DPCG_HIP(hipStreamBeginCapture(ex.cap_stream, hipStreamCaptureModeRelaxed));
         for (int i = 0; i < chunk && st >= 0; ++i) st = enqueue_iteration(h, flags, nullptr, ex.cap_stream, i);
         e = hipStreamEndCapture(ex.cap_stream, &graph);
+    }
+    if (e != hipSuccess) {
+        // The capture was voided from outside -- HIP refuses a device-wide wait while ANY stream captures, and void-s the capture
+        // too: another host thread of the application calling torch.cuda.synchronize() at that moment does it
+        // (tools/thread_probe.py).  Not an error of this solve: it runs update by update, the next one captures again.
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        return DPCG_OK;                                  // (h->graph_exec stays null: the caller checks)
     }
     if (st < 0) {
         if (graph) (void)hipGraphDestroy(graph);
         return st;
     }
-    DPCG_HIP(e);
     e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     DPCG_HIP(e);
@@ -236,7 +245,10 @@ struct Solve {
         if (many_launches) chunk = std::max(1, std::min(chunk, 1024 / per_update));   // keep the graph at ~1K nodes
         if (defer_x && (chunk & 1)) chunk += 1;   // a replayed chunk must start at an even update (p buffer parity)
         use_graph = !(flags & DPCG_NO_GRAPH) && !x_true && max_iter >= chunk && h->precond != DPCG_PRECOND_CALLBACK;
-        if (use_graph) DPCG_TRY(ensure_graph(h, flags, chunk));
+        if (use_graph) {
+            DPCG_TRY(ensure_graph(h, flags, chunk));
+            if (!h->graph_exec) use_graph = false;       // a voided capture (see ensure_graph)
+        }
         *ex.prog_host = 0;
         if (h->perm) {                     // b, x0, x_true arrive in the caller's numbering
             if (!h->pb) DPCG_TRY(dev_alloc(&h->pb, n));

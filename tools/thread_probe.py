@@ -1,4 +1,5 @@
-"""Four host threads, each on its own stream, creating systems, attaching IC(0) / ICT / Jacobi and solving, over and over: the device
+"""Four host threads, each on its own stream, creating systems, attaching IC(0) / ICT / Jacobi and solving, over and over -- beside a
+fifth that keeps calling torch.cuda.synchronize() and allocating: the device
 block cache (thread-local scopes, one process-wide pool) and the setup routines under concurrency.  Every result must equal the
 one computed alone."""
 import threading
@@ -36,9 +37,29 @@ for a in range(4):
         alone[(a, p)] = (x.iterations, x.x.cpu().numpy())
         S.close()
 out = {}
+stop_noise = threading.Event()
+noise_refused = [0]
+
+
+def noise():
+    """A host thread of the application itself: device-wide waits and allocations while the library works on the other threads."""
+    while not stop_noise.is_set():
+        try:
+            torch.cuda.synchronize()
+            t = torch.empty(1 << 20, device="cuda")
+            del t
+            torch.cuda.synchronize()
+        except Exception:                       # HIP refuses a device-wide wait while ANY stream captures: the application's own matter
+            noise_refused[0] += 1
+
+
+noisy = threading.Thread(target=noise)
+noisy.start()
 threads = [threading.Thread(target=run, args=(i, 12, out)) for i in range(4)]
 [t.start() for t in threads]
 [t.join() for t in threads]
+stop_noise.set()
+noisy.join()
 bad = 0
 for i in range(4):
     for a, p, it, x in out[i]:
