@@ -93,6 +93,11 @@ void free_levels(Levels &l) {
     dev_free(l.spin_err);
     dev_free(l.lm_pos);
     dev_free(l.lm_from_lower);
+    dev_free(l.lm_to_upper);
+    dev_free(l.ride_diag);
+    dev_free(l.sw_chunks);
+    dev_free(l.sw_nchunks);
+    dev_free(l.sw_lidx);
     dev_free(l.lm_rhs);
     dev_free(l.lm_out);
     l = Levels();
@@ -596,7 +601,8 @@ int rz_partial_count(const dpcg_system *h) {
     return h->vec_grid;
 }
 
-int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, bool in_loop, double *part_rz, int *n_part_rz) {
+int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, bool in_loop, double *part_rz, int *n_part_rz,
+                  bool lower_first_done) {
     if (n_part_rz) *n_part_rz = 0;
     switch (h->precond) {
         case DPCG_PRECOND_NONE:
@@ -649,6 +655,15 @@ int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, boo
                 upper_io.dot_part = part_rz;
                 upper_io.dot_grid = h->vec_grid;
             }
+            if (lower_io.keep_lm && h->lvlL.sweep && h->lvlU.sweep && h->lvlL.lm_to_upper) {
+                // colour sweeps: the last lower level opens the upper solve (its rows are L^T's first level)
+                lower_io.pair_out = h->lvlU.lm_out;
+                lower_io.pair_dst = z;
+                lower_io.dot_with = upper_io.dot_with;
+                lower_io.dot_part = upper_io.dot_part;
+                upper_io.skip_first = true;
+            }
+            lower_io.skip_first = lower_first_done;        // (the first lower level rode on K2: ride_eligible)
             launch_sptrsv(h->L, h->lvlL, false, r, h->t, s, in_loop ? &h->scal->done : nullptr, &lower_io);
             launch_sptrsv(h->Lt, h->lvlU, true, h->t, z, s, in_loop ? &h->scal->done : nullptr, &upper_io);
             if (upper_io.dot_done) *n_part_rz = upper_io.dot_count;

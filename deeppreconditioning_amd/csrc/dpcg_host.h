@@ -111,8 +111,9 @@ FuseArgs fuse_args(dpcg_system *h);
 // z = M r for the handle's preconditioner (cg.py:61,81); in_loop: kernels return at once when the solve is done
 // part_rz / n_part_rz (may be null): where the apply may leave per-workgroup partials of <r,z> (cg.py:82) when its last kernel
 // can sum them on the way; *n_part_rz = their count, or 0 when the caller has to launch the dot product itself
+// lower_first_done: the first level of the lower solve has been computed already (colour sweeps: it rode on K2)
 int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, bool in_loop = false, double *part_rz = nullptr,
-                  int *n_part_rz = nullptr);
+                  int *n_part_rz = nullptr, bool lower_first_done = false);
 // number of <r,z> partials an in-loop apply of the handle's preconditioner leaves (vec_grid when it leaves none)
 int rz_partial_count(const dpcg_system *h);
 int check_spin_errors(dpcg_system *h, hipStream_t s);

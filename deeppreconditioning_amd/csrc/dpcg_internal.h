@@ -30,6 +30,7 @@ constexpr int kRingMaxLevels = 8192;   // levels per LDS-ring segment (their off
 constexpr int kTileMinBlocks = 1536;   // fewest 256-row blocks for which the x-tile SpMV is chosen
 constexpr int kReorderMinRows = 65536;  // DPCG_REORDER_AUTO leaves smaller systems alone (x stays cache-resident anyway)
 constexpr int kTileTableMax = 4096;   // chunk-id span a block may cover (262,144 columns)
+constexpr uint16_t kTileDiag = 0xffff; // local index of a row's own diagonal in the x-tile plan of a colour sweep (no slot: times 1.0)
 
 struct CsrDev {
     int64_t n = 0, nnz = 0;
@@ -155,6 +156,18 @@ struct Levels {
     // result by position AND in the handle's numbering and sums <r,z> on the way (k_lm_sweep): no way-in / way-out passes.
     bool sweep = false;
     int sweep_grid = 0;                    // workgroups per level launch; an apply leaves n_levels * sweep_grid partials of <r,z>
+    // Tiled sweeps: an x-tile plan (as SpmvPlan's) per level of the level-ordered copy -- blocks of 256 rows counted from the
+    // level's first row; the solution entries a block gathers are staged in LDS in 64-entry chunks (k_lm_sweep_tile).
+    int32_t *sw_chunks = nullptr, *sw_nchunks = nullptr;
+    uint16_t *sw_lidx = nullptr;
+    std::vector<int> sw_blk0;              // host: first block of each level in sw_chunks / sw_nchunks
+    std::vector<int> sw_max_chunks;        // host: per level the largest chunk count of a block (0: the level keeps the gather sweep)
+    // L only, when L^T's first level is L's last one (levels of L^T = levels of L reversed): position here -> position in
+    // L^T's numbering, so that the last lower sweep can emit the first level of the upper solve (z = y / d) as well
+    int32_t *lm_to_upper = nullptr;
+    // L only: the diagonal of the rows of the FIRST level, by row (1.0 elsewhere) -- in the PCG loop that level (y = r / d,
+    // nothing to wait for) rides on the kernel that updates r (k_update_r<3>), and the sweeps start at the second level
+    double *ride_diag = nullptr;
     // Invariant (factors that are one sync-free launch, single_syncfree_segment): between solves the LOWER factor's lm_out
     // holds the sync-free kernels' "pending" pattern everywhere -- set up by build_levels, restored by whoever consumed the
     // values (the way-out pass of a paired apply; launch_sptrsv itself after a standalone lower solve).  A solve with
@@ -175,6 +188,11 @@ struct SptrsvIo {
     // kernel (lower solve) or the way-out pass (upper solve) presets to the pending pattern for whoever solves next.
     bool fused_entry = false;
     double *refill = nullptr;
+    // Colour sweeps, paired apply: the LOWER solve's last level also emits the first level of the upper solve (rows without
+    // dependants: z = y / d) -- by position into pair_out[lm_to_upper[j]], by row into pair_dst, its share of <dot_with, z>
+    // into dot_part[0 .. sweep_grid); the UPPER solve then starts at its second level (skip_first).
+    double *pair_out = nullptr, *pair_dst = nullptr;
+    bool skip_first = false;
 };
 bool single_syncfree_segment(const Levels &lv);   // level-major, the whole factor one sync-free launch
 void launch_fill_pending(double *v, int64_t n, hipStream_t s);
@@ -320,6 +338,9 @@ void launch_update_r_two_kernel(int precond_fused, int64_t n, Scalars *scal, con
 void launch_update_r(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
                      const double *q, double *r, const double *dinv, double *z, double *part_rz, double *part_rr,
                      int grid, hipStream_t s, int store_z = 1);
+void launch_update_r_ride(int64_t n, Scalars *scal, const double *part_pq, int n_part_pq, const double *q, double *r,
+                          const double *first_level_diag, const int32_t *pos, double *lm_out, int first_level_rows,
+                          double *part_rr, int grid, hipStream_t s);
 void launch_dot_partials(int64_t n, const Scalars *scal, const double *a, const double *b, double *part, int grid,
                          hipStream_t s);
 void launch_update_xp(int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
@@ -362,6 +383,8 @@ void launch_invert_positions(int64_t n, const int32_t *rows, int32_t *pos, hipSt
 void launch_compose_positions(int64_t n, const int32_t *rows, const int32_t *pos, int32_t *out, hipStream_t s);   // out[j] = pos[rows[j]]
 
 // Builds the x-tile plan of A on the device; *ok = 1 when every block is tileable, *max_chunks its widest tile.
+void launch_sweep_tile_plan(int j0, int count, const int32_t *lo_rowptr, const int32_t *lo_cpos, int32_t *chunks, int32_t *nchunks,
+                            uint16_t *lidx, int *ok_and_max_dev, hipStream_t s);
 void launch_tile_plan(const CsrDev &A, int nrb, int32_t *chunks, int32_t *nchunks, uint16_t *lidx, int *ok_and_max_dev,
                       hipStream_t s);
 void launch_max_row_len(int n, const int32_t *rp, int *out_dev, hipStream_t s);

@@ -13,14 +13,21 @@ namespace dpcg {
 // accesses, loads of the next pair issued before the current pair is consumed, and the first loads
 // issued before the partial reduction so that its latency is hidden.
 // ------------------------------------------------------------------------------------------------
-// PRE: 0 = M = I (z aliases r, not stored), 1 = Jacobi fused, 2 = generic M (z computed later).
+// PRE: 0 = M = I (z aliases r, not stored), 1 = Jacobi fused, 2 = generic M (z computed later), 3 = as 2, and the first
+// level of the lower triangular solve that follows rides along (colour sweeps: its rows have no dependencies, y = r / d):
+// `dinv` then holds that level's DIAGONAL by row (RideArgs), and y goes to the solve's own numbering, out[pos[row]].
+struct RideArgs {
+    const int32_t *pos;     // row -> level-order position of the factor (Levels::lm_pos)
+    double *out;            // the lower solve's solution vector by position (Levels::lm_out)
+    int count;              // rows of the first level (positions 0 .. count)
+};
 template <int PRE, bool F2 = false>   // F2: KB of the two-kernel iteration (workgroup 0 also advances k and rz_prev)
 __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restrict__ sc,
                                                      const double *__restrict__ part_pq, int n_part_pq,
                                                      const double *__restrict__ q, double *__restrict__ r,
                                                      const double *__restrict__ dinv, double *__restrict__ z,
                                                      double *__restrict__ part_rz, double *__restrict__ part_rr,
-                                                     int store_z) {
+                                                     int store_z, RideArgs ride) {
     __shared__ double sh[8];
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -29,12 +36,15 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
     const double2 *__restrict__ d2 = reinterpret_cast<const double2 *>(dinv);
     double2 *__restrict__ r2 = reinterpret_cast<double2 *>(r);
     double2 *__restrict__ z2 = reinterpret_cast<double2 *>(z);
+    const int2 *__restrict__ pos2 = reinterpret_cast<const int2 *>(ride.pos);
     double2 qa = make_double2(0, 0), ra = qa, da = qa;
+    int2 pa = make_int2(0, 0);
     bool have = i < n2;
     if (have) {
         qa = q2[i];
         ra = r2[i];
-        if (PRE == 1) da = d2[i];
+        if (PRE == 1 || PRE == 3) da = d2[i];
+        if (PRE == 3) pa = pos2[i];
     }
     // Everything the head needs is requested before anything is looked at: the SpMV's partials of <p,Ap>, the `done`
     // word and <r,z> travel together with the first vector loads, so the head exposes ONE memory round trip; a finished
@@ -63,12 +73,14 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
     while (have) {
         const int64_t cur = i;
         const double2 qc = qa, rc = ra, dc = da;
+        const int2 pc = pa;
         i += stride;
         have = i < n2;
         if (have) {
             qa = q2[i];
             ra = r2[i];
-            if (PRE == 1) da = d2[i];
+            if (PRE == 1 || PRE == 3) da = d2[i];
+            if (PRE == 3) pa = pos2[i];
         }
         double2 rn;
         rn.x = rc.x - alpha * qc.x;                                     // cg.py:80
@@ -76,6 +88,10 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
         r2[cur] = rn;
         a_rr += rn.x * rn.x;                                            // cg.py:86
         a_rr += rn.y * rn.y;
+        if (PRE == 3) {                                                 // first level of L y = r (cg.py:81)
+            if (pc.x < ride.count) ride.out[pc.x] = rn.x / dc.x;
+            if (pc.y < ride.count) ride.out[pc.y] = rn.y / dc.y;
+        }
         if (PRE == 1) {
             double2 zn;
             zn.x = dc.x * rn.x;                                         // cg.py:81 (M = diag(1/a_ii))
@@ -90,6 +106,10 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
         const double rn = r[e] - alpha * q[e];
         r[e] = rn;
         a_rr += rn * rn;
+        if (PRE == 3) {
+            const int pe = ride.pos[e];
+            if (pe < ride.count) ride.out[pe] = rn / dinv[e];
+        }
         if (PRE == 1) {
             const double zn = dinv[e] * rn;
             z[e] = zn;
@@ -99,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
     block_sum2(a_rr, a_rz, sh);
     if (threadIdx.x == 0) {
         part_rr[blockIdx.x] = a_rr;
-        if (PRE != 2) part_rz[blockIdx.x] = PRE == 1 ? a_rz : a_rr;     // PRE 0: z = r; PRE 2: <r,z> comes later
+        if (PRE < 2) part_rz[blockIdx.x] = PRE == 1 ? a_rz : a_rr;      // PRE 0: z = r; PRE 2, 3: <r,z> comes later
     }
 }
 
@@ -108,13 +128,13 @@ void launch_update_r_two_kernel(int precond_fused, int64_t n, Scalars *scal, con
                                 double *part_rr, int grid, hipStream_t s) {
     if (precond_fused == 0)
         hipLaunchKernelGGL((k_update_r<0, true>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r,
-                           dinv, z, part_rz, part_rr, 1);
+                           dinv, z, part_rz, part_rr, 1, RideArgs{nullptr, nullptr, 0});
     else if (precond_fused == 1)
         hipLaunchKernelGGL((k_update_r<1, true>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r,
-                           dinv, z, part_rz, part_rr, 1);
+                           dinv, z, part_rz, part_rr, 1, RideArgs{nullptr, nullptr, 0});
     else
         hipLaunchKernelGGL((k_update_r<2, true>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r,
-                           dinv, z, part_rz, part_rr, 1);
+                           dinv, z, part_rz, part_rr, 1, RideArgs{nullptr, nullptr, 0});
 }
 
 // Two-kernel iteration: state before the first update (see fused_head).
@@ -170,15 +190,24 @@ void launch_final_fused(int64_t n, Scalars *scal, const double *part_rr, int n_p
 void launch_update_r(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
                      const double *q, double *r, const double *dinv, double *z, double *part_rz, double *part_rr,
                      int grid, hipStream_t s, int store_z) {
+    const RideArgs none{nullptr, nullptr, 0};
     if (precond_fused == 0)
         hipLaunchKernelGGL(k_update_r<0>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, dinv, z,
-                           part_rz, part_rr, store_z);
+                           part_rz, part_rr, store_z, none);
     else if (precond_fused == 1)
         hipLaunchKernelGGL(k_update_r<1>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, dinv, z,
-                           part_rz, part_rr, store_z);
+                           part_rz, part_rr, store_z, none);
     else
         hipLaunchKernelGGL(k_update_r<2>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, dinv, z,
-                           part_rz, part_rr, store_z);
+                           part_rz, part_rr, store_z, none);
+}
+
+// K2 for a preconditioner applied by colour sweeps: the first level of the lower solve rides along (k_update_r<3>)
+void launch_update_r_ride(int64_t n, Scalars *scal, const double *part_pq, int n_part_pq, const double *q, double *r,
+                          const double *first_level_diag, const int32_t *pos, double *lm_out, int first_level_rows,
+                          double *part_rr, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(k_update_r<3>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, first_level_diag,
+                       (double *)nullptr, (double *)nullptr, part_rr, 0, RideArgs{pos, lm_out, first_level_rows});
 }
 
 // part[b] = partial of <a,b>; skipped once the solve is done (scal may be null: always run).

@@ -410,6 +410,43 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
             for (int l = 0; l < lv.n_levels; ++l) widest = std::max<int64_t>(widest, level_ptr[l + 1] - level_ptr[l]);
             const int64_t blocks = (widest + kBlock - 1) / kBlock;
             lv.sweep_grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, kMaxSpmvGrid / lv.n_levels));
+            // x-tile plans of the levels (k_lm_sweep_tile); a level without off-diagonal entries, or with a block whose columns
+            // are too spread out, keeps the gather sweep
+            static const bool tiles_on = [] { const char *e = getenv("DPCG_SWEEP_TILES"); return !(e && e[0] == '0'); }();
+            if (tiles_on) {
+                lv.sw_blk0.assign((size_t)lv.n_levels + 1, 0);
+                for (int l = 0; l < lv.n_levels; ++l)
+                    lv.sw_blk0[(size_t)l + 1] = lv.sw_blk0[(size_t)l] + (level_ptr[l + 1] - level_ptr[l] + kBlock - 1) / kBlock;
+                const int64_t nb = lv.sw_blk0.back();
+                DPCG_TRY(dev_alloc(&lv.sw_chunks, nb * kTileMaxChunks));
+                DPCG_TRY(dev_alloc(&lv.sw_nchunks, nb));
+                DPCG_TRY(dev_alloc(&lv.sw_lidx, nnz + 4));
+                DPCG_HIP(hipMemsetAsync(lv.sw_lidx + nnz, 0, 4 * sizeof(uint16_t), s));
+                DevBuf<int32_t> d_flags;
+                DPCG_TRY(d_flags.alloc(2 * (int64_t)lv.n_levels));
+                std::vector<int32_t> h_flags((size_t)2 * lv.n_levels);
+                for (int l = 0; l < lv.n_levels; ++l) { h_flags[(size_t)2 * l] = 1; h_flags[(size_t)2 * l + 1] = 0; }
+                DPCG_HIP(hipMemcpyAsync(d_flags.p, h_flags.data(), h_flags.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+                for (int l = 0; l < lv.n_levels; ++l)
+                    launch_sweep_tile_plan(level_ptr[l], level_ptr[l + 1] - level_ptr[l], lv.lo_rowptr, lv.lo_cpos,
+                                           lv.sw_chunks + (size_t)lv.sw_blk0[(size_t)l] * kTileMaxChunks, lv.sw_nchunks + lv.sw_blk0[(size_t)l],
+                                           lv.sw_lidx, reinterpret_cast<int *>(d_flags.p) + 2 * l, s);
+                DPCG_HIP(hipMemcpyAsync(h_flags.data(), d_flags.p, h_flags.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                DPCG_HIP(hipStreamSynchronize(s));
+                lv.sw_max_chunks.assign((size_t)lv.n_levels, 0);
+                int most = 0;
+                for (int l = 0; l < lv.n_levels; ++l) {
+                    if (h_flags[(size_t)2 * l] == 1) lv.sw_max_chunks[(size_t)l] = h_flags[(size_t)2 * l + 1];
+                    most = std::max(most, lv.sw_max_chunks[(size_t)l]);
+                }
+                if (most > 0) {             // as make_plan: workgroups per CU by the LDS a block takes, a multiple of 8
+                    const size_t lds = (size_t)(most * kTileChunk + kStreamCap + 8) * sizeof(double);
+                    const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+                    int g = (int)std::min<int64_t>(blocks, std::min<int64_t>(per_cu * 256, kMaxSpmvGrid / lv.n_levels));
+                    if (g > 8) g -= g % 8;
+                    lv.sweep_grid = std::max(1, g);
+                }
+            }
         }
         bool any = false;
         for (const auto &seg : lv.segments) any = any || !(seg.merged && seg.ring_w > 0);
@@ -783,6 +820,24 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
         if (h->lvlL.level_major && h->lvlU.level_major) {      // the lower result feeds the upper solve without leaving level-major order
             DPCG_TRY(dev_alloc(&h->lvlU.lm_from_lower, n));
             launch_compose_positions(n, h->lvlU.rows, h->lvlL.lm_pos, h->lvlU.lm_from_lower, s);
+            // colour sweeps: the first level of L^T holds the rows of L's last level (no dependants; equal counts: the same set)
+            // -- the last lower sweep can open the upper solve (SptrsvIo::pair_out)
+            const Levels &lo = h->lvlL, &up = h->lvlU;
+            if (lo.sweep && up.sweep && lo.n_levels == up.n_levels && lo.n_levels >= 2 && lo.sweep_grid == up.sweep_grid &&
+                up.level_ptr[1] - up.level_ptr[0] == lo.level_ptr[(size_t)lo.n_levels] - lo.level_ptr[(size_t)lo.n_levels - 1]) {
+                static const bool pair_on = [] { const char *e = getenv("DPCG_SWEEP_PAIR"); return !(e && e[0] == '0'); }();
+                if (pair_on) {
+                    DPCG_TRY(dev_alloc(&h->lvlL.lm_to_upper, n));
+                    launch_invert_positions(n, h->lvlU.lm_from_lower, h->lvlL.lm_to_upper, s);
+                }
+            }
+            // ... and L's first level (diagonal only) can ride on the kernel that updates r (Levels::ride_diag)
+            static const bool ride_on = [] { const char *e = getenv("DPCG_SWEEP_RIDE"); return !(e && e[0] == '0'); }();
+            if (ride_on && lo.sweep && lo.n_levels >= 2) {
+                DPCG_TRY(dev_alloc(&h->lvlL.ride_diag, n));
+                DPCG_HIP(hipMemsetAsync(h->lvlL.ride_diag, 0, (size_t)n * sizeof(double), s));    // (only first-level rows are read)
+                launch_scatter_f64(lo.level_ptr[1], lo.rows, lo.lo_val, h->lvlL.ride_diag, s);
+            }
             DPCG_CHECK_LAUNCH();
         }
     }

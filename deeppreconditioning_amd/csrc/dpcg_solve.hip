@@ -61,12 +61,18 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
     // direction (measured: 34.9 -> 33.1 us per update at 1M DoF).
     const bool z_on_the_fly = pre == 1;
     const double *z = pre == 2 ? h->z : h->r;
-    launch_update_r(pre, n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->dinv, h->z, h->part_rz, h->part_rr,
-                    h->vec_grid, s, z_on_the_fly ? 0 : 1);
+    // colour sweeps: the first level of the lower solve (rows without dependencies: y = r / d) rides on K2
+    const bool ride = pre == 2 && h->precond == DPCG_PRECOND_LLT_SOLVE && h->lvlL.sweep && h->lvlL.ride_diag && h->lvlL.n_levels >= 2;
+    if (ride)
+        launch_update_r_ride(n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->lvlL.ride_diag, h->lvlL.lm_pos, h->lvlL.lm_out,
+                             h->lvlL.level_ptr[1], h->part_rr, h->vec_grid, s);
+    else
+        launch_update_r(pre, n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->dinv, h->z, h->part_rz, h->part_rr,
+                        h->vec_grid, s, z_on_the_fly ? 0 : 1);
     const int np_rz = pre == 2 ? rz_partial_count(h) : h->vec_grid;
     if (pre == 2) {
         int np = 0;
-        DPCG_TRY(apply_precond(h, h->r, h->z, s, true, h->part_rz, &np));            // cg.py:81 (+ cg.py:82 when fused)
+        DPCG_TRY(apply_precond(h, h->r, h->z, s, true, h->part_rz, &np, ride));      // cg.py:81 (+ cg.py:82 when fused)
         if (np == 0) launch_dot_partials(n, h->scal, h->r, h->z, h->part_rz, h->vec_grid, s);   // cg.py:82
     }
     // K3: beta; x += alpha p; p = z + beta p; workgroup 0: stopping test of the new iterate   cg.py:79,82-83,86,71

@@ -215,10 +215,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv_vector(int64_t n, const int32_t
 // parked in LDS, thread i adds row i in column order -- the same bits as the gather kernels and the CPU.
 // Per non-zero the matrix stream shrinks from 12 to 10 bytes and the global gathers disappear.
 // ------------------------------------------------------------------------------------------------
+// `diag_from` (colour sweeps: the rows are one level of a level-ordered triangular factor, columns are positions): a column
+// >= diag_from is the row's own diagonal -- no chunk is staged for it and its local index is kTileDiag (the kernel
+// multiplies it by 1.0, so the product slot holds the diagonal itself).  INT_MAX: a plain matrix.
 __global__ __launch_bounds__(kBlock) void k_tile_plan(int64_t n, const int32_t *__restrict__ rowptr,
                                                       const int32_t *__restrict__ col, int nrb,
                                                       int32_t *__restrict__ chunks, int32_t *__restrict__ nchunks,
-                                                      uint16_t *__restrict__ lidx, int *ok_and_max) {
+                                                      uint16_t *__restrict__ lidx, int *ok_and_max, int diag_from) {
     __shared__ int s_min, s_max, s_nc;
     __shared__ uint16_t slot_of[kTileTableMax];
     const int t = threadIdx.x;
@@ -231,13 +234,15 @@ __global__ __launch_bounds__(kBlock) void k_tile_plan(int64_t n, const int32_t *
         int lo = 0x7fffffff, hi = -1;
         for (int k = t; k < cnt; k += kBlock) {
             const int c = col[base + k];
+            if (c >= diag_from) continue;
             lo = c < lo ? c : lo;
             hi = c > hi ? c : hi;
         }
         if (hi >= 0) { atomicMin(&s_min, lo); atomicMax(&s_max, hi); }
         __syncthreads();
-        if (cnt == 0) {
+        if (cnt == 0 || s_max < 0) {                      // no entries (or diagonals only): nothing to stage
             if (t == 0) nchunks[rb] = 0;
+            for (int k = t; k < cnt; k += kBlock) lidx[base + k] = kTileDiag;
             __syncthreads();
             continue;
         }
@@ -251,7 +256,10 @@ __global__ __launch_bounds__(kBlock) void k_tile_plan(int64_t n, const int32_t *
         }
         for (int e = t; e < span; e += kBlock) slot_of[e] = 0;
         __syncthreads();
-        for (int k = t; k < cnt; k += kBlock) slot_of[col[base + k] / kTileChunk - cb] = 1;
+        for (int k = t; k < cnt; k += kBlock) {
+            const int c = col[base + k];
+            if (c < diag_from) slot_of[c / kTileChunk - cb] = 1;
+        }
         __syncthreads();
         if (t == 0) {                                     // ascending chunk ids -> slots 1..nc
             int nc = 0;
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_plan(int64_t n, const int32_t *
         if (s_nc <= kTileMaxChunks)
             for (int k = t; k < cnt; k += kBlock) {
                 const int c = col[base + k];
-                lidx[base + k] = (uint16_t)((slot_of[c / kTileChunk - cb] - 1) * kTileChunk + c % kTileChunk);
+                lidx[base + k] = c >= diag_from ? kTileDiag : (uint16_t)((slot_of[c / kTileChunk - cb] - 1) * kTileChunk + c % kTileChunk);
             }
         __syncthreads();
     }
@@ -279,7 +287,17 @@ void launch_tile_plan(const CsrDev &A, int nrb, int32_t *chunks, int32_t *nchunk
                       hipStream_t s) {
     const int grid = nrb < 2048 ? nrb : 2048;
     hipLaunchKernelGGL(k_tile_plan, dim3(grid), dim3(kBlock), 0, s, A.n, A.rowptr, A.col, nrb, chunks, nchunks, lidx,
-                       ok_and_max_dev);
+                       ok_and_max_dev, 0x7fffffff);
+}
+
+// The same plan for `count` consecutive rows of a level-ordered factor copy that start at row j0 (one level of a colour sweep):
+// blocks are counted from j0, the arrays of block b are chunks[b * kTileMaxChunks ..] / nchunks[b]; lidx is indexed like cpos.
+void launch_sweep_tile_plan(int j0, int count, const int32_t *lo_rowptr, const int32_t *lo_cpos, int32_t *chunks, int32_t *nchunks,
+                            uint16_t *lidx, int *ok_and_max_dev, hipStream_t s) {
+    const int nrb = (count + kStreamRows - 1) / kStreamRows;
+    const int grid = nrb < 2048 ? nrb : 2048;
+    hipLaunchKernelGGL(k_tile_plan, dim3(grid), dim3(kBlock), 0, s, (int64_t)count, lo_rowptr + j0, lo_cpos, nrb, chunks, nchunks,
+                       lidx, ok_and_max_dev, j0);
 }
 
 // XT: x-tile elements staged per thread (tile_max_chunks * 64 / 256, rounded up).  VT / XV: storage types of the

@@ -1395,7 +1395,8 @@ __global__ __launch_bounds__(kBlock) void k_lm_sweep(int j0, int count, const in
                                                      const int32_t *__restrict__ lo_cp, const double *__restrict__ lo_v,
                                                      const double *__restrict__ src, const int32_t *__restrict__ src_map,
                                                      double *out, double *__restrict__ dst, const int32_t *__restrict__ rows,
-                                                     const double *__restrict__ dotv, double *__restrict__ part, const int *done) {
+                                                     const double *__restrict__ dotv, double *__restrict__ part,
+                                                     double *__restrict__ out2, const int32_t *__restrict__ map2, const int *done) {
     if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     constexpr int U = kStreamCap / kBlock;
     __shared__ double prod[kStreamCap];
@@ -1439,8 +1440,14 @@ __global__ __launch_bounds__(kBlock) void k_lm_sweep(int j0, int count, const in
             double acc = bi;
             const int ks = UPPER ? rs + 1 : rs, ke = UPPER ? re : re - 1;
             for (int k = ks; k < ke; ++k) acc -= prod[k];
-            const double y = acc / lo_v[base + (UPPER ? rs : re - 1)];
-            out[j] = y;
+            const double d = lo_v[base + (UPPER ? rs : re - 1)];
+            double y = acc / d;
+            if (out2) {                    // (see k_lm_sweep_tile: the row also opens the paired upper solve)
+                y = y / d;
+                out2[map2[j]] = y;
+            } else {
+                out[j] = y;
+            }
             if (dst) dst[own] = y;
             dot += dv * y;
         }
@@ -1452,19 +1459,167 @@ __global__ __launch_bounds__(kBlock) void k_lm_sweep(int j0, int count, const in
     }
 }
 
+// The same sweep with the solution entries a block gathers staged in LDS (Levels::sw_*: the x-tile plan of the level, as
+// k_spmv_tile's): the block's chunks of `out` arrive by coalesced 512-byte wave loads one block ahead instead of one gather
+// per entry through the L2, the matrix stream is values + 16-bit local indices read as aligned pairs, and a row's diagonal
+// travels through its product slot (local index kTileDiag: times 1.0).  Same arithmetic, same order, same bits.
+// `out2` (the last level of a lower solve paired with an upper one whose first level holds the same rows): the row also
+// opens the upper solve -- z = y / d goes to out2[map2[j]], to dst and into the dot product; y itself is not stored.
+template <bool UPPER, int XT>
+__global__ __launch_bounds__(kBlock) void k_lm_sweep_tile(int j0, int count, int n_total, const int32_t *__restrict__ lo_rp,
+                                                          const double *__restrict__ lo_v, const uint16_t *__restrict__ lidx,
+                                                          const int32_t *__restrict__ chunks, const int32_t *__restrict__ nchunks,
+                                                          int tile_doubles, const double *__restrict__ src,
+                                                          const int32_t *__restrict__ src_map, double *out, double *__restrict__ dst,
+                                                          const int32_t *__restrict__ rows, const double *__restrict__ dotv,
+                                                          double *__restrict__ part, double *__restrict__ out2,
+                                                          const int32_t *__restrict__ map2, const int *done) {
+    if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
+    constexpr int U = kStreamCap / kBlock;
+    constexpr int UP = U / 2;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *xs = smem;                      // the staged chunks of `out`
+    double *prod = smem + tile_doubles;     // products, kStreamCap + 4 doubles
+    double *sh = prod + kStreamCap + 4;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nblk = (count + kBlock - 1) / kBlock;
+    int b_lo, b_hi;
+    split_range(nblk, virtual_block(), b_lo, b_hi);
+    typedef double VPair __attribute__((ext_vector_type(2)));
+    typedef unsigned short IPair __attribute__((ext_vector_type(2)));
+    constexpr int XP = (XT * (kBlock / 64) + 7) / 8;
+    VPair a[UP], xt[XP];
+    IPair li[UP];
+    int cnt = 0, base = 0, rs = 0, re = 0, nc = 0, own = 0, m2 = 0;
+    double bi = 0.0, dv = 0.0;
+    bool live = false;
+    auto fetch = [&](int blk) {
+        const int jb = j0 + blk * kBlock;
+        const int jend = (jb + kBlock < j0 + count) ? jb + kBlock : j0 + count;
+        const int j = jb + t;
+        base = lo_rp[jb] & ~1;
+        cnt = lo_rp[jend] - base;
+        live = j < jend;
+        rs = re = 0;
+        if (live) {
+            struct __attribute__((packed, aligned(4))) Ext { int32_t s, e; };
+            const Ext ext = *reinterpret_cast<const Ext *>(lo_rp + j);
+            rs = ext.s - base;
+            re = ext.e - base;
+            own = rows[j];
+            bi = src[src_map ? src_map[j] : j];
+            if (dotv) dv = dotv[own];
+            if (map2) m2 = map2[j];
+        }
+        const int lastp = cnt > 0 ? (cnt - 1) / 2 : 0;
+#pragma unroll
+        for (int u = 0; u < UP; ++u) {
+            const int pr = t + u * kBlock;
+            const int64_t kabs = base + 2 * (int64_t)(pr <= lastp ? pr : lastp);
+            a[u] = *reinterpret_cast<const VPair *>(lo_v + kabs);          // (aligned pairs: see k_spmv_tile)
+            li[u] = *reinterpret_cast<const IPair *>(lidx + kabs);
+        }
+        nc = nchunks[blk];
+        const int32_t *__restrict__ cl = chunks + (int64_t)blk * kTileMaxChunks;
+        const int my_cid = cl[lane < kTileMaxChunks ? lane : 0];
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            const int ci = 2 * (wv + u * (kBlock / 64)) + (lane >> 5);
+            const int cid = __shfl(my_cid, ci);
+            const int64_t gi = (int64_t)(ci < nc ? cid : 0) * kTileChunk + 2 * (lane & 31);
+            xt[u] = *reinterpret_cast<const VPair *>(out + (gi < n_total ? gi : ((n_total - 1) & ~1)));
+        }
+    };
+    if (b_lo < b_hi) fetch(b_lo);
+    double dot = 0.0;
+    for (int blk = b_lo; blk < b_hi; ++blk) {
+        const int j = j0 + blk * kBlock + t;
+        const int ks = rs, ke = re, cnt_cur = cnt, own_c = own, m2_c = m2;
+        const double bi_c = bi, dv_c = dv;
+        const bool live_c = live;
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            const int ci = 2 * (wv + u * (kBlock / 64)) + (lane >> 5);
+            if (ci < nc) *reinterpret_cast<VPair *>(xs + ci * kTileChunk + 2 * (lane & 31)) = xt[u];
+        }
+        __syncthreads();                    // tile complete (and every thread is past the previous row sums)
+#pragma unroll
+        for (int u = 0; u < UP; ++u) {
+            const int k = 2 * (t + u * kBlock);
+            if (k < cnt_cur) {
+                const unsigned short l0 = li[u][0], l1 = li[u][1];
+                const double x0 = xs[l0 == kTileDiag ? 0 : l0], x1 = xs[l1 == kTileDiag ? 0 : l1];
+                double2 pp;
+                pp.x = a[u][0] * (l0 == kTileDiag ? 1.0 : x0);
+                pp.y = a[u][1] * (l1 == kTileDiag ? 1.0 : x1);
+                *reinterpret_cast<double2 *>(prod + k) = pp;
+            }
+        }
+        if (blk + 1 < b_hi) fetch(blk + 1);  // the next block's stream, right-hand side and chunks are in flight from here on
+        __syncthreads();
+        if (live_c) {
+            double acc = bi_c;
+            const int k0 = UPPER ? ks + 1 : ks, k1 = UPPER ? ke : ke - 1;
+            for (int k = k0; k < k1; ++k) acc -= prod[k];
+            const double d = prod[UPPER ? ks : ke - 1];
+            double y = acc / d;
+            if (out2) {
+                y = y / d;
+                out2[m2_c] = y;
+            } else {
+                out[j] = y;
+            }
+            if (dst) dst[own_c] = y;
+            dot += dv_c * y;
+        }
+    }
+    if (part) {
+        __syncthreads();
+        const double tot = block_sum(dot, sh);
+        if (t == 0) part[blockIdx.x] = tot;
+    }
+}
+
 // The whole factor as colour sweeps (Levels::sweep).  `src` / `src_map`: where the right-hand side comes from; dst: the result in
 // the handle's numbering (null: by position in lv.lm_out only).
 static void launch_sweeps(const Levels &lv, bool upper, const double *src, const int32_t *src_map, double *dst, const double *dotv,
-                          double *part, hipStream_t s, const int *done) {
-    for (int l = 0; l < lv.n_levels; ++l) {
+                          double *part, hipStream_t s, const int *done, const SptrsvIo *io) {
+    const int first = (io && io->skip_first) ? 1 : 0;
+    for (int l = first; l < lv.n_levels; ++l) {
         const int j0 = lv.level_ptr[l], cnt = lv.level_ptr[l + 1] - j0;
-        double *pl = part ? part + (size_t)l * lv.sweep_grid : nullptr;
+        // the last level of a lower solve whose rows open the paired upper solve: z instead of y, into the upper numbering
+        const bool emit = !upper && io && io->pair_out && l == lv.n_levels - 1;
+        double *pl = emit ? part : (part ? part + (size_t)l * lv.sweep_grid : nullptr);
+        double *o2 = emit ? io->pair_out : nullptr;
+        const int32_t *m2 = emit ? lv.lm_to_upper : nullptr;
+        double *d = emit ? io->pair_dst : dst;
+        const double *dw = (emit || upper) ? dotv : nullptr;
+        if (!dw) pl = nullptr;
+        const int mc = l < (int)lv.sw_max_chunks.size() ? lv.sw_max_chunks[l] : 0;
+        if (mc > 0) {
+            const int tile_doubles = mc * kTileChunk;
+            const size_t lds = (size_t)(tile_doubles + kStreamCap + 8) * sizeof(double);
+            const int32_t *ch = lv.sw_chunks + (size_t)lv.sw_blk0[l] * kTileMaxChunks, *nch = lv.sw_nchunks + lv.sw_blk0[l];
+#define DPCG_SWEEP_TILE(UP_, XT_)                                                                                              \
+    hipLaunchKernelGGL((k_lm_sweep_tile<UP_, XT_>), dim3(lv.sweep_grid), dim3(kBlock), lds, s, j0, cnt, (int)lv.level_ptr.back(), \
+                       lv.lo_rowptr, lv.lo_val, lv.sw_lidx, ch, nch, tile_doubles, src, src_map, lv.lm_out, d, lv.rows, dw, pl, \
+                       o2, m2, done)
+            if (upper) {
+                if (mc <= 20) DPCG_SWEEP_TILE(true, 5);
+                else DPCG_SWEEP_TILE(true, (kTileMaxChunks * kTileChunk / kBlock));
+            } else {
+                if (mc <= 20) DPCG_SWEEP_TILE(false, 5);
+                else DPCG_SWEEP_TILE(false, (kTileMaxChunks * kTileChunk / kBlock));
+            }
+#undef DPCG_SWEEP_TILE
+            continue;
+        }
         if (upper)
             hipLaunchKernelGGL(k_lm_sweep<true>, dim3(lv.sweep_grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_cpos, lv.lo_val,
-                               src, src_map, lv.lm_out, dst, lv.rows, dotv, pl, done);
+                               src, src_map, lv.lm_out, d, lv.rows, dw, pl, o2, m2, done);
         else
             hipLaunchKernelGGL(k_lm_sweep<false>, dim3(lv.sweep_grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_cpos, lv.lo_val,
-                               src, src_map, lv.lm_out, dst, lv.rows, dotv, pl, done);
+                               src, src_map, lv.lm_out, d, lv.rows, dw, pl, o2, m2, done);
     }
 }
 
@@ -1483,8 +1638,8 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
         const bool keep = io && io->keep_lm;
         const bool dot = io && io->dot_with && io->dot_part;
         launch_sweeps(lv, upper, chained ? io->lm_in : rhs, chained ? lv.lm_from_lower : lv.rows, keep ? nullptr : out,
-                      dot ? io->dot_with : nullptr, dot ? io->dot_part : nullptr, s, done);
-        if (dot) {
+                      dot ? io->dot_with : nullptr, dot ? io->dot_part : nullptr, s, done, io);
+        if (dot && upper) {
             io->dot_done = true;
             io->dot_count = lv.n_levels * lv.sweep_grid;
         }

@@ -2110,6 +2110,11 @@ def test_preconditioner_net_hip_forward_against_the_dense_restatement(D, monkeyp
     ("poisson3d_64", lambda: O.poisson3d(64), None, 2),                               # 2 x 131 072 rows: the colour-sweep kernels
     ("unstructured3d_34_rcm", lambda: O.unstructured_like(O.poisson3d(34), seed=2), "rcm", 2),
     ("random_spd_nonbipartite", None, None, None),
+    # tiled sweeps (solution chunks staged in LDS) + the last lower level opening the upper solve: scaled values, a scrambled
+    # numbering behind the library's RCM (wider chunk lists), and a pattern with triangles (three or more colours / levels)
+    ("poisson3d_66_scaled", lambda: _scaled(O.poisson3d(66), 21), None, 2),
+    ("unstructured3d_66_rcm", lambda: O.unstructured_like(O.poisson3d(66), seed=5), "rcm", 2),
+    ("six_point_760_scaled", lambda: _scaled(_six_point(760), 22), None, None),
 ])
 def test_ic0_in_multicolour_order(D, name, make, reorder, colors):
     """`IC0("solve", ordering="multicolor")`: IC(0) of Q A Q^T with the unknowns colour by colour (2 colours for every grid
