@@ -340,7 +340,7 @@ void launch_update_r(int precond_fused, int64_t n, Scalars *scal, const double *
                      int grid, hipStream_t s, int store_z = 1);
 void launch_update_r_ride(int64_t n, Scalars *scal, const double *part_pq, int n_part_pq, const double *q, double *r,
                           const double *first_level_diag, const int32_t *pos, double *lm_out, int first_level_rows,
-                          double *part_rr, int grid, hipStream_t s);
+                          double *part_rr, int grid, hipStream_t s, bool two_kernel = false);
 void launch_dot_partials(int64_t n, const Scalars *scal, const double *a, const double *b, double *part, int grid,
                          hipStream_t s);
 void launch_update_xp(int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,

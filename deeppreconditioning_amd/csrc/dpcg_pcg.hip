@@ -202,12 +202,17 @@ void launch_update_r(int precond_fused, int64_t n, Scalars *scal, const double *
                            part_rz, part_rr, store_z, none);
 }
 
-// K2 for a preconditioner applied by colour sweeps: the first level of the lower solve rides along (k_update_r<3>)
+// K2 (two_kernel: KB) for a preconditioner applied by colour sweeps: the first level of the lower solve rides along (k_update_r<3>)
 void launch_update_r_ride(int64_t n, Scalars *scal, const double *part_pq, int n_part_pq, const double *q, double *r,
                           const double *first_level_diag, const int32_t *pos, double *lm_out, int first_level_rows,
-                          double *part_rr, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(k_update_r<3>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, first_level_diag,
-                       (double *)nullptr, (double *)nullptr, part_rr, 0, RideArgs{pos, lm_out, first_level_rows});
+                          double *part_rr, int grid, hipStream_t s, bool two_kernel) {
+    const RideArgs ride{pos, lm_out, first_level_rows};
+    if (two_kernel)
+        hipLaunchKernelGGL((k_update_r<3, true>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, first_level_diag,
+                           (double *)nullptr, (double *)nullptr, part_rr, 0, ride);
+    else
+        hipLaunchKernelGGL((k_update_r<3, false>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, first_level_diag,
+                           (double *)nullptr, (double *)nullptr, part_rr, 0, ride);
 }
 
 // part[b] = partial of <a,b>; skipped once the solve is done (scal may be null: always run).

@@ -237,6 +237,14 @@ static bool level_major_syncfree() {              // development knob: DPCG_LM_S
 // `long_rows`: most rows hold more entries than the three of the LDS-ring / strip records (a 27-point stencil, a factor with
 // fill): those kernels would walk nearly every row entry by entry, so such a factor takes the sync-free kernels with their
 // wider records instead (27-point 64^3, IC(0): 24.6 ms per update in strips, see DESIGN).
+// fewest rows per level (on average) for which a factor of <= 4 levels is solved by colour sweeps (DPCG_SWEEP_MIN_ROWS: development
+// knob).  Before the sweeps were tiled and paired the single sync-free launch won below 131 072 rows a level; now, per PCG update
+// with IC(0) in red-black order (tools/mc_probe.py): 256^2 (2 x 32 768 rows) 25.5 -> 17.3 us, 40^3 (2 x 32 000) 29.6 -> 26.6 us.
+static int64_t sweep_min_rows() {
+    static const int64_t v = [] { const char *e = getenv("DPCG_SWEEP_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)16384; }();
+    return v;
+}
+
 int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_t *rp, const int32_t *ci, const double *v,
                  hipStream_t s, const int32_t *relabel = nullptr, bool upper = false, bool long_rows = false) {
     constexpr int kMergeMax = 2048;  // levels this narrow are walked by one workgroup
@@ -349,7 +357,7 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
             // multicolour order at 1M rows: 2 levels of 500K): there a launch per level on the records wins (measured per
             // apply, 100^3 red-black: 104.7 us sync-free, 63.6 with four blocks per ticket, 59.4 one launch per level;
             // 256^2 red-black, 2 x 32K rows: 19.8 sync-free, 30.6 per level)
-            const bool few_very_wide = lv.n_levels <= 4 && n / lv.n_levels >= 131072;
+            const bool few_very_wide = lv.n_levels <= 4 && n / lv.n_levels >= sweep_min_rows();
             if (lv.level_major && level_major_syncfree() && !few_very_wide) return 1;
             if (lv.level_major && few_very_wide) return 2;
             const int64_t rows_in_seg = (int64_t)level_ptr[seg.hi] - level_ptr[seg.lo];
@@ -404,7 +412,7 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         DPCG_HIP(hipMemsetAsync(lv.spin_err, 0, sizeof(int), s));
         // colour sweeps (see Levels::sweep): a level-major factor of a few very wide levels whose blocks fit the LDS product buffer
         static const bool sweeps_on = [] { const char *e = getenv("DPCG_SWEEPS"); return !(e && e[0] == '0'); }();
-        if (sweeps_on && lv.level_major && lv.stream_ok && lv.n_levels <= 4 && n / lv.n_levels >= 131072) {
+        if (sweeps_on && lv.level_major && lv.stream_ok && lv.n_levels <= 4 && n / lv.n_levels >= sweep_min_rows()) {
             lv.sweep = true;
             int64_t widest = 0;
             for (int l = 0; l < lv.n_levels; ++l) widest = std::max<int64_t>(widest, level_ptr[l + 1] - level_ptr[l]);

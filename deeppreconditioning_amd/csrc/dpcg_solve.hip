@@ -31,16 +31,22 @@ static bool defer_x_eligible(const dpcg_system *h, int flags, const double *x_tr
 static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hipStream_t s, int j) {
     const int64_t n = h->A.n;
     const bool f32 = (flags & DPCG_SPMV_F32) != 0;
+    // colour sweeps: the first level of the lower solve (rows without dependencies: y = r / d) rides on the kernel that updates r
+    const bool ride = h->precond == DPCG_PRECOND_LLT_SOLVE && h->lvlL.sweep && h->lvlL.ride_diag && h->lvlL.n_levels >= 2;
     if (fuse_eligible(h, flags, x_true)) {
         // KA: test of the current iterate, p = z + beta p, deferred x += alpha p, q = A p, partials of <p,q>
         launch_spmv_fused(h->A, h->planA, fuse_args(h), h->q, h->part_pq, h->scal, s);          // cg.py:71,83,79,75
         // KB: alpha; r -= alpha q; (z = M r fused); partials <r,z>, <r,r>; k += 1                cg.py:78,80-82,86
         const int pre = h->precond == DPCG_PRECOND_NONE ? 0 : (h->precond == DPCG_PRECOND_JACOBI ? 1 : 2);
-        launch_update_r_two_kernel(pre, n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->dinv, h->z, h->part_rz,
-                                   h->part_rr, h->vec_grid, s);
+        if (ride)
+            launch_update_r_ride(n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->lvlL.ride_diag, h->lvlL.lm_pos, h->lvlL.lm_out,
+                                 h->lvlL.level_ptr[1], h->part_rr, h->vec_grid, s, true);
+        else
+            launch_update_r_two_kernel(pre, n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->dinv, h->z, h->part_rz,
+                                       h->part_rr, h->vec_grid, s);
         if (pre == 2) {
             int np = 0;
-            DPCG_TRY(apply_precond(h, h->r, h->z, s, true, h->part_rz, &np));                    // cg.py:81 (+ cg.py:82 when fused)
+            DPCG_TRY(apply_precond(h, h->r, h->z, s, true, h->part_rz, &np, ride));              // cg.py:81 (+ cg.py:82 when fused)
             if (np == 0) launch_dot_partials(n, h->scal, h->r, h->z, h->part_rz, h->vec_grid, s);   // cg.py:82
         }
         return DPCG_OK;
@@ -61,8 +67,6 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
     // direction (measured: 34.9 -> 33.1 us per update at 1M DoF).
     const bool z_on_the_fly = pre == 1;
     const double *z = pre == 2 ? h->z : h->r;
-    // colour sweeps: the first level of the lower solve (rows without dependencies: y = r / d) rides on K2
-    const bool ride = pre == 2 && h->precond == DPCG_PRECOND_LLT_SOLVE && h->lvlL.sweep && h->lvlL.ride_diag && h->lvlL.n_levels >= 2;
     if (ride)
         launch_update_r_ride(n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->lvlL.ride_diag, h->lvlL.lm_pos, h->lvlL.lm_out,
                              h->lvlL.level_ptr[1], h->part_rr, h->vec_grid, s);

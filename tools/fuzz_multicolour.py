@@ -1,0 +1,110 @@
+"""Randomised check of IC(0) in multicolour order through the colour-sweep kernels (tiled sweeps, the last lower level opening the
+upper solve, the first riding on the r update): grid-like patterns as tools/fuzz_ic0_setup.py's -- 2-D / 3-D boxes of random
+extents, random coefficients, a share of the edges removed, a third of the 2-D ones with a diagonal neighbour (triangles: three
+or more colours), natural or scrambled numbering (the latter through the library's reordering or not) -- mostly beyond 262 144
+rows, where the sweeps are chosen.  With Q from precond_ordering(): the factor must equal oracle IC(0) of Q A Q^T bit for bit, an
+apply sequential substitution bit for bit (twice), and a PCG solve oracle/pcg_oracle.c's (count equal, history 1e-10).
+
+    python tools/fuzz_multicolour.py [cases] [seed] [verbose]
+"""
+import sys
+import numpy as np
+import scipy.sparse as sp
+import torch
+import deeppreconditioning_amd as D
+from oracle import c_oracle as CO
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+
+
+def grid_matrix(shape, drop, diagonal=False):
+    n = int(np.prod(shape))
+    idx = np.arange(n).reshape(shape)
+    rows, cols = [], []
+    for ax in range(len(shape)):
+        a = np.take(idx, np.arange(shape[ax] - 1), axis=ax).ravel()
+        b = np.take(idx, np.arange(1, shape[ax]), axis=ax).ravel()
+        keep = rng.uniform(size=a.size) >= drop
+        rows.append(a[keep])
+        cols.append(b[keep])
+    if diagonal and len(shape) == 2:
+        a, b = idx[:-1, :-1].ravel(), idx[1:, 1:].ravel()
+        keep = rng.uniform(size=a.size) >= drop
+        rows.append(a[keep])
+        cols.append(b[keep])
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    w = -rng.uniform(0.2, 2.0, r.size)
+    off = sp.coo_matrix((w, (r, c)), shape=(n, n)).tocsr()
+    off = off + off.T
+    A = (off + sp.diags(np.asarray(abs(off).sum(axis=1)).ravel() + rng.uniform(0.05, 0.5, n))).tocsr()
+    A.sort_indices()
+    return A
+
+
+bad = 0
+for case in range(cases):
+    dim = int(rng.choice([2, 3, 3]))
+    target = int(rng.choice([60000, 270000, 300000, 420000, 600000, 1000000]))
+    if dim == 2:
+        nx = int(rng.integers(max(8, int(target ** 0.5 / 2)), int(target ** 0.5 * 2)))
+        shape = (max(2, target // nx), nx)
+    else:
+        side = max(4, int(round(target ** (1 / 3))))
+        shape = (max(2, target // (side * side)), int(side * rng.uniform(0.7, 1.3)) + 1, side)
+    drop = float(rng.choice([0.0, 0.0, 0.05, 0.3]))
+    diagonal = dim == 2 and bool(rng.integers(0, 3) == 0)
+    A = grid_matrix(shape, drop, diagonal)
+    n = A.shape[0]
+    scramble = bool(rng.integers(0, 3) == 0)
+    if scramble:
+        p = rng.permutation(n)
+        A = A[p][:, p].tocsr()
+        A.sort_indices()
+    reorder = str(rng.choice(["auto", "None", "rcm"])) if scramble else "None"
+    reorder = None if reorder == "None" else reorder
+    tag = f"case {case}: shape={shape} n={n} drop={drop} diagonal={diagonal} scramble={scramble} reorder={reorder}"
+    S = D.CsrSystem.from_any(A, reorder=reorder)
+    S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+    nc, q = S.precond_ordering()
+    Bc = A[q][:, q].tocsr()
+    Bc.sort_indices()
+    Lref = CO.ic0(Bc)
+    rp, ci, v = S.factor()
+    ok = np.array_equal(rp, Lref.indptr) and np.array_equal(ci, Lref.indices) and np.array_equal(v, Lref.data)
+    what = "factor"
+    if ok:
+        b = rng.uniform(-1, 1, n)
+        zc = CO.sptrsv_upper(CO.transpose_csr(Lref), CO.sptrsv_lower(Lref, b[q]))
+        zref = np.empty(n)
+        zref[q] = zc
+        bd = torch.from_numpy(b).cuda()
+        ok = (np.array_equal(S.precond_apply(bd).cpu().numpy(), zref) and np.array_equal(S.precond_apply(bd).cpu().numpy(), zref))
+        what = "apply"
+    if ok:
+        qinv = np.empty(n, dtype=np.int32)
+        qinv[q] = np.arange(n, dtype=np.int32)
+        if S.reordered:
+            ph = S.permutation()
+            B = A[ph][:, ph].tocsr()
+            B.sort_indices()
+            bb, pperm = b[ph], qinv[ph]
+        else:
+            B, bb, pperm = A, b, qinv
+        _, it, hist, _ = CO.pcg(B, bb, "llt_solve", L=Lref, precond_perm=pperm, max_iter=60)
+        flags = 0 if rng.integers(0, 2) else D._lib.NO_GRAPH
+        res = S.solve(bd, max_iter=60, flags=flags)
+        m = min(len(hist), len(res.res_history))
+        ok = res.iterations == it and np.allclose(res.res_history[:m], hist[:m], rtol=1e-10, atol=0)
+        what = f"solve (iterations {res.iterations} vs {it})"
+        # the apply after a solve (the loop's hand-over of the first level must not leave anything behind)
+        ok = ok and np.array_equal(S.precond_apply(bd).cpu().numpy(), zref)
+    info = S.info()
+    if not ok:
+        bad += 1
+        print("MULTICOLOUR MISMATCH in", what, tag, flush=True)
+    elif len(sys.argv) > 3:
+        print("ok", tag, "colours", nc, "levels", info["levels_lower"], info["levels_upper"], flush=True)
+    S.close()
+print(f"fuzz_multicolour: {cases} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)

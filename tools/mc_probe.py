@@ -8,7 +8,9 @@ import torch
 import deeppreconditioning_amd as D
 from deeppreconditioning_amd import poisson
 
-cases = [("poisson2d_256", lambda: poisson.poisson_system(2, 256)), ("poisson2d_1024", lambda: poisson.poisson_system(2, 1024)),
+cases = [("poisson2d_64", lambda: poisson.poisson_system(2, 64)), ("poisson2d_128", lambda: poisson.poisson_system(2, 128)),
+         ("poisson3d_40", lambda: poisson.poisson_system(3, 40)), ("poisson2d_512", lambda: poisson.poisson_system(2, 512)),
+         ("poisson2d_256", lambda: poisson.poisson_system(2, 256)), ("poisson2d_1024", lambda: poisson.poisson_system(2, 1024)),
          ("poisson3d_64", lambda: poisson.poisson_system(3, 64)), ("poisson3d_100", lambda: poisson.poisson_system(3, 100)),
          ("scrambled3d_100", lambda: D.CsrSystem.from_any(poisson.unstructured_like_csr(3, 100, 0))),
          ("scrambled2d_256", lambda: D.CsrSystem.from_any(poisson.unstructured_like_csr(2, 256, 0)))]
