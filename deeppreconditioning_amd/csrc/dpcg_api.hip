@@ -276,8 +276,9 @@ void free_precond(dpcg_system *h) {
     free_csr(h->Ltp);
     free_levels(h->lvlL);
     free_levels(h->lvlU);
-    dev_free(h->fmap);
-    dev_free(h->fmap_inv);
+    if (h->fmap != h->mc_perm) dev_free(h->fmap);            // (the handle's cached colouring is not the preconditioner's to free)
+    if (h->fmap_inv != h->mc_iperm) dev_free(h->fmap_inv);
+    h->fmap = h->fmap_inv = nullptr;
     h->precond_colors = 0;
     h->precond_fn = nullptr;
     h->precond_user = nullptr;
@@ -328,6 +329,7 @@ extern "C" int dpcg_destroy(dpcg_handle_t h) {
     free_precond(h);
     free_csr(h->A);
     free_csr(h->A_user);
+    dev_free(h->mc_perm); dev_free(h->mc_iperm);
     dev_free(h->perm); dev_free(h->iperm); dev_free(h->pb); dev_free(h->pxt); dev_free(h->pv0); dev_free(h->pv1);
     dev_free(h->pf0); dev_free(h->pf1);
     free_plan(h->planA);
@@ -388,6 +390,9 @@ extern "C" int dpcg_reorder(dpcg_handle_t h, int mode, dpcg_stream_t stream, int
         return st;
     }
     free_precond(h);                 // an attached preconditioner referred to the old matrix
+    dev_free(h->mc_perm);            // ... and so did a cached colouring
+    dev_free(h->mc_iperm);
+    h->mc_colors = 0;
     free_ell(h->ell_a);
     drop_graph(h);
     dev_free(h->A.val32);            // recreated on demand from the reordered values

@@ -214,6 +214,11 @@ struct dpcg_system {
     // fmap_inv the inverse; owned.  Null: the factor is in the caller's numbering (handle index through iperm, if any).
     int32_t *fmap = nullptr, *fmap_inv = nullptr;
     int precond_colors = 0;               // colours of that ordering (0: caller's ordering)
+    // The multicolour ordering of the handle's PATTERN (and its inverse), kept across preconditioner setups and
+    // dpcg_update_values -- the colouring only looks at the pattern; fmap / fmap_inv alias these arrays while a factor in that
+    // ordering is attached.  Dropped when the handle is renumbered or destroyed.
+    int32_t *mc_perm = nullptr, *mc_iperm = nullptr;
+    int mc_colors = 0;
     dpcg::SpmvPlan planL, planLt;
     // dpcg_reorder: the handle iterates on A = P A_user P^T; perm[new] = old, iperm[old] = new (device)
     int32_t *perm = nullptr, *iperm = nullptr;

@@ -245,6 +245,11 @@ static int64_t sweep_min_rows() {
     return v;
 }
 
+static int sweep_max_levels() {
+    static const int v = [] { const char *e = getenv("DPCG_SWEEP_MAX_LEVELS"); return e ? atoi(e) : 4; }();
+    return v;
+}
+
 int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_t *rp, const int32_t *ci, const double *v,
                  hipStream_t s, const int32_t *relabel = nullptr, bool upper = false, bool long_rows = false) {
     constexpr int kMergeMax = 2048;  // levels this narrow are walked by one workgroup
@@ -357,7 +362,7 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
             // multicolour order at 1M rows: 2 levels of 500K): there a launch per level on the records wins (measured per
             // apply, 100^3 red-black: 104.7 us sync-free, 63.6 with four blocks per ticket, 59.4 one launch per level;
             // 256^2 red-black, 2 x 32K rows: 19.8 sync-free, 30.6 per level)
-            const bool few_very_wide = lv.n_levels <= 4 && n / lv.n_levels >= sweep_min_rows();
+            const bool few_very_wide = lv.n_levels <= sweep_max_levels() && n / lv.n_levels >= sweep_min_rows();
             if (lv.level_major && level_major_syncfree() && !few_very_wide) return 1;
             if (lv.level_major && few_very_wide) return 2;
             const int64_t rows_in_seg = (int64_t)level_ptr[seg.hi] - level_ptr[seg.lo];
@@ -412,7 +417,7 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         DPCG_HIP(hipMemsetAsync(lv.spin_err, 0, sizeof(int), s));
         // colour sweeps (see Levels::sweep): a level-major factor of a few very wide levels whose blocks fit the LDS product buffer
         static const bool sweeps_on = [] { const char *e = getenv("DPCG_SWEEPS"); return !(e && e[0] == '0'); }();
-        if (sweeps_on && lv.level_major && lv.stream_ok && lv.n_levels <= 4 && n / lv.n_levels >= sweep_min_rows()) {
+        if (sweeps_on && lv.level_major && lv.stream_ok && lv.n_levels <= sweep_max_levels() && n / lv.n_levels >= sweep_min_rows()) {
             lv.sweep = true;
             int64_t widest = 0;
             for (int l = 0; l < lv.n_levels; ++l) widest = std::max<int64_t>(widest, level_ptr[l + 1] - level_ptr[l]);
@@ -888,12 +893,31 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
     CsrDev Ac;
     int32_t *cperm = nullptr, *ciperm = nullptr;
     int n_colors = 0;
+    PhaseTimer pt0(s);
     if (ordering == DPCG_ORDER_MULTICOLOR) {
-        DPCG_TRY(multicolor_order(h->A, &cperm, &ciperm, &n_colors, s));
+        // the colouring looks at the pattern only: computed once per handle numbering (kept across dpcg_update_values)
+        static const bool keep_coloring = [] { const char *ev = getenv("DPCG_KEEP_COLORING"); return !(ev && ev[0] == '0'); }();
+        if (!h->mc_perm || !keep_coloring) {
+            int32_t *p = nullptr, *ip = nullptr;
+            int nc = 0;
+            DPCG_TRY(multicolor_order(h->A, &p, &ip, &nc, s));
+            if (h->fmap == h->mc_perm) {       // the attached factor keeps the arrays it was built with until it is replaced
+                h->mc_perm = h->mc_iperm = nullptr;
+            } else {
+                dev_free(h->mc_perm);
+                dev_free(h->mc_iperm);
+            }
+            h->mc_perm = p;
+            h->mc_iperm = ip;
+            h->mc_colors = nc;
+        }
+        cperm = h->mc_perm;
+        ciperm = h->mc_iperm;
+        n_colors = h->mc_colors;
+        pt0.mark("multicolour ordering");
         const int stp = permute_csr(h->A, cperm, ciperm, Ac, s);
+        pt0.mark("Q A Q^T");
         if (stp < 0) {
-            dev_free(cperm);
-            dev_free(ciperm);
             free_csr(Ac);
             return stp;
         }
@@ -907,8 +931,6 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
     auto fail = [&](int st) {
         free_csr(Lf);
         free_csr(Ac);
-        dev_free(cperm);
-        dev_free(ciperm);
         return st;
     };
     int st = DPCG_OK;

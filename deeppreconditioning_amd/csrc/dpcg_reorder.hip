@@ -627,11 +627,185 @@ __global__ __launch_bounds__(kBlock) void k_check_coloring(int64_t n, const int3
     }
 }
 
+// ---- two colours by REGIONS: kRegions seeds spread over the index range grow level-synchronously, so that the searches meet after
+// a fraction of the graph's diameter (a single breadth-first search of a 256^2 grid is 511 dependent steps, of a 100^3 grid 298: at
+// ~3 launches a step that was 3 of the 4.4 / 5.3 ms of an IC(0) setup in multicolour order).  state[v] = region << 1 | parity within
+// the region, step[v] = the step at which v joined (-1: not yet).
+constexpr int kRegions = 256;
+constexpr int kRegionBatch = 16;      // growth steps enqueued between two looks at the visited count
+
+__global__ void k_region_seed(int64_t n, int32_t *step, int32_t *state, int *visited) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= kRegions) return;
+    // hashed positions: evenly spaced indices would line the seeds up along one edge of a naturally ordered grid
+    // (two seeds may coincide -- the later region simply stays empty)
+    const int64_t v = (int64_t)(((unsigned long long)jp_priority(r + 1) * (unsigned long long)n) >> 32);
+    if (atomicCAS(step + v, -1, 0) == -1) {
+        state[v] = r << 1;
+        atomicAdd(visited, 1);
+    }
+}
+
+// one growth step: an unvisited vertex with a neighbour that joined at step `cur` joins the region of the FIRST such neighbour in
+// its row (ascending columns: deterministic), with the opposite parity
+__global__ __launch_bounds__(kBlock) void k_region_grow(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                        int32_t *step, int32_t *state, int cur, int *visited) {
+    __shared__ int sh_new;
+    if (threadIdx.x == 0) sh_new = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int joined = 0;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) {
+        if (__hip_atomic_load(step + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) continue;
+        for (int k = rp[v]; k < rp[v + 1]; ++k) {
+            const int u = ci[k];
+            if (__hip_atomic_load(step + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cur) {
+                state[v] = state[u] ^ 1;           // (state[u] was written by an earlier launch)
+                __hip_atomic_store(step + v, cur + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ++joined;
+                break;
+            }
+        }
+    }
+    if (joined) atomicAdd(&sh_new, joined);
+    __syncthreads();
+    if (threadIdx.x == 0 && sh_new) atomicAdd(visited, sh_new);
+}
+
+// rel[a * kRegions + b] |= 1 when an edge joins regions a and b with opposite parities (the two regions agree as they are),
+//                          2 when it joins equal parities (one of the two has to be flipped)
+__global__ __launch_bounds__(kBlock) void k_region_relations(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                             const int32_t *__restrict__ state, unsigned int *rel) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) {
+        const int sv = state[v];
+        for (int k = rp[v]; k < rp[v + 1]; ++k) {
+            const int u = ci[k];
+            if (u <= v) continue;
+            const int su = state[u];
+            if ((su >> 1) == (sv >> 1)) continue;   // inside a region: the final edge-by-edge check looks at those
+            const unsigned bit = ((su ^ sv) & 1) ? 1u : 2u;
+            unsigned int *a = rel + (size_t)(sv >> 1) * kRegions + (su >> 1), *b = rel + (size_t)(su >> 1) * kRegions + (sv >> 1);
+            if (!(__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(a, bit);
+            if (!(__hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(b, bit);
+        }
+    }
+}
+
+// mask[v] = -1 (a candidate) for the vertices of the regions of component `comp`, 0 otherwise: k_min_degree's "unvisited" filter
+__global__ __launch_bounds__(kBlock) void k_region_mask(int64_t n, const int32_t *__restrict__ state, const int32_t *__restrict__ comp_of,
+                                                        int comp, int32_t *__restrict__ mask) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) mask[v] = comp_of[state[v] >> 1] == comp ? -1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_region_colors(int64_t n, const int32_t *__restrict__ state, const int32_t *__restrict__ flip,
+                                                          int32_t *__restrict__ color) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) color[v] = (state[v] & 1) ^ flip[state[v] >> 1];
+}
+
 __global__ __launch_bounds__(kBlock) void k_invert_perm(int64_t n, const int32_t *__restrict__ perm, int32_t *__restrict__ iperm) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) iperm[perm[r]] = (int32_t)r;
 }
 }  // namespace
+
+// Two colours through regions (see k_region_seed).  *colored = true when `color` holds a proper 2-colouring in which the vertex
+// of smallest (degree, index) of every connected component has colour 0 -- what the search-by-search parity colouring below
+// produces too, so the two agree vertex by vertex.  false (nothing to report): an odd cycle, a component without a seed, more
+// than a handful of components -- the caller goes on with the other methods.
+static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bool *colored, hipStream_t s) {
+    const int64_t n = A.n;
+    *colored = false;
+    if (n < 4 * kRegions) return DPCG_OK;
+    Buf<int32_t> step, state, deg, mask, d_small;
+    Buf<unsigned int> rel;
+    Buf<unsigned long long> best;
+    DPCG_TRY(step.alloc(n)); DPCG_TRY(state.alloc(n)); DPCG_TRY(deg.alloc(n)); DPCG_TRY(mask.alloc(n));
+    DPCG_TRY(d_small.alloc(2 * kRegions)); DPCG_TRY(rel.alloc((int64_t)kRegions * kRegions)); DPCG_TRY(best.alloc(1));
+    PhaseTimer pt(s);
+    DPCG_HIP(hipMemsetAsync(step.p, 0xff, (size_t)n * sizeof(int32_t), s));
+    DPCG_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
+    hipLaunchKernelGGL(k_region_seed, dim3((kRegions + 63) / 64), dim3(64), 0, s, n, step.p, state.p, flags);
+    int visited = 0, cur = 0;
+    for (;;) {
+        for (int b = 0; b < kRegionBatch; ++b, ++cur)
+            hipLaunchKernelGGL(k_region_grow, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, step.p, state.p, cur, flags);
+        int now = 0;
+        DPCG_HIP(hipMemcpyAsync(&now, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        if (now == n) break;
+        if (now == visited) return DPCG_OK;          // a component without a seed
+        visited = now;
+    }
+    pt.mark("  regions: growth");
+    DPCG_HIP(hipMemsetAsync(rel.p, 0, (size_t)kRegions * kRegions * sizeof(unsigned int), s));
+    hipLaunchKernelGGL(k_region_relations, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, state.p, rel.p);
+    std::vector<unsigned int> h_rel((size_t)kRegions * kRegions);
+    DPCG_HIP(hipMemcpyAsync(h_rel.data(), rel.p, h_rel.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    // walk the graph of regions: flip[b] relative to the first region of its component
+    std::vector<int32_t> flip((size_t)kRegions, 0), comp((size_t)kRegions, -1), stack;
+    int n_comp = 0;
+    for (int r0 = 0; r0 < kRegions; ++r0) {
+        if (comp[(size_t)r0] >= 0) continue;
+        comp[(size_t)r0] = n_comp;
+        stack.assign(1, r0);
+        while (!stack.empty()) {
+            const int a = stack.back();
+            stack.pop_back();
+            for (int b = 0; b < kRegions; ++b) {
+                const unsigned bits = h_rel[(size_t)a * kRegions + b];
+                if (!bits) continue;
+                if (bits == 3u) return DPCG_OK;                                   // an odd cycle through the two regions
+                const int want = flip[(size_t)a] ^ (bits == 2u ? 1 : 0);
+                if (comp[(size_t)b] < 0) {
+                    comp[(size_t)b] = n_comp;
+                    flip[(size_t)b] = want;
+                    stack.push_back(b);
+                } else if (flip[(size_t)b] != want) {
+                    return DPCG_OK;                                               // an odd cycle through several regions
+                }
+            }
+        }
+        ++n_comp;
+    }
+    // (an empty region -- its seed coincided with another one -- is a component of its own without vertices: harmless)
+    std::vector<int32_t> h_small((size_t)2 * kRegions);
+    for (int r = 0; r < kRegions; ++r) h_small[(size_t)r] = comp[(size_t)r];
+    DPCG_HIP(hipMemcpyAsync(d_small.p, h_small.data(), kRegions * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_degrees, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, A.rowptr, deg.p);
+    int real_comps = 0;
+    for (int c = 0; c < n_comp; ++c) {
+        // the component's vertex of smallest (degree, index) gets colour 0
+        DPCG_HIP(hipMemsetAsync(best.p, 0xff, sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k_region_mask, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, state.p, d_small.p, c, mask.p);
+        hipLaunchKernelGGL(k_min_degree, dim3(rows_grid(n, 1024)), dim3(kBlock), 0, s, (const int32_t *)nullptr, (int64_t)0, n, deg.p, mask.p, 1,
+                           best.p);
+        unsigned long long hb = 0;
+        DPCG_HIP(hipMemcpyAsync(&hb, best.p, sizeof(hb), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        if (hb == ~0ull) continue;                                                 // an empty region
+        if (++real_comps > 8) return DPCG_OK;                                      // many components: the searches below handle them
+        int32_t sv = 0;
+        DPCG_HIP(hipMemcpyAsync(&sv, state.p + (hb & 0xffffffffu), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        if (((sv & 1) ^ flip[(size_t)(sv >> 1)]) != 0)
+            for (int r = 0; r < kRegions; ++r)
+                if (comp[(size_t)r] == c) flip[(size_t)r] ^= 1;
+    }
+    DPCG_HIP(hipMemcpyAsync(d_small.p + kRegions, flip.data(), kRegions * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_region_colors, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, state.p, d_small.p + kRegions, color);
+    DPCG_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
+    hipLaunchKernelGGL(k_check_coloring, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, A.rowptr, A.col, color, flags);
+    int bad = 0;
+    DPCG_HIP(hipMemcpyAsync(&bad, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    *colored = bad == 0;
+    pt.mark("  regions: relations, flips, check");
+    return DPCG_OK;
+}
 
 int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_colors, hipStream_t s) {
     const int64_t n = A.n;
@@ -642,7 +816,10 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
     DPCG_TRY(color.alloc(n)); DPCG_TRY(perm.alloc(n)); DPCG_TRY(iperm.alloc(n)); DPCG_TRY(iota.alloc(n));
     DPCG_TRY(key_sorted.alloc(n)); DPCG_TRY(flags.alloc(4));
     bool colored = false;
-    {   // 1. breadth-first parity, component by component
+    PhaseTimer pt(s);
+    static const bool regions_on = [] { const char *e = getenv("DPCG_COLOR_REGIONS"); return !(e && e[0] == '0'); }();
+    if (regions_on) DPCG_TRY(two_colors_by_regions(A, color.p, flags.p, &colored, s));      // 0. two colours, many searches at once
+    if (!colored) {   // 1. breadth-first parity, component by component
         Buf<int32_t> deg, level, order, start, count;
         Buf<unsigned long long> best;
         const int64_t nlv = n + 2 + 2 * kBfsBatch;
@@ -707,12 +884,14 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
     DPCG_TRY(reduce_max_i32(color.p, reinterpret_cast<int32_t *>(flags.p + 3), n, s));
     DPCG_HIP(hipMemcpyAsync(&cmax, flags.p + 3, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
+    pt.mark("  colours");
     launch_iota(n, iota.p, s);
     // stable sort by colour: ascending vertex index inside a colour
     DPCG_TRY(sort_pairs_u32_i32(reinterpret_cast<const uint32_t *>(color.p), key_sorted.p, iota.p, perm.p, n, bits_for((uint64_t)cmax), s));
     hipLaunchKernelGGL(k_invert_perm, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, perm.p, iperm.p);
     DPCG_HIP(hipStreamSynchronize(s));
     DPCG_CHECK_LAUNCH();
+    pt.mark("  sort by colour");
     if (n_colors) *n_colors = cmax + 1;
     *perm_out = perm.release();
     *iperm_out = iperm.release();

@@ -1240,11 +1240,21 @@ def test_update_values_on_the_same_pattern(D, case):
     assert S.reordered == F.reordered
     x = _dev(O.rhs(A0.shape[0], 6))
     assert torch.equal(S @ x, F @ x)
-    for pc, flags in ((D.Jacobi(), 0), (D.IC0("solve"), 0), (D.Jacobi(), D._lib.SPMV_F32), (D.Jacobi(), D._lib.NO_SMALL | D._lib.NO_TEAM)):
+    S.set_preconditioner(D.IC0("solve", ordering="multicolor"))      # (the colouring of the pattern: computed here, kept by the handle)
+    colouring = S.precond_ordering()
+    S.update_values(A0.data)
+    S.update_values(A1.data)
+    for pc, flags in ((D.Jacobi(), 0), (D.IC0("solve"), 0), (D.Jacobi(), D._lib.SPMV_F32), (D.Jacobi(), D._lib.NO_SMALL | D._lib.NO_TEAM),
+                      (D.IC0("solve", ordering="multicolor"), 0), (D.IC0("solve", ordering="multicolor"), D._lib.NO_GRAPH)):
         S.set_preconditioner(pc)
         F.set_preconditioner(pc)
         rs, rf = S.solve(b, flags=flags), F.solve(b, flags=flags)
         assert rs.iterations == rf.iterations and torch.equal(rs.x, rf.x) and np.array_equal(rs.res_history, rf.res_history)
+    # the factor in multicolour order: the ordering found on the first system, the values of the second
+    assert S.precond_ordering()[0] == colouring[0] == F.precond_ordering()[0]
+    assert np.array_equal(S.precond_ordering()[1], colouring[1]) and np.array_equal(F.precond_ordering()[1], colouring[1])
+    for got, want in zip(S.factor(), F.factor()):
+        assert np.array_equal(got, want)
     # and against the oracle on the new matrix
     S.set_preconditioner(D.Jacobi())
     A1d = A1.astype(np.float64)

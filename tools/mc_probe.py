@@ -14,6 +14,26 @@ cases = [("poisson2d_64", lambda: poisson.poisson_system(2, 64)), ("poisson2d_12
          ("poisson3d_64", lambda: poisson.poisson_system(3, 64)), ("poisson3d_100", lambda: poisson.poisson_system(3, 100)),
          ("scrambled3d_100", lambda: D.CsrSystem.from_any(poisson.unstructured_like_csr(3, 100, 0))),
          ("scrambled2d_256", lambda: D.CsrSystem.from_any(poisson.unstructured_like_csr(2, 256, 0)))]
+def _grid_with_dropped_edges(m, drop, diagonal):
+    """m x m grid, a share of the edges removed (and, optionally, the south-west / north-east diagonal added): the parity
+    colouring no longer applies (several components / triangles) -- greedy colouring, 3 .. 7 colours."""
+    import numpy as np
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    idx = np.arange(m * m).reshape(m, m)
+    pairs = [(idx[:, 1:], idx[:, :-1]), (idx[1:, :], idx[:-1, :])] + ([(idx[1:, 1:], idx[:-1, :-1])] if diagonal else [])
+    r = np.concatenate([a.ravel() for a, _ in pairs])
+    c = np.concatenate([b.ravel() for _, b in pairs])
+    keep = rng.uniform(size=r.size) >= drop
+    off = sp.coo_matrix((-np.ones(int(keep.sum())), (r[keep], c[keep])), shape=(m * m, m * m)).tocsr()
+    A = (off + off.T + sp.diags(np.full(m * m, 6.5))).tocsr()
+    A.sort_indices()
+    return D.CsrSystem.from_any(A)
+
+
+cases += [("six_point_1000", lambda: _grid_with_dropped_edges(1000, 0.0, True)),
+          ("dropped2d_1000", lambda: _grid_with_dropped_edges(1000, 0.3, False)),
+          ("dropped_six_1000", lambda: _grid_with_dropped_edges(1000, 0.1, True))]
 only = sys.argv[1:] or None
 for name, make in cases:
     if only and name not in only:
