@@ -358,8 +358,11 @@ def extra_workloads(D, poisson, torch) -> dict:
     for name, pc in (("jacobi", D.Jacobi()), ("ic0_solve", D.IC0("solve")),
                      ("ic0_multicolor_solve", D.IC0("solve", ordering="multicolor")),
                      ("ict_multiply_reference_default", D.ICT("multiply", 1, 0.1))):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         s.set_preconditioner(pc)            # first attach: module load etc.; the second one is timed (test.py:130-135 `setups`)
         torch.cuda.synchronize()
+        first_ms = (time.perf_counter() - t0) * 1e3
         t0 = time.perf_counter()
         s.set_preconditioner(pc)
         torch.cuda.synchronize()
@@ -367,6 +370,8 @@ def extra_workloads(D, poisson, torch) -> dict:
         r = solve_twice(s, b)
         c2[name] = {"iterations": r.iterations, "status": r.status, "ms": round(r.seconds * 1e3, 3),
                     "iterations_per_s": round(r.iterations / r.seconds, 1), "setup_ms": round(setup_ms, 2)}
+        if name == "ic0_multicolor_solve":  # the colouring belongs to the pattern: the handle keeps it (setup_ms: values changed only)
+            c2[name]["setup_new_pattern_ms"] = round(first_ms, 2)
         if name in ("ic0_solve", "ic0_multicolor_solve"):
             c2[name]["apply_roofline"] = apply_roofline(s, time_apply(s, b, torch))
         if name == "ic0_solve":
@@ -438,8 +443,11 @@ def extra_workloads(D, poisson, torch) -> dict:
                                    "pcg_us_per_update": round(r.seconds / r.iterations * 1e6, 1), "pcg_ms": round(r.seconds * 1e3, 3),
                                    "apply_roofline": apply_roofline(s_t, apply_us)}
         # the same factorisation in multicolour (here: red-black) order: 2 levels instead of hundreds
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         s_t.set_preconditioner(D.IC0("solve", ordering="multicolor"))
         torch.cuda.synchronize()
+        first_ms = (time.perf_counter() - t0) * 1e3
         t0 = time.perf_counter()
         s_t.set_preconditioner(D.IC0("solve", ordering="multicolor"))
         torch.cuda.synchronize()
@@ -449,7 +457,7 @@ def extra_workloads(D, poisson, torch) -> dict:
         r = solve_twice(s_t, b_t)
         s_t.set_preconditioner(D.Jacobi())
         rj = solve_twice(s_t, b_t)
-        trsv[f"poisson3d_{n3}_multicolor"] = {"colors": n_colors, "setup_ms": round(setup_ms, 2),
+        trsv[f"poisson3d_{n3}_multicolor"] = {"colors": n_colors, "setup_ms": round(setup_ms, 2), "setup_new_pattern_ms": round(first_ms, 2),
                                               "apply_us": round(apply_us, 1), "pcg_iterations": r.iterations,
                                               "pcg_us_per_update": round(r.seconds / r.iterations * 1e6, 1),
                                               "pcg_ms": round(r.seconds * 1e3, 3), "jacobi_pcg_ms": round(rj.seconds * 1e3, 3),
@@ -500,6 +508,13 @@ def extra_workloads(D, poisson, torch) -> dict:
         if name != "jacobi":
             c3[name]["apply_roofline"] = apply_roofline(s3, time_apply(s3, b3, torch))
             c3[name]["levels"] = s3.info()["levels_lower"]
+        if name == "ic0_multicolor_solve":   # that was the first attach on this pattern (colouring included); again, colouring kept:
+            c3[name]["setup_new_pattern_ms"] = c3[name]["setup_ms"]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            s3.set_preconditioner(pc)
+            torch.cuda.synchronize()
+            c3[name]["setup_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
     c3["levels"] = s3.info()["levels_lower"]
     # config 5 AS BASELINE STATES IT: mixed fp32-SpMV / fp64 PCG on this 1M-DoF unstructured system (values not
     # fp32-representable; the fp32 copy is made from the reordered matrix), residual-matched to the fp64 run

@@ -276,6 +276,9 @@ void free_precond(dpcg_system *h) {
     free_csr(h->Ltp);
     free_levels(h->lvlL);
     free_levels(h->lvlU);
+    free_plan(h->planM);
+    free_plan(h->planL);
+    free_plan(h->planLt);
     if (h->fmap != h->mc_perm) dev_free(h->fmap);            // (the handle's cached colouring is not the preconditioner's to free)
     if (h->fmap_inv != h->mc_iperm) dev_free(h->fmap_inv);
     h->fmap = h->fmap_inv = nullptr;

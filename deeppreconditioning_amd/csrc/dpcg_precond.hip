@@ -750,7 +750,7 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
         DPCG_TRY(permute_csr(h->Lt, h->perm, h->iperm, h->Ltp, s));
         DPCG_TRY(make_plan(h->Lp, h->planL, s));
         DPCG_TRY(make_plan(h->Ltp, h->planLt, s));
-    } else {
+    } else if (mode == DPCG_PRECOND_LLT_MULTIPLY) {          // (the triangular solves run on their schedules, not on SpMV plans)
         DPCG_TRY(make_plan(h->L, h->planL, s));
         DPCG_TRY(make_plan(h->Lt, h->planLt, s));
     }
