@@ -156,6 +156,10 @@ struct Levels {
     // result by position AND in the handle's numbering and sums <r,z> on the way (k_lm_sweep): no way-in / way-out passes.
     bool sweep = false;
     int sweep_grid = 0;                    // workgroups per level launch; an apply leaves n_levels * sweep_grid partials of <r,z>
+    // More levels than the partials have room for at a useful grid (sweep_dot false): every level is launched with a grid of its
+    // own (sw_grid) and <r,z> is a launch of its own after the apply.
+    bool sweep_dot = true;
+    std::vector<int> sw_grid;
     // Tiled sweeps: an x-tile plan (as SpmvPlan's) per level of the level-ordered copy -- blocks of 256 rows counted from the
     // level's first row; the solution entries a block gathers are staged in LDS in 64-entry chunks (k_lm_sweep_tile).
     int32_t *sw_chunks = nullptr, *sw_nchunks = nullptr;

@@ -245,9 +245,15 @@ static int64_t sweep_min_rows() {
     return v;
 }
 
-static int sweep_max_levels() {
-    static const int v = [] { const char *e = getenv("DPCG_SWEEP_MAX_LEVELS"); return e ? atoi(e) : 4; }();
-    return v;
+// Up to 4 levels of >= sweep_min_rows() rows each; a fifth when the levels are very wide (>= 131 072 rows on average).  Measured at
+// 1M rows on greedy colourings (tools/mc_probe.py, us per PCG update, sync-free launch -> sweeps with a grid per level): 5 levels
+// 119 -> 98, 7 levels 123 -> 162 / 152 (hashed-priority colour classes scatter a level's columns: the gather sweep, many launches).
+// DPCG_SWEEP_MAX_LEVELS: development knob (then for any width).
+static bool sweep_levels_ok(int64_t n, int n_levels) {
+    static const int knob = [] { const char *e = getenv("DPCG_SWEEP_MAX_LEVELS"); return e ? atoi(e) : 0; }();
+    if (n_levels < 1 || n / n_levels < sweep_min_rows()) return false;
+    if (knob > 0) return n_levels <= knob;
+    return n_levels <= 4 || (n_levels == 5 && n / n_levels >= 131072);
 }
 
 int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_t *rp, const int32_t *ci, const double *v,
@@ -362,7 +368,7 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
             // multicolour order at 1M rows: 2 levels of 500K): there a launch per level on the records wins (measured per
             // apply, 100^3 red-black: 104.7 us sync-free, 63.6 with four blocks per ticket, 59.4 one launch per level;
             // 256^2 red-black, 2 x 32K rows: 19.8 sync-free, 30.6 per level)
-            const bool few_very_wide = lv.n_levels <= sweep_max_levels() && n / lv.n_levels >= sweep_min_rows();
+            const bool few_very_wide = sweep_levels_ok(n, lv.n_levels);
             if (lv.level_major && level_major_syncfree() && !few_very_wide) return 1;
             if (lv.level_major && few_very_wide) return 2;
             const int64_t rows_in_seg = (int64_t)level_ptr[seg.hi] - level_ptr[seg.lo];
@@ -417,7 +423,7 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
         DPCG_HIP(hipMemsetAsync(lv.spin_err, 0, sizeof(int), s));
         // colour sweeps (see Levels::sweep): a level-major factor of a few very wide levels whose blocks fit the LDS product buffer
         static const bool sweeps_on = [] { const char *e = getenv("DPCG_SWEEPS"); return !(e && e[0] == '0'); }();
-        if (sweeps_on && lv.level_major && lv.stream_ok && lv.n_levels <= sweep_max_levels() && n / lv.n_levels >= sweep_min_rows()) {
+        if (sweeps_on && lv.level_major && lv.stream_ok && sweep_levels_ok(n, lv.n_levels)) {
             lv.sweep = true;
             int64_t widest = 0;
             for (int l = 0; l < lv.n_levels; ++l) widest = std::max<int64_t>(widest, level_ptr[l + 1] - level_ptr[l]);
@@ -458,6 +464,21 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
                     int g = (int)std::min<int64_t>(blocks, std::min<int64_t>(per_cu * 256, kMaxSpmvGrid / lv.n_levels));
                     if (g > 8) g -= g % 8;
                     lv.sweep_grid = std::max(1, g);
+                }
+            }
+            // more than four levels: the partials of <r,z> (levels x grid <= 2048) would leave each level a grid too small for
+            // its rows -- every level gets the grid its size asks for, and the dot product becomes a launch of its own
+            lv.sweep_dot = lv.n_levels <= 4;
+            if (!lv.sweep_dot) {
+                lv.sw_grid.assign((size_t)lv.n_levels, 1);
+                for (int l = 0; l < lv.n_levels; ++l) {
+                    const int64_t bl = (level_ptr[l + 1] - level_ptr[l] + kBlock - 1) / kBlock;
+                    const int mc = l < (int)lv.sw_max_chunks.size() ? lv.sw_max_chunks[(size_t)l] : 0;
+                    const size_t lds = (size_t)(mc * kTileChunk + kStreamCap + 8) * sizeof(double);
+                    const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+                    int g = (int)std::min<int64_t>(bl, (int64_t)per_cu * 256);
+                    if (g > 8) g -= g % 8;
+                    lv.sw_grid[(size_t)l] = std::max(1, g);
                 }
             }
         }
@@ -836,7 +857,7 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
             // colour sweeps: the first level of L^T holds the rows of L's last level (no dependants; equal counts: the same set)
             // -- the last lower sweep can open the upper solve (SptrsvIo::pair_out)
             const Levels &lo = h->lvlL, &up = h->lvlU;
-            if (lo.sweep && up.sweep && lo.n_levels == up.n_levels && lo.n_levels >= 2 && lo.sweep_grid == up.sweep_grid &&
+            if (lo.sweep && up.sweep && lo.n_levels == up.n_levels && lo.n_levels >= 2 && (lo.sweep_grid == up.sweep_grid || !up.sweep_dot) &&
                 up.level_ptr[1] - up.level_ptr[0] == lo.level_ptr[(size_t)lo.n_levels] - lo.level_ptr[(size_t)lo.n_levels - 1]) {
                 static const bool pair_on = [] { const char *e = getenv("DPCG_SWEEP_PAIR"); return !(e && e[0] == '0'); }();
                 if (pair_on) {

@@ -1589,6 +1589,7 @@ static void launch_sweeps(const Levels &lv, bool upper, const double *src, const
         const int j0 = lv.level_ptr[l], cnt = lv.level_ptr[l + 1] - j0;
         // the last level of a lower solve whose rows open the paired upper solve: z instead of y, into the upper numbering
         const bool emit = !upper && io && io->pair_out && l == lv.n_levels - 1;
+        const int grid = lv.sweep_dot ? lv.sweep_grid : lv.sw_grid[(size_t)l];
         double *pl = emit ? part : (part ? part + (size_t)l * lv.sweep_grid : nullptr);
         double *o2 = emit ? io->pair_out : nullptr;
         const int32_t *m2 = emit ? lv.lm_to_upper : nullptr;
@@ -1601,7 +1602,7 @@ static void launch_sweeps(const Levels &lv, bool upper, const double *src, const
             const size_t lds = (size_t)(tile_doubles + kStreamCap + 8) * sizeof(double);
             const int32_t *ch = lv.sw_chunks + (size_t)lv.sw_blk0[l] * kTileMaxChunks, *nch = lv.sw_nchunks + lv.sw_blk0[l];
 #define DPCG_SWEEP_TILE(UP_, XT_)                                                                                              \
-    hipLaunchKernelGGL((k_lm_sweep_tile<UP_, XT_>), dim3(lv.sweep_grid), dim3(kBlock), lds, s, j0, cnt, (int)lv.level_ptr.back(), \
+    hipLaunchKernelGGL((k_lm_sweep_tile<UP_, XT_>), dim3(grid), dim3(kBlock), lds, s, j0, cnt, (int)lv.level_ptr.back(), \
                        lv.lo_rowptr, lv.lo_val, lv.sw_lidx, ch, nch, tile_doubles, src, src_map, lv.lm_out, d, lv.rows, dw, pl, \
                        o2, m2, done)
             if (upper) {
@@ -1615,10 +1616,10 @@ static void launch_sweeps(const Levels &lv, bool upper, const double *src, const
             continue;
         }
         if (upper)
-            hipLaunchKernelGGL(k_lm_sweep<true>, dim3(lv.sweep_grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_cpos, lv.lo_val,
+            hipLaunchKernelGGL(k_lm_sweep<true>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_cpos, lv.lo_val,
                                src, src_map, lv.lm_out, d, lv.rows, dw, pl, o2, m2, done);
         else
-            hipLaunchKernelGGL(k_lm_sweep<false>, dim3(lv.sweep_grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_cpos, lv.lo_val,
+            hipLaunchKernelGGL(k_lm_sweep<false>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_cpos, lv.lo_val,
                                src, src_map, lv.lm_out, d, lv.rows, dw, pl, o2, m2, done);
     }
 }

@@ -1637,6 +1637,20 @@ def _six_point(m):
     return A
 
 
+def _grid_with_dropped_edges(m, drop, seed):
+    rng = np.random.default_rng(seed)
+    idx = np.arange(m * m).reshape(m, m)
+    pairs = [(idx[:, 1:], idx[:, :-1]), (idx[1:, :], idx[:-1, :])]
+    r = np.concatenate([a.ravel() for a, _ in pairs])
+    c = np.concatenate([b.ravel() for _, b in pairs])
+    keep = rng.uniform(size=r.size) >= drop
+    off = sp.coo_matrix((-rng.uniform(0.5, 1.5, int(keep.sum())), (r[keep], c[keep])), shape=(m * m, m * m)).tocsr()
+    off = off + off.T
+    A = (off + sp.diags(np.asarray(abs(off).sum(axis=1)).ravel() + 0.05)).tocsr()
+    A.sort_indices()
+    return A
+
+
 @pytest.mark.parametrize("case", ["ict_poisson2d_100_thr0.1", "ict_scaled_2d_100_thr0.02", "ict_scaled_2d_100_thr0", "ict_poisson2d_256_thr0.1",
                                   "ic0_six_point_128_cross_terms", "ict_scaled_2d_400_strips_thr0.1", "ict_scaled_2d_400_strips_thr0",
                                   "ic0_six_point_400_strips_cross_terms"])
@@ -2125,6 +2139,9 @@ def test_preconditioner_net_hip_forward_against_the_dense_restatement(D, monkeyp
     ("poisson3d_66_scaled", lambda: _scaled(O.poisson3d(66), 21), None, 2),
     ("unstructured3d_66_rcm", lambda: O.unstructured_like(O.poisson3d(66), seed=5), "rcm", 2),
     ("six_point_760_scaled", lambda: _scaled(_six_point(760), 22), None, None),
+    # a grid with 30 % of its edges removed (many components: greedy colouring, five colours): five very wide levels, each
+    # swept with a grid of its own, <r,z> a launch of its own
+    ("dropped_edges_2d_1000", lambda: _grid_with_dropped_edges(1000, 0.3, 23), None, None),
 ])
 def test_ic0_in_multicolour_order(D, name, make, reorder, colors):
     """`IC0("solve", ordering="multicolor")`: IC(0) of Q A Q^T with the unknowns colour by colour (2 colours for every grid
