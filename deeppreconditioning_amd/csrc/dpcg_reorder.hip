@@ -610,6 +610,40 @@ __global__ __launch_bounds__(kBlock) void k_jp_round(int64_t n, const int32_t *_
     if (left) atomicAdd(remaining, left);
 }
 
+// Iterated greedy (Culberson): the graph is coloured AFRESH, greedily, class by class of the previous colouring -- a class is an
+// independent set, so its vertices can all be coloured at once, each with the smallest colour none of its already recoloured
+// neighbours has.  The new colouring never has more colours than the old one; taking the classes in another order (last to first)
+// tends to need fewer.  Deterministic: a vertex reads neighbours of other classes only, and those do not change during the launch.
+__global__ __launch_bounds__(kBlock) void k_recolor_class(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                          const int32_t *__restrict__ old_color, int32_t *new_color, int cls) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) {
+        if (old_color[v] != cls) continue;
+        unsigned long long used = 0ull;
+        for (int k = rp[v]; k < rp[v + 1]; ++k) {
+            const int u = ci[k];
+            const int cu = u != v ? new_color[u] : -1;
+            if (cu >= 0) used |= 1ull << cu;
+        }
+        new_color[v] = __ffsll((long long)~used) - 1;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_color_histogram(int64_t n, const int32_t *__restrict__ color, int *hist) {
+    __shared__ int sh[64];
+    if (threadIdx.x < 64) sh[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) atomicAdd(&sh[color[v] & 63], 1);
+    __syncthreads();
+    if (threadIdx.x < 64 && sh[threadIdx.x]) atomicAdd(hist + threadIdx.x, sh[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_remap_colors(int64_t n, int32_t *color, const int32_t *__restrict__ map) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) color[v] = map[color[v]];
+}
+
 __global__ __launch_bounds__(kBlock) void k_parity_colors(int64_t n, const int32_t *__restrict__ level, int32_t *__restrict__ color) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) color[v] = level[v] < 0 ? -1 : (level[v] & 1);
@@ -879,6 +913,31 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
         DPCG_HIP(hipMemcpyAsync(&bad, flags.p + 2, sizeof(int), hipMemcpyDeviceToHost, s));
         DPCG_HIP(hipStreamSynchronize(s));
         if (bad) return invalid("multicolour ordering: improper colouring (is the pattern structurally symmetric?)");
+        // fewer colours = fewer levels for the triangular solves: a few passes of iterated greedy over the classes, last to first
+        static const int passes = [] { const char *e = getenv("DPCG_RECOLOR_PASSES"); return e ? atoi(e) : 3; }();
+        Buf<int> hist;
+        Buf<int32_t> map;
+        DPCG_TRY(hist.alloc(64));
+        DPCG_TRY(map.alloc(64));
+        for (int pass = 0; pass < passes; ++pass) {
+            DPCG_HIP(hipMemsetAsync(hist.p, 0, 64 * sizeof(int), s));
+            hipLaunchKernelGGL(k_color_histogram, dim3(rows_grid(n, 1024)), dim3(kBlock), 0, s, n, color.p, hist.p);
+            int h_hist[64];
+            DPCG_HIP(hipMemcpyAsync(h_hist, hist.p, sizeof(h_hist), hipMemcpyDeviceToHost, s));
+            DPCG_HIP(hipStreamSynchronize(s));
+            // empty classes are squeezed out, the others keep their order
+            int32_t h_map[64];
+            int used = 0;
+            for (int c = 0; c < 64; ++c) h_map[c] = h_hist[c] > 0 ? used++ : 0;
+            DPCG_HIP(hipMemcpyAsync(map.p, h_map, sizeof(h_map), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_remap_colors, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, color.p, map.p);
+            DPCG_HIP(hipStreamSynchronize(s));      // (h_map is on the stack)
+            if (used <= 2 || pass == passes - 1) break;
+            DPCG_HIP(hipMemsetAsync(iota.p, 0xff, (size_t)n * sizeof(int32_t), s));          // (iota: free until the sort below)
+            for (int c = used - 1; c >= 0; --c)
+                hipLaunchKernelGGL(k_recolor_class, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, color.p, iota.p, c);
+            DPCG_HIP(hipMemcpyAsync(color.p, iota.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        }
     }
     int32_t cmax = 0;
     DPCG_TRY(reduce_max_i32(color.p, reinterpret_cast<int32_t *>(flags.p + 3), n, s));
