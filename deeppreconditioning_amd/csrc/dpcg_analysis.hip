@@ -706,6 +706,37 @@ __global__ __launch_bounds__(kBlock) void k_tril_copy(int64_t n, const int32_t *
     }
 }
 
+// ---- value-only refresh of a factor whose pattern is kept (dpcg_precond.hip: refresh_parked_ic0) -------------------------------
+__global__ __launch_bounds__(kBlock) void k_iota_f64(int64_t count, double *out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < count; k += stride) out[k] = (double)k;
+}
+void launch_iota_f64(int64_t count, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_iota_f64, dim3(grid_rows(count)), dim3(kBlock), 0, s, count, out);
+}
+__global__ __launch_bounds__(kBlock) void k_f64_to_i32(int64_t count, const double *__restrict__ in, int32_t *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < count; k += stride) out[k] = (int32_t)in[k];
+}
+void launch_f64_to_i32(int64_t count, const double *in, int32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_f64_to_i32, dim3(grid_rows(count)), dim3(kBlock), 0, s, count, in, out);
+}
+// the values of the level-ordered copy again: position j holds factor row rows[j], entries in the row's own order (k_lo_copy)
+__global__ __launch_bounds__(kBlock) void k_lo_values(int64_t n, const int32_t *__restrict__ rows, const int32_t *__restrict__ rp,
+                                                      const double *__restrict__ v, const int32_t *__restrict__ lo_rp,
+                                                      double *__restrict__ lo_v) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        const int i = rows[j];
+        const int src = rp[i], len = rp[i + 1] - src, dst = lo_rp[j];
+        for (int k = 0; k < len; ++k) lo_v[dst + k] = v[src + k];
+    }
+}
+void launch_lo_values(int64_t n, const int32_t *rows, const int32_t *rp, const double *v, const int32_t *lo_rp, double *lo_v,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_lo_values, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rows, rp, v, lo_rp, lo_v);
+}
+
 void launch_tril_copy(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, const int32_t *lrp, int32_t *lci,
                       double *lv, hipStream_t s) {
     hipLaunchKernelGGL(k_tril_copy, dim3(grid_rows(n)), dim3(kBlock), 0, s, n, rp, ci, v, lrp, lci, lv);

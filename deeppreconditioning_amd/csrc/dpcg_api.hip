@@ -264,7 +264,37 @@ void drop_graph(dpcg_system *h) {
     h->graph_key = -1;
 }
 
-void free_precond(dpcg_system *h) {
+void free_parked(dpcg_system *h) {
+    dpcg_system::Parked &p = h->parked;
+    free_csr(p.L);
+    free_csr(p.Lt);
+    free_levels(p.lvlL);
+    free_levels(p.lvlU);
+    dev_free(p.map_al);
+    dev_free(p.t_order);
+    dev_free(p.rows_l);
+    dev_free(p.rows_u);
+    p.valid = false;
+    p.colors = 0;
+}
+
+// dpcg_update_values: an IC(0) in multicolour order applied by colour sweeps keeps everything its PATTERN determined
+// (dpcg_system::Parked); the handle has no preconditioner until the next setup, which then only computes values.
+static void park_precond(dpcg_system *h) {
+    static const bool on = [] { const char *e = getenv("DPCG_PARK_IC0"); return !(e && e[0] == '0'); }();
+    if (!on || h->precond != DPCG_PRECOND_LLT_SOLVE || !h->fmap || h->fmap != h->mc_perm) return;
+    if (!h->lvlL.sweep || !h->lvlU.sweep || h->lvlL.n_levels < 1) return;
+    dpcg_system::Parked &p = h->parked;
+    p.L = h->L;          h->L = CsrDev();
+    p.Lt = h->Lt;        h->Lt = CsrDev();
+    p.lvlL = h->lvlL;    h->lvlL = Levels();
+    p.lvlU = h->lvlU;    h->lvlU = Levels();
+    p.colors = h->precond_colors;
+    p.valid = true;       // (map_al / t_order / rows_*: kept from an earlier refresh, or built at the first one)
+}
+
+void free_precond(dpcg_system *h, bool keep_parked) {
+    if (!keep_parked) free_parked(h);
     drop_graph(h);
     free_ell(h->ell_m);
     free_ell(h->ell_t);
@@ -455,7 +485,8 @@ extern "C" int dpcg_update_values(dpcg_handle_t h, const void *val, int val_dtyp
         dev_free(h->A.val32);                    // an fp32 original or copy of the OLD values: made again on demand
     }
     h->A.val32_lossless = 0;                     // decided again on demand
-    free_precond(h);
+    if (!h->parked.valid) park_precond(h);
+    free_precond(h, true);
     free_ell(h->ell_a);
     drop_graph(h);
     DPCG_CHECK_LAUNCH();

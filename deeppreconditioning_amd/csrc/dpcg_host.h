@@ -66,6 +66,7 @@ inline void dev_free(T *&p) {
 }
 
 void free_csr(CsrDev &c);
+void free_parked(dpcg_system *h);                       // dpcg_api.hip: the multicolour IC(0) parked by dpcg_update_values
 void free_levels(Levels &l);
 int count_levels_on_demand(dpcg_system *h);   // dpcg_precond.hip
 void free_plan(SpmvPlan &plan);
@@ -102,7 +103,7 @@ struct ExtrasRegistry {
 };
 ExtrasRegistry &extras();
 void drop_graph(dpcg_system *h);
-void free_precond(dpcg_system *h);
+void free_precond(dpcg_system *h, bool keep_parked = false);   // (by default a parked factor goes too)
 // work vectors, partial buffers, history (grown on demand)
 int ensure_work(dpcg_system *h, int max_iter, bool need_f32, bool need_err);
 // whether a solve with these flags runs two-kernel updates, and the extra operands of its SpMV kernel

@@ -223,6 +223,20 @@ struct dpcg_system {
     // ordering is attached.  Dropped when the handle is renumbered or destroyed.
     int32_t *mc_perm = nullptr, *mc_iperm = nullptr;
     int mc_colors = 0;
+    // An IC(0) in multicolour order, applied by colour sweeps, that dpcg_update_values PARKED instead of freeing (the handle has
+    // no preconditioner meanwhile): everything that depends on the pattern only -- the factor's pattern, both schedules with their
+    // tile plans and maps -- is kept, and the next dpcg_set_precond_ic0_ordered(multicolour, solve) only computes the values
+    // again (refresh_parked_ic0): gather tril(Q A Q^T) through map_al, the numeric factorisation level by level, L^T's values
+    // through t_order, the values of the two level-ordered copies.  Any other preconditioner call frees it.
+    struct Parked {
+        bool valid = false;
+        dpcg::CsrDev L, Lt;
+        dpcg::Levels lvlL, lvlU;
+        int colors = 0;
+        int32_t *map_al = nullptr;      // entry of L -> entry of the handle's A            (built at the first refresh)
+        int32_t *t_order = nullptr;     // entry of L^T -> entry of L
+        int32_t *rows_l = nullptr, *rows_u = nullptr;   // level-order position -> factor row, for L and for L^T
+    } parked;
     dpcg::SpmvPlan planL, planLt;
     // dpcg_reorder: the handle iterates on A = P A_user P^T; perm[new] = old, iperm[old] = new (device)
     int32_t *perm = nullptr, *iperm = nullptr;
@@ -486,6 +500,10 @@ void launch_sf_records(int64_t n, const int32_t *rows, const int32_t *lo_rp, con
                        bool upper, int32_t *meta, double *pv, int width, hipStream_t s);
 void launch_count_long_rows(int64_t n, const int32_t *lo_rp, int limit, int *counter, hipStream_t s);
 void launch_tril_count(int64_t n, const int32_t *rp, const int32_t *ci, int32_t *cnt, int *flag, hipStream_t s);
+void launch_iota_f64(int64_t count, double *out, hipStream_t s);
+void launch_f64_to_i32(int64_t count, const double *in, int32_t *out, hipStream_t s);
+void launch_lo_values(int64_t n, const int32_t *rows, const int32_t *rp, const double *v, const int32_t *lo_rp, double *lo_v,
+                      hipStream_t s);
 void launch_tril_copy(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, const int32_t *lrp, int32_t *lci,
                       double *lv, hipStream_t s);
 void launch_gen_poisson(int dim, int64_t n, int32_t *rowptr, int32_t *col, void *val, int val_dtype, hipStream_t s);

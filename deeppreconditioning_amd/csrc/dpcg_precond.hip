@@ -896,6 +896,91 @@ extern "C" int dpcg_set_precond_llt(dpcg_handle_t h, int mode, int64_t nnz, cons
     return st;
 }
 
+// The values of a parked IC(0) in multicolour order again (dpcg_system::Parked), from the handle's CURRENT matrix values: the same
+// tril(Q A Q^T), the same level-by-level factorisation in the same order as a full setup -- the same bits -- without the
+// colouring, the permutation, the level analysis, the transposition, the schedules and their tile plans.  The entry maps are
+// built at the first refresh by sending entry NUMBERS through the very kernels the setup sends values through.
+namespace {
+int refresh_parked_ic0(dpcg_system *h, hipStream_t s) {
+    dpcg_system::Parked &P = h->parked;
+    const int64_t n = h->A.n, nnzl = P.L.nnz;
+    PhaseTimer pt(s);
+    if (!P.map_al) {
+        DevBuf<double> ids, lids;
+        DevBuf<int32_t> lcol;
+        DPCG_TRY(ids.alloc(h->A.nnz));
+        DPCG_TRY(lids.alloc(nnzl));
+        DPCG_TRY(lcol.alloc(nnzl));
+        launch_iota_f64(h->A.nnz, ids.p, s);
+        CsrDev Aid = h->A, Ac;                               // (borrowed pattern, entry numbers as values)
+        Aid.val = ids.p;
+        Aid.val32 = nullptr;
+        Aid.owned = false;
+        int st = permute_csr(Aid, h->mc_perm, h->mc_iperm, Ac, s);
+        if (st < 0) {
+            free_csr(Ac);
+            return st;
+        }
+        launch_tril_copy(n, Ac.rowptr, Ac.col, Ac.val, P.L.rowptr, lcol.p, lids.p, s);
+        st = dev_alloc(&P.map_al, nnzl);
+        if (st >= 0) launch_f64_to_i32(nnzl, lids.p, P.map_al, s);
+        free_csr(Ac);
+        DPCG_TRY(st);
+        // L^T's entries in terms of L's
+        launch_iota_f64(nnzl, lids.p, s);
+        CsrDev Lid = P.L, Ltid;
+        Lid.val = lids.p;
+        Lid.val32 = nullptr;
+        Lid.owned = false;
+        st = transpose_lower(Lid, Ltid, s);
+        if (st >= 0) st = dev_alloc(&P.t_order, nnzl);
+        if (st >= 0) launch_f64_to_i32(nnzl, Ltid.val, P.t_order, s);
+        free_csr(Ltid);
+        DPCG_TRY(st);
+        // level-order position -> factor row (the schedules list handle indices)
+        DPCG_TRY(dev_alloc(&P.rows_l, n));
+        DPCG_TRY(dev_alloc(&P.rows_u, n));
+        launch_compose_positions(n, P.lvlL.rows, h->mc_iperm, P.rows_l, s);
+        launch_compose_positions(n, P.lvlU.rows, h->mc_iperm, P.rows_u, s);
+        DPCG_HIP(hipStreamSynchronize(s));
+        DPCG_CHECK_LAUNCH();
+        pt.mark("refresh: entry maps");
+    }
+    DevBuf<int32_t> bad;
+    DPCG_TRY(bad.alloc(1));
+    DPCG_HIP(hipMemsetAsync(bad.p, 0, sizeof(int32_t), s));
+    launch_gather_f64(nnzl, P.map_al, h->A.val, P.L.val, s);                   // tril(Q A Q^T)
+    const std::vector<int32_t> &lp = P.lvlL.level_ptr;                          // the levels of tril(A)'s pattern are L's
+    for (int l = 0; l + 1 < (int)lp.size(); ++l)
+        launch_ic0_level(P.rows_l, lp[(size_t)l], lp[(size_t)l + 1] - lp[(size_t)l], P.L.rowptr, P.L.col, P.L.val, reinterpret_cast<int *>(bad.p),
+                         s, nullptr, 0.0);
+    launch_gather_f64(nnzl, P.t_order, P.L.val, P.Lt.val, s);
+    launch_lo_values(n, P.rows_l, P.L.rowptr, P.L.val, P.lvlL.lo_rowptr, P.lvlL.lo_val, s);
+    launch_lo_values(n, P.rows_u, P.Lt.rowptr, P.Lt.val, P.lvlU.lo_rowptr, P.lvlU.lo_val, s);
+    if (P.lvlL.ride_diag) launch_scatter_f64(lp[1], P.lvlL.rows, P.lvlL.lo_val, P.lvlL.ride_diag, s);
+    int32_t h_bad = 0;
+    DPCG_HIP(hipMemcpyAsync(&h_bad, bad.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    DPCG_CHECK_LAUNCH();
+    pt.mark("refresh: values");
+    if (h_bad) {
+        set_error("IC(0): non-positive pivot at row " + std::to_string(h_bad - 1));
+        return DPCG_ERR_PIVOT;
+    }
+    free_precond(h, true);
+    h->L = P.L;          P.L = CsrDev();
+    h->Lt = P.Lt;        P.Lt = CsrDev();
+    h->lvlL = P.lvlL;    P.lvlL = Levels();
+    h->lvlU = P.lvlU;    P.lvlU = Levels();
+    h->fmap = h->mc_perm;
+    h->fmap_inv = h->mc_iperm;
+    h->precond_colors = P.colors;
+    h->precond = DPCG_PRECOND_LLT_SOLVE;
+    P.valid = false;     // (the maps stay for the next round)
+    return DPCG_OK;
+}
+}  // namespace
+
 // IC(0) of A on its lower-triangular pattern (stands in for ilupp.ichol0, test.py:83), entirely on the device: tril(A)
 // by count / scan / copy, the level sets of its pattern, then the numeric factorisation one launch per level
 // (k_ic0_level) in the operation order of the CPU restatement (bit-identical factor).  The handle keeps its previous
@@ -909,6 +994,14 @@ extern "C" int dpcg_set_precond_ic0_ordered(dpcg_handle_t h, int mode, int order
     hipStream_t s = (hipStream_t)stream;
     SetupScope scope(s, true);          // (the preconditioner being replaced may be in use on another stream)
     const int64_t n = h->A.n;
+    if (h->parked.valid) {              // new values on the pattern of a parked factor: only the values are computed again
+        static const bool keep = [] { const char *ev = getenv("DPCG_KEEP_COLORING"); return !(ev && ev[0] == '0'); }();
+        if (ordering == DPCG_ORDER_MULTICOLOR && mode == DPCG_PRECOND_LLT_SOLVE && keep && h->mc_perm) {
+            const int st = refresh_parked_ic0(h, s);
+            if (st < 0) free_parked(h);
+            return st;
+        }
+    }
     // DPCG_ORDER_MULTICOLOR: IC(0) of Q A Q^T, Q = the handle's matrix colour by colour (dpcg_reorder.hip: multicolor_order).
     // The permuted matrix is a temporary; the factor stays in that numbering and is addressed through fmap.
     CsrDev Ac;

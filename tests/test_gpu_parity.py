@@ -1255,6 +1255,34 @@ def test_update_values_on_the_same_pattern(D, case):
     assert np.array_equal(S.precond_ordering()[1], colouring[1]) and np.array_equal(F.precond_ordering()[1], colouring[1])
     for got, want in zip(S.factor(), F.factor()):
         assert np.array_equal(got, want)
+    # new values while such a factor is attached: applied by colour sweeps (the 74 088-row case) it is PARKED -- pattern, schedules
+    # and maps kept, no preconditioner meanwhile -- and the next setup only computes the values again; twice (the first refresh
+    # builds the entry maps), then everything must be what a fresh handle gives, bit for bit
+    for vals in (A0.data, A1.data):
+        S.update_values(vals)
+        assert S.info()["precond"] == 0
+        S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+    assert np.array_equal(S.precond_ordering()[1], colouring[1])
+    for got, want in zip(S.factor(), F.factor()):
+        assert np.array_equal(got, want)
+    assert torch.equal(S.precond_apply(b), F.precond_apply(b)) and torch.equal(S.precond_apply(b), F.precond_apply(b))
+    assert torch.equal(S.sptrsv(b, upper=False), F.sptrsv(b, upper=False)) and torch.equal(S.sptrsv(b, upper=True), F.sptrsv(b, upper=True))
+    for flags in (0, D._lib.NO_GRAPH):
+        rs, rf = S.solve(b, flags=flags), F.solve(b, flags=flags)
+        assert rs.iterations == rf.iterations and torch.equal(rs.x, rf.x) and np.array_equal(rs.res_history, rf.res_history)
+    # a parked factor does not survive another preconditioner or a failed refresh
+    S.update_values(A1.data)
+    S.set_preconditioner(D.Jacobi())
+    S.update_values(A1.data)
+    S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+    assert torch.equal(S.precond_apply(b), F.precond_apply(b))
+    S.update_values(-A1.data)                              # (negative definite: the factorisation must fail, parked or not)
+    with pytest.raises(Exception):
+        S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+    assert S.info()["precond"] == 0
+    S.update_values(A1.data)
+    S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+    assert torch.equal(S.precond_apply(b), F.precond_apply(b))
     # and against the oracle on the new matrix
     S.set_preconditioner(D.Jacobi())
     A1d = A1.astype(np.float64)

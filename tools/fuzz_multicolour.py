@@ -66,6 +66,18 @@ for case in range(cases):
     tag = f"case {case}: shape={shape} n={n} drop={drop} diagonal={diagonal} scramble={scramble} reorder={reorder}"
     S = D.CsrSystem.from_any(A, reorder=reorder)
     S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+    refresh = bool(rng.integers(0, 2))
+    if refresh:
+        # the time-stepping sequence: other values on the same pattern (the factor is parked, the setup only computes values -- the
+        # first time it also builds its entry maps), then the original values again; everything below must hold as for a new handle
+        d = rng.uniform(0.5, 2.0, n)
+        A2 = (sp.diags(d) @ A @ sp.diags(d)).tocsr()
+        A2.sort_indices()
+        assert np.array_equal(A2.indices, A.indices)
+        for vals in (A2.data, A.data, A2.data, A.data)[:int(rng.choice([2, 4]))]:
+            S.update_values(vals if rng.integers(0, 2) else torch.from_numpy(vals).cuda())
+            S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+    tag += f" refresh={refresh}"
     nc, q = S.precond_ordering()
     Bc = A[q][:, q].tocsr()
     Bc.sort_indices()
