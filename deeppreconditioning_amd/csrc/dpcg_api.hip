@@ -363,6 +363,7 @@ extern "C" int dpcg_destroy(dpcg_handle_t h) {
     free_csr(h->A);
     free_csr(h->A_user);
     dev_free(h->mc_perm); dev_free(h->mc_iperm);
+    dev_free(h->perm_val_map);
     dev_free(h->perm); dev_free(h->iperm); dev_free(h->pb); dev_free(h->pxt); dev_free(h->pv0); dev_free(h->pv1);
     dev_free(h->pf0); dev_free(h->pf1);
     free_plan(h->planA);
@@ -471,15 +472,25 @@ extern "C" int dpcg_update_values(dpcg_handle_t h, const void *val, int val_dtyp
         }
         DPCG_HIP(hipStreamSynchronize(s));       // a host source buffer may be released by the caller
     }
-    if (h->perm) {                               // P A P^T again: same pattern, so the plan of the old one fits
-        CsrDev B;
-        const int st = permute_csr(h->A_user, h->perm, h->iperm, B, s);
-        if (st < 0) {
+    if (h->perm) {                               // P A P^T again: same pattern, so only its values move
+        if (!h->perm_val_map) {
+            // which entry of the caller's matrix each entry of P A P^T is: entry NUMBERS sent through the permutation once
+            double *ids = nullptr;
+            DPCG_TRY(dev_alloc(&ids, nnz));
+            launch_iota_f64(nnz, ids, s);
+            CsrDev Uid = h->A_user, B;
+            Uid.val = ids;
+            Uid.val32 = nullptr;
+            Uid.owned = false;
+            int st = permute_csr(Uid, h->perm, h->iperm, B, s);
+            if (st >= 0) st = dev_alloc(&h->perm_val_map, nnz);
+            if (st >= 0) launch_f64_to_i32(nnz, B.val, h->perm_val_map, s);
             free_csr(B);
-            return st;
+            dev_free(ids);
+            DPCG_TRY(st);
         }
-        free_csr(h->A);                          // (with its fp32 copy)
-        h->A = B;
+        launch_gather_f64(nnz, h->perm_val_map, h->A_user.val, h->A.val, s);
+        dev_free(h->A.val32);                    // (a copy of the old values)
         if (!val32_fresh) dev_free(h->A_user.val32);
     } else if (!val32_fresh) {
         dev_free(h->A.val32);                    // an fp32 original or copy of the OLD values: made again on demand

@@ -241,6 +241,7 @@ struct dpcg_system {
     // dpcg_reorder: the handle iterates on A = P A_user P^T; perm[new] = old, iperm[old] = new (device)
     int32_t *perm = nullptr, *iperm = nullptr;
     dpcg::CsrDev A_user;                  // the caller's matrix once A has been replaced by the reordered one
+    int32_t *perm_val_map = nullptr;      // entry of A -> entry of A_user (built by the first dpcg_update_values: later ones only gather)
     double gather_ratio = 0.0;            // measured x-gather line traffic / bytes used of the caller's matrix
     double *pb = nullptr, *pxt = nullptr; // b / x_true gathered into the handle's numbering
     double *pv0 = nullptr, *pv1 = nullptr;   // scratch of the standalone operators on a reordered handle
