@@ -35,6 +35,8 @@ COMPARABILITY = {
                            "rule (level-1 fill + 'ict' drop tolerance); ilupp's rule is unpinned, columns will differ",
     "incomplete_cholesky_0": "algorithm comparable (textbook IC(0) = ilupp.ichol0's definition), values unpinned against ilupp",
     "incomplete_cholesky_solve": "not in the reference: IC(0) applied by triangular solves",
+    "incomplete_cholesky_multicolor": "not in the reference: IC(0) of the system in multicolour order, applied by triangular solves "
+                                      "(another elimination order: another preconditioner; the fastest of the IC variants here)",
     "learned": "comparable given the same checkpoint; spconv's weight layout is assumed KRSC (unpinned)",
 }
 
@@ -97,6 +99,8 @@ class BenchmarkSuite:
             return IC0("multiply")
         if name == "incomplete_cholesky_solve":     # IC(0) applied by triangular solves (not in the reference)
             return IC0("solve")
+        if name == "incomplete_cholesky_multicolor":    # ... in multicolour order (opt-in: not among the default techniques)
+            return IC0("solve", ordering="multicolor")
         if name == "learned":                       # test.py:100-105
             with torch.no_grad():
                 out = self.model(system_tril)

@@ -1119,10 +1119,12 @@ def test_benchmark_suite_over_reference_style_folders(D, tmp_path):
         np.savetxt(folder / "solution.csv", x)
         np.savetxt(folder / "right_hand_side.csv", m @ x)
     data = SludgePatternDataSet("test", batch_size=1, shuffle=False, root=tmp_path / "raw")   # the last 20 %: case 4
-    suite = BenchmarkSuite(data, None, techniques=("vanilla", "jacobi", "incomplete_cholesky_solve"),
+    suite = BenchmarkSuite(data, None, techniques=("vanilla", "jacobi", "incomplete_cholesky_solve", "incomplete_cholesky_multicolor"),
                            results_directory=tmp_path / "results")
     suite.run()
     suite.dump_csv()
+    assert suite.successes["incomplete_cholesky_multicolor"] == [100]              # (test.py:149: 100 * (1 - info))
+    assert 0 < suite.iterations["incomplete_cholesky_multicolor"][0] < suite.iterations["jacobi"][0]
     m = mats[4]
     b = (m @ O.rhs(m.shape[0], 4)).astype(np.float32).astype(np.float64)          # the data set carries fp32 vectors
     assert suite.iterations["jacobi"] == [CO.pcg(m, b, "jacobi", dinv=O.jacobi_dinv(m))[1]]
