@@ -248,9 +248,67 @@ __global__ __launch_bounds__(kBlock) void k_tile_plan(int64_t n, const int32_t *
         }
         const int cb = s_min / kTileChunk;
         const int span = s_max / kTileChunk - cb + 1;
-        // not tileable: columns too spread out, or no room for the alignment slots of the grouped loads
-        if (span > kTileTableMax || cnt > kStreamCap - 3) {
+        // not tileable: no room for the alignment slots of the grouped loads
+        if (cnt > kStreamCap - 3) {
             if (t == 0) { nchunks[rb] = 0; atomicExch(&ok_and_max[0], 0); }
+            __syncthreads();
+            continue;
+        }
+        if (span > kTileTableMax) {
+            // Columns far apart (a system numbered colour by colour, periodic couplings, a second region): too wide for the
+            // table of chunk ids, yet possibly only a few chunks.  The distinct chunk ids go through a 128-entry hash table
+            // instead; slots are still handed out in ascending chunk order, so the plan is what the table would have made.
+            int *hkeys = reinterpret_cast<int *>(slot_of), *hrank = hkeys + 128;
+            __shared__ int s_over;
+            if (t < 128) hkeys[t] = -1;
+            if (t == 0) s_over = 0;
+            __syncthreads();
+            for (int k = t; k < cnt; k += kBlock) {
+                const int c = col[base + k];
+                if (c >= diag_from) continue;
+                const int ch = c / kTileChunk;
+                unsigned hsl = ((unsigned)ch * 2654435761u) >> 25;
+                int probes = 0;
+                for (; probes < 128; ++probes, hsl = (hsl + 1) & 127) {
+                    const int old = atomicCAS(&hkeys[hsl], -1, ch);
+                    if (old == -1) { atomicAdd(&s_nc, 1); break; }
+                    if (old == ch) break;
+                }
+                if (probes == 128) s_over = 1;
+            }
+            __syncthreads();
+            const bool ok = !s_over && s_nc <= kTileMaxChunks;
+            if (t == 0) {
+                if (!ok) {
+                    nchunks[rb] = 0;
+                    atomicExch(&ok_and_max[0], 0);
+                } else {
+                    int keys[kTileMaxChunks], where[kTileMaxChunks], nc = 0;
+                    for (int e = 0; e < 128; ++e)
+                        if (hkeys[e] >= 0) {                      // insertion sort by chunk id
+                            int q = nc++;
+                            for (; q > 0 && keys[q - 1] > hkeys[e]; --q) { keys[q] = keys[q - 1]; where[q] = where[q - 1]; }
+                            keys[q] = hkeys[e];
+                            where[q] = e;
+                        }
+                    for (int q = 0; q < nc; ++q) {
+                        chunks[(int64_t)rb * kTileMaxChunks + q] = keys[q];
+                        hrank[where[q]] = q;
+                    }
+                    nchunks[rb] = nc;
+                    atomicMax(&ok_and_max[1], nc);
+                }
+            }
+            __syncthreads();
+            if (ok)
+                for (int k = t; k < cnt; k += kBlock) {
+                    const int c = col[base + k];
+                    if (c >= diag_from) { lidx[base + k] = kTileDiag; continue; }
+                    const int ch = c / kTileChunk;
+                    unsigned hsl = ((unsigned)ch * 2654435761u) >> 25;
+                    while (hkeys[hsl] != ch) hsl = (hsl + 1) & 127;
+                    lidx[base + k] = (uint16_t)(hrank[hsl] * kTileChunk + c % kTileChunk);
+                }
             __syncthreads();
             continue;
         }

@@ -59,6 +59,35 @@ def test_spmv_stream_bit_exact(D, make, monkeypatch):
     assert np.array_equal((S2 @ _dev(x)).cpu().numpy(), ref)
 
 
+def test_spmv_tile_plan_with_far_couplings(D, monkeypatch):
+    """Columns far apart but in few chunks -- a grid numbered colour by colour (every row's neighbours sit half the matrix away), a
+    periodic coupling, two regions coupled at an interface -- are still tileable: the distinct chunk ids of a block go through a
+    small hash table when their span exceeds the table of the banded case.  Same bits as the gather kernel and the CPU."""
+    monkeypatch.setenv("DPCG_SPMV_KERNEL", "tile")
+    m = 40
+    A = O.poisson3d(m)
+    i, j, k = np.meshgrid(np.arange(m), np.arange(m), np.arange(m), indexing="ij")
+    q = np.argsort(((i + j + k) % 2).ravel(), kind="stable")                  # red-black, colour by colour
+    Ac = A[q][:, q].tocsr()
+    Ac.sort_indices()
+    n = A.shape[0]
+    P = sp.coo_matrix((np.full(m * m, -0.5), (np.arange(m * m), n - m * m + np.arange(m * m))), shape=(n, n)).tocsr()
+    Ap = (A + P + P.T).tocsr()                                                # first plane coupled to the last one
+    Ap.sort_indices()
+    for M_ in (Ac, Ap):
+        S = D.CsrSystem.from_any(M_, reorder=None)
+        assert S.info()["spmv_kernel"] == "tile"
+        x = O.rhs(n, 3)
+        assert np.array_equal((S @ _dev(x)).cpu().numpy(), CO.spmv(M_, x))
+        S.set_preconditioner(D.Jacobi())
+        b = O.rhs(n, 0)
+        res = S.solve(_dev(b), flags=D._lib.NO_FUSE)                          # (K1 = the tile kernel)
+        _, it, hist, _ = CO.pcg(M_, b, "jacobi", dinv=O.jacobi_dinv(M_))
+        assert res.iterations == it
+        np.testing.assert_allclose(res.res_history, hist, rtol=HIST_RTOL)
+        S.close()
+
+
 def test_spmv_tile_plan_selection(D, monkeypatch):
     """Poisson grids are tileable (few runs of columns per 256-row block); a random permutation is not.  The
     tile kernel is chosen by default only for systems that stream from HBM (checked at full size in
