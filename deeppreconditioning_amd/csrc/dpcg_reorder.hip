@@ -682,8 +682,10 @@ __global__ void k_region_seed(int64_t n, int32_t *step, int32_t *state, int *vis
 
 // one growth step: an unvisited vertex with a neighbour that joined at step `cur` joins the region of the FIRST such neighbour in
 // its row (ascending columns: deterministic), with the opposite parity
+// `skip` (may be null): entries the growth does not walk along (edges that lie on a triangle, k_triangle_edges)
 __global__ __launch_bounds__(kBlock) void k_region_grow(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
-                                                        int32_t *step, int32_t *state, int cur, int *visited) {
+                                                        const uint8_t *__restrict__ skip, int32_t *step, int32_t *state, int cur,
+                                                        int *visited) {
     __shared__ int sh_new;
     if (threadIdx.x == 0) sh_new = 0;
     __syncthreads();
@@ -693,6 +695,7 @@ __global__ __launch_bounds__(kBlock) void k_region_grow(int64_t n, const int32_t
         if (__hip_atomic_load(step + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) continue;
         for (int k = rp[v]; k < rp[v + 1]; ++k) {
             const int u = ci[k];
+            if (skip && skip[k]) continue;
             if (__hip_atomic_load(step + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cur) {
                 state[v] = state[u] ^ 1;           // (state[u] was written by an earlier launch)
                 __hip_atomic_store(step + v, cur + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -706,37 +709,89 @@ __global__ __launch_bounds__(kBlock) void k_region_grow(int64_t n, const int32_t
     if (threadIdx.x == 0 && sh_new) atomicAdd(visited, sh_new);
 }
 
-// rel[a * kRegions + b] |= 1 when an edge joins regions a and b with opposite parities (the two regions agree as they are),
-//                          2 when it joins equal parities (one of the two has to be flipped)
+// rel[2 * (a * kRegions + b) + 0] counts the edges that join regions a and b with opposite parities (the two regions agree as they
+// are), [.. + 1] those that join equal parities (one of the two has to be flipped); a bipartite graph fills one of the two only
 __global__ __launch_bounds__(kBlock) void k_region_relations(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                             const uint8_t *__restrict__ skip, const int32_t *__restrict__ step,
                                                              const int32_t *__restrict__ state, unsigned int *rel) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) {
+        if (step[v] < 0) continue;
         const int sv = state[v];
         for (int k = rp[v]; k < rp[v + 1]; ++k) {
             const int u = ci[k];
-            if (u <= v) continue;
+            if (u <= v || (skip && skip[k]) || step[u] < 0) continue;
             const int su = state[u];
             if ((su >> 1) == (sv >> 1)) continue;   // inside a region: the final edge-by-edge check looks at those
-            const unsigned bit = ((su ^ sv) & 1) ? 1u : 2u;
-            unsigned int *a = rel + (size_t)(sv >> 1) * kRegions + (su >> 1), *b = rel + (size_t)(su >> 1) * kRegions + (sv >> 1);
-            if (!(__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(a, bit);
-            if (!(__hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(b, bit);
+            const int which = ((su ^ sv) & 1) ? 0 : 1;
+            atomicAdd(rel + 2 * ((size_t)(sv >> 1) * kRegions + (su >> 1)) + which, 1u);
+            atomicAdd(rel + 2 * ((size_t)(su >> 1) * kRegions + (sv >> 1)) + which, 1u);
         }
     }
 }
 
 // mask[v] = -1 (a candidate) for the vertices of the regions of component `comp`, 0 otherwise: k_min_degree's "unvisited" filter
-__global__ __launch_bounds__(kBlock) void k_region_mask(int64_t n, const int32_t *__restrict__ state, const int32_t *__restrict__ comp_of,
-                                                        int comp, int32_t *__restrict__ mask) {
+__global__ __launch_bounds__(kBlock) void k_region_mask(int64_t n, const int32_t *__restrict__ step, const int32_t *__restrict__ state,
+                                                        const int32_t *__restrict__ comp_of, int comp, int32_t *__restrict__ mask) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) mask[v] = comp_of[state[v] >> 1] == comp ? -1 : 0;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride)
+        mask[v] = (step[v] >= 0 && comp_of[state[v] >> 1] == comp) ? -1 : 0;
 }
 
-__global__ __launch_bounds__(kBlock) void k_region_colors(int64_t n, const int32_t *__restrict__ state, const int32_t *__restrict__ flip,
-                                                          int32_t *__restrict__ color) {
+// (a vertex no region reached -- only possible when edges were skipped -- stays uncoloured: -1)
+__global__ __launch_bounds__(kBlock) void k_region_colors(int64_t n, const int32_t *__restrict__ step, const int32_t *__restrict__ state,
+                                                          const int32_t *__restrict__ flip, int32_t *__restrict__ color) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) color[v] = (state[v] & 1) ^ flip[state[v] >> 1];
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride)
+        color[v] = step[v] < 0 ? -1 : ((state[v] & 1) ^ flip[state[v] >> 1]);
+}
+
+// skip[k] = 1 for the entries (v, u) whose endpoints share a neighbour: the edge lies on a triangle.  A mesh graph that is bipartite
+// but for refinement interfaces / a few extra couplings has its odd cycles there; without those edges what is left can be
+// two-coloured, and the conflicts then sit on the skipped edges only.  Rows hold ascending columns: a merge per entry.
+__global__ __launch_bounds__(kBlock) void k_triangle_edges(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                           uint8_t *__restrict__ skip) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) {
+        const int vs = rp[v], ve = rp[v + 1];
+        for (int k = vs; k < ve; ++k) {
+            const int u = ci[k];
+            bool tri = false;
+            if (u != v) {
+                int a = vs, b = rp[u];
+                const int be = rp[u + 1];
+                while (a < ve && b < be) {
+                    const int ca = ci[a], cb = ci[b];
+                    if (ca == cb) {
+                        if (ca != v && ca != u) { tri = true; break; }
+                        ++a; ++b;
+                    } else if (ca < cb) ++a;
+                    else ++b;
+                }
+            }
+            skip[k] = tri ? 1 : 0;
+        }
+    }
+}
+
+// Repair of an almost proper two-colouring (a mesh that is bipartite but for a few odd cycles -- refinement interfaces, a handful
+// of extra couplings): of every edge that joins two vertices of one colour the endpoint of larger index loses its colour
+// (-1); Jones-Plassmann then colours those vertices around the ones that keep theirs.  *marked counts them.
+__global__ __launch_bounds__(kBlock) void k_mark_conflicts(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                           const int32_t *__restrict__ color, int32_t *__restrict__ out, int *marked) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int mine = 0;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) {
+        const int cv = color[v];
+        bool lose = cv < 0;
+        for (int k = rp[v]; k < rp[v + 1]; ++k) {
+            const int u = ci[k];
+            lose = lose || (u < v && color[u] == cv);
+        }
+        out[v] = lose ? -1 : cv;
+        mine += lose ? 1 : 0;
+    }
+    if (mine) atomicAdd(marked, mine);
 }
 
 __global__ __launch_bounds__(kBlock) void k_invert_perm(int64_t n, const int32_t *__restrict__ perm, int32_t *__restrict__ iperm) {
@@ -749,15 +804,22 @@ __global__ __launch_bounds__(kBlock) void k_invert_perm(int64_t n, const int32_t
 // of smallest (degree, index) of every connected component has colour 0 -- what the search-by-search parity colouring below
 // produces too, so the two agree vertex by vertex.  false (nothing to report): an odd cycle, a component without a seed, more
 // than a handful of components -- the caller goes on with the other methods.
-static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bool *colored, hipStream_t s) {
+// *nearly (may be null): when the graph has odd cycles the walk still hands out flips (first relation seen wins) and `color` holds
+// an IMPROPER two-colouring whose conflicts the caller may repair (repair_two_coloring) -- *nearly = true then.
+// skip (may be null, with nearly): entries the regions do not grow along nor relate through (k_triangle_edges); vertices they then
+// cannot reach stay uncoloured.
+static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bool *colored, bool *nearly, const uint8_t *skip,
+                                 hipStream_t s) {
     const int64_t n = A.n;
     *colored = false;
+    if (nearly) *nearly = false;
+    bool odd_cycle = false;
     if (n < 4 * kRegions) return DPCG_OK;
     Buf<int32_t> step, state, deg, mask, d_small;
     Buf<unsigned int> rel;
     Buf<unsigned long long> best;
     DPCG_TRY(step.alloc(n)); DPCG_TRY(state.alloc(n)); DPCG_TRY(deg.alloc(n)); DPCG_TRY(mask.alloc(n));
-    DPCG_TRY(d_small.alloc(2 * kRegions)); DPCG_TRY(rel.alloc((int64_t)kRegions * kRegions)); DPCG_TRY(best.alloc(1));
+    DPCG_TRY(d_small.alloc(2 * kRegions)); DPCG_TRY(rel.alloc(2 * (int64_t)kRegions * kRegions)); DPCG_TRY(best.alloc(1));
     PhaseTimer pt(s);
     DPCG_HIP(hipMemsetAsync(step.p, 0xff, (size_t)n * sizeof(int32_t), s));
     DPCG_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
@@ -765,18 +827,22 @@ static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bo
     int visited = 0, cur = 0;
     for (;;) {
         for (int b = 0; b < kRegionBatch; ++b, ++cur)
-            hipLaunchKernelGGL(k_region_grow, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, step.p, state.p, cur, flags);
+            hipLaunchKernelGGL(k_region_grow, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, skip, step.p, state.p, cur,
+                               flags);
         int now = 0;
         DPCG_HIP(hipMemcpyAsync(&now, flags, sizeof(int), hipMemcpyDeviceToHost, s));
         DPCG_HIP(hipStreamSynchronize(s));
         if (now == n) break;
-        if (now == visited) return DPCG_OK;          // a component without a seed
+        if (now == visited) {                        // a component without a seed
+            if (skip && nearly && (int64_t)(n - now) * 8 <= n) break;     // (skipped edges: a few unreachable vertices are repaired later)
+            return DPCG_OK;
+        }
         visited = now;
     }
     pt.mark("  regions: growth");
-    DPCG_HIP(hipMemsetAsync(rel.p, 0, (size_t)kRegions * kRegions * sizeof(unsigned int), s));
-    hipLaunchKernelGGL(k_region_relations, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, state.p, rel.p);
-    std::vector<unsigned int> h_rel((size_t)kRegions * kRegions);
+    DPCG_HIP(hipMemsetAsync(rel.p, 0, 2 * (size_t)kRegions * kRegions * sizeof(unsigned int), s));
+    hipLaunchKernelGGL(k_region_relations, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, skip, step.p, state.p, rel.p);
+    std::vector<unsigned int> h_rel(2 * (size_t)kRegions * kRegions);
     DPCG_HIP(hipMemcpyAsync(h_rel.data(), rel.p, h_rel.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
     // walk the graph of regions: flip[b] relative to the first region of its component
@@ -790,16 +856,21 @@ static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bo
             const int a = stack.back();
             stack.pop_back();
             for (int b = 0; b < kRegions; ++b) {
-                const unsigned bits = h_rel[(size_t)a * kRegions + b];
-                if (!bits) continue;
-                if (bits == 3u) return DPCG_OK;                                   // an odd cycle through the two regions
-                const int want = flip[(size_t)a] ^ (bits == 2u ? 1 : 0);
+                const unsigned opposite = h_rel[2 * ((size_t)a * kRegions + b)], equal = h_rel[2 * ((size_t)a * kRegions + b) + 1];
+                if (!opposite && !equal) continue;
+                const unsigned bits = (opposite ? 1u : 0u) | (equal ? 2u : 0u);
+                if (bits == 3u) {                                                 // an odd cycle through the two regions
+                    if (!nearly) return DPCG_OK;
+                    odd_cycle = true;
+                }
+                const int want = flip[(size_t)a] ^ (equal > opposite ? 1 : 0);    // (nearly bipartite: the majority decides)
                 if (comp[(size_t)b] < 0) {
                     comp[(size_t)b] = n_comp;
                     flip[(size_t)b] = want;
                     stack.push_back(b);
-                } else if (flip[(size_t)b] != want) {
-                    return DPCG_OK;                                               // an odd cycle through several regions
+                } else if (flip[(size_t)b] != want && bits != 3u) {
+                    if (!nearly) return DPCG_OK;                                  // an odd cycle through several regions
+                    odd_cycle = true;
                 }
             }
         }
@@ -814,7 +885,7 @@ static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bo
     for (int c = 0; c < n_comp; ++c) {
         // the component's vertex of smallest (degree, index) gets colour 0
         DPCG_HIP(hipMemsetAsync(best.p, 0xff, sizeof(unsigned long long), s));
-        hipLaunchKernelGGL(k_region_mask, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, state.p, d_small.p, c, mask.p);
+        hipLaunchKernelGGL(k_region_mask, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, step.p, state.p, d_small.p, c, mask.p);
         hipLaunchKernelGGL(k_min_degree, dim3(rows_grid(n, 1024)), dim3(kBlock), 0, s, (const int32_t *)nullptr, (int64_t)0, n, deg.p, mask.p, 1,
                            best.p);
         unsigned long long hb = 0;
@@ -830,13 +901,16 @@ static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bo
                 if (comp[(size_t)r] == c) flip[(size_t)r] ^= 1;
     }
     DPCG_HIP(hipMemcpyAsync(d_small.p + kRegions, flip.data(), kRegions * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_region_colors, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, state.p, d_small.p + kRegions, color);
+    hipLaunchKernelGGL(k_region_colors, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, step.p, state.p, d_small.p + kRegions, color);
     DPCG_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
     hipLaunchKernelGGL(k_check_coloring, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, A.rowptr, A.col, color, flags);
     int bad = 0;
     DPCG_HIP(hipMemcpyAsync(&bad, flags, sizeof(int), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
     *colored = bad == 0;
+    if (nearly) *nearly = bad != 0;
+    if (pt.on) fprintf(stderr, "[dpcg setup]   regions: %d components, odd cycle %d, proper %d\n", real_comps, (int)odd_cycle, (int)*colored);
+    (void)odd_cycle;
     pt.mark("  regions: relations, flips, check");
     return DPCG_OK;
 }
@@ -852,8 +926,31 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
     bool colored = false;
     PhaseTimer pt(s);
     static const bool regions_on = [] { const char *e = getenv("DPCG_COLOR_REGIONS"); return !(e && e[0] == '0'); }();
-    if (regions_on) DPCG_TRY(two_colors_by_regions(A, color.p, flags.p, &colored, s));      // 0. two colours, many searches at once
-    if (!colored) {   // 1. breadth-first parity, component by component
+    bool nearly = false, repaired = false;
+    static const bool repair_on = [] { const char *e = getenv("DPCG_COLOR_REPAIR"); return !(e && e[0] == '0'); }();
+    if (regions_on) DPCG_TRY(two_colors_by_regions(A, color.p, flags.p, &colored, repair_on ? &nearly : nullptr, nullptr, s));   // 0. two colours, many searches at once
+    if (!colored && nearly) {
+        // 0b. nearly bipartite (odd cycles, but few): the regions once more without the edges that lie on triangles -- breadth-first
+        // parity follows every shortcut, an extra coupling would flip the cone of vertices behind it -- then the two big classes stay
+        // and the few vertices on conflicting edges are recoloured
+        Buf<uint8_t> skip;
+        DPCG_TRY(skip.alloc(A.nnz));
+        hipLaunchKernelGGL(k_triangle_edges, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, skip.p);
+        DPCG_TRY(two_colors_by_regions(A, color.p, flags.p, &colored, &nearly, skip.p, s));
+    }
+    if (!colored && nearly) {
+        DPCG_HIP(hipMemsetAsync(flags.p, 0, 4 * sizeof(int), s));
+        hipLaunchKernelGGL(k_mark_conflicts, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, color.p, iota.p, flags.p + 2);
+        int marked = 0;
+        DPCG_HIP(hipMemcpyAsync(&marked, flags.p + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        if (pt.on) fprintf(stderr, "[dpcg setup]   nearly two-coloured: %d of %lld vertices on conflicting edges\n", marked, (long long)n);
+        if ((int64_t)marked * 8 <= n) {
+            DPCG_HIP(hipMemcpyAsync(color.p, iota.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+            repaired = true;
+        }
+    }
+    if (!colored && !repaired) {   // 1. breadth-first parity, component by component
         Buf<int32_t> deg, level, order, start, count;
         Buf<unsigned long long> best;
         const int64_t nlv = n + 2 + 2 * kBfsBatch;
@@ -890,8 +987,8 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
             colored = bad == 0;
         }
     }
-    if (!colored) {   // 2. Jones-Plassmann greedy colouring
-        DPCG_HIP(hipMemsetAsync(color.p, 0xff, (size_t)n * sizeof(int32_t), s));
+    if (!colored) {   // 2. Jones-Plassmann greedy colouring (of everything, or of the vertices the repair left uncoloured)
+        if (!repaired) DPCG_HIP(hipMemsetAsync(color.p, 0xff, (size_t)n * sizeof(int32_t), s));
         DPCG_HIP(hipMemsetAsync(flags.p, 0, 4 * sizeof(int), s));
         int rounds = 0;
         for (;;) {
@@ -914,7 +1011,9 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
         DPCG_HIP(hipStreamSynchronize(s));
         if (bad) return invalid("multicolour ordering: improper colouring (is the pattern structurally symmetric?)");
         // fewer colours = fewer levels for the triangular solves: a few passes of iterated greedy over the classes, last to first
-        static const int passes = [] { const char *e = getenv("DPCG_RECOLOR_PASSES"); return e ? atoi(e) : 3; }();
+        // (not after a repair: the two big classes are what the repair is for)
+        static const int passes_knob = [] { const char *e = getenv("DPCG_RECOLOR_PASSES"); return e ? atoi(e) : 3; }();
+        const int passes = repaired ? 1 : passes_knob;
         Buf<int> hist;
         Buf<int32_t> map;
         DPCG_TRY(hist.alloc(64));

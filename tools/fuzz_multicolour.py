@@ -56,6 +56,19 @@ for case in range(cases):
     diagonal = dim == 2 and bool(rng.integers(0, 3) == 0)
     A = grid_matrix(shape, drop, diagonal)
     n = A.shape[0]
+    extra = 0.0
+    if not diagonal and drop == 0.0 and rng.integers(0, 3) == 0:
+        # bipartite but for a few odd cycles: an extra coupling (a grid diagonal) at a small share of the vertices
+        extra = float(rng.choice([0.002, 0.01, 0.05]))
+        stride = shape[-1] + 1
+        v = rng.choice(n - stride - 1, max(1, int(extra * n)), replace=False)
+        v = v[(v % shape[-1]) < shape[-1] - 1]
+        if len(shape) == 3 and rng.integers(0, 4):      # (one case in four keeps the links that wrap into the next plane: odd cycles
+            v = v[((v // shape[-1]) % shape[-2]) < shape[-2] - 1]     # without a triangle -- the repair gives up, greedy colouring)
+        E = sp.coo_matrix((-rng.uniform(0.1, 0.5, v.size), (v, v + stride)), shape=(n, n)).tocsr()
+        E = E + E.T
+        A = (A + E + sp.diags(np.asarray(abs(E).sum(axis=1)).ravel())).tocsr()
+        A.sort_indices()
     scramble = bool(rng.integers(0, 3) == 0)
     if scramble:
         p = rng.permutation(n)
@@ -63,7 +76,7 @@ for case in range(cases):
         A.sort_indices()
     reorder = str(rng.choice(["auto", "None", "rcm"])) if scramble else "None"
     reorder = None if reorder == "None" else reorder
-    tag = f"case {case}: shape={shape} n={n} drop={drop} diagonal={diagonal} scramble={scramble} reorder={reorder}"
+    tag = f"case {case}: shape={shape} n={n} drop={drop} diagonal={diagonal} extra={extra} scramble={scramble} reorder={reorder}"
     S = D.CsrSystem.from_any(A, reorder=reorder)
     S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
     refresh = bool(rng.integers(0, 2))

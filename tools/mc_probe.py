@@ -32,6 +32,25 @@ def _grid_with_dropped_edges(m, drop, diagonal):
     return D.CsrSystem.from_any(A)
 
 
+def _grid3d_with_extra_links(m, share):
+    """m^3 7-point grid plus a diagonal coupling at a share of the vertices: bipartite but for a few odd cycles, like a hex mesh with
+    refinement interfaces."""
+    import numpy as np
+    import scipy.sparse as sp
+    from oracle import oracle as O
+    rng = np.random.default_rng(9)
+    A = O.poisson3d(m).tolil()
+    n = m ** 3
+    v = rng.choice(n - m - 2, int(share * n), replace=False)
+    v = v[((v % m) < m - 1) & (((v // m) % m) < m - 1)]                                   # (no links that wrap into the next row / plane)
+    E = sp.coo_matrix((np.full(v.size, -0.3), (v, v + m + 1)), shape=(n, n)).tocsr()      # (i, j, k) -- (i, j + 1, k + 1)
+    B = (O.poisson3d(m) + E + E.T + sp.diags(np.asarray(abs(E + E.T).sum(axis=1)).ravel())).tocsr()
+    B.sort_indices()
+    return D.CsrSystem.from_any(B)
+
+
+cases += [("nearly_bipartite3d_100", lambda: _grid3d_with_extra_links(100, 0.005)),
+          ("nearly_bipartite3d_64", lambda: _grid3d_with_extra_links(64, 0.02))]
 cases += [("six_point_1000", lambda: _grid_with_dropped_edges(1000, 0.0, True)),
           ("dropped2d_1000", lambda: _grid_with_dropped_edges(1000, 0.3, False)),
           ("dropped_six_1000", lambda: _grid_with_dropped_edges(1000, 0.1, True))]

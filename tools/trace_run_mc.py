@@ -16,6 +16,13 @@ if which == "c2":
     s = poisson.poisson_system(2, 256)
 elif which == "natural":
     s = poisson.poisson_system(3, 100)
+elif which == "nearly":                      # bipartite but for 0.5 % extra couplings (tools/mc_probe.py)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mc_probe_cases", str(ROOT / "tools" / "mc_probe.py"))
+    sys.argv = [sys.argv[0], "none"]
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    s = mod._grid3d_with_extra_links(100, 0.005)
 else:
     s = D.CsrSystem.from_any(poisson.unstructured_like_csr(3, 100, 0))
 s.set_preconditioner(D.IC0("solve", ordering="multicolor"))
