@@ -647,7 +647,7 @@ extern "C" int dpcg_spmv_f32(dpcg_handle_t h, const float *x, float *y, dpcg_str
 int rz_partial_count(const dpcg_system *h) {
     if (h->precond == DPCG_PRECOND_CSR) return h->planM.grid;
     if (h->precond == DPCG_PRECOND_LLT_MULTIPLY) return h->planL.grid;
-    if (h->precond == DPCG_PRECOND_LLT_SOLVE && h->lvlU.sweep && h->lvlU.sweep_dot) return h->lvlU.n_levels * h->lvlU.sweep_grid;   // colour sweeps
+    if (h->precond == DPCG_PRECOND_LLT_SOLVE && h->lvlU.sweep) return h->lvlU.sweep_grid;   // colour sweeps
     return h->vec_grid;
 }
 
@@ -700,7 +700,7 @@ int apply_precond(dpcg_system *h, const double *r, double *z, hipStream_t s, boo
                     upper_io.refill = h->lvlL.lm_out;
                 }
             }
-            if (part_rz && n_part_rz && !(h->lvlU.sweep && !h->lvlU.sweep_dot)) {   // <r,z> summed by the kernel that takes z out of level-major order
+            if (part_rz && n_part_rz) {                    // <r,z> summed by the kernel that takes z out of level-major order
                 upper_io.dot_with = r;
                 upper_io.dot_part = part_rz;
                 upper_io.dot_grid = h->vec_grid;

@@ -155,11 +155,10 @@ struct Levels {
     // IC(0) in multicolour order): one CSR-stream launch per level that gathers its right-hand side itself, writes the
     // result by position AND in the handle's numbering and sums <r,z> on the way (k_lm_sweep): no way-in / way-out passes.
     bool sweep = false;
-    int sweep_grid = 0;                    // workgroups per level launch; an apply leaves n_levels * sweep_grid partials of <r,z>
-    // More levels than the partials have room for at a useful grid (sweep_dot false): every level is launched with a grid of its
-    // own (sw_grid) and <r,z> is a launch of its own after the apply.
-    bool sweep_dot = true;
-    std::vector<int> sw_grid;
+    // workgroups per level launch.  An apply leaves sweep_grid partials of <r,z>: workgroup i of every launch that contributes
+    // adds its share to slot i (the first such launch of the apply stores instead) -- one fixed order of additions per slot,
+    // whatever the number of levels
+    int sweep_grid = 0;
     // Tiled sweeps: an x-tile plan (as SpmvPlan's) per level of the level-ordered copy -- blocks of 256 rows counted from the
     // level's first row; the solution entries a block gathers are staged in LDS in 64-entry chunks (k_lm_sweep_tile).
     int32_t *sw_chunks = nullptr, *sw_nchunks = nullptr;
@@ -194,7 +193,7 @@ struct SptrsvIo {
     double *refill = nullptr;
     // Colour sweeps, paired apply: the LOWER solve's last level also emits the first level of the upper solve (rows without
     // dependants: z = y / d) -- by position into pair_out[lm_to_upper[j]], by row into pair_dst, its share of <dot_with, z>
-    // into dot_part[0 .. sweep_grid); the UPPER solve then starts at its second level (skip_first).
+    // STORED into dot_part[0 .. sweep_grid); the UPPER solve then starts at its second level (skip_first) and adds to those.
     double *pair_out = nullptr, *pair_dst = nullptr;
     bool skip_first = false;
 };

@@ -246,8 +246,8 @@ static int64_t sweep_min_rows() {
 }
 
 // Up to 4 levels of >= sweep_min_rows() rows each; a fifth when the levels are very wide (>= 131 072 rows on average).  Measured at
-// 1M rows on greedy colourings (tools/mc_probe.py, us per PCG update, sync-free launch -> sweeps with a grid per level): 5 levels
-// 119 -> 98, 7 levels 123 -> 162 / 152 (hashed-priority colour classes scatter a level's columns: the gather sweep, many launches).
+// 1M rows on greedy colourings (tools/mc_probe.py, us per PCG update, sync-free launch -> sweeps): 5 levels 119 -> 98, 7 levels
+// 123 -> 162 / 152 (hashed-priority colour classes scatter a level's columns: the gather sweep, many launches).
 // DPCG_SWEEP_MAX_LEVELS: development knob (then for any width).
 static bool sweep_levels_ok(int64_t n, int n_levels) {
     static const int knob = [] { const char *e = getenv("DPCG_SWEEP_MAX_LEVELS"); return e ? atoi(e) : 0; }();
@@ -428,7 +428,7 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
             int64_t widest = 0;
             for (int l = 0; l < lv.n_levels; ++l) widest = std::max<int64_t>(widest, level_ptr[l + 1] - level_ptr[l]);
             const int64_t blocks = (widest + kBlock - 1) / kBlock;
-            lv.sweep_grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, kMaxSpmvGrid / lv.n_levels));
+            lv.sweep_grid = (int)std::max<int64_t>(1, std::min<int64_t>(blocks, kMaxSpmvGrid));
             // x-tile plans of the levels (k_lm_sweep_tile); a level without off-diagonal entries, or with a block whose columns
             // are too spread out, keeps the gather sweep
             static const bool tiles_on = [] { const char *e = getenv("DPCG_SWEEP_TILES"); return !(e && e[0] == '0'); }();
@@ -461,24 +461,10 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
                 if (most > 0) {             // as make_plan: workgroups per CU by the LDS a block takes, a multiple of 8
                     const size_t lds = (size_t)(most * kTileChunk + kStreamCap + 8) * sizeof(double);
                     const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
-                    int g = (int)std::min<int64_t>(blocks, std::min<int64_t>(per_cu * 256, kMaxSpmvGrid / lv.n_levels));
+                    static const int grid_cap = [] { const char *e = getenv("DPCG_SWEEP_GRID"); return e ? atoi(e) : 1024; }();
+                    int g = (int)std::min<int64_t>(blocks, std::min<int64_t>(std::min(per_cu * 256, grid_cap), kMaxSpmvGrid));
                     if (g > 8) g -= g % 8;
                     lv.sweep_grid = std::max(1, g);
-                }
-            }
-            // more than four levels: the partials of <r,z> (levels x grid <= 2048) would leave each level a grid too small for
-            // its rows -- every level gets the grid its size asks for, and the dot product becomes a launch of its own
-            lv.sweep_dot = lv.n_levels <= 4;
-            if (!lv.sweep_dot) {
-                lv.sw_grid.assign((size_t)lv.n_levels, 1);
-                for (int l = 0; l < lv.n_levels; ++l) {
-                    const int64_t bl = (level_ptr[l + 1] - level_ptr[l] + kBlock - 1) / kBlock;
-                    const int mc = l < (int)lv.sw_max_chunks.size() ? lv.sw_max_chunks[(size_t)l] : 0;
-                    const size_t lds = (size_t)(mc * kTileChunk + kStreamCap + 8) * sizeof(double);
-                    const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
-                    int g = (int)std::min<int64_t>(bl, (int64_t)per_cu * 256);
-                    if (g > 8) g -= g % 8;
-                    lv.sw_grid[(size_t)l] = std::max(1, g);
                 }
             }
         }
@@ -857,7 +843,7 @@ int finish_llt(dpcg_system *h, int mode, hipStream_t s, LevelSort *lower_levels 
             // colour sweeps: the first level of L^T holds the rows of L's last level (no dependants; equal counts: the same set)
             // -- the last lower sweep can open the upper solve (SptrsvIo::pair_out)
             const Levels &lo = h->lvlL, &up = h->lvlU;
-            if (lo.sweep && up.sweep && lo.n_levels == up.n_levels && lo.n_levels >= 2 && (lo.sweep_grid == up.sweep_grid || !up.sweep_dot) &&
+            if (lo.sweep && up.sweep && lo.n_levels == up.n_levels && lo.n_levels >= 2 && lo.sweep_grid == up.sweep_grid &&
                 up.level_ptr[1] - up.level_ptr[0] == lo.level_ptr[(size_t)lo.n_levels] - lo.level_ptr[(size_t)lo.n_levels - 1]) {
                 static const bool pair_on = [] { const char *e = getenv("DPCG_SWEEP_PAIR"); return !(e && e[0] == '0'); }();
                 if (pair_on) {

@@ -1396,7 +1396,8 @@ __global__ __launch_bounds__(kBlock) void k_lm_sweep(int j0, int count, const in
                                                      const double *__restrict__ src, const int32_t *__restrict__ src_map,
                                                      double *out, double *__restrict__ dst, const int32_t *__restrict__ rows,
                                                      const double *__restrict__ dotv, double *__restrict__ part,
-                                                     double *__restrict__ out2, const int32_t *__restrict__ map2, const int *done) {
+                                                     double *__restrict__ out2, const int32_t *__restrict__ map2, int accumulate,
+                                                     const int *done) {
     if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     constexpr int U = kStreamCap / kBlock;
     __shared__ double prod[kStreamCap];
@@ -1453,9 +1454,9 @@ __global__ __launch_bounds__(kBlock) void k_lm_sweep(int j0, int count, const in
         }
         __syncthreads();          // prod is reused by the next block
     }
-    if (part) {
+    if (part) {     // (`accumulate`: an earlier launch of this apply has stored its share in the slot already)
         const double tot = block_sum(dot, sh);
-        if (t == 0) part[blockIdx.x] = tot;
+        if (t == 0) part[blockIdx.x] = accumulate ? part[blockIdx.x] + tot : tot;
     }
 }
 
@@ -1473,7 +1474,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_sweep_tile(int j0, int count, int
                                                           const int32_t *__restrict__ src_map, double *out, double *__restrict__ dst,
                                                           const int32_t *__restrict__ rows, const double *__restrict__ dotv,
                                                           double *__restrict__ part, double *__restrict__ out2,
-                                                          const int32_t *__restrict__ map2, const int *done) {
+                                                          const int32_t *__restrict__ map2, int accumulate, const int *done) {
     if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     constexpr int U = kStreamCap / kBlock;
     constexpr int UP = U / 2;
@@ -1576,7 +1577,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_sweep_tile(int j0, int count, int
     if (part) {
         __syncthreads();
         const double tot = block_sum(dot, sh);
-        if (t == 0) part[blockIdx.x] = tot;
+        if (t == 0) part[blockIdx.x] = accumulate ? part[blockIdx.x] + tot : tot;
     }
 }
 
@@ -1589,8 +1590,11 @@ static void launch_sweeps(const Levels &lv, bool upper, const double *src, const
         const int j0 = lv.level_ptr[l], cnt = lv.level_ptr[l + 1] - j0;
         // the last level of a lower solve whose rows open the paired upper solve: z instead of y, into the upper numbering
         const bool emit = !upper && io && io->pair_out && l == lv.n_levels - 1;
-        const int grid = lv.sweep_dot ? lv.sweep_grid : lv.sw_grid[(size_t)l];
-        double *pl = emit ? part : (part ? part + (size_t)l * lv.sweep_grid : nullptr);
+        const int grid = lv.sweep_grid;
+        double *pl = part;
+        // the first launch of the apply that sums <r,z> stores its shares, the later ones add theirs: the lower solve's last level
+        // when it opens the upper one, otherwise the upper solve's first level
+        const int acc = emit ? 0 : ((upper && l == 0) ? 0 : 1);
         double *o2 = emit ? io->pair_out : nullptr;
         const int32_t *m2 = emit ? lv.lm_to_upper : nullptr;
         double *d = emit ? io->pair_dst : dst;
@@ -1604,7 +1608,7 @@ static void launch_sweeps(const Levels &lv, bool upper, const double *src, const
 #define DPCG_SWEEP_TILE(UP_, XT_)                                                                                              \
     hipLaunchKernelGGL((k_lm_sweep_tile<UP_, XT_>), dim3(grid), dim3(kBlock), lds, s, j0, cnt, (int)lv.level_ptr.back(), \
                        lv.lo_rowptr, lv.lo_val, lv.sw_lidx, ch, nch, tile_doubles, src, src_map, lv.lm_out, d, lv.rows, dw, pl, \
-                       o2, m2, done)
+                       o2, m2, acc, done)
             if (upper) {
                 if (mc <= 20) DPCG_SWEEP_TILE(true, 5);
                 else DPCG_SWEEP_TILE(true, (kTileMaxChunks * kTileChunk / kBlock));
@@ -1617,10 +1621,10 @@ static void launch_sweeps(const Levels &lv, bool upper, const double *src, const
         }
         if (upper)
             hipLaunchKernelGGL(k_lm_sweep<true>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_cpos, lv.lo_val,
-                               src, src_map, lv.lm_out, d, lv.rows, dw, pl, o2, m2, done);
+                               src, src_map, lv.lm_out, d, lv.rows, dw, pl, o2, m2, acc, done);
         else
             hipLaunchKernelGGL(k_lm_sweep<false>, dim3(grid), dim3(kBlock), 0, s, j0, cnt, lv.lo_rowptr, lv.lo_cpos, lv.lo_val,
-                               src, src_map, lv.lm_out, d, lv.rows, dw, pl, o2, m2, done);
+                               src, src_map, lv.lm_out, d, lv.rows, dw, pl, o2, m2, acc, done);
     }
 }
 
@@ -1642,7 +1646,7 @@ void launch_sptrsv(const CsrDev &T, const Levels &lv, bool upper, const double *
                       dot ? io->dot_with : nullptr, dot ? io->dot_part : nullptr, s, done, io);
         if (dot && upper) {
             io->dot_done = true;
-            io->dot_count = lv.n_levels * lv.sweep_grid;
+            io->dot_count = lv.sweep_grid;
         }
         return;
     }
