@@ -165,6 +165,7 @@ struct Levels {
     uint16_t *sw_lidx = nullptr;
     std::vector<int> sw_blk0;              // host: first block of each level in sw_chunks / sw_nchunks
     std::vector<int> sw_max_chunks;        // host: per level the largest chunk count of a block (0: the level keeps the gather sweep)
+    bool sweep_nt = false;                 // the factor's stream exceeds the Infinity Cache: read non-temporally
     // L only, when L^T's first level is L's last one (levels of L^T = levels of L reversed): position here -> position in
     // L^T's numbering, so that the last lower sweep can emit the first level of the upper solve (z = y / d) as well
     int32_t *lm_to_upper = nullptr;

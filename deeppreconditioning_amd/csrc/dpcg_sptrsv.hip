@@ -1466,7 +1466,8 @@ __global__ __launch_bounds__(kBlock) void k_lm_sweep(int j0, int count, const in
 // travels through its product slot (local index kTileDiag: times 1.0).  Same arithmetic, same order, same bits.
 // `out2` (the last level of a lower solve paired with an upper one whose first level holds the same rows): the row also
 // opens the upper solve -- z = y / d goes to out2[map2[j]], to dst and into the dot product; y itself is not stored.
-template <bool UPPER, int XT>
+// NT: the factor's stream (values, local indices) is read non-temporally -- a factor beyond the Infinity Cache, as k_spmv_tile's NT.
+template <bool UPPER, int XT, bool NT = false>
 __global__ __launch_bounds__(kBlock) void k_lm_sweep_tile(int j0, int count, int n_total, const int32_t *__restrict__ lo_rp,
                                                           const double *__restrict__ lo_v, const uint16_t *__restrict__ lidx,
                                                           const int32_t *__restrict__ chunks, const int32_t *__restrict__ nchunks,
@@ -1517,8 +1518,10 @@ __global__ __launch_bounds__(kBlock) void k_lm_sweep_tile(int j0, int count, int
         for (int u = 0; u < UP; ++u) {
             const int pr = t + u * kBlock;
             const int64_t kabs = base + 2 * (int64_t)(pr <= lastp ? pr : lastp);
-            a[u] = *reinterpret_cast<const VPair *>(lo_v + kabs);          // (aligned pairs: see k_spmv_tile)
-            li[u] = *reinterpret_cast<const IPair *>(lidx + kabs);
+            const VPair *vp = reinterpret_cast<const VPair *>(lo_v + kabs);          // (aligned pairs: see k_spmv_tile)
+            const IPair *ip = reinterpret_cast<const IPair *>(lidx + kabs);
+            a[u] = NT ? __builtin_nontemporal_load(vp) : *vp;
+            li[u] = NT ? __builtin_nontemporal_load(ip) : *ip;
         }
         nc = nchunks[blk];
         const int32_t *__restrict__ cl = chunks + (int64_t)blk * kTileMaxChunks;
@@ -1606,9 +1609,16 @@ static void launch_sweeps(const Levels &lv, bool upper, const double *src, const
             const size_t lds = (size_t)(tile_doubles + kStreamCap + 8) * sizeof(double);
             const int32_t *ch = lv.sw_chunks + (size_t)lv.sw_blk0[l] * kTileMaxChunks, *nch = lv.sw_nchunks + lv.sw_blk0[l];
 #define DPCG_SWEEP_TILE(UP_, XT_)                                                                                              \
+    do {                                                                                                                       \
+    if (lv.sweep_nt)                                                                                                           \
+        hipLaunchKernelGGL((k_lm_sweep_tile<UP_, XT_, true>), dim3(grid), dim3(kBlock), lds, s, j0, cnt, (int)lv.level_ptr.back(), \
+                           lv.lo_rowptr, lv.lo_val, lv.sw_lidx, ch, nch, tile_doubles, src, src_map, lv.lm_out, d, lv.rows, dw, pl, \
+                           o2, m2, acc, done);                                                                                     \
+    else                                                                                                                       \
     hipLaunchKernelGGL((k_lm_sweep_tile<UP_, XT_>), dim3(grid), dim3(kBlock), lds, s, j0, cnt, (int)lv.level_ptr.back(), \
                        lv.lo_rowptr, lv.lo_val, lv.sw_lidx, ch, nch, tile_doubles, src, src_map, lv.lm_out, d, lv.rows, dw, pl, \
-                       o2, m2, acc, done)
+                       o2, m2, acc, done);                                                                                     \
+    } while (0)
             if (upper) {
                 if (mc <= 20) DPCG_SWEEP_TILE(true, 5);
                 else DPCG_SWEEP_TILE(true, (kTileMaxChunks * kTileChunk / kBlock));
