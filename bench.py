@@ -660,6 +660,23 @@ def extra_workloads(D, poisson, torch) -> dict:
     out["c4_poisson3d_256_jacobi"] = {"iterations": r.iterations, "iterations_per_s": round(r.iterations / r.seconds, 2),
                                       "spmv_gbs": round(gbs, 1), "spmv_frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
                                       "spmv_us_per_launch": round(ms * 1e3, 1)}
+    # the same system to the solution (reference defaults): Jacobi against IC(0) in multicolour order, every stream from HBM
+    to_solution = {}
+    for name, pc in (("jacobi", D.Jacobi()), ("ic0_multicolor_solve", D.IC0("solve", ordering="multicolor"))):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s4.set_preconditioner(pc)
+        torch.cuda.synchronize()
+        setup_ms = (time.perf_counter() - t0) * 1e3
+        s4.solve(b4, want_history=False)
+        r = s4.solve(b4, want_history=False)
+        to_solution[name] = {"iterations": r.iterations, "status": r.status, "ms": round(r.seconds * 1e3, 2),
+                             "us_per_update": round(r.seconds / r.iterations * 1e6, 1), "setup_new_pattern_ms": round(setup_ms, 2)}
+    to_solution["ic0_multicolor_solve"]["apply_roofline"] = {
+        "bound": "hbm", "algorithmic_bytes_per_apply": 2 * sptrsv_bytes(s4.n, s4.info()["precond_nnz"]),
+        "levels": [s4.info()["levels_lower"], s4.info()["levels_upper"]]}
+    in_loop_apply(to_solution["ic0_multicolor_solve"], to_solution["jacobi"]["us_per_update"])
+    out["c4_poisson3d_256_to_solution"] = to_solution
     s4.close()
     del s4, b4
     # config 4 as ONE GPU sees it: its 8 of the 64 systems (s mod 8 == rank), full solves at the reference defaults,
