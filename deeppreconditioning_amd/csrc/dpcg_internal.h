@@ -18,7 +18,7 @@ namespace dpcg {
 // number of reduction partials is bounded and every kernel after a reduction can re-reduce the
 // partials itself (deterministically) instead of waiting on a host round trip or a float atomic.
 constexpr int kBlock = 256;
-constexpr int kMaxGrid = 512;         // vector kernels: 2 workgroups per CU (fewer partials to re-reduce)
+constexpr int kMaxGrid = 1024;        // vector kernels: 4 workgroups per CU (same box, 1M DoF, us per Jacobi update: 512 -> 31.5, 1024 -> 31.2, 1536 -> 32.5, 2048 -> 33.3)
 constexpr int kMaxSpmvGrid = 2048;    // SpMV: 8 workgroups per CU = 32 waves per CU (40 VGPRs, 16 KiB LDS each)
 constexpr int kStreamCap = 2048;      // products staged in LDS per 256-row block (16 KiB)
 constexpr int kStreamRows = 256;      // rows per row-block of the CSR-stream SpMV
