@@ -162,11 +162,22 @@ for case in range(cases):
                 # 100x per update has no tight head: case 41 of seed 2024, HIP vs C 1.1e-8 where the two oracles differ by 6.2e-9)
                 nh = max(1, min(4, mm // 4))
                 head_ok = rel_m[:nh].size == 0 or float(rel_m[:nh].max()) < max(1e-9, 30 * float(drift_m[:nh].max()))
-                if not (head_ok and (rel_m.size == 0 or float(rel_m.max()) < tol_m)
+                # (the drift is chaotic: once two roundings of p have parted, the gap grows by a factor per update -- case 86 of seed
+                # 477: equal to 1e-15 for nine updates, 2.4e-9 at update 15, x4 per update at the end, 1.9e-4 at update 36 where the two
+                # CPU oracles are 2e-7 apart, counts equal.  So: the first half of the history within 30x the oracles' drift, the second
+                # half within 1e-3.)
+                half = rel_m.size // 2
+                body_ok = (rel_m.size == 0 or (float(rel_m[:max(half, 1)].max()) < tol_m and float(rel_m.max()) < max(tol_m, 1e-3)))
+                if not (head_ok and body_ok
                         and abs(rm.iterations - itm) <= 0.02 * itm + 1 + abs(len(hn) - 1 - itm)):
                     bad += 1
                     print("MIXED-PRECISION MISMATCH", tag, kind, "iters", rm.iterations, itm, len(hn) - 1, "max rel",
                           float(rel_m.max()) if rel_m.size else None, "oracle drift", float(drift_m.max()) if drift_m.size else None)
+                if only is not None:
+                    np.set_printoptions(precision=3, linewidth=200)
+                    print(kind, "mixed GPU / C mixed oracle - 1:", rm.res_history[:mm] / hm[:mm] - 1)
+                    print(kind, "mixed numpy oracle / C mixed oracle - 1:", hn[:mm] / hm[:mm] - 1)
+                    print(kind, "C mixed history:", hm[:mm])
             for flags in (0, D._lib.NO_SMALL, D._lib.NO_SMALL | D._lib.NO_FUSE):
                 r = S.solve(torch.from_numpy(b).cuda(), x0_dev, flags=flags)
                 h = r.res_history
