@@ -87,9 +87,15 @@ def time_apply(system, b, torch, reps: int = 20) -> float:
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--systems-per-gpu", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 2 with --config4)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 3; 1 with --config4)")
+    ap.add_argument("--systems-per-gpu", type=int, default=None)
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE config 4 as stated: 64 x poisson3d(256) sharded 8 per GPU over 8 GPUs (8 x --gpus systems, "
+                         "distinct b per system id); same flags otherwise")
+    ap.add_argument("--scatter", default="specs", choices=["specs", "arrays"],
+                    help="N > 1: what rank 0 scatters -- 3-integer specs (systems rebuilt in the owner's HBM) or the CSR arrays + b "
+                         "of every system as grouped point-to-point sends (the real-matrix path)")
     ap.add_argument("--dim", type=int, default=3)
     # (`--grid`, not `--n`: torch.distributed.run reads `--n` in front of the script's own arguments as an ambiguous
     # abbreviation of its --nnodes / --nproc-per-node and refuses the command line)
@@ -100,7 +106,14 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / result reduction (nccl = RCCL; gloo lets the "
                          "N > 1 control flow be exercised with several ranks sharing one GPU)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config4:
+        args.dim, args.n = 3, 256
+        args.systems_per_gpu = 8 if args.systems_per_gpu is None else args.systems_per_gpu
+    args.systems_per_gpu = 1 if args.systems_per_gpu is None else args.systems_per_gpu
+    args.steps = (2 if args.config4 else 20) if args.steps is None else args.steps
+    args.warmup = (1 if args.config4 else 3) if args.warmup is None else args.warmup
+    return args
 
 
 def cpu_baseline(dim: int, n: int) -> dict:
@@ -203,31 +216,69 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- the batch: systems already resident in HBM before the timed region --------------------
+    # ---- the batch: rank 0 owns its description; scatter over the backend (RCCL when nccl); systems resident in HBM before
+    # ---- the timed region.  System s of the batch has right-hand side default_rng(s) and goes to rank s mod world.
+    from deeppreconditioning_amd import batch as B
     make_pc = lambda: {"jacobi": D.Jacobi(), "none": None, "ic0": D.IC0("solve")}[args.precond]   # noqa: E731
-    system = poisson.poisson_system(args.dim, args.n)
-    system.set_preconditioner(make_pc())
-    # every rank owns systems rank, rank+world, ... of the global batch; distinct b per system
-    my_ids = [rank + world * j for j in range(args.systems_per_gpu)]
-    rhs = [poisson.rhs(system.n, seed=i) for i in my_ids]
-    group = [system]
-    if args.systems_per_gpu > 1:
-        # several systems per GPU: handles that share the one matrix in HBM (borrowed CSR arrays, own work vectors),
-        # up to 4 in flight at once on separate streams -- another system's kernels fill this one's launch boundaries
-        from deeppreconditioning_amd.batch import solve_batch
+    comm = {"backend": None, "ranks": 1, "scatter_mode": None, "scatter_ms": None, "gather_ms": None}
+    count = world * args.systems_per_gpu
+    my_ids = list(range(count))
+    received = None
+    if dist is not None:
+        dist.barrier()                       # the first collective creates the communicator: not part of the scatter's time
+        barrier()
+        t_sc = time.perf_counter()
+        if args.scatter == "specs":
+            specs = [B.SystemSpec(args.dim, args.n, i) for i in range(count)] if rank == 0 else None
+            my_specs, my_ids, count = B.scatter_specs(specs)
+            assert all((sp.dim, sp.n) == (args.dim, args.n) for sp in my_specs)
+            my_seeds = [sp.seed for sp in my_specs]
+        else:
+            systems0 = None
+            if rank == 0:                    # rank 0 holds every system of the batch (here: generated in ITS HBM)
+                rp0, ci0, v0 = poisson.poisson_csr(args.dim, args.n)
+                systems0 = [(rp0, ci0, v0, poisson.rhs(rp0.numel() - 1, seed=i)) for i in range(count)]
+            received, my_ids, _sizes = B.scatter_systems(systems0)
+            del systems0
+            my_seeds = list(my_ids)
+        torch.cuda.synchronize()
+        comm.update(backend=dist.get_backend() + (" (RCCL over xGMI)" if args.backend == "nccl" else ""),
+                    ranks=dist.get_world_size(), scatter_mode=args.scatter,
+                    scatter_ms=round((time.perf_counter() - t_sc) * 1e3, 3))
+    else:
+        my_seeds = list(my_ids)
+    if received is not None:
+        # the real-matrix path: every system arrives with its own arrays (in host memory with gloo); one handle per system
+        dev = torch.device("cuda", torch.cuda.current_device())
+        received = [tuple(t.to(dev) for t in parts) for parts in received]
+        handles = [D.CsrSystem(rp_, ci_, v_, rp_.numel() - 1) for rp_, ci_, v_, _ in received]
+        rhs = [parts[3] for parts in received]
+    else:
+        # synthetic systems are rebuilt in the owner's HBM from their specs; systems of one rank share the ONE matrix (the
+        # handles borrow the same CSR arrays, own work vectors) and differ in their right-hand sides
         rp_, ci_, v_ = poisson.poisson_csr(args.dim, args.n)
-        group = [D.CsrSystem(rp_, ci_, v_, rp_.numel() - 1) for _ in range(min(4, args.systems_per_gpu))]
-        for g in group:
-            g.set_preconditioner(make_pc())
+        handles = [D.CsrSystem(rp_, ci_, v_, rp_.numel() - 1) for _ in range(min(4, len(my_seeds)))]
+        rhs = [poisson.rhs(handles[0].n, seed=i) for i in my_seeds]
+    for h in handles:
+        h.set_preconditioner(make_pc())
+    system = handles[0]
+    from deeppreconditioning_amd.batch import solve_batch
+    last_records = np.zeros((len(rhs), 4))
 
     def step() -> int:
-        if len(group) == 1:
-            return sum(system.solve(b, want_history=False).iterations for b in rhs)
-        its = 0
-        for lo in range(0, len(rhs), len(group)):
-            chunk = rhs[lo:lo + len(group)]
-            its += sum(r.iterations for r in solve_batch(group[:len(chunk)], chunk, n_streams=len(chunk)))
-        return its
+        if len(rhs) == 1:
+            results = [system.solve(rhs[0], want_history=False)]
+        else:
+            # up to 4 systems of a rank in flight at once on separate streams: another system's kernels fill this one's
+            # launch boundaries
+            results = []
+            for lo in range(0, len(rhs), 4):
+                chunk = rhs[lo:lo + 4]
+                hs = handles[lo:lo + len(chunk)] if len(handles) == len(rhs) else handles[:len(chunk)]
+                results += solve_batch(hs, chunk, n_streams=len(chunk))
+        for i, r in enumerate(results):
+            last_records[i] = (r.iterations, r.status, r.final_res, r.seconds)
+        return sum(r.iterations for r in results)
 
     # Device wake-up, part of the setup (not a step, not timed): while torch was imported and the systems were built the GPU sat
     # idle, and ~10 ms after load resumes its power management stalls everything once for 50-90 ms (tools/idle_probe.py: one
@@ -248,9 +299,27 @@ def main() -> None:
 
     tot = torch.tensor([float(iters_local)], device=red_dev, dtype=torch.float64)
     tmax = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
+    per_rank = None
     if dist is not None:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # ---- gather (outside `value`): the result records of the last step's systems, all_gather over the backend
+        barrier()
+        t_g = time.perf_counter()
+        table = B.gather_records(last_records, count)
+        torch.cuda.synchronize()
+        comm["gather_ms"] = round((time.perf_counter() - t_g) * 1e3, 3)
+        comm["gathered_records"] = {"systems": int(table.shape[0]), "iterations": [int(v) for v in table[:, 0]],
+                                    "status": [int(v) for v in table[:, 1]],
+                                    "max_final_res": float(table[:, 2].max()) if table.size else None}
+        # one record per rank (its own clock and its own SpMV roofline), gathered the same way
+        ms_r = system.spmv_dot_bench(repeats=100)
+        gbs_r = loop_kernel_bytes(system) / (ms_r * 1e-3) / 1e9
+        mine = np.array([[iters_local / elapsed, elapsed, ms_r * 1e3, gbs_r / HBM_PEAK_GBS]])
+        ranks_table = B.gather_records(mine, world)
+        per_rank = [{"rank": r, "iterations_per_s": round(float(ranks_table[r, 0]), 1), "seconds": round(float(ranks_table[r, 1]), 4),
+                     "spmv_us_per_launch": round(float(ranks_table[r, 2]), 3), "roofline_frac": round(float(ranks_table[r, 3]), 4)}
+                    for r in range(world)]
     total_iters, t = float(tot.item()), float(tmax.item())
 
     if rank == 0:
@@ -271,11 +340,15 @@ def main() -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * t / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "backend": comm["backend"], "ranks": comm["ranks"], "scatter_mode": comm["scatter_mode"],
+            "scatter_ms": comm["scatter_ms"], "gather_ms": comm["gather_ms"],
             "config": {"workload": f"poisson{args.dim}d_{args.n}_{args.precond}_pcg_fp64", "dof": n, "nnz": nnz,
                        "rtol_sq": 1e-8, "max_iter": 1024, "iterations_per_solve": check.iterations,
                        "final_res": check.final_res, "systems_per_gpu_per_step": args.systems_per_gpu,
-                       "parallelism": f"independent systems sharded one-per-rank x{world}, no data-path collective"
-                                      + (f"; {args.systems_per_gpu} systems per GPU, {len(group)} interleaved on streams"
+                       "batch": ("BASELINE config 4: 64 x poisson3d(256), 8 per GPU on 8 GPUs" if args.config4 else None),
+                       "systems_in_batch": count,
+                       "parallelism": f"independent systems sharded s mod {world}, no data-path collective"
+                                      + (f"; {args.systems_per_gpu} systems per GPU, {min(4, len(rhs))} interleaved on streams"
                                          if args.systems_per_gpu > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": (f"k_spmv_{info['spmv_kernel']}<FUSE> (p = z + beta p, x += alpha p, q = A p, <p,q>)"
                                     if info["two_kernel_updates"] else
@@ -294,6 +367,10 @@ def main() -> None:
                                                                       max(v for k, v in ceilings.items() if isinstance(v, float)
                                                                           and not k.startswith("cache_resident"))), 4)},
         }
+        if per_rank is not None:
+            line["per_rank"] = per_rank
+            line["gathered_records"] = comm["gathered_records"]
+            line["roofline"]["per_rank_frac"] = [r["roofline_frac"] for r in per_rank]
         if args.precond == "jacobi" and not info["two_kernel_updates"]:
             # the whole PCG update of the timed solve against the same peak: K1 + K2 (q, r, dinv read; r written) + K3 (r, dinv, p read;
             # p written; every other update also p', x read and x written) = B_spmv + 9.5 n x 8 bytes, over wall time per update

@@ -115,18 +115,18 @@ def solve_specs_local(specs: list[SystemSpec], *, precond: str = "jacobi", rtol_
     return out
 
 
-def solve_specs_distributed(specs: list[SystemSpec] | None, local_solver=None, **kw) -> np.ndarray | None:
-    """All ranks call this; rank 0 passes the batch, the others None.
+def _comm_device():
+    """Where collective payloads live: HBM for the nccl (= RCCL) backend, host memory for gloo."""
+    import torch.distributed as dist
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
 
-    scatter: the spec table is broadcast (3 int64 per system).  Solve: rank r takes systems
-    r, r+world, ... with no communication.  gather: fixed-size result records are all-gathered;
-    every rank returns the full (count, 4) table in batch order.  `local_solver(specs, **kw)`
-    defaults to `solve_specs_local` (tests inject a stand-in to exercise the sharding on CPU/gloo).
-    """
+
+def scatter_specs(specs: list[SystemSpec] | None) -> tuple[list[SystemSpec], list[int], int]:
+    """The scatter of a synthetic batch: all ranks call it, rank 0 passes the batch, the others None.
+    The spec table (3 int64 per system) is broadcast; returns (this rank's specs, their batch indices, batch size)."""
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
-    backend = dist.get_backend()
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    dev = _comm_device()
     meta = torch.zeros(1, dtype=torch.int64, device=dev)
     if rank == 0:
         meta[0] = len(specs)
@@ -134,22 +134,44 @@ def solve_specs_distributed(specs: list[SystemSpec] | None, local_solver=None, *
     count = int(meta.item())
     table = torch.zeros((count, 3), dtype=torch.int64, device=dev)
     if rank == 0:
-        table.copy_(torch.tensor([[s.dim, s.n, s.seed] for s in specs], dtype=torch.int64))
+        table.copy_(torch.tensor([[s.dim, s.n, s.seed] for s in specs], dtype=torch.int64).reshape(count, 3))
     dist.broadcast(table, 0)
     mine = shard(count, rank, world)
     rows = table.cpu().numpy()
-    local = (local_solver or solve_specs_local)([SystemSpec(*map(int, rows[i])) for i in mine], **kw)
-    per_rank = (count + world - 1) // world
-    buf = torch.full((per_rank, 4), -1.0, dtype=torch.float64, device=dev)
+    return [SystemSpec(*map(int, rows[i])) for i in mine], mine, count
+
+
+def gather_records(local: np.ndarray, count: int, width: int = 4) -> np.ndarray:
+    """The gather: every rank contributes the fixed-size records of the systems it owns (in the order
+    of `shard`), `all_gather` over the backend, every rank returns the (count, width) table in batch order."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = _comm_device()
+    mine = shard(count, rank, world)
+    per_rank = max((count + world - 1) // world, 1)
+    buf = torch.full((per_rank, width), -1.0, dtype=torch.float64, device=dev)
     if len(mine):
-        buf[: len(mine)] = torch.from_numpy(local).to(dev)
+        buf[: len(mine)] = torch.from_numpy(np.asarray(local, dtype=np.float64).reshape(len(mine), width)).to(dev)
     gathered = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(gathered, buf)
-    out = np.zeros((count, 4), dtype=np.float64)
+    out = np.zeros((count, width), dtype=np.float64)
     for r in range(world):
         idx = shard(count, r, world)
         out[idx] = gathered[r].cpu().numpy()[: len(idx)]
     return out
+
+
+def solve_specs_distributed(specs: list[SystemSpec] | None, local_solver=None, **kw) -> np.ndarray | None:
+    """All ranks call this; rank 0 passes the batch, the others None.
+
+    scatter: the spec table is broadcast (3 int64 per system; `scatter_specs`).  Solve: rank r takes systems
+    r, r+world, ... with no communication.  gather: fixed-size result records are all-gathered (`gather_records`);
+    every rank returns the full (count, 4) table in batch order.  `local_solver(specs, **kw)`
+    defaults to `solve_specs_local` (tests inject a stand-in to exercise the sharding on CPU/gloo).
+    """
+    my_specs, _, count = scatter_specs(specs)
+    local = (local_solver or solve_specs_local)(my_specs, **kw)
+    return gather_records(local, count)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -173,25 +195,17 @@ def _default_local_solver(items, *, precond: str = "jacobi", rtol_sq: float = 1e
     return recs, xs
 
 
-def solve_systems_distributed(systems, *, gather_x: bool = False, local_solver=None, **kw):
-    """All ranks call this; rank 0 passes `systems` = [(rowptr int32, col int32, val fp64, b fp64), ...] as numpy
-    arrays or torch tensors (what `io.load_case` / `coo_to_csr_device` return), the others None.
-
-    scatter: a size table (n, nnz per system) is broadcast; then, in rounds of one system per peer, rank 0 posts
-    the four arrays of every peer's next system as ONE group of point-to-point sends (`batch_isend_irecv`: on the
-    nccl backend a ncclGroupStart / ncclSend x 4 per peer / ncclGroupEnd, i.e. one xGMI link per peer, all peers
-    at once) while each peer posts the matching receives into its own HBM.  Rank 0 keeps its own systems.
-    solve: rank r owns systems r, r + world, ... and solves them with no communication.
-    gather: fixed-size records are all-gathered; with `gather_x` every owner sends its solutions back to rank 0
-    (same grouped point-to-point form).  Returns the (count, 4) record table on every rank -- and, on rank 0 with
-    `gather_x`, `(table, [x_0, ..., x_{count-1}])` in batch order.
-    `local_solver(items, **kw) -> (records, xs)` defaults to solving on this rank's GPU (tests inject a stand-in to
-    run the exchange on CPU / gloo)."""
+def scatter_systems(systems):
+    """The scatter of REAL matrices: all ranks call it, rank 0 passes `systems` = [(rowptr int32, col
+    int32, val fp64, b fp64), ...] (numpy arrays or torch tensors), the others None.  A size table (n, nnz per system) is
+    broadcast; then, in rounds of one system per peer, rank 0 posts the four arrays of every peer's next system as ONE group
+    of point-to-point sends (`batch_isend_irecv`: on the nccl backend a ncclGroupStart / ncclSend x 4 per peer /
+    ncclGroupEnd, i.e. one xGMI link per peer, all peers at once) while each peer posts the matching receives into its own
+    HBM.  Rank 0 keeps its own systems.  Returns (this rank's systems in `shard` order, their batch indices, (count, 2)
+    size table)."""
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
-    nccl = dist.get_backend() == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
-    solver = local_solver or _default_local_solver
+    dev = _comm_device()
 
     def to_dev(a, dtype):
         t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
@@ -234,20 +248,16 @@ def solve_systems_distributed(systems, *, gather_x: bool = False, local_solver=N
                 w.wait()
         del staged
     order = shard(count, rank, world)
-    recs, xs = solver([mine[s] for s in order], **kw)
-    del mine
-    per_rank = (count + world - 1) // world
-    buf = torch.full((max(per_rank, 1), 4), -1.0, dtype=torch.float64, device=dev)
-    if len(order):
-        buf[: len(order)] = torch.from_numpy(np.asarray(recs, dtype=np.float64).reshape(-1, 4)).to(dev)
-    gathered = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(gathered, buf)
-    table = np.zeros((count, 4), dtype=np.float64)
-    for r in range(world):
-        idx = shard(count, r, world)
-        table[idx] = gathered[r].cpu().numpy()[: len(idx)]
-    if not gather_x:
-        return table
+    return [mine[s] for s in order], order, sizes_h
+
+
+def gather_solutions(xs, order, sizes_h):
+    """Every owner sends its solutions back to rank 0 (grouped point-to-point, the scatter's form).  Returns the list of x in
+    batch order on rank 0, None elsewhere."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = _comm_device()
+    count = len(sizes_h)
     out_x: list = [None] * count
     for base in range(0, count, world):
         ops, keep = [], []
@@ -267,4 +277,27 @@ def solve_systems_distributed(systems, *, gather_x: bool = False, local_solver=N
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         del keep
-    return (table, out_x) if rank == 0 else table
+    return out_x if rank == 0 else None
+
+
+def solve_systems_distributed(systems, *, gather_x: bool = False, local_solver=None, **kw):
+    """All ranks call this; rank 0 passes `systems` = [(rowptr int32, col int32, val fp64, b fp64), ...] as numpy
+    arrays or torch tensors (what `io.load_case` / `coo_to_csr_device` return), the others None.
+
+    scatter: `scatter_systems` (size table broadcast, then the arrays as grouped point-to-point sends, one xGMI link per
+    peer).  solve: rank r owns systems r, r + world, ... and solves them with no communication.
+    gather: fixed-size records are all-gathered (`gather_records`); with `gather_x` every owner sends its solutions back to
+    rank 0 (`gather_solutions`).  Returns the (count, 4) record table on every rank -- and, on rank 0 with
+    `gather_x`, `(table, [x_0, ..., x_{count-1}])` in batch order.
+    `local_solver(items, **kw) -> (records, xs)` defaults to solving on this rank's GPU (tests inject a stand-in to
+    run the exchange on CPU / gloo)."""
+    import torch.distributed as dist
+    solver = local_solver or _default_local_solver
+    items, order, sizes_h = scatter_systems(systems)
+    recs, xs = solver(items, **kw)
+    del items
+    table = gather_records(recs, len(sizes_h))
+    if not gather_x:
+        return table
+    out_x = gather_solutions(xs, order, sizes_h)
+    return (table, out_x) if dist.get_rank() == 0 else table

@@ -2021,6 +2021,42 @@ def test_bench_script_control_flow_at_two_ranks(golden):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0.3 < rf["frac"] < 1.0 and rf["achieved"] > 0
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["us_per_launch"] * 1e-6) / 1e9) < 1.0
     assert "cpu_baseline" not in line and "extra" not in line
+    _check_scatter_gather_keys(line, systems=2, it=it, mode="specs")
+
+
+def _check_scatter_gather_keys(line, systems, it, mode):
+    """What `bench.py` reports at N > 1 about the path north_star describes: rank 0 scattered the batch over the
+    backend, every rank solved its share, the records were gathered -- times beside `value`, never inside it."""
+    assert line["backend"].startswith("gloo") and line["ranks"] == 2 and line["scatter_mode"] == mode
+    assert line["scatter_ms"] > 0 and line["gather_ms"] > 0
+    rec = line["gathered_records"]
+    assert rec["systems"] == systems and len(rec["iterations"]) == systems and set(rec["status"]) == {0}
+    assert abs(rec["iterations"][0] - it) == 0 and all(abs(v - it) <= 0.05 * it for v in rec["iterations"])   # system 0 is the golden one
+    assert rec["max_final_res"] < 1e-8
+    pr = line["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and all(r["iterations_per_s"] > 0 and 0.2 < r["roofline_frac"] < 1.0 for r in pr)
+    assert line["roofline"]["per_rank_frac"] == [r["roofline_frac"] for r in pr]
+    # `value` is the whole job over the slowest rank's clock: no rank alone is faster than the job, their sum is not slower
+    assert sum(r["iterations_per_s"] for r in pr) >= 0.999 * line["value"]
+
+
+def test_bench_script_scatters_real_arrays_at_two_ranks(golden):
+    """The same script with `--scatter arrays`: rank 0 holds every system's CSR arrays and right-hand side and sends each
+    owner its share as grouped point-to-point messages (the real-matrix path of batch.scatter_systems); the owners solve what
+    ARRIVED -- the gathered iteration counts prove the matrices and right-hand sides crossed intact."""
+    it = int(golden["pcg_poisson3d_64_jacobi/iters"])
+    line = _run_bench(["--steps", "1", "--warmup", "1", "--grid", "64", "--systems-per-gpu", "3", "--scatter", "arrays"])
+    assert line["n_gpus"] == 2 and line["config"]["systems_in_batch"] == 6
+    _check_scatter_gather_keys(line, systems=6, it=it, mode="arrays")
+
+
+def test_bench_script_config4_flag_at_two_ranks():
+    """`--config4` is BASELINE config 4 in one flag (256^3 systems, 8 per GPU, distinct b per system id): here with
+    --systems-per-gpu 1 and one step so that two ranks on one GPU finish in seconds; the shape of the line is what counts."""
+    line = _run_bench(["--config4", "--steps", "1", "--warmup", "0", "--systems-per-gpu", "1"])
+    assert line["config"]["dof"] == 256 ** 3 and line["config"]["workload"].startswith("poisson3d_256_jacobi")
+    assert line["config"]["batch"].startswith("BASELINE config 4") and line["gathered_records"]["systems"] == 2
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == 1740111876
 
 
 def test_bench_script_config4_shape_at_two_ranks(golden):
@@ -2034,6 +2070,7 @@ def test_bench_script_config4_shape_at_two_ranks(golden):
     # distinct right-hand sides per system (seed = global system id): counts differ by a few around the seed-0 one
     assert abs(total - 2 * 2 * 8 * it) < 0.05 * 2 * 2 * 8 * it, total
     assert "roofline" in line
+    _check_scatter_gather_keys(line, systems=16, it=it, mode="specs")
 
 
 def test_reordering_checks_its_input_pattern(D):

@@ -1,0 +1,174 @@
+"""BASELINE config 3 on genuinely unstructured matrices: a quadtree-refined finite-volume Laplacian (hanging nodes, holes,
+hexRef8 numbering) and a Delaunay graph Laplacian (deeppreconditioning_amd/meshes.py, restated in oracle/oracle.py).
+
+CPU part: the product's generators and the oracle's give the same bits; the matrices are what they claim to be (symmetric,
+positive diagonal / non-positive off-diagonals, irreducibly diagonally dominant, irregular degrees, triangles).
+GPU part (`-m gpu`): SpMV bit-exact, Jacobi / IC(0) caller's order / IC(0) multicolour PCG against oracle/pcg_oracle.c --
+counts equal, residual histories within north_star's 1e-10 -- at ~10K rows and at the ~1M rows config 3 names.
+"""
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import c_oracle as CO
+from oracle import oracle as O
+
+HIST_RTOL = 1e-10
+
+
+def _product_meshes():
+    import importlib.util
+    import pathlib
+    path = pathlib.Path(__file__).resolve().parent.parent / "deeppreconditioning_amd" / "meshes.py"
+    spec = importlib.util.spec_from_file_location("dpcg_meshes_under_test", path)       # (no torch / GPU needed for this file)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _same(A, B):
+    return (A.shape == B.shape and np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+            and np.array_equal(A.data, B.data))
+
+
+def test_mesh_generators_product_and_oracle_agree():
+    M = _product_meshes()
+    for numbering in ("foam", "random"):
+        assert _same(M.quadtree_fv_laplacian(72, 3, numbering=numbering), O.quadtree_fv_laplacian(72, 3, numbering=numbering))
+    assert _same(M.delaunay_laplacian(5000, 2), O.delaunay_laplacian(5000, 2))
+    assert not _same(O.quadtree_fv_laplacian(72, 3), O.quadtree_fv_laplacian(72, 4))
+
+
+@pytest.mark.parametrize("name,make", [("quadtree_foam", lambda: O.quadtree_fv_laplacian(80, 1)),
+                                       ("quadtree_random", lambda: O.quadtree_fv_laplacian(80, 1, numbering="random")),
+                                       ("delaunay", lambda: O.delaunay_laplacian(6000, 1))])
+def test_mesh_matrices_are_spd_m_matrices_with_irregular_structure(name, make):
+    A = make()
+    n = A.shape[0]
+    assert A.indices.dtype == np.int32 and A.has_sorted_indices and abs(A - A.T).max() == 0.0
+    d = A.diagonal()
+    off = A - sp.diags(d)
+    assert d.min() > 0 and off.data.max() < 0                                  # generate_data.py:71: positive diagonal, negative couplings
+    slack = d + np.asarray(off.sum(axis=1)).ravel()
+    assert slack.min() > -1e-12 * d.max() and (slack > 1e-9).sum() > 0          # weakly dominant everywhere, strictly on the boundary
+    assert sp.csgraph.connected_components(A, directed=False)[0] == 1           # irreducible -> positive definite
+    assert np.linalg.eigvalsh(A.toarray()).min() > 0 if n <= 7000 else True
+    deg = np.diff(A.indptr)
+    assert len(np.unique(deg)) >= 4                                             # irregular degree
+    T = (off != 0).astype(np.int32)
+    assert (T @ T).multiply(T).sum() > 0                                        # triangles in the graph
+    if name == "quadtree_foam":
+        r = np.repeat(np.arange(n), deg)
+        assert abs(r - A.indices).max() > n // 2                                # appended children: couplings across the whole numbering
+    # the oracle solves it: Jacobi PCG converges, IC(0) exists and preconditions better
+    b = O.rhs(n, 0)
+    _, it_j, hist, x = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A))
+    assert hist[-1] < 1e-8 and np.linalg.norm(b - A @ x) / np.linalg.norm(b) < 2e-4
+    _, it_c, _, _ = CO.pcg(A, b, "llt_solve", L=CO.ic0(A))
+    assert it_c < it_j
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _permuted(A, perm):
+    B = A[perm][:, perm].tocsr()
+    B.sort_indices()
+    return B
+
+
+@pytest.fixture(scope="module")
+def D():
+    import torch
+    import deeppreconditioning_amd as pkg
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    pkg._lib.lib()
+    return pkg
+
+
+def _mesh_parity(D, A, expect, max_iter):
+    n = A.shape[0]
+    b = O.rhs(n, 0)
+    S = D.CsrSystem.from_any(A)
+    info = S.info()
+    if expect.get("reordered") is not None:
+        assert S.reordered == expect["reordered"], info
+    if expect.get("kernel"):
+        assert info["spmv_kernel"] in expect["kernel"], info
+    perm = S.permutation() if S.reordered else np.arange(n)
+    B = _permuted(A, perm) if S.reordered else A
+    x = O.rhs(n, 7)
+    y = (S @ _dev(x)).cpu().numpy()
+    assert np.array_equal(y[perm], CO.spmv(B, x[perm]))                       # bit-exact on the matrix the handle iterates on
+    # Jacobi
+    S.set_preconditioner(D.Jacobi())
+    res = S.solve(_dev(b), max_iter=max_iter)
+    _, it, hist, xs = CO.pcg(B, b[perm], "jacobi", dinv=O.jacobi_dinv(B), max_iter=max_iter)
+    assert res.iterations == it
+    np.testing.assert_allclose(res.res_history, hist, rtol=HIST_RTOL)
+    np.testing.assert_allclose(res.x.cpu().numpy()[perm], xs, rtol=1e-7, atol=1e-10)
+    out = {"jacobi": it}
+    # IC(0) in the caller's order: the factor of the CALLER's matrix bit for bit, applied by triangular solves
+    S.set_preconditioner(D.IC0("solve"))
+    Lref = CO.ic0(A)
+    rp, ci, v = S.factor()
+    assert np.array_equal(rp, Lref.indptr) and np.array_equal(ci, Lref.indices) and np.array_equal(v, Lref.data)
+    zref = CO.sptrsv_upper(CO.transpose_csr(Lref), CO.sptrsv_lower(Lref, b))
+    assert np.array_equal(S.precond_apply(_dev(b)).cpu().numpy(), zref)
+    res = S.solve(_dev(b), max_iter=max_iter)
+    kw = dict(precond_perm=perm) if S.reordered else {}
+    _, it, hist, _ = CO.pcg(B, b[perm], "llt_solve", L=Lref, max_iter=max_iter, **kw)
+    assert res.iterations == it
+    np.testing.assert_allclose(res.res_history, hist, rtol=HIST_RTOL)
+    out["ic0_caller"] = (it, S.info()["levels_lower"])
+    # IC(0) in multicolour order: IC(0) of Q A Q^T bit for bit, PCG through orc_pcg_perm
+    S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+    nc, q = S.precond_ordering()
+    assert np.array_equal(np.sort(q), np.arange(n)) and 2 <= nc <= expect.get("max_colors", 12)
+    Lq = CO.ic0(_permuted(A, q))
+    rp, ci, v = S.factor()
+    assert np.array_equal(rp, Lq.indptr) and np.array_equal(ci, Lq.indices) and np.array_equal(v, Lq.data)
+    assert S.info()["levels_lower"] <= nc
+    zq = np.empty(n)
+    zq[q] = CO.sptrsv_upper(CO.transpose_csr(Lq), CO.sptrsv_lower(Lq, b[q]))
+    assert np.array_equal(S.precond_apply(_dev(b)).cpu().numpy(), zq)
+    qinv = np.empty(n, dtype=np.int32)
+    qinv[q] = np.arange(n, dtype=np.int32)
+    res = S.solve(_dev(b), max_iter=max_iter)
+    _, it, hist, _ = CO.pcg(B, b[perm], "llt_solve", L=Lq, precond_perm=qinv[perm], max_iter=max_iter)
+    assert res.iterations == it
+    np.testing.assert_allclose(res.res_history, hist, rtol=HIST_RTOL)
+    out["ic0_multicolor"] = (it, nc)
+    S.close()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make", [("quadtree_foam", lambda: O.quadtree_fv_laplacian(96, 2)),
+                                       ("quadtree_random", lambda: O.quadtree_fv_laplacian(96, 2, numbering="random")),
+                                       ("quadtree_foam_300", lambda: O.quadtree_fv_laplacian(300, 5)),
+                                       ("delaunay", lambda: O.delaunay_laplacian(12000, 2)),
+                                       ("delaunay_100k", lambda: O.delaunay_laplacian(100000, 3))])
+def test_unstructured_meshes_small(D, name, make):
+    """The launch forms below the 1M-DoF kernels (two-kernel updates, gather SpMV, LDS-ring / sync-free triangular solves) on the
+    same kinds of matrices."""
+    out = _mesh_parity(D, make(), {}, 1024)
+    assert out["ic0_caller"][0] < out["jacobi"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make,expect", [
+    ("quadtree_foam_1M", lambda: O.quadtree_fv_laplacian(1000, 0), {"max_colors": 8}),
+    ("quadtree_random_1M", lambda: O.quadtree_fv_laplacian(1000, 0, numbering="random"),
+     {"reordered": True, "kernel": ("tile",), "max_colors": 8}),
+    ("delaunay_1M", lambda: O.delaunay_laplacian(1000000, 0), {"reordered": True, "kernel": ("tile",), "max_colors": 9})])
+def test_config3_unstructured_meshes_million_dof(D, name, make, expect):
+    """BASELINE config 3 ("OpenFOAM interFoam pressure-correction matrix, ~1M DoF, unstructured CSR") on matrices with irregular
+    degree, triangles and no grid structure: the plain call (the library reorders a scattered numbering by itself and plans the
+    x-tile SpMV on the result), 300 updates each of Jacobi, IC(0) in the caller's order (level-scheduled L / L^T solves) and IC(0)
+    in multicolour order against the C oracle on the system the handle iterates on -- counts equal, histories within 1e-10."""
+    _mesh_parity(D, make(), expect, 300)
