@@ -66,6 +66,8 @@ inline void dev_free(T *&p) {
 }
 
 void free_csr(CsrDev &c);
+// dpcg_icholt.hip: ILU++-style thresholded incomplete Cholesky of a symmetric CSR matrix into an owned lower-triangular CSR
+int icholt_factor(const CsrDev &A, int add_fill_in, double threshold, CsrDev &Lf, hipStream_t s);
 void free_parked(dpcg_system *h);                       // dpcg_api.hip: the multicolour IC(0) parked by dpcg_update_values
 void free_levels(Levels &l);
 int count_levels_on_demand(dpcg_system *h);   // dpcg_precond.hip

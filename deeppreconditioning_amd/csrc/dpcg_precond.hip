@@ -1383,6 +1383,27 @@ extern "C" int dpcg_set_precond_ict(dpcg_handle_t h, int mode, int fill_in, doub
     return st;
 }
 
+// ilupp.icholt as ILU++ defines it (contract: oracle/oracle.py::icholt; device routine: dpcg_icholt.hip).  Like IC(0) / ICT it
+// factors the CALLER's matrix and leaves the previous preconditioner in place when it fails.
+extern "C" int dpcg_set_precond_icholt(dpcg_handle_t h, int mode, int add_fill_in, double threshold, dpcg_stream_t stream) {
+    if (!h) return invalid("NULL handle");
+    if (mode != DPCG_PRECOND_LLT_MULTIPLY && mode != DPCG_PRECOND_LLT_SOLVE) return invalid("bad LLT mode");
+    if (add_fill_in < 0 || !(threshold >= 0.0)) return invalid("dpcg_set_precond_icholt: add_fill_in >= 0 and threshold >= 0");
+    hipStream_t s = (hipStream_t)stream;
+    SetupScope scope(s, true);          // (the preconditioner being replaced may be in use on another stream)
+    const CsrDev &Asrc = h->perm ? h->A_user : h->A;
+    PhaseTimer pt(s);
+    CsrDev Lf;
+    int st = icholt_factor(Asrc, add_fill_in, threshold, Lf, s);
+    if (st < 0) return st;
+    pt.mark("icholt: columns");
+    free_precond(h);
+    h->L = Lf;
+    st = finish_llt(h, mode, s);
+    if (st < 0) free_precond(h);
+    return st;
+}
+
 extern "C" int dpcg_get_factor(dpcg_handle_t h, int32_t *rowptr, int32_t *col, double *val) {
     if (!h) return invalid("NULL handle");
     if (h->precond != DPCG_PRECOND_LLT_MULTIPLY && h->precond != DPCG_PRECOND_LLT_SOLVE) {

@@ -246,12 +246,35 @@ class IC0(Preconditioner):
         raise TypeError("IC0 needs the system matrix: attach it with CsrSystem.set_preconditioner")
 
 
+class ICholT(Preconditioner):
+    """`ilupp.icholt(A, add_fill_in, threshold)` -- what the reference's harness runs by default, with `add_fill_in=1,
+    threshold=0.1` (test.py:81-88) -- factored on the device the way ILU++ defines it (Saad's dual-threshold rule on the lower
+    triangle): per column the candidates below threshold * ||column||_2 are dropped and of the rest the
+    nnz(A[k+1:, k]) + add_fill_in largest are kept.  The ilupp binary is not available: the factor equals the restatement of
+    the published algorithm (oracle/oracle.py::icholt) bit for bit, PARITY UNPINNED against ilupp's own output.
+    mode="multiply" is the reference's use (it multiplies by L L^T, test.py:88), mode="solve" applies the factor by triangular
+    solves.  See dpcg_set_precond_icholt in include/dpcg.h for the limits (64 kept entries per row / column)."""
+
+    def __init__(self, mode: str = "multiply", add_fill_in: int = 1, threshold: float = 0.1):
+        if mode not in ("solve", "multiply"):
+            raise ValueError("mode must be 'solve' or 'multiply'")
+        if add_fill_in < 0 or not threshold >= 0:
+            raise ValueError("add_fill_in >= 0 and threshold >= 0")
+        self.mode = L.PRECOND_LLT_SOLVE if mode == "solve" else L.PRECOND_LLT_MULTIPLY
+        self.add_fill_in, self.threshold = int(add_fill_in), float(threshold)
+
+    def _attach(self, system):
+        L.check(L.lib().dpcg_set_precond_icholt(system._h, self.mode, self.add_fill_in, self.threshold, _stream()))
+
+    def __matmul__(self, r):
+        raise TypeError("ICholT needs the system matrix: attach it with CsrSystem.set_preconditioner")
+
+
 class ICT(Preconditioner):
-    """Thresholded incomplete Cholesky with level-1 fill computed at setup: what the reference's harness runs by default,
-    `ilupp.icholt(A, add_fill_in=1, threshold=0.1)` (test.py:81-88).  ilupp is not available: the factor follows the
-    contract of oracle/oracle.py::ict (level-1 fill, MATLAB's 'ict' drop rule), PARITY UNPINNED against ilupp itself.
-    mode="multiply" is the reference's use (it multiplies by L L^T, test.py:88), mode="solve" applies the factor by
-    triangular solves."""
+    """Thresholded incomplete Cholesky on a STATIC pattern -- tril(A) plus level-1 fill -- with MATLAB's 'ict' drop rule
+    (contract: oracle/oracle.py::ict).  Not what `ilupp.icholt` computes (that is `ICholT`: a per-column entry count instead
+    of a fill level); kept because a pattern known before the values lets the factorisation run level-parallel at any size.
+    mode="multiply" multiplies by L L^T, mode="solve" applies the factor by triangular solves."""
 
     def __init__(self, mode: str = "multiply", fill_in: int = 1, threshold: float = 0.1):
         if mode not in ("solve", "multiply"):

@@ -260,3 +260,34 @@ def test_config2_learned_like_preconditioning_factor(golden):
     _check(golden, name, it, hist)
     _, it, hist, _ = CO.pcg(A, b, "llt_multiply", L=L)
     _check(golden, name, it, hist)
+
+
+def test_icholt_restates_the_dual_threshold_rule():
+    """oracle.icholt = ilupp.icholt as ILU++ describes it (test.py:81-88's default technique; the binary is absent, so this
+    pins the restatement to the PROPERTIES of the published algorithm): with no bound on the entries and no threshold it is the
+    exact Cholesky factor; a column keeps at most nnz(A[k+1:, k]) + add_fill_in off-diagonal entries; what is kept is never
+    smaller than what was dropped of the same column by count; every kept entry passes the threshold relative to its
+    column's norm; raising add_fill_in or lowering the threshold makes L L^T approach A and PCG converge faster."""
+    A = O.poisson2d(9)
+    n = A.shape[0]
+    L = O.icholt(A, add_fill_in=n, threshold=0.0, cand_cap=10 ** 6, row_cap=10 ** 6)
+    np.testing.assert_allclose(L.toarray(), np.linalg.cholesky(A.toarray()), rtol=0, atol=5e-16)
+    A = O.unstructured_like(O.poisson2d(30), seed=3)
+    n = A.shape[0]
+    b = O.rhs(n, 0)
+    below = np.bincount(sp.tril(A, -1).tocoo().col, minlength=n)
+    prev_err, prev_it = np.inf, 10 ** 9
+    for fill, thr in ((0, 0.3), (1, 0.1), (2, 0.01), (6, 0.0)):
+        L = O.icholt(A, fill, thr)
+        assert (L.diagonal() > 0).all() and sp.triu(L, 1).nnz == 0 and L.has_sorted_indices
+        C = sp.tril(L, -1).tocsc()
+        assert (np.diff(C.indptr) <= below + fill).all()
+        err = sp.linalg.norm(L @ L.T - A)
+        it = CO.pcg(A, b, "llt_solve", L=L)[1]
+        assert err < prev_err and it <= prev_it
+        prev_err, prev_it = err, it
+    # the threshold is relative to the column: a column scaled up keeps the same pattern
+    L1 = O.icholt(A, 1, 0.1)
+    assert L1.nnz < O.icholt(A, 1, 0.0).nnz                          # the threshold does drop entries here
+    with pytest.raises(ValueError):
+        O.icholt(sp.csr_matrix(np.array([[1.0, 2.0], [2.0, 1.0]])), 0, 0.0)        # indefinite: breakdown
