@@ -501,7 +501,7 @@ static int ensure_team(dpcg_system *h, hipStream_t s) {
         DPCG_TRY(dev_alloc(&h->p2, h->A.n));
         drop_graph(h);
     }
-    if (!h->team_part) DPCG_TRY(dev_alloc(&h->team_part, 3 * 2 * 32));
+    if (!h->team_part) DPCG_TRY(dev_alloc(&h->team_part, 4 * 2 * 32));
     if (!h->team_sync) DPCG_TRY(dev_alloc(&h->team_sync, 2));
     return DPCG_OK;
 }
@@ -548,7 +548,7 @@ static int solve_team_one(dpcg_system *h, const double *b, const double *x0, dou
     const TeamDesc d = make_team_desc(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags);
     DPCG_HIP(hipMemcpyAsync(h->team_desc, &d, sizeof(d), hipMemcpyHostToDevice, s));
     DPCG_HIP(hipMemsetAsync(h->team_sync, 0, 2 * sizeof(unsigned int), s));
-    launch_fill_pending(h->team_part, 3 * 2 * 32, s);                                // every reduction slot: "not written yet"
+    launch_fill_pending(h->team_part, 4 * 2 * 32, s);                                // every reduction slot: "not written yet"
     DPCG_HIP(hipStreamSynchronize(s));
     // one team launch at a time per process: the workgroups of a team wait for each other, and two such launches dispatched at
     // once from two host threads could each hold part of the chip waiting for the rest of it (the 4 s bound would end that)
@@ -593,9 +593,12 @@ extern "C" int dpcg_solve(dpcg_handle_t h, const double *b, const double *x0, do
     if (small_eligible(h, flags, x_true))
         return solve_small_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
                                seconds, res_history);
-    if ((flags & DPCG_TEAM) && team_eligible(h, flags, x_true))      // a single team: on request only (it trails the multi-launch path)
-        return solve_team_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
-                              seconds, res_history);
+    if ((flags & DPCG_TEAM) && team_eligible(h, flags, x_true)) {    // a single team: on request only (it trails the multi-launch path)
+        const int st = solve_team_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
+                                      seconds, res_history);
+        if (st != DPCG_ERR_STATE) return st;
+        // the team never became co-resident (a plain launch assumes it): the multi-launch path below needs no such thing
+    }
     Solve sv;
     sv.h = h;
     sv.s = (hipStream_t)stream;
@@ -646,9 +649,9 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
             SmallDesc *descs = nullptr;
             Scalars *out = nullptr;
             int cap = 0;
-            ~BatchScratch() {
-                if (descs) (void)device_free(descs);
-                if (out) (void)device_free(out);
+            ~BatchScratch() {          // (allocated through the block cache: freed through it)
+                dev_free(descs);
+                dev_free(out);
             }
         };
         static thread_local BatchScratch scratch;
@@ -687,12 +690,14 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
         // up to eight systems per launch, one team (normally: one XCD) each; the launches follow one another
         struct TeamScratch {
             TeamDesc *descs = nullptr;
-            ~TeamScratch() { if (descs) (void)device_free(descs); }
+            ~TeamScratch() { dev_free(descs); }
         };
         static thread_local TeamScratch scratch;
         if (!scratch.descs) DPCG_TRY(dev_alloc(&scratch.descs, 8));
         int worst_team = DPCG_OK;
-        for (int g0 = 0; g0 < count; g0 += 8) {
+        bool team_timed_out = false;       // a team waited in vain for its members (the chip shared with another process, a long kernel
+                                           // holding CUs: the launch is a plain one, co-residency is assumed, not guaranteed)
+        for (int g0 = 0; g0 < count && !team_timed_out; g0 += 8) {
             const int ng = std::min(8, count - g0);
             TeamDesc descs[8];
             int slabs = 1, wmax = 1;
@@ -703,7 +708,7 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
                 descs[i] = make_team_desc(hi, b[g0 + i], x0 ? x0[g0 + i] : nullptr, x ? x[g0 + i] : nullptr, rtol_sq, atol_sq,
                                           max_iter, flags);
                 DPCG_HIP(hipMemsetAsync(hi->team_sync, 0, 2 * sizeof(unsigned int), nullptr));
-                launch_fill_pending(hi->team_part, 3 * 2 * 32, nullptr);
+                launch_fill_pending(hi->team_part, 4 * 2 * 32, nullptr);
                 slabs = std::max(slabs, team_slabs_per_wg(hi->A.n));
                 wmax = std::max(wmax, hi->ell_a.W);
             }
@@ -719,8 +724,8 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
                 DPCG_HIP(hipMemcpy(hi->scal_host, hi->scal, sizeof(Scalars), hipMemcpyDeviceToHost));
                 const Scalars sc = *hi->scal_host;
                 if (sc.status < 0) {
-                    set_error("team solve: a workgroup waited (4 s) for a team member that never arrived");
-                    return sc.status;
+                    team_timed_out = true;
+                    break;
                 }
                 if (iters) iters[g0 + i] = sc.k;
                 if (final_res) final_res[g0 + i] = sc.res;
@@ -729,7 +734,14 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
                 worst_team = std::max(worst_team, sc.status);
             }
         }
-        return worst_team;
+        if (!team_timed_out) return worst_team;
+        // not an error: the whole batch runs again through the multi-launch path below, which needs no co-residency
+        static bool warned = false;
+        if (!warned) {
+            warned = true;
+            fprintf(stderr, "[dpcg] team solve: a workgroup waited 4 s for a team member that never became resident; "
+                            "the batch is solved through the multi-launch path instead\n");
+        }
     }
     std::vector<hipStream_t> streams((size_t)n_streams, nullptr);
     for (auto &st : streams) DPCG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));

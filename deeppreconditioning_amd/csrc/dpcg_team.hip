@@ -153,18 +153,24 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
     // Two team-wide sums at once, and a team barrier in the same breath.  The 2 x 32 partials ARE the flags: a slot holds a
     // reserved NaN pattern until its owner stores the value (one 8-byte agent-scope store), and the readers -- lanes 0-63 of
     // wave 0, one slot each -- poll the slots themselves: no counter, no atomic, no second round trip to fetch the values.
-    // Three slot sets rotate (generation g uses set g % 3; writing generation g a workgroup re-arms its slots of set (g + 1) % 3,
-    // which everybody finished reading before anybody could write generation g - 1).  `publish`: the workgroup's stores of z and p
-    // must be visible to whoever passes this point, so every wave drains them first.  Every workgroup returns the same bits.
+    // FOUR slot sets rotate: generation g uses set g % 4 and, writing it, a workgroup re-arms its slots of set (g + 2) % 4 --
+    // last used by generation g - 2, which everybody finished reading before anybody could write generation g - 1 -- i.e. TWO
+    // generations ahead of their next use, and the publishing lane drains its earlier stores before it stores a value: whoever
+    // has seen this workgroup's generation-g value knows that its re-arm of set (g + 1) % 4 (issued at generation g - 1) has
+    // landed, so a reader that moves on to generation g + 1 cannot find a stale, non-pending value there.  (With three sets the
+    // re-arm of the NEXT set and the current value were two unordered stores to different addresses -- other channel, other XCD:
+    // a reader could have summed the value of three generations ago into alpha / beta.)  `publish`: the workgroup's stores of z
+    // and p must be visible to whoever passes this point, so every wave drains them first.  Every workgroup returns the same bits.
     unsigned int gen = 0;
     auto team_sum2 = [&](double a, double b2, bool publish, double &ra, double &rb) -> bool {
         if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         a = team_block_sum(a, sh);                                 // (two workgroup barriers inside: behind every wave's drain)
         b2 = team_block_sum(b2, sh);
         const double pend = __longlong_as_double((long long)kTeamPending);
-        double *cur = d.part + (gen % 3) * (2 * kTeamSize), *nxt = d.part + ((gen + 1) % 3) * (2 * kTeamSize);
+        double *cur = d.part + (gen & 3) * (2 * kTeamSize), *nxt = d.part + ((gen + 2) & 3) * (2 * kTeamSize);
         ++gen;
         if (t == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the re-arm stores of the previous generation have landed
             st_agent(nxt + rank, pend);
             st_agent(nxt + kTeamSize + rank, pend);
             st_agent(cur + rank, a);

@@ -1734,10 +1734,11 @@ def test_icholt_as_ilupp_defines_it(D):
     A = O.poisson2d(10).tolil()
     A[37, 37] = -1.0
     S = D.CsrSystem.from_any(A.tocsr())
-    S.set_preconditioner(D.Jacobi())
+    S.set_preconditioner(None)
     with pytest.raises(DpcgError) as ei:
         S.set_preconditioner(D.ICholT("solve"))
     assert ei.value.status == ERR_PIVOT and "37" in str(ei.value)
+    assert S.info()["precond"] == D._lib.PRECOND_NONE                    # the previous preconditioner (none) is still in place
     S.close()
     with pytest.raises(ValueError):
         D.ICholT("solve", add_fill_in=-1)

@@ -86,6 +86,53 @@ __global__ __launch_bounds__(256) void k_streams(int64_t n2, const d2 *__restric
     if (!W && acc == 12345.678) part[blockIdx.x] = acc;
 }
 
+// ---- the guide's shape (MI355X_MICROARCH.md: "6.29 TB/s measured (float4 copy)"): 16 B per lane, no slabs --------------------
+// flat: one element per thread, one workgroup per 4 KiB (grid = n / BS).  stride: a persistent grid whose workgroups walk the
+// buffer TOGETHER (element i of pass p at p * G * BS * U + ...): at any instant the chip reads one contiguous window instead
+// of G distant slabs -- fewer DRAM pages open at once.
+template <int BS, bool NT>
+__global__ __launch_bounds__(BS) void k_copy_flat(int64_t n2, const d2 *__restrict__ in, d2 *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    if (i < n2) {
+        const d2 t = NT ? __builtin_nontemporal_load(in + i) : in[i];
+        if (NT) __builtin_nontemporal_store(t, out + i);
+        else out[i] = t;
+    }
+}
+template <int BS, int U, int R, bool W, bool NT>
+__global__ __launch_bounds__(BS) void k_copy_stride(int64_t n2, const d2 *__restrict__ in, d2 *__restrict__ out, double *part) {
+    const int64_t span = (int64_t)gridDim.x * BS * U;
+    double acc = 0.0;
+    for (int64_t i0 = (int64_t)blockIdx.x * BS * U; i0 < n2; i0 += span) {
+        d2 a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int64_t i = i0 + u * BS + threadIdx.x;
+            i = i < n2 ? i : n2 - 1;
+            d2 sacc = {0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const d2 *p = in + ((i0 + u * BS) * R + (int64_t)r * BS + threadIdx.x);
+                sacc += NT ? __builtin_nontemporal_load(p) : *p;
+            }
+            a[u] = sacc;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * BS + threadIdx.x;
+            if (W) {
+                if (i < n2) {
+                    if (NT) __builtin_nontemporal_store(a[u], out + i);
+                    else out[i] = a[u];
+                }
+            } else {
+                acc += a[u].x + a[u].y;
+            }
+        }
+    }
+    if (!W && acc == 12345.678) part[blockIdx.x] = acc;
+}
+
 int main() {
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -120,6 +167,31 @@ int main() {
         timeit(name, (double)(N2) * 16 * (R + (W ? 1 : 0)),                                                                \
                [&] { hipLaunchKernelGGL((k_streams<R, U, W>), dim3(G), dim3(256), 0, s, (int64_t)(N2), in, out, part); }); \
     } while (0)
+    // ---- the guide's float4-copy shapes first (1 GiB in, 1 GiB out) ----
+    {
+        const int64_t N2 = n2 * 8;
+#define FLAT(BS, NT)                                                                                                       \
+    do {                                                                                                                   \
+        snprintf(name, sizeof name, "flat copy BS=%d nt=%d (one 16 B element per thread)", BS, NT);                         \
+        timeit(name, (double)N2 * 32, [&] { hipLaunchKernelGGL((k_copy_flat<BS, NT>), dim3((unsigned)((N2 + BS - 1) / BS)), dim3(BS), 0, s, N2, in, out); }); \
+    } while (0)
+#define STRIDE(BS, U, R, W, NT, G, NN)                                                                                     \
+    do {                                                                                                                   \
+        snprintf(name, sizeof name, "grid-stride R=%d write=%d BS=%d U=%d nt=%d grid=%d", R, W, BS, U, NT, G);              \
+        timeit(name, (double)(NN) * 16 * (R + (W ? 1 : 0)),                                                                 \
+               [&] { hipLaunchKernelGGL((k_copy_stride<BS, U, R, W, NT>), dim3(G), dim3(BS), 0, s, (int64_t)(NN), in, out, part); }); \
+    } while (0)
+        FLAT(256, false); FLAT(512, false); FLAT(1024, false); FLAT(256, true);
+        for (int g : {1024, 2048, 4096, 8192}) { STRIDE(256, 1, 1, true, false, g, N2); STRIDE(256, 2, 1, true, false, g, N2); STRIDE(256, 4, 1, true, false, g, N2); }
+        STRIDE(512, 2, 1, true, false, 1024, N2); STRIDE(1024, 1, 1, true, false, 512, N2); STRIDE(1024, 2, 1, true, false, 1024, N2);
+        STRIDE(256, 2, 1, true, true, 2048, N2); STRIDE(256, 4, 1, true, true, 4096, N2);
+        snprintf(name, sizeof name, "hipMemcpyAsync device-to-device");
+        timeit(name, (double)N2 * 32, [&] { CK(hipMemcpyAsync(out, in, (size_t)N2 * 16, hipMemcpyDeviceToDevice, s)); });
+        // the SpMV's ratio, walked together instead of in slabs
+        for (int g : {1536, 2048, 4096}) { STRIDE(256, 1, 11, true, false, g, n2); STRIDE(256, 2, 11, true, false, g, n2); }
+        STRIDE(256, 1, 11, true, true, 2048, n2); STRIDE(256, 2, 11, true, true, 2048, n2);
+        for (int g : {2048, 4096}) { STRIDE(256, 2, 2, true, false, g, n2 * 4); STRIDE(256, 4, 4, false, false, g, n2 * 3); }
+    }
     // copy (1 GiB in, 1 GiB out)
     for (int g : {1024, 2048, 4096, 8192}) { RATIO(1, 2, true, false, g, n2 * 8); RATIO(1, 4, true, false, g, n2 * 8); }
     RATIO(1, 4, true, true, 2048, n2 * 8);
