@@ -425,6 +425,64 @@ def main() -> None:
         dist.destroy_process_group()
 
 
+def mesh_workloads(D, poisson, torch, solve_twice, pmc_all) -> dict:
+    """BASELINE config 3 on GENUINELY unstructured matrices (deeppreconditioning_amd/meshes.py): a quadtree-refined finite-volume
+    Laplacian with hanging nodes and holes -- in OpenFOAM's own numbering (hexRef8: children appended) and in a random one -- and the
+    Laplacian of a Delaunay triangulation of 1M random points.  Per system through the PLAIN call: kernel chosen, gather ratio of the
+    caller's numbering, SpMV roofline and PMC traffic, Jacobi / IC(0) in multicolour order to the solution (reference defaults: they
+    stop at max_iter = 1024 on these 2-D meshes unless they converge), IC(0) in the caller's order per update."""
+    from deeppreconditioning_amd import meshes
+    out = {}
+    for name, make in (("quadtree_foam", lambda: meshes.quadtree_fv_laplacian(1000, 0)),
+                       ("quadtree_random", lambda: meshes.quadtree_fv_laplacian(1000, 0, numbering="random")),
+                       ("delaunay", lambda: meshes.delaunay_laplacian(1000000, 0))):
+        A = make()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        S = D.CsrSystem.from_any(A)
+        torch.cuda.synchronize()
+        create_ms = (time.perf_counter() - t0) * 1e3
+        info = S.info()
+        b = poisson.rhs(S.n, 0)
+        deg = np.diff(A.indptr)
+        S.set_preconditioner(D.Jacobi())
+        ms = S.spmv_dot_bench(200)
+        b_alg = loop_kernel_bytes(S)
+        gbs = b_alg / (ms * 1e-3) / 1e9
+        tr = pmc_all.get(f"spmv_mesh_{name}")
+        e = {"dof": S.n, "nnz": S.nnz, "row_lengths": [int(deg.min()), int(deg.max())], "create_incl_upload_and_reordering_ms": round(create_ms, 1),
+             "reordered": info["reordered"], "gather_ratio_before": round(info["gather_ratio"], 2), "spmv_kernel": info["spmv_kernel"],
+             "spmv_roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                               "algorithmic_bytes_per_launch": b_alg, "us_per_launch": round(ms * 1e3, 2),
+                               "traffic": tr["bytes"] if tr else None, "traffic_over_algorithmic": tr["ratio"] if tr else None,
+                               "traffic_source": "profiles/r04_mesh_spmv_traffic.md (rocprofv3 --pmc passes of tools/pmc_mesh_run.py)"}}
+        r = solve_twice(S, b)
+        e["jacobi"] = {"iterations": r.iterations, "status": r.status, "final_res": r.final_res, "ms": round(r.seconds * 1e3, 3),
+                       "us_per_update": round(r.seconds / max(r.iterations, 1) * 1e6, 1), "iterations_per_s": round(r.iterations / r.seconds, 1)}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+        torch.cuda.synchronize()
+        setup_ms = (time.perf_counter() - t0) * 1e3
+        r = solve_twice(S, b)
+        e["ic0_multicolor_solve"] = {"colors": S.precond_ordering()[0], "levels": S.info()["levels_lower"], "setup_new_pattern_ms": round(setup_ms, 2),
+                                     "iterations": r.iterations, "status": r.status, "final_res": r.final_res, "ms": round(r.seconds * 1e3, 3),
+                                     "us_per_update": round(r.seconds / max(r.iterations, 1) * 1e6, 1)}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        S.set_preconditioner(D.IC0("solve"))
+        torch.cuda.synchronize()
+        setup_ms = (time.perf_counter() - t0) * 1e3
+        S.solve(b, max_iter=20, want_history=False)
+        r = S.solve(b, max_iter=40, want_history=False)      # (per update only: 2 000 levels in OpenFOAM's numbering cost milliseconds each)
+        e["ic0_solve"] = {"levels": S.info()["levels_lower"], "setup_ms": round(setup_ms, 2), "updates_timed": r.iterations,
+                          "us_per_update": round(r.seconds / max(r.iterations, 1) * 1e6, 1)}
+        out[f"c3_mesh_{name}"] = e
+        S.close()
+        del S, A
+    return out
+
+
 def extra_workloads(D, poisson, torch) -> dict:
     """Secondary numbers (not the headline), one entry per BASELINE.json config that fits one GPU."""
     out = {}
@@ -512,7 +570,25 @@ def extra_workloads(D, poisson, torch) -> dict:
             net(inp)
         torch.cuda.synchronize()
         fwd_cached_ms = (time.perf_counter() - t0) / 5 * 1e3
-    c2["learned_random_weights_llt_multiply"] = {"iterations": r.iterations, "status": r.status, "ms": round(r.seconds * 1e3, 3),
+    # the forward against ITS roofline: fp32 matrix cores (v_mfma_f32_16x16x4_f32: 155 TFLOP/s dense, MI355X_MICROARCH.md) and, beside
+    # it, the minimum bytes through HBM; timed with events on the stream the forward is enqueued on (torch's current stream)
+    with torch.no_grad():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            net(inp)
+        e1.record()
+        torch.cuda.synchronize()
+    fwd_ev_ms = e0.elapsed_time(e1) / 20
+    cost = mdl.forward_cost(net, inp)
+    forward_roofline = {"bound": "mfma", "achieved": round(cost["flops"] / fwd_ev_ms / 1e9, 2), "peak": 155.0, "unit": "TFLOP/s",
+                        "frac": round(cost["flops"] / fwd_ev_ms / 1e9 / 155.0, 4), "dtype": "f32 (exact fp32 MFMA, no xf32 on gfx950)",
+                        "ms_per_forward": round(fwd_ev_ms, 4), "flops_per_forward": cost["flops"],
+                        "min_hbm_bytes_per_forward": cost["min_hbm_bytes"],
+                        "hbm_frac_at_min_bytes": round(cost["min_hbm_bytes"] / (fwd_ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "layers": cost["layers"],
+                        "kernel_trace": "profiles/r04_cnn_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/trace_run_cnn.py)"}
+    c2["learned_random_weights_llt_multiply"] = {"forward_roofline": forward_roofline, "iterations": r.iterations, "status": r.status, "ms": round(r.seconds * 1e3, 3),
                                                  "iterations_per_s": round(r.iterations / r.seconds, 1),
                                                  "nnz_L": int(Lparts[1].numel()),
                                                  "cnn_forward_ms": round(fwd_ms, 3), "cnn_forward_plan_cached_ms": round(fwd_cached_ms, 3),
@@ -661,6 +737,7 @@ def extra_workloads(D, poisson, torch) -> dict:
     c3["not_reordered"]["ic0_solve_us_per_update"] = round(r.seconds / r.iterations * 1e6, 1)
     out["c3_unstructured3d_100"] = c3
     del s3, s3n, A
+    out.update(mesh_workloads(D, poisson, torch, solve_twice, pmc_all))
     # config 5: mixed fp32 SpMV / fp64 everything else on the headline system
     s5 = poisson.poisson_system(3, 100)
     s5.set_preconditioner(D.Jacobi())

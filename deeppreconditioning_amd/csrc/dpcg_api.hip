@@ -223,9 +223,17 @@ int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s, bool allow_tile) {
                 // (DPCG_SPMV_NT=0/1 overrides: development knob)
                 static const int nt_knob = [] { const char *e = getenv("DPCG_SPMV_NT"); return e ? atoi(e) : -1; }();
                 plan.stream_nt = nt_knob >= 0 ? nt_knob != 0 : stream_bytes >= 512e6;
+                // ... and walked by the whole grid together (row blocks dealt out cyclically) instead of in slabs
+                // (DPCG_SPMV_CYCLIC=0/1 overrides: development knob)
+                static const int cyc_knob = [] { const char *e = getenv("DPCG_SPMV_CYCLIC"); return e ? atoi(e) : -1; }();
+                plan.cyclic = cyc_knob >= 0 ? cyc_knob != 0 : plan.stream_nt;
                 const size_t lds = (size_t)(h_flags[1] * kTileChunk + kStreamCap + 8) * sizeof(double);
-                static const int wg_knob = [] { const char *e = getenv("DPCG_SPMV_WG_PER_CU"); return e ? atoi(e) : 8; }();   // development
-                const int per_cu = (int)std::min<size_t>((size_t)(wg_knob < 1 ? 1 : wg_knob), (160 * 1024) / lds);
+                // (cyclic: THREE workgroups per CU -- with the grid walking together, each workgroup's own one-block-ahead prefetch
+                // carries the latency, and fewer workgroups keep the window the chip reads at any instant narrow; 256^3, us per
+                // launch at 2 / 3 / 4 / 5 / 6 / 8 per CU: 299 / 272 / 284 / 292 / 293 / 294, slabs at 6: 298 -- profiles/r04_spmv_cyclic_ab.txt)
+                static const int wg_knob = [] { const char *e = getenv("DPCG_SPMV_WG_PER_CU"); return e ? atoi(e) : 0; }();   // development
+                const int want = wg_knob >= 1 ? wg_knob : (plan.cyclic ? 3 : 8);
+                const int per_cu = (int)std::min<size_t>((size_t)want, (160 * 1024) / lds);
                 cap = std::min(cap, per_cu * 256);
             } else {
                 dev_free(plan.tile_chunks);

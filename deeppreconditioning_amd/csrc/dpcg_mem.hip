@@ -27,15 +27,40 @@ std::shared_mutex &capture_lock() {
 }
 }  // namespace
 
-CaptureGuard::CaptureGuard() { capture_lock().lock_shared(); }
-CaptureGuard::~CaptureGuard() { capture_lock().unlock_shared(); }
+namespace {
+// The lock is not recursive: a device-wide wait or a hipFree issued by the thread that holds a CaptureGuard would wait for itself.
+// Nothing inside a capture allocates or frees today; should that change, the wait is refused (it would void the capture anyway)
+// and the free is deferred to the end of the capture instead of deadlocking.
+thread_local int tl_capture_depth = 0;
+thread_local std::vector<void *> *tl_deferred_frees = nullptr;
+}  // namespace
+
+CaptureGuard::CaptureGuard() {
+    if (tl_capture_depth++ == 0) capture_lock().lock_shared();
+}
+CaptureGuard::~CaptureGuard() {
+    if (--tl_capture_depth != 0) return;
+    capture_lock().unlock_shared();
+    if (tl_deferred_frees) {
+        std::vector<void *> *list = tl_deferred_frees;
+        tl_deferred_frees = nullptr;
+        for (void *p : *list) (void)device_free(p);
+        delete list;
+    }
+}
 
 hipError_t device_wide_wait() {
+    if (tl_capture_depth > 0) return hipErrorStreamCaptureUnsupported;
     std::unique_lock<std::shared_mutex> lock(capture_lock());
     return hipDeviceSynchronize();
 }
 
 hipError_t device_free(void *p) {
+    if (tl_capture_depth > 0) {
+        if (!tl_deferred_frees) tl_deferred_frees = new std::vector<void *>();
+        tl_deferred_frees->push_back(p);
+        return hipSuccess;
+    }
     std::unique_lock<std::shared_mutex> lock(capture_lock());
     return hipFree(p);
 }

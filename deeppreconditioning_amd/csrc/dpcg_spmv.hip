@@ -372,16 +372,26 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
                                                       const int32_t *__restrict__ nchunks,
                                                       const XV *__restrict__ x, const double *__restrict__ xdot,
                                                       double *__restrict__ y, int nrb, int tile_doubles,
-                                                      double *__restrict__ part_pq, IterCtlDev ctl, int64_t nnz) {
+                                                      double *__restrict__ part_pq, IterCtlDev ctl, int64_t nnz, int cyclic) {
     constexpr int U = kStreamCap / kBlock;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     XV *xs = reinterpret_cast<XV *>(smem);  // the staged x chunks of this block (tile_doubles slots reserved)
     double *prod = smem + tile_doubles;     // products, kStreamCap + 4 doubles
     double *sh = prod + kStreamCap + 4;     // 4 doubles for the block reduction
     const int t = threadIdx.x;
-    const int v = virtual_block();
-    int rb_lo, rb_hi;
-    split_range(nrb, v, rb_lo, rb_hi);
+    // Which row blocks a workgroup takes.  Slabs (cache-resident systems): workgroup v owns one contiguous range, the slabs of an
+    // XCD are neighbours, so the x halo of neighbouring row blocks is shared in that XCD's L2.  Cyclic (`cyclic` != 0: streams
+    // from HBM): row block b, b + G, b + 2 G, ... -- the whole grid walks the matrix TOGETHER, so at any instant the chip reads one
+    // contiguous window of the streams instead of G distant slabs (fewer DRAM pages open at once: tools/stream_lab, an 11 : 1
+    // stream 5.3 -> 5.6 TB/s, non-temporal 5.4 -> 6.0); row blocks a plane apart still meet in one XCD when G is a multiple of 8.
+    int rb_lo, rb_hi, rb_step = 1;
+    if (cyclic) {
+        rb_lo = blockIdx.x;
+        rb_hi = nrb;
+        rb_step = gridDim.x;
+    } else {
+        split_range(nrb, virtual_block(), rb_lo, rb_hi);
+    }
     constexpr int G = 16 / sizeof(VT);      // consecutive non-zeros per 16-byte value load: 2 (fp64) or 4 (fp32)
     constexpr int UP = U / G;               // such groups per thread
     typedef VT VPair __attribute__((ext_vector_type(G)));            // native vectors: one load, stay in registers
@@ -447,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
         if (!iteration_head(ctl)) return;
     }
     double acc = 0.0;
-    for (int rb = rb_lo; rb < rb_hi; ++rb) {
+    for (int rb = rb_lo; rb < rb_hi; rb += rb_step) {
         const int64_t row = (int64_t)rb * kStreamRows + t;
         const int ks = rs - base, ke = re - base, cnt_cur = cnt;
 #pragma unroll
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
                 }
             }
         }
-        if (rb + 1 < rb_hi) fetch(rb + 1);   // next block's stream and x chunks are in flight from here on
+        if (rb + rb_step < rb_hi) fetch(rb + rb_step);   // next block's stream and x chunks are in flight from here on
         __syncthreads();
         if (row < n) {
             double s = 0.0;
@@ -517,7 +527,7 @@ static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, 
 #define DPCG_LAUNCH_TILE_X(CTLV, DOTV, XTV, NTV)                                                                         \
     hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV, XTV, VT, XT, NTV>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr, \
                        val, plan.tile_lidx, plan.tile_chunks, plan.tile_nchunks, x, xdot, (double *)y, plan.nrb,         \
-                       tile_doubles, part_pq, d, A.nnz)
+                       tile_doubles, part_pq, d, A.nnz, plan.cyclic ? 1 : 0)
 #define DPCG_LAUNCH_TILE(CTLV, DOTV)                                                          \
     do {                                                                                      \
         if (plan.stream_nt) {                                                                 \

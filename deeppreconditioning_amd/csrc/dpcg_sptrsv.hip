@@ -1065,11 +1065,11 @@ bool launch_ring_factor(const Levels &lv, double *diag, double *fac, hipStream_t
     if (width <= 512) {
         int threads = (width + 63) / 64 * 64;
         threads = threads < 64 ? 64 : threads;
-        if (xdesc) DPCG_RING_FACTOR(kRingChunk, 1, 2, threads);
+        if (xdesc) DPCG_RING_FACTOR(4, 1, 2, threads);              // (a chunk of 4: the general form's records are 22 registers a row; 6 spilled)
         else DPCG_RING_FACTOR(kRingChunk, 1, 1, threads);
     } else {
         const int threads = ((width + 1) / 2 + 63) / 64 * 64;
-        if (xdesc) DPCG_RING_FACTOR(kRingChunk / 2, 2, 2, threads);
+        if (xdesc) DPCG_RING_FACTOR(2, 2, 2, threads);
         else DPCG_RING_FACTOR(kRingChunk / 2, 2, 1, threads);
     }
 #undef DPCG_RING_FACTOR

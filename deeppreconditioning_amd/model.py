@@ -224,7 +224,7 @@ def _hip_forward(net, t: SparseBatch) -> SparseBatch:
     return hip_conv_stack(_conv_layers(net), t, lower=True, cache=net.__dict__.setdefault("_hip_plans", {}))
 
 
-def hip_conv_stack(layers, t: SparseBatch, lower: bool = False, cache: dict | None = None) -> SparseBatch:
+def hip_conv_stack(layers, t: SparseBatch, lower: bool = False, cache: dict | None = None, _sorted_once: bool = False) -> SparseBatch:
     """Run `[(SparseConv2d, nn.PReLU | None), ...]` (stride 1, windows up to 2 x 2) on the HIP path (`dpcg_convnet_*`).
     lower=True: the last layer is pointwise with one output channel and model.py:53-57 is fused into it (`lower_csr`)."""
     import ctypes as C
@@ -235,7 +235,9 @@ def hip_conv_stack(layers, t: SparseBatch, lower: bool = False, cache: dict | No
     feats = t.features.contiguous()
     kernels = [tuple(c.kernel_size) for c, _ in layers]
     paddings = [tuple(c.padding) for c, _ in layers]
-    key = (indices.data_ptr(), indices._version, indices.shape[0], tuple(t.spatial_shape), t.batch_size, tuple(kernels), tuple(paddings))
+    # (tensors created under torch.inference_mode() track no version counter: reading it raises)
+    version = 0 if indices.is_inference() else indices._version
+    key = (indices.data_ptr(), version, indices.shape[0], tuple(t.spatial_shape), t.batch_size, tuple(kernels), tuple(paddings))
     plan = cache.get(key)
     with torch.cuda.device(feats.device):
         if plan is None:
@@ -253,14 +255,14 @@ def hip_conv_stack(layers, t: SparseBatch, lower: bool = False, cache: dict | No
                 else:
                     plan = _ConvnetPlan(indices, t.batch_size, t.spatial_shape, kernels, paddings)
             except L.DpcgError as exc:
-                if "sorted" not in str(exc):
+                if "sorted" not in str(exc) or _sorted_once:        # (sorting does not remove duplicate sites: one retry only)
                     raise
                 # sites in another order: sort them once (spconv accepts any order; the data sets emit sorted ones)
                 H, W = t.spatial_shape
                 k = (indices[:, 0].long() * H + indices[:, 1].long()) * W + indices[:, 2].long()
                 order = torch.argsort(k)
                 return hip_conv_stack(layers, SparseBatch(feats[order], indices[order].contiguous(), t.spatial_shape, t.batch_size),
-                                      lower, cache)
+                                      lower, cache, _sorted_once=True)
             cache[key] = plan
         n = len(layers)
         chan = (C.c_int32 * (n + 1))(*([layers[0][0].in_channels] + [c.out_channels for c, _ in layers]))
@@ -277,6 +279,35 @@ def hip_conv_stack(layers, t: SparseBatch, lower: bool = False, cache: dict | No
     if lower:
         out.lower_csr = (plan.lower_rowptr, plan.lower_col, lower_val)  # rows = batch * height, sample b at [b * H, (b + 1) * H)
     return out
+
+
+def forward_cost(net, t: SparseBatch) -> dict:
+    """Flop and byte model of `PreconditionerNet.forward` on the HIP path for the pattern of `t` (whose plan must be cached: call
+    the net once first).  Per layer: sites = active output sites; flops = 2 * taps * C_in * C_out * sites (every tap of every
+    output site is a C_in x C_out product on the matrix cores, absent neighbours included -- they are multiplied as zeros);
+    bytes = the minimum the layer moves through HBM: its input features once (sites_in * C_in * 4), its output features
+    (sites * C_out * 4; the last layer writes fp64 values of the lower triangle instead) and its rulebook (taps * sites * 4)."""
+    layers = _conv_layers(net)
+    plans = net.__dict__.get("_hip_plans", {})
+    plan = next((p for p in plans.values() if p.indices.data_ptr() == t.indices.contiguous().data_ptr()), None)
+    if plan is None or layers is None:
+        raise ValueError("forward_cost: run the net on this input first (HIP path, cached plan)")
+    import ctypes as C
+    from . import _lib as L
+    out, sites_in, total_f, total_b = [], int(t.indices.shape[0]), 0, 0
+    for li, (conv, _) in enumerate(layers):
+        sites, h, w, nl = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.lib().dpcg_convnet_plan_info(plan.handle, li, C.byref(sites), C.byref(h), C.byref(w), C.byref(nl)))
+        taps = conv.kernel_size[0] * conv.kernel_size[1]
+        flops = 2 * taps * conv.in_channels * conv.out_channels * sites.value
+        last = li == len(layers) - 1
+        byts = sites_in * conv.in_channels * 4 + (plan.nnz_lower * 8 if last else sites.value * conv.out_channels * 4) + taps * sites.value * 4
+        out.append({"layer": li, "kernel": list(conv.kernel_size), "c_in": conv.in_channels, "c_out": conv.out_channels,
+                    "sites": sites.value, "flops": flops, "min_hbm_bytes": byts})
+        total_f += flops
+        total_b += byts
+        sites_in = sites.value
+    return {"layers": out, "flops": total_f, "min_hbm_bytes": total_b}
 
 
 # `PreconditionerSparseUNet` and its sub-manifold / inverse convolutions (model.py:62-179 of the reference) are OUTSIDE the

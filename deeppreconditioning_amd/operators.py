@@ -437,13 +437,13 @@ class CsrSystem:
                 v = v.to(torch.float64)
             if v.numel() != self.nnz:
                 raise ValueError(f"expected {self.nnz} values")
-            if self._keep:                      # a system created from device arrays borrows them: borrow the new ones likewise
-                if v.dtype != torch.float64 or v.data_ptr() % 16:
-                    v = v.to(torch.float64).clone()
-                self._keep = (self._keep[0], self._keep[1], v)
+            if self._keep and (v.dtype != torch.float64 or v.data_ptr() % 16):
+                v = v.to(torch.float64).clone()
             with torch.cuda.device(self.device):
                 L.check(L.lib().dpcg_update_values(self._h, _dev_ptr(v), L.F64 if v.dtype == torch.float64 else L.F32,
                                                    L.DEVICE, _stream()))
+            if self._keep:                      # a system created from device arrays borrows them: borrow the new ones likewise --
+                self._keep = (self._keep[0], self._keep[1], v)      # only once the call has succeeded (the handle still points at the old buffer otherwise)
         else:
             a = values.detach().cpu().numpy() if isinstance(values, torch.Tensor) else np.asarray(values)
             dt = L.F32 if a.dtype == np.float32 else L.F64
