@@ -173,6 +173,10 @@ def measured_stream_ceilings() -> dict:
         out["triad_2r1w" + tag] = round(stream_bench(2, True, 512 * mib, 10, nt), 1)
         out["spmv_like_11r1w" + tag] = round(stream_bench(11, True, 128 * mib, 10, nt), 1)
         out["read_only" + tag] = round(stream_bench(4, False, 384 * mib, 10, nt), 1)
+        # the same streams WALKED TOGETHER by the whole grid instead of one slab per workgroup; the copy then is the shape
+        # MI355X_MICROARCH.md quotes 6.29 TB/s for (one 16-byte element per thread)
+        out["copy_float4" + tag] = round(stream_bench(1, True, 1024 * mib, 10, nt, walk=True), 1)
+        out["spmv_like_11r1w_walk" + tag] = round(stream_bench(11, True, 128 * mib, 10, nt, walk=True), 1)
     # the same kernel on footprints INSIDE the Infinity Cache (the headline system's regime: ~100 MB per SpMV, 24-48 MB per
     # vector kernel): what the fabric delivers to a plain stream of that size, launched back to back
     out["cache_resident_spmv_like_11r1w_96MB"] = round(stream_bench(11, True, 8 * mib, 40, False), 1)
@@ -409,7 +413,8 @@ def main() -> None:
                 "traffic": pmc_all.get("spmv_3d_256"), "algorithmic_bytes_per_launch": b4_alg,
                 "us_per_launch": round(ms4 * 1e3, 2), "dof": s4.n, "nnz": s4.nnz,
                 "frac_of_measured_spmv_like_stream": round(b4_alg / (ms4 * 1e-3) / 1e9 /
-                                                           max(ceilings["spmv_like_11r1w"], ceilings["spmv_like_11r1w_nt"]), 4),
+                                                           max(ceilings["spmv_like_11r1w"], ceilings["spmv_like_11r1w_nt"],
+                                                               ceilings["spmv_like_11r1w_walk"], ceilings["spmv_like_11r1w_walk_nt"]), 4),
                 "non_temporal_streams": bool(s4.info().get("spmv_nt", False)),
                 "us_per_launch_by_placement": [round(v * 1e3, 2) for v in samples],
                 "placement": "median of four creations of the system on fresh allocations"}

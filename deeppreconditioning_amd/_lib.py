@@ -53,6 +53,7 @@ SIGNATURES = {
     "dpcg_get_precond_ordering": (_int, [_p, C.POINTER(_int), _p]),
     "dpcg_set_precond_ict": (_int, [_p, _int, _int, _dbl, _p]),
     "dpcg_set_precond_icholt": (_int, [_p, _int, _int, _dbl, _p]),
+    "dpcg_get_reduction_geometry": (_int, [_p, _p]),
     "dpcg_get_factor": (_int, [_p, _p, _p, _p]),
     "dpcg_spmv": (_int, [_p, _p, _p, _p]),
     "dpcg_spmv_f32": (_int, [_p, _p, _p, _p]),

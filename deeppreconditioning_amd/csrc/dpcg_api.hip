@@ -567,6 +567,18 @@ extern "C" int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spm
     return DPCG_OK;
 }
 
+extern "C" int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[8]) {
+    if (!h || !out) return invalid("dpcg_get_reduction_geometry: NULL argument");
+    out[0] = h->planA.grid;
+    out[1] = h->planA.nrb;
+    out[2] = (h->planA.kernel == SPMV_TILE && h->planA.cyclic) ? 1 : 0;
+    out[3] = h->vec_grid;
+    out[4] = fuse_eligible(h, 0, nullptr) ? 1 : 0;
+    out[5] = h->planA.kernel;
+    out[6] = out[7] = 0;
+    return DPCG_OK;
+}
+
 int ensure_work(dpcg_system *h, int max_iter, bool need_f32, bool need_err) {
     const int64_t n = h->A.n;
     if (!h->x) {
@@ -862,7 +874,13 @@ extern "C" int dpcg_stream_bench(int n_read, int write, int nontemporal, int64_t
         // a footprint inside the Infinity Cache (256 MiB) streams best with one element in flight per lane and 6 workgroups
         // per CU, one beyond it with two and 8 (tools/stream_lab; profiles/r03_stream_lab.txt)
         const bool resident = (int64_t)(n_read + (write ? 1 : 0)) * out_bytes < ((int64_t)200 << 20);
-        const int grid = resident ? 1536 : kMaxSpmvGrid, in_flight = resident ? 1 : 2;
+        // nontemporal: bit 0 = non-temporal accesses, bit 1 = the streams WALKED TOGETHER instead of in slabs (k_stream_walk): a copy as
+        // one 16-byte element per thread (the guide's float4-copy shape), the other ratios on a persistent grid of 2048
+        const bool walk = (nontemporal & 2) != 0;
+        const int64_t flat = (out_bytes / 16 + kBlock - 1) / kBlock;
+        const int grid = walk ? (int)(n_read == 1 && flat <= 0x7fffffff ? flat : kMaxSpmvGrid) : (resident ? 1536 : kMaxSpmvGrid);
+        const int in_flight = walk ? 0 : (resident ? 1 : 2);
+        nontemporal &= 1;
         for (int i = 0; i < 2 && e == hipSuccess; ++i)
             moved = launch_stream_bench(n_read, write != 0, nontemporal != 0, out_bytes, in, out, part, grid, s, in_flight);
         if (e == hipSuccess && moved < 0) st = invalid("dpcg_stream_bench: n_read must be 1, 2, 4 or 11");

@@ -125,6 +125,37 @@ __global__ __launch_bounds__(kBlock) void k_stream_bench(int64_t n2, const doubl
     if (!W && acc == 12345.678) part[blockIdx.x] = acc;      // keeps the loads alive; never true for the zero-filled input
 }
 
+// The same streams WALKED TOGETHER: workgroup b takes elements b, b + G, b + 2 G, ... (G = gridDim.x; with G = n2 / 256 every
+// workgroup moves one 4-KiB piece: the "float4 copy" shape MI355X_MICROARCH.md quotes 6.29 TB/s for), so that at any instant the
+// chip touches one contiguous window of each stream instead of G distant slabs.  Measured on this pool (tools/stream_lab,
+// profiles/r04_stream_lab.txt): copy 5.3 (slabs) -> 6.3 TB/s (6.7 non-temporal), 11 : 1 5.3 -> 5.6 (6.0 non-temporal).
+template <int R, bool W, bool NT>
+__global__ __launch_bounds__(kBlock) void k_stream_walk(int64_t n2, const double2 *__restrict__ in, double2 *__restrict__ out,
+                                                        double *__restrict__ part) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int64_t span = (int64_t)gridDim.x * kBlock;
+    double acc = 0.0;
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < n2; i0 += span) {
+        const int64_t i = i0 + threadIdx.x;
+        d2 sum = {0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const d2 *p = reinterpret_cast<const d2 *>(in) + (i0 * R + (int64_t)r * kBlock + threadIdx.x);
+            sum += NT ? __builtin_nontemporal_load(p) : *p;
+        }
+        if (W) {
+            if (i < n2) {
+                d2 *q = reinterpret_cast<d2 *>(out) + i;
+                if (NT) __builtin_nontemporal_store(sum, q);
+                else *q = sum;
+            }
+        } else {
+            acc += sum.x + sum.y;
+        }
+    }
+    if (!W && acc == 12345.678) part[blockIdx.x] = acc;
+}
+
 // out_bytes: size of the written stream (rounded down to 16 B; the input is n_read times as long, plus one slab of slack);
 // returns the bytes one launch moves (reads + writes), or -1 for an unsupported n_read
 // `in_flight`: output elements in flight per lane (2 suits streams from HBM, 1 footprints inside the Infinity Cache -- tools/stream_lab)
@@ -133,6 +164,24 @@ int64_t launch_stream_bench(int n_read, bool write, bool nt, int64_t out_bytes, 
     const int64_t n2 = out_bytes / 16;
     const double2 *i2 = reinterpret_cast<const double2 *>(in);
     double2 *o2 = reinterpret_cast<double2 *>(out);
+    if (in_flight == 0) {                 // the streams walked together (k_stream_walk); `grid` as given
+#define DPCG_WALK_CASE(RV)                                                                                                      \
+    case RV:                                                                                                                    \
+        if (write && nt) hipLaunchKernelGGL((k_stream_walk<RV, true, true>), dim3(grid), dim3(kBlock), 0, s, n2, i2, o2, part);   \
+        else if (write) hipLaunchKernelGGL((k_stream_walk<RV, true, false>), dim3(grid), dim3(kBlock), 0, s, n2, i2, o2, part);   \
+        else if (nt) hipLaunchKernelGGL((k_stream_walk<RV, false, true>), dim3(grid), dim3(kBlock), 0, s, n2, i2, o2, part);      \
+        else hipLaunchKernelGGL((k_stream_walk<RV, false, false>), dim3(grid), dim3(kBlock), 0, s, n2, i2, o2, part);             \
+        break
+        switch (n_read) {
+            DPCG_WALK_CASE(1);
+            DPCG_WALK_CASE(2);
+            DPCG_WALK_CASE(4);
+            DPCG_WALK_CASE(11);
+            default: return -1;
+        }
+#undef DPCG_WALK_CASE
+        return n2 * 16 * (n_read + (write ? 1 : 0));
+    }
 #define DPCG_STREAM_LAUNCH(RV, WV, NTV)                                                                                     \
     do {                                                                                                                    \
         if (in_flight == 1)                                                                                                 \

@@ -509,6 +509,14 @@ class CsrSystem:
                 "gather_ratio": ratio.value,
                 "precond": pk.value, "precond_nnz": pn.value, "levels_lower": ll.value, "levels_upper": lu.value}
 
+    def reduction_geometry(self) -> dict:
+        """How the handle's kernels sum their dot products (dpcg_get_reduction_geometry): what a checker needs to add in the same
+        order (oracle/c_oracle.pcg(..., device_tree=...))."""
+        out = (C.c_int32 * 8)()
+        L.check(L.lib().dpcg_get_reduction_geometry(self._h, out))
+        return {"spmv_grid": out[0], "nrb": out[1], "cyclic": out[2], "vec_grid": out[3], "two_kernel_updates": bool(out[4]),
+                "spmv_kernel": ("stream", "vector", "tile")[out[5]]}
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
             L.lib().dpcg_destroy(self._h)
@@ -622,12 +630,15 @@ def dot(a: torch.Tensor, b: torch.Tensor) -> float:
     return float(out.value)
 
 
-def stream_bench(n_read: int = 2, write: bool = True, out_bytes: int = 1 << 27, repeats: int = 10, nontemporal: bool = False) -> float:
+def stream_bench(n_read: int = 2, write: bool = True, out_bytes: int = 1 << 27, repeats: int = 10, nontemporal: bool = False,
+                 walk: bool = False) -> float:
     """GB/s (reads + writes) of the library's own streaming kernel on this box: per 16 bytes written, `n_read` x 16
     contiguous bytes are read (or only reduced when write=False) -- the measured HBM ceiling next to the 8 TB/s spec
     (SURVEY.md 8-d2).  n_read = 11 with write is the read:write ratio of a 7-point CSR SpMV."""
     ms, moved = C.c_float(), C.c_int64()
-    L.check(L.lib().dpcg_stream_bench(int(n_read), 1 if write else 0, 1 if nontemporal else 0, int(out_bytes), int(repeats),
+    # walk: the streams walked together by the whole grid instead of one slab per workgroup (a copy then is the guide's
+    # float4-copy shape: one 16-byte element per thread)
+    L.check(L.lib().dpcg_stream_bench(int(n_read), 1 if write else 0, (1 if nontemporal else 0) | (2 if walk else 0), int(out_bytes), int(repeats),
                                       C.byref(ms), C.byref(moved), _stream()))
     return moved.value / (ms.value * 1e-3) / 1e9
 

@@ -180,6 +180,12 @@ int dpcg_set_precond_icholt(dpcg_handle_t h, int mode, int add_fill_in, double t
  * around the call on a reordered handle -- while SpMV, dots and vector updates stay the HIP kernels. */
 typedef void (*dpcg_precond_fn)(void *user, const double *r, double *z, int64_t n, dpcg_stream_t stream);
 int dpcg_set_precond_callback(dpcg_handle_t h, dpcg_precond_fn fn, void *user);
+/* The geometry of the handle's reductions, for a checker that wants to sum in the same order (oracle/pcg_oracle.c,
+ * orc_set_dot_tree: with it the CPU restatement reproduces the multi-launch solve's residual history BIT FOR BIT for M = I /
+ * Jacobi): out[0] = workgroups of the SpMV kernel of the PCG loop, out[1] = its 256-row blocks, out[2] = 1 when the blocks are
+ * dealt out cyclically (0: contiguous slabs), out[3] = workgroups of the vector kernels, out[4] = 1 when a solve with default
+ * flags runs two-kernel updates, out[5] = the SpMV kernel (0 gather, 1 vector, 2 x-tile), out[6..7] = 0. */
+int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[8]);
 /* Copy the current factor L out (host arrays sized from dpcg_get_info's precond_nnz). */
 int dpcg_get_factor(dpcg_handle_t h, int32_t *rowptr, int32_t *col, double *val);
 
@@ -198,8 +204,10 @@ int dpcg_spmv_dot_bench(dpcg_handle_t h, const double *x, double *y, int repeats
 /* The HBM streaming ceiling of this box with the library's own access shape (SURVEY.md 8-d2 asks for a measured ceiling
  * beside the 8 TB/s spec; nothing in the reference corresponds -- its loop runs on torch CPU/CUDA ops, cg.py:75-86): per 16
  * bytes written, n_read x 16 contiguous bytes are read (n_read = 1 copy, 2 triad, 4, or 11 = the read:write ratio of a
- * 7-point CSR SpMV); write = 0: read-only, n_read x out_bytes are only reduced.  nontemporal = 1: non-temporal loads and
- * stores.  `repeats` launches between HIP events on `stream`; *bytes_per_launch = reads + writes of one launch. */
+ * 7-point CSR SpMV); write = 0: read-only, n_read x out_bytes are only reduced.  nontemporal: bit 0 = non-temporal loads and
+ * stores; bit 1 = the streams are WALKED TOGETHER by the whole grid (workgroup b takes pieces b, b + G, ...) instead of one
+ * contiguous slab per workgroup -- a copy then is one 16-byte element per thread, the "float4 copy" MI355X_MICROARCH.md quotes
+ * 6.29 TB/s for (measured here: 6.3; slabs 5.3).  `repeats` launches between HIP events on `stream`; *bytes_per_launch = reads + writes of one launch. */
 int dpcg_stream_bench(int n_read, int write, int nontemporal, int64_t out_bytes, int repeats, float *ms_per_launch,
                       int64_t *bytes_per_launch, dpcg_stream_t stream);
 

@@ -128,11 +128,22 @@ def sptrsv_upper(U: sp.csr_matrix, y: np.ndarray) -> np.ndarray:
 
 
 def pcg(A: sp.csr_matrix, b: np.ndarray, kind: str = "none", *, dinv=None, M=None, L=None, x0=None, rtol=1e-8,
-        max_iter=1024, init_check="z", mixed=False, precond_perm=None):
+        max_iter=1024, init_check="z", mixed=False, precond_perm=None, device_tree=None):
     """Returns (seconds, iterations, residual_history, x) -- same tuple as oracle.oracle's PCG.
     mixed=True: config 5, the loop's `A @ pk` on fp32-stored values and pk (orc_pcg_mixed).
     precond_perm: A (and b, x0, x) are the permuted system P A_c P^T, row i = the caller's row precond_perm[i], while
-    dinv / M / L stay in the caller's numbering: z' = P M P^T r' (orc_pcg_perm)."""
+    dinv / M / L stay in the caller's numbering: z' = P M P^T r' (orc_pcg_perm).
+    device_tree: {"spmv_grid", "nrb", "cyclic", "vec_grid"} (CsrSystem.reduction_geometry() of the handle under test): every dot
+    product is summed in the DEVICE's reduction tree (orc_set_dot_tree) instead of the oracle's fixed blocks -- for kind "none" /
+    "jacobi" the history then equals the multi-launch HIP solve's BIT FOR BIT."""
+    if device_tree is not None:
+        lib().orc_set_dot_tree(1, int(device_tree["spmv_grid"]), int(device_tree["nrb"]), int(device_tree["cyclic"]),
+                               int(device_tree["vec_grid"]))
+        try:
+            return pcg(A, b, kind, dinv=dinv, M=M, L=L, x0=x0, rtol=rtol, max_iter=max_iter, init_check=init_check, mixed=mixed,
+                       precond_perm=precond_perm)
+        finally:
+            lib().orc_set_dot_tree(0, 0, 0, 0, 0)
     n = A.shape[0]
     rp, ci, v = _csr_parts(A)
     b = np.ascontiguousarray(b, dtype=np.float64)

@@ -2453,3 +2453,70 @@ def test_team_kernel_batches_of_systems(D):
         assert sb.status == 0 and sb.final_res == s1.final_res and torch.equal(sb.x, s1.x)
     for S in systems:
         S.close()
+
+
+# ---- round 4: the oracle sums its dot products in the DEVICE's reduction tree: histories equal bit for bit ------------------------
+@pytest.mark.parametrize("name,make,flags,max_iter", [
+    ("poisson3d_100", lambda: O.poisson3d(100), 0, 1024),                       # headline: x-tile SpMV (slabs), three-kernel updates
+    ("poisson2d_1024", lambda: O.poisson2d(1024), 0, 1024),                     # runs into the cap: 1024 updates, still the same bits
+    ("poisson3d_64", lambda: O.poisson3d(64), 0, 1024),                         # two-kernel updates (gather SpMV with the vector update fused)
+    ("poisson2d_300_three_kernel", lambda: O.poisson2d(300), "NO_FUSE", 1024),
+    ("poisson2d_150", lambda: O.poisson2d(150), 0, 1024),                       # 22 500 rows: a few row blocks per workgroup
+    ("unstructured3d_100", lambda: O.unstructured_like(O.poisson3d(100), seed=0), 0, 1024),   # reordered handle: the oracle on P A P^T
+    ("delaunay_100k", lambda: O.delaunay_laplacian(100000, 3), 0, 1024),
+    ("quadtree_foam_300", lambda: O.quadtree_fv_laplacian(300, 5), 0, 1024),
+    ("poisson3d_256_cyclic", lambda: None, 0, 40)])                             # beyond the Infinity Cache: row blocks dealt out cyclically
+def test_history_equals_the_device_tree_oracle_bit_for_bit(D, name, make, flags, max_iter):
+    """oracle/pcg_oracle.c with `device_tree` adds every dot product in the order the kernels do (wave DPP tree, four wave sums,
+    partials re-reduced; slabs or cyclic row blocks of the SpMV; pairs in k_update_r) -- geometry from `reduction_geometry()`.
+    Everything else was the same arithmetic already, so for M = I and Jacobi the residual history, the iteration count and the
+    solution of the multi-launch solve equal the CPU restatement's BIT FOR BIT: no tolerance, no chaotic window."""
+    from deeppreconditioning_amd import poisson
+    if make() is None:
+        S = poisson.poisson_system(3, 256)
+        rp, ci, v = (t.cpu().numpy() for t in poisson.poisson_csr(3, 256))
+        A = sp.csr_matrix((v, ci, rp), shape=(S.n, S.n))
+        assert S.reduction_geometry()["cyclic"] == 1
+    else:
+        A = make()
+        S = D.CsrSystem.from_any(A)
+    n = A.shape[0]
+    geo = S.reduction_geometry()
+    fl = (getattr(D._lib, flags) if isinstance(flags, str) else flags) | D._lib.NO_SMALL
+    b = O.rhs(n, 0)
+    perm = S.permutation() if S.reordered else None
+    B = _permuted(A, perm) if perm is not None else A
+    bb = b[perm] if perm is not None else b
+    for kind, pc, okw in (("jacobi", D.Jacobi(), dict(dinv=O.jacobi_dinv(B))), ("none", None, {})):
+        S.set_preconditioner(pc)
+        res = S.solve(_dev(b), flags=fl, max_iter=max_iter)
+        _, it, hist, x = CO.pcg(B, bb, kind, max_iter=max_iter, device_tree=geo, **okw)
+        assert res.iterations == it, (name, kind, geo)
+        assert np.array_equal(res.res_history, hist), (name, kind, geo, int(np.argmax(res.res_history != hist)))
+        xs = res.x.cpu().numpy()
+        assert np.array_equal(xs[perm] if perm is not None else xs, x), (name, kind)
+    S.close()
+
+
+@pytest.mark.parametrize("name,make", [("poisson3d_100", lambda: O.poisson3d(100)),
+                                       ("unstructured3d_100_lossy_values", lambda: O.unstructured_like(O.poisson3d(100), seed=0)),
+                                       ("unstructured2d_200", lambda: O.unstructured_like(O.poisson2d(200), seed=2))])
+def test_mixed_precision_equals_the_device_tree_oracle_bit_for_bit(D, name, make):
+    """BASELINE config 5 against the oracle's ARITHMETIC, not a bound: rounding p to fp32 is discontinuous, so two
+    implementations whose fp64 dots differ in the last bits drift apart (`_check_mixed`'s 1e-4) -- with the device's reduction
+    tree in the oracle there is nothing left to differ: orc_pcg_mixed's history equals DPCG_SPMV_F32's bit for bit."""
+    A = make()
+    n = A.shape[0]
+    S = D.CsrSystem.from_any(A)
+    geo = S.reduction_geometry()
+    b = O.rhs(n, 0)
+    perm = S.permutation() if S.reordered else None
+    B = _permuted(A, perm) if perm is not None else A
+    bb = b[perm] if perm is not None else b
+    S.set_preconditioner(D.Jacobi())
+    res = S.solve(_dev(b), flags=D._lib.SPMV_F32 | D._lib.NO_SMALL)
+    _, it, hist, x = CO.pcg(B, bb, "jacobi", dinv=O.jacobi_dinv(B), mixed=True, device_tree=geo)
+    assert res.iterations == it and np.array_equal(res.res_history, hist), (name, geo, int(np.argmax(res.res_history != hist)))
+    xs = res.x.cpu().numpy()
+    assert np.array_equal(xs[perm] if perm is not None else xs, x)
+    S.close()
