@@ -153,6 +153,12 @@ for case in range(cases):
                 itm, hm = CO.pcg(Bm, bm, okind, x0=x0m, mixed=True, **kwm)[1:3]
                 hn = np.array(O.preconditioned_conjugate_gradient(O.MixedOperatorX0(Bm), bm, O.Precond(okind, **kwm), x0=x0m)[2])
                 rm = S.solve(torch.from_numpy(b).cuda(), x0_dev, flags=D._lib.SPMV_F32)
+                if kind in ("none", "jacobi"):
+                    # round 4: the oracle sums in the DEVICE's reduction tree, so there is no drift to bound -- bit for bit
+                    itd, hd = CO.pcg(Bm, bm, okind, x0=x0m, mixed=True, device_tree=S.reduction_geometry(), **kwm)[1:3]
+                    if not (rm.iterations == itd and np.array_equal(rm.res_history, hd)):
+                        bad += 1
+                        print("MIXED-PRECISION BITS MISMATCH", tag, kind, rm.iterations, itd)
                 mm = min(len(hm), len(hn), len(rm.res_history))
                 sigm = np.abs(hm[:mm]) > 1e-22
                 drift_m = np.abs(hn[:mm] - hm[:mm])[sigm] / np.abs(hm[:mm])[sigm]
@@ -167,6 +173,8 @@ for case in range(cases):
                 # CPU oracles are 2e-7 apart, counts equal.  So: the first half of the history within 30x the oracles' drift, the second
                 # half within 1e-3.)
                 half = rel_m.size // 2
+                # (kept for IC(0) only, whose <r,z> the apply's last kernel sums in a tree the oracle does not restate; M = I and Jacobi
+                # are held to the bits above)
                 body_ok = (rel_m.size == 0 or (float(rel_m[:max(half, 1)].max()) < tol_m and float(rel_m.max()) < max(tol_m, 1e-3)))
                 if not (head_ok and body_ok
                         and abs(rm.iterations - itm) <= 0.02 * itm + 1 + abs(len(hn) - 1 - itm)):
@@ -178,9 +186,16 @@ for case in range(cases):
                     print(kind, "mixed GPU / C mixed oracle - 1:", rm.res_history[:mm] / hm[:mm] - 1)
                     print(kind, "mixed numpy oracle / C mixed oracle - 1:", hn[:mm] / hm[:mm] - 1)
                     print(kind, "C mixed history:", hm[:mm])
+            tree_hist = None
+            if kind in ("none", "jacobi"):     # round 4: the multi-launch forms against the device-tree oracle, bit for bit
+                tree_hist = CO.pcg(B, bo, kind, x0=x0o, device_tree=S.reduction_geometry(),
+                                   **(dict(dinv=O.jacobi_dinv(B)) if kind == "jacobi" else {}))[1:3]
             for flags in (0, D._lib.NO_SMALL, D._lib.NO_SMALL | D._lib.NO_FUSE):
                 r = S.solve(torch.from_numpy(b).cuda(), x0_dev, flags=flags)
                 h = r.res_history
+                if tree_hist is not None and flags and not (r.iterations == tree_hist[0] and np.array_equal(h, tree_hist[1])):
+                    bad += 1
+                    print("BITS MISMATCH against the device-tree oracle", tag, kind, "flags", flags, r.iterations, tree_hist[0])
                 m = min(len(h), len(hist))
                 # M = L L^T multiplied is the reference's own "unstable" technique (test.py:45): rounding differences
                 # grow to O(1) within tens of updates, so only the first entries and a count window are comparable;
