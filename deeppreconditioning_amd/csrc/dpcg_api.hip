@@ -205,20 +205,25 @@ int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s, bool allow_tile) {
         const bool force_stream = force && strcmp(force, "stream") == 0;
         const bool force_tile = force && strcmp(force, "tile") == 0;
         if (allow_tile && !force_stream && A.nnz > 0 && (force_tile || plan.nrb >= kTileMinBlocks)) {
-            int *d_flags = nullptr, h_flags[2] = {1, 0};
+            int *d_flags = nullptr, h_flags[3] = {1, 0, 0};    // every block planned | widest tile | blocks without a tile
             DPCG_TRY(dev_alloc(&plan.tile_chunks, (int64_t)plan.nrb * kTileMaxChunks));
             DPCG_TRY(dev_alloc(&plan.tile_nchunks, plan.nrb));
             DPCG_TRY(dev_alloc(&plan.tile_lidx, A.nnz + 4));                   // read in aligned groups of 2 or 4
             DPCG_HIP(hipMemsetAsync(plan.tile_lidx + A.nnz, 0, 4 * sizeof(uint16_t), s));
-            DPCG_TRY(dev_alloc(&d_flags, 2));
+            DPCG_TRY(dev_alloc(&d_flags, 3));
             DPCG_HIP(hipMemcpyAsync(d_flags, h_flags, sizeof(h_flags), hipMemcpyHostToDevice, s));
             launch_tile_plan(A, plan.nrb, plan.tile_chunks, plan.tile_nchunks, plan.tile_lidx, d_flags, s);
             DPCG_HIP(hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
             DPCG_HIP(hipStreamSynchronize(s));
             dev_free(d_flags);
-            if (h_flags[0] == 1 && h_flags[1] > 0) {
+            // blocks that touch more than kTileMaxChunks chunks gather instead (k_spmv_tile<..., MIX>): worth it while they are few
+            // (DPCG_TILE_MIX_MAX: largest share of such blocks in percent, development knob; 0 = the round-3 behaviour)
+            static const int mix_max = [] { const char *e = getenv("DPCG_TILE_MIX_MAX"); return e ? atoi(e) : 30; }();
+            const bool mix_ok = h_flags[2] == 0 || (int64_t)h_flags[2] * 100 <= (int64_t)mix_max * plan.nrb;
+            if (h_flags[0] == 1 && h_flags[1] > 0 && mix_ok) {
                 plan.kernel = SPMV_TILE;
                 plan.tile_max_chunks = h_flags[1];
+                plan.tile_mixed = h_flags[2] > 0;
                 // streams that cannot stay in the 256 MiB Infinity Cache are read (and y written) non-temporally
                 // (DPCG_SPMV_NT=0/1 overrides: development knob)
                 static const int nt_knob = [] { const char *e = getenv("DPCG_SPMV_NT"); return e ? atoi(e) : -1; }();
@@ -556,9 +561,11 @@ extern "C" int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spm
     if (!h) return invalid("dpcg_get_info: NULL handle");
     if (n) *n = h->A.n;
     if (nnz) *nnz = h->A.nnz;
-    if (spmv_kernel)   // +16: two-kernel updates; +32: the x-tile kernel streams non-temporally
+    if (spmv_kernel)   // +16: two-kernel updates; x-tile kernel: +32 non-temporal streams, +64 some blocks gather, +128 cyclic row blocks
         *spmv_kernel = h->planA.kernel + (fuse_eligible(h, 0, nullptr) ? 16 : 0) +
-                       (h->planA.kernel == SPMV_TILE && h->planA.stream_nt ? 32 : 0);
+                       (h->planA.kernel == SPMV_TILE && h->planA.stream_nt ? 32 : 0) +
+                       (h->planA.kernel == SPMV_TILE && h->planA.tile_mixed ? 64 : 0) +
+                       (h->planA.kernel == SPMV_TILE && h->planA.cyclic ? 128 : 0);
     if (precond_kind) *precond_kind = h->precond;
     if (precond_nnz) *precond_nnz = h->precond == DPCG_PRECOND_CSR ? h->M.nnz : h->L.nnz;
     if ((n_levels_lower || n_levels_upper) && h->lvlL.n_levels < 0) DPCG_TRY(count_levels_on_demand(h));

@@ -54,6 +54,7 @@ struct SpmvPlan {
     uint16_t *tile_lidx = nullptr;     // [nnz]
     int tile_max_chunks = 0;           // largest chunk count of any block (sizes the dynamic LDS)
     bool stream_nt = false;            // x-tile kernel: once-read streams and y non-temporal (streams beyond the Infinity Cache)
+    bool tile_mixed = false;           // x-tile kernel: some blocks have no tile (tile_nchunks = -1) and gather instead
     bool cyclic = false;               // x-tile kernel: row blocks dealt out cyclically (b, b + G, ...) instead of in slabs (see k_spmv_tile)
     int max_row_len = 0;               // longest row (the team kernel keeps rows of <= 7 entries in registers)
 };

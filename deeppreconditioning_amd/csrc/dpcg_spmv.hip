@@ -221,7 +221,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_vector(int64_t n, const int32_t
 __global__ __launch_bounds__(kBlock) void k_tile_plan(int64_t n, const int32_t *__restrict__ rowptr,
                                                       const int32_t *__restrict__ col, int nrb,
                                                       int32_t *__restrict__ chunks, int32_t *__restrict__ nchunks,
-                                                      uint16_t *__restrict__ lidx, int *ok_and_max, int diag_from) {
+                                                      uint16_t *__restrict__ lidx, int *ok_and_max, int diag_from,
+                                                      int allow_flagged /* ok_and_max[2] counts the blocks without a tile */) {
     __shared__ int s_min, s_max, s_nc;
     __shared__ uint16_t slot_of[kTileTableMax];
     const int t = threadIdx.x;
@@ -280,8 +281,13 @@ __global__ __launch_bounds__(kBlock) void k_tile_plan(int64_t n, const int32_t *
             const bool ok = !s_over && s_nc <= kTileMaxChunks;
             if (t == 0) {
                 if (!ok) {
-                    nchunks[rb] = 0;
-                    atomicExch(&ok_and_max[0], 0);
+                    if (allow_flagged) {                       // too many chunks: this block gathers (k_spmv_tile<..., MIX>)
+                        nchunks[rb] = -1;
+                        atomicAdd(&ok_and_max[2], 1);
+                    } else {
+                        nchunks[rb] = 0;
+                        atomicExch(&ok_and_max[0], 0);
+                    }
                 } else {
                     int keys[kTileMaxChunks], where[kTileMaxChunks], nc = 0;
                     for (int e = 0; e < 128; ++e)
@@ -327,9 +333,11 @@ __global__ __launch_bounds__(kBlock) void k_tile_plan(int64_t n, const int32_t *
                     slot_of[e] = (uint16_t)(++nc);
                 }
             s_nc = nc;
-            nchunks[rb] = nc <= kTileMaxChunks ? nc : 0;
-            if (nc > kTileMaxChunks) atomicExch(&ok_and_max[0], 0);
-            else atomicMax(&ok_and_max[1], nc);
+            nchunks[rb] = nc <= kTileMaxChunks ? nc : (allow_flagged ? -1 : 0);   // -1: too many chunks, this block gathers (k_spmv_tile<..., MIX>)
+            if (nc > kTileMaxChunks) {
+                if (allow_flagged) atomicAdd(&ok_and_max[2], 1);
+                else atomicExch(&ok_and_max[0], 0);
+            } else atomicMax(&ok_and_max[1], nc);
         }
         __syncthreads();
         if (s_nc <= kTileMaxChunks)
@@ -345,7 +353,7 @@ void launch_tile_plan(const CsrDev &A, int nrb, int32_t *chunks, int32_t *nchunk
                       hipStream_t s) {
     const int grid = nrb < 2048 ? nrb : 2048;
     hipLaunchKernelGGL(k_tile_plan, dim3(grid), dim3(kBlock), 0, s, A.n, A.rowptr, A.col, nrb, chunks, nchunks, lidx,
-                       ok_and_max_dev, 0x7fffffff);
+                       ok_and_max_dev, 0x7fffffff, 1);            // (ok_and_max_dev: three ints)
 }
 
 // The same plan for `count` consecutive rows of a level-ordered factor copy that start at row j0 (one level of a colour sweep):
@@ -355,7 +363,7 @@ void launch_sweep_tile_plan(int j0, int count, const int32_t *lo_rowptr, const i
     const int nrb = (count + kStreamRows - 1) / kStreamRows;
     const int grid = nrb < 2048 ? nrb : 2048;
     hipLaunchKernelGGL(k_tile_plan, dim3(grid), dim3(kBlock), 0, s, (int64_t)count, lo_rowptr + j0, lo_cpos, nrb, chunks, nchunks,
-                       lidx, ok_and_max_dev, j0);
+                       lidx, ok_and_max_dev, j0, 0);
 }
 
 // XT: x-tile elements staged per thread (tile_max_chunks * 64 / 256, rounded up).  VT / XV: storage types of the
@@ -364,7 +372,10 @@ void launch_sweep_tile_plan(int j0, int count, const int32_t *lo_rowptr, const i
 // NT: the once-read streams (matrix values, local indices, row extents) are loaded and y is stored NON-TEMPORALLY -- for
 // systems whose streams exceed the 256 MiB Infinity Cache, where caching them only evicts the x chunks that ARE reused
 // (tools/stream_lab on the same box: an 11-reads-per-write stream 5.05 -> 5.22 TB/s with non-temporal accesses).
-template <bool CTL, bool DOT, int XT, typename VT, typename XV, bool NT = false>
+// MIX: some blocks of the plan touch more than kTileMaxChunks chunks (nchunks = -1: an OpenFOAM numbering whose refined cells were
+// appended couples a block to a few dozen places) -- such a block gathers x[col] through the L2 like the CSR-stream kernel does, its
+// value stream already prefetched; every other block keeps its LDS tile.  Same products, same order, same bits.
+template <bool CTL, bool DOT, int XT, typename VT, typename XV, bool NT = false, bool MIX = false>
 __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *__restrict__ rowptr,
                                                       const VT *__restrict__ val,
                                                       const uint16_t *__restrict__ lidx,
@@ -372,7 +383,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
                                                       const int32_t *__restrict__ nchunks,
                                                       const XV *__restrict__ x, const double *__restrict__ xdot,
                                                       double *__restrict__ y, int nrb, int tile_doubles,
-                                                      double *__restrict__ part_pq, IterCtlDev ctl, int64_t nnz, int cyclic) {
+                                                      double *__restrict__ part_pq, IterCtlDev ctl, int64_t nnz, int cyclic,
+                                                      const int32_t *__restrict__ col) {
     constexpr int U = kStreamCap / kBlock;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     XV *xs = reinterpret_cast<XV *>(smem);  // the staged x chunks of this block (tile_doubles slots reserved)
@@ -466,6 +478,33 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
             if (ci < nc) *reinterpret_cast<XPair *>(xs + ci * kTileChunk + 2 * (lane & 31)) = xt[u];
         }
         __syncthreads();                    // tile complete (and every thread is past the previous row sums)
+        if (MIX && nc < 0) {                // a block without a tile: its columns from the CSR, x through the L2
+            typedef int CGroup __attribute__((ext_vector_type(G)));
+            const int lastp = cnt_cur > 0 ? (cnt_cur - 1) / G : 0;
+            CGroup cg[UP];
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+                const int pr = t + u * kBlock;
+                const int64_t kabs = base + G * (int64_t)(pr <= lastp ? pr : lastp);
+                cg[u] = *reinterpret_cast<const CGroup *>(col + (cnt_cur > 0 ? kabs : 0));    // (col is padded like lidx: see make_plan)
+            }
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+                const int k = G * (t + u * kBlock);
+                XV xg[G];
+#pragma unroll
+                for (int e = 0; e < G; ++e) xg[e] = x[cg[u][e]];
+                if (k < cnt_cur) {
+#pragma unroll
+                    for (int e = 0; e < G; e += 2) {
+                        double2 pp;
+                        pp.x = (double)a[u][e] * (double)xg[e];
+                        pp.y = (double)a[u][e + 1] * (double)xg[e + 1];
+                        *reinterpret_cast<double2 *>(prod + k + e) = pp;
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < UP; ++u) {
             const int k = G * (t + u * kBlock);
@@ -478,6 +517,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
                     *reinterpret_cast<double2 *>(prod + k + e) = pp;
                 }
             }
+        }
         }
         if (rb + rb_step < rb_hi) fetch(rb + rb_step);   // next block's stream and x chunks are in flight from here on
         __syncthreads();
@@ -527,10 +567,17 @@ static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, 
 #define DPCG_LAUNCH_TILE_X(CTLV, DOTV, XTV, NTV)                                                                         \
     hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV, XTV, VT, XT, NTV>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr, \
                        val, plan.tile_lidx, plan.tile_chunks, plan.tile_nchunks, x, xdot, (double *)y, plan.nrb,         \
-                       tile_doubles, part_pq, d, A.nnz, plan.cyclic ? 1 : 0)
+                       tile_doubles, part_pq, d, A.nnz, plan.cyclic ? 1 : 0, A.col)
+#define DPCG_LAUNCH_TILE_MIX(CTLV, DOTV, XTV)                                                                                  \
+    hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV, XTV, VT, XT, false, true>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr, \
+                       val, plan.tile_lidx, plan.tile_chunks, plan.tile_nchunks, x, xdot, (double *)y, plan.nrb,             \
+                       tile_doubles, part_pq, d, A.nnz, plan.cyclic ? 1 : 0, A.col)
 #define DPCG_LAUNCH_TILE(CTLV, DOTV)                                                          \
     do {                                                                                      \
-        if (plan.stream_nt) {                                                                 \
+        if (plan.tile_mixed) {                                                                \
+            if (plan.tile_max_chunks <= 20) DPCG_LAUNCH_TILE_MIX(CTLV, DOTV, 5);              \
+            else DPCG_LAUNCH_TILE_MIX(CTLV, DOTV, (kTileMaxChunks * kTileChunk / kBlock));    \
+        } else if (plan.stream_nt) {                                                          \
             if (plan.tile_max_chunks <= 20) DPCG_LAUNCH_TILE_X(CTLV, DOTV, 5, true);          \
             else DPCG_LAUNCH_TILE_X(CTLV, DOTV, (kTileMaxChunks * kTileChunk / kBlock), true);  \
         } else {                                                                              \
@@ -542,6 +589,7 @@ static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, 
         else if (dot) DPCG_LAUNCH_TILE(false, true);
         else DPCG_LAUNCH_TILE(false, false);
 #undef DPCG_LAUNCH_TILE
+#undef DPCG_LAUNCH_TILE_MIX
 #undef DPCG_LAUNCH_TILE_X
     } else if (plan.kernel == SPMV_STREAM || plan.kernel == SPMV_TILE) {
         if (c && dot) DPCG_LAUNCH_STREAM(true, true);

@@ -505,7 +505,8 @@ class CsrSystem:
         flag, ratio = C.c_int(0), C.c_double(0.0)
         L.check(L.lib().dpcg_get_permutation(self._h, C.byref(flag), None, C.byref(ratio)))
         return {"n": n.value, "nnz": nnz.value, "spmv_kernel": ("stream", "vector", "tile")[k.value & 15],
-                "two_kernel_updates": bool(k.value & 16), "spmv_nt": bool(k.value & 32), "reordered": bool(flag.value),
+                "two_kernel_updates": bool(k.value & 16), "spmv_nt": bool(k.value & 32), "spmv_mixed_tiles": bool(k.value & 64),
+                "spmv_cyclic": bool(k.value & 128), "reordered": bool(flag.value),
                 "gather_ratio": ratio.value,
                 "precond": pk.value, "precond_nnz": pn.value, "levels_lower": ll.value, "levels_upper": lu.value}
 

@@ -94,7 +94,9 @@ int dpcg_create(dpcg_handle_t *out, int64_t n, int64_t nnz, const int32_t *rowpt
 int dpcg_destroy(dpcg_handle_t h);
 /* Introspection (any out pointer may be NULL).  spmv_kernel: 0 gather (CSR-stream), 1 CSR-vector, 2 x-tile; +16 when
  * a default solve runs two-kernel updates (see DPCG_NO_FUSE), +32 when the x-tile kernel reads its once-read streams and
- * writes y non-temporally (streams beyond the Infinity Cache).  precond_nnz: nnz of M (CSR) or of L. */
+ * writes y non-temporally (streams beyond the Infinity Cache), +64 when some 256-row blocks of the x-tile plan touch too many
+ * places of x for an LDS tile and gather instead, +128 when the row blocks are dealt out to the workgroups cyclically instead of
+ * in slabs.  precond_nnz: nnz of M (CSR) or of L. */
 int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spmv_kernel, int *precond_kind,
                   int64_t *precond_nnz, int *n_levels_lower, int *n_levels_upper);
 

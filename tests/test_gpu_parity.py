@@ -2520,3 +2520,38 @@ def test_mixed_precision_equals_the_device_tree_oracle_bit_for_bit(D, name, make
     xs = res.x.cpu().numpy()
     assert np.array_equal(xs[perm] if perm is not None else xs, x)
     S.close()
+
+
+def test_spmv_tile_plan_with_blocks_that_gather(D):
+    """An x-tile plan need not cover every block: a 256-row block whose columns touch more than 40 chunks of x (an OpenFOAM
+    numbering whose refined cells were appended couples some blocks to dozens of places) gathers through the L2 inside the same
+    kernel (k_spmv_tile<..., MIX>), the others keep their LDS tiles -- round 3 dropped the whole system to the gather kernel.
+    Same bits: A @ x equals the CPU row sums, and the Jacobi PCG equals the device-tree oracle bit for bit."""
+    m = 700
+    A0 = O.poisson2d(m)
+    n = A0.shape[0]
+    rng = np.random.default_rng(3)
+    blocks = np.arange(0, n // 256, 9)                                   # every ninth block gets 60 couplings to far places
+    rows = (blocks[:, None] * 256 + rng.integers(0, 256, (blocks.size, 60))).ravel()
+    cols = rng.integers(0, n, rows.size)
+    keep = np.abs(rows - cols) > 4 * m
+    E = sp.coo_matrix((np.full(int(keep.sum()), -0.25), (rows[keep], cols[keep])), shape=(n, n)).tocsr()
+    E.sum_duplicates()
+    Esym = (E + E.T).tocsr()
+    A = (A0 + Esym + sp.diags(np.asarray(abs(Esym).sum(axis=1)).ravel())).tocsr()
+    A.sort_indices()
+    S = D.CsrSystem.from_any(A, reorder=None)
+    info = S.info()
+    assert info["spmv_kernel"] == "tile" and info["spmv_mixed_tiles"] and not info["reordered"], info
+    x = O.rhs(n, 5)
+    assert np.array_equal((S @ _dev(x)).cpu().numpy(), CO.spmv(A, x))
+    assert np.array_equal(S.spmv_f32(_dev(x).float()).cpu().numpy(), CO.spmv_f32(A, x.astype(np.float32)))     # fp32 groups of four
+    S.set_preconditioner(D.Jacobi())
+    b = O.rhs(n, 0)
+    res = S.solve(_dev(b), max_iter=200)
+    _, it, hist, xo = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A), max_iter=200, device_tree=S.reduction_geometry())
+    assert res.iterations == it and np.array_equal(res.res_history, hist) and np.array_equal(res.x.cpu().numpy(), xo)
+    mixed = S.solve(_dev(b), max_iter=200, flags=D._lib.SPMV_F32)
+    _, itm, hm, _ = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A), max_iter=200, mixed=True, device_tree=S.reduction_geometry())
+    assert mixed.iterations == itm and np.array_equal(mixed.res_history, hm)
+    S.close()
