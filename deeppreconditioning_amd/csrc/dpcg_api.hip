@@ -216,9 +216,13 @@ int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s, bool allow_tile) {
             DPCG_HIP(hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
             DPCG_HIP(hipStreamSynchronize(s));
             dev_free(d_flags);
-            // blocks that touch more than kTileMaxChunks chunks gather instead (k_spmv_tile<..., MIX>): worth it while they are few
-            // (DPCG_TILE_MIX_MAX: largest share of such blocks in percent, development knob; 0 = the round-3 behaviour)
-            static const int mix_max = [] { const char *e = getenv("DPCG_TILE_MIX_MAX"); return e ? atoi(e) : 30; }();
+            // Blocks that touch more than kTileMaxChunks chunks can gather instead (k_spmv_tile<..., MIX>, same bits).  OFF by default
+            // (DPCG_TILE_MIX_MAX = largest share of such blocks in percent): on the system that motivated it -- the 1M-row quadtree
+            // mesh in OpenFOAM's numbering, 12 % of the blocks at 41-51 chunks, the others at 25 on average -- the plan is SLOWER than
+            // the gather kernel (19.7 vs 16.7 us: tiles of 40 chunks stage 6.4 x the vector and leave 4 workgroups per CU); what that
+            // system wants is the reordering (14.2 us).  profiles/r04_mesh_probe_mix.txt
+            const char *mix_env = getenv("DPCG_TILE_MIX_MAX");
+            const int mix_max = mix_env ? atoi(mix_env) : 0;
             const bool mix_ok = h_flags[2] == 0 || (int64_t)h_flags[2] * 100 <= (int64_t)mix_max * plan.nrb;
             if (h_flags[0] == 1 && h_flags[1] > 0 && mix_ok) {
                 plan.kernel = SPMV_TILE;
@@ -571,18 +575,6 @@ extern "C" int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spm
     if ((n_levels_lower || n_levels_upper) && h->lvlL.n_levels < 0) DPCG_TRY(count_levels_on_demand(h));
     if (n_levels_lower) *n_levels_lower = h->lvlL.n_levels;
     if (n_levels_upper) *n_levels_upper = h->lvlU.n_levels;
-    return DPCG_OK;
-}
-
-extern "C" int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[8]) {
-    if (!h || !out) return invalid("dpcg_get_reduction_geometry: NULL argument");
-    out[0] = h->planA.grid;
-    out[1] = h->planA.nrb;
-    out[2] = (h->planA.kernel == SPMV_TILE && h->planA.cyclic) ? 1 : 0;
-    out[3] = h->vec_grid;
-    out[4] = fuse_eligible(h, 0, nullptr) ? 1 : 0;
-    out[5] = h->planA.kernel;
-    out[6] = out[7] = 0;
     return DPCG_OK;
 }
 

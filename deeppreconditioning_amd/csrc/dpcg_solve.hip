@@ -489,6 +489,20 @@ static bool team_eligible(const dpcg_system *h, int flags, const double *x_true)
     return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI;
 }
 
+extern "C" int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[8]) {
+    if (!h || !out) return invalid("dpcg_get_reduction_geometry: NULL argument");
+    out[0] = h->planA.grid;
+    out[1] = h->planA.nrb;
+    out[2] = (h->planA.kernel == SPMV_TILE && h->planA.cyclic) ? 1 : 0;
+    out[3] = h->vec_grid;
+    out[4] = fuse_eligible(h, 0, nullptr) ? 1 : 0;
+    out[5] = h->planA.kernel;
+    // threads of the one-workgroup solve a default call takes (0: not that form)
+    out[6] = small_eligible(h, 0, nullptr) ? (small_variant((int)h->A.n, h->planA.max_row_len, h->precond) % 16 != 0 ? 768 : 1024) : 0;
+    out[7] = team_eligible(h, 0, nullptr) ? 1 : 0;
+    return DPCG_OK;
+}
+
 static std::mutex &team_launch_mutex() {
     static std::mutex *m = new std::mutex();
     return *m;

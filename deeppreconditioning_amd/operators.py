@@ -516,7 +516,7 @@ class CsrSystem:
         out = (C.c_int32 * 8)()
         L.check(L.lib().dpcg_get_reduction_geometry(self._h, out))
         return {"spmv_grid": out[0], "nrb": out[1], "cyclic": out[2], "vec_grid": out[3], "two_kernel_updates": bool(out[4]),
-                "spmv_kernel": ("stream", "vector", "tile")[out[5]]}
+                "spmv_kernel": ("stream", "vector", "tile")[out[5]], "small_threads": out[6], "team_eligible": bool(out[7])}
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:

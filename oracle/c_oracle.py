@@ -135,15 +135,18 @@ def pcg(A: sp.csr_matrix, b: np.ndarray, kind: str = "none", *, dinv=None, M=Non
     dinv / M / L stay in the caller's numbering: z' = P M P^T r' (orc_pcg_perm).
     device_tree: {"spmv_grid", "nrb", "cyclic", "vec_grid"} (CsrSystem.reduction_geometry() of the handle under test): every dot
     product is summed in the DEVICE's reduction tree (orc_set_dot_tree) instead of the oracle's fixed blocks -- for kind "none" /
-    "jacobi" the history then equals the multi-launch HIP solve's BIT FOR BIT."""
+    "jacobi" the history then equals the multi-launch HIP solve's BIT FOR BIT.  "form": "small" (+ "small_threads") restates the
+    one-workgroup solve of systems up to 6144 rows -- every preconditioner kind it serves: none / jacobi / csr / llt_multiply --,
+    "form": "team" the 32-workgroup team solve."""
     if device_tree is not None:
+        form = {"multi": 0, "small": 1, "team": 2}[device_tree.get("form", "multi")]
         lib().orc_set_dot_tree(1, int(device_tree["spmv_grid"]), int(device_tree["nrb"]), int(device_tree["cyclic"]),
-                               int(device_tree["vec_grid"]))
+                               int(device_tree["vec_grid"]), form, int(device_tree.get("small_threads", 0)))
         try:
             return pcg(A, b, kind, dinv=dinv, M=M, L=L, x0=x0, rtol=rtol, max_iter=max_iter, init_check=init_check, mixed=mixed,
                        precond_perm=precond_perm)
         finally:
-            lib().orc_set_dot_tree(0, 0, 0, 0, 0)
+            lib().orc_set_dot_tree(0, 0, 0, 0, 0, 0, 0)
     n = A.shape[0]
     rp, ci, v = _csr_parts(A)
     b = np.ascontiguousarray(b, dtype=np.float64)

@@ -2522,11 +2522,13 @@ def test_mixed_precision_equals_the_device_tree_oracle_bit_for_bit(D, name, make
     S.close()
 
 
-def test_spmv_tile_plan_with_blocks_that_gather(D):
+def test_spmv_tile_plan_with_blocks_that_gather(D, monkeypatch):
     """An x-tile plan need not cover every block: a 256-row block whose columns touch more than 40 chunks of x (an OpenFOAM
-    numbering whose refined cells were appended couples some blocks to dozens of places) gathers through the L2 inside the same
-    kernel (k_spmv_tile<..., MIX>), the others keep their LDS tiles -- round 3 dropped the whole system to the gather kernel.
-    Same bits: A @ x equals the CPU row sums, and the Jacobi PCG equals the device-tree oracle bit for bit."""
+    numbering whose refined cells were appended couples some blocks to dozens of places) can gather through the L2 inside the
+    same kernel (k_spmv_tile<..., MIX>) while the others keep their LDS tiles.  Opt-in (DPCG_TILE_MIX_MAX: on the quadtree mesh
+    that motivated it the gather kernel is faster, profiles/r04_mesh_probe_mix.txt), but the same bits: A @ x equals the CPU row
+    sums, the Jacobi PCG -- fp64 and mixed (fp32 groups of four) -- equals the device-tree oracle bit for bit."""
+    monkeypatch.setenv("DPCG_TILE_MIX_MAX", "30")
     m = 700
     A0 = O.poisson2d(m)
     n = A0.shape[0]
@@ -2545,7 +2547,7 @@ def test_spmv_tile_plan_with_blocks_that_gather(D):
     assert info["spmv_kernel"] == "tile" and info["spmv_mixed_tiles"] and not info["reordered"], info
     x = O.rhs(n, 5)
     assert np.array_equal((S @ _dev(x)).cpu().numpy(), CO.spmv(A, x))
-    assert np.array_equal(S.spmv_f32(_dev(x).float()).cpu().numpy(), CO.spmv_f32(A, x.astype(np.float32)))     # fp32 groups of four
+    assert np.array_equal(S.spmv_f32(_dev(x.astype(np.float32))).cpu().numpy(), CO.spmv_mixed(A, x).astype(np.float32))
     S.set_preconditioner(D.Jacobi())
     b = O.rhs(n, 0)
     res = S.solve(_dev(b), max_iter=200)
@@ -2554,4 +2556,62 @@ def test_spmv_tile_plan_with_blocks_that_gather(D):
     mixed = S.solve(_dev(b), max_iter=200, flags=D._lib.SPMV_F32)
     _, itm, hm, _ = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A), max_iter=200, mixed=True, device_tree=S.reduction_geometry())
     assert mixed.iterations == itm and np.array_equal(mixed.res_history, hm)
+    S.close()
+
+
+def _lower_factor_like_the_cnn(A, seed):
+    return O.learned_like_factor_preconditioning(A, seed=seed)
+
+
+@pytest.mark.parametrize("name,make", [("poisson2d_49", lambda: O.poisson2d(49)),                     # 2 401 rows: the reference's mesh size
+                                       ("unstructured2d_52", lambda: O.unstructured_like(O.poisson2d(52), seed=6)),
+                                       ("quadtree_45", lambda: O.quadtree_fv_laplacian(45, 3)),
+                                       ("poisson3d_18", lambda: O.poisson3d(18)),                     # 5 832 rows, 7 entries a row: the streamed-matrix variant
+                                       ("delaunay_4000", lambda: O.delaunay_laplacian(4000, 1))])
+def test_one_workgroup_solve_equals_the_device_tree_oracle_bit_for_bit(D, name, make):
+    """The reference's own systems have 2.4K-5.5K rows: libdpcg solves them in ONE workgroup (dpcg_small.hip).  With that kernel's
+    reduction tree in the oracle (`form="small"`) the whole solve -- history, count, x -- equals the CPU restatement bit for bit for
+    EVERY technique the harness runs through it: vanilla, Jacobi, M = L L^T as one CSR (the reference's own, chaotic one:
+    test.py:88,105 -- no window, no bound here) and z = L (L^T r)."""
+    A = make()
+    n = A.shape[0]
+    assert n <= 6144
+    S = D.CsrSystem.from_any(A)
+    b = O.rhs(n, 1)
+    L0 = CO.ic0(A)
+    Lc = _lower_factor_like_the_cnn(A, 2)
+    M0 = (L0 @ L0.T).tocsr()
+    M0.sort_indices()
+    cases = [("none", None, {}), ("jacobi", D.Jacobi(), dict(dinv=O.jacobi_dinv(A))), ("csr", M0, dict(M=M0)),
+             ("llt_multiply", D.LLtMultiply(L0), dict(L=L0)), ("llt_multiply", D.LLtMultiply(Lc), dict(L=Lc))]
+    for kind, pc, okw in cases:
+        S.set_preconditioner(pc)
+        geo = S.reduction_geometry()
+        assert geo["small_threads"] in (768, 1024), geo
+        for x0 in (None, O.rhs(n, 4)):
+            res = S.solve(_dev(b), None if x0 is None else _dev(x0))
+            _, it, hist, x = CO.pcg(A, b, kind, x0=x0, device_tree={**geo, "form": "small"}, **okw)
+            assert res.iterations == it, (name, kind, geo)
+            assert np.array_equal(res.res_history, hist), (name, kind, geo, int(np.argmax(res.res_history != hist)))
+            assert np.array_equal(res.x.cpu().numpy(), x), (name, kind)
+    S.close()
+
+
+@pytest.mark.parametrize("name,make", [("poisson2d_256", lambda: O.poisson2d(256)), ("poisson3d_33", lambda: O.poisson3d(33)),
+                                       ("quadtree_150", lambda: O.quadtree_fv_laplacian(150, 2, n_blobs=10))])
+def test_team_solve_equals_the_device_tree_oracle_bit_for_bit(D, name, make):
+    """The team solve of mid-size systems (32 workgroups per system, dpcg_team.hip) against the oracle with THAT tree."""
+    A = make()
+    n = A.shape[0]
+    S = D.CsrSystem.from_any(A, reorder=None)
+    b = O.rhs(n, 1)
+    for kind, pc, okw in (("jacobi", D.Jacobi(), dict(dinv=O.jacobi_dinv(A))), ("none", None, {})):
+        S.set_preconditioner(pc)
+        geo = S.reduction_geometry()
+        if not geo["team_eligible"]:
+            pytest.skip("rows longer than the team kernel keeps in registers")
+        res = S.solve(_dev(b), flags=D._lib.TEAM)
+        _, it, hist, x = CO.pcg(A, b, kind, device_tree={**geo, "form": "team"}, **okw)
+        assert res.iterations == it and np.array_equal(res.res_history, hist), (name, kind, int(np.argmax(res.res_history != hist)))
+        assert np.array_equal(res.x.cpu().numpy(), x)
     S.close()

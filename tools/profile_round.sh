@@ -20,6 +20,8 @@ rm -rf $out/${tag}_c3_trace
 rocprofv3 --kernel-trace --output-format csv -d $out/${tag}_c3_trace -- python3 $OLDPWD/tools/trace_run_c3.py > $out/${tag}_c3_trace.log 2>&1
 rm -rf $out/${tag}_c3mc_trace
 rocprofv3 --kernel-trace --output-format csv -d $out/${tag}_c3mc_trace -- python3 $OLDPWD/tools/trace_run_c3.py multicolor > $out/${tag}_c3mc_trace.log 2>&1
+rm -rf $out/${tag}_cnn_stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_cnn_stats -- python3 $OLDPWD/tools/trace_run_cnn.py > $out/${tag}_cnn_stats.log 2>&1
 # keep the merged-back volume small: only the CSVs that the reports read
-find $out/${tag}_stats $out/${tag}_stats_c4 $out/${tag}_c3_trace $out/${tag}_c3mc_trace $out/${tag}_pmc_* -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' ! -name '*kernel_trace.csv' -delete
+find $out/${tag}_stats $out/${tag}_stats_c4 $out/${tag}_cnn_stats $out/${tag}_c3_trace $out/${tag}_c3mc_trace $out/${tag}_pmc_* -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' ! -name '*kernel_trace.csv' -delete
 ls -la $out/${tag}_stats/* | head
