@@ -235,7 +235,7 @@ int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s, bool allow_tile) {
                 // ... and walked by the whole grid together (row blocks dealt out cyclically) instead of in slabs
                 // (DPCG_SPMV_CYCLIC=0/1 overrides: development knob)
                 static const int cyc_knob = [] { const char *e = getenv("DPCG_SPMV_CYCLIC"); return e ? atoi(e) : -1; }();
-                plan.cyclic = cyc_knob >= 0 ? cyc_knob != 0 : plan.stream_nt;
+                plan.cyclic = cyc_knob >= 0 ? cyc_knob : (plan.stream_nt ? 2 : 0);     // 2: an XCD's blocks of a pass are one run (256^3: 272 -> 267 us)
                 const size_t lds = (size_t)(h_flags[1] * kTileChunk + kStreamCap + 8) * sizeof(double);
                 // (cyclic: THREE workgroups per CU -- with the grid walking together, each workgroup's own one-block-ahead prefetch
                 // carries the latency, and fewer workgroups keep the window the chip reads at any instant narrow; 256^3, us per

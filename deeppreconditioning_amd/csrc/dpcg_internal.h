@@ -55,7 +55,7 @@ struct SpmvPlan {
     int tile_max_chunks = 0;           // largest chunk count of any block (sizes the dynamic LDS)
     bool stream_nt = false;            // x-tile kernel: once-read streams and y non-temporal (streams beyond the Infinity Cache)
     bool tile_mixed = false;           // x-tile kernel: some blocks have no tile (tile_nchunks = -1) and gather instead
-    bool cyclic = false;               // x-tile kernel: row blocks dealt out cyclically (b, b + G, ...) instead of in slabs (see k_spmv_tile)
+    int cyclic = 0;                    // x-tile kernel: row blocks dealt out cyclically (b, b + G, ...) instead of in slabs; 2: XCD runs inside a pass (see k_spmv_tile)
     int max_row_len = 0;               // longest row (the team kernel keeps rows of <= 7 entries in registers)
 };
 
@@ -168,6 +168,7 @@ struct Levels {
     std::vector<int> sw_blk0;              // host: first block of each level in sw_chunks / sw_nchunks
     std::vector<int> sw_max_chunks;        // host: per level the largest chunk count of a block (0: the level keeps the gather sweep)
     bool sweep_nt = false;                 // the factor's stream exceeds the Infinity Cache: read non-temporally
+    bool sweep_cyclic = false;             // ... and its blocks dealt out cyclically, three workgroups per CU (as the x-tile SpMV's)
     // L only, when L^T's first level is L's last one (levels of L^T = levels of L reversed): position here -> position in
     // L^T's numbering, so that the last lower sweep can emit the first level of the upper solve (z = y / d) as well
     int32_t *lm_to_upper = nullptr;

@@ -463,7 +463,10 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
                 if (most > 0) {             // as make_plan: workgroups per CU by the LDS a block takes, a multiple of 8
                     const size_t lds = (size_t)(most * kTileChunk + kStreamCap + 8) * sizeof(double);
                     const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
-                    static const int grid_cap = [] { const char *e = getenv("DPCG_SWEEP_GRID"); return e ? atoi(e) : 1024; }();
+                    static const int grid_knob = [] { const char *e = getenv("DPCG_SWEEP_GRID"); return e ? atoi(e) : 0; }();
+                    static const int cyc_knob = [] { const char *e = getenv("DPCG_SWEEP_CYCLIC"); return e ? atoi(e) : -1; }();
+                    lv.sweep_cyclic = cyc_knob >= 0 ? cyc_knob != 0 : lv.sweep_nt;
+                    const int grid_cap = grid_knob > 0 ? grid_knob : (lv.sweep_cyclic ? 768 : 1024);
                     int g = (int)std::min<int64_t>(blocks, std::min<int64_t>(std::min(per_cu * 256, grid_cap), kMaxSpmvGrid));
                     if (g > 8) g -= g % 8;
                     lv.sweep_grid = std::max(1, g);

@@ -493,7 +493,7 @@ extern "C" int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[8]) {
     if (!h || !out) return invalid("dpcg_get_reduction_geometry: NULL argument");
     out[0] = h->planA.grid;
     out[1] = h->planA.nrb;
-    out[2] = (h->planA.kernel == SPMV_TILE && h->planA.cyclic) ? 1 : 0;
+    out[2] = h->planA.kernel == SPMV_TILE ? h->planA.cyclic : 0;       // 0 slabs, 1 cyclic, 2 cyclic with XCD runs inside a pass
     out[3] = h->vec_grid;
     out[4] = fuse_eligible(h, 0, nullptr) ? 1 : 0;
     out[5] = h->planA.kernel;

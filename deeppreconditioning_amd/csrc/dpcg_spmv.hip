@@ -398,7 +398,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv_tile(int64_t n, const int32_t *
     // stream 5.3 -> 5.6 TB/s, non-temporal 5.4 -> 6.0); row blocks a plane apart still meet in one XCD when G is a multiple of 8.
     int rb_lo, rb_hi, rb_step = 1;
     if (cyclic) {
-        rb_lo = blockIdx.x;
+        // (cyclic == 2: inside every pass of G blocks an XCD takes a contiguous run of them -- the window the chip reads is the
+        // same, the x halo of neighbouring row blocks is shared in that XCD's L2 again)
+        rb_lo = cyclic == 2 ? virtual_block() : (int)blockIdx.x;
         rb_hi = nrb;
         rb_step = gridDim.x;
     } else {
@@ -567,11 +569,11 @@ static void spmv_dispatch(const CsrDev &A, const SpmvPlan &plan, const VT *val, 
 #define DPCG_LAUNCH_TILE_X(CTLV, DOTV, XTV, NTV)                                                                         \
     hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV, XTV, VT, XT, NTV>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr, \
                        val, plan.tile_lidx, plan.tile_chunks, plan.tile_nchunks, x, xdot, (double *)y, plan.nrb,         \
-                       tile_doubles, part_pq, d, A.nnz, plan.cyclic ? 1 : 0, A.col)
+                       tile_doubles, part_pq, d, A.nnz, plan.cyclic, A.col)
 #define DPCG_LAUNCH_TILE_MIX(CTLV, DOTV, XTV)                                                                                  \
     hipLaunchKernelGGL((k_spmv_tile<CTLV, DOTV, XTV, VT, XT, false, true>), dim3(plan.grid), dim3(kBlock), lds, s, A.n, A.rowptr, \
                        val, plan.tile_lidx, plan.tile_chunks, plan.tile_nchunks, x, xdot, (double *)y, plan.nrb,             \
-                       tile_doubles, part_pq, d, A.nnz, plan.cyclic ? 1 : 0, A.col)
+                       tile_doubles, part_pq, d, A.nnz, plan.cyclic, A.col)
 #define DPCG_LAUNCH_TILE(CTLV, DOTV)                                                          \
     do {                                                                                      \
         if (plan.tile_mixed) {                                                                \

@@ -1475,7 +1475,8 @@ __global__ __launch_bounds__(kBlock) void k_lm_sweep_tile(int j0, int count, int
                                                           const int32_t *__restrict__ src_map, double *out, double *__restrict__ dst,
                                                           const int32_t *__restrict__ rows, const double *__restrict__ dotv,
                                                           double *__restrict__ part, double *__restrict__ out2,
-                                                          const int32_t *__restrict__ map2, int accumulate, const int *done) {
+                                                          const int32_t *__restrict__ map2, int accumulate, const int *done,
+                                                          int cyclic) {
     if (done && *done) return;   // the solve has converged: the rest of the enqueued updates are no-ops
     constexpr int U = kStreamCap / kBlock;
     constexpr int UP = U / 2;
@@ -1485,8 +1486,16 @@ __global__ __launch_bounds__(kBlock) void k_lm_sweep_tile(int j0, int count, int
     double *sh = prod + kStreamCap + 4;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int nblk = (count + kBlock - 1) / kBlock;
-    int b_lo, b_hi;
-    split_range(nblk, virtual_block(), b_lo, b_hi);
+    // slabs, or -- a factor beyond the Infinity Cache -- the blocks dealt out cyclically so that the grid walks the streams together
+    // (see k_spmv_tile)
+    int b_lo, b_hi, b_step = 1;
+    if (cyclic) {
+        b_lo = virtual_block();               // (inside a pass an XCD takes one contiguous run of blocks: see k_spmv_tile)
+        b_hi = nblk;
+        b_step = gridDim.x;
+    } else {
+        split_range(nblk, virtual_block(), b_lo, b_hi);
+    }
     typedef double VPair __attribute__((ext_vector_type(2)));
     typedef unsigned short IPair __attribute__((ext_vector_type(2)));
     constexpr int XP = (XT * (kBlock / 64) + 7) / 8;
@@ -1536,7 +1545,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_sweep_tile(int j0, int count, int
     };
     if (b_lo < b_hi) fetch(b_lo);
     double dot = 0.0;
-    for (int blk = b_lo; blk < b_hi; ++blk) {
+    for (int blk = b_lo; blk < b_hi; blk += b_step) {
         const int j = j0 + blk * kBlock + t;
         const int ks = rs, ke = re, cnt_cur = cnt, own_c = own, m2_c = m2;
         const double bi_c = bi, dv_c = dv;
@@ -1559,7 +1568,7 @@ __global__ __launch_bounds__(kBlock) void k_lm_sweep_tile(int j0, int count, int
                 *reinterpret_cast<double2 *>(prod + k) = pp;
             }
         }
-        if (blk + 1 < b_hi) fetch(blk + 1);  // the next block's stream, right-hand side and chunks are in flight from here on
+        if (blk + b_step < b_hi) fetch(blk + b_step);  // the next block's stream, right-hand side and chunks are in flight from here on
         __syncthreads();
         if (live_c) {
             double acc = bi_c;
@@ -1613,11 +1622,11 @@ static void launch_sweeps(const Levels &lv, bool upper, const double *src, const
     if (lv.sweep_nt)                                                                                                           \
         hipLaunchKernelGGL((k_lm_sweep_tile<UP_, XT_, true>), dim3(grid), dim3(kBlock), lds, s, j0, cnt, (int)lv.level_ptr.back(), \
                            lv.lo_rowptr, lv.lo_val, lv.sw_lidx, ch, nch, tile_doubles, src, src_map, lv.lm_out, d, lv.rows, dw, pl, \
-                           o2, m2, acc, done);                                                                                     \
+                           o2, m2, acc, done, lv.sweep_cyclic ? 1 : 0);                                                            \
     else                                                                                                                       \
     hipLaunchKernelGGL((k_lm_sweep_tile<UP_, XT_>), dim3(grid), dim3(kBlock), lds, s, j0, cnt, (int)lv.level_ptr.back(), \
                        lv.lo_rowptr, lv.lo_val, lv.sw_lidx, ch, nch, tile_doubles, src, src_map, lv.lm_out, d, lv.rows, dw, pl, \
-                       o2, m2, acc, done);                                                                                     \
+                       o2, m2, acc, done, 0);                                                                                  \
     } while (0)
             if (upper) {
                 if (mc <= 20) DPCG_SWEEP_TILE(true, 5);

@@ -185,7 +185,7 @@ int dpcg_set_precond_callback(dpcg_handle_t h, dpcg_precond_fn fn, void *user);
 /* The geometry of the handle's reductions, for a checker that wants to sum in the same order (oracle/pcg_oracle.c,
  * orc_set_dot_tree: with it the CPU restatement reproduces the multi-launch solve's residual history BIT FOR BIT for M = I /
  * Jacobi): out[0] = workgroups of the SpMV kernel of the PCG loop, out[1] = its 256-row blocks, out[2] = 1 when the blocks are
- * dealt out cyclically (0: contiguous slabs), out[3] = workgroups of the vector kernels, out[4] = 1 when a solve with default
+ * dealt out cyclically, 2 when cyclically with an XCD's blocks of a pass contiguous (0: contiguous slabs), out[3] = workgroups of the vector kernels, out[4] = 1 when a solve with default
  * flags runs two-kernel updates, out[5] = the SpMV kernel (0 gather, 1 vector, 2 x-tile), out[6] = threads of the one-workgroup
  * solve when a default call takes that form (0 otherwise), out[7] = 1 when the system is eligible for the team solve. */
 int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[8]);

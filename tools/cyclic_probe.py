@@ -27,7 +27,9 @@ else:
         print(f"{dim}d {n}: SpMV {us:.2f} us, Jacobi {r.iterations / r.seconds:.0f} it/s ({r.iterations})")
 '''
 quick = len(sys.argv) > 1 and sys.argv[1] == "per_cu"
-todo = ([("c4", [{"DPCG_SPMV_CYCLIC": "1", "DPCG_SPMV_WG_PER_CU": w} for w in ("2", "3", "4", "5")])] if quick else
+xcd = len(sys.argv) > 1 and sys.argv[1] == "xcd"
+todo = ([("c4", [{"DPCG_SPMV_CYCLIC": c, "DPCG_SPMV_WG_PER_CU": w} for c in ("1", "2") for w in ("3", "4")])] if xcd else
+        [("c4", [{"DPCG_SPMV_CYCLIC": "1", "DPCG_SPMV_WG_PER_CU": w} for w in ("2", "3", "4", "5")])] if quick else
         [("c4", [{"DPCG_SPMV_CYCLIC": c, "DPCG_SPMV_WG_PER_CU": w} for c in "01" for w in ("4", "6", "8")]),
          ("c3", [{"DPCG_SPMV_CYCLIC": c} for c in "01"])])
 for what, settings in todo:
