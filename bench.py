@@ -418,6 +418,22 @@ def main() -> None:
                 "non_temporal_streams": bool(s4.info().get("spmv_nt", False)),
                 "us_per_launch_by_placement": [round(v * 1e3, 2) for v in samples],
                 "placement": "median of four creations of the system on fresh allocations"}
+            # the same kernel INSIDE the PCG loop (K2 / K3 stream 1.5 GB through the Infinity Cache between two SpMVs, so p is not
+            # resident when K1 starts): wall time per update of a 48-update solve, measured live; the in-loop K1 time itself needs the
+            # profiler -- the median of the committed kernel trace of tools/trace_run_c4.py is quoted beside it
+            b4 = poisson.rhs(s4.n, 0)
+            s4.solve(b4, max_iter=8, want_history=False)
+            r4 = s4.solve(b4, max_iter=48, want_history=False)
+            in_loop = {"pcg_us_per_update": round(r4.seconds / max(r4.iterations, 1) * 1e6, 1), "updates": r4.iterations}
+            tr = ROOT / "profiles" / "r04_kernel_trace_256cubed_summary.txt"
+            if tr.exists():
+                for ln in tr.read_text().splitlines():
+                    if ln.startswith("k_spmv_tile") and "median" in ln:
+                        in_loop["k1_us_median_in_loop_rocprof"] = float(ln.split("median")[1].split("us")[0])
+                        in_loop["k1_frac_in_loop_rocprof"] = round(b4_alg / (in_loop["k1_us_median_in_loop_rocprof"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                        in_loop["source"] = "profiles/r04_kernel_trace_256cubed_summary.txt (rocprofv3 --kernel-trace of tools/trace_run_c4.py)"
+                        break
+            line["roofline"]["hbm_bound_256cubed"]["in_loop"] = in_loop
             s4.close()
             del s4
         if world == 1 and not args.no_cpu_baseline:

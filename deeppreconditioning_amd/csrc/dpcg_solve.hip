@@ -489,7 +489,7 @@ static bool team_eligible(const dpcg_system *h, int flags, const double *x_true)
     return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI;
 }
 
-extern "C" int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[8]) {
+extern "C" int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]) {
     if (!h || !out) return invalid("dpcg_get_reduction_geometry: NULL argument");
     out[0] = h->planA.grid;
     out[1] = h->planA.nrb;
@@ -500,6 +500,28 @@ extern "C" int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[8]) {
     // threads of the one-workgroup solve a default call takes (0: not that form)
     out[6] = small_eligible(h, 0, nullptr) ? (small_variant((int)h->A.n, h->planA.max_row_len, h->precond) % 16 != 0 ? 768 : 1024) : 0;
     out[7] = team_eligible(h, 0, nullptr) ? 1 : 0;
+    // who sums <r,z> in a multi-launch update (cg.py:82): 0 k_update_r (M = I, Jacobi), 1 k_dot_partials, 2 k_lm_finish (way out of a
+    // level-major solve), 3 the SpMV that applied M (its plan in out[9..11]), 9 a tree the checker does not restate
+    int rzk = 0;
+    const SpmvPlan *pm = nullptr;
+    switch (h->precond) {
+        case DPCG_PRECOND_NONE: case DPCG_PRECOND_JACOBI: rzk = 0; break;
+        case DPCG_PRECOND_CSR: pm = &h->planM; break;
+        case DPCG_PRECOND_LLT_MULTIPLY: pm = &h->planL; break;
+        case DPCG_PRECOND_LLT_SOLVE:
+            rzk = h->lvlU.sweep ? 9 : ((h->lvlU.level_major && h->lvlU.strips.n_strips == 0) ? 2 : 1);
+            break;
+        default: rzk = 1; break;
+    }
+    out[9] = out[10] = out[11] = 0;
+    if (pm) {
+        rzk = pm->kernel == SPMV_VECTOR ? 9 : 3;
+        out[9] = pm->grid;
+        out[10] = pm->nrb;
+        out[11] = pm->kernel == SPMV_TILE ? pm->cyclic : 0;
+    }
+    out[8] = rzk;
+    out[12] = out[13] = out[14] = out[15] = 0;
     return DPCG_OK;
 }
 

@@ -513,10 +513,11 @@ class CsrSystem:
     def reduction_geometry(self) -> dict:
         """How the handle's kernels sum their dot products (dpcg_get_reduction_geometry): what a checker needs to add in the same
         order (oracle/c_oracle.pcg(..., device_tree=...))."""
-        out = (C.c_int32 * 8)()
+        out = (C.c_int32 * 16)()
         L.check(L.lib().dpcg_get_reduction_geometry(self._h, out))
         return {"spmv_grid": out[0], "nrb": out[1], "cyclic": out[2], "vec_grid": out[3], "two_kernel_updates": bool(out[4]),
-                "spmv_kernel": ("stream", "vector", "tile")[out[5]], "small_threads": out[6], "team_eligible": bool(out[7])}
+                "spmv_kernel": ("stream", "vector", "tile")[out[5]], "small_threads": out[6], "team_eligible": bool(out[7]),
+                "rz_kind": out[8], "m_grid": out[9], "m_nrb": out[10], "m_cyclic": out[11]}
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:

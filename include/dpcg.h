@@ -187,8 +187,11 @@ int dpcg_set_precond_callback(dpcg_handle_t h, dpcg_precond_fn fn, void *user);
  * Jacobi): out[0] = workgroups of the SpMV kernel of the PCG loop, out[1] = its 256-row blocks, out[2] = 1 when the blocks are
  * dealt out cyclically, 2 when cyclically with an XCD's blocks of a pass contiguous (0: contiguous slabs), out[3] = workgroups of the vector kernels, out[4] = 1 when a solve with default
  * flags runs two-kernel updates, out[5] = the SpMV kernel (0 gather, 1 vector, 2 x-tile), out[6] = threads of the one-workgroup
- * solve when a default call takes that form (0 otherwise), out[7] = 1 when the system is eligible for the team solve. */
-int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[8]);
+ * solve when a default call takes that form (0 otherwise), out[7] = 1 when the system is eligible for the team solve,
+ * out[8] = who sums <r,z> behind the CURRENT preconditioner in a multi-launch update (0 the r-update kernel, 1 a separate dot
+ * launch, 2 the way-out pass of a level-major triangular solve, 3 the SpMV that applied M -- its grid / row blocks / walk in
+ * out[9..11] --, 9 a tree the checker does not restate: colour sweeps, the CSR-vector kernel), out[12..15] = 0. */
+int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]);
 /* Copy the current factor L out (host arrays sized from dpcg_get_info's precond_nnz). */
 int dpcg_get_factor(dpcg_handle_t h, int32_t *rowptr, int32_t *col, double *val);
 

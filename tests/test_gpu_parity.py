@@ -2615,3 +2615,55 @@ def test_team_solve_equals_the_device_tree_oracle_bit_for_bit(D, name, make):
         assert res.iterations == it and np.array_equal(res.res_history, hist), (name, kind, int(np.argmax(res.res_history != hist)))
         assert np.array_equal(res.x.cpu().numpy(), x)
     S.close()
+
+
+@pytest.mark.parametrize("name,make,pc,okind", [
+    ("poisson2d_256_ic0_ring", lambda: O.poisson2d(256), "ic0", "llt_solve"),
+    ("poisson3d_40_ic0", lambda: O.poisson3d(40), "ic0", "llt_solve"),
+    ("poisson3d_64_ic0_strips", lambda: O.poisson3d(64), "ic0", "llt_solve"),
+    ("unstructured3d_100_ic0_level_major", lambda: O.unstructured_like(O.poisson3d(100), seed=0), "ic0", "llt_solve"),
+    ("quadtree_300_ic0", lambda: O.quadtree_fv_laplacian(300, 5), "ic0", "llt_solve"),
+    ("quadtree_random_300_ic0", lambda: O.quadtree_fv_laplacian(300, 5, numbering="random"), "ic0", "llt_solve"),
+    ("delaunay_100k_ic0", lambda: O.delaunay_laplacian(100000, 3), "ic0", "llt_solve"),
+    ("quadtree_96_icholt", lambda: O.quadtree_fv_laplacian(96, 2), "icholt", "llt_solve"),
+    ("poisson2d_100_ic0_multiplied", lambda: O.poisson2d(100), "ic0_multiply", "llt_multiply"),
+    ("poisson3d_30_ic0_multiplied", lambda: O.poisson3d(30), "ic0_multiply", "llt_multiply")])
+def test_applied_preconditioners_equal_the_device_tree_oracle_bit_for_bit(D, name, make, pc, okind):
+    """Round 4's bit-for-bit parity beyond M = I / Jacobi: behind a preconditioner that is APPLIED -- IC(0) / icholt by triangular
+    solves (LDS ring, strips, sync-free, level-major forms; reordered handles), z = L (L^T r) multiplied (the reference's chaotic
+    technique, test.py:88) -- <r,z> is summed by a separate launch, by the way-out pass of a level-major solve or by the SpMV that
+    applied M; `reduction_geometry()` says which, the oracle adds in that order, and history, count and x are EQUAL.  (IC(0)-PCG on
+    the quadtree meshes is the rounding-sensitive case of tests/test_meshes.py: one ulp in b moves its history by 1e-6.)"""
+    A = make()
+    n = A.shape[0]
+    S = D.CsrSystem.from_any(A)
+    b = O.rhs(n, 0)
+    perm = S.permutation() if S.reordered else None
+    if pc == "icholt":
+        S.set_preconditioner(D.ICholT("solve", add_fill_in=1, threshold=0.1))
+        Lref = O.icholt(A, 1, 0.1)
+    else:
+        S.set_preconditioner(D.IC0("solve" if pc == "ic0" else "multiply"))
+        Lref = CO.ic0(A)
+    assert np.array_equal(S.factor()[2], Lref.data)
+    geo = S.reduction_geometry()
+    assert geo["rz_kind"] in (1, 2, 3), geo
+    if perm is not None and okind == "llt_multiply":
+        pytest.skip("a reordered handle multiplies by P L P^T: other row sums than the caller-order oracle's")
+    B = _permuted(A, perm) if perm is not None else A
+    bb = b[perm] if perm is not None else b
+    kw = dict(precond_perm=perm) if perm is not None else {}
+    for flags in (D._lib.NO_SMALL, D._lib.NO_SMALL | D._lib.NO_FUSE):
+        res = S.solve(_dev(b), flags=flags, max_iter=400)
+        _, it, hist, x = CO.pcg(B, bb, okind, L=Lref, max_iter=400, device_tree=geo, **kw)
+        assert res.iterations == it, (name, geo, flags)
+        assert np.array_equal(res.res_history, hist), (name, geo, flags, int(np.argmax(res.res_history != hist)))
+        xs = res.x.cpu().numpy()
+        assert np.array_equal(xs[perm] if perm is not None else xs, x), (name, flags)
+    # a tree the oracle does not restate is said, not guessed: colour sweeps
+    if n >= 65536:
+        S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+        if S.reduction_geometry()["rz_kind"] == 9:
+            with pytest.raises(ValueError):
+                CO.pcg(B, bb, "llt_solve", L=Lref, device_tree=S.reduction_geometry(), **kw)
+    S.close()
