@@ -629,6 +629,78 @@ __global__ __launch_bounds__(kBlock) void k_recolor_class(int64_t n, const int32
     }
 }
 
+// A LAST colour class of a handful of vertices (greedy colourings of meshes with triangles leave such: 2-6 vertices of a fifth
+// colour on a 1M-row quadtree mesh) costs the triangular solves a level of its own -- two launches for nothing.  One wave folds it
+// away where a local move does: a vertex v of the last class takes colour c < last when no neighbour has c, or when exactly ONE
+// neighbour u has c and u can move to another colour c2 < last that none of u's neighbours has.  Vertices are taken one after
+// another in index order (moves see the moves before them): deterministic.  Whatever stays keeps its colour: never more colours.
+__global__ __launch_bounds__(kBlock) void k_collect_class(int64_t n, const int32_t *__restrict__ color, int cls, int *count, int *list) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride)
+        if (color[v] == cls) {
+            const int at = atomicAdd(count, 1);
+            if (at < 64) list[at] = (int)v;
+        }
+}
+__global__ __launch_bounds__(64) void k_fold_tiny_class(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                        int32_t *color, int last, const int *__restrict__ count_in,
+                                                        const int *__restrict__ list_in, int *left) {
+    __shared__ int list[64];
+    const int lane = threadIdx.x;
+    const int s_count = *count_in;
+    if (s_count > 64) {                                            // (not tiny after all: leave it)
+        if (lane == 0) *left = s_count;
+        return;
+    }
+    {   // the members in index order, whatever order the collection appended them in
+        const int mine = lane < s_count ? list_in[lane] : 0x7fffffff;
+        int rank = 0;
+        for (int o = 0; o < s_count; ++o) rank += list_in[o] < mine ? 1 : 0;
+        if (lane < s_count) list[rank] = mine;
+    }
+    __syncthreads();
+    const int count = s_count < 64 ? s_count : 64;
+    int remaining = s_count;
+    for (int q = 0; q < count; ++q) {
+        const int v = list[q];
+        const int dv = rp[v + 1] - rp[v];
+        if (dv > 64) continue;
+        const int u = lane < dv ? ci[rp[v] + lane] : v;            // lane <-> neighbour (the diagonal entry counts as "v itself")
+        const int cu = u != v ? __hip_atomic_load(color + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        bool done = false;
+        for (int c = 0; c < last && !done; ++c) {
+            const unsigned long long has = __ballot(cu == c);
+            const int cnt = __popcll(has);
+            if (cnt == 0) {
+                if (lane == 0) __hip_atomic_store(color + v, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                done = true;
+            } else if (cnt == 1) {
+                const int src = __ffsll((long long)has) - 1;
+                const int w = __shfl(u, src);                          // the one neighbour of colour c
+                const int dw = rp[w + 1] - rp[w];
+                if (dw > 64) continue;
+                const int x = lane < dw ? ci[rp[w] + lane] : w;
+                const int cx = (x != w && x != v) ? __hip_atomic_load(color + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+                for (int c2 = 0; c2 < last; ++c2) {
+                    if (c2 == c) continue;
+                    if (__ballot(cx == c2) == 0) {                     // w may take c2 (v leaves `last`, so v does not block it)
+                        if (lane == 0) {
+                            __hip_atomic_store(color + w, c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(color + v, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        done = true;
+                        break;
+                    }
+                }
+            }
+        }
+        if (done) --remaining;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the next vertex reads what this one stored
+        __syncthreads();
+    }
+    if (lane == 0) *left = remaining;
+}
+
 __global__ __launch_bounds__(kBlock) void k_color_histogram(int64_t n, const int32_t *__restrict__ color, int *hist) {
     __shared__ int sh[64];
     if (threadIdx.x < 64) sh[threadIdx.x] = 0;
@@ -637,6 +709,12 @@ __global__ __launch_bounds__(kBlock) void k_color_histogram(int64_t n, const int
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) atomicAdd(&sh[color[v] & 63], 1);
     __syncthreads();
     if (threadIdx.x < 64 && sh[threadIdx.x]) atomicAdd(hist + threadIdx.x, sh[threadIdx.x]);
+}
+
+static int h_hist_last_nonempty(const int *hist) {
+    for (int c = 63; c >= 0; --c)
+        if (hist[c] > 0) return hist[c];
+    return 0;
 }
 
 __global__ __launch_bounds__(kBlock) void k_remap_colors(int64_t n, int32_t *color, const int32_t *__restrict__ map) {
@@ -1031,7 +1109,25 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
             DPCG_HIP(hipMemcpyAsync(map.p, h_map, sizeof(h_map), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_remap_colors, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, color.p, map.p);
             DPCG_HIP(hipStreamSynchronize(s));      // (h_map is on the stack)
-            if (used <= 2 || pass == passes - 1) break;
+            if (used <= 2 || pass == passes - 1) {
+                // a last class of a handful of vertices is folded into the others where a local move does (never more colours)
+                static const bool fold_on = [] { const char *e = getenv("DPCG_COLOR_FOLD"); return !(e && e[0] == '0'); }();
+                if (fold_on && used > 2 && h_hist_last_nonempty(h_hist) <= 64) {
+                    Buf<int> members;
+                    DPCG_TRY(members.alloc(66));
+                    DPCG_HIP(hipMemsetAsync(members.p, 0, sizeof(int), s));
+                    hipLaunchKernelGGL(k_collect_class, dim3(rows_grid(n, 1024)), dim3(kBlock), 0, s, n, color.p, used - 1, members.p, members.p + 1);
+                    hipLaunchKernelGGL(k_fold_tiny_class, dim3(1), dim3(64), 0, s, n, A.rowptr, A.col, color.p, used - 1, members.p,
+                                       members.p + 1, members.p + 65);
+                    DPCG_HIP(hipMemsetAsync(flags.p + 2, 0, sizeof(int), s));
+                    hipLaunchKernelGGL(k_check_coloring, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, A.rowptr, A.col, color.p, flags.p + 2);
+                    int bad_fold = 0;
+                    DPCG_HIP(hipMemcpyAsync(&bad_fold, flags.p + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+                    DPCG_HIP(hipStreamSynchronize(s));
+                    if (bad_fold) return invalid("multicolour ordering: folding the last class left an improper colouring");
+                }
+                break;
+            }
             DPCG_HIP(hipMemsetAsync(iota.p, 0xff, (size_t)n * sizeof(int32_t), s));          // (iota: free until the sort below)
             for (int c = used - 1; c >= 0; --c)
                 hipLaunchKernelGGL(k_recolor_class, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, color.p, iota.p, c);

@@ -2476,7 +2476,7 @@ def test_history_equals_the_device_tree_oracle_bit_for_bit(D, name, make, flags,
         S = poisson.poisson_system(3, 256)
         rp, ci, v = (t.cpu().numpy() for t in poisson.poisson_csr(3, 256))
         A = sp.csr_matrix((v, ci, rp), shape=(S.n, S.n))
-        assert S.reduction_geometry()["cyclic"] == 1
+        assert S.reduction_geometry()["cyclic"] in (1, 2)
     else:
         A = make()
         S = D.CsrSystem.from_any(A)

@@ -3,8 +3,9 @@ hexRef8 numbering) and a Delaunay graph Laplacian (deeppreconditioning_amd/meshe
 
 CPU part: the product's generators and the oracle's give the same bits; the matrices are what they claim to be (symmetric,
 positive diagonal / non-positive off-diagonals, irreducibly diagonally dominant, irregular degrees, triangles).
-GPU part (`-m gpu`): SpMV bit-exact, Jacobi / IC(0) caller's order / IC(0) multicolour PCG against oracle/pcg_oracle.c --
-counts equal, residual histories within north_star's 1e-10 -- at ~10K rows and at the ~1M rows config 3 names.
+GPU part (`-m gpu`): SpMV bit-exact; Jacobi and IC(0) in the caller's order against oracle/pcg_oracle.c with the device's reduction
+trees -- counts, histories and x EQUAL --; IC(0) in multicolour order (colour sweeps) counts equal and histories within north_star's
+1e-10 while the recurrence is stable -- at ~10K rows and at the ~1M rows config 3 names.
 """
 
 import numpy as np
@@ -134,11 +135,11 @@ def _mesh_parity(D, A, expect, max_iter):
     assert np.array_equal(y[perm], CO.spmv(B, x[perm]))                       # bit-exact on the matrix the handle iterates on
     # Jacobi
     S.set_preconditioner(D.Jacobi())
-    res = S.solve(_dev(b), max_iter=max_iter)
-    it, hist, xs, dc, drift = _oracle_pair(B, b[perm], "jacobi", dinv=O.jacobi_dinv(B), max_iter=max_iter)
-    _check_history(res, it, hist, dc, drift, "jacobi")
-    if drift.max() < 1e-9:
-        np.testing.assert_allclose(res.x.cpu().numpy()[perm], xs, rtol=1e-6, atol=1e-9)
+    NO_SMALL = D._lib.NO_SMALL
+    res = S.solve(_dev(b), max_iter=max_iter, flags=NO_SMALL)
+    # (round 4) the oracle adds its dot products in the device's reduction tree: history, count and x are EQUAL
+    _, it, hist, xs = CO.pcg(B, b[perm], "jacobi", dinv=O.jacobi_dinv(B), max_iter=max_iter, device_tree=S.reduction_geometry())
+    assert res.iterations == it and np.array_equal(res.res_history, hist) and np.array_equal(res.x.cpu().numpy()[perm], xs)
     out = {"jacobi": it}
     # IC(0) in the caller's order: the factor of the CALLER's matrix bit for bit, applied by triangular solves
     S.set_preconditioner(D.IC0("solve"))
@@ -147,10 +148,12 @@ def _mesh_parity(D, A, expect, max_iter):
     assert np.array_equal(rp, Lref.indptr) and np.array_equal(ci, Lref.indices) and np.array_equal(v, Lref.data)
     zref = CO.sptrsv_upper(CO.transpose_csr(Lref), CO.sptrsv_lower(Lref, b))
     assert np.array_equal(S.precond_apply(_dev(b)).cpu().numpy(), zref)
-    res = S.solve(_dev(b), max_iter=max_iter)
+    res = S.solve(_dev(b), max_iter=max_iter, flags=NO_SMALL)
     kw = dict(precond_perm=perm) if S.reordered else {}
-    it, hist, _, dc, drift = _oracle_pair(B, b[perm], "llt_solve", L=Lref, max_iter=max_iter, **kw)
-    _check_history(res, it, hist, dc, drift, "ic0 caller")
+    geo = S.reduction_geometry()
+    assert geo["rz_kind"] in (1, 2), geo
+    _, it, hist, _ = CO.pcg(B, b[perm], "llt_solve", L=Lref, max_iter=max_iter, device_tree=geo, **kw)
+    assert res.iterations == it and np.array_equal(res.res_history, hist)      # bit for bit, rounding-sensitive as these systems are
     out["ic0_caller"] = (it, S.info()["levels_lower"])
     # IC(0) in multicolour order: IC(0) of Q A Q^T bit for bit, PCG through orc_pcg_perm
     S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
@@ -165,9 +168,14 @@ def _mesh_parity(D, A, expect, max_iter):
     assert np.array_equal(S.precond_apply(_dev(b)).cpu().numpy(), zq)
     qinv = np.empty(n, dtype=np.int32)
     qinv[q] = np.arange(n, dtype=np.int32)
-    res = S.solve(_dev(b), max_iter=max_iter)
-    it, hist, _, dc, drift = _oracle_pair(B, b[perm], "llt_solve", L=Lq, precond_perm=qinv[perm], max_iter=max_iter)
-    _check_history(res, it, hist, dc, drift, "ic0 multicolour")
+    res = S.solve(_dev(b), max_iter=max_iter, flags=NO_SMALL)
+    geo = S.reduction_geometry()
+    if geo["rz_kind"] in (1, 2):
+        _, it, hist, _ = CO.pcg(B, b[perm], "llt_solve", L=Lq, precond_perm=qinv[perm], max_iter=max_iter, device_tree=geo)
+        assert res.iterations == it and np.array_equal(res.res_history, hist)
+    else:        # colour sweeps sum <r,z> on the way in a tree of their own: 1e-10 while the recurrence is stable (see _check_history)
+        it, hist, _, dc, drift = _oracle_pair(B, b[perm], "llt_solve", L=Lq, precond_perm=qinv[perm], max_iter=max_iter)
+        _check_history(res, it, hist, dc, drift, "ic0 multicolour")
     out["ic0_multicolor"] = (it, nc)
     S.close()
     return out
