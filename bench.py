@@ -5,9 +5,12 @@
 A step = one pass of the hot path over one batch: every rank solves `--systems-per-gpu` (default 1)
 1M-DoF pressure-Poisson systems (3-D 7-point, 100^3, Jacobi-preconditioned fp64 PCG, rtol 1e-8 on
 <r,r>/<b,b>, max_iter 1024 -- the reference defaults, cg.py:51) that are already resident in HBM.
-N > 1: one process per GPU (torch.distributed over RCCL), systems sharded with no data-path
-collective; the timed region is bracketed by barrier + synchronize and the MAX over ranks is taken.
-Rank 0 prints ONE JSON line.  `value` = PCG iterations of all ranks / that time.
+N > 1: one process per GPU (torch.distributed over RCCL).  Rank 0 owns the batch description and SCATTERS it over the backend
+(3-integer specs of the synthetic systems -- rebuilt in the owner's HBM -- or, `--scatter arrays`, the CSR arrays and right-hand
+sides as grouped point-to-point sends), system s goes to rank s mod N, every rank solves its share with no data-path collective,
+the result records are GATHERED (all_gather).  The timed region (the solves) is bracketed by barrier + synchronize and the MAX
+over ranks is taken; `scatter_ms` / `gather_ms` are reported beside `value`, never inside it.  `--config4`: BASELINE config 4 as
+stated (64 x 256^3 over 8 GPUs, 8 per GPU).  Rank 0 prints ONE JSON line.  `value` = PCG iterations of all ranks / that time.
 """
 
 from __future__ import annotations

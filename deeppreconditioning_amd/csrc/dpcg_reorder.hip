@@ -634,32 +634,34 @@ __global__ __launch_bounds__(kBlock) void k_recolor_class(int64_t n, const int32
 // away where a local move does: a vertex v of the last class takes colour c < last when no neighbour has c, or when exactly ONE
 // neighbour u has c and u can move to another colour c2 < last that none of u's neighbours has.  Vertices are taken one after
 // another in index order (moves see the moves before them): deterministic.  Whatever stays keeps its colour: never more colours.
+constexpr int kFoldMax = 256;          // largest last class the fold looks at (one wave, ~3 us a vertex)
 __global__ __launch_bounds__(kBlock) void k_collect_class(int64_t n, const int32_t *__restrict__ color, int cls, int *count, int *list) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride)
         if (color[v] == cls) {
             const int at = atomicAdd(count, 1);
-            if (at < 64) list[at] = (int)v;
+            if (at < kFoldMax) list[at] = (int)v;
         }
 }
 __global__ __launch_bounds__(64) void k_fold_tiny_class(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                         int32_t *color, int last, const int *__restrict__ count_in,
                                                         const int *__restrict__ list_in, int *left) {
-    __shared__ int list[64];
+    __shared__ int list[kFoldMax];
     const int lane = threadIdx.x;
     const int s_count = *count_in;
-    if (s_count > 64) {                                            // (not tiny after all: leave it)
+    if (s_count > kFoldMax) {                                      // (not tiny after all: leave it)
         if (lane == 0) *left = s_count;
         return;
     }
-    {   // the members in index order, whatever order the collection appended them in
-        const int mine = lane < s_count ? list_in[lane] : 0x7fffffff;
+    // the members in index order, whatever order the collection appended them in
+    for (int e = lane; e < s_count; e += 64) {
+        const int mine = list_in[e];
         int rank = 0;
         for (int o = 0; o < s_count; ++o) rank += list_in[o] < mine ? 1 : 0;
-        if (lane < s_count) list[rank] = mine;
+        list[rank] = mine;
     }
     __syncthreads();
-    const int count = s_count < 64 ? s_count : 64;
+    const int count = s_count;
     int remaining = s_count;
     for (int q = 0; q < count; ++q) {
         const int v = list[q];
@@ -1112,13 +1114,13 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
             if (used <= 2 || pass == passes - 1) {
                 // a last class of a handful of vertices is folded into the others where a local move does (never more colours)
                 static const bool fold_on = [] { const char *e = getenv("DPCG_COLOR_FOLD"); return !(e && e[0] == '0'); }();
-                if (fold_on && used > 2 && h_hist_last_nonempty(h_hist) <= 64) {
+                if (fold_on && used > 2 && h_hist_last_nonempty(h_hist) <= kFoldMax) {
                     Buf<int> members;
-                    DPCG_TRY(members.alloc(66));
+                    DPCG_TRY(members.alloc(kFoldMax + 2));
                     DPCG_HIP(hipMemsetAsync(members.p, 0, sizeof(int), s));
                     hipLaunchKernelGGL(k_collect_class, dim3(rows_grid(n, 1024)), dim3(kBlock), 0, s, n, color.p, used - 1, members.p, members.p + 1);
                     hipLaunchKernelGGL(k_fold_tiny_class, dim3(1), dim3(64), 0, s, n, A.rowptr, A.col, color.p, used - 1, members.p,
-                                       members.p + 1, members.p + 65);
+                                       members.p + 1, members.p + kFoldMax + 1);
                     DPCG_HIP(hipMemsetAsync(flags.p + 2, 0, sizeof(int), s));
                     hipLaunchKernelGGL(k_check_coloring, dim3(rows_grid(n)), dim3(kBlock), 0, s, n, A.rowptr, A.col, color.p, flags.p + 2);
                     int bad_fold = 0;
