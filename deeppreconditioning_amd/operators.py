@@ -512,7 +512,7 @@ class CsrSystem:
 
     def reduction_geometry(self) -> dict:
         """How the handle's kernels sum their dot products (dpcg_get_reduction_geometry): what a checker needs to add in the same
-        order (oracle/c_oracle.pcg(..., device_tree=...))."""
+        order (the tests' CPU restatement takes it as `device_tree=`)."""
         out = (C.c_int32 * 16)()
         L.check(L.lib().dpcg_get_reduction_geometry(self._h, out))
         return {"spmv_grid": out[0], "nrb": out[1], "cyclic": out[2], "vec_grid": out[3], "two_kernel_updates": bool(out[4]),
