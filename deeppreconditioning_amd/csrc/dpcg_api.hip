@@ -88,6 +88,7 @@ void free_levels(Levels &l) {
     dev_free(l.strips.lo_cpos); dev_free(l.strips.lo_val); dev_free(l.strips.val); dev_free(l.strips.b_lo);
     dev_free(l.strips.meta); dev_free(l.strips.ticket);
     dev_free(l.sf_meta);
+    dev_free(l.sfs_blk);
     dev_free(l.sf_val);
     dev_free(l.tickets);
     dev_free(l.spin_err);

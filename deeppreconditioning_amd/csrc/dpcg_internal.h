@@ -133,6 +133,10 @@ struct Levels {
     int32_t *sf_meta = nullptr;            // records of the sync-free kernel (dpcg_analysis.hip: k_sf_records)
     double *sf_val = nullptr;
     int rec_w = 3;                         // entries a record holds (3, 6 or 14); longer rows walk the level-ordered copy
+    // Level-major sync-free solve in CSR-stream form (k_sptrsv_syncfree_stream): 256-row blocks that never straddle a level,
+    // {first position, end position} per block; null: the record kernel
+    int32_t *sfs_blk = nullptr;
+    int sfs_nblk = 0;
     // Strip-pipelined solve (k_sptrsv_strips): the rows once more, sorted by (strip, strip-local level, row), with their
     // own level offsets (n_strips * nlev + 1 entries), level-ordered factor copy and records.  n_strips == 0: not used.
     struct Strips {
@@ -203,6 +207,8 @@ struct SptrsvIo {
 };
 bool single_syncfree_segment(const Levels &lv);   // level-major, the whole factor one sync-free launch
 void launch_fill_pending(double *v, int64_t n, hipStream_t s);
+// largest entry count of the blocks {blk[2b], blk[2b+1]} of a level-ordered copy -> *out_dev (atomicMax)
+void launch_sfs_block_max(const int32_t *blk, int nblk, const int32_t *lo_rowptr, int *out_dev, hipStream_t s);
 
 }  // namespace dpcg
 

@@ -501,6 +501,28 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
             DPCG_TRY(dev_alloc(&lv.lm_out, n));
             launch_invert_positions(n, lv.rows, lv.lm_pos, s);
             launch_fill_pending(lv.lm_out, n, s);        // the invariant of Levels::lm_out
+            // the whole factor ONE sync-free launch: its CSR-stream form (DPCG_SF_STREAM=1; blocks of <= 256 rows of one level each)
+            static const bool sfs_on = [] { const char *e = getenv("DPCG_SF_STREAM"); return e && e[0] == '1'; }();
+            if (sfs_on && !lv.sweep && lv.segments.size() == 1 && lv.segments[0].syncfree) {
+                std::vector<int32_t> blk;
+                for (int l = 0; l < lv.n_levels; ++l)
+                    for (int j0 = level_ptr[l]; j0 < level_ptr[l + 1]; j0 += kBlock) {
+                        blk.push_back(j0);
+                        blk.push_back(std::min(j0 + kBlock, level_ptr[l + 1]));
+                    }
+                const int nblk = (int)(blk.size() / 2);
+                DevBuf<int32_t> most;
+                DPCG_TRY(most.alloc(1));
+                DPCG_TRY(dev_alloc(&lv.sfs_blk, (int64_t)blk.size()));
+                DPCG_HIP(hipMemcpyAsync(lv.sfs_blk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+                DPCG_HIP(hipMemsetAsync(most.p, 0, sizeof(int32_t), s));
+                launch_sfs_block_max(lv.sfs_blk, nblk, lv.lo_rowptr, reinterpret_cast<int *>(most.p), s);
+                int32_t h_most = 0;
+                DPCG_HIP(hipMemcpyAsync(&h_most, most.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                DPCG_HIP(hipStreamSynchronize(s));       // (blk is a local)
+                if (h_most > kStreamCap) dev_free(lv.sfs_blk);      // a block's entries do not fit the product buffer: records
+                else lv.sfs_nblk = nblk;
+            }
         }
     }
     pt.mark("  sync-free records");

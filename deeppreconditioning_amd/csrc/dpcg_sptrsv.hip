@@ -661,6 +661,116 @@ __global__ __launch_bounds__(BS) void k_sptrsv_syncfree_rec(int j0, int count, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// The level-major sync-free solve in CSR-STREAM form.  The record kernel above moves 96 bytes of fixed-width record per row of a
+// factor with rows of up to six entries (128 with the vectors) although such a row holds 3.5 entries on average; this form streams
+// the level-ordered copy itself -- 12 bytes per entry, 4 per row extent -- the way the colour sweeps do: a ticket is a block of
+// <= 256 consecutive rows of ONE level (Levels::sfs_blk: blocks never straddle a level, so no row of a block depends on another
+// one of it), lane k of the block takes entry k of its contiguous val / position segment and polls the solution entry it needs
+// (8 in flight per lane), parks value x solution in LDS, and after a barrier thread j subtracts row j's products in column order and
+// divides by the diagonal (which travels through its product slot): the arithmetic and order of every other triangular-solve
+// kernel, bit-identical to sequential substitution.  rhs_map / refill as in the record kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_sfs_block_max(const int32_t *__restrict__ blk, int nblk, const int32_t *__restrict__ lo_rp,
+                                                          int *out) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b < nblk) atomicMax(out, lo_rp[blk[2 * b + 1]] - lo_rp[blk[2 * b]]);
+}
+void launch_sfs_block_max(const int32_t *blk, int nblk, const int32_t *lo_rowptr, int *out_dev, hipStream_t s) {
+    hipLaunchKernelGGL(k_sfs_block_max, dim3((nblk + kBlock - 1) / kBlock), dim3(kBlock), 0, s, blk, nblk, lo_rowptr, out_dev);
+}
+
+template <bool UPPER>
+__global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_stream(const int32_t *__restrict__ blk, int nblk,
+                                                                   const int32_t *__restrict__ lo_rp,
+                                                                   const int32_t *__restrict__ lo_cp,
+                                                                   const double *__restrict__ lo_v,
+                                                                   const double *__restrict__ rhs, double *out,
+                                                                   unsigned int *ticket, const int *done, int *err,
+                                                                   const int32_t *__restrict__ rhs_map,
+                                                                   double *__restrict__ refill) {
+    constexpr int U = kStreamCap / kBlock;
+    __shared__ double prod[kStreamCap];
+    __shared__ unsigned int s_lb;
+    const int t = threadIdx.x;
+    if (done && *done) return;
+    const double pend = __longlong_as_double((long long)kPendingBits);
+    for (;;) {
+        __syncthreads();                                 // (prod of the previous block has been read)
+        if (t == 0) s_lb = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const unsigned int b = s_lb;
+        if (b >= (unsigned int)nblk) {
+            if (t == 0 && b == (unsigned int)nblk + gridDim.x - 1) atomicExch(ticket, 0u);   // the last leaver re-arms the word
+            break;
+        }
+        const int jb = blk[2 * b], jend = blk[2 * b + 1];
+        const int j = jb + t;
+        const bool live = j < jend;
+        const int base = lo_rp[jb];
+        const int cnt = lo_rp[jend] - base;
+        int rs = 0, re = 0;
+        double bi = 0.0;
+        if (live) {
+            rs = lo_rp[j] - base;
+            re = lo_rp[j + 1] - base;
+            bi = rhs[rhs_map ? rhs_map[j] : j];
+            if (refill) refill[j] = pend;
+        }
+        int c[U];
+        double a[U], y[U];
+        const int last = cnt > 0 ? cnt - 1 : 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = t + u * kBlock;
+            const int kk = k < cnt ? k : last;
+            c[u] = lo_cp[base + kk];
+            a[u] = lo_v[base + kk];
+        }
+        // an entry whose position lies before the block is a dependency (earlier level); the others are the rows' own diagonals
+        bool waiting = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool dep = (t + u * kBlock) < cnt && c[u] < jb;
+            y[u] = dep ? __hip_atomic_load(out + c[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1.0;
+            waiting = waiting || is_pending(y[u]);
+        }
+        unsigned spins = 0;
+        unsigned long long t_wait = 0;
+        while (waiting) {                                // every entry this lane waits for belongs to an earlier ticket
+            __builtin_amdgcn_s_sleep(1);
+            waiting = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (is_pending(y[u])) {
+                    y[u] = __hip_atomic_load(out + c[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    waiting = waiting || is_pending(y[u]);
+                }
+            }
+            if (waiting && spin_expired(spins, t_wait)) {   // bounded: never hang the device on a malformed schedule
+                atomicExch(err, 1);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (is_pending(y[u])) y[u] = __builtin_nan("");
+                waiting = false;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = t + u * kBlock;
+            if (k < cnt) prod[k] = a[u] * y[u];          // (a diagonal: times 1.0 -- the slot holds the diagonal itself)
+        }
+        __syncthreads();
+        if (live) {
+            double acc = bi;
+            const int k0 = UPPER ? rs + 1 : rs, k1 = UPPER ? re : re - 1;
+            for (int k = k0; k < k1; ++k) acc -= prod[k];
+            const double d = prod[UPPER ? rs : re - 1];
+            __hip_atomic_store(out + j, acc / d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Strip-pipelined triangular solve (banded factors with many narrow levels: natural / RCM-ordered grids).
 // The level walk through an LDS ring (k_sptrsv_ring_pipe) costs ~0.35 us per level but runs on ONE CU; the sync-free
 // kernel uses the whole chip but pays a ~2.7 us hand-off per level.  Here the rows are cut into STRIPS of consecutive
@@ -1249,6 +1359,20 @@ static void launch_schedule(int64_t n, const Levels &lv, bool upper, bool lm, co
             grid = grid < 16 ? 16 : grid;
             grid = grid > nblocks ? nblocks : grid;
             grid = grid > 2048 ? 2048 : grid;       // 8 workgroups per CU: all resident
+            if (lm && lv.sfs_blk) {                     // CSR-stream form (see k_sptrsv_syncfree_stream)
+                int g = ((int)(factor * seg.max_width) + kBlock - 1) / kBlock + 4;
+                g = g > lv.sfs_nblk ? lv.sfs_nblk : g;
+                g = g > 2048 ? 2048 : g;
+                if (upper)
+                    hipLaunchKernelGGL(k_sptrsv_syncfree_stream<true>, dim3(g), dim3(kBlock), 0, s, lv.sfs_blk, lv.sfs_nblk, lv.lo_rowptr,
+                                       cols, lv.lo_val, rhs, out, reinterpret_cast<unsigned int *>(lv.tickets + seg_index), done,
+                                       lv.spin_err, rhs_map, sf_refill);
+                else
+                    hipLaunchKernelGGL(k_sptrsv_syncfree_stream<false>, dim3(g), dim3(kBlock), 0, s, lv.sfs_blk, lv.sfs_nblk, lv.lo_rowptr,
+                                       cols, lv.lo_val, rhs, out, reinterpret_cast<unsigned int *>(lv.tickets + seg_index), done,
+                                       lv.spin_err, rhs_map, sf_refill);
+                continue;
+            }
             if (lm) {                                   // (lm_out was filled with the pending pattern by the way-in pass)
 #define DPCG_SF_LM(UP, BSV, WV)                                                                                              \
     do {                                                                                                                     \
