@@ -22,6 +22,7 @@ constexpr int kMaxGrid = 1024;        // vector kernels: 4 workgroups per CU (sa
 constexpr int kMaxSpmvGrid = 2048;    // SpMV: 8 workgroups per CU = 32 waves per CU (40 VGPRs, 16 KiB LDS each)
 constexpr int kStreamCap = 2048;      // products staged in LDS per 256-row block (16 KiB)
 constexpr int kStreamRows = 256;      // rows per row-block of the CSR-stream SpMV
+constexpr int kSfsBlock = 512;        // rows per block of the CSR-stream form of the level-major sync-free solve
 
 enum SpmvKernel { SPMV_STREAM = 0, SPMV_VECTOR = 1, SPMV_TILE = 2 };
 constexpr int kTileChunk = 64;        // x is staged in LDS in chunks of 64 doubles (512 B, one wave-load)

@@ -501,14 +501,20 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
             DPCG_TRY(dev_alloc(&lv.lm_out, n));
             launch_invert_positions(n, lv.rows, lv.lm_pos, s);
             launch_fill_pending(lv.lm_out, n, s);        // the invariant of Levels::lm_out
-            // the whole factor ONE sync-free launch: its CSR-stream form (DPCG_SF_STREAM=1; blocks of <= 256 rows of one level each)
-            static const bool sfs_on = [] { const char *e = getenv("DPCG_SF_STREAM"); return e && e[0] == '1'; }();
+            // The whole factor ONE sync-free launch: in CSR-stream form (k_sptrsv_syncfree_stream; blocks of <= 512 rows of one level
+            // each) when the rows are long -- records of width 14 move 256 bytes per row whatever it holds.  Measured per PCG update
+            // at 1M rows, records -> stream (tools/sfs_probe.py, profiles/r04_sfs_probe.txt): Delaunay IC(0) (19 levels, rows of up to
+            // 12 entries) 188 -> 148 us; the scrambled 100^3 / 1024^2 factors (width 6 / 3) 136 -> 140 / 131 -> 131; 64^3 72 -> 103
+            // (blocks of 256 or 1024 rows are worse everywhere: 179 / 168 us on 100^3 -- tickets, not bytes, bound these solves).
+            // DPCG_SF_STREAM=0/1 overrides.
+            static const int sfs_knob = [] { const char *e = getenv("DPCG_SF_STREAM"); return e ? atoi(e) : -1; }();
+            const bool sfs_on = sfs_knob >= 0 ? sfs_knob != 0 : lv.rec_w == 14;
             if (sfs_on && !lv.sweep && lv.segments.size() == 1 && lv.segments[0].syncfree) {
                 std::vector<int32_t> blk;
                 for (int l = 0; l < lv.n_levels; ++l)
-                    for (int j0 = level_ptr[l]; j0 < level_ptr[l + 1]; j0 += kBlock) {
+                    for (int j0 = level_ptr[l]; j0 < level_ptr[l + 1]; j0 += kSfsBlock) {
                         blk.push_back(j0);
-                        blk.push_back(std::min(j0 + kBlock, level_ptr[l + 1]));
+                        blk.push_back(std::min(j0 + kSfsBlock, level_ptr[l + 1]));
                     }
                 const int nblk = (int)(blk.size() / 2);
                 DevBuf<int32_t> most;
@@ -520,7 +526,7 @@ int build_levels(Levels &lv, LevelSort &ls, int64_t n, int64_t nnz, const int32_
                 int32_t h_most = 0;
                 DPCG_HIP(hipMemcpyAsync(&h_most, most.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
                 DPCG_HIP(hipStreamSynchronize(s));       // (blk is a local)
-                if (h_most > kStreamCap) dev_free(lv.sfs_blk);      // a block's entries do not fit the product buffer: records
+                if (h_most > kStreamCap / kBlock * kSfsBlock) dev_free(lv.sfs_blk);      // a block's entries do not fit the product buffer: records
                 else lv.sfs_nblk = nblk;
             }
         }

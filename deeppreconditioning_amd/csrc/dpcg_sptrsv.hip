@@ -679,8 +679,8 @@ void launch_sfs_block_max(const int32_t *blk, int nblk, const int32_t *lo_rowptr
     hipLaunchKernelGGL(k_sfs_block_max, dim3((nblk + kBlock - 1) / kBlock), dim3(kBlock), 0, s, blk, nblk, lo_rowptr, out_dev);
 }
 
-template <bool UPPER>
-__global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_stream(const int32_t *__restrict__ blk, int nblk,
+template <bool UPPER, int BS>      // BS rows (= threads) per block
+__global__ __launch_bounds__(BS) void k_sptrsv_syncfree_stream(const int32_t *__restrict__ blk, int nblk,
                                                                    const int32_t *__restrict__ lo_rp,
                                                                    const int32_t *__restrict__ lo_cp,
                                                                    const double *__restrict__ lo_v,
@@ -688,8 +688,8 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_stream(const int32_t
                                                                    unsigned int *ticket, const int *done, int *err,
                                                                    const int32_t *__restrict__ rhs_map,
                                                                    double *__restrict__ refill) {
-    constexpr int U = kStreamCap / kBlock;
-    __shared__ double prod[kStreamCap];
+    constexpr int U = kStreamCap / kBlock;      // entries per thread: BS * U product slots
+    __shared__ double prod[BS * U];
     __shared__ unsigned int s_lb;
     const int t = threadIdx.x;
     if (done && *done) return;
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_stream(const int32_t
         const int last = cnt > 0 ? cnt - 1 : 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int k = t + u * kBlock;
+            const int k = t + u * BS;
             const int kk = k < cnt ? k : last;
             c[u] = lo_cp[base + kk];
             a[u] = lo_v[base + kk];
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_stream(const int32_t
         bool waiting = false;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool dep = (t + u * kBlock) < cnt && c[u] < jb;
+            const bool dep = (t + u * BS) < cnt && c[u] < jb;
             y[u] = dep ? __hip_atomic_load(out + c[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1.0;
             waiting = waiting || is_pending(y[u]);
         }
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(kBlock) void k_sptrsv_syncfree_stream(const int32_t
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int k = t + u * kBlock;
+            const int k = t + u * BS;
             if (k < cnt) prod[k] = a[u] * y[u];          // (a diagonal: times 1.0 -- the slot holds the diagonal itself)
         }
         __syncthreads();
@@ -1360,15 +1360,16 @@ static void launch_schedule(int64_t n, const Levels &lv, bool upper, bool lm, co
             grid = grid > nblocks ? nblocks : grid;
             grid = grid > 2048 ? 2048 : grid;       // 8 workgroups per CU: all resident
             if (lm && lv.sfs_blk) {                     // CSR-stream form (see k_sptrsv_syncfree_stream)
-                int g = ((int)(factor * seg.max_width) + kBlock - 1) / kBlock + 4;
+                constexpr int SB = kSfsBlock;
+                int g = ((int)(factor * seg.max_width) + SB - 1) / SB + 4;
                 g = g > lv.sfs_nblk ? lv.sfs_nblk : g;
-                g = g > 2048 ? 2048 : g;
+                g = g > 2048 * 256 / SB ? 2048 * 256 / SB : g;
                 if (upper)
-                    hipLaunchKernelGGL(k_sptrsv_syncfree_stream<true>, dim3(g), dim3(kBlock), 0, s, lv.sfs_blk, lv.sfs_nblk, lv.lo_rowptr,
+                    hipLaunchKernelGGL((k_sptrsv_syncfree_stream<true, SB>), dim3(g), dim3(SB), 0, s, lv.sfs_blk, lv.sfs_nblk, lv.lo_rowptr,
                                        cols, lv.lo_val, rhs, out, reinterpret_cast<unsigned int *>(lv.tickets + seg_index), done,
                                        lv.spin_err, rhs_map, sf_refill);
                 else
-                    hipLaunchKernelGGL(k_sptrsv_syncfree_stream<false>, dim3(g), dim3(kBlock), 0, s, lv.sfs_blk, lv.sfs_nblk, lv.lo_rowptr,
+                    hipLaunchKernelGGL((k_sptrsv_syncfree_stream<false, SB>), dim3(g), dim3(SB), 0, s, lv.sfs_blk, lv.sfs_nblk, lv.lo_rowptr,
                                        cols, lv.lo_val, rhs, out, reinterpret_cast<unsigned int *>(lv.tickets + seg_index), done,
                                        lv.spin_err, rhs_map, sf_refill);
                 continue;
