@@ -17,7 +17,10 @@ for name, make in (("delaunay_1M", lambda: meshes.delaunay_laplacian(1000000, 0)
     print(f"{name} {r.seconds / r.iterations * 1e6:.1f} us/update", end="; ", flush=True)
     s.close()
 '''
-for stream in ("1", "0"):
-    for f in ("0.35", "0.5", "0.85", "1.2", "1.7", "2.5"):
-        r = subprocess.run([sys.executable, "-c", CHILD], env={**os.environ, "DPCG_SF_STREAM": stream, "DPCG_SF_FACTOR": f}, capture_output=True, text=True)
-        print(f"stream={stream} factor={f}: " + r.stdout.strip() + (r.stderr[-300:] if r.returncode else ""), flush=True)
+import itertools
+gates = sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"]
+for stream, gate in itertools.product(("1", "0") if gates == ["0"] else ("1",), gates):
+    for f in (("0.35", "0.5", "0.85", "1.2", "1.7", "2.5") if gates == ["0"] else ("0.85", "1.7", "2.5", "4", "6")):
+        r = subprocess.run([sys.executable, "-c", CHILD], env={**os.environ, "DPCG_SF_STREAM": stream, "DPCG_SF_FACTOR": f, "DPCG_SF_GATE": gate},
+                           capture_output=True, text=True)
+        print(f"stream={stream} gate={gate} factor={f}: " + r.stdout.strip() + (r.stderr[-300:] if r.returncode else ""), flush=True)
