@@ -1125,7 +1125,7 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
             DPCG_TRY(prank.alloc(n));
             DPCG_TRY(pdeg.alloc(n));
             DPCG_TRY(pctl.alloc(1));
-            const int T = std::max(2, (int)((A.nnz - n) / std::max<int64_t>(n, 1)) - 2);
+            const int T = std::max(2, (int)(((A.nnz - n) + n / 2) / std::max<int64_t>(n, 1)) - 2);      // average degree (rounded) - 2
             DPCG_HIP(hipMemsetAsync(pctl.p, 0x7f, sizeof(int), s));
             hipLaunchKernelGGL(k_peel_init, dim3(rows_grid(n, 1024)), dim3(kBlock), 0, s, n, A.rowptr, A.col, prank.p, pdeg.p, peel_rounds, pctl.p);
             for (int r = 0; r < peel_rounds; ++r) {
