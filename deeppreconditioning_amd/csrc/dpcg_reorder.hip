@@ -791,10 +791,10 @@ __global__ __launch_bounds__(kBlock) void k_check_coloring(int64_t n, const int3
 // a fraction of the graph's diameter (a single breadth-first search of a 256^2 grid is 511 dependent steps, of a 100^3 grid 298: at
 // ~3 launches a step that was 3 of the 4.4 / 5.3 ms of an IC(0) setup in multicolour order).  state[v] = region << 1 | parity within
 // the region, step[v] = the step at which v joined (-1: not yet).
-constexpr int kRegions = 256;
+constexpr int kRegionsSmall = 256, kRegionsLarge = 1024;      // seeds: 1024 from 2M vertices on (a 256^3 grid: ~40 -> ~25 growth steps of 0.5 ms each)
 constexpr int kRegionBatch = 16;      // growth steps enqueued between two looks at the visited count
 
-__global__ void k_region_seed(int64_t n, int32_t *step, int32_t *state, int *visited) {
+__global__ void k_region_seed(int64_t n, int32_t *step, int32_t *state, int *visited, int kRegions) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= kRegions) return;
     // hashed positions: evenly spaced indices would line the seeds up along one edge of a naturally ordered grid
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(kBlock) void k_region_grow(int64_t n, const int32_t
 // are), [.. + 1] those that join equal parities (one of the two has to be flipped); a bipartite graph fills one of the two only
 __global__ __launch_bounds__(kBlock) void k_region_relations(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                              const uint8_t *__restrict__ skip, const int32_t *__restrict__ step,
-                                                             const int32_t *__restrict__ state, unsigned int *rel) {
+                                                             const int32_t *__restrict__ state, unsigned int *rel, int kRegions) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) {
         if (step[v] < 0) continue;
@@ -935,21 +935,22 @@ __global__ __launch_bounds__(kBlock) void k_invert_perm(int64_t n, const int32_t
 // skip (may be null, with nearly): entries the regions do not grow along nor relate through (k_triangle_edges); vertices they then
 // cannot reach stay uncoloured.
 static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bool *colored, bool *nearly, const uint8_t *skip,
-                                 hipStream_t s) {
+                                 hipStream_t s, int32_t *const scratch[4] /* four vectors of n entries the caller does not need yet */) {
     const int64_t n = A.n;
+    const int kRegions = n >= (1 << 21) ? kRegionsLarge : kRegionsSmall;
     *colored = false;
     if (nearly) *nearly = false;
     bool odd_cycle = false;
     if (n < 4 * kRegions) return DPCG_OK;
-    Buf<int32_t> step, state, deg, mask, d_small;
+    struct View { int32_t *p; } step{scratch[0]}, state{scratch[1]}, deg{scratch[2]}, mask{scratch[3]};   // (hipMalloc of 4 x 67 MB at 256^3: ~8 ms)
+    Buf<int32_t> d_small;
     Buf<unsigned int> rel;
     Buf<unsigned long long> best;
-    DPCG_TRY(step.alloc(n)); DPCG_TRY(state.alloc(n)); DPCG_TRY(deg.alloc(n)); DPCG_TRY(mask.alloc(n));
     DPCG_TRY(d_small.alloc(2 * kRegions)); DPCG_TRY(rel.alloc(2 * (int64_t)kRegions * kRegions)); DPCG_TRY(best.alloc(1));
     PhaseTimer pt(s);
     DPCG_HIP(hipMemsetAsync(step.p, 0xff, (size_t)n * sizeof(int32_t), s));
     DPCG_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
-    hipLaunchKernelGGL(k_region_seed, dim3((kRegions + 63) / 64), dim3(64), 0, s, n, step.p, state.p, flags);
+    hipLaunchKernelGGL(k_region_seed, dim3((kRegions + 63) / 64), dim3(64), 0, s, n, step.p, state.p, flags, kRegions);
     int visited = 0, cur = 0;
     for (;;) {
         for (int b = 0; b < kRegionBatch; ++b, ++cur)
@@ -967,7 +968,7 @@ static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bo
     }
     pt.mark("  regions: growth");
     DPCG_HIP(hipMemsetAsync(rel.p, 0, 2 * (size_t)kRegions * kRegions * sizeof(unsigned int), s));
-    hipLaunchKernelGGL(k_region_relations, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, skip, step.p, state.p, rel.p);
+    hipLaunchKernelGGL(k_region_relations, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, skip, step.p, state.p, rel.p, kRegions);
     std::vector<unsigned int> h_rel(2 * (size_t)kRegions * kRegions);
     DPCG_HIP(hipMemcpyAsync(h_rel.data(), rel.p, h_rel.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
@@ -1054,7 +1055,8 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
     static const bool regions_on = [] { const char *e = getenv("DPCG_COLOR_REGIONS"); return !(e && e[0] == '0'); }();
     bool nearly = false, repaired = false;
     static const bool repair_on = [] { const char *e = getenv("DPCG_COLOR_REPAIR"); return !(e && e[0] == '0'); }();
-    if (regions_on) DPCG_TRY(two_colors_by_regions(A, color.p, flags.p, &colored, repair_on ? &nearly : nullptr, nullptr, s));   // 0. two colours, many searches at once
+    int32_t *const scratch[4] = {perm.p, iperm.p, iota.p, reinterpret_cast<int32_t *>(key_sorted.p)};     // (free until the sort by colour)
+    if (regions_on) DPCG_TRY(two_colors_by_regions(A, color.p, flags.p, &colored, repair_on ? &nearly : nullptr, nullptr, s, scratch));   // 0. two colours, many searches at once
     if (!colored && nearly) {
         // 0b. nearly bipartite (odd cycles, but few): the regions once more without the edges that lie on triangles -- breadth-first
         // parity follows every shortcut, an extra coupling would flip the cone of vertices behind it -- then the two big classes stay
@@ -1062,7 +1064,7 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
         Buf<uint8_t> skip;
         DPCG_TRY(skip.alloc(A.nnz));
         hipLaunchKernelGGL(k_triangle_edges, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, skip.p);
-        DPCG_TRY(two_colors_by_regions(A, color.p, flags.p, &colored, &nearly, skip.p, s));
+        DPCG_TRY(two_colors_by_regions(A, color.p, flags.p, &colored, &nearly, skip.p, s, scratch));
     }
     if (!colored && nearly) {
         DPCG_HIP(hipMemsetAsync(flags.p, 0, 4 * sizeof(int), s));
