@@ -325,19 +325,40 @@ __global__ __launch_bounds__(kBlock) void k_tile_plan(int64_t n, const int32_t *
             if (c < diag_from) slot_of[c / kTileChunk - cb] = 1;
         }
         __syncthreads();
-        if (t == 0) {                                     // ascending chunk ids -> slots 1..nc
-            int nc = 0;
-            for (int e = 0; e < span; ++e)
+        {   // ascending chunk ids -> slots 1..nc: thread t numbers the marks of its run of the table behind a workgroup-wide scan
+            // (one thread walking up to 4096 entries was 7 ms of a 256^3 plan)
+            __shared__ int s_wave[kBlock / 64];
+            const int per = (span + kBlock - 1) / kBlock, e0 = t * per, e1 = (e0 + per < span) ? e0 + per : span;
+            int mine = 0;
+            for (int e = e0; e < e1; ++e) mine += slot_of[e] ? 1 : 0;
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(incl, off);
+                if ((t & 63) >= off) incl += y;
+            }
+            if ((t & 63) == 63) s_wave[t >> 6] = incl;
+            __syncthreads();
+            int before = incl - mine, total = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) {
+                if (w < (t >> 6)) before += s_wave[w];
+                total += s_wave[w];
+            }
+            int nc = before;
+            for (int e = e0; e < e1; ++e)
                 if (slot_of[e]) {
                     if (nc < kTileMaxChunks) chunks[(int64_t)rb * kTileMaxChunks + nc] = cb + e;
                     slot_of[e] = (uint16_t)(++nc);
                 }
-            s_nc = nc;
-            nchunks[rb] = nc <= kTileMaxChunks ? nc : (allow_flagged ? -1 : 0);   // -1: too many chunks, this block gathers (k_spmv_tile<..., MIX>)
-            if (nc > kTileMaxChunks) {
-                if (allow_flagged) atomicAdd(&ok_and_max[2], 1);
-                else atomicExch(&ok_and_max[0], 0);
-            } else atomicMax(&ok_and_max[1], nc);
+            if (t == 0) {
+                s_nc = total;
+                nchunks[rb] = total <= kTileMaxChunks ? total : (allow_flagged ? -1 : 0);   // -1: too many chunks, this block gathers (k_spmv_tile<..., MIX>)
+                if (total > kTileMaxChunks) {
+                    if (allow_flagged) atomicAdd(&ok_and_max[2], 1);
+                    else atomicExch(&ok_and_max[0], 0);
+                } else atomicMax(&ok_and_max[1], total);
+            }
         }
         __syncthreads();
         if (s_nc <= kTileMaxChunks)
