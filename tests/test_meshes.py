@@ -184,9 +184,7 @@ def _mesh_parity(D, A, expect, max_iter):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,make", [("quadtree_foam", lambda: O.quadtree_fv_laplacian(96, 2)),
                                        ("quadtree_random", lambda: O.quadtree_fv_laplacian(96, 2, numbering="random")),
-                                       ("quadtree_foam_300", lambda: O.quadtree_fv_laplacian(300, 5)),
-                                       ("delaunay", lambda: O.delaunay_laplacian(12000, 2)),
-                                       ("delaunay_100k", lambda: O.delaunay_laplacian(100000, 3))])
+                                       ("delaunay", lambda: O.delaunay_laplacian(12000, 2))])
 def test_unstructured_meshes_small(D, name, make):
     """The launch forms below the 1M-DoF kernels (two-kernel updates, gather SpMV, LDS-ring / sync-free triangular solves) on the
     same kinds of matrices."""
@@ -203,7 +201,7 @@ def test_unstructured_meshes_small(D, name, make):
 def test_config3_unstructured_meshes_million_dof(D, name, make, expect):
     """BASELINE config 3 ("OpenFOAM interFoam pressure-correction matrix, ~1M DoF, unstructured CSR") on matrices with irregular
     degree, triangles and no grid structure: the plain call (the library reorders a scattered numbering by itself and plans the
-    x-tile SpMV on the result), 120 updates each of Jacobi, IC(0) in the caller's order (level-scheduled L / L^T solves) and IC(0)
+    x-tile SpMV on the result), 60 updates each of Jacobi, IC(0) in the caller's order (level-scheduled L / L^T solves) and IC(0)
     in multicolour order against the C oracle on the system the handle iterates on -- counts equal, histories within 1e-10 (`_check_history`: where a one-ulp
     perturbation of b moves the oracle itself, 100 x that drift)."""
-    _mesh_parity(D, make(), expect, 120)
+    _mesh_parity(D, make(), expect, 60)
