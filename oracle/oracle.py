@@ -10,7 +10,12 @@ Parity status: PINNED.  Every function here that restates an importable referenc
 (`cg.py`, `utils.py`) is checked in `tests/test_oracle_golden.py` against fixtures in
 `tests/golden/` that were produced by importing the reference itself in the build container
 (`tests/golden/make_golden.py`).  The preconditioner *constructors* that need ilupp / pyamg /
-spconv (absent, `test.py:81-105`) are unpinned; see DESIGN.md.
+spconv (absent, `test.py:81-105`) are unpinned against those binaries: `ic0` (textbook IC(0)) and `icholt` (ILU++'s
+dual-threshold rule, the harness's default `ilupp.icholt(add_fill_in=1, threshold=0.1)`) restate the PUBLISHED algorithms
+and are pinned by their properties (tests/test_oracle_golden.py); see DESIGN.md.  The mesh generators
+(`quadtree_fv_laplacian`, `delaunay_laplacian`) are inputs, not algorithm: they stand in for the OpenFOAM matrices of
+BASELINE config 3.  The C twin (pcg_oracle.c) can also add its dot products in the DEVICE's reduction trees
+(`c_oracle.pcg(..., device_tree=...)`): that changes the order of additions only, and makes the comparison bit for bit.
 
 Every function cites the reference file:line it follows (paths relative to the reference root).
 """
