@@ -106,6 +106,9 @@ def parse_args():
     ap.add_argument("--precond", default="jacobi", choices=["jacobi", "none", "ic0"])
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and run the scatter / gather even with ONE rank (under torch.distributed.run): "
+                         "exercises the RCCL path of this script on a one-GPU box")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / result reduction (nccl = RCCL; gloo lets the "
                          "N > 1 control flow be exercised with several ranks sharing one GPU)")
@@ -205,7 +208,7 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_dist and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":

@@ -2067,6 +2067,33 @@ def _run_bench(extra_args, port_env=None):
     return json.loads(lines[0])
 
 
+def test_bench_script_runs_its_collectives_on_rccl_with_one_rank(golden):
+    """The box has one GPU, so RCCL cannot carry two ranks here -- but it can carry ONE: `--force-dist` under torch.distributed.run
+    with --nproc-per-node 1 and the nccl backend takes bench.py through communicator creation, barrier, the spec broadcast, the
+    all_reduce of the result and both all_gathers ON RCCL, with the keys the N > 1 line carries."""
+    import json
+    import pathlib
+    import socket
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {**__import__("os").environ, "PYTHONPATH": str(root)}
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(root / "bench.py"), "--gpus", "1", "--force-dist", "--no-extra", "--no-cpu-baseline",
+           "--steps", "2", "--warmup", "1", "--grid", "64", "--systems-per-gpu", "2"]
+    proc = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    line = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][0])
+    assert line["backend"].startswith("nccl") and line["ranks"] == 1 and line["scatter_ms"] > 0 and line["gather_ms"] > 0
+    assert line["gathered_records"]["systems"] == 2 and line["gathered_records"]["iterations"][0] == int(golden["pcg_poisson3d_64_jacobi/iters"])
+    assert len(line["per_rank"]) == 1 and line["per_rank"][0]["roofline_frac"] > 0.2
+
+
 def test_bench_script_control_flow_at_two_ranks(golden):
     """`bench.py`'s own N > 1 control flow (rendezvous, sharding, barrier + synchronize, MAX over ranks, the rank-0
     line), launched the way the driver launches it.  Headline shape: one 1M-DoF system per rank, 187 iterations each."""
