@@ -37,25 +37,41 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// value of lane `l` (the same for every lane of the wave: a loop counter, a first-lane read) -- the wave's loops over a handful of
+// dependencies / candidates read each other's registers this way instead of going through LDS (64+ cycles a dependent read)
+__device__ __forceinline__ int lane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double lane_d(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ int first_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // rcnt[i]: kept entries of row i so far; row i's list at [i * kIctCap ..]: column j, L_ij, and rcc = (position after L_ij in column
 // j's list) + 256 * (kept entries of column j), i.e. where the entries of column j below row i start and end; column j's kept
 // (row, value) at [j * kIctCap ..], rows ascending; diag[k] = L_kk.  status[0] = code, status[1] = column.
-// Per column two dependent round trips remain: the entries of its dependencies, and the counters of the rows it appends to (beside
-// which the next row's list is fetched; the entry this column itself adds to that list is handed over in registers).  The next
-// row of A is fetched a column ahead.
+//
+// ONE dependent round trip per column: the entries of its dependencies.  Everything else is fetched ahead or written behind --
+// the next row of A a column ahead; row k + 1's list while column k is computed (the entry column k itself adds to it is handed
+// over in registers); the counters of the rows column k appends to are requested when the column is done, and the appends
+// themselves are issued in column k + 1, after ITS dependencies' entries have been requested.
+// Row k's list lives in registers (lane d: dependency d) and so do the candidates (lane c: candidate c): a pair (row, product)
+// finds its candidate by a compare across the wave.  A column with many pairs, or more than 64 candidates, goes through the LDS
+// hash table (keyed by row) and, beyond 64 candidates, through the LDS selection; `use_regs` = 0 forces that path (tests).
 __global__ __launch_bounds__(64) void k_icholt(int n, const int32_t *__restrict__ arp, const int32_t *__restrict__ aci,
                                                const double *__restrict__ av, int add_fill, double tau, int *rcnt, int *rcol,
-                                               int *rcc, double *rval, int *crow, double *cval, double *diag, int *status) {
+                                               int *rcc, double *rval, int *crow, double *cval, double *diag, int *status,
+                                               int use_regs) {
+    constexpr int kNone = 0x7fffffff;
     __shared__ int hkey[kIctHash];
     __shared__ double hval[kIctHash];
     __shared__ int used[kIctCand];
     __shared__ int ci[kIctCand], si[kIctCand], keep[kIctCand];
     __shared__ double cv[kIctCand], sv[kIctCand];
-    __shared__ int dj[kIctCap], dst[kIctCap], doff[kIctCap + 1];
-    __shared__ double dv[kIctCap];
     __shared__ int s_nused, s_err, s_pk, s_fwd;
     __shared__ double s_diag, s_fwd_l;
     const int lane = threadIdx.x;
+    const unsigned long long below = (1ull << lane) - 1ull;    // the lanes before this one
     for (int q = lane; q < kIctHash; q += 64) hkey[q] = -1;
     if (lane == 0) { s_nused = 0; s_err = 0; }
     wave_sync();
@@ -80,9 +96,27 @@ __global__ __launch_bounds__(64) void k_icholt(int n, const int32_t *__restrict_
     int ac = -1;
     double ax = 0.0;
     if (p0 + lane < p1) { ac = aci[p0 + lane]; ax = av[p0 + lane]; }
-    // row k's list of L, fetched while column k - 1 was being appended (row 0: empty)
+    // row k's list of L, fetched while column k - 1 was computed (row 0: empty)
     int m = 0, rj = 0, rc = 0;
     double rv = 0.0;
+    // the appends of column k - 1, still to be issued: this lane's kept entry (row pa_row, value pa_l, link pa_link) goes to slot
+    // pa_cur (requested at the end of column k - 1) of its row's list
+    bool pa = false;
+    int pa_row = 0, pa_link = 0, pa_cur = 0;
+    double pa_l = 0.0;
+    bool overflow = false;
+    auto issue_appends = [&](int col) {
+        if (pa) {
+            if (pa_cur >= kIctCap) overflow = true;
+            else {
+                st_i(rcol + (size_t)pa_row * kIctCap + pa_cur, col);
+                st_i(rcc + (size_t)pa_row * kIctCap + pa_cur, pa_link);
+                st_d(rval + (size_t)pa_row * kIctCap + pa_cur, pa_l);
+                st_i(rcnt + pa_row, pa_cur + 1);
+            }
+        }
+        pa = false;
+    };
     for (int k = 0; k < n; ++k) {
         const int a0 = p0, a1 = p1;
         const int my_c = ac;
@@ -92,117 +126,47 @@ __global__ __launch_bounds__(64) void k_icholt(int n, const int32_t *__restrict_
         ac = -1;
         if (k + 1 < n && p1 + lane < p2) { ac = aci[p1 + lane]; ax = av[p1 + lane]; }
         p0 = p1; p1 = p2; p2 = p3;
-        // ---- column k of A (= row k of the symmetric matrix, entries at or right of the diagonal)
         if (lane == 0) { s_pk = 0; s_diag = __builtin_nan(""); s_fwd = 0; }
         wave_sync();
-        if (my_c == k) s_diag = my_v;
-        else if (my_c > k) {
-            hval[slot_of(my_c)] = my_v;
-            atomicAdd(&s_pk, 1);
+        // ---- the dependencies j (ascending: columns finish in order; lane d holds dependency d): L_kj, and where the entries of
+        // column j below row k lie
+        const int d_at = rc & 255, d_len = lane < m ? (rc >> 8) - d_at : 0, d_st = rj * kIctCap + d_at;
+        int d_off = 0, total = 0;                              // exclusive scan of the lengths over the lanes
+        for (int d = 0; d < m; ++d) {
+            const int len = lane_i(d_len, d);
+            if (lane > d) d_off += len;
+            total += len;
         }
-        for (int q = a0 + 64 + lane; q < a1; q += 64) {        // (a row of A with more than 64 entries)
-            const int c = aci[q];
-            const double v = av[q];
-            if (c == k) s_diag = v;
-            else if (c > k) {
-                hval[slot_of(c)] = v;
-                atomicAdd(&s_pk, 1);
+        // pair q of the flattened (dependency, entry) list: its dependency, address and L_kj
+        auto pair_of = [&](int q, int &d, int &at, double &lkj) {
+            d = 0;
+            at = lane_i(d_st, 0) + q;
+            lkj = lane_d(rv, 0);
+            for (int o = 1; o < m; ++o) {
+                const int off = lane_i(d_off, o), st = lane_i(d_st, o);
+                const double l = lane_d(rv, o);
+                if (off <= q) { d = o; at = st + (q - off); lkj = l; }
+            }
+        };
+        int d0 = -1, i0 = -1;
+        double prod0 = 0.0;
+        if (total > 0) {                                       // the first 64 pairs: requested before anything else
+            int at;
+            pair_of(lane, d0, at, prod0);
+            if (lane < total) {
+                i0 = ld_i(crow + at);
+                prod0 = prod0 * ld_d(cval + at);
+            } else {
+                d0 = -1;
             }
         }
-        // the dependencies j (ascending: columns finish in order) with their L_kj, and where their entries below row k lie
-        const int d_at = rc & 255, d_len = lane < m ? (rc >> 8) - d_at : 0;
-        if (lane < m) { dj[lane] = rj; dv[lane] = rv; dst[lane] = rj * kIctCap + d_at; }
-        {   // exclusive scan of the lengths over the lanes
-            int x = d_len;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int y = __shfl_up(x, off);
-                if (lane >= off) x += y;
-            }
-            if (lane < m) doff[lane + 1] = x;
-            if (lane == 0) doff[0] = 0;
-        }
-        wave_sync();
-        double dg = s_diag;
-        if (!(dg == dg)) {                                   // no diagonal entry
-            if (lane == 0) { status[0] = ICHOLT_NODIAG; status[1] = k; }
+        // ---- written behind: the appends of column k - 1; fetched ahead: row k + 1's list as the columns before k leave it (every
+        // slot; the count says which hold entries)
+        issue_appends(k - 1);
+        if (__ballot(overflow)) {
+            if (lane == 0) { status[0] = ICHOLT_ROWCAP; status[1] = k - 1; }
             return;
         }
-        for (int d = 0; d < m; ++d) dg = dg - dv[d] * dv[d];
-        const int total = doff[m];
-        for (int base = 0; base < total; base += 64) {
-            const int q = base + lane;
-            int d = -1, i = -1;
-            double prod = 0.0;
-            if (q < total) {
-                d = 0;                                        // the dependency whose entries hold pair q
-                for (int o = 1; o < m; ++o) d += doff[o] <= q ? 1 : 0;
-                const int at = dst[d] + (q - doff[d]);
-                i = ld_i(crow + at);
-                prod = dv[d] * ld_d(cval + at);
-            }
-            // updates of one candidate must come in ascending j: one dependency at a time, its entries side by side
-            const int d_lo = __shfl(d, 0);
-            const int last = (total - base < 64 ? total - base : 64) - 1;
-            const int d_hi = __shfl(d, last);
-            for (int dd = d_lo; dd <= d_hi; ++dd) {
-                if (d == dd) {
-                    const int sl = slot_of(i);
-                    hval[sl] = hval[sl] - prod;
-                }
-                wave_sync();
-            }
-        }
-        wave_sync();
-        const int nused = s_nused, pk = s_pk + add_fill;
-        if (s_err || nused > kIctCand || pk > kIctCap) {
-            if (lane == 0) { status[0] = s_err ? s_err : (nused > kIctCand ? ICHOLT_CAND : ICHOLT_COLCAP); status[1] = k; }
-            return;
-        }
-        if (!(dg > 0.0)) {
-            if (lane == 0) { status[0] = ICHOLT_PIVOT; status[1] = k; }
-            return;
-        }
-        const double dk = sqrt(dg);
-        // ---- the candidates, sorted by row (rank counting), the table cleared on the way
-        for (int c = lane; c < nused; c += 64) {
-            const int sl = used[c];
-            ci[c] = hkey[sl];
-            cv[c] = hval[sl];
-            hkey[sl] = -1;
-        }
-        if (lane == 0) s_nused = 0;
-        wave_sync();
-        for (int c = lane; c < nused; c += 64) {
-            const int me = ci[c];
-            int rank = 0;
-            for (int o = 0; o < nused; ++o) rank += ci[o] < me ? 1 : 0;
-            si[rank] = me;
-            sv[rank] = cv[c];
-        }
-        wave_sync();
-        double ss = 0.0;
-        for (int c = 0; c < nused; ++c) ss = ss + sv[c] * sv[c];
-        const double bound = tau * sqrt(ss);
-        int nk = 0;
-        for (int c = 0; c < nused; ++c) nk += !(fabs(sv[c]) < bound) ? 1 : 0;
-        for (int c = lane; c < nused; c += 64) {
-            int kp = !(fabs(sv[c]) < bound) ? 1 : 0;
-            if (kp && nk > pk) {                              // the pk largest: how many kept candidates come before this one
-                const double mine = fabs(sv[c]);
-                int better = 0;
-                for (int o = 0; o < nused; ++o) {
-                    const double other = fabs(sv[o]);
-                    if (!(other < bound) && (other > mine || (other == mine && o < c))) ++better;
-                }
-                kp = better < pk ? 1 : 0;
-            }
-            keep[c] = kp;
-        }
-        wave_sync();
-        int nkept = 0;
-        for (int c = 0; c < nused; ++c) nkept += keep[c];
-        // ---- fetch ahead: row k + 1's list as the columns before k left it (every slot; the count says which hold entries)
         int nm = 0, nrj = 0, nrc = 0;
         double nrv = 0.0;
         if (k + 1 < n) {
@@ -211,38 +175,222 @@ __global__ __launch_bounds__(64) void k_icholt(int n, const int32_t *__restrict_
             nrc = ld_i(rcc + (size_t)(k + 1) * kIctCap + lane);
             nrv = ld_d(rval + (size_t)(k + 1) * kIctCap + lane);
         }
-        // ---- column k of L, and its entries appended to their rows' lists
-        bool overflow = false;
-        for (int c = lane; c < nused; c += 64) {
-            if (!keep[c]) continue;
-            int pos = 0;
-            for (int o = 0; o < c; ++o) pos += keep[o];
-            const int i = si[c];
-            const double l = sv[c] / dk;
-            st_i(crow + (size_t)k * kIctCap + pos, i);
-            st_d(cval + (size_t)k * kIctCap + pos, l);
-            const int cur = ld_i(rcnt + i);
-            if (cur >= kIctCap) { overflow = true; continue; }
-            const int link = (pos + 1) + 256 * nkept;
-            st_i(rcol + (size_t)i * kIctCap + cur, k);
-            st_i(rcc + (size_t)i * kIctCap + cur, link);
-            st_d(rval + (size_t)i * kIctCap + cur, l);
-            st_i(rcnt + i, cur + 1);
-            if (i == k + 1) { s_fwd = link; s_fwd_l = l; }    // (pos = 0: link > 0)
+        // ---- column k of A (= row k of the symmetric matrix, entries at or right of the diagonal), its diagonal reduced
+        const int alen = a1 - a0;
+        const unsigned long long at_diag = __ballot(my_c == k);
+        int pk = __popcll(__ballot(my_c > k));
+        double dg = at_diag ? lane_d(my_v, __ffsll((long long)at_diag) - 1) : __builtin_nan("");
+        const bool regs = use_regs && alen + total <= 64;
+        int me = kNone;                                        // this lane's candidate (regs): row, value; nl lanes in use
+        double val = 0.0;
+        int nl = 0;
+        if (regs) {
+            if (my_c > k) { me = my_c; val = my_v; }
+            nl = alen;
+        } else {
+            if (my_c > k) hval[slot_of(my_c)] = my_v;
+            if (alen > 64) {                                   // (a row of A with more than 64 entries)
+                for (int q = a0 + 64 + lane; q < a1; q += 64) {
+                    const int c = aci[q];
+                    const double v = av[q];
+                    if (c == k) s_diag = v;
+                    else if (c > k) {
+                        hval[slot_of(c)] = v;
+                        atomicAdd(&s_pk, 1);
+                    }
+                }
+                wave_sync();
+                pk += first_i(s_pk);
+                const double late = s_diag;
+                if (late == late) dg = late;
+            }
         }
-        if (lane == 0) diag[k] = dk;
-        if (__ballot(overflow)) {
-            if (lane == 0) { status[0] = ICHOLT_ROWCAP; status[1] = k; }
+        pk += add_fill;
+        if (!(dg == dg)) {                                   // no diagonal entry
+            if (lane == 0) { status[0] = ICHOLT_NODIAG; status[1] = k; }
             return;
         }
+        for (int d = 0; d < m; ++d) {
+            const double l = lane_d(rv, d);
+            dg = dg - l * l;
+        }
+        // ---- the updates: of one candidate in ascending j (one product, one subtraction at a time)
+        if (regs) {
+            for (int q = 0; q < total; ++q) {
+                const int ip = lane_i(i0, q);
+                const double pp = lane_d(prod0, q);
+                if (__ballot(me == ip)) {
+                    if (me == ip) val = val - pp;
+                } else {
+                    if (lane == nl) { me = ip; val = 0.0 - pp; }
+                    ++nl;
+                }
+            }
+        } else {
+            for (int base = 0; base < total; base += 64) {
+                int d = d0, i = i0;
+                double prod = prod0;
+                if (base > 0) {
+                    int at;
+                    pair_of(base + lane, d, at, prod);
+                    if (base + lane < total) {
+                        i = ld_i(crow + at);
+                        prod = prod * ld_d(cval + at);
+                    } else {
+                        d = -1;
+                    }
+                }
+                const int d_lo = lane_i(d, 0);
+                const int last = (total - base < 64 ? total - base : 64) - 1;
+                const int d_hi = lane_i(d, last);
+                for (int dd = d_lo; dd <= d_hi; ++dd) {        // one dependency at a time, its entries side by side
+                    if (d == dd) {
+                        const int sl = slot_of(i);
+                        hval[sl] = hval[sl] - prod;
+                    }
+                    wave_sync();
+                }
+            }
+            wave_sync();
+            nl = first_i(s_nused);
+            if (s_err || nl > kIctCand) {
+                if (lane == 0) { status[0] = ICHOLT_CAND; status[1] = k; }
+                return;
+            }
+            if (nl <= 64) {                                    // out of the table into the registers (the table cleared on the way)
+                if (lane < nl) {
+                    const int sl = used[lane];
+                    me = hkey[sl];
+                    val = hval[sl];
+                    hkey[sl] = -1;
+                }
+                if (lane == 0) s_nused = 0;
+            }
+        }
+        if (pk > kIctCap) {
+            if (lane == 0) { status[0] = ICHOLT_COLCAP; status[1] = k; }
+            return;
+        }
+        if (!(dg > 0.0)) {
+            if (lane == 0) { status[0] = ICHOLT_PIVOT; status[1] = k; }
+            return;
+        }
+        const double dk = sqrt(dg);
+        if (nl <= 64) {
+            // ---- the candidates sorted by row (rank counting), norm, threshold, the pk largest
+            int rank = 0;
+            for (int o = 0; o < nl; ++o) rank += lane_i(me, o) < me ? 1 : 0;
+            const int ncand = __popcll(__ballot(me != kNone));
+            if (me != kNone) { si[rank] = me; sv[rank] = val; }
+            wave_sync();
+            const int row = lane < ncand ? si[lane] : kNone;
+            const double w = lane < ncand ? sv[lane] : 0.0;
+            const double sq = w * w, aw = fabs(w);
+            double ss = 0.0;
+            for (int c = 0; c < ncand; ++c) ss = ss + lane_d(sq, c);
+            const double bound = tau * sqrt(ss);
+            const bool pass = lane < ncand && !(aw < bound);
+            const unsigned long long passed = __ballot(pass);
+            bool kp = pass;
+            if (__popcll(passed) > pk) {                      // how many kept candidates come before this one (ties: smaller row)
+                int better = 0;
+                for (int o = 0; o < ncand; ++o) {
+                    if (!((passed >> o) & 1ull)) continue;
+                    const double other = lane_d(aw, o);
+                    better += (other > aw || (other == aw && o < lane)) ? 1 : 0;
+                }
+                kp = pass && better < pk;
+            }
+            const unsigned long long kept = __ballot(kp);
+            const int nkept = __popcll(kept), pos = __popcll(kept & below);
+            // ---- column k of L; its entries' rows' counters requested (the appends follow in the next column)
+            if (kp) {
+                const double l = w / dk;
+                st_i(crow + (size_t)k * kIctCap + pos, row);
+                st_d(cval + (size_t)k * kIctCap + pos, l);
+                pa = true;
+                pa_row = row;
+                pa_l = l;
+                pa_link = (pos + 1) + 256 * nkept;
+                pa_cur = ld_i(rcnt + row);
+                if (row == k + 1) { s_fwd = pa_link; s_fwd_l = l; }    // (link > 0)
+            }
+        } else {
+            // ---- the same through LDS for a column of up to kIctCand candidates (its appends issued at once)
+            const int nused = nl;
+            for (int c = lane; c < nused; c += 64) {
+                const int sl = used[c];
+                ci[c] = hkey[sl];
+                cv[c] = hval[sl];
+                hkey[sl] = -1;
+            }
+            if (lane == 0) s_nused = 0;
+            wave_sync();
+            for (int c = lane; c < nused; c += 64) {
+                const int mine = ci[c];
+                int rank = 0;
+                for (int o = 0; o < nused; ++o) rank += ci[o] < mine ? 1 : 0;
+                si[rank] = mine;
+                sv[rank] = cv[c];
+            }
+            wave_sync();
+            double ss = 0.0;
+            for (int c = 0; c < nused; ++c) ss = ss + sv[c] * sv[c];
+            const double bound = tau * sqrt(ss);
+            int nk = 0;
+            for (int c = 0; c < nused; ++c) nk += !(fabs(sv[c]) < bound) ? 1 : 0;
+            for (int c = lane; c < nused; c += 64) {
+                int kp = !(fabs(sv[c]) < bound) ? 1 : 0;
+                if (kp && nk > pk) {
+                    const double mine = fabs(sv[c]);
+                    int better = 0;
+                    for (int o = 0; o < nused; ++o) {
+                        const double other = fabs(sv[o]);
+                        if (!(other < bound) && (other > mine || (other == mine && o < c))) ++better;
+                    }
+                    kp = better < pk ? 1 : 0;
+                }
+                keep[c] = kp;
+            }
+            wave_sync();
+            int nkept = 0;
+            for (int c = 0; c < nused; ++c) nkept += keep[c];
+            for (int c = lane; c < nused; c += 64) {
+                if (!keep[c]) continue;
+                int pos = 0;
+                for (int o = 0; o < c; ++o) pos += keep[o];
+                const int i = si[c];
+                const double l = sv[c] / dk;
+                st_i(crow + (size_t)k * kIctCap + pos, i);
+                st_d(cval + (size_t)k * kIctCap + pos, l);
+                const int cur = ld_i(rcnt + i);
+                if (cur >= kIctCap) { overflow = true; continue; }
+                const int link = (pos + 1) + 256 * nkept;
+                st_i(rcol + (size_t)i * kIctCap + cur, k);
+                st_i(rcc + (size_t)i * kIctCap + cur, link);
+                st_d(rval + (size_t)i * kIctCap + cur, l);
+                st_i(rcnt + i, cur + 1);
+                if (i == k + 1) { s_fwd = link; s_fwd_l = l; }
+            }
+            if (__ballot(overflow)) {
+                if (lane == 0) { status[0] = ICHOLT_ROWCAP; status[1] = k; }
+                return;
+            }
+        }
+        if (lane == 0) diag[k] = dk;
         wave_sync();
-        // the next row's list: what was fetched, plus the entry this column added to it
-        m = nm; rj = nrj; rc = nrc; rv = nrv;
-        if (s_fwd) {
-            if (lane == m) { rj = k; rc = s_fwd; rv = s_fwd_l; }
+        // the next row's list: what was fetched, plus the entry this column adds to it
+        m = first_i(nm); rj = nrj; rc = nrc; rv = nrv;
+        const int fwd = first_i(s_fwd);
+        if (fwd) {
+            if (lane == m) { rj = k; rc = fwd; rv = s_fwd_l; }
             m += 1;
         }
         wave_sync();
+    }
+    issue_appends(n - 1);
+    if (__ballot(overflow)) {
+        if (lane == 0) { status[0] = ICHOLT_ROWCAP; status[1] = n - 1; }
     }
 }
 
@@ -292,11 +440,14 @@ int icholt_factor(const CsrDev &A, int add_fill_in, double threshold, CsrDev &Lf
         (st = dev_alloc(&cval, wide)) < 0 || (st = dev_alloc(&diag, n)) < 0 || (st = dev_alloc(&status, 2)) < 0 ||
         (st = dev_alloc(&cnt, n + 1)) < 0 || (st = dev_alloc(&Lf.rowptr, n + 1)) < 0)
         return cleanup(st);
+    // DPCG_ICHOLT_REGS=0: every column through the LDS hash table (the path of columns with many pairs; development / test knob)
+    const char *knob = getenv("DPCG_ICHOLT_REGS");
+    const int use_regs = !(knob && knob[0] == '0');
     hipError_t e = hipMemsetAsync(rcnt, 0, (size_t)n * sizeof(int), s);
     if (e == hipSuccess) e = hipMemsetAsync(status, 0, 2 * sizeof(int), s);
     if (e != hipSuccess) return cleanup(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
     hipLaunchKernelGGL(k_icholt, dim3(1), dim3(64), 0, s, (int)n, A.rowptr, A.col, A.val, add_fill_in, threshold, rcnt, rcol, rcc,
-                       rval, crow, cval, diag, status);
+                       rval, crow, cval, diag, status, use_regs);
     int h_status[2] = {0, 0};
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(h_status, status, sizeof(h_status), hipMemcpyDeviceToHost, s);

@@ -1689,18 +1689,38 @@ def test_ict_level1_fill_with_drop_tolerance(D):
         D.ICT("solve", fill_in=-1)
 
 
-def test_icholt_as_ilupp_defines_it(D):
+def _banded_random_spd(n, per_row, band, seed):
+    """Rows with `per_row` random lower neighbours inside a band, diagonally dominant: columns of many candidates for icholt."""
+    rng = np.random.default_rng(seed)
+    r = np.repeat(np.arange(n), per_row)
+    c = r - rng.integers(1, band + 1, r.size)
+    r, c = r[c >= 0], c[c >= 0]
+    E = sp.coo_matrix((-rng.uniform(0.1, 1.0, r.size), (r, c)), shape=(n, n)).tocsr()
+    E.sum_duplicates()
+    E = E + E.T
+    A = (E + sp.diags(np.asarray(abs(E).sum(axis=1)).ravel() + 0.5)).tocsr()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("regs", ["1", "0"])
+def test_icholt_as_ilupp_defines_it(D, monkeypatch, regs):
     """`ICholT` = `ilupp.icholt(A, add_fill_in, threshold)`, the reference harness's default technique (test.py:81-88), factored
     on the device column by column with ILU++'s dual-threshold rule.  The ilupp binary is absent (parity unpinned against it):
     the device factor equals the restatement of the published algorithm, oracle.icholt, BIT FOR BIT -- pattern and values --
-    on grids, scaled / scrambled systems, a quadtree mesh with hanging nodes and a Delaunay graph, for the harness's
-    arguments and others; PCG with the factor solved and multiplied matches the oracle with the same factor; the limits
-    and the error paths of the ABI."""
+    on grids, scaled / scrambled systems, a quadtree mesh with hanging nodes and a Delaunay graph, a banded random matrix whose
+    columns hold more than 64 candidates (the LDS selection) -- for the harness's arguments and others, with the candidates of
+    a column in registers (`regs` = 1, the default) and with every column through the LDS hash table (DPCG_ICHOLT_REGS=0: the
+    path of columns with many updates); PCG with the factor solved and multiplied matches the oracle with the same factor;
+    the limits and the error paths of the ABI."""
     from deeppreconditioning_amd._lib import DpcgError, ERR_INVALID, ERR_PIVOT
+    monkeypatch.setenv("DPCG_ICHOLT_REGS", regs)
     cases = [(O.poisson2d(24), 1, 0.1), (O.poisson2d(24), 0, 0.0), (O.poisson3d(10), 1, 0.1), (O.poisson3d(10), 3, 0.01),
              (O.unstructured_like(O.poisson3d(9), seed=2), 1, 0.1), (O.unstructured_like(O.poisson2d(40), seed=5), 2, 0.05),
              (O.quadtree_fv_laplacian(40, 1), 1, 0.1), (O.quadtree_fv_laplacian(40, 1, numbering="random"), 4, 0.001),
-             (O.delaunay_laplacian(3000, 4), 1, 0.1), (O.poisson2d(12), 200, 0.0)]
+             (O.delaunay_laplacian(3000, 4), 1, 0.1), (_banded_random_spd(400, 10, 150, 7), 8, 1e-4), (O.poisson2d(12), 200, 0.0)]
+    with pytest.raises(ValueError):
+        O.icholt(cases[-2][0], 8, 1e-4, cand_cap=64)                     # (that case does hold columns of more than 64 candidates)
     for A, fill, thr in cases:
         n = A.shape[0]
         S = D.CsrSystem.from_any(A)
