@@ -900,6 +900,38 @@ __global__ __launch_bounds__(kBlock) void k_triangle_edges(int64_t n, const int3
     }
 }
 
+// How far from bipartite?  Of the rows v = 0, stride, 2 stride, ... : out[0] counts them, out[1] those with an entry on a triangle (a
+// proven odd cycle through the vertex).  A Delaunay graph or a grid with a diagonal per cell: every vertex; a grid: none; a mesh
+// with refinement interfaces or a few extra couplings: the vertices there.
+__global__ __launch_bounds__(kBlock) void k_triangle_sample(int64_t n, int64_t stride_rows, const int32_t *__restrict__ rp,
+                                                            const int32_t *__restrict__ ci, int *out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int seen = 0, touched = 0;
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t * stride_rows < n; t += stride) {
+        const int64_t v = t * stride_rows;
+        const int vs = rp[v], ve = rp[v + 1];
+        bool tri = false;
+        for (int k = vs; k < ve && !tri; ++k) {
+            const int u = ci[k];
+            if (u == v) continue;
+            int a = vs, b = rp[u];
+            const int be = rp[u + 1];
+            while (a < ve && b < be) {
+                const int ca = ci[a], cb = ci[b];
+                if (ca == cb) {
+                    if (ca != v && ca != u) { tri = true; break; }
+                    ++a; ++b;
+                } else if (ca < cb) ++a;
+                else ++b;
+            }
+        }
+        ++seen;
+        touched += tri ? 1 : 0;
+    }
+    if (seen) atomicAdd(out, seen);
+    if (touched) atomicAdd(out + 1, touched);
+}
+
 // Repair of an almost proper two-colouring (a mesh that is bipartite but for a few odd cycles -- refinement interfaces, a handful
 // of extra couplings): of every edge that joins two vertices of one colour the endpoint of larger index loses its colour
 // (-1); Jones-Plassmann then colours those vertices around the ones that keep theirs.  *marked counts them.
@@ -962,6 +994,7 @@ static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bo
         if (now == n) break;
         if (now == visited) {                        // a component without a seed
             if (skip && nearly && (int64_t)(n - now) * 8 <= n) break;     // (skipped edges: a few unreachable vertices are repaired later)
+            if (pt.on) fprintf(stderr, "[dpcg setup]   regions: %lld of %lld vertices not reached after %d steps\n", (long long)(n - now), (long long)n, cur);
             return DPCG_OK;
         }
         visited = now;
@@ -1019,7 +1052,10 @@ static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bo
         DPCG_HIP(hipMemcpyAsync(&hb, best.p, sizeof(hb), hipMemcpyDeviceToHost, s));
         DPCG_HIP(hipStreamSynchronize(s));
         if (hb == ~0ull) continue;                                                 // an empty region
-        if (++real_comps > 8) return DPCG_OK;                                      // many components: the searches below handle them
+        if (++real_comps > 8) {                                                    // many components: the searches below handle them
+            if (pt.on) fprintf(stderr, "[dpcg setup]   regions: more than 8 components\n");
+            return DPCG_OK;
+        }
         int32_t sv = 0;
         DPCG_HIP(hipMemcpyAsync(&sv, state.p + (hb & 0xffffffffu), sizeof(int32_t), hipMemcpyDeviceToHost, s));
         DPCG_HIP(hipStreamSynchronize(s));
@@ -1056,7 +1092,29 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
     bool nearly = false, repaired = false;
     static const bool repair_on = [] { const char *e = getenv("DPCG_COLOR_REPAIR"); return !(e && e[0] == '0'); }();
     int32_t *const scratch[4] = {perm.p, iperm.p, iota.p, reinterpret_cast<int32_t *>(key_sorted.p)};     // (free until the sort by colour)
-    if (regions_on) DPCG_TRY(two_colors_by_regions(A, color.p, flags.p, &colored, repair_on ? &nearly : nullptr, nullptr, s, scratch));   // 0. two colours, many searches at once
+    // -1. how far from bipartite is the graph?  Triangles through a sample of the vertices (every 64th; all of a small graph).  More
+    // than an eighth of them on a triangle (a Delaunay graph, a grid with diagonals: all of them): no two big classes to be had -- the
+    // two-colouring attempts below would each walk the whole graph to find that out (1M-row meshes: 45 of the 49 ms of this
+    // function) -- straight to the greedy colouring.  Some, but few: the graph has odd cycles, so the plain regions (0.) are skipped
+    // and the regions without the triangle edges (0b.) tried at once.  None: as a grid.
+    bool far = false, some = false;
+    if (regions_on) {
+        const int64_t stride_rows = n >= 4096 ? 64 : 1;
+        DPCG_HIP(hipMemsetAsync(flags.p, 0, 4 * sizeof(int), s));
+        hipLaunchKernelGGL(k_triangle_sample, dim3(rows_grid((n + stride_rows - 1) / stride_rows, 256)), dim3(kBlock), 0, s, n, stride_rows,
+                           A.rowptr, A.col, flags.p);
+        int h_tri[2] = {0, 0};
+        DPCG_HIP(hipMemcpyAsync(h_tri, flags.p, sizeof(h_tri), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        some = h_tri[1] > 0;
+        far = (int64_t)h_tri[1] * 8 > (int64_t)h_tri[0];
+        if (pt.on) fprintf(stderr, "[dpcg setup]   %d of %d sampled vertices on a triangle\n", h_tri[1], h_tri[0]);
+        pt.mark("  triangle sample");
+    }
+    bool odd_proven = some;
+    if (regions_on && !some) DPCG_TRY(two_colors_by_regions(A, color.p, flags.p, &colored, repair_on ? &nearly : nullptr, nullptr, s, scratch));   // 0. two colours, many searches at once
+    odd_proven = odd_proven || nearly;      // (every vertex reached and the colouring improper: an odd cycle)
+    if (regions_on && repair_on && some && !far) nearly = true;
     if (!colored && nearly) {
         // 0b. nearly bipartite (odd cycles, but few): the regions once more without the edges that lie on triangles -- breadth-first
         // parity follows every shortcut, an extra coupling would flip the cone of vertices behind it -- then the two big classes stay
@@ -1064,7 +1122,9 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
         Buf<uint8_t> skip;
         DPCG_TRY(skip.alloc(A.nnz));
         hipLaunchKernelGGL(k_triangle_edges, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, skip.p);
+        nearly = false;
         DPCG_TRY(two_colors_by_regions(A, color.p, flags.p, &colored, &nearly, skip.p, s, scratch));
+        pt.mark("  regions without triangle edges");
     }
     if (!colored && nearly) {
         DPCG_HIP(hipMemsetAsync(flags.p, 0, 4 * sizeof(int), s));
@@ -1078,7 +1138,7 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
             repaired = true;
         }
     }
-    if (!colored && !repaired) {   // 1. breadth-first parity, component by component
+    if (!colored && !repaired && !odd_proven) {   // 1. breadth-first parity, component by component (pointless once an odd cycle is known)
         Buf<int32_t> deg, level, order, start, count;
         Buf<unsigned long long> best;
         const int64_t nlv = n + 2 + 2 * kBfsBatch;
@@ -1114,6 +1174,7 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
             DPCG_HIP(hipStreamSynchronize(s));
             colored = bad == 0;
         }
+        pt.mark("  breadth-first parity");
     }
     if (!colored) {   // 2. Jones-Plassmann greedy colouring (of everything, or of the vertices the repair left uncoloured)
         if (!repaired) DPCG_HIP(hipMemsetAsync(color.p, 0xff, (size_t)n * sizeof(int32_t), s));
@@ -1136,6 +1197,7 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
                 hipLaunchKernelGGL(k_peel_degrees, dim3(rows_grid(n, 1024)), dim3(kBlock), 0, s, n, A.rowptr, A.col, prank.p, peel_rounds, pdeg.p, pctl.p);
             }
             rank_dev = prank.p;
+            pt.mark("  peel ranks");
         }
         int rounds = 0;
         for (;;) {
@@ -1157,6 +1219,8 @@ int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, i
         DPCG_HIP(hipMemcpyAsync(&bad, flags.p + 2, sizeof(int), hipMemcpyDeviceToHost, s));
         DPCG_HIP(hipStreamSynchronize(s));
         if (bad) return invalid("multicolour ordering: improper colouring (is the pattern structurally symmetric?)");
+        if (pt.on) fprintf(stderr, "[dpcg setup]   greedy colouring: %d rounds\n", rounds);
+        pt.mark("  greedy rounds");
         // fewer colours = fewer levels for the triangular solves: a few passes of iterated greedy over the classes, last to first
         // (not after a repair: the two big classes are what the repair is for)
         static const int passes_knob = [] { const char *e = getenv("DPCG_RECOLOR_PASSES"); return e ? atoi(e) : 3; }();
