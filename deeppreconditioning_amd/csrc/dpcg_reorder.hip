@@ -794,7 +794,7 @@ __global__ __launch_bounds__(kBlock) void k_check_coloring(int64_t n, const int3
 constexpr int kRegionsSmall = 256, kRegionsLarge = 1024;      // seeds: 1024 from 2M vertices on (a 256^3 grid: ~40 -> ~25 growth steps of 0.5 ms each)
 constexpr int kRegionBatch = 16;      // growth steps enqueued between two looks at the visited count
 
-__global__ void k_region_seed(int64_t n, int32_t *step, int32_t *state, int *visited, int kRegions) {
+__global__ void k_region_seed(int64_t n, int32_t *step, int32_t *state, int *visited, int kRegions, int32_t *front, int *front_n) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= kRegions) return;
     // hashed positions: evenly spaced indices would line the seeds up along one edge of a naturally ordered grid
@@ -803,36 +803,71 @@ __global__ void k_region_seed(int64_t n, int32_t *step, int32_t *state, int *vis
     if (atomicCAS(step + v, -1, 0) == -1) {
         state[v] = r << 1;
         atomicAdd(visited, 1);
+        front[atomicAdd(front_n, 1)] = (int32_t)v;
     }
 }
 
-// one growth step: an unvisited vertex with a neighbour that joined at step `cur` joins the region of the FIRST such neighbour in
-// its row (ascending columns: deterministic), with the opposite parity
-// `skip` (may be null): entries the growth does not walk along (edges that lie on a triangle, k_triangle_edges)
-__global__ __launch_bounds__(kBlock) void k_region_grow(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
-                                                        const uint8_t *__restrict__ skip, int32_t *step, int32_t *state, int cur,
-                                                        int *visited) {
-    __shared__ int sh_new;
-    if (threadIdx.x == 0) sh_new = 0;
-    __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    int joined = 0;
-    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) {
-        if (__hip_atomic_load(step + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) continue;
-        for (int k = rp[v]; k < rp[v + 1]; ++k) {
-            const int u = ci[k];
-            if (skip && skip[k]) continue;
-            if (__hip_atomic_load(step + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cur) {
-                state[v] = state[u] ^ 1;           // (state[u] was written by an earlier launch)
-                __hip_atomic_store(step + v, cur + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ++joined;
-                break;
+// One growth step, from the FRONT (the vertices that joined at step `cur`; at 256^3 a scan of all 16.8M vertices per step was 12.5 of
+// the 15 ms of this ordering): k_region_push offers every unvisited neighbour of a front vertex u the parent u -- cand[v] = the
+// smallest such u, which is the first neighbour of v's (ascending) row that joined at step cur, whatever order the lanes run in --
+// and lists v once (the offer that finds cand[v] unset); k_region_settle then gives the listed vertices their region and the
+// opposite parity of their parent.  front_n[cur & 3] = length of the front of step cur ([(cur + 2) & 3] is cleared on the way).
+constexpr int kCandUnset = 0x7f7f7f7f;      // (hipMemset of 0x7f)
+__global__ __launch_bounds__(kBlock) void k_region_push(const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                        const uint8_t *__restrict__ skip, const int32_t *__restrict__ step,
+                                                        int32_t *cand, const int32_t *__restrict__ front, int32_t *next, int *front_n,
+                                                        int cur) {
+    const int count = front_n[cur & 3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) front_n[(cur + 2) & 3] = 0;
+    const int stride = gridDim.x * kBlock, lane = threadIdx.x & 63;
+    int *const next_n = front_n + ((cur + 1) & 3);
+    for (int t0 = blockIdx.x * kBlock; t0 < count; t0 += stride) {      // (the same trip count for every lane of a wave)
+        const int t = t0 + threadIdx.x;
+        unsigned long long won = 0;          // the entries of u's row whose vertex this lane lists
+        int r0 = 0;
+        if (t < count) {
+            const int u = front[t];
+            r0 = rp[u];
+            for (int k = r0; k < rp[u + 1]; ++k) {
+                if (skip && skip[k]) continue;
+                const int v = ci[k];
+                if (step[v] >= 0) continue;
+                if (atomicMin(cand + v, u) != kCandUnset) continue;
+                if (k - r0 < 64) won |= 1ull << (k - r0);
+                else next[atomicAdd(next_n, 1)] = v;
             }
         }
+        // one counter update per wave (16.8M single-address atomics were most of a 256^3 growth)
+        const int mine = __popcll(won);
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(incl, off);
+            if (lane >= off) incl += y;
+        }
+        const int total = __shfl(incl, 63);
+        if (total == 0) continue;
+        int base = 0;
+        if (lane == 63) base = atomicAdd(next_n, total);
+        int at = __shfl(base, 63) + incl - mine;
+        while (won) {
+            const int kb = __ffsll((long long)won) - 1;
+            won &= won - 1;
+            next[at++] = ci[r0 + kb];
+        }
     }
-    if (joined) atomicAdd(&sh_new, joined);
-    __syncthreads();
-    if (threadIdx.x == 0 && sh_new) atomicAdd(visited, sh_new);
+}
+__global__ __launch_bounds__(kBlock) void k_region_settle(int32_t *step, int32_t *state, const int32_t *__restrict__ cand,
+                                                          const int32_t *__restrict__ next, const int *__restrict__ front_n, int cur,
+                                                          int *visited) {
+    const int count = front_n[(cur + 1) & 3];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && count) atomicAdd(visited, count);
+    const int stride = gridDim.x * kBlock;
+    for (int t = blockIdx.x * kBlock + threadIdx.x; t < count; t += stride) {
+        const int v = next[t];
+        state[v] = state[cand[v]] ^ 1;           // (the parent's state was written by an earlier launch)
+        step[v] = cur + 1;
+    }
 }
 
 // rel[2 * (a * kRegions + b) + 0] counts the edges that join regions a and b with opposite parities (the two regions agree as they
@@ -982,12 +1017,22 @@ static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bo
     PhaseTimer pt(s);
     DPCG_HIP(hipMemsetAsync(step.p, 0xff, (size_t)n * sizeof(int32_t), s));
     DPCG_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
-    hipLaunchKernelGGL(k_region_seed, dim3((kRegions + 63) / 64), dim3(64), 0, s, n, step.p, state.p, flags, kRegions);
+    // during the growth: cand in `deg`, the two fronts in `mask` and in `color` (all three are written afresh afterwards)
+    int32_t *const cand = deg.p, *const front[2] = {mask.p, color};
+    Buf<int> front_n;
+    DPCG_TRY(front_n.alloc(4));
+    DPCG_HIP(hipMemsetAsync(front_n.p, 0, 4 * sizeof(int), s));
+    DPCG_HIP(hipMemsetAsync(cand, 0x7f, (size_t)n * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_region_seed, dim3((kRegions + 63) / 64), dim3(64), 0, s, n, step.p, state.p, flags, kRegions, front[0], front_n.p);
     int visited = 0, cur = 0;
+    const int grow_grid = rows_grid(n / 4 + 1, 2048);
     for (;;) {
-        for (int b = 0; b < kRegionBatch; ++b, ++cur)
-            hipLaunchKernelGGL(k_region_grow, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, skip, step.p, state.p, cur,
+        for (int b = 0; b < kRegionBatch; ++b, ++cur) {
+            hipLaunchKernelGGL(k_region_push, dim3(grow_grid), dim3(kBlock), 0, s, A.rowptr, A.col, skip, step.p, cand, front[cur & 1],
+                               front[(cur + 1) & 1], front_n.p, cur);
+            hipLaunchKernelGGL(k_region_settle, dim3(grow_grid), dim3(kBlock), 0, s, step.p, state.p, cand, front[(cur + 1) & 1], front_n.p, cur,
                                flags);
+        }
         int now = 0;
         DPCG_HIP(hipMemcpyAsync(&now, flags, sizeof(int), hipMemcpyDeviceToHost, s));
         DPCG_HIP(hipStreamSynchronize(s));
