@@ -256,18 +256,48 @@ __global__ __launch_bounds__(kBlock) void k_perm_lengths(int64_t n, const int32_
         len[r] = r < n ? rp[perm[r] + 1] - rp[perm[r]] : 0;
 }
 
-// row r of P A P^T = row perm[r] of A with columns relabelled through iperm, sorted ascending (insertion sort in place:
-// rows are short; the values move with their columns, so every product of a row sum is the same number as before,
-// only their order in the sum follows the new column order)
+// row r of P A P^T = row perm[r] of A with columns relabelled through iperm, sorted ascending (the values move with their columns,
+// so every product of a row sum is the same number as before, only their order in the sum follows the new column order).
+// A row of up to kPermStage entries is staged in the thread's own LDS column: its loads are independent of each other, the
+// insertion sort runs in LDS and the row is written once (sorting in place in global memory -- a dependent load of the entry just
+// written per step -- took 6.2 ms for the 117M entries of a 256^3 system); longer rows sort in place.
+constexpr int kPermStage = 16;
 __global__ __launch_bounds__(kBlock) void k_perm_rows(int64_t n, const int32_t *__restrict__ perm,
                                                       const int32_t *__restrict__ iperm, const int32_t *__restrict__ rp,
                                                       const int32_t *__restrict__ ci, const double *__restrict__ v,
                                                       const int32_t *__restrict__ nrp, int32_t *__restrict__ nci,
                                                       double *__restrict__ nv) {
+    __shared__ int sc[kPermStage][kBlock];
+    __shared__ double sx[kPermStage][kBlock];
+    const int tid = threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) {
         const int old = perm[r];
         const int src = rp[old], len = rp[old + 1] - src, dst = nrp[r];
+        if (len <= kPermStage) {
+            for (int k = 0; k < len; ++k) {
+                sc[k][tid] = iperm[ci[src + k]];
+                sx[k][tid] = v[src + k];
+            }
+            for (int k = 1; k < len; ++k) {
+                const int c = sc[k][tid];
+                if (sc[k - 1][tid] <= c) continue;               // (already in place: the common case)
+                const double x = sx[k][tid];
+                int q = k;
+                while (q > 0 && sc[q - 1][tid] > c) {
+                    sc[q][tid] = sc[q - 1][tid];
+                    sx[q][tid] = sx[q - 1][tid];
+                    --q;
+                }
+                sc[q][tid] = c;
+                sx[q][tid] = x;
+            }
+            for (int k = 0; k < len; ++k) {
+                nci[dst + k] = sc[k][tid];
+                nv[dst + k] = sx[k][tid];
+            }
+            continue;
+        }
         for (int k = 0; k < len; ++k) {
             const int c = iperm[ci[src + k]];
             const double x = v[src + k];
