@@ -921,6 +921,19 @@ __global__ __launch_bounds__(kBlock) void k_region_relations(int64_t n, const in
     }
 }
 
+// the related pairs of regions (a < b) as a list {a, b, opposite, equal}: a region touches a dozen others, so the host reads some
+// 10K entries instead of the kRegions^2 matrix (8 MB and a million pairs to look at with 1024 regions)
+__global__ __launch_bounds__(kBlock) void k_region_pairs(const unsigned int *__restrict__ rel, int kRegions, int4 *__restrict__ out,
+                                                         int *count) {
+    const int64_t total = (int64_t)kRegions * kRegions, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += stride) {
+        const int a = (int)(idx / kRegions), b = (int)(idx % kRegions);
+        if (a >= b) continue;
+        const unsigned opposite = rel[2 * idx], equal = rel[2 * idx + 1];
+        if (opposite | equal) out[atomicAdd(count, 1)] = make_int4(a, b, (int)opposite, (int)equal);
+    }
+}
+
 // mask[v] = -1 (a candidate) for the vertices of the regions of component `comp`, 0 otherwise: k_min_degree's "unvisited" filter
 __global__ __launch_bounds__(kBlock) void k_region_mask(int64_t n, const int32_t *__restrict__ step, const int32_t *__restrict__ state,
                                                         const int32_t *__restrict__ comp_of, int comp, int32_t *__restrict__ mask) {
@@ -1077,9 +1090,27 @@ static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bo
     pt.mark("  regions: growth");
     DPCG_HIP(hipMemsetAsync(rel.p, 0, 2 * (size_t)kRegions * kRegions * sizeof(unsigned int), s));
     hipLaunchKernelGGL(k_region_relations, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, skip, step.p, state.p, rel.p, kRegions);
-    std::vector<unsigned int> h_rel(2 * (size_t)kRegions * kRegions);
-    DPCG_HIP(hipMemcpyAsync(h_rel.data(), rel.p, h_rel.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    Buf<int4> pairs;
+    Buf<int> n_pairs;
+    DPCG_TRY(pairs.alloc((int64_t)kRegions * kRegions / 2));
+    DPCG_TRY(n_pairs.alloc(1));
+    DPCG_HIP(hipMemsetAsync(n_pairs.p, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_region_pairs, dim3(rows_grid((int64_t)kRegions * kRegions, 1024)), dim3(kBlock), 0, s, rel.p, kRegions, pairs.p, n_pairs.p);
+    int h_n_pairs = 0;
+    DPCG_HIP(hipMemcpyAsync(&h_n_pairs, n_pairs.p, sizeof(int), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
+    std::vector<int4> h_pairs((size_t)h_n_pairs);
+    if (h_n_pairs) DPCG_HIP(hipMemcpyAsync(h_pairs.data(), pairs.p, h_pairs.size() * sizeof(int4), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    // every region's neighbours in ascending order (the list arrives in the order of the atomics: sorted here, so that the walk below
+    // -- and with it, for a graph with odd cycles, which relation is seen first -- is the same from run to run)
+    struct Rel { int b; unsigned opposite, equal; };
+    std::vector<std::vector<Rel>> adj((size_t)kRegions);
+    for (const int4 &q : h_pairs) {
+        adj[(size_t)q.x].push_back(Rel{q.y, (unsigned)q.z, (unsigned)q.w});
+        adj[(size_t)q.y].push_back(Rel{q.x, (unsigned)q.z, (unsigned)q.w});
+    }
+    for (auto &list : adj) std::sort(list.begin(), list.end(), [](const Rel &x, const Rel &y) { return x.b < y.b; });
     // walk the graph of regions: flip[b] relative to the first region of its component
     std::vector<int32_t> flip((size_t)kRegions, 0), comp((size_t)kRegions, -1), stack;
     int n_comp = 0;
@@ -1090,9 +1121,9 @@ static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bo
         while (!stack.empty()) {
             const int a = stack.back();
             stack.pop_back();
-            for (int b = 0; b < kRegions; ++b) {
-                const unsigned opposite = h_rel[2 * ((size_t)a * kRegions + b)], equal = h_rel[2 * ((size_t)a * kRegions + b) + 1];
-                if (!opposite && !equal) continue;
+            for (const Rel &nb : adj[(size_t)a]) {
+                const int b = nb.b;
+                const unsigned opposite = nb.opposite, equal = nb.equal;
                 const unsigned bits = (opposite ? 1u : 0u) | (equal ? 2u : 0u);
                 if (bits == 3u) {                                                 // an odd cycle through the two regions
                     if (!nearly) return DPCG_OK;
