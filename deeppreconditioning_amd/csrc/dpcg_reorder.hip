@@ -837,6 +837,36 @@ __global__ void k_region_seed(int64_t n, int32_t *step, int32_t *state, int *vis
     }
 }
 
+// One growth step by a scan of every vertex (systems below 2M rows, where a step is a few microseconds and one launch instead of
+// two matters more than the vertices looked at in vain): an unvisited vertex with a neighbour that joined at step `cur` joins the region of the FIRST such neighbour in
+// its row (ascending columns: deterministic), with the opposite parity
+// `skip` (may be null): entries the growth does not walk along (edges that lie on a triangle, k_triangle_edges)
+__global__ __launch_bounds__(kBlock) void k_region_grow(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                        const uint8_t *__restrict__ skip, int32_t *step, int32_t *state, int cur,
+                                                        int *visited) {
+    __shared__ int sh_new;
+    if (threadIdx.x == 0) sh_new = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int joined = 0;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += stride) {
+        if (__hip_atomic_load(step + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) continue;
+        for (int k = rp[v]; k < rp[v + 1]; ++k) {
+            const int u = ci[k];
+            if (skip && skip[k]) continue;
+            if (__hip_atomic_load(step + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cur) {
+                state[v] = state[u] ^ 1;           // (state[u] was written by an earlier launch)
+                __hip_atomic_store(step + v, cur + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ++joined;
+                break;
+            }
+        }
+    }
+    if (joined) atomicAdd(&sh_new, joined);
+    __syncthreads();
+    if (threadIdx.x == 0 && sh_new) atomicAdd(visited, sh_new);
+}
+
 // One growth step, from the FRONT (the vertices that joined at step `cur`; at 256^3 a scan of all 16.8M vertices per step was 12.5 of
 // the 15 ms of this ordering): k_region_push offers every unvisited neighbour of a front vertex u the parent u -- cand[v] = the
 // smallest such u, which is the first neighbour of v's (ascending) row that joined at step cur, whatever order the lanes run in --
@@ -1069,8 +1099,14 @@ static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bo
     hipLaunchKernelGGL(k_region_seed, dim3((kRegions + 63) / 64), dim3(64), 0, s, n, step.p, state.p, flags, kRegions, front[0], front_n.p);
     int visited = 0, cur = 0;
     const int grow_grid = rows_grid(n / 4 + 1, 2048);
+    const bool from_front = n >= (1 << 21);       // (the same regions either way: measured 256^2 0.39 -> 0.57 ms from the front, 256^3 12.5 -> 8.2)
     for (;;) {
         for (int b = 0; b < kRegionBatch; ++b, ++cur) {
+            if (!from_front) {
+                hipLaunchKernelGGL(k_region_grow, dim3(rows_grid(n, 2048)), dim3(kBlock), 0, s, n, A.rowptr, A.col, skip, step.p, state.p, cur,
+                                   flags);
+                continue;
+            }
             hipLaunchKernelGGL(k_region_push, dim3(grow_grid), dim3(kBlock), 0, s, A.rowptr, A.col, skip, step.p, cand, front[cur & 1],
                                front[(cur + 1) & 1], front_n.p, cur);
             hipLaunchKernelGGL(k_region_settle, dim3(grow_grid), dim3(kBlock), 0, s, step.p, state.p, cand, front[(cur + 1) & 1], front_n.p, cur,
