@@ -101,6 +101,61 @@ __global__ __launch_bounds__(kBlock) void k_bfs_step(const int32_t *__restrict__
     }
 }
 
+// A run of NARROW frontiers as one launch of one workgroup: a 2-D mesh of a million cells has ~2000 levels of ~500 vertices, and a
+// launch per level costs ~7 us of which the work is a fraction (three searches: 42 of the 80 ms of its reordering).  Here the levels
+// follow each other behind workgroup barriers -- what a thread appends to `order`, the next level's threads (same CU, same L1) read
+// -- until the frontier is empty or wider than `cap`; out[0] = the first level NOT expanded, out[1] = its width.  What it saves is the
+// launches, not the ~5 dependent memory accesses of a level: on a graph that does not fit the L2 those cost ~6 us a level either way
+// (1M-cell mesh, frontiers of ~500: 45.9 ms against 42.3 for the launches), so the cap is narrow there (narrow_cap()).
+constexpr int kNarrowCap = 2048;
+__global__ __launch_bounds__(1024) void k_bfs_narrow(const int32_t *__restrict__ rp, const int32_t *__restrict__ ci, int32_t *level,
+                                                     int32_t *order, int32_t *start, int32_t *count, int L, int max_level, int cap, int *out) {
+    __shared__ int s_next, s_s0, s_c0;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        s_s0 = start[L];
+        s_c0 = count[L];
+        s_next = 0;
+    }
+    __syncthreads();
+    for (;;) {
+        const int s0 = s_s0, c0 = s_c0;
+        if (c0 == 0 || c0 > cap || L >= max_level) break;
+        for (int idx = t; idx < c0; idx += 1024) {
+            const int v = order[s0 + idx];
+            const int ks = rp[v], ke = rp[v + 1];
+            for (int k0 = ks; k0 < ke; k0 += 8) {            // (as k_bfs_step: columns, their levels, the claims, phase by phase)
+                int u[8], lu[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) u[q] = k0 + q < ke ? ci[k0 + q] : v;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) lu[q] = u[q] != v ? level[u[q]] : 0;   // (a stale -1 only costs the atomic below)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (lu[q] < 0) lu[q] = atomicCAS(&level[u[q]], -1, L + 1);      // -1: this thread claimed it
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (lu[q] == -1 && u[q] != v) order[s0 + c0 + atomicAdd(&s_next, 1)] = u[q];
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            const int c1 = s_next;
+            start[L + 1] = s0 + c0;
+            count[L + 1] = c1;
+            s_s0 = s0 + c0;
+            s_c0 = c1;
+            s_next = 0;
+        }
+        ++L;
+        __syncthreads();
+    }
+    if (t == 0) {
+        out[0] = L;
+        out[1] = s_c0;
+    }
+}
+
 // Cuthill-McKee, step A for level L: key[u] = position of u's first-numbered neighbour in level L - 1; that parent's
 // child counter goes up by one.
 __global__ __launch_bounds__(kBlock) void k_cm_keys(const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
@@ -197,6 +252,77 @@ __global__ __launch_bounds__(kBlock) void k_cm_place(const int32_t *__restrict__
         const int np = s1 + base[mp] + rank;
         pos[u] = np;
         vertex_at[np] = u;
+    }
+}
+
+// Cuthill-McKee positions of a run of NARROW levels (this one and the one before it of at most 1024 vertices) as one launch of one
+// workgroup: the same order as k_cm_keys / k_scan_range / k_cm_place give -- a level sorted by (position of the first-numbered
+// parent, degree, index) -- with the children counted, scanned and ranked among their siblings in LDS (the three launches of a level
+// are ~15 dependent memory round trips, 18.6 us; 37 of the 80 ms of a 1M-cell 2-D mesh's reordering).
+__global__ __launch_bounds__(1024) void k_cm_narrow(const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                    const int32_t *__restrict__ level, const int32_t *__restrict__ order,
+                                                    const int32_t *__restrict__ deg, const int32_t *__restrict__ start,
+                                                    const int32_t *__restrict__ count, int32_t *pos, int32_t *vertex_at, int L_first,
+                                                    int L_last, int *err) {
+    __shared__ int s_deg[1024], s_u[1024], s_child[1024], s_base[1024], s_grp[1024], s_wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int L = L_first; L <= L_last; ++L) {
+        const int s1 = start[L], c1 = count[L], s0 = start[L - 1];
+        s_child[t] = 0;
+        __syncthreads();
+        int u = -1, mp = 0x7fffffff, du = 0, slot = 0;
+        if (t < c1) {
+            u = order[s1 + t];
+            const int ks = rp[u], ke = rp[u + 1];
+            for (int k0 = ks; k0 < ke; k0 += 8) {            // eight neighbours at a time: columns, levels, positions
+                int v[8], lv8[8], pv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = ci[k0 + q < ke ? k0 + q : ke - 1];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) lv8[q] = level[v[q]];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pv[q] = lv8[q] == L - 1 ? pos[v[q]] : 0x7fffffff;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) mp = pv[q] < mp ? pv[q] : mp;
+            }
+            du = deg[u];
+            if (mp == 0x7fffffff) atomicExch(err, 1);       // (no parent in its own row: the pattern is not symmetric)
+            else slot = atomicAdd(&s_child[mp - s0], 1);     // arrival among the parent's children (any order)
+        }
+        s_deg[t] = du;
+        s_u[t] = u;
+        __syncthreads();
+        {   // exclusive scan of the children counts over the (at most 1024) parents
+            const int mine = s_child[t];
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(incl, off);
+                if (lane >= off) incl += y;
+            }
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            int before = 0;
+            for (int w = 0; w < wave; ++w) before += s_wsum[w];
+            s_base[t] = before + incl - mine;
+        }
+        __syncthreads();
+        const bool placed = u >= 0 && mp != 0x7fffffff;
+        if (placed) s_grp[s_base[mp - s0] + slot] = t;
+        __syncthreads();
+        if (placed) {
+            const int b = s_base[mp - s0], e = b + s_child[mp - s0];
+            int rank = 0;
+            for (int j = b; j < e; ++j) {
+                const int o = s_grp[j];
+                const int dw = s_deg[o], w = s_u[o];
+                if (o != t && (dw < du || (dw == du && w < u))) ++rank;
+            }
+            const int np = s1 + b + rank;
+            pos[u] = np;
+            vertex_at[np] = u;
+        }
+        __syncthreads();
     }
 }
 
@@ -441,12 +567,28 @@ namespace {
 int bfs(const CsrDev &A, int root, int L0, int at, int32_t *level, int32_t *order, int32_t *start, int32_t *count,
         std::vector<int32_t> &h_start, std::vector<int32_t> &h_count, int *n_levels, hipStream_t s) {
     hipLaunchKernelGGL(k_bfs_seed, dim3(1), dim3(64), 0, s, root, L0, at, level, order, start, count);
+    static const bool narrow_on = [] { const char *e = getenv("DPCG_RCM_NARROW"); return !(e && e[0] == '0'); }();   // development knob
+    Buf<int> where;
+    DPCG_TRY(where.alloc(2));
     int L = L0;
+    int32_t last = 1;                                      // width of level L (the seed)
+    // measured, create + RCM, a launch per level -> narrow runs: 60K-cell mesh 16.1 -> 6.4 ms, 30K rows in two components 12.0 -> 4.1,
+    // a 5000-vertex path 131 -> 28.5, 600^2 scrambled 38.6 -> 21.5 (tools/rcm_narrow_ab.py)
+    const int cap = A.n <= 524288 ? kNarrowCap : 128;
     for (;;) {
+        if (narrow_on && last <= cap) {                    // narrow frontiers: one workgroup walks them, level after level
+            hipLaunchKernelGGL(k_bfs_narrow, dim3(1), dim3(1024), 0, s, A.rowptr, A.col, level, order, start, count, L, (int)A.n + 1, cap,
+                               where.p);
+            int h_where[2] = {0, 0};
+            DPCG_HIP(hipMemcpyAsync(h_where, where.p, sizeof(h_where), hipMemcpyDeviceToHost, s));
+            DPCG_HIP(hipStreamSynchronize(s));
+            L = h_where[0];
+            last = h_where[1];
+            if (last == 0 || (int64_t)L >= A.n + 1) break;
+        }
         for (int b = 0; b < kBfsBatch; ++b)
             hipLaunchKernelGGL(k_bfs_step, dim3(kBfsGrid), dim3(kBlock), 0, s, A.rowptr, A.col, level, order, start, count, L + b);
         L += kBfsBatch;
-        int32_t last = 0;
         DPCG_HIP(hipMemcpyAsync(&last, count + L, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         DPCG_HIP(hipStreamSynchronize(s));
         if (last == 0 || (int64_t)L >= A.n + 1) break;
@@ -509,7 +651,12 @@ int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_c
         ++n_bfs;
         if (comps.empty()) {
             // pseudo-peripheral start vertex for the first (normally the only) component
-            for (int sweep = 0; sweep < 4; ++sweep) {
+            // ONE move: from the vertex of smallest degree to the smallest-degree vertex of its last level.  Moving on while the
+            // search gets deeper (George-Liu, up to four more searches) cost a 1M-cell 2-D mesh one search of ~2000 levels more
+            // (64.1 -> 49.4 ms to create the system), a Delaunay graph two (37.6 -> 25.6), for the same SpMV time (14.1 / 17.1 us):
+            // tools/rcm_narrow_ab.py.  DPCG_RCM_SWEEPS: development knob.
+            static const int sweeps = [] { const char *e = getenv("DPCG_RCM_SWEEPS"); return e ? atoi(e) : 1; }();
+            for (int sweep = 0; sweep < sweeps; ++sweep) {
                 const int last = nl - 1;
                 int cand = -1;
                 DPCG_TRY(min_degree(order.p, h_start[(size_t)last], (int64_t)h_start[(size_t)last] + h_count[(size_t)last], 0, &cand));
@@ -550,7 +697,16 @@ int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_c
     // rows (3-D) against 14 / 29 us for the launches below; with release / acquire fences instead, which write the L2 back, 39 / 100 us.)
     for (const Comp &c : comps) {
         hipLaunchKernelGGL(k_cm_root, dim3(1), dim3(64), 0, s, order.p, pos.p, vertex_at.p, c.start[0]);
+        static const bool narrow_on = [] { const char *e = getenv("DPCG_RCM_NARROW"); return !(e && e[0] == '0'); }();
         for (int l = 1; l < c.nl; ++l) {
+            if (narrow_on && c.count[(size_t)l] <= 1024 && c.count[(size_t)l - 1] <= 1024) {     // a run of narrow levels: one launch
+                int e = l + 1;
+                while (e < c.nl && c.count[(size_t)e] <= 1024) ++e;
+                hipLaunchKernelGGL(k_cm_narrow, dim3(1), dim3(1024), 0, s, A.rowptr, A.col, level.p, order.p, deg.p, start.p, count.p, pos.p,
+                                   vertex_at.p, c.L0 + l, c.L0 + e - 1, err.p);
+                l = e - 1;
+                continue;
+            }
             const int L = c.L0 + l, s1 = c.start[(size_t)l], c1 = c.count[(size_t)l];
             const int s0 = c.start[(size_t)l - 1], c0 = c.count[(size_t)l - 1];
             const int g = rows_grid(c1, 1024);
