@@ -501,7 +501,8 @@ extern "C" int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]) {
     out[6] = small_eligible(h, 0, nullptr) ? (small_variant((int)h->A.n, h->planA.max_row_len, h->precond) % 16 != 0 ? 768 : 1024) : 0;
     out[7] = team_eligible(h, 0, nullptr) ? 1 : 0;
     // who sums <r,z> in a multi-launch update (cg.py:82): 0 k_update_r (M = I, Jacobi), 1 k_dot_partials, 2 k_lm_finish (way out of a
-    // level-major solve), 3 the SpMV that applied M (its plan in out[9..11]), 9 a tree the checker does not restate
+    // level-major solve), 3 the SpMV that applied M (its plan in out[9..11]), 4 the colour sweeps (out[12..15]), 9 a tree the checker
+    // does not restate
     int rzk = 0;
     const SpmvPlan *pm = nullptr;
     switch (h->precond) {
@@ -520,8 +521,27 @@ extern "C" int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]) {
         out[10] = pm->nrb;
         out[11] = pm->kernel == SPMV_TILE ? pm->cyclic : 0;
     }
-    out[8] = rzk;
     out[12] = out[13] = out[14] = out[15] = 0;
+    if (rzk == 9 && h->precond == DPCG_PRECOND_LLT_SOLVE && h->lvlU.sweep && h->lvlU.n_levels <= 16) {
+        // colour sweeps: <r,z> is summed launch by launch over the levels of the upper solve -- the first of them by the lower solve's
+        // last launch when that one opens the upper solve (apply_precond) -- every workgroup adding its share to its slot.
+        // [12] launches, [13] workgroups, [14] two bits per launch, first launch lowest: how its workgroups walk the level's row blocks
+        // (0 slabs by virtual block, 1 blocks b, b + G, ..., 2 the same by virtual block), [15] 1 = the first launch is the lower solve's
+        const Levels &lo = h->lvlL, &up = h->lvlU;
+        const bool paired = lo.level_major && up.level_major && up.lm_from_lower && lo.sweep && lo.lm_to_upper;
+        auto mode = [](const Levels &lv, int l) {
+            const bool tiled = l < (int)lv.sw_max_chunks.size() && lv.sw_max_chunks[(size_t)l] > 0;
+            return tiled ? (lv.sweep_cyclic ? 2 : 0) : 1;
+        };
+        int packed = 0;
+        for (int l = 0; l < up.n_levels; ++l) packed |= ((l == 0 && paired) ? mode(lo, lo.n_levels - 1) : mode(up, l)) << (2 * l);
+        rzk = 4;
+        out[12] = up.n_levels;
+        out[13] = up.sweep_grid;
+        out[14] = packed;
+        out[15] = paired ? 1 : 0;
+    }
+    out[8] = rzk;
     return DPCG_OK;
 }
 

@@ -190,7 +190,10 @@ int dpcg_set_precond_callback(dpcg_handle_t h, dpcg_precond_fn fn, void *user);
  * solve when a default call takes that form (0 otherwise), out[7] = 1 when the system is eligible for the team solve,
  * out[8] = who sums <r,z> behind the CURRENT preconditioner in a multi-launch update (0 the r-update kernel, 1 a separate dot
  * launch, 2 the way-out pass of a level-major triangular solve, 3 the SpMV that applied M -- its grid / row blocks / walk in
- * out[9..11] --, 9 a tree the checker does not restate: colour sweeps, the CSR-vector kernel), out[12..15] = 0. */
+ * out[9..11] --, 4 the colour sweeps of a triangular solve: out[12] launches that add to <r,z> (the levels of the upper solve, first
+ * to last), out[13] workgroups of each, out[14] two bits per launch, first launch lowest (how a workgroup walks the level's 256-row
+ * blocks: 0 its slab by virtual block, 1 blocks b, b + G, ..., 2 the same by virtual block), out[15] = 1 when the first of them is the
+ * lower solve's last launch --, 9 a tree the checker does not restate: the CSR-vector kernel, more than 16 sweeps). */
 int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]);
 /* Copy the current factor L out (host arrays sized from dpcg_get_info's precond_nnz). */
 int dpcg_get_factor(dpcg_handle_t h, int32_t *rowptr, int32_t *col, double *val);

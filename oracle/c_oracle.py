@@ -127,6 +127,37 @@ def sptrsv_upper(U: sp.csr_matrix, y: np.ndarray) -> np.ndarray:
     return z
 
 
+def factor_levels(L: sp.csr_matrix) -> np.ndarray:
+    """Level of every row of a lower-triangular factor (diagonal last in a row): 0 without off-diagonal entries, else 1 + the highest
+    level among the rows it depends on -- the level sets the device schedules its triangular solves by."""
+    n = L.shape[0]
+    rp, ci = L.indptr.astype(np.int64), L.indices
+    offd = np.ones(L.nnz, dtype=bool)
+    offd[rp[1:] - 1] = False
+    col = ci[offd]
+    per_row = np.diff(rp) - 1
+    has = per_row > 0
+    starts = np.concatenate(([0], np.cumsum(per_row)))[:-1][has]
+    level = np.zeros(n, dtype=np.int32)
+    while True:
+        new = np.zeros(n, dtype=np.int32)
+        if col.size:
+            new[has] = np.maximum.reduceat(level[col] + 1, starts)
+        if np.array_equal(new, level):
+            return level
+        level = new
+
+
+def sweep_rows(L: sp.csr_matrix, handle_index: np.ndarray) -> list:
+    """The rows (as handle indices) every colour-sweep launch that adds to <r,z> walks, in its order: the levels of the UPPER solve are
+    those of the lower one read backwards, a level's rows in ascending handle index (dpcg_precond.hip: compute_levels(order_by),
+    reversed_levels).  handle_index[i]: the handle's index of factor row i.  For `device_tree["sweep_rows"]`."""
+    level = factor_levels(L)
+    nl = int(level.max()) + 1 if level.size else 0
+    hi = np.asarray(handle_index)
+    return [np.sort(hi[level == nl - 1 - k]).astype(np.int32) for k in range(nl)]
+
+
 def pcg(A: sp.csr_matrix, b: np.ndarray, kind: str = "none", *, dinv=None, M=None, L=None, x0=None, rtol=1e-8,
         max_iter=1024, init_check="z", mixed=False, precond_perm=None, device_tree=None):
     """Returns (seconds, iterations, residual_history, x) -- same tuple as oracle.oracle's PCG.
@@ -139,15 +170,25 @@ def pcg(A: sp.csr_matrix, b: np.ndarray, kind: str = "none", *, dinv=None, M=Non
     one-workgroup solve of systems up to 6144 rows -- every preconditioner kind it serves: none / jacobi / csr / llt_multiply --,
     "form": "team" the 32-workgroup team solve.  "rz_kind" (+ "m_grid", "m_nrb", "m_cyclic"): who sums <r,z> behind an APPLIED
     preconditioner in the multi-launch form (orc_set_rz_tree) -- with it "csr", "llt_multiply" and "llt_solve" match bit for bit too,
-    as long as the handle's answer is 0..3."""
+    as long as the handle's answer is 0..4 (4: colour sweeps; then also "sweep_grid", "sweep_modes", "sweep_rows")."""
     if device_tree is not None:
         form = {"multi": 0, "small": 1, "team": 2}[device_tree.get("form", "multi")]
         lib().orc_set_dot_tree(1, int(device_tree["spmv_grid"]), int(device_tree["nrb"]), int(device_tree["cyclic"]),
                                int(device_tree["vec_grid"]), form, int(device_tree.get("small_threads", 0)))
         rzk = int(device_tree.get("rz_kind", 0))
-        if form == 0 and rzk not in (0, 1, 2, 3):
-            raise ValueError("device_tree: the handle sums <r,z> in a tree this oracle does not restate (colour sweeps / CSR-vector kernel)")
+        if form == 0 and rzk not in (0, 1, 2, 3, 4):
+            raise ValueError("device_tree: the handle sums <r,z> in a tree this oracle does not restate (CSR-vector kernel, more than 16 sweeps)")
         lib().orc_set_rz_tree(rzk, int(device_tree.get("m_grid", 0)), int(device_tree.get("m_nrb", 0)), int(device_tree.get("m_cyclic", 0)))
+        if form == 0 and rzk == 4:
+            # colour sweeps: "sweep_grid", "sweep_modes" (one per launch) from reduction_geometry(), "sweep_rows": per launch the handle's
+            # indices of the level's rows in level-major order (the caller derives them from the factor: tests/test_meshes.py::sweep_rows)
+            rows = [np.ascontiguousarray(r, dtype=np.int32) for r in device_tree["sweep_rows"]]
+            modes = np.ascontiguousarray(device_tree["sweep_modes"], dtype=np.int32)
+            if len(rows) != len(modes):
+                raise ValueError("device_tree: one row list per sweep launch")
+            cnt = np.array([r.size for r in rows], dtype=np.int32)
+            cat = np.ascontiguousarray(np.concatenate(rows) if rows else np.zeros(0, np.int32), dtype=np.int32)
+            lib().orc_set_sweep_tree(C.c_int(len(rows)), C.c_int(int(device_tree["sweep_grid"])), _p(cnt), _p(modes), _p(cat))
         try:
             return pcg(A, b, kind, dinv=dinv, M=M, L=L, x0=x0, rtol=rtol, max_iter=max_iter, init_check=init_check, mixed=mixed,
                        precond_perm=precond_perm)

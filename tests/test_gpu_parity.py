@@ -2424,6 +2424,20 @@ def test_ic0_in_multicolour_order(D, name, make, reorder, colors):
         np.testing.assert_allclose(res.res_history, hist, rtol=HIST_RTOL)
     r_true = b - A @ res.x.cpu().numpy()
     assert np.dot(r_true, r_true) / np.dot(b, b) < 1.01e-8
+    # (round 4) with the oracle's dot products in the device's trees -- <r,z> as the colour sweeps sum it, launch by launch over the
+    # levels (orc_set_sweep_tree), or as the way-out pass / a dot launch does -- the history is the device's BIT FOR BIT
+    geo = S.reduction_geometry()
+    if geo["rz_kind"] in (1, 2, 4) and geo["spmv_kernel"] != "vector":      # (the CSR-vector kernel's row sums are not restated)
+        if geo["rz_kind"] == 4:
+            hidx = q
+            if S.reordered:
+                iph = np.empty(n, dtype=np.int64)
+                iph[S.permutation()] = np.arange(n)
+                hidx = iph[q]
+            geo["sweep_rows"] = CO.sweep_rows(Lref, hidx)
+            assert len(geo["sweep_rows"]) == len(geo["sweep_modes"]) == info["levels_upper"]
+        _, it_t, hist_t, _ = CO.pcg(B, bb, "llt_solve", L=Lref, precond_perm=pperm, device_tree=geo)
+        assert res.iterations == it_t and np.array_equal(res.res_history, hist_t), (name, geo["rz_kind"], geo.get("sweep_modes"))
     # against IC(0) in the caller's order: far fewer levels, a bounded loss of iterations, still ahead of Jacobi
     S.set_preconditioner(D.IC0("solve"))
     assert S.precond_ordering()[0] == 0 and np.array_equal(S.precond_ordering()[1], np.arange(n))

@@ -170,13 +170,19 @@ def _mesh_parity(D, A, expect, max_iter):
     qinv[q] = np.arange(n, dtype=np.int32)
     res = S.solve(_dev(b), max_iter=max_iter, flags=NO_SMALL)
     geo = S.reduction_geometry()
-    if geo["rz_kind"] in (1, 2):
+    if geo["rz_kind"] == 4:      # colour sweeps: <r,z> summed launch by launch over the levels -- restated too (orc_set_sweep_tree)
+        iperm = np.empty(n, dtype=np.int64)
+        iperm[perm] = np.arange(n)
+        geo["sweep_rows"] = CO.sweep_rows(Lq, iperm[q])
+        assert len(geo["sweep_rows"]) == len(geo["sweep_modes"]) == S.info()["levels_upper"]
+    if geo["rz_kind"] in (1, 2, 4):
         _, it, hist, _ = CO.pcg(B, b[perm], "llt_solve", L=Lq, precond_perm=qinv[perm], max_iter=max_iter, device_tree=geo)
         assert res.iterations == it and np.array_equal(res.res_history, hist)
-    else:        # colour sweeps sum <r,z> on the way in a tree of their own: 1e-10 while the recurrence is stable (see _check_history)
+    else:        # a tree the checker does not restate: 1e-10 while the recurrence is stable (see _check_history)
         it, hist, _, dc, drift = _oracle_pair(B, b[perm], "llt_solve", L=Lq, precond_perm=qinv[perm], max_iter=max_iter)
         _check_history(res, it, hist, dc, drift, "ic0 multicolour")
     out["ic0_multicolor"] = (it, nc)
+    out["ic0_multicolor_rz_kind"] = geo["rz_kind"]
     S.close()
     return out
 
@@ -202,6 +208,7 @@ def test_config3_unstructured_meshes_million_dof(D, name, make, expect):
     """BASELINE config 3 ("OpenFOAM interFoam pressure-correction matrix, ~1M DoF, unstructured CSR") on matrices with irregular
     degree, triangles and no grid structure: the plain call (the library reorders a scattered numbering by itself and plans the
     x-tile SpMV on the result), 60 updates each of Jacobi, IC(0) in the caller's order (level-scheduled L / L^T solves) and IC(0)
-    in multicolour order against the C oracle on the system the handle iterates on -- counts equal, histories within 1e-10 (`_check_history`: where a one-ulp
-    perturbation of b moves the oracle itself, 100 x that drift)."""
-    _mesh_parity(D, make(), expect, 60)
+    in multicolour order against the C oracle on the system the handle iterates on, the oracle's dot products in the device's
+    reduction trees -- the colour sweeps' launch-by-launch <r,z> included: counts and histories EQUAL."""
+    out = _mesh_parity(D, make(), expect, 60)
+    assert out["ic0_multicolor_rz_kind"] == 4          # 4-5 wide levels: colour sweeps, restated (never the tolerance branch)
