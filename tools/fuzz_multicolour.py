@@ -43,6 +43,7 @@ def grid_matrix(shape, drop, diagonal=False):
 
 
 bad = 0
+bitwise = 0
 for case in range(cases):
     dim = int(rng.choice([2, 3, 3]))
     target = int(rng.choice([60000, 270000, 300000, 420000, 600000, 1000000]))
@@ -122,6 +123,20 @@ for case in range(cases):
         m = min(len(hist), len(res.res_history))
         ok = res.iterations == it and np.allclose(res.res_history[:m], hist[:m], rtol=1e-10, atol=0)
         what = f"solve (iterations {res.iterations} vs {it})"
+        # ... and with the oracle's dot products in the device's reduction trees (the colour sweeps' <r,z> included): bit for bit
+        geo = S.reduction_geometry()
+        if ok and geo["rz_kind"] in (1, 2, 4) and geo["spmv_kernel"] != "vector" and (n > 6144 or (flags & D._lib.NO_SMALL)):
+            if geo["rz_kind"] == 4:
+                hidx = q
+                if S.reordered:
+                    iph = np.empty(n, dtype=np.int64)
+                    iph[S.permutation()] = np.arange(n)
+                    hidx = iph[q]
+                geo["sweep_rows"] = CO.sweep_rows(Lref, hidx)
+            _, it_t, hist_t, _ = CO.pcg(B, bb, "llt_solve", L=Lref, precond_perm=pperm, max_iter=60, device_tree=geo)
+            ok = res.iterations == it_t and np.array_equal(res.res_history, hist_t)
+            what = f"solve against the device-tree oracle (rz_kind {geo['rz_kind']}, iterations {res.iterations} vs {it_t})"
+            bitwise += 1
         # the apply after a solve (the loop's hand-over of the first level must not leave anything behind)
         ok = ok and np.array_equal(S.precond_apply(bd).cpu().numpy(), zref)
     info = S.info()
@@ -131,5 +146,5 @@ for case in range(cases):
     elif len(sys.argv) > 3:
         print("ok", tag, "colours", nc, "levels", info["levels_lower"], info["levels_upper"], flush=True)
     S.close()
-print(f"fuzz_multicolour: {cases} cases, {bad} mismatches")
+print(f"fuzz_multicolour: {cases} cases ({bitwise} of them also bit for bit against the device-tree oracle), {bad} mismatches")
 sys.exit(1 if bad else 0)
