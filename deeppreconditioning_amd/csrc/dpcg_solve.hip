@@ -496,7 +496,7 @@ extern "C" int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]) {
     out[2] = h->planA.kernel == SPMV_TILE ? h->planA.cyclic : 0;       // 0 slabs, 1 cyclic, 2 cyclic with XCD runs inside a pass
     out[3] = h->vec_grid;
     out[4] = fuse_eligible(h, 0, nullptr) ? 1 : 0;
-    out[5] = h->planA.kernel;
+    out[5] = h->planA.kernel | (h->planA.kernel == SPMV_VECTOR ? h->planA.tpr << 8 : 0);      // (+ lanes per row of the CSR-vector kernel)
     // threads of the one-workgroup solve a default call takes (0: not that form)
     out[6] = small_eligible(h, 0, nullptr) ? (small_variant((int)h->A.n, h->planA.max_row_len, h->precond) % 16 != 0 ? 768 : 1024) : 0;
     out[7] = team_eligible(h, 0, nullptr) ? 1 : 0;
@@ -516,10 +516,13 @@ extern "C" int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]) {
     }
     out[9] = out[10] = out[11] = 0;
     if (pm) {
-        rzk = pm->kernel == SPMV_VECTOR ? 9 : 3;
+        rzk = 3;
         out[9] = pm->grid;
         out[10] = pm->nrb;
         out[11] = pm->kernel == SPMV_TILE ? pm->cyclic : 0;
+        // lanes per row where a CSR-vector kernel applies M (bits 8-15: M or L; 16-23: L^T of an L L^T product)
+        if (pm->kernel == SPMV_VECTOR) out[11] |= pm->tpr << 8;
+        if (h->precond == DPCG_PRECOND_LLT_MULTIPLY && h->planLt.kernel == SPMV_VECTOR) out[11] |= h->planLt.tpr << 16;
     }
     out[12] = out[13] = out[14] = out[15] = 0;
     if (rzk == 9 && h->precond == DPCG_PRECOND_LLT_SOLVE && h->lvlU.sweep && h->lvlU.n_levels <= 16) {

@@ -186,14 +186,16 @@ int dpcg_set_precond_callback(dpcg_handle_t h, dpcg_precond_fn fn, void *user);
  * orc_set_dot_tree: with it the CPU restatement reproduces the multi-launch solve's residual history BIT FOR BIT for M = I /
  * Jacobi): out[0] = workgroups of the SpMV kernel of the PCG loop, out[1] = its 256-row blocks, out[2] = 1 when the blocks are
  * dealt out cyclically, 2 when cyclically with an XCD's blocks of a pass contiguous (0: contiguous slabs), out[3] = workgroups of the vector kernels, out[4] = 1 when a solve with default
- * flags runs two-kernel updates, out[5] = the SpMV kernel (0 gather, 1 vector, 2 x-tile), out[6] = threads of the one-workgroup
+ * flags runs two-kernel updates, out[5] = the SpMV kernel in bits 0-7 (0 gather, 1 vector, 2 x-tile) and, for the vector kernel, its
+ * lanes per row in bits 8-15, out[6] = threads of the one-workgroup
  * solve when a default call takes that form (0 otherwise), out[7] = 1 when the system is eligible for the team solve,
  * out[8] = who sums <r,z> behind the CURRENT preconditioner in a multi-launch update (0 the r-update kernel, 1 a separate dot
  * launch, 2 the way-out pass of a level-major triangular solve, 3 the SpMV that applied M -- its grid / row blocks / walk in
- * out[9..11] --, 4 the colour sweeps of a triangular solve: out[12] launches that add to <r,z> (the levels of the upper solve, first
+ * out[9..11]; out[11] bits 8-15: lanes per row when that SpMV is the vector kernel, bits 16-23: the same for the L^T product of
+ * M = L L^T --, 4 the colour sweeps of a triangular solve: out[12] launches that add to <r,z> (the levels of the upper solve, first
  * to last), out[13] workgroups of each, out[14] two bits per launch, first launch lowest (how a workgroup walks the level's 256-row
  * blocks: 0 its slab by virtual block, 1 blocks b, b + G, ..., 2 the same by virtual block), out[15] = 1 when the first of them is the
- * lower solve's last launch --, 9 a tree the checker does not restate: the CSR-vector kernel, more than 16 sweeps). */
+ * lower solve's last launch --, 9 a tree the checker does not restate: more than 16 sweeps). */
 int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]);
 /* Copy the current factor L out (host arrays sized from dpcg_get_info's precond_nnz). */
 int dpcg_get_factor(dpcg_handle_t h, int32_t *rowptr, int32_t *col, double *val);

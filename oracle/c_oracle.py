@@ -127,6 +127,16 @@ def sptrsv_upper(U: sp.csr_matrix, y: np.ndarray) -> np.ndarray:
     return z
 
 
+def spmv_vector(A: sp.csr_matrix, x: np.ndarray, tpr: int) -> np.ndarray:
+    """y = A x with every row summed as the CSR-vector kernel sums it (`tpr` lanes per row, aligned pairs, shuffle tree:
+    orc_spmv_vector) -- the bits of `S @ x` when reduction_geometry() says spmv_kernel "vector", spmv_tpr `tpr`."""
+    rp, ci, v = _csr_parts(A)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty(A.shape[0], dtype=np.float64)
+    lib().orc_spmv_vector(C.c_int64(A.shape[0]), _p(rp), _p(ci), _p(v), _p(x), _p(y), C.c_int(int(tpr)))
+    return y
+
+
 def factor_levels(L: sp.csr_matrix) -> np.ndarray:
     """Level of every row of a lower-triangular factor (diagonal last in a row): 0 without off-diagonal entries, else 1 + the highest
     level among the rows it depends on -- the level sets the device schedules its triangular solves by."""
@@ -179,6 +189,11 @@ def pcg(A: sp.csr_matrix, b: np.ndarray, kind: str = "none", *, dinv=None, M=Non
         if form == 0 and rzk not in (0, 1, 2, 3, 4):
             raise ValueError("device_tree: the handle sums <r,z> in a tree this oracle does not restate (CSR-vector kernel, more than 16 sweeps)")
         lib().orc_set_rz_tree(rzk, int(device_tree.get("m_grid", 0)), int(device_tree.get("m_nrb", 0)), int(device_tree.get("m_cyclic", 0)))
+        # CSR-vector kernels (rows of many entries): lanes per row for the system's matrix, for M (or L) and for L^T
+        vec = (int(device_tree.get("spmv_tpr", 0)), int(device_tree.get("m_tpr", 0)), int(device_tree.get("mt_tpr", 0))) if form == 0 else (0, 0, 0)
+        if mixed and any(vec):
+            raise ValueError("device_tree: the mixed-precision CSR-vector kernel is not restated")
+        lib().orc_set_vector_tree(*[C.c_int(t) for t in vec])
         if form == 0 and rzk == 4:
             # colour sweeps: "sweep_grid", "sweep_modes" (one per launch) from reduction_geometry(), "sweep_rows": per launch the handle's
             # indices of the level's rows in level-major order (the caller derives them from the factor: tests/test_meshes.py::sweep_rows)
@@ -194,6 +209,7 @@ def pcg(A: sp.csr_matrix, b: np.ndarray, kind: str = "none", *, dinv=None, M=Non
                        precond_perm=precond_perm)
         finally:
             lib().orc_set_dot_tree(0, 0, 0, 0, 0, 0, 0)
+            lib().orc_set_vector_tree(0, 0, 0)
     n = A.shape[0]
     rp, ci, v = _csr_parts(A)
     b = np.ascontiguousarray(b, dtype=np.float64)

@@ -119,6 +119,57 @@ def test_spmv_vector_kernel(D):
     np.testing.assert_allclose(y, ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
 
 
+def test_csr_vector_kernel_equals_its_restatement_bit_for_bit(D):
+    """(round 4) The CSR-vector kernel -- rows of many entries: several lanes share a row, each adds aligned pairs of its entries,
+    a shuffle tree folds them -- restated in the oracle (orc_spmv_vector; lanes per row from reduction_geometry()): `S @ x` bit for
+    bit, and with it whole solves: a long-row system with M = I / Jacobi, and M = L L^T MULTIPLIED with a learned-like factor of ~15
+    entries a row (the reference's technique, test.py:91-105, on config 2's kind of factor) -- histories, counts and x EQUAL."""
+    A = O.poisson2d(48)
+    L_ = O.learned_like_factor(A, seed=2)
+    M = (L_ @ L_.T).tocsr()                                  # ~60 non-zeros per row
+    M.sort_indices()
+    S = D.CsrSystem.from_any(M)
+    geo = S.reduction_geometry()
+    assert geo["spmv_kernel"] == "vector" and geo["spmv_tpr"] in (2, 4, 8, 16, 32, 64)
+    x = O.rhs(M.shape[0], 1)
+    assert np.array_equal((S @ _dev(x)).cpu().numpy(), CO.spmv_vector(M, x, geo["spmv_tpr"]))
+    S.close()
+    # a long-row SPD system: rows of 20-30 entries inside a band, 20 000 rows (multi-launch path)
+    rng = np.random.default_rng(5)
+    n = 20000
+    r_ = np.repeat(np.arange(n), 12)
+    c_ = r_ - rng.integers(1, 400, r_.size)
+    r_, c_ = r_[c_ >= 0], c_[c_ >= 0]
+    E = sp.coo_matrix((rng.uniform(-1, 1, r_.size), (r_, c_)), shape=(n, n)).tocsr()
+    E.sum_duplicates()
+    E = E + E.T
+    A = (E + sp.diags(np.asarray(abs(E).sum(axis=1)).ravel() + 0.05)).tocsr()
+    A.sort_indices()
+    S = D.CsrSystem.from_any(A, reorder=None)
+    geo = S.reduction_geometry()
+    assert geo["spmv_kernel"] == "vector"
+    b = O.rhs(n, 3)
+    assert np.array_equal((S @ _dev(b)).cpu().numpy(), CO.spmv_vector(A, b, geo["spmv_tpr"]))
+    for kind, pc, kw in (("none", None, {}), ("jacobi", D.Jacobi(), {"dinv": O.jacobi_dinv(A)})):
+        S.set_preconditioner(pc)
+        res = S.solve(_dev(b))
+        _, it, hist, xs = CO.pcg(A, b, kind, device_tree=S.reduction_geometry(), **kw)
+        assert res.iterations == it and it > 5 and np.array_equal(res.res_history, hist) and np.array_equal(res.x.cpu().numpy(), xs), kind
+    S.close()
+    # M = L L^T multiplied, L with ~15 entries a row: both products of the apply on the vector kernel, <r,z> summed by the second
+    A = O.poisson2d(128)
+    L_ = O.learned_like_factor(A, seed=4)
+    S = D.CsrSystem.from_any(A)
+    S.set_preconditioner(D.LLtMultiply(L_))
+    geo = S.reduction_geometry()
+    assert geo["rz_kind"] == 3 and geo["m_tpr"] > 0 and geo["mt_tpr"] > 0, geo
+    b = O.rhs(A.shape[0], 1)
+    res = S.solve(_dev(b), flags=D._lib.NO_SMALL)
+    _, it, hist, xs = CO.pcg(A, b, "llt_multiply", L=L_, device_tree=geo)
+    assert res.iterations == it and np.array_equal(res.res_history, hist) and np.array_equal(res.x.cpu().numpy(), xs)
+    S.close()
+
+
 def test_spmv_ragged_rows_and_empty_rows(D):
     rng = np.random.default_rng(0)
     n = 1000
