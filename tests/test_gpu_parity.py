@@ -2051,6 +2051,13 @@ def test_config2_cnn_emitted_factor_at_full_size(D):
     np.testing.assert_allclose(res.res_history[:m], hist[:m], rtol=1e-9)
     r_true = bh - A @ res.x.cpu().numpy()
     assert np.dot(r_true, r_true) / np.dot(bh, bh) < 1.5e-8
+    # (round 4) chaotic or not: with the oracle's sums in the device's order -- both products of the apply on the CSR-vector kernel
+    # (15 entries a row), <r,z> out of the second, the x-tile SpMV's <p,Ap> -- the whole history, the count and x are the device's
+    geo = S.reduction_geometry()
+    assert geo["rz_kind"] == 3 and geo["m_tpr"] > 0 and geo["mt_tpr"] > 0
+    res = S.solve(_dev(bh), flags=D._lib.NO_SMALL)
+    _, it_t, hist_t, xs = CO.pcg(A, bh, "llt_multiply", L=Lsp, device_tree=geo)
+    assert res.iterations == it_t and np.array_equal(res.res_history, hist_t) and np.array_equal(res.x.cpu().numpy(), xs)
     S.close()
 
 

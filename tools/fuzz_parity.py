@@ -188,7 +188,7 @@ for case in range(cases):
                     print(kind, "mixed numpy oracle / C mixed oracle - 1:", hn[:mm] / hm[:mm] - 1)
                     print(kind, "C mixed history:", hm[:mm])
             tree_hist = None
-            if kind in ("none", "jacobi") and S.reduction_geometry()["spmv_kernel"] != "vector":     # round 4: the multi-launch forms against the device-tree oracle, bit for bit
+            if kind in ("none", "jacobi"):     # round 4: the multi-launch forms against the device-tree oracle (CSR-vector kernel included), bit for bit
                 tree_hist = CO.pcg(B, bo, kind, x0=x0o, device_tree=S.reduction_geometry(),
                                    **(dict(dinv=O.jacobi_dinv(B)) if kind == "jacobi" else {}))[1:3]
             for flags in (0, D._lib.NO_SMALL, D._lib.NO_SMALL | D._lib.NO_FUSE):
