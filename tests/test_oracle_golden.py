@@ -291,3 +291,52 @@ def test_icholt_restates_the_dual_threshold_rule():
     assert L1.nnz < O.icholt(A, 1, 0.0).nnz                          # the threshold does drop entries here
     with pytest.raises(ValueError):
         O.icholt(sp.csr_matrix(np.array([[1.0, 2.0], [2.0, 1.0]])), 0, 0.0)        # indefinite: breakdown
+
+
+def test_device_tree_restatements_sum_every_term_once():
+    """The checker's restatements of the device's summation orders (round 4: the CSR-vector kernel's row sums, the colour sweeps'
+    launch-by-launch <r,z>) are the SAME sums in another order: against the oracle's own order they agree to rounding, whatever
+    the geometry -- a term dropped or taken twice would show at once.  (That they are the DEVICE's order is what the -m gpu
+    tests establish, bit for bit.)"""
+    A = O.poisson2d(40)
+    L_ = O.learned_like_factor(A, seed=3)
+    M = (L_ @ L_.T).tocsr()
+    M.sort_indices()
+    x = O.rhs(M.shape[0], 1)
+    ref = CO.spmv(M, x)
+    for tpr in (2, 4, 16, 64):
+        y = CO.spmv_vector(M, x, tpr)
+        np.testing.assert_allclose(y, ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+        assert np.array_equal(y, CO.spmv_vector(M, x, tpr))
+    # level sets of a factor: the anti-diagonals of a naturally ordered grid
+    Lg = CO.ic0(O.poisson2d(6))
+    assert np.array_equal(CO.factor_levels(Lg).reshape(6, 6), np.add.outer(np.arange(6), np.arange(6)))
+    rows = CO.sweep_rows(Lg, np.arange(36))
+    assert len(rows) == 11 and rows[0].tolist() == [35] and rows[-1].tolist() == [0] and sum(r.size for r in rows) == 36
+    # PCG with IC(0) in red-black order, <r,z> summed as three sweeps in each of the three walks would: the history of the plain oracle
+    n = A.shape[0]
+    idx = np.arange(n).reshape(40, 40)
+    q = np.concatenate([idx[(np.add.outer(np.arange(40), np.arange(40)) % 2) == c].ravel() for c in (0, 1)]).astype(np.int32)
+    Bq = A[q][:, q].tocsr()
+    Bq.sort_indices()
+    Lq = CO.ic0(Bq)
+    qinv = np.empty(n, dtype=np.int32)
+    qinv[q] = np.arange(n, dtype=np.int32)
+    b = O.rhs(n, 0)
+    _, it, hist, xs = CO.pcg(A, b, "llt_solve", L=Lq, precond_perm=qinv)
+    rows = CO.sweep_rows(Lq, q)
+    assert len(rows) == 2
+    for modes, grid in (([0, 0], 8), ([2, 1], 16), ([1, 2], 3)):
+        geo = {"spmv_grid": 7, "nrb": 7, "cyclic": 0, "vec_grid": 7, "rz_kind": 4, "sweep_grid": grid, "sweep_modes": modes, "sweep_rows": rows}
+        _, it_t, hist_t, xs_t = CO.pcg(A, b, "llt_solve", L=Lq, precond_perm=qinv, device_tree=geo)
+        assert it_t == it
+        np.testing.assert_allclose(hist_t, hist, rtol=1e-9)
+    # ... and M = L L^T multiplied on the vector kernel's row sums
+    geo = {"spmv_grid": 7, "nrb": 7, "cyclic": 0, "vec_grid": 7, "rz_kind": 3, "m_grid": 8, "m_nrb": 7, "m_cyclic": 0, "m_tpr": 8, "mt_tpr": 4}
+    Lp = O.learned_like_factor_preconditioning(A)
+    _, it, hist, _ = CO.pcg(A, b, "llt_multiply", L=Lp)
+    _, it_t, hist_t, _ = CO.pcg(A, b, "llt_multiply", L=Lp, device_tree=geo)
+    assert it_t == it
+    np.testing.assert_allclose(hist_t, hist, rtol=1e-9)
+    with pytest.raises(ValueError):
+        CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A), mixed=True, device_tree={"spmv_grid": 7, "nrb": 7, "cyclic": 0, "vec_grid": 7, "spmv_tpr": 4})
