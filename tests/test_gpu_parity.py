@@ -2485,7 +2485,7 @@ def test_ic0_in_multicolour_order(D, name, make, reorder, colors):
     # (round 4) with the oracle's dot products in the device's trees -- <r,z> as the colour sweeps sum it, launch by launch over the
     # levels (orc_set_sweep_tree), or as the way-out pass / a dot launch does -- the history is the device's BIT FOR BIT
     geo = S.reduction_geometry()
-    if geo["rz_kind"] in (1, 2, 4) and geo["spmv_kernel"] != "vector":      # (the CSR-vector kernel's row sums are not restated)
+    if geo["rz_kind"] in (1, 2, 4) and n < 800000:      # (the 1M-row case: tests/test_meshes.py holds that size to the bits, 60 updates)
         if geo["rz_kind"] == 4:
             hidx = q
             if S.reordered:
