@@ -191,8 +191,6 @@ def pcg(A: sp.csr_matrix, b: np.ndarray, kind: str = "none", *, dinv=None, M=Non
         lib().orc_set_rz_tree(rzk, int(device_tree.get("m_grid", 0)), int(device_tree.get("m_nrb", 0)), int(device_tree.get("m_cyclic", 0)))
         # CSR-vector kernels (rows of many entries): lanes per row for the system's matrix, for M (or L) and for L^T
         vec = (int(device_tree.get("spmv_tpr", 0)), int(device_tree.get("m_tpr", 0)), int(device_tree.get("mt_tpr", 0))) if form == 0 else (0, 0, 0)
-        if mixed and any(vec):
-            raise ValueError("device_tree: the mixed-precision CSR-vector kernel is not restated")
         lib().orc_set_vector_tree(*[C.c_int(t) for t in vec])
         if form == 0 and rzk == 4:
             # colour sweeps: "sweep_grid", "sweep_modes" (one per launch) from reduction_geometry(), "sweep_rows": per launch the handle's

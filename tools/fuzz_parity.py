@@ -153,9 +153,9 @@ for case in range(cases):
                 itm, hm = CO.pcg(Bm, bm, okind, x0=x0m, mixed=True, **kwm)[1:3]
                 hn = np.array(O.preconditioned_conjugate_gradient(O.MixedOperatorX0(Bm), bm, O.Precond(okind, **kwm), x0=x0m)[2])
                 rm = S.solve(torch.from_numpy(b).cuda(), x0_dev, flags=D._lib.SPMV_F32)
-                if kind in ("none", "jacobi") and S.reduction_geometry()["spmv_kernel"] != "vector":
+                if kind in ("none", "jacobi"):
                     # round 4: the oracle sums in the DEVICE's reduction tree, so there is no drift to bound -- bit for bit
-                    # (rows too long for the in-order kernels take the CSR-vector SpMV, whose row sums are shuffle trees)
+                    # (rows too long for the in-order kernels take the CSR-vector SpMV, whose shuffle-tree row sums are restated too)
                     itd, hd = CO.pcg(Bm, bm, okind, x0=x0m, mixed=True, device_tree=S.reduction_geometry(), **kwm)[1:3]
                     if not (rm.iterations == itd and np.array_equal(rm.res_history, hd)):
                         bad += 1
