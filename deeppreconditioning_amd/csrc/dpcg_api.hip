@@ -106,6 +106,8 @@ void free_levels(Levels &l) {
 
 int grid_for(int64_t n) {
     int64_t g = (n + kBlock - 1) / kBlock;
+    static const int64_t cap = [] { const char *e = getenv("DPCG_VEC_GRID"); return e ? (int64_t)atoll(e) : (int64_t)kMaxGrid; }();   // development knob
+    if (g > cap) g = cap;
     if (g > kMaxGrid) g = kMaxGrid;
     if (g < 1) g = 1;
     return (int)g;
