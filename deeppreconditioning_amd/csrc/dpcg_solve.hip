@@ -489,6 +489,13 @@ static bool team_eligible(const dpcg_system *h, int flags, const double *x_true)
     return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI;
 }
 
+// One mid-size system, default flags: the team kernel while a workgroup holds ONE slab of it.  DPCG_NO_SMALL ("no whole-solve
+// kernel") keeps it on the launches, as it does for the one-workgroup kernel; DPCG_TEAM_SINGLE=0: development knob.
+static bool single_team_default(const dpcg_system *h, int flags) {
+    static const bool on = [] { const char *e = getenv("DPCG_TEAM_SINGLE"); return !(e && e[0] == '0'); }();
+    return on && !(flags & (DPCG_NO_SMALL | DPCG_NO_GRAPH)) && h->A.n <= 32 * 1024;
+}
+
 extern "C" int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]) {
     if (!h || !out) return invalid("dpcg_get_reduction_geometry: NULL argument");
     out[0] = h->planA.grid;
@@ -499,7 +506,7 @@ extern "C" int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]) {
     out[5] = h->planA.kernel | (h->planA.kernel == SPMV_VECTOR ? h->planA.tpr << 8 : 0);      // (+ lanes per row of the CSR-vector kernel)
     // threads of the one-workgroup solve a default call takes (0: not that form)
     out[6] = small_eligible(h, 0, nullptr) ? (small_variant((int)h->A.n, h->planA.max_row_len, h->precond) % 16 != 0 ? 768 : 1024) : 0;
-    out[7] = team_eligible(h, 0, nullptr) ? 1 : 0;
+    out[7] = team_eligible(h, 0, nullptr) ? (single_team_default(h, 0) ? 2 : 1) : 0;      // 2: a single default solve takes that form too
     // who sums <r,z> in a multi-launch update (cg.py:82): 0 k_update_r (M = I, Jacobi), 1 k_dot_partials, 2 k_lm_finish (way out of a
     // level-major solve), 3 the SpMV that applied M (its plan in out[9..11]), 4 the colour sweeps (out[12..15]), 9 a tree the checker
     // does not restate
@@ -560,7 +567,7 @@ static int ensure_team(dpcg_system *h, hipStream_t s) {
         DPCG_TRY(dev_alloc(&h->p2, h->A.n));
         drop_graph(h);
     }
-    if (!h->team_part) DPCG_TRY(dev_alloc(&h->team_part, 4 * 2 * 32));
+    if (!h->team_part) DPCG_TRY(dev_alloc(&h->team_part, 4 * 2 * 32 + 8));      // (+ 8 words of phase times, DPCG_TEAM_TRACE)
     if (!h->team_sync) DPCG_TRY(dev_alloc(&h->team_sync, 2));
     return DPCG_OK;
 }
@@ -586,6 +593,8 @@ static TeamDesc make_team_desc(dpcg_system *h, const double *b, const double *x0
     d.bar = h->team_sync;
     d.part = h->team_part;
     d.err = reinterpret_cast<int *>(h->team_sync + 1);
+    static const bool trace = [] { const char *e = getenv("DPCG_TEAM_TRACE"); return e && e[0] == '1'; }();
+    d.dbg = trace ? reinterpret_cast<unsigned long long *>(h->team_part + 4 * 2 * 32) : nullptr;
     return d;
 }
 
@@ -626,6 +635,14 @@ static int solve_team_one(dpcg_system *h, const double *b, const double *x0, dou
     if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
     if (iters) *iters = sc.k;
     if (final_res) *final_res = sc.res;
+    if (d.dbg && sc.k > 0) {
+        unsigned long long w[8];
+        DPCG_HIP(hipMemcpy(w, d.dbg, sizeof(w), hipMemcpyDeviceToHost));
+        const double us = 0.01 / sc.k;       // 100 MHz ticks -> us per update
+        fprintf(stderr, "[dpcg team] %d updates, us per update on rank 0: SpMV %.2f, sum <p,Ap> %.2f (block sums %.2f, hand-off %.2f), vector update + publish %.2f, "
+                "sum <r,z> %.2f (drain %.2f, block sums %.2f, hand-off %.2f), total %.2f\n", sc.k, w[0] * us, w[1] * us, w[5] * us, (w[1] - w[5]) * us, w[2] * us,
+                w[3] * us, w[6] * us, w[7] * us, (w[3] - w[6] - w[7]) * us, w[4] * us);
+    }
     if (res_history) {
         DPCG_HIP(hipMemcpyAsync(res_history, h->hist, (size_t)(sc.k + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
         DPCG_HIP(hipStreamSynchronize(s));
@@ -652,7 +669,9 @@ extern "C" int dpcg_solve(dpcg_handle_t h, const double *b, const double *x0, do
     if (small_eligible(h, flags, x_true))
         return solve_small_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
                                seconds, res_history);
-    if ((flags & DPCG_TEAM) && team_eligible(h, flags, x_true)) {    // a single team: on request only (it trails the multi-launch path)
+    // a single team: up to 32 768 rows (one 1024-row slab per workgroup) by default -- 7.1-8.7 us per update against 9.7-14.4 for the
+    // launches (tools/team_crossover_probe.py); beyond, on request only (two slabs: 10.2-11.7 against 9.6-13.4)
+    if (team_eligible(h, flags, x_true) && ((flags & DPCG_TEAM) || single_team_default(h, flags))) {
         const int st = solve_team_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
                                       seconds, res_history);
         if (st != DPCG_ERR_STATE) return st;

@@ -90,6 +90,26 @@ __device__ __forceinline__ double team_block_sum(double v, double *sh) {
     return s;
 }
 
+// Two such sums behind ONE pair of barriers (each in the order of team_block_sum).  sh: 32 doubles.
+__device__ __forceinline__ void team_block_sum2(double &a, double &b, double *sh) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) {
+        sh[threadIdx.x >> 6] = a;
+        sh[16 + (threadIdx.x >> 6)] = b;
+    }
+    __syncthreads();
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int w = 0; w < kTeamThreads / 64; ++w) {
+        sa += sh[w];
+        sb += sh[16 + w];
+    }
+    a = sa;
+    b = sb;
+}
+
 // RPT: 1024-row slabs per workgroup; WMAX: entries per row.  The matrix slice is read ONCE per solve into LDS -- used as
 // per-thread private storage (slot [k][j][t] belongs to thread t: conflict-free, no barrier): values fp64, columns 16-bit
 // (n <= 65 536) -- 10 bytes per entry, 143 KB for two slabs of 7-entry rows; in registers the same slice spilled (260 B of
@@ -101,7 +121,7 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
     extern __shared__ __attribute__((aligned(16))) double team_smem[];
     double *lv = team_smem;                                                        // [RPT][WMAX][1024] values
     unsigned short *lc = reinterpret_cast<unsigned short *>(lv + RPT * WMAX * kTeamThreads);   // [RPT][WMAX][1024] columns
-    __shared__ double sh[16];
+    __shared__ double sh[32];
     __shared__ double s_part[2 * kTeamSize];
     __shared__ int s_flag;
     const TeamDesc d = descs[team];
@@ -162,10 +182,17 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
     // a reader could have summed the value of three generations ago into alpha / beta.)  `publish`: the workgroup's stores of z
     // and p must be visible to whoever passes this point, so every wave drains them first.  Every workgroup returns the same bits.
     unsigned int gen = 0;
-    auto team_sum2 = [&](double a, double b2, bool publish, double &ra, double &rb) -> bool {
+    const bool timed = d.dbg != nullptr && rank == 0 && t == 0;     // DPCG_TEAM_TRACE: where an update's time goes (ticks of rank 0)
+    unsigned long long tk_drain = 0, tk_bsum = 0;
+    auto team_sum2 = [&](double a, double b2, bool publish, double &ra, double &rb, bool two = true) -> bool {
+        unsigned long long q0 = timed ? wall_clock64() : 0;
         if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        a = team_block_sum(a, sh);                                 // (two workgroup barriers inside: behind every wave's drain)
-        b2 = team_block_sum(b2, sh);
+        if (timed) { const unsigned long long q1 = wall_clock64(); tk_drain += q1 - q0; q0 = q1; }
+        // (two workgroup barriers inside: behind every wave's drain.  One sum, or two behind the same pair of barriers: a block sum
+        // is ~0.6 us of rank 0's time, DPCG_TEAM_TRACE -- four of them were 2.5 of the 8.9 us of an update at 10K rows)
+        if (two) team_block_sum2(a, b2, sh);
+        else a = team_block_sum(a, sh);
+        if (timed) tk_bsum += wall_clock64() - q0;
         const double pend = __longlong_as_double((long long)kTeamPending);
         double *cur = d.part + (gen & 3) * (2 * kTeamSize), *nxt = d.part + ((gen + 2) & 3) * (2 * kTeamSize);
         ++gen;
@@ -248,7 +275,7 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
     }
     double bb = 0.0, dummy = 0.0, rz = 0.0, tt = 0.0;
     if (alive) alive = team_sum2(bb_loc, rz_loc, true, bb, rz);    // z_0 and p_{-1} = 0 are published behind this point
-    if (alive) alive = team_sum2(t0_loc, 0.0, false, tt, dummy);
+    if (alive) alive = team_sum2(t0_loc, 0.0, false, tt, dummy, false);
     double res = tt / bb, beta = 0.0;
     int k_done = 0, status = DPCG_MAX_ITER;
     bool stop = false;
@@ -259,16 +286,23 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
         else if (!(res == res)) { stop = true; status = DPCG_BREAKDOWN; }
     }
     // ---- cg.py:70-87: two team barriers per update ---------------------------------------------------------------------
+    unsigned long long tk[5] = {0, 0, 0, 0, 0}, tk_bsum_a = 0;
+    const unsigned long long tk_start = timed ? wall_clock64() : 0;
+    tk_drain = tk_bsum = 0;
     while (alive && !stop && k_done < d.max_iter) {
         // update k_done: p_k = z_k + beta_k p_{k-1}; the neighbours' entries from Z = z_k and P[(k+1) & 1] = p_{k-1}
         double *Pold = (k_done & 1) ? d.p0 : d.p1, *Pnew = (k_done & 1) ? d.p1 : d.p0;
+        unsigned long long c0 = timed ? wall_clock64() : 0;
         spmv(d.z, Pold, beta);                                    // cg.py:75
         double pq_loc = 0.0;
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
             if (row[k] >= 0) pq_loc += q[k] * p[k];
         double pq = 0.0;
-        if (!(alive = team_sum2(pq_loc, 0.0, false, pq, dummy))) break;     // barrier A: every SpMV of this update is done
+        if (timed) { const unsigned long long c1 = wall_clock64(); tk[0] += c1 - c0; c0 = c1; }
+        const unsigned long long bs0 = tk_bsum;
+        if (!(alive = team_sum2(pq_loc, 0.0, false, pq, dummy, false))) break;     // barrier A: every SpMV of this update is done
+        if (timed) { const unsigned long long c1 = wall_clock64(); tk[1] += c1 - c0; c0 = c1; tk_bsum_a += tk_bsum - bs0; }
         const double alpha = rz / pq;                             // cg.py:78
         double rz_new_loc = 0.0, rr_loc = 0.0;
 #pragma unroll
@@ -284,7 +318,9 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
             }
         }
         double rz_new = 0.0, rr = 0.0;
+        if (timed) { const unsigned long long c1 = wall_clock64(); tk[2] += c1 - c0; c0 = c1; }
         if (!(alive = team_sum2(rz_new_loc, rr_loc, true, rz_new, rr))) break;   // barrier B: z, p published and <r,z>, <r,r> known
+        if (timed) tk[3] += wall_clock64() - c0;
         beta = rz_new / rz;                                       // cg.py:82
 #pragma unroll
         for (int k = 0; k < RPT; ++k) p[k] = z[k] + beta * p[k];  // cg.py:83
@@ -299,6 +335,10 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
         if (row[k] >= 0) d.x[row[k]] = x[k];
+    if (timed) {
+        d.dbg[0] = tk[0]; d.dbg[1] = tk[1]; d.dbg[2] = tk[2]; d.dbg[3] = tk[3]; d.dbg[4] = wall_clock64() - tk_start;
+        d.dbg[5] = tk_bsum_a; d.dbg[6] = tk_drain; d.dbg[7] = tk_bsum - tk_bsum_a;
+    }
     if (rank == 0 && t == 0) {
         Scalars *sc = d.out;
         sc->k = k_done;

@@ -517,7 +517,7 @@ class CsrSystem:
         L.check(L.lib().dpcg_get_reduction_geometry(self._h, out))
         return {"spmv_grid": out[0], "nrb": out[1], "cyclic": out[2], "vec_grid": out[3], "two_kernel_updates": bool(out[4]),
                 "spmv_kernel": ("stream", "vector", "tile")[out[5] & 255], "spmv_tpr": out[5] >> 8, "small_threads": out[6],
-                "team_eligible": bool(out[7]), "rz_kind": out[8], "m_grid": out[9], "m_nrb": out[10], "m_cyclic": out[11] & 255,
+                "team_eligible": bool(out[7]), "team_by_default": out[7] == 2, "rz_kind": out[8], "m_grid": out[9], "m_nrb": out[10], "m_cyclic": out[11] & 255,
                 "m_tpr": (out[11] >> 8) & 255, "mt_tpr": (out[11] >> 16) & 255, "sweep_grid": out[13],
                 "sweep_modes": [(out[14] >> (2 * k)) & 3 for k in range(out[12])], "sweep_paired": bool(out[15])}
 

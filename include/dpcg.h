@@ -61,7 +61,8 @@ enum dpcg_solve_flags {
                                 reference's <z0,z0> (cg.py:66)                                      */
     DPCG_SPMV_F32 = 2,       /* mixed precision: A@p with fp32 val and fp32 p, fp64 everywhere else */
     DPCG_NO_GRAPH = 4,       /* launch kernels one by one instead of replaying a hipGraph           */
-    DPCG_NO_SMALL = 8,       /* do not use the one-workgroup whole-solve kernel for systems <= 6144 rows */
+    DPCG_NO_SMALL = 8,       /* no whole-solve kernel for ONE system: neither the one-workgroup kernel (<= 6144 rows) nor, up to
+                                32 768 rows, the team kernel -- the multi-launch path */
     DPCG_VAL32_IF_LOSSLESS = 16, /* stream the matrix values as fp32 when every value survives the round trip
                                 fp64 -> fp32 -> fp64 unchanged (true for the reference's data, which is fp32
                                 upcast to fp64: data_set.py:121, test.py:68): 8 instead of 12 bytes per non-zero,
@@ -71,9 +72,9 @@ enum dpcg_solve_flags {
                                 x += alpha p (cg.py:79); same arithmetic, bit-identical results              */
     DPCG_NO_TEAM = 64,       /* do not use the one-launch whole-solve kernel for mid-size systems (6 145 .. 65 536 rows,
                                 M = I or Jacobi: a team of 32 workgroups per system, up to eight systems per launch) */
-    DPCG_TEAM = 128          /* use that kernel also for a SINGLE system or a batch of two (by default it serves batches of
-                                three or more: one team alone trails the multi-launch path, 12.5 vs 9.5 us per update at
-                                65 536 rows; eight teams together deliver 2.4x its aggregate rate)                   */
+    DPCG_TEAM = 128          /* use that kernel also for a SINGLE system of more than 32 768 rows or a batch of two (by default it
+                                serves batches of three or more, and one system up to 32 768 rows -- 7.1-8.7 us per update against
+                                9.7-14.4 for the launches; at 65 536 rows one team trails them, 10.8 vs 9.6) */
 };
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -188,7 +189,8 @@ int dpcg_set_precond_callback(dpcg_handle_t h, dpcg_precond_fn fn, void *user);
  * dealt out cyclically, 2 when cyclically with an XCD's blocks of a pass contiguous (0: contiguous slabs), out[3] = workgroups of the vector kernels, out[4] = 1 when a solve with default
  * flags runs two-kernel updates, out[5] = the SpMV kernel in bits 0-7 (0 gather, 1 vector, 2 x-tile) and, for the vector kernel, its
  * lanes per row in bits 8-15, out[6] = threads of the one-workgroup
- * solve when a default call takes that form (0 otherwise), out[7] = 1 when the system is eligible for the team solve,
+ * solve when a default call takes that form (0 otherwise), out[7] = 1 when the system is eligible for the team solve (2: and a
+ * single default solve takes it),
  * out[8] = who sums <r,z> behind the CURRENT preconditioner in a multi-launch update (0 the r-update kernel, 1 a separate dot
  * launch, 2 the way-out pass of a level-major triangular solve, 3 the SpMV that applied M -- its grid / row blocks / walk in
  * out[9..11]; out[11] bits 8-15: lanes per row when that SpMV is the vector kernel, bits 16-23: the same for the L^T product of

@@ -290,10 +290,13 @@ def test_pcg_no_graph_path_matches_graph_path(D):
     b = _dev(O.rhs(A.shape[0], 0))
     S = D.CsrSystem.from_any(A)
     S.set_preconditioner(D.Jacobi())
-    r1 = S.solve(b)
-    r2 = S.solve(b, flags=D._lib.NO_GRAPH)
+    r1 = S.solve(b, flags=D._lib.NO_SMALL)                    # the multi-launch path as a replayed hipGraph (13 824 rows: a plain call
+    r2 = S.solve(b, flags=D._lib.NO_GRAPH)                    # would take the one-launch team kernel) ... and launch by launch
     assert r1.iterations == r2.iterations and np.array_equal(r1.res_history, r2.res_history)
     assert torch.equal(r1.x, r2.x)  # deterministic reductions: bitwise reproducible
+    r0 = S.solve(b)                                           # the plain call: the team kernel, another summation order, the same solve
+    assert S.reduction_geometry()["team_by_default"] and r0.iterations == r1.iterations
+    np.testing.assert_allclose(r0.res_history, r1.res_history, rtol=HIST_RTOL)
 
 
 def test_pcg_solution_and_true_residual(D):
@@ -2516,8 +2519,8 @@ def test_ic0_in_multicolour_order(D, name, make, reorder, colors):
                                        ("poisson3d_33", lambda: O.poisson3d(33)),
                                        ("unstructured2d_150", lambda: O.unstructured_like(O.poisson2d(150), seed=4))])
 def test_team_kernel_matches_multi_launch_path_and_oracle(D, name, make):
-    """6 145 .. 65 536 rows, M = I / Jacobi: the one-launch team solve (DPCG_TEAM forces it for a single system; batches of
-    three or more take it by themselves) against oracle/pcg_oracle.c (counts equal, history within 1e-10, x) and against the
+    """6 145 .. 65 536 rows, M = I / Jacobi: the one-launch team solve (a single system takes it by itself up to 32 768 rows,
+    DPCG_TEAM forces it beyond; batches of three or more take it by themselves) against oracle/pcg_oracle.c (counts equal, history within 1e-10, x) and against the
     multi-launch path: x0, max_iter caps, both stopping tests, and the breakdown status."""
     A = make()
     n = A.shape[0]
@@ -2529,7 +2532,10 @@ def test_team_kernel_matches_multi_launch_path_and_oracle(D, name, make):
             continue         # unpreconditioned CG on the D A D-scaled system is chaotic (the two CPU oracles differ by 19 % there)
         S.set_preconditioner(pc)
         team = S.solve(_dev(b), flags=D._lib.TEAM)
-        multi = S.solve(_dev(b))
+        multi = S.solve(_dev(b), flags=D._lib.NO_TEAM)
+        plain = S.solve(_dev(b))
+        assert S.reduction_geometry()["team_by_default"] == (n <= 32768)
+        assert np.array_equal(plain.res_history, (team if n <= 32768 else multi).res_history)     # which path a plain call takes
         _, it, hist, x = CO.pcg(A, b, kind, **okw)
         assert team.iterations == multi.iterations == it and team.status == multi.status == 0
         np.testing.assert_allclose(team.res_history, hist, rtol=HIST_RTOL)
