@@ -442,6 +442,7 @@ struct TeamDesc {
     unsigned int *bar;         // the team's barrier counter (zero at launch)
     double *part;              // 3 sets x 2 x kTeamSize doubles, all preset to the "pending" pattern at launch
     int *err;
+    int *xcc;                  // 32 words: the XCD every workgroup of the team found itself on (exchanged once per solve)
     unsigned long long *dbg;   // DPCG_TEAM_TRACE=1: 8 words, ticks (100 MHz) rank 0 spent per phase of the updates; else null
 };
 

@@ -489,11 +489,13 @@ static bool team_eligible(const dpcg_system *h, int flags, const double *x_true)
     return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI;
 }
 
-// One mid-size system, default flags: the team kernel while a workgroup holds ONE slab of it.  DPCG_NO_SMALL ("no whole-solve
+// One mid-size system, default flags: the team kernel (with the team on one XCD -- the usual placement -- 5.9-7.2 us per update up to
+// 32K rows, 8.4-10.3 up to 64K, against 9.6-14.5 for the launches: profiles/r04_team_trace.txt).  DPCG_NO_SMALL ("no whole-solve
 // kernel") keeps it on the launches, as it does for the one-workgroup kernel; DPCG_TEAM_SINGLE=0: development knob.
 static bool single_team_default(const dpcg_system *h, int flags) {
     static const bool on = [] { const char *e = getenv("DPCG_TEAM_SINGLE"); return !(e && e[0] == '0'); }();
-    return on && !(flags & (DPCG_NO_SMALL | DPCG_NO_GRAPH)) && h->A.n <= 32 * 1024;
+    (void)h;
+    return on && !(flags & (DPCG_NO_SMALL | DPCG_NO_GRAPH));
 }
 
 extern "C" int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]) {
@@ -567,7 +569,7 @@ static int ensure_team(dpcg_system *h, hipStream_t s) {
         DPCG_TRY(dev_alloc(&h->p2, h->A.n));
         drop_graph(h);
     }
-    if (!h->team_part) DPCG_TRY(dev_alloc(&h->team_part, 4 * 2 * 32 + 8));      // (+ 8 words of phase times, DPCG_TEAM_TRACE)
+    if (!h->team_part) DPCG_TRY(dev_alloc(&h->team_part, 4 * 2 * 32 + 8 + 16));      // (+ 8 words of phase times, DPCG_TEAM_TRACE; + 32 ints: the XCDs)
     if (!h->team_sync) DPCG_TRY(dev_alloc(&h->team_sync, 2));
     return DPCG_OK;
 }
@@ -593,6 +595,7 @@ static TeamDesc make_team_desc(dpcg_system *h, const double *b, const double *x0
     d.bar = h->team_sync;
     d.part = h->team_part;
     d.err = reinterpret_cast<int *>(h->team_sync + 1);
+    d.xcc = reinterpret_cast<int *>(h->team_part + 4 * 2 * 32 + 8);
     static const bool trace = [] { const char *e = getenv("DPCG_TEAM_TRACE"); return e && e[0] == '1'; }();
     d.dbg = trace ? reinterpret_cast<unsigned long long *>(h->team_part + 4 * 2 * 32) : nullptr;
     return d;
@@ -669,8 +672,7 @@ extern "C" int dpcg_solve(dpcg_handle_t h, const double *b, const double *x0, do
     if (small_eligible(h, flags, x_true))
         return solve_small_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
                                seconds, res_history);
-    // a single team: up to 32 768 rows (one 1024-row slab per workgroup) by default -- 7.1-8.7 us per update against 9.7-14.4 for the
-    // launches (tools/team_crossover_probe.py); beyond, on request only (two slabs: 10.2-11.7 against 9.6-13.4)
+    // a single team by default (tools/team_crossover_probe.py)
     if (team_eligible(h, flags, x_true) && ((flags & DPCG_TEAM) || single_team_default(h, flags))) {
         const int st = solve_team_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
                                       seconds, res_history);
@@ -764,7 +766,7 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
     }
     bool all_team = true;
     for (int i = 0; i < count; ++i) all_team = all_team && team_eligible(handles[i], flags, nullptr);
-    if (all_team && (count >= 3 || (flags & DPCG_TEAM))) {
+    if (all_team && ((flags & DPCG_TEAM) || single_team_default(handles[0], flags))) {      // (any count: one team already beats the launches)
         // up to eight systems per launch, one team (normally: one XCD) each; the launches follow one another
         struct TeamScratch {
             TeamDesc *descs = nullptr;

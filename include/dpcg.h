@@ -61,8 +61,8 @@ enum dpcg_solve_flags {
                                 reference's <z0,z0> (cg.py:66)                                      */
     DPCG_SPMV_F32 = 2,       /* mixed precision: A@p with fp32 val and fp32 p, fp64 everywhere else */
     DPCG_NO_GRAPH = 4,       /* launch kernels one by one instead of replaying a hipGraph           */
-    DPCG_NO_SMALL = 8,       /* no whole-solve kernel for ONE system: neither the one-workgroup kernel (<= 6144 rows) nor, up to
-                                32 768 rows, the team kernel -- the multi-launch path */
+    DPCG_NO_SMALL = 8,       /* no whole-solve kernel for ONE system: neither the one-workgroup kernel (<= 6144 rows) nor the team
+                                kernel (6 145 .. 65 536 rows) -- the multi-launch path */
     DPCG_VAL32_IF_LOSSLESS = 16, /* stream the matrix values as fp32 when every value survives the round trip
                                 fp64 -> fp32 -> fp64 unchanged (true for the reference's data, which is fp32
                                 upcast to fp64: data_set.py:121, test.py:68): 8 instead of 12 bytes per non-zero,
@@ -72,9 +72,8 @@ enum dpcg_solve_flags {
                                 x += alpha p (cg.py:79); same arithmetic, bit-identical results              */
     DPCG_NO_TEAM = 64,       /* do not use the one-launch whole-solve kernel for mid-size systems (6 145 .. 65 536 rows,
                                 M = I or Jacobi: a team of 32 workgroups per system, up to eight systems per launch) */
-    DPCG_TEAM = 128          /* use that kernel also for a SINGLE system of more than 32 768 rows or a batch of two (by default it
-                                serves batches of three or more, and one system up to 32 768 rows -- 7.1-8.7 us per update against
-                                9.7-14.4 for the launches; at 65 536 rows one team trails them, 10.8 vs 9.6) */
+    DPCG_TEAM = 128          /* use that kernel whatever the other flags say (it serves one system and batches by default:
+                                5.9-10.3 us per update against 9.6-14.5 for the launches; eight teams together 3.8x their rate) */
 };
 
 /* ---- library ------------------------------------------------------------------------------- */

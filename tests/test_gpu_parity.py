@@ -2519,8 +2519,7 @@ def test_ic0_in_multicolour_order(D, name, make, reorder, colors):
                                        ("poisson3d_33", lambda: O.poisson3d(33)),
                                        ("unstructured2d_150", lambda: O.unstructured_like(O.poisson2d(150), seed=4))])
 def test_team_kernel_matches_multi_launch_path_and_oracle(D, name, make):
-    """6 145 .. 65 536 rows, M = I / Jacobi: the one-launch team solve (a single system takes it by itself up to 32 768 rows,
-    DPCG_TEAM forces it beyond; batches of three or more take it by themselves) against oracle/pcg_oracle.c (counts equal, history within 1e-10, x) and against the
+    """6 145 .. 65 536 rows, M = I / Jacobi: the one-launch team solve (what a plain call and batches take) against oracle/pcg_oracle.c (counts equal, history within 1e-10, x) and against the
     multi-launch path: x0, max_iter caps, both stopping tests, and the breakdown status."""
     A = make()
     n = A.shape[0]
@@ -2534,8 +2533,8 @@ def test_team_kernel_matches_multi_launch_path_and_oracle(D, name, make):
         team = S.solve(_dev(b), flags=D._lib.TEAM)
         multi = S.solve(_dev(b), flags=D._lib.NO_TEAM)
         plain = S.solve(_dev(b))
-        assert S.reduction_geometry()["team_by_default"] == (n <= 32768)
-        assert np.array_equal(plain.res_history, (team if n <= 32768 else multi).res_history)     # which path a plain call takes
+        assert S.reduction_geometry()["team_by_default"]
+        assert np.array_equal(plain.res_history, team.res_history)                          # the path a plain call takes
         _, it, hist, x = CO.pcg(A, b, kind, **okw)
         assert team.iterations == multi.iterations == it and team.status == multi.status == 0
         np.testing.assert_allclose(team.res_history, hist, rtol=HIST_RTOL)
