@@ -489,8 +489,8 @@ static bool team_eligible(const dpcg_system *h, int flags, const double *x_true)
     return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI;
 }
 
-// One mid-size system, default flags: the team kernel (with the team on one XCD -- the usual placement -- 5.9-7.2 us per update up to
-// 32K rows, 8.4-10.3 up to 64K, against 9.6-14.5 for the launches: profiles/r04_team_trace.txt).  DPCG_NO_SMALL ("no whole-solve
+// One mid-size system, default flags: the team kernel (with the team on one XCD -- the usual placement -- 5.0-6.3 us per update up to
+// 32K rows, 7.3-9.3 up to 64K, against 9.6-14.6 for the launches: profiles/r04_team_trace.txt).  DPCG_NO_SMALL ("no whole-solve
 // kernel") keeps it on the launches, as it does for the one-workgroup kernel; DPCG_TEAM_SINGLE=0: development knob.
 static bool single_team_default(const dpcg_system *h, int flags) {
     static const bool on = [] { const char *e = getenv("DPCG_TEAM_SINGLE"); return !(e && e[0] == '0'); }();

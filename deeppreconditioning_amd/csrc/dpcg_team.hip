@@ -92,33 +92,38 @@ __device__ __forceinline__ bool team_barrier(unsigned int *bar, unsigned int &ta
     return *s_flag != 0;
 }
 
-// Sum over the 1024 threads of the workgroup in a fixed order; every thread gets the result.  sh: 16 doubles.
-__device__ __forceinline__ double team_block_sum(double v, double *sh) {
+// Sum over the 1024 threads of the workgroup in a fixed order; every thread gets the result.  sh: 2 x 32 doubles, the two halves
+// used in turn (`phase`), so ONE barrier per sum suffices: whoever writes a half again has passed the barrier of the sum in between,
+// behind which every thread had read it.  (A workgroup barrier here also waits for the wave's outstanding stores: ~0.35 us each in
+// the update loop, DPCG_TEAM_TRACE.)
+__device__ __forceinline__ double team_block_sum(double v, double *sh, int &phase) {
+    double *slot = sh + (phase & 1) * 32;
+    ++phase;
     v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 63) slot[threadIdx.x >> 6] = v;
     __syncthreads();
     double s = 0.0;
 #pragma unroll
-    for (int w = 0; w < kTeamThreads / 64; ++w) s += sh[w];
+    for (int w = 0; w < kTeamThreads / 64; ++w) s += slot[w];
     return s;
 }
 
-// Two such sums behind ONE pair of barriers (each in the order of team_block_sum).  sh: 32 doubles.
-__device__ __forceinline__ void team_block_sum2(double &a, double &b, double *sh) {
+// Two such sums behind the one barrier (each in the order of team_block_sum).
+__device__ __forceinline__ void team_block_sum2(double &a, double &b, double *sh, int &phase) {
+    double *slot = sh + (phase & 1) * 32;
+    ++phase;
     a = wave_sum(a);
     b = wave_sum(b);
-    __syncthreads();
     if ((threadIdx.x & 63) == 63) {
-        sh[threadIdx.x >> 6] = a;
-        sh[16 + (threadIdx.x >> 6)] = b;
+        slot[threadIdx.x >> 6] = a;
+        slot[16 + (threadIdx.x >> 6)] = b;
     }
     __syncthreads();
     double sa = 0.0, sb = 0.0;
 #pragma unroll
     for (int w = 0; w < kTeamThreads / 64; ++w) {
-        sa += sh[w];
-        sb += sh[16 + w];
+        sa += slot[w];
+        sb += slot[16 + w];
     }
     a = sa;
     b = sb;
@@ -135,8 +140,9 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
     extern __shared__ __attribute__((aligned(16))) double team_smem[];
     double *lv = team_smem;                                                        // [RPT][WMAX][1024] values
     unsigned short *lc = reinterpret_cast<unsigned short *>(lv + RPT * WMAX * kTeamThreads);   // [RPT][WMAX][1024] columns
-    __shared__ double sh[32];
-    __shared__ double s_part[2 * kTeamSize];
+    __shared__ double sh[64];
+    int sum_phase = 0;
+    __shared__ double s_part[2][2 * kTeamSize];      // (two sets in turn: no barrier behind the last read of one)
     __shared__ int s_flag;
     const TeamDesc d = descs[team];
     const int t = threadIdx.x;
@@ -217,13 +223,14 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
         unsigned long long q0 = timed ? wall_clock64() : 0;
         if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (timed) { const unsigned long long q1 = wall_clock64(); tk_drain += q1 - q0; q0 = q1; }
-        // (two workgroup barriers inside: behind every wave's drain.  One sum, or two behind the same pair of barriers: a block sum
-        // is ~0.6 us of rank 0's time, DPCG_TEAM_TRACE -- four of them were 2.5 of the 8.9 us of an update at 10K rows)
-        if (two) team_block_sum2(a, b2, sh);
-        else a = team_block_sum(a, sh);
+        // (a workgroup barrier inside: behind every wave's drain.  One sum, or two behind the same barrier: a block sum with two barriers
+        // was ~0.6 us of rank 0's time, DPCG_TEAM_TRACE -- four of them 2.5 of the 8.9 us of an update at 10K rows)
+        if (two) team_block_sum2(a, b2, sh, sum_phase);
+        else a = team_block_sum(a, sh, sum_phase);
         if (timed) tk_bsum += wall_clock64() - q0;
         const double pend = __longlong_as_double((long long)kTeamPending);
         double *cur = d.part + (gen & 3) * (2 * kTeamSize), *nxt = d.part + ((gen + 2) & 3) * (2 * kTeamSize);
+        double *const sp = s_part[gen & 1];
         ++gen;
         if (t == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the re-arm stores of the previous generation have landed
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
                     }
                 }
             }
-            s_part[t] = v;
+            sp[t] = v;
             if (t == 0) s_flag = ok;
         }
         __syncthreads();
@@ -258,11 +265,10 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
         ra = rb = 0.0;
 #pragma unroll
         for (int w = 0; w < kTeamSize; ++w) {
-            ra += s_part[w];
-            rb += s_part[kTeamSize + w];
+            ra += sp[w];
+            rb += sp[kTeamSize + w];
         }
-        __syncthreads();
-        return true;
+        return true;       // (this set is written again two reductions on, behind the block sums' barriers of the next one)
     };
     // ---- cg.py:58-67 -------------------------------------------------------------------------------------------------
     double bb_loc = 0.0;

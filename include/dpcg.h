@@ -73,7 +73,7 @@ enum dpcg_solve_flags {
     DPCG_NO_TEAM = 64,       /* do not use the one-launch whole-solve kernel for mid-size systems (6 145 .. 65 536 rows,
                                 M = I or Jacobi: a team of 32 workgroups per system, up to eight systems per launch) */
     DPCG_TEAM = 128          /* use that kernel whatever the other flags say (it serves one system and batches by default:
-                                5.9-10.3 us per update against 9.6-14.5 for the launches; eight teams together 3.8x their rate) */
+                                5.0-9.3 us per update against 9.6-14.6 for the launches; eight teams together 4.4x their rate) */
 };
 
 /* ---- library ------------------------------------------------------------------------------- */
