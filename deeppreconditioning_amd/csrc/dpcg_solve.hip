@@ -473,6 +473,14 @@ static int solve_small_one(dpcg_system *h, const double *b, const double *x0, do
 // ------------------------------------------------------------------------------------------------
 // mid-size systems: the whole solve in one launch, a team of 32 workgroups per system (dpcg_team.hip)
 // ------------------------------------------------------------------------------------------------
+// Rows beyond which ONE system (M = I / Jacobi) takes the team kernel instead of the one-workgroup kernel: that one holds up to 6 rows
+// per thread -- 2.7 us per update at 2.4K rows, 3.0 at 4 096 (4 rows per thread), but 6.7-7.5 at 4.9K-6.1K (5-6 rows: the matrix no
+// longer stays in registers) where a team takes 5.0 (tools/small_vs_team_probe.py).  Batches of such systems keep the one-workgroup
+// kernel (256 of them in one launch).  DPCG_TEAM_MIN_ROWS: development knob.
+static int team_min_rows() {
+    static const int v = [] { const char *e = getenv("DPCG_TEAM_MIN_ROWS"); return e ? atoi(e) : 4096; }();
+    return v;
+}
 static bool team_eligible(const dpcg_system *h, int flags, const double *x_true) {
     static const bool enabled = [] {
         const char *e = getenv("DPCG_TEAM");
@@ -483,7 +491,7 @@ static bool team_eligible(const dpcg_system *h, int flags, const double *x_true)
         return cus >= 256;                       // eight teams of 32 workgroups, one workgroup per CU, all resident
     }();
     if (!enabled || x_true || (flags & (DPCG_SPMV_F32 | DPCG_NO_TEAM | DPCG_NO_FUSE | DPCG_VAL32_IF_LOSSLESS))) return false;
-    if (h->A.n <= kSmallMaxN || h->A.n > team_max_rows() || h->perm) return false;
+    if (h->A.n <= team_min_rows() || h->A.n > team_max_rows() || h->perm) return false;
     if (h->planA.max_row_len < 1 || h->planA.max_row_len > team_max_row_len()) return false;   // rows live in registers
     if (h->planA.kernel == SPMV_VECTOR) return false;     // long rows: the multi-launch path's row-sharing kernel
     return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI;
@@ -669,7 +677,8 @@ extern "C" int dpcg_solve(dpcg_handle_t h, const double *b, const double *x0, do
                           double *final_res, double *seconds, double *res_history, const double *x_true,
                           double *err_history) {
     DPCG_TRY(check_solve_args(h, b, max_iter, flags, x_true, err_history));
-    if (small_eligible(h, flags, x_true))
+    const bool team_first = team_eligible(h, flags, x_true) && ((flags & DPCG_TEAM) || single_team_default(h, flags));
+    if (small_eligible(h, flags, x_true) && !team_first)
         return solve_small_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
                                seconds, res_history);
     // a single team by default (tools/team_crossover_probe.py)

@@ -62,7 +62,7 @@ enum dpcg_solve_flags {
     DPCG_SPMV_F32 = 2,       /* mixed precision: A@p with fp32 val and fp32 p, fp64 everywhere else */
     DPCG_NO_GRAPH = 4,       /* launch kernels one by one instead of replaying a hipGraph           */
     DPCG_NO_SMALL = 8,       /* no whole-solve kernel for ONE system: neither the one-workgroup kernel (<= 6144 rows) nor the team
-                                kernel (6 145 .. 65 536 rows) -- the multi-launch path */
+                                kernel (4 097 .. 65 536 rows, M = I / Jacobi) -- the multi-launch path */
     DPCG_VAL32_IF_LOSSLESS = 16, /* stream the matrix values as fp32 when every value survives the round trip
                                 fp64 -> fp32 -> fp64 unchanged (true for the reference's data, which is fp32
                                 upcast to fp64: data_set.py:121, test.py:68): 8 instead of 12 bytes per non-zero,

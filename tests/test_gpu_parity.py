@@ -2712,12 +2712,17 @@ def test_one_workgroup_solve_equals_the_device_tree_oracle_bit_for_bit(D, name, 
         S.set_preconditioner(pc)
         geo = S.reduction_geometry()
         assert geo["small_threads"] in (768, 1024), geo
-        for x0 in (None, O.rhs(n, 4)):
-            res = S.solve(_dev(b), None if x0 is None else _dev(x0))
-            _, it, hist, x = CO.pcg(A, b, kind, x0=x0, device_tree={**geo, "form": "small"}, **okw)
-            assert res.iterations == it, (name, kind, geo)
-            assert np.array_equal(res.res_history, hist), (name, kind, geo, int(np.argmax(res.res_history != hist)))
-            assert np.array_equal(res.x.cpu().numpy(), x), (name, kind)
+        # beyond 4 096 rows a plain call with M = I / Jacobi takes the TEAM kernel (the one-workgroup kernel's 5-6 rows per thread are
+        # slower): both are checked, each against its own tree
+        forms = [(D._lib.NO_TEAM, "small")] + ([(0, "team")] if geo["team_by_default"] else [(0, "small")])
+        assert geo["team_by_default"] == (n > 4096 and kind in ("none", "jacobi") and not S.reordered and int(np.diff(A.indptr).max()) <= 7), (name, kind, geo)
+        for flags, form in forms:
+            for x0 in (None, O.rhs(n, 4)):
+                res = S.solve(_dev(b), None if x0 is None else _dev(x0), flags=flags)
+                _, it, hist, x = CO.pcg(A, b, kind, x0=x0, device_tree={**geo, "form": form}, **okw)
+                assert res.iterations == it, (name, kind, form, geo)
+                assert np.array_equal(res.res_history, hist), (name, kind, form, geo, int(np.argmax(res.res_history != hist)))
+                assert np.array_equal(res.x.cpu().numpy(), x), (name, kind, form)
     S.close()
 
 
