@@ -1,4 +1,6 @@
-"""Window (workgroups in flight) of the CSR-stream sync-free solve: DPCG_SF_FACTOR x the widest level.   python tools/sfs_window_probe.py"""
+"""Window (workgroups in flight) of the CSR-stream sync-free solve: DPCG_SF_FACTOR x the widest level.   python tools/sfs_window_probe.py
+(The `gate` column drove DPCG_SF_GATE, a level-gate experiment that was measured -- profiles/r04_sfs_window.txt -- and removed from
+the library: the variable is ignored now.)"""
 import os
 import subprocess
 import sys
