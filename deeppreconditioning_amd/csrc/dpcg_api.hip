@@ -184,11 +184,16 @@ int make_plan(const CsrDev &A, SpmvPlan &plan, hipStream_t s, bool allow_tile) {
     int h_max = 0;
     DPCG_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
-    if (A.n <= 65536) {                                  // (only the team kernel of mid-size systems asks)
-        DPCG_HIP(hipMemsetAsync(d_max, 0, sizeof(int), s));
-        launch_max_row_len((int)A.n, A.rowptr, d_max, s);
-        DPCG_HIP(hipMemcpyAsync(&plan.max_row_len, d_max, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (A.n <= chip_max_rows()) {                        // (only the whole-solve kernels of mid-size and cache-sized systems ask)
+        int *d_bl = nullptr, h_bl[2] = {0, 0};
+        DPCG_TRY(dev_alloc(&d_bl, 2));
+        DPCG_HIP(hipMemsetAsync(d_bl, 0, 2 * sizeof(int), s));
+        launch_band_and_len(A, d_bl, s);
+        DPCG_HIP(hipMemcpyAsync(h_bl, d_bl, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         DPCG_HIP(hipStreamSynchronize(s));
+        dev_free(d_bl);
+        plan.max_band = h_bl[0];
+        plan.max_row_len = h_bl[1];
     }
     dev_free(d_max);
     const char *force = getenv("DPCG_SPMV_KERNEL");
@@ -393,6 +398,7 @@ extern "C" int dpcg_destroy(dpcg_handle_t h) {
     dev_free(h->part_pq); dev_free(h->part_rz); dev_free(h->part_rr); dev_free(h->part_bb);
     dev_free(h->scal); dev_free(h->hist); dev_free(h->err_hist); dev_free(h->small_desc);
     dev_free(h->team_desc); dev_free(h->team_part); dev_free(h->team_sync);
+    dev_free(h->chip_part); dev_free(h->chip_zp);
     if (h->scal_host) (void)hipHostFree(h->scal_host);
     HandleExtras ex;
     if (extras().take(h, ex)) {

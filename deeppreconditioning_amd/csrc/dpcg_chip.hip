@@ -1,0 +1,445 @@
+// Whole-solve kernel for LARGE cache-sized systems (65 537 .. 1 048 576 rows, rows of <= 7 entries, M = I / Jacobi): the WHOLE CHIP as
+// one team -- hand-written for gfx950 (MI355X: 256 CUs in 8 XCDs, wave64, 512 KiB of vector registers and 160 KiB of LDS per CU).
+//
+// The multi-launch update of the 1M-DoF headline system (cg.py:70-87) is three launches: the SpMV streams the matrix (83 MB) out of
+// the Infinity Cache at 0.79 of the HBM peak in 16.4 us, the two vector kernels stream r, p, x, dinv (64-88 MB) in another 14.8 us
+// behind two kernel boundaries -- every update, although NOTHING of it changes but four vectors.  The chip holds 128 MiB of
+// registers and 40 MiB of LDS: the matrix (8 + 2 bytes per entry) AND the vectors fit.  So here the solve (cg.py:58-90) is ONE launch:
+//   * 256 workgroups of 512 threads, one per CU (the kernel takes all of a CU's LDS, so the hardware cannot place two).  Workgroup
+//     v (its "virtual" index: blocks b, b + 8, ... share an XCD, and v = (b % 8) * 32 + b / 8 gives each XCD one contiguous eighth
+//     of the rows -- placement is a speed matter only) owns rows [v * per, (v + 1) * per), per = ceil(n / 256); thread t owns rows
+//     v * per + t + 512 k, k < RPT <= 8: consecutive lanes, consecutive rows, so what a wave gathers for one entry slot of a
+//     banded matrix is one contiguous run.
+//   * the matrix slice of a thread is read ONCE per solve: the values of its RPT x WMAX entry slots go to LDS (39 slots per thread:
+//     conflict-free private columns [slot][t]) and, beyond that, to registers; the columns are kept as 16-bit offsets from the row
+//     (col - row + 32768: the handle's matrix must have a half-bandwidth below 32 768 -- stencils and RCM-ordered meshes do),
+//     two to a register.  x, r, p, q, dinv of the own rows live in registers for the whole solve.
+//   * what the other workgroups need of an update is PUBLISHED as 16-byte granules {z_{k+1}[i], p_k[i]} (one write-through store
+//     per row and update); a row gathers one granule per entry and recomputes p_{k+1}[c] = z_{k+1}[c] + beta p_k[c] -- the owner's
+//     expression, and with contraction off the owner's bits (cg.py:83) -- so that publishing needs no barrier of its own.
+//   * TWO chip-wide reductions per update (<p,Ap> | <r,z>, <r,r>), which double as the barriers: a workgroup's partial pair is ONE
+//     16-byte write-through store into its slot of the current slot set (256 x 16 B), which held a reserved NaN pattern; wave 0 of
+//     every workgroup polls the 256 slots (4 per lane, coalesced 1-KiB loads) until none is pending and sums them in ONE fixed
+//     tree -- lane l: ((s[l] + s[l+64]) + s[l+128]) + s[l+192], then the wave's DPP tree -- so all workgroups hold bit-identical
+//     alpha / beta and take the decision of cg.py:71 identically, with no broadcast.  Four slot sets rotate, a workgroup re-arms
+//     the set two generations ahead behind a drain (dpcg_team.hip explains why two).
+//   * every store another workgroup reads is an agent-scope (sc1, write-through) store, every load of such data an sc1 load that
+//     bypasses the CU's L1, and every wave drains its stores before its workgroup signals: correct for ANY placement of the
+//     workgroups (MI355X_MICROARCH.md, "Valid forms").
+//   * co-residency is checked up front (occupancy query x CUs >= 256) and every wait is bounded (20 ms): a launch whose workgroups
+//     cannot all become resident (another process's kernel holding CUs) reports DPCG_ERR_STATE and the caller solves through the
+//     multi-launch path instead.
+// Row sums run in CSR order and every dot product in a fixed tree (restated in oracle/pcg_oracle.c, form 3), so history, count and
+// x equal the CPU restatement's bit for bit.
+#include <algorithm>
+
+#include "dpcg_device.h"
+
+namespace dpcg {
+
+namespace {
+
+constexpr int kChipWGs = 256;           // one workgroup per CU
+constexpr int kChipThreads = 512;       // 8 waves: two per SIMD, 256 vector registers per lane
+constexpr int kChipMaxRpt = 8;          // rows per thread: n <= 256 * 512 * 8
+constexpr int kChipLdsSlots = 39;       // 8-byte value slots per thread kept in LDS: 39 * 512 * 8 = 159 744 B of the CU's 163 840
+constexpr unsigned long long kChipSpinTicks = 2000000ull;               // 20 ms of the 100 MHz constant clock
+constexpr unsigned long long kChipPending = 0x7ff8dead0badbeefULL;      // a quiet NaN that no arithmetic here produces
+constexpr int kSc1 = 16;                // cache-policy operand of the buffer builtins on gfx950: bit 4 = sc1 (agent scope)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t chip_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double lo_f64(const u32x4 &g) { return __hiloint2double((int)g.y, (int)g.x); }
+__device__ __forceinline__ double hi_f64(const u32x4 &g) { return __hiloint2double((int)g.w, (int)g.z); }
+__device__ __forceinline__ u32x4 pack_f64x2(double a, double b) {
+    u32x4 g;
+    g.x = (unsigned)__double2loint(a);
+    g.y = (unsigned)__double2hiint(a);
+    g.z = (unsigned)__double2loint(b);
+    g.w = (unsigned)__double2hiint(b);
+    return g;
+}
+__device__ __forceinline__ bool row_valid_bits(unsigned lens, int k) { return ((lens >> (4 * k)) & 8u) != 0; }
+__device__ __forceinline__ bool is_pending(const u32x4 &g) {
+    return (g.x == (unsigned)(kChipPending & 0xffffffffu) && g.y == (unsigned)(kChipPending >> 32)) ||
+           (g.z == (unsigned)(kChipPending & 0xffffffffu) && g.w == (unsigned)(kChipPending >> 32));
+}
+
+// RPT: rows per thread (2, 4, 8); WMAX: entry slots per row (5, 7); JAC: M = diag(1 / a_ii) (else M = I: z = r, no dinv registers).
+template <int RPT, int WMAX, bool JAC, bool TRACE>
+__global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
+    constexpr int NS = RPT * WMAX;                                   // entry slots of a thread
+    constexpr int NLDS = NS < kChipLdsSlots ? NS : kChipLdsSlots;    // ... whose values live in LDS
+    constexpr int NREG = NS - NLDS;                                  // ... and in registers (the first NREG slots)
+    extern __shared__ __attribute__((aligned(16))) double chip_lv[];   // [NLDS][512]: slot s of thread t at [(s - NREG) * 512 + t]
+    __shared__ double sh[2 * 16];          // block sums: two halves used in turn, 2 x 8 wave sums each
+    __shared__ double s_res[2][2];         // the reduced pair, two sets in turn
+    __shared__ int s_flag;
+    const int t = threadIdx.x;
+    const int v = ((int)blockIdx.x & 7) * (kChipWGs / 8) + ((int)blockIdx.x >> 3);
+    const int row0 = v * d.per + t;        // row of slot k: row0 + 512 k
+    const __amdgpu_buffer_rsrc_t zp_rs = chip_rsrc(d.zp, (unsigned)d.n * 16u);
+    const __amdgpu_buffer_rsrc_t part_rs = chip_rsrc(d.part, 4u * kChipWGs * 16u);
+
+    // ---- the matrix slice and the vectors of the own rows: read once ------------------------------------------------------
+    double vr[NREG > 0 ? NREG : 1];
+    unsigned dl[(NS + 1) / 2];
+    unsigned lens = 0;                     // 4 bits per row: 8 | length for a row that exists, 0 otherwise
+    double x[RPT], r[RPT], p[RPT], q[RPT], dv[JAC ? RPT : 1];
+    double bb_loc = 0.0;
+    // (unconditional loads from clamped addresses -- a predicated load is a branch with a wait of its own, and 56 of them in a row
+    // were 56 dependent round trips: the extents of all rows first, then one row's entries at a time, all of them in flight together)
+    int rs_k[RPT], len_k[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int loc = k * kChipThreads + t, i = row0 + k * kChipThreads;
+        const bool valid = loc < d.per && i < d.n;
+        const int ic = valid ? i : 0;
+        const int rs = d.rp[ic], re = d.rp[ic + 1];
+        const double bi = d.b[ic];
+        const double xi = d.x0 ? d.x0[ic] : 0.0;
+        const double di = JAC ? d.dinv[ic] : 1.0;
+        rs_k[k] = rs;
+        len_k[k] = valid ? re - rs : 0;
+        lens |= (valid ? (8u | (unsigned)(re - rs)) : 0u) << (4 * k);
+        x[k] = valid ? xi : 0.0;
+        r[k] = valid ? bi : 0.0;
+        p[k] = q[k] = 0.0;
+        if (JAC) dv[k] = valid ? di : 1.0;
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        if (row_valid_bits(lens, k)) bb_loc += r[k] * r[k];
+        const int i = row0 + k * kChipThreads;
+        int cj[WMAX];
+        double aj[WMAX];
+#pragma unroll
+        for (int j = 0; j < WMAX; ++j) {
+            const int e = j < len_k[k] ? rs_k[k] + j : 0;          // (entry 0 exists: nnz >= n >= 1)
+            cj[j] = d.ci[e];
+            aj[j] = d.val[e];
+        }
+#pragma unroll
+        for (int j = 0; j < WMAX; ++j) {
+            const int s = k * WMAX + j;
+            const bool on = j < len_k[k];
+            const int c = on ? cj[j] : i;
+            const double a = on ? aj[j] : 0.0;
+            const unsigned del = (unsigned)(c - i + 32768) & 0xffffu;
+            if (s & 1) dl[s >> 1] |= del << 16;
+            else dl[s >> 1] = del;
+            if (s < NREG) vr[s < NREG ? s : 0] = a;
+            else chip_lv[(s - NREG) * kChipThreads + t] = a;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    auto row_on = [&](int k) -> bool { return ((lens >> (4 * k)) & 8u) != 0; };
+
+    // q = A p_{k} for the own rows; the gathered entries of p_k are recomputed from the published granules {z_k, p_{k-1}}.
+    // All WMAX gathers of a row are in flight together, the next row's are issued while this row's are consumed (the compiler
+    // schedules the unrolled loop); row sums in CSR order.
+    auto spmv = [&](double beta) {
+        u32x4 g[2][WMAX];
+        // the LDS-resident values never change, so the optimiser would hoist their loads out of the update loop -- into registers the
+        // kernel does not have.  An opaque copy of the thread's column index per call keeps the loads where they are.
+        int tl = t;
+        asm volatile("" : "+v"(tl));
+        const double *lvt = chip_lv + tl;
+        // (likewise the gather addresses: they are loop-invariant too, and 56 hoisted addresses are 56 registers)
+#pragma unroll
+        for (int e = 0; e < (NS + 1) / 2; ++e) asm volatile("" : "+v"(dl[e]));
+        asm volatile("" : "+v"(lens));       // (and the 56 `j < len` lane masks)
+        auto request = [&](int k, u32x4 (&gk)[WMAX]) {
+            const int rowk = row0 + k * kChipThreads;
+#pragma unroll
+            for (int j = 0; j < WMAX; ++j) {
+                const int s = k * WMAX + j;
+                const int del = (int)((dl[s >> 1] >> (16 * (s & 1))) & 0xffffu);
+                const int c = rowk + del - 32768;
+                gk[j] = __builtin_amdgcn_raw_buffer_load_b128(zp_rs, c * 16, 0, kSc1);   // (a row that does not exist: out of range, zeros)
+            }
+        };
+        request(0, g[0]);
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            if (k + 1 < RPT) request(k + 1, g[(k + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);                     // (keeps the scheduler from hoisting every row's gathers to the top:
+            const int len = (int)((lens >> (4 * k)) & 7u);         //  two rows' granules in flight is what the registers hold)
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < WMAX; ++j) {
+                const int s = k * WMAX + j;
+                const double a = s < NREG ? vr[s < NREG ? s : 0] : lvt[(s - NREG) * kChipThreads];
+                const double pc = lo_f64(g[k & 1][j]) + beta * hi_f64(g[k & 1][j]);    // = p_k[c], cg.py:83
+                if (j < len) acc += a * pc;
+            }
+            q[k] = acc;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // Two chip-wide sums at once, and a chip barrier in the same breath (see the header).  `publish`: the workgroup's granule stores
+    // must be visible to whoever passes this point, so every wave drains them first.  Every workgroup returns the same bits.
+    unsigned gen = 0;
+    int sum_phase = 0;
+    const bool timed = TRACE && d.dbg != nullptr && v == 0 && t == 0;      // DPCG_CHIP_TRACE: where an update's time goes (ticks of workgroup 0)
+    unsigned long long tk_wait = 0;
+    auto chip_sum2 = [&](double a, double b2, bool publish, double &ra, double &rb) -> bool {
+        if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        double *slot = sh + (sum_phase & 1) * 16;
+        ++sum_phase;
+        a = wave_sum(a);
+        b2 = wave_sum(b2);
+        if ((t & 63) == 63) {
+            slot[t >> 6] = a;
+            slot[8 + (t >> 6)] = b2;
+        }
+        __syncthreads();                                           // (behind every wave's drain)
+        const int cur = (int)(gen & 3u) * kChipWGs * 16, nxt = (int)((gen + 2u) & 3u) * kChipWGs * 16;
+        double *const sres = s_res[gen & 1u];
+        ++gen;
+        if (t < 64) {                                              // wave 0 publishes the workgroup's pair and polls everybody's
+            if (t == 0) {
+                double sa = 0.0, sb = 0.0;
+#pragma unroll
+                for (int w = 0; w < kChipThreads / 64; ++w) {
+                    sa += slot[w];
+                    sb += slot[8 + w];
+                }
+                const unsigned plo = (unsigned)(kChipPending & 0xffffffffu), phi = (unsigned)(kChipPending >> 32);
+                u32x4 pend;
+                pend.x = plo; pend.y = phi; pend.z = plo; pend.w = phi;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-arm of the previous generation has landed
+                __builtin_amdgcn_raw_buffer_store_b128(pend, part_rs, nxt + v * 16, 0, kSc1);
+                __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2(sa, sb), part_rs, cur + v * 16, 0, kSc1);
+            }
+            const unsigned long long w0 = timed ? wall_clock64() : 0;
+            u32x4 s4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, cur + (t + 64 * u) * 16, 0, kSc1);
+            unsigned spins = 0;
+            unsigned long long t0 = 0;
+            int ok = 1;
+            for (;;) {
+                bool pend_any = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pend_any = pend_any || is_pending(s4[u]);
+                if (__ballot(pend_any) == 0) break;
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (is_pending(s4[u])) s4[u] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, cur + (t + 64 * u) * 16, 0, kSc1);
+                if ((++spins & 255u) == 0) {
+                    const unsigned long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    else if (now - t0 > kChipSpinTicks || __hip_atomic_load(d.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        atomicExch(d.err, 1);
+                        ok = 0;
+                        break;
+                    }
+                }
+            }
+            if (timed) tk_wait += wall_clock64() - w0;
+            double ta = ((lo_f64(s4[0]) + lo_f64(s4[1])) + lo_f64(s4[2])) + lo_f64(s4[3]);
+            double tb = ((hi_f64(s4[0]) + hi_f64(s4[1])) + hi_f64(s4[2])) + hi_f64(s4[3]);
+            ta = wave_sum(ta);
+            tb = wave_sum(tb);
+            if (t == 63) {
+                sres[0] = ta;
+                sres[1] = tb;
+                s_flag = ok;
+            }
+        }
+        __syncthreads();
+        if (!s_flag) return false;
+        ra = sres[0];
+        rb = sres[1];
+        return true;       // (sres is written again two reductions on, behind the barriers of the next one)
+    };
+    auto publish = [&](int k, double zk, double pk) {
+        __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2(zk, pk), zp_rs, (row0 + k * kChipThreads) * 16, 0, kSc1);
+    };
+
+    // ---- cg.py:58-67 -------------------------------------------------------------------------------------------------
+    bool alive = true;
+    double dummy = 0.0, dummy2 = 0.0;
+    if (d.x0) {                                                   // r = b - A x0 (cg.py:60): x0 published as "z", beta = 0
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+            if (row_on(k)) publish(k, x[k], 0.0);
+        alive = chip_sum2(0.0, 0.0, true, dummy, dummy2);
+        if (alive) {
+            spmv(0.0);
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) r[k] = r[k] - q[k];
+            alive = chip_sum2(0.0, 0.0, false, dummy, dummy2);    // everybody has read x0 out of the granules before z_0 overwrites them
+        }
+    }
+    double rz_loc = 0.0, t0_loc = 0.0;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const double zk = JAC ? dv[JAC ? k : 0] * r[k] : r[k];    // cg.py:61
+        p[k] = zk;                                                // cg.py:62
+        if (row_on(k)) {
+            rz_loc += r[k] * zk;
+            t0_loc += d.init_check_r ? r[k] * r[k] : zk * zk;     // cg.py:66: the first test is on z
+            publish(k, zk, 0.0);                                  // p_0 = z_0 + 0 * p_{-1} with p_{-1} = 0
+        }
+    }
+    double bb = 0.0, rz = 0.0, tt = 0.0;
+    if (alive) alive = chip_sum2(bb_loc, rz_loc, true, bb, rz);    // z_0 and p_{-1} = 0 are published behind this point
+    if (alive) alive = chip_sum2(t0_loc, 0.0, false, tt, dummy);
+    double res = tt / bb, beta = 0.0;
+    int k_done = 0, status = DPCG_MAX_ITER;
+    bool stop = false;
+    if (alive) {
+        if (v == 0 && t == 0 && d.hist_cap > 0) d.hist[0] = res;
+        const bool conv = (res < d.rtol_sq) || (tt < d.atol_sq);
+        if (conv) { stop = true; status = DPCG_OK; }
+        else if (!(res == res)) { stop = true; status = DPCG_BREAKDOWN; }
+    }
+    // ---- cg.py:70-87: two chip barriers per update -----------------------------------------------------------------------
+    unsigned long long tk[4] = {0, 0, 0, 0};
+    const unsigned long long tk_start = timed ? wall_clock64() : 0;
+    unsigned long long tk_wait_a = 0;
+    tk_wait = 0;
+    while (alive && !stop && k_done < d.max_iter) {
+        unsigned long long c0 = timed ? wall_clock64() : 0;
+        spmv(beta);                                               // cg.py:75
+        double pq_loc = 0.0;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+            if (row_on(k)) pq_loc += q[k] * p[k];
+        double pq = 0.0;
+        if (timed) { const unsigned long long c1 = wall_clock64(); tk[0] += c1 - c0; c0 = c1; }
+        const unsigned long long wa0 = tk_wait;
+        if (!(alive = chip_sum2(pq_loc, 0.0, false, pq, dummy))) break;         // barrier A: every SpMV of this update is done
+        if (timed) { const unsigned long long c1 = wall_clock64(); tk[1] += c1 - c0; c0 = c1; tk_wait_a += tk_wait - wa0; }
+        const double alpha = rz / pq;                             // cg.py:78
+        double rz_new_loc = 0.0, rr_loc = 0.0;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            x[k] = x[k] + alpha * p[k];                           // cg.py:79
+            r[k] = r[k] - alpha * q[k];                           // cg.py:80
+            const double zk = JAC ? dv[JAC ? k : 0] * r[k] : r[k];   // cg.py:81
+            if (row_on(k)) {
+                rz_new_loc += r[k] * zk;
+                rr_loc += r[k] * r[k];
+                publish(k, zk, p[k]);                             // z_{k+1} and p_k for the next update's gathers
+            }
+        }
+        double rz_new = 0.0, rr = 0.0;
+        if (timed) { const unsigned long long c1 = wall_clock64(); tk[2] += c1 - c0; c0 = c1; }
+        if (!(alive = chip_sum2(rz_new_loc, rr_loc, true, rz_new, rr))) break;  // barrier B: granules published, <r,z>, <r,r> known
+        if (timed) tk[3] += wall_clock64() - c0;
+        beta = rz_new / rz;                                       // cg.py:82
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) p[k] = (JAC ? dv[JAC ? k : 0] * r[k] : r[k]) + beta * p[k];   // cg.py:83 (z recomputed: the same product, the same bits)
+        rz = rz_new;
+        res = rr / bb;                                            // cg.py:86
+        ++k_done;
+        if (v == 0 && t == 0 && k_done < d.hist_cap) d.hist[k_done] = res;
+        const bool conv = (res < d.rtol_sq) || (rr < d.atol_sq);  // cg.py:71, tested before the next update's work
+        if (conv) { stop = true; status = DPCG_OK; }
+        else if (!(res == res)) { stop = true; status = DPCG_BREAKDOWN; }
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+        if (row_on(k)) d.x[row0 + k * kChipThreads] = x[k];
+    if (timed) {
+        d.dbg[0] = tk[0]; d.dbg[1] = tk[1]; d.dbg[2] = tk[2]; d.dbg[3] = tk[3]; d.dbg[4] = wall_clock64() - tk_start;
+        d.dbg[5] = tk_wait_a; d.dbg[6] = tk_wait - tk_wait_a; d.dbg[7] = (unsigned long long)k_done;
+    }
+    if (v == 0 && t == 0) {
+        Scalars *sc = d.out;
+        sc->k = k_done;
+        sc->res = res;
+        sc->bb = bb;
+        sc->status = alive ? status : DPCG_ERR_STATE;
+        sc->done = 1;
+    }
+}
+
+// largest |col - row| and longest row of a CSR pattern (what decides whether the chip kernel can hold it)
+__global__ __launch_bounds__(kBlock) void k_band_and_len(int64_t n, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                         int *out /* [0] band, [1] row length */) {
+    int band = 0, len = 0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const int s = rp[i], e = rp[i + 1];
+        len = e - s > len ? e - s : len;
+        if (e > s) {                       // columns ascend within a row: the extremes are its ends
+            const int lo = (int)i - ci[s], hi = ci[e - 1] - (int)i;
+            band = lo > band ? lo : band;
+            band = hi > band ? hi : band;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const int ob = __shfl_down(band, off), ol = __shfl_down(len, off);
+        band = ob > band ? ob : band;
+        len = ol > len ? ol : len;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&out[0], band);
+        atomicMax(&out[1], len);
+    }
+}
+
+template <int RPT, int WMAX, bool JAC, bool TRACE>
+int chip_launch(const ChipDesc &d, hipStream_t s, bool check_only) {
+    constexpr int NS = RPT * WMAX;
+    constexpr int NLDS = NS < kChipLdsSlots ? NS : kChipLdsSlots;
+    const int lds = NLDS * kChipThreads * (int)sizeof(double);
+    static int resident = -1;              // workgroups the occupancy query admits per CU (once per instantiation)
+    if (resident < 0) {
+        if (hipFuncSetAttribute((const void *)k_pcg_chip<RPT, WMAX, JAC, TRACE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return DPCG_ERR_HIP;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_pcg_chip<RPT, WMAX, JAC, TRACE>, kChipThreads, (size_t)lds) !=
+            hipSuccess)
+            return DPCG_ERR_HIP;
+        resident = per_cu;
+    }
+    if (resident < 1) return DPCG_ERR_STATE;       // the kernel does not fit a CU: refused up front
+    if (check_only) return DPCG_OK;
+    hipLaunchKernelGGL((k_pcg_chip<RPT, WMAX, JAC, TRACE>), dim3(kChipWGs), dim3(kChipThreads), (size_t)lds, s, d);
+    return DPCG_OK;
+}
+
+}  // namespace
+
+int chip_max_rows() { return kChipWGs * kChipThreads * kChipMaxRpt; }
+int chip_max_row_len() { return 7; }
+int chip_max_band() { return 32767; }
+int chip_workgroups() { return kChipWGs; }
+int chip_threads() { return kChipThreads; }
+
+void launch_band_and_len(const CsrDev &A, int *out2_zeroed_dev, hipStream_t s) {
+    int64_t g = (A.n + kBlock - 1) / kBlock;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_band_and_len, dim3((int)g), dim3(kBlock), 0, s, A.n, A.rowptr, A.col, out2_zeroed_dev);
+}
+
+// One system on the whole chip.  max_row_len <= 7; d.per = ceil(n / 256) <= 4096.  check_only: the occupancy query alone.
+// Returns DPCG_OK, DPCG_ERR_STATE when the kernel cannot be resident on every CU, or a negative HIP status.
+int launch_pcg_chip(const ChipDesc &d, int max_row_len, hipStream_t s, bool check_only) {
+    if (max_row_len < 1 || max_row_len > 7 || d.per < 1 || d.per > kChipThreads * kChipMaxRpt) return DPCG_ERR_INVALID;
+    const int rpt = (d.per + kChipThreads - 1) / kChipThreads;
+    const bool jac = d.precond == DPCG_PRECOND_JACOBI;
+    const bool tr = d.dbg != nullptr;
+#define DPCG_CHIP_T(RPTV, WV, JV) (tr ? chip_launch<RPTV, WV, JV, true>(d, s, check_only) : chip_launch<RPTV, WV, JV, false>(d, s, check_only))
+#define DPCG_CHIP_W(RPTV, WV) (jac ? DPCG_CHIP_T(RPTV, WV, true) : DPCG_CHIP_T(RPTV, WV, false))
+#define DPCG_CHIP_R(RPTV) (max_row_len <= 5 ? DPCG_CHIP_W(RPTV, 5) : DPCG_CHIP_W(RPTV, 7))
+    if (rpt <= 2) return DPCG_CHIP_R(2);
+    if (rpt <= 4) return DPCG_CHIP_R(4);
+    return DPCG_CHIP_R(8);
+#undef DPCG_CHIP_R
+#undef DPCG_CHIP_W
+#undef DPCG_CHIP_T
+}
+
+}  // namespace dpcg

@@ -57,7 +57,8 @@ struct SpmvPlan {
     bool stream_nt = false;            // x-tile kernel: once-read streams and y non-temporal (streams beyond the Infinity Cache)
     bool tile_mixed = false;           // x-tile kernel: some blocks have no tile (tile_nchunks = -1) and gather instead
     int cyclic = 0;                    // x-tile kernel: row blocks dealt out cyclically (b, b + G, ...) instead of in slabs; 2: XCD runs inside a pass (see k_spmv_tile)
-    int max_row_len = 0;               // longest row (the team kernel keeps rows of <= 7 entries in registers)
+    int max_row_len = 0;               // longest row (the team / chip kernels keep rows of <= 7 entries on chip); systems of <= 1 048 576 rows
+    int max_band = -1;                 // largest |col - row| (the chip kernel keeps columns as 16-bit offsets from the row); -1: not measured
 };
 
 // Device-resident scalar state of one solve.  Only block 0 of a kernel writes it; everybody else
@@ -273,6 +274,9 @@ struct dpcg_system {
     void *team_desc = nullptr;               // device, one TeamDesc (single mid-size solves, dpcg_team.hip)
     double *team_part = nullptr;             // the team's reduction partials (4 x 32 doubles)
     unsigned int *team_sync = nullptr;       // [0] barrier counter, [1] error flag
+    double *chip_part = nullptr;             // the chip kernel's reduction slots (4 x 256 x 2 doubles) + 8 trace words + the error flag
+    double *chip_zp = nullptr;               // ... and its published granules (2 n doubles)
+    double chip_trace_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DPCG_CHIP_TRACE: us per update by phase of the last chip solve ([7] = updates)
     dpcg::SmallEll ell_a, ell_m, ell_t;      // slab-ELL copies of A, M (or L), L^T for the small-system kernel
     hipGraphExec_t graph_exec = nullptr;
     int graph_key = -1;
@@ -446,6 +450,27 @@ struct TeamDesc {
     unsigned long long *dbg;   // DPCG_TEAM_TRACE=1: 8 words, ticks (100 MHz) rank 0 spent per phase of the updates; else null
 };
 
+// dpcg_chip.hip: whole-solve kernel for cache-sized systems (65 537 .. 1 048 576 rows), the whole chip as one team
+struct ChipDesc {
+    int n, precond, max_iter, init_check_r, hist_cap, per;   // per = ceil(n / 256): rows per workgroup
+    const int32_t *rp, *ci;
+    const double *val, *dinv;
+    const double *b, *x0;
+    double *x, *hist;
+    double *zp;                // 2 n doubles: the granules {z_{k+1}[i], p_k[i]} as the other workgroups see them
+    double rtol_sq, atol_sq;
+    Scalars *out;
+    double *part;              // 4 sets x 256 x 2 doubles, all preset to the "pending" pattern at launch
+    int *err;
+    unsigned long long *dbg;   // DPCG_CHIP_TRACE=1: 8 words, ticks (100 MHz) workgroup 0 spent per phase of the updates; else null
+};
+int chip_max_rows();
+int chip_max_row_len();
+int chip_max_band();
+int chip_workgroups();
+int chip_threads();
+void launch_band_and_len(const CsrDev &A, int *out2_zeroed_dev, hipStream_t s);
+int launch_pcg_chip(const ChipDesc &d, int max_row_len, hipStream_t s, bool check_only = false);
 int team_max_rows();
 int team_max_row_len();
 int launch_pcg_team(const TeamDesc *descs_dev, int nsys, int max_slabs_per_wg, int max_row_len, hipStream_t s);

@@ -661,6 +661,128 @@ static int solve_team_one(dpcg_system *h, const double *b, const double *x0, dou
     return sc.status;
 }
 
+// ------------------------------------------------------------------------------------------------
+// cache-sized systems: the whole solve in one launch, the whole chip as one team (dpcg_chip.hip)
+// ------------------------------------------------------------------------------------------------
+// 65 537 .. 1 048 576 rows, rows of <= 7 entries, half-bandwidth < 32 768 (stencils; meshes after the library's RCM), M = I / Jacobi:
+// matrix and vectors stay in registers and LDS for the whole solve.  DPCG_CHIP=0 / DPCG_CHIP_MIN_ROWS: development knobs.
+static bool chip_eligible(const dpcg_system *h, int flags, const double *x_true) {
+    static const bool enabled = [] {
+        const char *e = getenv("DPCG_CHIP");
+        if (e && e[0] == '0') return false;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        return cus >= chip_workgroups();         // one workgroup per CU, all resident
+    }();
+    static const int min_rows = [] { const char *e = getenv("DPCG_CHIP_MIN_ROWS"); return e ? atoi(e) : team_max_rows(); }();
+    if (!enabled || x_true || (flags & (DPCG_SPMV_F32 | DPCG_NO_TEAM | DPCG_NO_FUSE | DPCG_VAL32_IF_LOSSLESS))) return false;
+    if (h->A.n <= min_rows || h->A.n > chip_max_rows()) return false;
+    if (h->planA.max_row_len < 1 || h->planA.max_row_len > chip_max_row_len()) return false;
+    if (h->planA.max_band < 0 || h->planA.max_band > chip_max_band()) return false;
+    return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI;
+}
+// a plain call takes it (DPCG_NO_SMALL = "no whole-solve kernel for one system" keeps the launches, as for the other two)
+static bool chip_default(const dpcg_system *h, int flags) {
+    (void)h;
+    return !(flags & (DPCG_NO_SMALL | DPCG_NO_GRAPH));
+}
+static int chip_rows_per_wg(int64_t n) { return (int)((n + chip_workgroups() - 1) / chip_workgroups()); }
+
+static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, double *x, double rtol_sq, double atol_sq,
+                          int max_iter, int flags, hipStream_t s, int *iters, double *final_res, double *seconds,
+                          double *res_history) {
+    const int64_t n = h->A.n;
+    DPCG_TRY(ensure_work(h, max_iter, false, false));
+    constexpr int kSlots = 4 * 256 * 2;                               // reduction slots (doubles), then 8 trace words, then the flag
+    if (!h->chip_part) DPCG_TRY(dev_alloc(&h->chip_part, kSlots + 8 + 2));
+    if (!h->chip_zp) DPCG_TRY(dev_alloc(&h->chip_zp, 2 * n));
+    if (h->perm) {                         // b and x0 arrive in the caller's numbering
+        if (!h->pb) DPCG_TRY(dev_alloc(&h->pb, n));
+        launch_gather_f64(n, h->perm, b, h->pb, s);
+        b = h->pb;
+        if (x0) {
+            launch_gather_f64(n, h->perm, x0, h->t, s);
+            x0 = h->t;
+        }
+    }
+    ChipDesc d;
+    memset(&d, 0, sizeof(d));
+    d.n = (int)n;
+    d.precond = h->precond;
+    d.max_iter = max_iter;
+    d.init_check_r = (flags & DPCG_INIT_CHECK_R) ? 1 : 0;
+    d.hist_cap = h->hist_cap;
+    d.per = chip_rows_per_wg(n);
+    d.rp = h->A.rowptr; d.ci = h->A.col; d.val = h->A.val; d.dinv = h->dinv;
+    d.b = b; d.x0 = x0;
+    d.x = (x && !h->perm) ? x : h->x;
+    d.hist = h->hist;
+    d.zp = h->chip_zp;
+    d.rtol_sq = rtol_sq; d.atol_sq = atol_sq;
+    d.out = h->scal;
+    d.part = h->chip_part;
+    d.err = reinterpret_cast<int *>(h->chip_part + kSlots + 8);
+    static const bool trace = [] { const char *e = getenv("DPCG_CHIP_TRACE"); return e && e[0] == '1'; }();
+    d.dbg = trace ? reinterpret_cast<unsigned long long *>(h->chip_part + kSlots) : nullptr;
+    const int st0 = launch_pcg_chip(d, h->planA.max_row_len, s, true);                // refused up front when it cannot be resident
+    if (st0 != DPCG_OK) return st0;
+    launch_fill_pending(h->chip_part, kSlots, s);                                     // every reduction slot: "not written yet"
+    DPCG_HIP(hipMemsetAsync(d.err, 0, 2 * sizeof(int), s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    // one whole-chip launch at a time per process (see solve_team_one)
+    std::lock_guard<std::mutex> one_team_launch(team_launch_mutex());
+    const auto t0 = std::chrono::steady_clock::now();                                // cg.py:69 (the launch is the loop)
+    DPCG_TRY(launch_pcg_chip(d, h->planA.max_row_len, s));
+    DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    const auto t1 = std::chrono::steady_clock::now();                                // cg.py:88
+    DPCG_CHECK_LAUNCH();
+    const Scalars sc = *h->scal_host;
+    if (sc.status < 0) {
+        set_error("chip solve: a workgroup waited (20 ms) for one that never became resident");
+        return sc.status;
+    }
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    if (iters) *iters = sc.k;
+    if (final_res) *final_res = sc.res;
+    if (d.dbg) {
+        unsigned long long w[8];
+        DPCG_HIP(hipMemcpy(w, d.dbg, sizeof(w), hipMemcpyDeviceToHost));
+        const double us = sc.k > 0 ? 0.01 / sc.k : 0.0;       // 100 MHz ticks -> us per update
+        for (int i = 0; i < 7; ++i) h->chip_trace_us[i] = w[i] * us;
+        h->chip_trace_us[7] = (double)sc.k;
+        static const bool print = [] { const char *e = getenv("DPCG_CHIP_TRACE_PRINT"); return e && e[0] == '1'; }();
+        if (print && sc.k > 0)
+            fprintf(stderr, "[dpcg chip] %d updates, us per update on workgroup 0: SpMV %.2f, sum <p,Ap> %.2f (of it waiting for the slots %.2f), "
+                    "vector update + publish %.2f, sum <r,z> %.2f (waiting %.2f), total %.2f\n", sc.k, w[0] * us, w[1] * us, w[5] * us,
+                    w[2] * us, w[3] * us, w[6] * us, w[4] * us);
+    }
+    bool pending = false;
+    if (res_history) {
+        DPCG_HIP(hipMemcpyAsync(res_history, h->hist, (size_t)(sc.k + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+        pending = true;
+    }
+    if (x && h->perm) launch_scatter_f64(n, h->perm, h->x, x, s);                    // back to the caller's numbering
+    if (pending) DPCG_HIP(hipStreamSynchronize(s));
+    return sc.status;
+}
+
+extern "C" int dpcg_get_chip_info(dpcg_handle_t h, int32_t out[8], double trace_us[8]) {
+    if (!h || !out) return invalid("dpcg_get_chip_info: NULL argument");
+    const bool el = chip_eligible(h, 0, nullptr);
+    out[0] = el ? (chip_default(h, 0) ? 2 : 1) : 0;          // 2: a plain dpcg_solve takes the chip kernel
+    out[1] = chip_workgroups();
+    out[2] = chip_threads();
+    out[3] = chip_rows_per_wg(h->A.n);
+    out[4] = h->planA.max_row_len;
+    out[5] = h->planA.max_band;
+    out[6] = out[7] = 0;
+    if (trace_us)
+        for (int i = 0; i < 8; ++i) trace_us[i] = h->chip_trace_us[i];
+    return DPCG_OK;
+}
+
 static int check_solve_args(dpcg_handle_t h, const double *b, int max_iter, int flags, const double *x_true,
                             double *err_history) {
     if (!h || !b) return invalid("dpcg_solve: NULL handle or b");
@@ -687,6 +809,13 @@ extern "C" int dpcg_solve(dpcg_handle_t h, const double *b, const double *x0, do
                                       seconds, res_history);
         if (st != DPCG_ERR_STATE) return st;
         // the team never became co-resident (a plain launch assumes it): the multi-launch path below needs no such thing
+    }
+    // cache-sized systems on the whole chip
+    if (chip_eligible(h, flags, x_true) && ((flags & DPCG_TEAM) || chip_default(h, flags))) {
+        const int st = solve_chip_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
+                                      seconds, res_history);
+        if (st != DPCG_ERR_STATE) return st;
+        // the workgroups never became co-resident, or the kernel was refused up front: the multi-launch path needs no such thing
     }
     Solve sv;
     sv.h = h;

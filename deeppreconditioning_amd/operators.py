@@ -521,6 +521,17 @@ class CsrSystem:
                 "m_tpr": (out[11] >> 8) & 255, "mt_tpr": (out[11] >> 16) & 255, "sweep_grid": out[13],
                 "sweep_modes": [(out[14] >> (2 * k)) & 3 for k in range(out[12])], "sweep_paired": bool(out[15])}
 
+    def chip_info(self) -> dict:
+        """The whole-chip solve of cache-sized systems (dpcg_get_chip_info): eligibility, the geometry a checker needs to add the dot
+        products in the kernel's order, and -- with DPCG_CHIP_TRACE=1 -- microseconds per update by phase of the last such solve."""
+        out = (C.c_int32 * 8)()
+        tr = (C.c_double * 8)()
+        L.check(L.lib().dpcg_get_chip_info(self._h, out, tr))
+        return {"chip_eligible": bool(out[0]), "chip_by_default": out[0] == 2, "workgroups": out[1], "threads": out[2],
+                "rows_per_workgroup": out[3], "max_row_len": out[4], "max_band": out[5],
+                "trace_us": {"spmv": tr[0], "sum_pq": tr[1], "update_publish": tr[2], "sum_rz_rr": tr[3], "loop": tr[4],
+                             "wait_pq": tr[5], "wait_rz": tr[6], "updates": int(tr[7])}}
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
             L.lib().dpcg_destroy(self._h)

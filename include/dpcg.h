@@ -198,6 +198,17 @@ int dpcg_set_precond_callback(dpcg_handle_t h, dpcg_precond_fn fn, void *user);
  * blocks: 0 its slab by virtual block, 1 blocks b, b + G, ..., 2 the same by virtual block), out[15] = 1 when the first of them is the
  * lower solve's last launch --, 9 a tree the checker does not restate: more than 16 sweeps). */
 int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]);
+/* The whole-chip solve (dpcg_chip.hip: 65 537 .. 1 048 576 rows, rows of <= 7 entries, half-bandwidth < 32 768, M = I / Jacobi -- matrix
+ * and vectors stay in registers and LDS for the whole solve, cg.py:58-90 in ONE launch of 256 workgroups).  out[0] = 1 when the
+ * system with its CURRENT preconditioner is eligible (2: and a plain dpcg_solve takes that form), out[1] = workgroups (256),
+ * out[2] = threads of each (512), out[3] = rows per workgroup (ceil(n / 256): workgroup v owns rows v * out[3] .., thread t of it
+ * rows v * out[3] + t + 512 k -- what a checker needs to add the dot products in the kernel's order), out[4] = longest row,
+ * out[5] = largest |col - row| (-1: not measured, systems beyond 1 048 576 rows).  trace_us (may be NULL): with DPCG_CHIP_TRACE=1 in
+ * the environment, microseconds per update that workgroup 0 spent in the phases of the last chip solve -- [0] q = A p (the SpMV
+ * phase), [1] sum <p,Ap> incl. its barrier, [2] vector updates + publishing, [3] sum <r,z>, <r,r> incl. its barrier, [4] the whole
+ * loop, [5] / [6] of [1] / [3]: waiting for the other workgroups' slots, [7] = the number of updates.  No reference counterpart
+ * (the reference's loop is host Python, cg.py:70-87). */
+int dpcg_get_chip_info(dpcg_handle_t h, int32_t out[8], double trace_us[8]);
 /* Copy the current factor L out (host arrays sized from dpcg_get_info's precond_nnz). */
 int dpcg_get_factor(dpcg_handle_t h, int32_t *rowptr, int32_t *col, double *val);
 
