@@ -14,18 +14,27 @@
 //     conflict-free private columns [slot][t]) and, beyond that, to registers; the columns are kept as 16-bit offsets from the row
 //     (col - row + 32768: the handle's matrix must have a half-bandwidth below 32 768 -- stencils and RCM-ordered meshes do),
 //     two to a register.  x, r, p, q, dinv of the own rows live in registers for the whole solve.
-//   * what the other workgroups need of an update is PUBLISHED as 16-byte granules {z_{k+1}[i], p_k[i]} (one write-through store
-//     per row and update); a row gathers one granule per entry and recomputes p_{k+1}[c] = z_{k+1}[c] + beta p_k[c] -- the owner's
+//   * what the other workgroups need of an update is PUBLISHED as 16-byte granules {z_{k+1}[i], p_k[i]} (one store per row and
+//     update); a row gathers one granule per entry and recomputes p_{k+1}[c] = z_{k+1}[c] + beta p_k[c] -- the owner's
 //     expression, and with contraction off the owner's bits (cg.py:83) -- so that publishing needs no barrier of its own.
-//   * TWO chip-wide reductions per update (<p,Ap> | <r,z>, <r,r>), which double as the barriers: a workgroup's partial pair is ONE
-//     16-byte write-through store into its slot of the current slot set (256 x 16 B), which held a reserved NaN pattern; wave 0 of
-//     every workgroup polls the 256 slots (4 per lane, coalesced 1-KiB loads) until none is pending and sums them in ONE fixed
-//     tree -- lane l: ((s[l] + s[l+64]) + s[l+128]) + s[l+192], then the wave's DPP tree -- so all workgroups hold bit-identical
-//     alpha / beta and take the decision of cg.py:71 identically, with no broadcast.  Four slot sets rotate, a workgroup re-arms
-//     the set two generations ahead behind a drain (dpcg_team.hip explains why two).
-//   * every store another workgroup reads is an agent-scope (sc1, write-through) store, every load of such data an sc1 load that
-//     bypasses the CU's L1, and every wave drains its stores before its workgroup signals: correct for ANY placement of the
-//     workgroups (MI355X_MICROARCH.md, "Valid forms").
+//   * TWO chip-wide reductions per update (<p,Ap> | <r,z>, <r,r>), which double as the barriers, in two hops: the 32 workgroups of a
+//     GROUP (equal blockIdx % 8: one XCD under the usual round-robin placement) exchange their partial pairs through 16-byte slots
+//     that held a reserved NaN pattern -- one store each, wave 0 of every workgroup polls the group's 32 slots -- and sum them in
+//     one fixed tree; eight members of each group then hand the group's pair to the eight groups (one 128-byte line of eight slots
+//     per destination group, polled by that group's 32 workgroups only: a flat exchange had all 256 CUs polling the same 32 lines
+//     and cost 4 us a barrier).  Every workgroup adds the same values in the same order: bit-identical alpha / beta everywhere,
+//     the decision of cg.py:71 taken identically, no broadcast.  Four slot sets rotate, a slot is re-armed two generations ahead
+//     behind a drain (dpcg_team.hip explains why two).
+//   * VISIBILITY.  Data another workgroup reads is stored with agent scope (sc1: written through to the memory side) and loaded
+//     with sc1 loads that bypass the CU's L1, every wave drains its stores before its workgroup signals -- correct for ANY
+//     placement (MI355X_MICROARCH.md, "Valid forms").  Written through, however, a line leaves the L2, and every one of the
+//     seven gathers of a granule then travels to the memory side: 117 MB per update, 25-30 us.  So each workgroup reports its XCD
+//     (XCC_ID) once per solve, and when every group does sit on one XCD the granules are kept TWICE: a copy stored plainly -- it
+//     stays in the XCD's shared L2, complete there once the storing wave's vmcnt has drained, where the group's sc1 loads hit
+//     it -- and, only for the rows within the matrix's bandwidth of the group's first and last row, a written-through copy for the
+//     neighbouring groups.  A gather takes the plain copy when the column belongs to the own group, the other one otherwise; the
+//     group-level slots are stored plainly too.  Any other placement keeps everything written through.  (A stale line anywhere
+//     would change the residual history, which the tests compare bit for bit with the CPU restatement over 1.3e9 gathers a solve.)
 //   * co-residency is checked up front (occupancy query x CUs >= 256) and every wait is bounded (20 ms): a launch whose workgroups
 //     cannot all become resident (another process's kernel holding CUs) reports DPCG_ERR_STATE and the caller solves through the
 //     multi-launch path instead.
@@ -45,6 +54,9 @@ constexpr int kChipMaxRpt = 8;          // rows per thread: n <= 256 * 512 * 8
 constexpr int kChipLdsSlots = 39;       // 8-byte value slots per thread kept in LDS: 39 * 512 * 8 = 159 744 B of the CU's 163 840
 constexpr unsigned long long kChipSpinTicks = 2000000ull;               // 20 ms of the 100 MHz constant clock
 constexpr unsigned long long kChipPending = 0x7ff8dead0badbeefULL;      // a quiet NaN that no arithmetic here produces
+constexpr int kChipZpPad = 4096;        // granules of slack behind each copy (group shifts; rows that do not exist gather there)
+constexpr int kChipS1Bytes = 4 * kChipWGs * 16;                // group-level slots: 4 sets x 256 workgroups x 16 B
+constexpr int kChipSlotBytes = kChipS1Bytes + 4 * 8 * 8 * 16;  // + chip-level slots: 4 sets x 8 destination groups x 8 source groups
 constexpr int kSc1 = 16;                // cache-policy operand of the buffer builtins on gfx950: bit 4 = sc1 (agent scope)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -81,8 +93,14 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     const int t = threadIdx.x;
     const int v = ((int)blockIdx.x & 7) * (kChipWGs / 8) + ((int)blockIdx.x >> 3);
     const int row0 = v * d.per + t;        // row of slot k: row0 + 512 k
-    const __amdgpu_buffer_rsrc_t zp_rs = chip_rsrc(d.zp, (unsigned)d.n * 16u);
-    const __amdgpu_buffer_rsrc_t part_rs = chip_rsrc(d.part, 4u * kChipWGs * 16u);
+    const int grp = (int)blockIdx.x & 7, rank = (int)blockIdx.x >> 3;       // v = 32 grp + rank
+    const int glo = grp * (kChipWGs / 8) * d.per;                           // the group's rows: [glo, ghi)
+    const int ghi = (glo + (kChipWGs / 8) * d.per < d.n) ? glo + (kChipWGs / 8) * d.per : d.n;
+    // the granules: a plainly stored copy (read inside the group; group g's part shifted by 128 g bytes so that no line belongs to
+    // two groups) and a written-through copy behind it (see the header)
+    const int remote_base = (d.n + kChipZpPad) * 16;
+    const __amdgpu_buffer_rsrc_t zp_rs = chip_rsrc(d.zp, 2u * (unsigned)(d.n + kChipZpPad) * 16u);
+    const __amdgpu_buffer_rsrc_t part_rs = chip_rsrc(d.part, (unsigned)kChipSlotBytes);
 
     // ---- the matrix slice and the vectors of the own rows: read once ------------------------------------------------------
     double vr[NREG > 0 ? NREG : 1];
@@ -136,6 +154,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    bool local = false;                     // every group on one XCD (established below, once per solve)
     auto row_on = [&](int k) -> bool { return ((lens >> (4 * k)) & 8u) != 0; };
 
     // q = A p_{k} for the own rows; the gathered entries of p_k are recomputed from the published granules {z_k, p_{k-1}}.
@@ -148,6 +167,9 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         int tl = t;
         asm volatile("" : "+v"(tl));
         const double *lvt = chip_lv + tl;
+        int glo_l = glo, span_l = local ? ghi - glo : 0;
+        const int local_shift = grp * 128;
+        asm volatile("" : "+s"(glo_l), "+s"(span_l));            // (and the 56 `own` lane masks)
         // (likewise the gather addresses: they are loop-invariant too, and 56 hoisted addresses are 56 registers)
 #pragma unroll
         for (int e = 0; e < (NS + 1) / 2; ++e) asm volatile("" : "+v"(dl[e]));
@@ -159,7 +181,8 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
                 const int s = k * WMAX + j;
                 const int del = (int)((dl[s >> 1] >> (16 * (s & 1))) & 0xffffu);
                 const int c = rowk + del - 32768;
-                gk[j] = __builtin_amdgcn_raw_buffer_load_b128(zp_rs, c * 16, 0, kSc1);   // (a row that does not exist: out of range, zeros)
+                const bool own = (unsigned)(c - glo_l) < (unsigned)span_l;              // the column's owner is in this group: the plain copy
+                gk[j] = __builtin_amdgcn_raw_buffer_load_b128(zp_rs, c * 16 + (own ? local_shift : remote_base), 0, kSc1);
             }
         };
         request(0, g[0]);
@@ -185,8 +208,41 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     // must be visible to whoever passes this point, so every wave drains them first.  Every workgroup returns the same bits.
     unsigned gen = 0;
     int sum_phase = 0;
-    const bool timed = TRACE && d.dbg != nullptr && v == 0 && t == 0;      // DPCG_CHIP_TRACE: where an update's time goes (ticks of workgroup 0)
-    unsigned long long tk_wait = 0;
+    // DPCG_CHIP_TRACE: where an update's time goes -- ticks (100 MHz) of thread 0 of EVERY workgroup, accumulated in LDS (registers
+    // are what this kernel does not have): [0] q = A p, [1] sum <p,Ap>, [2] vector update + publish, [3] sum <r,z>, [4] the loop,
+    // [5] / [6] of [1] / [3] waiting for slots, [7] last stamp
+    __shared__ unsigned long long s_tk[8];
+    const bool timed = TRACE && d.dbg != nullptr && t == 0;
+    if (TRACE && t < 8) s_tk[t] = 0;
+    auto stamp = [&](int idx) {             // adds the time since the previous stamp to phase idx (idx < 0: only restarts the clock)
+        if (timed) {
+            const unsigned long long now = wall_clock64();
+            if (idx >= 0) s_tk[idx] += now - s_tk[7];
+            s_tk[7] = now;
+        }
+    };
+    int wait_idx = 5;
+    // polls one slot per lane (lanes < count) until none is pending; false when the wait ran out
+    auto poll_slots = [&](u32x4 &sv, int off, int count) -> bool {
+        const bool mine = t < count;
+        sv = pack_f64x2(0.0, 0.0);
+        if (mine) sv = __builtin_amdgcn_raw_buffer_load_b128(part_rs, off, 0, kSc1);
+        unsigned spins = 0;
+        unsigned long long t0 = 0;
+        while (__ballot(mine && is_pending(sv)) != 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (mine && is_pending(sv)) sv = __builtin_amdgcn_raw_buffer_load_b128(part_rs, off, 0, kSc1);
+            if ((++spins & 255u) == 0) {
+                const unsigned long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > kChipSpinTicks || __hip_atomic_load(d.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    atomicExch(d.err, 1);
+                    return false;
+                }
+            }
+        }
+        return true;
+    };
     auto chip_sum2 = [&](double a, double b2, bool publish, double &ra, double &rb) -> bool {
         if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         double *slot = sh + (sum_phase & 1) * 16;
@@ -198,10 +254,15 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
             slot[8 + (t >> 6)] = b2;
         }
         __syncthreads();                                           // (behind every wave's drain)
-        const int cur = (int)(gen & 3u) * kChipWGs * 16, nxt = (int)((gen + 2u) & 3u) * kChipWGs * 16;
+        const int set_cur = (int)(gen & 3u), set_nxt = (int)((gen + 2u) & 3u);
         double *const sres = s_res[gen & 1u];
         ++gen;
-        if (t < 64) {                                              // wave 0 publishes the workgroup's pair and polls everybody's
+        if (t < 64) {                                              // wave 0 does the exchange
+            const unsigned plo = (unsigned)(kChipPending & 0xffffffffu), phi = (unsigned)(kChipPending >> 32);
+            u32x4 pend;
+            pend.x = plo; pend.y = phi; pend.z = plo; pend.w = phi;
+            const unsigned long long w0 = timed ? wall_clock64() : 0;
+            // hop 1: the group's 32 pairs
             if (t == 0) {
                 double sa = 0.0, sb = 0.0;
 #pragma unroll
@@ -209,44 +270,29 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
                     sa += slot[w];
                     sb += slot[8 + w];
                 }
-                const unsigned plo = (unsigned)(kChipPending & 0xffffffffu), phi = (unsigned)(kChipPending >> 32);
-                u32x4 pend;
-                pend.x = plo; pend.y = phi; pend.z = plo; pend.w = phi;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-arm of the previous generation has landed
-                __builtin_amdgcn_raw_buffer_store_b128(pend, part_rs, nxt + v * 16, 0, kSc1);
-                __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2(sa, sb), part_rs, cur + v * 16, 0, kSc1);
-            }
-            const unsigned long long w0 = timed ? wall_clock64() : 0;
-            u32x4 s4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) s4[u] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, cur + (t + 64 * u) * 16, 0, kSc1);
-            unsigned spins = 0;
-            unsigned long long t0 = 0;
-            int ok = 1;
-            for (;;) {
-                bool pend_any = false;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) pend_any = pend_any || is_pending(s4[u]);
-                if (__ballot(pend_any) == 0) break;
-                __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (is_pending(s4[u])) s4[u] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, cur + (t + 64 * u) * 16, 0, kSc1);
-                if ((++spins & 255u) == 0) {
-                    const unsigned long long now = wall_clock64();
-                    if (t0 == 0) t0 = now;
-                    else if (now - t0 > kChipSpinTicks || __hip_atomic_load(d.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        atomicExch(d.err, 1);
-                        ok = 0;
-                        break;
-                    }
+                const int o_n = (set_nxt * kChipWGs + v) * 16, o_c = (set_cur * kChipWGs + v) * 16;
+                if (local) {
+                    __builtin_amdgcn_raw_buffer_store_b128(pend, part_rs, o_n, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2(sa, sb), part_rs, o_c, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(pend, part_rs, o_n, 0, kSc1);
+                    __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2(sa, sb), part_rs, o_c, 0, kSc1);
                 }
             }
-            if (timed) tk_wait += wall_clock64() - w0;
-            double ta = ((lo_f64(s4[0]) + lo_f64(s4[1])) + lo_f64(s4[2])) + lo_f64(s4[3]);
-            double tb = ((hi_f64(s4[0]) + hi_f64(s4[1])) + hi_f64(s4[2])) + hi_f64(s4[3]);
-            ta = wave_sum(ta);
-            tb = wave_sum(tb);
+            u32x4 sv;
+            int ok = poll_slots(sv, (set_cur * kChipWGs + grp * 32 + t) * 16, 32) ? 1 : 0;
+            double ga = wave_sum(lo_f64(sv)), gb = wave_sum(hi_f64(sv));        // (lanes 32-63 add +0.0)
+            // hop 2: eight members of the group hand its pair to the eight groups, everybody sums the eight pairs of its group's line
+            if (t == 63 && rank < 8) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int o_n = kChipS1Bytes + ((set_nxt * 8 + rank) * 8 + grp) * 16, o_c = kChipS1Bytes + ((set_cur * 8 + rank) * 8 + grp) * 16;
+                __builtin_amdgcn_raw_buffer_store_b128(pend, part_rs, o_n, 0, kSc1);
+                __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2(ga, gb), part_rs, o_c, 0, kSc1);
+            }
+            if (ok) ok = poll_slots(sv, kChipS1Bytes + ((set_cur * 8 + grp) * 8 + t) * 16, 8) ? 1 : 0;
+            if (timed) s_tk[wait_idx] += wall_clock64() - w0;
+            const double ta = wave_sum(lo_f64(sv)), tb = wave_sum(hi_f64(sv));  // (lanes 8-63 add +0.0)
             if (t == 63) {
                 sres[0] = ta;
                 sres[1] = tb;
@@ -259,13 +305,44 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         rb = sres[1];
         return true;       // (sres is written again two reductions on, behind the barriers of the next one)
     };
+    unsigned far_rows = 0xffu;              // bit k: row k of this thread is gathered by another group (all of them until `local` holds)
+    int row0_l = row0;                      // an opaque copy per update: 16 hoisted store addresses are 16 registers the loop does not have
     auto publish = [&](int k, double zk, double pk) {
-        __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2(zk, pk), zp_rs, (row0 + k * kChipThreads) * 16, 0, kSc1);
+        const int o = (row0_l + k * kChipThreads) * 16;
+        if (local) __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2(zk, pk), zp_rs, o + grp * 128, 0, 0);
+        if ((far_rows >> k) & 1u) __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2(zk, pk), zp_rs, o + remote_base, 0, kSc1);
     };
 
-    // ---- cg.py:58-67 -------------------------------------------------------------------------------------------------
     bool alive = true;
     double dummy = 0.0, dummy2 = 0.0;
+    // ---- where the groups sit: every workgroup reports its XCD, everybody reads the 256 answers ---------------------------
+    if (d.xcc) {
+        if (t == 0) {
+            unsigned xid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
+            __hip_atomic_store(d.xcc + v, (int)(xid & 0xf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        alive = chip_sum2(0.0, 0.0, true, dummy, dummy2);
+        if (alive) {
+            int same = 1;
+            if (t < kChipWGs) {
+                const int mine = __hip_atomic_load(d.xcc + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int first = __hip_atomic_load(d.xcc + (t & ~31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                same = mine == first ? 1 : 0;
+            }
+            local = __syncthreads_and(same) != 0;
+        }
+        if (local) {
+            far_rows = 0;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int i = row0 + k * kChipThreads;
+                if (i < glo + d.band || i >= ghi - d.band) far_rows |= 1u << k;
+            }
+        }
+    }
+
+    // ---- cg.py:58-67 -------------------------------------------------------------------------------------------------
     if (d.x0) {                                                   // r = b - A x0 (cg.py:60): x0 published as "z", beta = 0
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
@@ -302,24 +379,28 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         else if (!(res == res)) { stop = true; status = DPCG_BREAKDOWN; }
     }
     // ---- cg.py:70-87: two chip barriers per update -----------------------------------------------------------------------
-    unsigned long long tk[4] = {0, 0, 0, 0};
+    if (TRACE) {
+        __syncthreads();
+        if (t < 8) s_tk[t] = 0;
+        __syncthreads();
+    }
     const unsigned long long tk_start = timed ? wall_clock64() : 0;
-    unsigned long long tk_wait_a = 0;
-    tk_wait = 0;
+    stamp(-1);
     while (alive && !stop && k_done < d.max_iter) {
-        unsigned long long c0 = timed ? wall_clock64() : 0;
         spmv(beta);                                               // cg.py:75
         double pq_loc = 0.0;
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
             if (row_on(k)) pq_loc += q[k] * p[k];
         double pq = 0.0;
-        if (timed) { const unsigned long long c1 = wall_clock64(); tk[0] += c1 - c0; c0 = c1; }
-        const unsigned long long wa0 = tk_wait;
+        stamp(0);
+        wait_idx = 5;
         if (!(alive = chip_sum2(pq_loc, 0.0, false, pq, dummy))) break;         // barrier A: every SpMV of this update is done
-        if (timed) { const unsigned long long c1 = wall_clock64(); tk[1] += c1 - c0; c0 = c1; tk_wait_a += tk_wait - wa0; }
+        stamp(1);
+        wait_idx = 6;
         const double alpha = rz / pq;                             // cg.py:78
         double rz_new_loc = 0.0, rr_loc = 0.0;
+        asm volatile("" : "+v"(row0_l), "+v"(far_rows));
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             x[k] = x[k] + alpha * p[k];                           // cg.py:79
@@ -332,9 +413,9 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
             }
         }
         double rz_new = 0.0, rr = 0.0;
-        if (timed) { const unsigned long long c1 = wall_clock64(); tk[2] += c1 - c0; c0 = c1; }
+        stamp(2);
         if (!(alive = chip_sum2(rz_new_loc, rr_loc, true, rz_new, rr))) break;  // barrier B: granules published, <r,z>, <r,r> known
-        if (timed) tk[3] += wall_clock64() - c0;
+        stamp(3);
         beta = rz_new / rz;                                       // cg.py:82
 #pragma unroll
         for (int k = 0; k < RPT; ++k) p[k] = (JAC ? dv[JAC ? k : 0] * r[k] : r[k]) + beta * p[k];   // cg.py:83 (z recomputed: the same product, the same bits)
@@ -349,9 +430,10 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
         if (row_on(k)) d.x[row0 + k * kChipThreads] = x[k];
-    if (timed) {
-        d.dbg[0] = tk[0]; d.dbg[1] = tk[1]; d.dbg[2] = tk[2]; d.dbg[3] = tk[3]; d.dbg[4] = wall_clock64() - tk_start;
-        d.dbg[5] = tk_wait_a; d.dbg[6] = tk_wait - tk_wait_a; d.dbg[7] = (unsigned long long)k_done;
+    if (timed) {                            // eight words per workgroup: [4] the loop, [7] (workgroup 0) `local` in bit 0
+        unsigned long long *o = d.dbg + 8 * v;
+        o[0] = s_tk[0]; o[1] = s_tk[1]; o[2] = s_tk[2]; o[3] = s_tk[3]; o[4] = wall_clock64() - tk_start;
+        o[5] = s_tk[5]; o[6] = s_tk[6]; o[7] = local ? 1ull : 0ull;
     }
     if (v == 0 && t == 0) {
         Scalars *sc = d.out;
@@ -416,6 +498,8 @@ int chip_max_row_len() { return 7; }
 int chip_max_band() { return 32767; }
 int chip_workgroups() { return kChipWGs; }
 int chip_threads() { return kChipThreads; }
+int chip_slot_doubles() { return kChipSlotBytes / 8; }
+int64_t chip_zp_doubles(int64_t n) { return 4 * (n + kChipZpPad); }
 
 void launch_band_and_len(const CsrDev &A, int *out2_zeroed_dev, hipStream_t s) {
     int64_t g = (A.n + kBlock - 1) / kBlock;

@@ -276,6 +276,7 @@ struct dpcg_system {
     unsigned int *team_sync = nullptr;       // [0] barrier counter, [1] error flag
     double *chip_part = nullptr;             // the chip kernel's reduction slots (4 x 256 x 2 doubles) + 8 trace words + the error flag
     double *chip_zp = nullptr;               // ... and its published granules (2 n doubles)
+    double chip_trace_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // ... over the 256 workgroups: SpMV phase max / mean, publish max / mean, `local`
     double chip_trace_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DPCG_CHIP_TRACE: us per update by phase of the last chip solve ([7] = updates)
     dpcg::SmallEll ell_a, ell_m, ell_t;      // slab-ELL copies of A, M (or L), L^T for the small-system kernel
     hipGraphExec_t graph_exec = nullptr;
@@ -457,18 +458,22 @@ struct ChipDesc {
     const double *val, *dinv;
     const double *b, *x0;
     double *x, *hist;
-    double *zp;                // 2 n doubles: the granules {z_{k+1}[i], p_k[i]} as the other workgroups see them
+    double *zp;                // 2 x (n + 4096) granules {z_{k+1}[i], p_k[i]}: the copy read inside a group and the written-through one
+    int band;                  // largest |col - row| of the matrix
+    int *xcc;                  // 256 words: the XCD every workgroup found itself on (exchanged once per solve); null: never store plainly
     double rtol_sq, atol_sq;
     Scalars *out;
-    double *part;              // 4 sets x 256 x 2 doubles, all preset to the "pending" pattern at launch
+    double *part;              // chip_slot_doubles() doubles, all preset to the "pending" pattern at launch
     int *err;
-    unsigned long long *dbg;   // DPCG_CHIP_TRACE=1: 8 words, ticks (100 MHz) workgroup 0 spent per phase of the updates; else null
+    unsigned long long *dbg;   // DPCG_CHIP_TRACE=1: 8 words per workgroup, ticks (100 MHz) its thread 0 spent per phase of the updates; else null
 };
 int chip_max_rows();
 int chip_max_row_len();
 int chip_max_band();
 int chip_workgroups();
 int chip_threads();
+int chip_slot_doubles();          // reduction slots (doubles) of a chip solve
+int64_t chip_zp_doubles(int64_t n);  // granule storage (doubles) of a chip solve
 void launch_band_and_len(const CsrDev &A, int *out2_zeroed_dev, hipStream_t s);
 int launch_pcg_chip(const ChipDesc &d, int max_row_len, hipStream_t s, bool check_only = false);
 int team_max_rows();

@@ -694,9 +694,9 @@ static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, dou
                           double *res_history) {
     const int64_t n = h->A.n;
     DPCG_TRY(ensure_work(h, max_iter, false, false));
-    constexpr int kSlots = 4 * 256 * 2;                               // reduction slots (doubles), then 8 trace words, then the flag
-    if (!h->chip_part) DPCG_TRY(dev_alloc(&h->chip_part, kSlots + 8 + 2));
-    if (!h->chip_zp) DPCG_TRY(dev_alloc(&h->chip_zp, 2 * n));
+    const int kSlots = chip_slot_doubles();                           // reduction slots (doubles), then 8 trace words, the flag, 256 XCD ids
+    if (!h->chip_part) DPCG_TRY(dev_alloc(&h->chip_part, kSlots + 8 * 256 + 2 + 128));      // slots | trace words | flag | XCD ids
+    if (!h->chip_zp) DPCG_TRY(dev_alloc(&h->chip_zp, chip_zp_doubles(n)));
     if (h->perm) {                         // b and x0 arrive in the caller's numbering
         if (!h->pb) DPCG_TRY(dev_alloc(&h->pb, n));
         launch_gather_f64(n, h->perm, b, h->pb, s);
@@ -722,7 +722,10 @@ static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, dou
     d.rtol_sq = rtol_sq; d.atol_sq = atol_sq;
     d.out = h->scal;
     d.part = h->chip_part;
-    d.err = reinterpret_cast<int *>(h->chip_part + kSlots + 8);
+    d.err = reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256);
+    d.band = h->planA.max_band;
+    static const bool plain_ok = [] { const char *e = getenv("DPCG_CHIP_LOCAL"); return !(e && e[0] == '0'); }();   // development: 0 = everything written through
+    d.xcc = plain_ok ? reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256 + 2) : nullptr;
     static const bool trace = [] { const char *e = getenv("DPCG_CHIP_TRACE"); return e && e[0] == '1'; }();
     d.dbg = trace ? reinterpret_cast<unsigned long long *>(h->chip_part + kSlots) : nullptr;
     const int st0 = launch_pcg_chip(d, h->planA.max_row_len, s, true);                // refused up front when it cannot be resident
@@ -747,16 +750,29 @@ static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, dou
     if (iters) *iters = sc.k;
     if (final_res) *final_res = sc.res;
     if (d.dbg) {
-        unsigned long long w[8];
-        DPCG_HIP(hipMemcpy(w, d.dbg, sizeof(w), hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> w(8 * 256);
+        DPCG_HIP(hipMemcpy(w.data(), d.dbg, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         const double us = sc.k > 0 ? 0.01 / sc.k : 0.0;       // 100 MHz ticks -> us per update
-        for (int i = 0; i < 7; ++i) h->chip_trace_us[i] = w[i] * us;
+        for (int i = 0; i < 7; ++i) h->chip_trace_us[i] = w[i] * us;                 // workgroup 0
         h->chip_trace_us[7] = (double)sc.k;
+        // over the 256 workgroups: the slowest and the mean SpMV phase, the slowest publish phase
+        double sp_max = 0, sp_sum = 0, pb_max = 0, pb_sum = 0;
+        for (int g = 0; g < 256; ++g) {
+            sp_max = std::max(sp_max, w[8 * g] * us); sp_sum += w[8 * g] * us;
+            pb_max = std::max(pb_max, w[8 * g + 2] * us); pb_sum += w[8 * g + 2] * us;
+        }
+        h->chip_trace_x[0] = sp_max; h->chip_trace_x[1] = sp_sum / 256; h->chip_trace_x[2] = pb_max; h->chip_trace_x[3] = pb_sum / 256;
+        h->chip_trace_x[4] = (double)(w[7] & 1ull);
         static const bool print = [] { const char *e = getenv("DPCG_CHIP_TRACE_PRINT"); return e && e[0] == '1'; }();
-        if (print && sc.k > 0)
-            fprintf(stderr, "[dpcg chip] %d updates, us per update on workgroup 0: SpMV %.2f, sum <p,Ap> %.2f (of it waiting for the slots %.2f), "
-                    "vector update + publish %.2f, sum <r,z> %.2f (waiting %.2f), total %.2f\n", sc.k, w[0] * us, w[1] * us, w[5] * us,
-                    w[2] * us, w[3] * us, w[6] * us, w[4] * us);
+        if (print && sc.k > 0) {
+            fprintf(stderr, "[dpcg chip] %d updates, groups on one XCD each: %d; us per update on workgroup 0: SpMV %.2f, sum <p,Ap> %.2f (of it waiting for the slots %.2f), "
+                    "vector update + publish %.2f, sum <r,z> %.2f (waiting %.2f), total %.2f; SpMV phase over the workgroups: mean %.2f max %.2f; publish: mean %.2f max %.2f\n",
+                    sc.k, (int)(w[7] & 1ull), w[0] * us, w[1] * us, w[5] * us, w[2] * us, w[3] * us, w[6] * us, w[4] * us, sp_sum / 256, sp_max, pb_sum / 256, pb_max);
+            if (getenv("DPCG_CHIP_TRACE_ALL")) {
+                for (int g = 0; g < 256; ++g) fprintf(stderr, "%s%.1f/%.1f", g % 32 ? " " : "\n   ", w[8 * g] * us, w[8 * g + 2] * us);
+                fprintf(stderr, "\n");
+            }
+        }
     }
     bool pending = false;
     if (res_history) {
@@ -777,9 +793,10 @@ extern "C" int dpcg_get_chip_info(dpcg_handle_t h, int32_t out[8], double trace_
     out[3] = chip_rows_per_wg(h->A.n);
     out[4] = h->planA.max_row_len;
     out[5] = h->planA.max_band;
-    out[6] = out[7] = 0;
     if (trace_us)
         for (int i = 0; i < 8; ++i) trace_us[i] = h->chip_trace_us[i];
+    out[6] = (int)h->chip_trace_x[4];                       // the last traced chip solve kept plainly stored copies (every group on one XCD)
+    out[7] = (int)(h->chip_trace_x[0] * 1000.0);            // ... and its slowest workgroup's SpMV phase, ns per update
     return DPCG_OK;
 }
 
