@@ -87,6 +87,56 @@ def time_apply(system, b, torch, reps: int = 20) -> float:
     return (time.perf_counter() - t0) / reps * 1e6
 
 
+def chip_roofline(system, b, check, k1: dict, traffic) -> dict:
+    """`roofline` object when the timed solve is the whole-chip kernel (dpcg_chip.hip: cg.py:58-90 in ONE launch, matrix and vectors
+    resident in LDS / registers).  `achieved` = ALGORITHMIC bytes of the launch -- updates x (B_spmv + 76 n), the accounting of the
+    multi-launch update it replaces -- over the kernel's duration between HIP events on its stream.  The bytes are
+    algorithmic: they are served on chip, so `frac` > 1 says that the solve no longer moves them, not that HBM got faster; `traffic`
+    (PMC) is what crossed the memory-side interface.  `spmv_phase`: the same kernel WITHOUT its gathers (development mode
+    DPCG_CHIP_BENCH: q = p, the loop runs the same number of updates) -- the difference is what q = A p costs per update."""
+    n, nnz = system.n, system.nnz
+    its = check.iterations
+    os.environ["DPCG_CHIP_EVENTS"] = "1"
+    try:
+        full = []
+        for _ in range(12):
+            r = system.solve(b, want_history=False)
+            assert r.iterations == its
+            full.append(system.chip_info()["kernel_ms"])
+        os.environ["DPCG_CHIP_BENCH"] = "1"
+        skip = []
+        for _ in range(12):
+            system.solve(b, max_iter=its, want_history=False)
+            skip.append(system.chip_info()["kernel_ms"])
+    finally:
+        os.environ.pop("DPCG_CHIP_EVENTS", None)
+        os.environ.pop("DPCG_CHIP_BENCH", None)
+    ms_full, ms_skip = float(np.median(full[2:])), float(np.median(skip[2:]))
+    b_spmv = spmv_bytes(n, nnz)
+    b_upd = b_spmv + int(9.5 * 8 * n)
+    achieved = its * b_upd / (ms_full * 1e-3) / 1e9
+    us_upd = ms_full * 1e3 / its
+    us_spmv = max((ms_full - ms_skip) * 1e3 / its, 1e-3)
+    ci = system.chip_info()
+    return {"bound": "hbm", "kernel": f"k_pcg_chip (the whole solve, cg.py:58-90, in one launch of {ci['workgroups']} workgroups x {ci['threads']} threads; "
+                                      f"{ci['rows_per_workgroup']} rows per workgroup, matrix and vectors resident in LDS / registers)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "algorithmic_bytes_per_launch": its * b_upd, "algorithmic_bytes_per_update": b_upd,
+            "us_per_launch": round(ms_full * 1e3, 2), "updates_per_launch": its, "us_per_update": round(us_upd, 3),
+            "timing": "HIP events on the launch stream around the kernel (DPCG_CHIP_EVENTS), median of 10 launches",
+            "regime": "on_chip_resident: the algorithmic bytes of an update are served from LDS / registers (matrix, x, r, p, q) and the XCDs' "
+                      "L2 (the published granules); frac > 1 of the HBM peak means they no longer cross the memory interface -- `traffic` is "
+                      "what did.  The streaming SpMV kernel (systems beyond 1,048,576 rows, other preconditioners) is `streaming_spmv_kernel`; "
+                      "its HBM-bound figure is `hbm_bound_256cubed`",
+            "spmv_phase": {"us_per_update": round(us_spmv, 3), "achieved": round(b_spmv / (us_spmv * 1e-6) / 1e9, 1), "unit": "GB/s",
+                           "frac": round(b_spmv / (us_spmv * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": b_spmv,
+                           "us_per_update_without_gathers": round(ms_skip * 1e3 / its, 3),
+                           "method": "kernel time minus the same kernel without the gathers of q = A p (DPCG_CHIP_BENCH), per update"},
+            "streaming_spmv_kernel": {k: k1[k] for k in ("kernel", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch", "us_per_launch",
+                                                          "traffic_source", "frac_of_measured_ceiling") if k in k1},
+            "measured_stream_gbs": k1.get("measured_stream_gbs")}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,11 +427,14 @@ def main() -> None:
                                                                       max(v for k, v in ceilings.items() if isinstance(v, float)
                                                                           and not k.startswith("cache_resident"))), 4)},
         }
+        chip = system.chip_info()
+        if chip["chip_by_default"] and args.precond in ("jacobi", "none"):
+            line["roofline"] = chip_roofline(system, poisson.rhs(n, 0), check, line["roofline"], pmc_all.get(f"chip_{args.dim}d_{args.n}"))
         if per_rank is not None:
             line["per_rank"] = per_rank
             line["gathered_records"] = comm["gathered_records"]
             line["roofline"]["per_rank_frac"] = [r["roofline_frac"] for r in per_rank]
-        if args.precond == "jacobi" and not info["two_kernel_updates"]:
+        if args.precond == "jacobi" and not info["two_kernel_updates"] and not chip["chip_by_default"]:
             # the whole PCG update of the timed solve against the same peak: K1 + K2 (q, r, dinv read; r written) + K3 (r, dinv, p read;
             # p written; every other update also p', x read and x written) = B_spmv + 9.5 n x 8 bytes, over wall time per update
             b_upd = b_alg + int(9.5 * 8 * n)
@@ -389,9 +442,10 @@ def main() -> None:
             line["roofline"]["whole_update"] = {"algorithmic_bytes": b_upd, "us": round(us_upd, 2),
                                                 "achieved": round(b_upd / (us_upd * 1e-6) / 1e9, 1),
                                                 "frac": round(b_upd / (us_upd * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-        line["roofline"]["regime"] = ("cache_resident_1M: the ~150 MB working set of the headline system lives in the 256 MiB "
-                                      "Infinity Cache, so `achieved` is fabric, not DRAM, bandwidth; the HBM-bound figure is "
-                                      "`hbm_bound_256cubed` below")
+        if "regime" not in line["roofline"]:
+            line["roofline"]["regime"] = ("cache_resident_1M: the ~150 MB working set of the headline system lives in the 256 MiB "
+                                          "Infinity Cache, so `achieved` is fabric, not DRAM, bandwidth; the HBM-bound figure is "
+                                          "`hbm_bound_256cubed` below")
         if world == 1:
             # the same kernel on a system far beyond the Infinity Cache (BASELINE config 4's 256^3: 1.74 GB per SpMV)
             # (the time of this kernel moves 274-303 us with where the system's arrays happen to land in HBM -- tools/c4_variance_probe.py,

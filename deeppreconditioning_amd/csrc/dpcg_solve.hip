@@ -724,6 +724,8 @@ static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, dou
     d.part = h->chip_part;
     d.err = reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256);
     d.band = h->planA.max_band;
+    { const char *e = getenv("DPCG_CHIP_HOPS"); d.hops = (e && e[0] == '1') ? 1 : 2; }      // read per solve (development)
+    { const char *e = getenv("DPCG_CHIP_BENCH"); d.bench = e ? atoi(e) : 0; }
     static const bool plain_ok = [] { const char *e = getenv("DPCG_CHIP_LOCAL"); return !(e && e[0] == '0'); }();   // development: 0 = everything written through
     d.xcc = plain_ok ? reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256 + 2) : nullptr;
     static const bool trace = [] { const char *e = getenv("DPCG_CHIP_TRACE"); return e && e[0] == '1'; }();
@@ -735,11 +737,26 @@ static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, dou
     DPCG_HIP(hipStreamSynchronize(s));
     // one whole-chip launch at a time per process (see solve_team_one)
     std::lock_guard<std::mutex> one_team_launch(team_launch_mutex());
+    // DPCG_CHIP_EVENTS=1 (read per solve; bench.py's roofline leg): HIP events on the launch stream around the kernel
+    static hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const char *ev_env = getenv("DPCG_CHIP_EVENTS");
+    const bool events = ev_env && ev_env[0] == '1';
+    if (events && !ev0) {
+        DPCG_HIP(hipEventCreate(&ev0));
+        DPCG_HIP(hipEventCreate(&ev1));
+    }
     const auto t0 = std::chrono::steady_clock::now();                                // cg.py:69 (the launch is the loop)
+    if (events) DPCG_HIP(hipEventRecord(ev0, s));
     DPCG_TRY(launch_pcg_chip(d, h->planA.max_row_len, s));
+    if (events) DPCG_HIP(hipEventRecord(ev1, s));
     DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
     const auto t1 = std::chrono::steady_clock::now();                                // cg.py:88
+    if (events) {
+        float ms = 0.0f;
+        DPCG_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        h->chip_trace_x[5] = (double)ms;
+    }
     DPCG_CHECK_LAUNCH();
     const Scalars sc = *h->scal_host;
     if (sc.status < 0) {
@@ -796,7 +813,7 @@ extern "C" int dpcg_get_chip_info(dpcg_handle_t h, int32_t out[8], double trace_
     if (trace_us)
         for (int i = 0; i < 8; ++i) trace_us[i] = h->chip_trace_us[i];
     out[6] = (int)h->chip_trace_x[4];                       // the last traced chip solve kept plainly stored copies (every group on one XCD)
-    out[7] = (int)(h->chip_trace_x[0] * 1000.0);            // ... and its slowest workgroup's SpMV phase, ns per update
+    out[7] = (int)(h->chip_trace_x[5] * 1.0e6);             // DPCG_CHIP_EVENTS=1: the last chip kernel between HIP events on its stream, ns
     return DPCG_OK;
 }
 
@@ -918,6 +935,31 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
             worst_small = std::max(worst_small, out[i].status);
         }
         return worst_small;
+    }
+    bool all_chip = true;
+    for (int i = 0; i < count; ++i) all_chip = all_chip && chip_eligible(handles[i], flags, nullptr);
+    if (all_chip && ((flags & DPCG_TEAM) || chip_default(handles[0], flags))) {
+        // cache-sized systems: the whole chip serves one system at a time (7-13 us per update against 30 for the launches -- nothing to
+        // interleave), and a batch member's result is bit for bit that of its single solve
+        int worst_chip = DPCG_OK;
+        bool refused = false;
+        for (int i = 0; i < count && !refused; ++i) {
+            int it = 0;
+            double fr = 0.0, sec = 0.0;
+            const int st = solve_chip_one(handles[i], b[i], x0 ? x0[i] : nullptr, x ? x[i] : nullptr, rtol_sq, atol_sq, max_iter, flags,
+                                          nullptr, &it, &fr, &sec, nullptr);
+            if (st == DPCG_ERR_STATE) { refused = true; break; }     // never co-resident: the whole batch takes the streams below
+            if (st < 0) return st;
+            if (iters) iters[i] = it;
+            if (final_res) final_res[i] = fr;
+            if (seconds) seconds[i] = sec;
+            if (status) status[i] = st;
+            worst_chip = std::max(worst_chip, st);
+        }
+        if (!refused) {
+            DPCG_HIP(hipStreamSynchronize(nullptr));
+            return worst_chip;
+        }
     }
     bool all_team = true;
     for (int i = 0; i < count; ++i) all_team = all_team && team_eligible(handles[i], flags, nullptr);

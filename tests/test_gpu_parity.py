@@ -2816,3 +2816,136 @@ def test_measurement_helpers_of_round_four(D):
     assert [l["c_out"] for l in cost["layers"]] == [16, 32, 64, 32, 16, 1] and cost["layers"][-1]["sites"] == out.features.shape[0]
     assert cost["flops"] == sum(2 * l["kernel"][0] * l["kernel"][1] * l["c_in"] * l["c_out"] * l["sites"] for l in cost["layers"])
     assert cost["min_hbm_bytes"] > 4 * out.features.shape[0]
+
+
+# ---- round 5: cache-sized systems, the whole solve in ONE launch on the whole chip (dpcg_chip.hip) ---------------------------------
+def _chip_tree(S):
+    ci = S.chip_info()
+    return {**S.reduction_geometry(), "form": "chip", "rows_per_workgroup": ci["rows_per_workgroup"]}
+
+
+@pytest.mark.parametrize("name,make,max_iter", [
+    ("poisson3d_100", lambda: O.poisson3d(100), 1024),            # the headline system: 8 rows a thread, 7 entries a row, 187 updates
+    ("poisson2d_1024", lambda: O.poisson2d(1024), 1024),          # 1 048 576 rows = the kernel's capacity; runs into the cap of cg.py:51
+    ("poisson3d_80", lambda: O.poisson3d(80), 1024),              # 512 000 rows: 4 rows a thread
+    ("poisson2d_512", lambda: O.poisson2d(512), 400),             # 262 144 rows: 2 rows a thread, 5 entries a row
+    ("poisson3d_41", lambda: O.poisson3d(41), 1024),              # 68 921 rows: just beyond the team kernel; most threads without a row
+    ("unstructured3d_60", lambda: O.unstructured_like(O.poisson3d(60), seed=1), 1024)])   # scattered numbering + D A D scaling: reordered inside the library, b / x in the caller's numbering
+def test_chip_solve_equals_the_device_tree_oracle_bit_for_bit(D, name, make, max_iter):
+    """65 537 .. 1 048 576 rows, rows of <= 7 entries, M = I / Jacobi: a plain call is ONE launch of 256 workgroups that keeps matrix
+    and vectors in registers and LDS for the whole solve (dpcg_chip.hip).  Against oracle/pcg_oracle.c with THAT kernel's reduction
+    tree (form "chip": 512-thread workgroups, two-hop exchange): history, count and x EQUAL -- every one of the ~1e9 gathers of a solve
+    read what its owner had published --, the reference's golden count and residual at the headline size, and the multi-launch path
+    within 1e-10."""
+    A = make()
+    n = A.shape[0]
+    S = D.CsrSystem.from_any(A)
+    b = O.rhs(n, 0)
+    perm = S.permutation() if S.reordered else None
+    B = _permuted(A, perm) if perm is not None else A
+    bb = b[perm] if perm is not None else b
+    for kind, pc, okw in (("jacobi", D.Jacobi(), dict(dinv=O.jacobi_dinv(B))), ("none", None, {})):
+        S.set_preconditioner(pc)
+        ci = S.chip_info()
+        if kind == "none" and name.startswith("unstructured"):
+            continue         # unpreconditioned CG on the D A D-scaled system is chaotic (the two CPU oracles differ by 19 % there)
+        assert S.reordered == name.startswith("unstructured")
+        assert ci["chip_by_default"] and ci["workgroups"] == 256 and ci["threads"] == 512, ci
+        res = S.solve(_dev(b), max_iter=max_iter)
+        multi = S.solve(_dev(b), max_iter=max_iter, flags=D._lib.NO_SMALL)
+        _, it, hist, x = CO.pcg(B, bb, kind, max_iter=max_iter, device_tree=_chip_tree(S), **okw)
+        assert res.iterations == it == multi.iterations and res.status == multi.status, (name, kind, res.iterations, it)
+        assert np.array_equal(res.res_history, hist), (name, kind, int(np.argmax(res.res_history != hist)))
+        xs = res.x.cpu().numpy()
+        assert np.array_equal(xs[perm] if perm is not None else xs, x), (name, kind)
+        np.testing.assert_allclose(multi.res_history, hist, rtol=HIST_RTOL)
+        assert not np.array_equal(multi.res_history, res.res_history)        # (another summation order: it WAS the other path)
+        again = S.solve(_dev(b), max_iter=max_iter)
+        assert np.array_equal(again.res_history, res.res_history) and torch.equal(again.x, res.x)     # reproducible to the bit
+    if name == "poisson3d_100":
+        assert res.iterations == 187 and abs(res.final_res - 9.7542989714295971e-09) <= 1e-10 * 9.76e-09   # SURVEY 8-c3: the reference's own run
+    S.close()
+
+
+def test_chip_solve_arguments_and_edges(D):
+    """x0 (cg.py:58-60), caps, both first tests (cg.py:66 / scipy's), b = 0, and what keeps a system OFF the chip kernel: the flags of
+    the other forms, a preconditioner it does not fuse, rows of more than 7 entries, a bandwidth beyond 16-bit offsets."""
+    A = O.poisson3d(64)
+    n = A.shape[0]
+    b, x0 = O.rhs(n, 1), O.rhs(n, 7)
+    S = D.CsrSystem.from_any(A, reorder=None)
+    S.set_preconditioner(D.Jacobi())
+    tree = _chip_tree(S)
+    dinv = O.jacobi_dinv(A)
+    for max_iter in (0, 1, 2, 25):
+        r = S.solve(_dev(b), _dev(x0), max_iter=max_iter)
+        _, it, hist, x = CO.pcg(A, b, "jacobi", dinv=dinv, x0=x0, max_iter=max_iter, device_tree=tree)
+        assert r.iterations == it and r.status == 1 and np.array_equal(r.res_history, hist) and np.array_equal(r.x.cpu().numpy(), x), max_iter
+    r = S.solve(_dev(b), flags=D._lib.INIT_CHECK_R, rtol_sq=1e-6)
+    _, it, hist, _ = CO.pcg(A, b, "jacobi", dinv=dinv, rtol=1e-6, init_check="r", device_tree=tree)
+    assert r.iterations == it and r.status == 0 and np.array_equal(r.res_history, hist)
+    rz = S.solve(_dev(np.zeros(n)))                     # <b,b> = 0 -> 0/0: breakdown, as on every other path (the reference spins to max_iter on NaN)
+    assert rz.status == 2 and rz.iterations == 0
+    x_in = _dev(x0)
+    keep = x_in.clone()
+    S.solve(_dev(b), x_in, max_iter=5)
+    assert torch.equal(x_in, keep)                      # x0 is not modified (cg.py:79 is out of place)
+    # the flags of the other forms keep the launches
+    for fl in (D._lib.NO_SMALL, D._lib.NO_TEAM, D._lib.NO_GRAPH):
+        m = S.solve(_dev(b), flags=fl)
+        full = S.solve(_dev(b))
+        assert m.iterations == full.iterations and not np.array_equal(m.res_history, full.res_history)
+    S.set_preconditioner(D.IC0("solve"))
+    assert not S.chip_info()["chip_eligible"]
+    S.close()
+    A9 = (A @ A).tocsr()                                # rows of up to 25 entries
+    A9.sort_indices()
+    S9 = D.CsrSystem.from_any(A9, reorder=None)
+    S9.set_preconditioner(D.Jacobi())
+    assert S9.chip_info()["max_row_len"] > 7 and not S9.chip_info()["chip_eligible"]
+    S9.close()
+    P = O.poisson3d(48)                                 # 110 592 rows; one coupling 40 000 rows away: beyond 16-bit offsets
+    m = P.shape[0]
+    E = sp.coo_matrix(([-0.5, -0.5], ([5, 40005], [40005, 5])), shape=(m, m)).tocsr()
+    W = (P + E + sp.diags(np.asarray(abs(E).sum(axis=1)).ravel())).tocsr()
+    W.sort_indices()
+    Sw = D.CsrSystem.from_any(W, reorder=None)
+    Sw.set_preconditioner(D.Jacobi())
+    ciw = Sw.chip_info()
+    assert ciw["max_band"] == 40000 and not ciw["chip_eligible"]
+    bw = O.rhs(m, 2)
+    rw = Sw.solve(_dev(bw))
+    _, itw, histw, _ = CO.pcg(W, bw, "jacobi", dinv=O.jacobi_dinv(W))
+    assert rw.iterations == itw
+    np.testing.assert_allclose(rw.res_history, histw, rtol=HIST_RTOL)
+    Sw.close()
+
+
+def test_chip_solve_with_everything_written_through(D):
+    """DPCG_CHIP_LOCAL=0 (read once per process, so a child process): no plainly stored copies, every granule written through to
+    the memory side -- the form any placement of the workgroups falls back to.  Same bits as the oracle."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import numpy as np, torch, sys
+        import deeppreconditioning_amd as D
+        from oracle import oracle as O, c_oracle as CO
+        A = O.poisson3d(70)
+        n = A.shape[0]
+        b = O.rhs(n, 3)
+        S = D.CsrSystem.from_any(A, reorder=None)
+        S.set_preconditioner(D.Jacobi())
+        ci = S.chip_info()
+        assert ci["chip_by_default"]
+        res = S.solve(torch.from_numpy(b).cuda())
+        tree = {**S.reduction_geometry(), "form": "chip", "rows_per_workgroup": ci["rows_per_workgroup"]}
+        _, it, hist, x = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A), device_tree=tree)
+        assert res.iterations == it and np.array_equal(res.res_history, hist) and np.array_equal(res.x.cpu().numpy(), x)
+        print("ok", it)
+    """)
+    import os
+    env = dict(os.environ, DPCG_CHIP_LOCAL="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                         cwd=str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
