@@ -56,7 +56,7 @@ constexpr unsigned long long kChipSpinTicks = 2000000ull;               // 20 ms
 constexpr unsigned long long kChipPending = 0x7ff8dead0badbeefULL;      // a quiet NaN that no arithmetic here produces
 constexpr int kChipZpPad = 4096;        // granules of slack behind each copy (group shifts; rows that do not exist gather there)
 constexpr int kChipS1Bytes = 4 * kChipWGs * 16;                // group-level slots: 4 sets x 256 workgroups x 16 B
-constexpr int kChipSlotBytes = 4 * 8 * kChipWGs * 16;          // room for either exchange: one hop = 4 sets x 8 replicas x 256 slots x 16 B (two hops use the first 20 KiB)
+constexpr int kChipSlotBytes = kChipS1Bytes + 4 * 8 * 8 * 16;  // + chip-level slots: 4 sets x 8 destination groups x 8 source groups
 constexpr int kSc1 = 16;                // cache-policy operand of the buffer builtins on gfx950: bit 4 = sc1 (agent scope)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     double vr[NREG > 0 ? NREG : 1];
     unsigned dl[(NS + 1) / 2];
     unsigned lens = 0;                     // 4 bits per row: 8 | length for a row that exists, 0 otherwise
-    double x[RPT], r[RPT], p[RPT], q[RPT];
+    double x[RPT], r[RPT], p[RPT], q[RPT], dv[JAC ? RPT : 1];
     double bb_loc = 0.0;
     // (unconditional loads from clamped addresses -- a predicated load is a branch with a wait of its own, and 56 of them in a row
     // were 56 dependent round trips: the extents of all rows first, then one row's entries at a time, all of them in flight together)
@@ -120,12 +120,14 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         const int rs = d.rp[ic], re = d.rp[ic + 1];
         const double bi = d.b[ic];
         const double xi = d.x0 ? d.x0[ic] : 0.0;
+        const double di = JAC ? d.dinv[ic] : 1.0;
         rs_k[k] = rs;
         len_k[k] = valid ? re - rs : 0;
         lens |= (valid ? (8u | (unsigned)(re - rs)) : 0u) << (4 * k);
         x[k] = valid ? xi : 0.0;
         r[k] = valid ? bi : 0.0;
         p[k] = q[k] = 0.0;
+        if (JAC) dv[k] = valid ? di : 1.0;
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -263,50 +265,6 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
             const unsigned long long w0 = timed ? wall_clock64() : 0;
             double ta, tb;
             int ok = 1;
-            if (d.hops == 1) {
-                // ONE hop: the workgroup's pair goes to eight replicas of the slot array, one per destination group (lanes 0-7, one
-                // written-through store each); a workgroup polls its group's replica -- 256 slots, 32 lines, 32 pollers a line
-                double sa = 0.0, sb = 0.0;
-#pragma unroll
-                for (int w = 0; w < kChipThreads / 64; ++w) {
-                    sa += slot[w];
-                    sb += slot[8 + w];
-                }
-                if (t < 8) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-arm of the previous generation has landed
-                    const int o_n = ((set_nxt * 8 + t) * kChipWGs + v) * 16, o_c = ((set_cur * 8 + t) * kChipWGs + v) * 16;
-                    __builtin_amdgcn_raw_buffer_store_b128(pend, part_rs, o_n, 0, kSc1);
-                    __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2(sa, sb), part_rs, o_c, 0, kSc1);
-                }
-                u32x4 s4[4];
-                const int base = ((set_cur * 8 + grp) * kChipWGs + t) * 16;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) s4[u] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, base + 64 * 16 * u, 0, kSc1);
-                unsigned spins = 0;
-                unsigned long long t0 = 0;
-                for (;;) {
-                    bool pend_any = false;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) pend_any = pend_any || is_pending(s4[u]);
-                    if (__ballot(pend_any) == 0) break;
-                    __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (is_pending(s4[u])) s4[u] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, base + 64 * 16 * u, 0, kSc1);
-                    if ((++spins & 255u) == 0) {
-                        const unsigned long long now = wall_clock64();
-                        if (t0 == 0) t0 = now;
-                        else if (now - t0 > kChipSpinTicks || __hip_atomic_load(d.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                            atomicExch(d.err, 1);
-                            ok = 0;
-                            break;
-                        }
-                    }
-                }
-                ta = wave_sum(((lo_f64(s4[0]) + lo_f64(s4[1])) + lo_f64(s4[2])) + lo_f64(s4[3]));
-                tb = wave_sum(((hi_f64(s4[0]) + hi_f64(s4[1])) + hi_f64(s4[2])) + hi_f64(s4[3]));
-                if (timed) s_tk[wait_idx] += wall_clock64() - w0;
-            } else {
             // hop 1: the group's 32 pairs
             if (t == 0) {
                 double sa = 0.0, sb = 0.0;
@@ -339,7 +297,6 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
             if (timed) s_tk[wait_idx] += wall_clock64() - w0;
             ta = wave_sum(lo_f64(sv));
             tb = wave_sum(hi_f64(sv));                                          // (lanes 8-63 add +0.0)
-            }
             if (t == 63) {
                 sres[0] = ta;
                 sres[1] = tb;
@@ -402,22 +359,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
             alive = chip_sum2(0.0, 0.0, false, dummy, dummy2);    // everybody has read x0 out of the granules before z_0 overwrites them
         }
     }
-    // M = diag(1 / a_ii): the inverse diagonal of the own rows is NOT kept in registers across the SpMV phase (where the gathers in
-    // flight need them): every update reads it again -- out of the L2, requested before the wait for <p,Ap>, so the latency is hidden
-    auto load_dinv = [&](double (&dvl)[JAC ? RPT : 1]) {
-        if (JAC) {
-            int r0 = row0;
-            asm volatile("" : "+v"(r0));                          // (not hoisted out of the update loop)
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int i = r0 + k * kChipThreads;
-                dvl[JAC ? k : 0] = d.dinv[row_on(k) ? i : 0];
-            }
-        }
-    };
     double rz_loc = 0.0, t0_loc = 0.0;
-    double dv[JAC ? RPT : 1];
-    load_dinv(dv);
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const double zk = JAC ? dv[JAC ? k : 0] * r[k] : r[k];    // cg.py:61
@@ -460,7 +402,6 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         for (int k = 0; k < RPT; ++k)
             if (row_on(k)) pq_loc += q[k] * p[k];
         double pq = 0.0;
-        load_dinv(dv);
         stamp(0);
         wait_idx = 5;
         if (!(alive = chip_sum2(pq_loc, 0.0, false, pq, dummy))) break;         // barrier A: every SpMV of this update is done

@@ -460,8 +460,7 @@ struct ChipDesc {
     double *x, *hist;
     double *zp;                // 2 x (n + 4096) granules {z_{k+1}[i], p_k[i]}: the copy read inside a group and the written-through one
     int band;                  // largest |col - row| of the matrix
-    int hops;                  // 1: one-hop exchange of the reduction partials (eight replicas), 2: group, then chip
-    int bench;                 // development: bit 0 = skip the gathers of q = A p (q = p), bit 1 = never stop before max_iter
+    int bench;                 // development (DPCG_CHIP_BENCH): the kernel variant without the gathers of q = A p (q = p) that never stops before max_iter
     int *xcc;                  // 256 words: the XCD every workgroup found itself on (exchanged once per solve); null: never store plainly
     double rtol_sq, atol_sq;
     Scalars *out;

@@ -724,7 +724,6 @@ static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, dou
     d.part = h->chip_part;
     d.err = reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256);
     d.band = h->planA.max_band;
-    { const char *e = getenv("DPCG_CHIP_HOPS"); d.hops = (e && e[0] == '1') ? 1 : 2; }      // read per solve (development)
     { const char *e = getenv("DPCG_CHIP_BENCH"); d.bench = e ? atoi(e) : 0; }
     static const bool plain_ok = [] { const char *e = getenv("DPCG_CHIP_LOCAL"); return !(e && e[0] == '0'); }();   // development: 0 = everything written through
     d.xcc = plain_ok ? reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256 + 2) : nullptr;
