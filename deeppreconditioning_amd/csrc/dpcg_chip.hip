@@ -83,7 +83,8 @@ __device__ __forceinline__ bool is_pending(const u32x4 &g) {
 // RPT: rows per thread (2, 4, 8); WMAX: entry slots per row (5, 7); JAC: M = diag(1 / a_ii) (else M = I: z = r, no dinv registers).
 template <int RPT, int WMAX, bool JAC, int MODE>
 __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
-    constexpr bool TRACE = MODE == 1;      // (MODE 2, development: q = p instead of the gathers, and the loop never stops before max_iter)
+    constexpr bool TRACE = MODE == 1;      // (development -- MODE 2: q = p instead of the gathers, the loop never stops before max_iter; MODE 3: the gathers
+                                           // issued, but every one out of range: no memory request, zeros returned)
     constexpr int NS = RPT * WMAX;                                   // entry slots of a thread
     constexpr int NLDS = NS < kChipLdsSlots ? NS : kChipLdsSlots;    // ... whose values live in LDS
     constexpr int NREG = NS - NLDS;                                  // ... and in registers (the first NREG slots)
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
                 const int del = (int)((dl[s >> 1] >> (16 * (s & 1))) & 0xffffu);
                 const int c = rowk + del - 32768;
                 const bool own = (unsigned)(c - glo_l) < (unsigned)span_l;              // the column's owner is in this group: the plain copy
-                gk[j] = __builtin_amdgcn_raw_buffer_load_b128(zp_rs, c * 16 + (own ? local_shift : remote_base), 0, kSc1);
+                gk[j] = __builtin_amdgcn_raw_buffer_load_b128(zp_rs, MODE == 3 ? (int)0x7ffffff0 : c * 16 + (own ? local_shift : remote_base), 0, kSc1);
             }
         };
         request(0, g[0]);
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         ++k_done;
         if (v == 0 && t == 0 && k_done < d.hist_cap) d.hist[k_done] = res;
         const bool conv = (res < d.rtol_sq) || (rr < d.atol_sq);  // cg.py:71, tested before the next update's work
-        if (MODE == 2) continue;                                  // (development: a fixed number of updates whatever the numbers do)
+        if (MODE >= 2) continue;                                  // (development: a fixed number of updates whatever the numbers do)
         if (conv) { stop = true; status = DPCG_OK; }
         else if (!(res == res)) { stop = true; status = DPCG_BREAKDOWN; }
     }
@@ -524,8 +525,8 @@ int launch_pcg_chip(const ChipDesc &d, int max_row_len, hipStream_t s, bool chec
     if (max_row_len < 1 || max_row_len > 7 || d.per < 1 || d.per > kChipThreads * kChipMaxRpt) return DPCG_ERR_INVALID;
     const int rpt = (d.per + kChipThreads - 1) / kChipThreads;
     const bool jac = d.precond == DPCG_PRECOND_JACOBI;
-    const int mode = d.bench ? 2 : (d.dbg != nullptr ? 1 : 0);
-#define DPCG_CHIP_T(RPTV, WV, JV) (mode == 2 ? chip_launch<RPTV, WV, JV, 2>(d, s, check_only) : (mode == 1 ? chip_launch<RPTV, WV, JV, 1>(d, s, check_only) : chip_launch<RPTV, WV, JV, 0>(d, s, check_only)))
+    const int mode = d.bench == 3 ? 3 : (d.bench ? 2 : (d.dbg != nullptr ? 1 : 0));
+#define DPCG_CHIP_T(RPTV, WV, JV) (mode == 3 ? chip_launch<RPTV, WV, JV, 3>(d, s, check_only) : mode == 2 ? chip_launch<RPTV, WV, JV, 2>(d, s, check_only) : (mode == 1 ? chip_launch<RPTV, WV, JV, 1>(d, s, check_only) : chip_launch<RPTV, WV, JV, 0>(d, s, check_only)))
 #define DPCG_CHIP_W(RPTV, WV) (jac ? DPCG_CHIP_T(RPTV, WV, true) : DPCG_CHIP_T(RPTV, WV, false))
 #define DPCG_CHIP_R(RPTV) (max_row_len <= 5 ? DPCG_CHIP_W(RPTV, 5) : DPCG_CHIP_W(RPTV, 7))
     if (rpt <= 2) return DPCG_CHIP_R(2);
