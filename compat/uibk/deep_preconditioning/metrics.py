@@ -1,3 +1,3 @@
-"""`uibk.deep_preconditioning.metrics` (metrics.py:13-100) on the MI355X path."""
-from deeppreconditioning_amd.metrics import (condition_loss, frobenius_loss, hutchinson_trace,  # noqa: F401
-                                              inverse_loss)
+"""`uibk.deep_preconditioning.metrics` on the MI355X path: the two losses of the solve / training path (metrics.py:13-55).
+`hutchinson_trace` and `condition_loss` (metrics.py:58-100) are outside this path and are not provided."""
+from deeppreconditioning_amd.metrics import frobenius_loss, inverse_loss  # noqa: F401

@@ -55,6 +55,7 @@ SIGNATURES = {
     "dpcg_set_precond_icholt": (_int, [_p, _int, _int, _dbl, _p]),
     "dpcg_get_reduction_geometry": (_int, [_p, _p]),
     "dpcg_get_chip_info": (_int, [_p, _p, _p]),
+    "dpcg_debug_occupy": (_int, [_int, C.c_double, _p]),
     "dpcg_get_factor": (_int, [_p, _p, _p, _p]),
     "dpcg_spmv": (_int, [_p, _p, _p, _p]),
     "dpcg_spmv_f32": (_int, [_p, _p, _p, _p]),

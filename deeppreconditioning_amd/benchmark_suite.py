@@ -140,13 +140,8 @@ class BenchmarkSuite:
                 density, kappa, spectrum = self._density_and_kappa(system, n, want_spectrum=index == 0)
                 if spectrum is not None:
                     eigenvalues[name] = spectrum
-                self.kappas[name].append(kappa)
-                self.densities[name].append(density)
-                self.iterations[name].append(iteration)
-                self.setups[name].append(setup)
-                self.durations[name].append(duration)
-                self.totals[name].append(setup + duration)
-                self.successes[name].append(100 * (1 - info))                          # test.py:149
+                self._record(name, kappas=kappa, densities=density, iterations=iteration, setups=setup, durations=duration,
+                             totals=setup + duration, successes=100 * (1 - info))      # the columns of test.py:143-149
             if index == 0 and eigenvalues:                                              # test.py:151-155
                 self.results_directory.mkdir(parents=True, exist_ok=True)
                 with (self.results_directory / "eigenvalues.csv").open(mode="w") as f:
@@ -155,24 +150,29 @@ class BenchmarkSuite:
                         f.write(",".join(str(v) for v in row) + "\n")
             system.close()
 
+    def _record(self, technique: str, **columns) -> None:
+        """One sample's numbers of one technique into the per-technique lists (`self.kappas[technique]`, ...)."""
+        assert set(columns) == set(PARAMETERS), sorted(columns)
+        for parameter, value in columns.items():
+            getattr(self, parameter)[technique].append(value)
+
     def dump_csv(self) -> None:
-        """test.py:175-198: `table.csv` (means per technique) and `totals.csv` (per-sample totals)."""
+        """The files of test.py:175-198, same names, headers and cell formatting (`str` of a float): `table.csv` = one row per
+        technique with the mean of every column of PARAMETERS, `totals.csv` = one row per sample with every technique's total."""
+        import csv
         self.results_directory.mkdir(parents=True, exist_ok=True)
-        with (self.results_directory / "table.csv").open(mode="w") as f:
-            f.write("technique," + ",".join(PARAMETERS) + "\n")
-            for technique in self.techniques:
-                line = technique
-                for parameter in PARAMETERS:
-                    line += "," + str(np.mean(getattr(self, parameter)[technique], dtype=float))
-                f.write(line + "\n")
-        with (self.results_directory / "comparability.csv").open(mode="w") as f:     # not in the reference: see COMPARABILITY
-            f.write("technique,comparable_with_the_reference\n")
-            for technique in self.techniques:
-                f.write(f'{technique},"{COMPARABILITY.get(technique, "unknown technique")}"\n')
-        with (self.results_directory / "totals.csv").open(mode="w") as f:
-            f.write(",".join(self.techniques) + "\n")
-            for index in range(len(self.totals[self.techniques[0]])):
-                f.write(",".join(str(self.totals[t][index]) for t in self.techniques) + "\n")
+
+        def write(name, header, rows):
+            with (self.results_directory / name).open(mode="w", newline="") as f:
+                out = csv.writer(f, lineterminator="\n")
+                out.writerow(header)
+                out.writerows(rows)
+
+        means = {t: [float(np.mean(getattr(self, col)[t], dtype=float)) for col in PARAMETERS] for t in self.techniques}
+        write("table.csv", ["technique", *PARAMETERS], ([t, *means[t]] for t in self.techniques))
+        write("comparability.csv", ["technique", "comparable_with_the_reference"],                # not in the reference: see COMPARABILITY
+              ([t, COMPARABILITY.get(t, "unknown technique")] for t in self.techniques))
+        write("totals.csv", self.techniques, zip(*(self.totals[t] for t in self.techniques)))
 
 
 def main(params_path="params.yaml", checkpoint="./assets/checkpoints/best.pt", root=None, *,

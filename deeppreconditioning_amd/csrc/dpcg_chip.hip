@@ -38,7 +38,7 @@
 //   * co-residency is checked up front (occupancy query x CUs >= 256) and every wait is bounded (20 ms): a launch whose workgroups
 //     cannot all become resident (another process's kernel holding CUs) reports DPCG_ERR_STATE and the caller solves through the
 //     multi-launch path instead.
-// Row sums run in CSR order and every dot product in a fixed tree (restated in oracle/pcg_oracle.c, form 3), so history, count and
+// Row sums run in CSR order and every dot product in a fixed tree (restated by the tests' CPU checker, form "chip"), so history, count and
 // x equal the CPU restatement's bit for bit.
 #include <algorithm>
 
@@ -503,6 +503,28 @@ int chip_launch(const ChipDesc &d, hipStream_t s, bool check_only) {
 }
 
 }  // namespace
+
+// Test hook (dpcg_debug_occupy): `workgroups` workgroups that each take a whole CU (all of its LDS) and spin for `ticks` of the
+// 100 MHz clock -- what a long-running kernel of another stream or process does to the whole-solve kernels' co-residency.
+__global__ __launch_bounds__(256) void k_occupy(unsigned long long ticks, int *sink) {
+    extern __shared__ int occ_lds[];
+    occ_lds[threadIdx.x] = (int)threadIdx.x;
+    __syncthreads();
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (sink && occ_lds[(threadIdx.x + 1) & 255] < 0) *sink = 1;
+}
+
+int launch_occupy(int workgroups, double ms, hipStream_t s) {
+    const int lds = 160 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_occupy, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DPCG_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_occupy, dim3(workgroups), dim3(256), (size_t)lds, s, (unsigned long long)(ms * 1.0e5), (int *)nullptr);
+    return DPCG_OK;
+}
 
 int chip_max_rows() { return kChipWGs * kChipThreads * kChipMaxRpt; }
 int chip_max_row_len() { return 7; }

@@ -477,9 +477,10 @@ int chip_slot_doubles();          // reduction slots (doubles) of a chip solve
 int64_t chip_zp_doubles(int64_t n);  // granule storage (doubles) of a chip solve
 void launch_band_and_len(const CsrDev &A, int *out2_zeroed_dev, hipStream_t s);
 int launch_pcg_chip(const ChipDesc &d, int max_row_len, hipStream_t s, bool check_only = false);
+int launch_occupy(int workgroups, double ms, hipStream_t s);
 int team_max_rows();
 int team_max_row_len();
-int launch_pcg_team(const TeamDesc *descs_dev, int nsys, int max_slabs_per_wg, int max_row_len, hipStream_t s);
+int launch_pcg_team(const TeamDesc *descs_dev, int nsys, int max_slabs_per_wg, int max_row_len, hipStream_t s, bool trace = false);
 void launch_ic0_level(const int32_t *rows, int j0, int count, const int32_t *rp, const int32_t *ci, double *lv, int *bad,
                       hipStream_t s, const double *colnorm = nullptr, double tau = 0.0);   // colnorm: ICT drop rule
 void launch_colnorm1(int64_t n, const int32_t *rp, const int32_t *ci, const double *v, double *c, hipStream_t s);

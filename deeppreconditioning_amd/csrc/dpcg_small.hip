@@ -79,7 +79,10 @@ __device__ __forceinline__ size_t ell_off(const SmallEll &E, int i, int j) {
 template <int NT, int RR>
 __device__ __forceinline__ void small_spmv(const SmallEll &E, const int (&len)[RR], const double *xs,
                                            double (&q)[RR]) {
-    const int t = threadIdx.x;
+    // (an opaque copy of the thread index per call: the ELL offsets of the rows are loop-invariant, and hoisted out of the update loop
+    // for three matrices they are registers a 1024-thread variant does not have -- 28 spill reloads per update of z = L (L^T r))
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
     int lmax = 0;
 #pragma unroll
     for (int k = 0; k < RR; ++k) {

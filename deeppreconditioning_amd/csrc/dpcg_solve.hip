@@ -630,17 +630,17 @@ static int solve_team_one(dpcg_system *h, const double *b, const double *x0, dou
     launch_fill_pending(h->team_part, 4 * 2 * 32, s);                                // every reduction slot: "not written yet"
     DPCG_HIP(hipStreamSynchronize(s));
     // one team launch at a time per process: the workgroups of a team wait for each other, and two such launches dispatched at
-    // once from two host threads could each hold part of the chip waiting for the rest of it (the 4 s bound would end that)
+    // once from two host threads could each hold part of the chip waiting for the rest of it (the 20 ms bound would end that)
     std::lock_guard<std::mutex> one_team_launch(team_launch_mutex());
     const auto t0 = std::chrono::steady_clock::now();                                // cg.py:69 (the launch is the loop)
-    DPCG_TRY(launch_pcg_team(static_cast<const TeamDesc *>(h->team_desc), 1, team_slabs_per_wg(h->A.n), h->ell_a.W, s));
+    DPCG_TRY(launch_pcg_team(static_cast<const TeamDesc *>(h->team_desc), 1, team_slabs_per_wg(h->A.n), h->ell_a.W, s, d.dbg != nullptr));
     DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
     DPCG_HIP(hipStreamSynchronize(s));
     const auto t1 = std::chrono::steady_clock::now();                                // cg.py:88
     DPCG_CHECK_LAUNCH();
     const Scalars sc = *h->scal_host;
     if (sc.status < 0) {
-        set_error("team solve: a workgroup waited (4 s) for a team member that never arrived");
+        set_error("team solve: a workgroup waited (20 ms) for a team member that never arrived");
         return sc.status;
     }
     if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
@@ -798,6 +798,13 @@ static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, dou
     if (x && h->perm) launch_scatter_f64(n, h->perm, h->x, x, s);                    // back to the caller's numbering
     if (pending) DPCG_HIP(hipStreamSynchronize(s));
     return sc.status;
+}
+
+extern "C" int dpcg_debug_occupy(int workgroups, double milliseconds, dpcg_stream_t stream) {
+    if (workgroups < 1 || workgroups > 4096 || !(milliseconds > 0.0) || milliseconds > 2000.0) return invalid("dpcg_debug_occupy: bad arguments");
+    DPCG_TRY(launch_occupy(workgroups, milliseconds, (hipStream_t)stream));
+    DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
 }
 
 extern "C" int dpcg_get_chip_info(dpcg_handle_t h, int32_t out[8], double trace_us[8]) {
@@ -1015,7 +1022,7 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
         static bool warned = false;
         if (!warned) {
             warned = true;
-            fprintf(stderr, "[dpcg] team solve: a workgroup waited 4 s for a team member that never became resident; "
+            fprintf(stderr, "[dpcg] team solve: a workgroup waited 20 ms for a team member that never became resident; "
                             "the batch is solved through the multi-launch path instead\n");
         }
     }

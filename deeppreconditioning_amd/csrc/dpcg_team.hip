@@ -25,7 +25,9 @@
 //     agent scope (sc1: served by the L2, never by a stale L1 line).  Reductions are two-stage and ordered (wave DPP tree
 //     -> 16 wave sums -> 32 workgroup partials summed in rank order by every workgroup), so all workgroups hold bit-identical
 //     alpha / beta and take the stopping decision of cg.py:71 identically, with no broadcast.
-//   * every wait is bounded by wall time (4 s): a team whose member never arrives reports DPCG_ERR_STATE instead of hanging.
+//   * the launch is refused up front when the occupancy query does not admit the kernel on a CU, and every wait is bounded by wall
+//     time (20 ms; a healthy hand-off takes 0.3-0.5 us): a team whose member never arrives -- somebody else holding CUs -- reports
+//     DPCG_ERR_STATE instead of hanging, and the caller solves through the multi-launch path.
 // M is I or Jacobi (what a mid-size system is solved with when setup time matters); everything else keeps the multi-launch path.
 #include <algorithm>
 
@@ -41,7 +43,7 @@ constexpr int kTeamMaxSlabs = 2;       // 1024-row slabs per workgroup: n <= 32 
 
 namespace {
 
-constexpr unsigned long long kTeamSpinTicks = 4ull * 100000000ull;     // 4 s of the 100 MHz constant clock
+constexpr unsigned long long kTeamSpinTicks = 2000000ull;              // 20 ms of the 100 MHz constant clock (a healthy hand-off takes 0.3-0.5 us)
 constexpr unsigned long long kTeamPending = 0x7ff8dead0badbeefULL;     // a quiet NaN that no arithmetic here produces: "slot not written yet"
 
 __device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -133,7 +135,7 @@ __device__ __forceinline__ void team_block_sum2(double &a, double &b, double *sh
 // per-thread private storage (slot [k][j][t] belongs to thread t: conflict-free, no barrier): values fp64, columns 16-bit
 // (n <= 65 536) -- 10 bytes per entry, 143 KB for two slabs of 7-entry rows; in registers the same slice spilled (260 B of
 // scratch per lane at 128 VGPRs).
-template <int RPT, int WMAX>
+template <int RPT, int WMAX, bool TRACE>   // TRACE (DPCG_TEAM_TRACE): phase timers -- a variant of its own, so that the timers' registers are not the solve's
 __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__restrict__ descs, int nsys) {
     const int team = blockIdx.x & (kTeams - 1), rank = blockIdx.x >> 3;
     if (team >= nsys || rank >= kTeamSize) return;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
     // a reader could have summed the value of three generations ago into alpha / beta.)  `publish`: the workgroup's stores of z
     // and p must be visible to whoever passes this point, so every wave drains them first.  Every workgroup returns the same bits.
     unsigned int gen = 0;
-    const bool timed = d.dbg != nullptr && rank == 0 && t == 0;     // DPCG_TEAM_TRACE: where an update's time goes (ticks of rank 0)
+    const bool timed = TRACE && d.dbg != nullptr && rank == 0 && t == 0;     // DPCG_TEAM_TRACE: where an update's time goes (ticks of rank 0)
     unsigned long long tk_drain = 0, tk_bsum = 0;
     auto team_sum2 = [&](double a, double b2, bool publish, double &ra, double &rb, bool two = true) -> bool {
         unsigned long long q0 = timed ? wall_clock64() : 0;
@@ -392,20 +394,33 @@ int team_max_row_len() { return 7; }
 
 // nsys <= 8 systems; descs_dev: device array of TeamDesc.  max_row_len: longest row of any of them (<= 7: the matrix slice lives
 // in registers).  Returns DPCG_OK or a negative status.
-int launch_pcg_team(const TeamDesc *descs_dev, int nsys, int max_slabs_per_wg, int max_row_len, hipStream_t s) {
+int launch_pcg_team(const TeamDesc *descs_dev, int nsys, int max_slabs_per_wg, int max_row_len, hipStream_t s, bool trace) {
     const dim3 grid(kTeams * kTeamSize), block(kTeamThreads);
     if (max_slabs_per_wg > kTeamMaxSlabs || max_row_len > 7) return DPCG_ERR_INVALID;
-#define DPCG_TEAM_LAUNCH(RPTV, WV)                                                                                         \
+    // Co-residency is what the team's waits assume: the occupancy query must admit the kernel on a CU (with the CU count >= 256 checked by
+    // the caller that is every workgroup of the grid); a kernel that does not fit is refused up front (DPCG_ERR_STATE: the caller takes
+    // the multi-launch path), and every wait inside is bounded (20 ms) for the case that somebody else holds CUs.
+#define DPCG_TEAM_LAUNCH_T(RPTV, WV, TV)                                                                                   \
     do {                                                                                                                   \
         const int lds = RPTV * WV * kTeamThreads * 10;                                                                     \
-        static bool attr_set = false;                                                                                      \
-        if (!attr_set) {                                                                                                   \
-            if (hipFuncSetAttribute((const void *)k_pcg_team<RPTV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != \
+        static int resident = -1;                                                                                          \
+        if (resident < 0) {                                                                                                \
+            if (hipFuncSetAttribute((const void *)k_pcg_team<RPTV, WV, TV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != \
                 hipSuccess)                                                                                                \
                 return DPCG_ERR_HIP;                                                                                       \
-            attr_set = true;                                                                                               \
+            int per_cu = 0;                                                                                                \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_pcg_team<RPTV, WV, TV>, kTeamThreads, \
+                                                             (size_t)lds) != hipSuccess)                                   \
+                return DPCG_ERR_HIP;                                                                                       \
+            resident = per_cu;                                                                                             \
         }                                                                                                                  \
-        hipLaunchKernelGGL((k_pcg_team<RPTV, WV>), grid, block, (size_t)lds, s, descs_dev, nsys);                          \
+        if (resident < 1) return DPCG_ERR_STATE;                                                                           \
+        hipLaunchKernelGGL((k_pcg_team<RPTV, WV, TV>), grid, block, (size_t)lds, s, descs_dev, nsys);                      \
+    } while (0)
+#define DPCG_TEAM_LAUNCH(RPTV, WV)                     \
+    do {                                               \
+        if (trace) DPCG_TEAM_LAUNCH_T(RPTV, WV, true); \
+        else DPCG_TEAM_LAUNCH_T(RPTV, WV, false);      \
     } while (0)
     if (max_slabs_per_wg <= 1) {
         if (max_row_len <= 5) DPCG_TEAM_LAUNCH(1, 5);
@@ -415,6 +430,7 @@ int launch_pcg_team(const TeamDesc *descs_dev, int nsys, int max_slabs_per_wg, i
         else DPCG_TEAM_LAUNCH(2, 7);
     }
 #undef DPCG_TEAM_LAUNCH
+#undef DPCG_TEAM_LAUNCH_T
     return DPCG_OK;
 }
 

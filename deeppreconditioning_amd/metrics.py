@@ -80,27 +80,3 @@ def inverse_loss_dense(systems_tril, preconditioners_tril) -> torch.Tensor:
     prod = torch.matmul(pre, systems)
     eye = torch.eye(systems.shape[1], device=prod.device).unsqueeze(0).expand((systems.shape[0], -1, -1))
     return torch.linalg.matrix_norm(prod - eye).mean()
-
-
-def _dense_pair(systems_tril, preconditioners_tril):
-    """Dense L (batch, N, N) and the mirrored dense A, as metrics.py:45-49,68-71,91-95 build them."""
-    pre = preconditioners_tril.dense()[:, 0]
-    systems = systems_tril.dense()[:, 0]
-    systems = systems + torch.tril(systems, -1).transpose(-1, -2)
-    return pre, systems
-
-
-def hutchinson_trace(systems_tril, preconditioners_tril) -> torch.Tensor:
-    """mean_b || (L_b L_b^T - A_b) v_b ||_2 for one standard-normal probe v_b per sample (metrics.py:58-78)."""
-    pre, systems = _dense_pair(systems_tril, preconditioners_tril)
-    vector = torch.randn(systems.shape[:2], device=systems.device, dtype=systems.dtype).unsqueeze(-1)
-    interim = torch.bmm(pre, torch.bmm(pre.transpose(-1, -2), vector))
-    interim = interim - torch.bmm(systems, vector)
-    return torch.linalg.vector_norm(interim.squeeze(-1), ord=2, dim=1).mean()
-
-
-def condition_loss(systems_tril, preconditioners_tril) -> torch.Tensor:
-    """mean_b sigma_max / sigma_min of L_b L_b^T A_b (metrics.py:81-100)."""
-    pre, systems = _dense_pair(systems_tril, preconditioners_tril)
-    sigmas = torch.linalg.svdvals(torch.matmul(torch.matmul(pre, pre.transpose(-1, -2)), systems))
-    return (sigmas.max(dim=1)[0] / sigmas.min(dim=1)[0]).mean()

@@ -211,6 +211,11 @@ int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]);
  * loop, [5] / [6] of [1] / [3]: waiting for the other workgroups' slots, [7] = the number of updates.  No reference counterpart
  * (the reference's loop is host Python, cg.py:70-87). */
 int dpcg_get_chip_info(dpcg_handle_t h, int32_t out[8], double trace_us[8]);
+/* Test hook: enqueue on `stream` a kernel of `workgroups` workgroups that each take a whole CU (all of its LDS) and spin for
+ * `milliseconds` -- what a long-running kernel of another stream or process does to the co-residency the one-launch solves (team,
+ * chip) rely on.  They bound every wait (20 ms) and fall back to the multi-launch path; the tests hold them to that with this call.
+ * No reference counterpart. */
+int dpcg_debug_occupy(int workgroups, double milliseconds, dpcg_stream_t stream);
 /* Copy the current factor L out (host arrays sized from dpcg_get_info's precond_nnz). */
 int dpcg_get_factor(dpcg_handle_t h, int32_t *rowptr, int32_t *col, double *val);
 

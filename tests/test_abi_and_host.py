@@ -189,6 +189,46 @@ def test_distributed_scatter_shard_gather_gloo_world2(count):
         np.testing.assert_array_equal(results[rank], expect)
 
 
+def _worker_config4(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = []
+
+    def local_solver(specs, **kw):
+        seen.extend((sp_.dim, sp_.n, sp_.seed) for sp_ in specs)
+        return _fake_local_solver(specs)
+
+    specs = [batch.SystemSpec(3, 256, s) for s in range(64)] if rank == 0 else None
+    out = batch.solve_specs_distributed(specs, local_solver=local_solver)
+    q.put((rank, out, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_config4_shape_gloo_world8():
+    """BASELINE config 4's exact shape -- 64 systems poisson3d(256), 8 ranks, 8 per rank -- through scatter / shard / gather over gloo
+    with a stand-in local solver (no GPU here): system s lands on rank s mod 8 with its own seed, every rank ends with the full
+    64-row table in batch order."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_config4, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    results = {r: (t, seen) for r, t, seen in (q.get(timeout=300) for _ in range(8))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    expect = _fake_local_solver([batch.SystemSpec(3, 256, s) for s in range(64)])
+    for rank in range(8):
+        table, seen = results[rank]
+        np.testing.assert_array_equal(table, expect)
+        assert seen == [(3, 256, s) for s in range(rank, 64, 8)]              # 8 per rank, system s on rank s mod 8
+
+
 # ---- the same for REAL matrices: the CSR arrays and right-hand sides travel, the solutions come back -------------
 def _fake_matrix_solver(items, **kw):
     """Stand-in for the GPU solve: x = A b computed from the arrays AS RECEIVED, so a corrupted or misrouted matrix shows

@@ -752,7 +752,7 @@ def test_reference_import_lines_resolve_through_the_compat_shim(D, monkeypatch):
     duration, iterations, info = cg_mod.preconditioned_conjugate_gradient(torch.from_numpy(A.toarray()), b, M)
     assert iterations == CO.pcg(A, O.rhs(400, 0), "jacobi", dinv=O.jacobi_dinv(A))[1] and info == 0
     assert hasattr(models, "PreconditionerNet") and hasattr(models, "PreconditionerSparseUNet")
-    for name, attrs in (("utils", ("sparse_matvec_mul", "benchmark_cg")), ("metrics", ("inverse_loss", "condition_loss")),
+    for name, attrs in (("utils", ("sparse_matvec_mul", "benchmark_cg")), ("metrics", ("inverse_loss", "frobenius_loss")),
                         ("data_set", ("SludgePatternDataSet", "StAnDataSet")),
                         ("test", ("BenchmarkSuite", "main"))):
         mod = importlib.import_module(f"uibk.deep_preconditioning.{name}")
@@ -2949,3 +2949,40 @@ def test_chip_solve_with_everything_written_through(D):
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
                          cwd=str(__import__("pathlib").Path(__file__).resolve().parents[1]))
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("name,make,form", [("poisson2d_150", lambda: O.poisson2d(150), "team"),
+                                            ("poisson3d_64", lambda: O.poisson3d(64), "chip")])
+def test_one_launch_solves_when_somebody_else_holds_cus(D, name, make, form):
+    """The one-launch solves (team: 4 097 .. 65 536 rows; chip: up to 1 048 576) need their workgroups co-resident.  A plain launch
+    cannot promise that when a long-running kernel of another stream holds CUs -- here 96 workgroups that take a whole CU each for
+    0.4 s (dpcg_debug_occupy).  Every wait inside is bounded (20 ms), the launch reports it, and the SAME call then solves through the
+    multi-launch path: right answer (that path's history, bit for bit), back within 80 ms instead of hanging; once the CUs are free
+    again a plain call is the one-launch form again."""
+    import time
+    A = make()
+    n = A.shape[0]
+    b = _dev(O.rhs(n, 2))
+    S = D.CsrSystem.from_any(A, reorder=None)
+    S.set_preconditioner(D.Jacobi())
+    if form == "team":
+        assert S.reduction_geometry()["team_by_default"]
+    else:
+        assert S.chip_info()["chip_by_default"]
+    one_launch = S.solve(b)
+    multi = S.solve(b, flags=D._lib.NO_SMALL)
+    assert one_launch.iterations == multi.iterations and not np.array_equal(one_launch.res_history, multi.res_history)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    D._lib.check(D._lib.lib().dpcg_debug_occupy(96, 400.0, side.cuda_stream))
+    time.sleep(0.03)                                           # the squatters are resident
+    t0 = time.perf_counter()
+    res = S.solve(b)
+    dt = time.perf_counter() - t0
+    assert res.status == 0 and res.iterations == multi.iterations
+    assert np.array_equal(res.res_history, multi.res_history) and torch.equal(res.x, multi.x)      # it WAS the multi-launch path
+    assert dt < 0.08, dt
+    side.synchronize()
+    again = S.solve(b)
+    assert np.array_equal(again.res_history, one_launch.res_history)
+    S.close()

@@ -212,3 +212,40 @@ def test_config3_unstructured_meshes_million_dof(D, name, make, expect):
     reduction trees -- the colour sweeps' launch-by-launch <r,z> included: counts and histories EQUAL."""
     out = _mesh_parity(D, make(), expect, 60)
     assert out["ic0_multicolor_rz_kind"] == 4          # 4-5 wide levels: colour sweeps, restated (never the tolerance branch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,make", [("quadtree_foam_1M", lambda: O.quadtree_fv_laplacian(1000, 0)),
+                                       ("quadtree_random_1M", lambda: O.quadtree_fv_laplacian(1000, 0, numbering="random")),
+                                       ("delaunay_1M", lambda: O.delaunay_laplacian(1000000, 0))])
+def test_million_row_meshes_full_length_histories(D, name, make):
+    """The 1M-row meshes to the END of their histories (the reference's defaults: rtol 1e-8 squared, cap 1024 -- cg.py:51), not the
+    first 60 updates: Jacobi and IC(0) in multicolour order through the plain multi-launch path against the C oracle with the device's
+    reduction trees on the system the handle iterates on -- counts, every residual of up to 1025, and x under Jacobi EQUAL."""
+    A = make()
+    n = A.shape[0]
+    b = O.rhs(n, 0)
+    S = D.CsrSystem.from_any(A)
+    perm = S.permutation() if S.reordered else np.arange(n)
+    B = _permuted(A, perm) if S.reordered else A
+    NO_SMALL = D._lib.NO_SMALL
+    S.set_preconditioner(D.Jacobi())
+    res = S.solve(_dev(b), flags=NO_SMALL)
+    _, it, hist, xs = CO.pcg(B, b[perm], "jacobi", dinv=O.jacobi_dinv(B), device_tree=S.reduction_geometry())
+    assert res.iterations == it and len(hist) == it + 1 and np.array_equal(res.res_history, hist), (name, res.iterations, it)
+    assert np.array_equal(res.x.cpu().numpy()[perm], xs)
+    S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+    nc, q = S.precond_ordering()
+    Lq = CO.ic0(_permuted(A, q))
+    qinv = np.empty(n, dtype=np.int32)
+    qinv[q] = np.arange(n, dtype=np.int32)
+    res = S.solve(_dev(b), flags=NO_SMALL)
+    geo = S.reduction_geometry()
+    assert geo["rz_kind"] == 4, geo
+    iperm = np.empty(n, dtype=np.int64)
+    iperm[perm] = np.arange(n)
+    geo["sweep_rows"] = CO.sweep_rows(Lq, iperm[q])
+    _, it_c, hist_c, _ = CO.pcg(B, b[perm], "llt_solve", L=Lq, precond_perm=qinv[perm], device_tree=geo)
+    assert res.iterations == it_c and np.array_equal(res.res_history, hist_c), (name, res.iterations, it_c)
+    assert it_c <= it            # (IC(0) never needs more updates than Jacobi here; the Delaunay system converges well inside the cap)
+    S.close()

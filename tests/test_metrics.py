@@ -1,4 +1,4 @@
-"""Dense losses of metrics.py:34-100 against values the reference itself returned (fixtures `metrics/*`, produced by
+"""The dense inverse loss of metrics.py:34-55 against values the reference itself returned (fixtures `metrics/*`, produced by
 tests/golden/make_golden.py on a duck-typed batch).  These are plain torch restatements: they run on the CPU here."""
 import numpy as np
 import torch
@@ -17,10 +17,7 @@ def _batches(golden):
 def test_dense_losses_match_the_reference(golden):
     systems, pre = _batches(golden)
     assert float(metrics.inverse_loss_dense(systems, pre)) == np.float32(golden["metrics/inverse_loss"])
-    np.testing.assert_allclose(float(metrics.condition_loss(systems, pre)), golden["metrics/condition_loss"], rtol=1e-5)
-    torch.manual_seed(7)
-    np.testing.assert_allclose(float(metrics.hutchinson_trace(systems, pre)),
-                               golden["metrics/hutchinson_trace_seed7_cpu"], rtol=1e-6)
+    assert not hasattr(metrics, "hutchinson_trace") and not hasattr(metrics, "condition_loss")     # outside the path
 
 
 def _sparse_batches(golden):
