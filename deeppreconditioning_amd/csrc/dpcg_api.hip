@@ -398,7 +398,7 @@ extern "C" int dpcg_destroy(dpcg_handle_t h) {
     dev_free(h->part_pq); dev_free(h->part_rz); dev_free(h->part_rr); dev_free(h->part_bb);
     dev_free(h->scal); dev_free(h->hist); dev_free(h->err_hist); dev_free(h->small_desc);
     dev_free(h->team_desc); dev_free(h->team_part); dev_free(h->team_sync);
-    dev_free(h->chip_part); dev_free(h->chip_zp);
+    dev_free(h->chip_part); dev_free(h->chip_zp); dev_free(h->chip_rt);
     if (h->scal_host) (void)hipHostFree(h->scal_host);
     HandleExtras ex;
     if (extras().take(h, ex)) {

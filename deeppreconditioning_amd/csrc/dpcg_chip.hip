@@ -42,43 +42,13 @@
 // x equal the CPU restatement's bit for bit.
 #include <algorithm>
 
-#include "dpcg_device.h"
+#include "dpcg_chip_device.h"
 
 namespace dpcg {
 
+using namespace chip;
+
 namespace {
-
-constexpr int kChipWGs = 256;           // one workgroup per CU
-constexpr int kChipThreads = 512;       // 8 waves: two per SIMD, 256 vector registers per lane
-constexpr int kChipMaxRpt = 8;          // rows per thread: n <= 256 * 512 * 8
-constexpr int kChipLdsSlots = 39;       // 8-byte value slots per thread kept in LDS: 39 * 512 * 8 = 159 744 B of the CU's 163 840
-constexpr unsigned long long kChipSpinTicks = 2000000ull;               // 20 ms of the 100 MHz constant clock
-constexpr unsigned long long kChipPending = 0x7ff8dead0badbeefULL;      // a quiet NaN that no arithmetic here produces
-constexpr int kChipZpPad = 4096;        // granules of slack behind each copy (group shifts; rows that do not exist gather there)
-constexpr int kChipS1Bytes = 4 * kChipWGs * 16;                // group-level slots: 4 sets x 256 workgroups x 16 B
-constexpr int kChipSlotBytes = kChipS1Bytes + 4 * 8 * 8 * 16;  // + chip-level slots: 4 sets x 8 destination groups x 8 source groups
-constexpr int kSc1 = 16;                // cache-policy operand of the buffer builtins on gfx950: bit 4 = sc1 (agent scope)
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t chip_rsrc(const void *p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ double lo_f64(const u32x4 &g) { return __hiloint2double((int)g.y, (int)g.x); }
-__device__ __forceinline__ double hi_f64(const u32x4 &g) { return __hiloint2double((int)g.w, (int)g.z); }
-__device__ __forceinline__ u32x4 pack_f64x2(double a, double b) {
-    u32x4 g;
-    g.x = (unsigned)__double2loint(a);
-    g.y = (unsigned)__double2hiint(a);
-    g.z = (unsigned)__double2loint(b);
-    g.w = (unsigned)__double2hiint(b);
-    return g;
-}
-__device__ __forceinline__ bool row_valid_bits(unsigned lens, int k) { return ((lens >> (4 * k)) & 8u) != 0; }
-__device__ __forceinline__ bool is_pending(const u32x4 &g) {
-    return (g.x == (unsigned)(kChipPending & 0xffffffffu) && g.y == (unsigned)(kChipPending >> 32)) ||
-           (g.z == (unsigned)(kChipPending & 0xffffffffu) && g.w == (unsigned)(kChipPending >> 32));
-}
 
 // RPT: rows per thread (2, 4, 8); WMAX: entry slots per row (5, 7); JAC: M = diag(1 / a_ii) (else M = I: z = r, no dinv registers).
 template <int RPT, int WMAX, bool JAC, int MODE>
@@ -208,8 +178,6 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
 
     // Two chip-wide sums at once, and a chip barrier in the same breath (see the header).  `publish`: the workgroup's granule stores
     // must be visible to whoever passes this point, so every wave drains them first.  Every workgroup returns the same bits.
-    unsigned gen = 0;
-    int sum_phase = 0;
     // DPCG_CHIP_TRACE: where an update's time goes -- ticks (100 MHz) of thread 0 of EVERY workgroup, accumulated in LDS (registers
     // are what this kernel does not have): [0] q = A p, [1] sum <p,Ap>, [2] vector update + publish, [3] sum <r,z>, [4] the loop,
     // [5] / [6] of [1] / [3] waiting for slots, [7] last stamp
@@ -223,93 +191,10 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
             s_tk[7] = now;
         }
     };
-    int wait_idx = 5;
-    // polls one slot per lane (lanes < count) until none is pending; false when the wait ran out
-    auto poll_slots = [&](u32x4 &sv, int off, int count) -> bool {
-        const bool mine = t < count;
-        sv = pack_f64x2(0.0, 0.0);
-        if (mine) sv = __builtin_amdgcn_raw_buffer_load_b128(part_rs, off, 0, kSc1);
-        unsigned spins = 0;
-        unsigned long long t0 = 0;
-        while (__ballot(mine && is_pending(sv)) != 0) {
-            __builtin_amdgcn_s_sleep(1);
-            if (mine && is_pending(sv)) sv = __builtin_amdgcn_raw_buffer_load_b128(part_rs, off, 0, kSc1);
-            if ((++spins & 255u) == 0) {
-                const unsigned long long now = wall_clock64();
-                if (t0 == 0) t0 = now;
-                else if (now - t0 > kChipSpinTicks || __hip_atomic_load(d.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    atomicExch(d.err, 1);
-                    return false;
-                }
-            }
-        }
-        return true;
-    };
-    auto chip_sum2 = [&](double a, double b2, bool publish, double &ra, double &rb) -> bool {
-        if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        double *slot = sh + (sum_phase & 1) * 16;
-        ++sum_phase;
-        a = wave_sum(a);
-        b2 = wave_sum(b2);
-        if ((t & 63) == 63) {
-            slot[t >> 6] = a;
-            slot[8 + (t >> 6)] = b2;
-        }
-        __syncthreads();                                           // (behind every wave's drain)
-        const int set_cur = (int)(gen & 3u), set_nxt = (int)((gen + 2u) & 3u);
-        double *const sres = s_res[gen & 1u];
-        ++gen;
-        if (t < 64) {                                              // wave 0 does the exchange
-            const unsigned plo = (unsigned)(kChipPending & 0xffffffffu), phi = (unsigned)(kChipPending >> 32);
-            u32x4 pend;
-            pend.x = plo; pend.y = phi; pend.z = plo; pend.w = phi;
-            const unsigned long long w0 = timed ? wall_clock64() : 0;
-            double ta, tb;
-            int ok = 1;
-            // hop 1: the group's 32 pairs
-            if (t == 0) {
-                double sa = 0.0, sb = 0.0;
-#pragma unroll
-                for (int w = 0; w < kChipThreads / 64; ++w) {
-                    sa += slot[w];
-                    sb += slot[8 + w];
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-arm of the previous generation has landed
-                const int o_n = (set_nxt * kChipWGs + v) * 16, o_c = (set_cur * kChipWGs + v) * 16;
-                if (local) {
-                    __builtin_amdgcn_raw_buffer_store_b128(pend, part_rs, o_n, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2(sa, sb), part_rs, o_c, 0, 0);
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(pend, part_rs, o_n, 0, kSc1);
-                    __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2(sa, sb), part_rs, o_c, 0, kSc1);
-                }
-            }
-            u32x4 sv;
-            ok = poll_slots(sv, (set_cur * kChipWGs + grp * 32 + t) * 16, 32) ? 1 : 0;
-            double ga = wave_sum(lo_f64(sv)), gb = wave_sum(hi_f64(sv));        // (lanes 32-63 add +0.0)
-            // hop 2: eight members of the group hand its pair to the eight groups, everybody sums the eight pairs of its group's line
-            if (t == 63 && rank < 8) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int o_n = kChipS1Bytes + ((set_nxt * 8 + rank) * 8 + grp) * 16, o_c = kChipS1Bytes + ((set_cur * 8 + rank) * 8 + grp) * 16;
-                __builtin_amdgcn_raw_buffer_store_b128(pend, part_rs, o_n, 0, kSc1);
-                __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2(ga, gb), part_rs, o_c, 0, kSc1);
-            }
-            if (ok) ok = poll_slots(sv, kChipS1Bytes + ((set_cur * 8 + grp) * 8 + t) * 16, 8) ? 1 : 0;
-            if (timed) s_tk[wait_idx] += wall_clock64() - w0;
-            ta = wave_sum(lo_f64(sv));
-            tb = wave_sum(hi_f64(sv));                                          // (lanes 8-63 add +0.0)
-            if (t == 63) {
-                sres[0] = ta;
-                sres[1] = tb;
-                s_flag = ok;
-            }
-        }
-        __syncthreads();
-        if (!s_flag) return false;
-        ra = sres[0];
-        rb = sres[1];
-        return true;       // (sres is written again two reductions on, behind the barriers of the next one)
-    };
+    Exchange X;
+    X.part_rs = part_rs; X.v = v; X.grp = grp; X.rank = rank; X.sh = sh; X.s_res = s_res; X.s_flag = &s_flag; X.err = d.err;
+    X.wait_acc = timed ? &s_tk[5] : nullptr;
+    auto chip_sum2 = [&](double a, double b2, bool publish, double &ra, double &rb) -> bool { return exchange2(X, a, b2, publish, ra, rb); };
     unsigned far_rows = 0xffu;              // bit k: row k of this thread is gathered by another group (all of them until `local` holds)
     int row0_l = row0;                      // an opaque copy per update: 16 hoisted store addresses are 16 registers the loop does not have
     auto publish = [&](int k, double zk, double pk) {
@@ -322,21 +207,8 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     double dummy = 0.0, dummy2 = 0.0;
     // ---- where the groups sit: every workgroup reports its XCD, everybody reads the 256 answers ---------------------------
     if (d.xcc) {
-        if (t == 0) {
-            unsigned xid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xid));
-            __hip_atomic_store(d.xcc + v, (int)(xid & 0xf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        alive = chip_sum2(0.0, 0.0, true, dummy, dummy2);
-        if (alive) {
-            int same = 1;
-            if (t < kChipWGs) {
-                const int mine = __hip_atomic_load(d.xcc + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int first = __hip_atomic_load(d.xcc + (t & ~31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                same = mine == first ? 1 : 0;
-            }
-            local = __syncthreads_and(same) != 0;
-        }
+        local = groups_on_one_xcd(X, d.xcc, alive);
+        X.local = local;
         if (local) {
             far_rows = 0;
 #pragma unroll
@@ -404,10 +276,10 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
             if (row_on(k)) pq_loc += q[k] * p[k];
         double pq = 0.0;
         stamp(0);
-        wait_idx = 5;
+        if (timed) X.wait_acc = &s_tk[5];
         if (!(alive = chip_sum2(pq_loc, 0.0, false, pq, dummy))) break;         // barrier A: every SpMV of this update is done
         stamp(1);
-        wait_idx = 6;
+        if (timed) X.wait_acc = &s_tk[6];
         const double alpha = rz / pq;                             // cg.py:78
         double rz_new_loc = 0.0, rr_loc = 0.0;
         asm volatile("" : "+v"(row0_l), "+v"(far_rows));

@@ -275,7 +275,8 @@ struct dpcg_system {
     double *team_part = nullptr;             // the team's reduction partials (4 x 32 doubles)
     unsigned int *team_sync = nullptr;       // [0] barrier counter, [1] error flag
     double *chip_part = nullptr;             // the chip kernel's reduction slots (4 x 256 x 2 doubles) + 8 trace words + the error flag
-    double *chip_zp = nullptr;               // ... and its published granules (2 n doubles)
+    double *chip_zp = nullptr;               // ... and its published granules
+    double *chip_rt = nullptr;               // M = L L^T multiplied on the chip: the published r and t = L^T r
     double chip_trace_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // ... over the 256 workgroups: SpMV phase max / mean, publish max / mean, `local`
     double chip_trace_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DPCG_CHIP_TRACE: us per update by phase of the last chip solve ([7] = updates)
     dpcg::SmallEll ell_a, ell_m, ell_t;      // slab-ELL copies of A, M (or L), L^T for the small-system kernel
@@ -468,6 +469,29 @@ struct ChipDesc {
     int *err;
     unsigned long long *dbg;   // DPCG_CHIP_TRACE=1: 8 words per workgroup, ticks (100 MHz) its thread 0 spent per phase of the updates; else null
 };
+// dpcg_chip_llt.hip: the same for M = L L^T multiplied (6 145 .. 262 144 rows, rows of A <= 7 and of L, L^T <= 16 entries)
+struct ChipLltDesc {
+    int n, max_iter, init_check_r, hist_cap, per, band;
+    const int32_t *rp, *ci;
+    const double *val;
+    const int32_t *lrp, *lci;          // L (what z = L t reads) ...
+    const double *lval;
+    const int32_t *trp, *tci;          // ... and L^T (what t = L^T r reads), both in the numbering the handle iterates in
+    const double *tval;
+    const double *b, *x0;
+    double *x, *hist;
+    double *zp;                // 2 x (n + 4096) granules {z, p}
+    double *rpub, *tpub;       // 2 x (n + 4096) granules each: r and t = L^T r as the other workgroups see them
+    double rtol_sq, atol_sq;
+    Scalars *out;
+    double *part;
+    int *err;
+    int *xcc;
+    unsigned int nonce;        // != 0: r and t travel as self-validating granules keyed by (nonce, generation); unique per launch
+};
+int chip_llt_max_rows();
+int chip_llt_max_row_len();
+int launch_pcg_chip_llt(const ChipLltDesc &d, int max_a, int max_l, hipStream_t s, bool check_only = false);
 int chip_max_rows();
 int chip_max_row_len();
 int chip_max_band();

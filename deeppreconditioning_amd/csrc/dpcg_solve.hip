@@ -2,6 +2,7 @@
 // update by update) ahead of a progress word the GPU posts to pinned memory, the whole-solve kernel for small systems,
 // and the batch entry point.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -800,6 +801,111 @@ static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, dou
     return sc.status;
 }
 
+// M = L L^T multiplied (the learned technique, IC multiplied) beyond the one-workgroup kernel: the whole chip, L and L^T resident
+static const CsrDev &llt_l(const dpcg_system *h) { return h->perm ? h->Lp : h->L; }
+static const CsrDev &llt_t(const dpcg_system *h) { return h->perm ? h->Ltp : h->Lt; }
+static bool chip_llt_eligible(const dpcg_system *h, int flags, const double *x_true) {
+    static const bool enabled = [] {
+        const char *e = getenv("DPCG_CHIP");
+        if (e && e[0] == '0') return false;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        return cus >= chip_workgroups();
+    }();
+    if (!enabled || x_true || h->precond != DPCG_PRECOND_LLT_MULTIPLY) return false;
+    if (flags & (DPCG_SPMV_F32 | DPCG_NO_TEAM | DPCG_NO_FUSE | DPCG_VAL32_IF_LOSSLESS)) return false;
+    if (h->A.n <= kSmallMaxN || h->A.n > chip_llt_max_rows()) return false;
+    if (h->planA.max_row_len < 1 || h->planA.max_row_len > chip_max_row_len()) return false;
+    const int ml = std::max(h->planL.max_row_len, h->planLt.max_row_len);
+    if (h->planL.max_row_len < 1 || h->planLt.max_row_len < 1 || ml > chip_llt_max_row_len()) return false;
+    if (ml > 8 && h->A.n > chip_llt_max_rows() / 2) return false;      // (two rows a thread of 16-entry factor rows: beyond the registers)
+    const int band = std::max(h->planA.max_band, std::max(h->planL.max_band, h->planLt.max_band));
+    if (h->planA.max_band < 0 || h->planL.max_band < 0 || h->planLt.max_band < 0 || band > chip_max_band()) return false;
+    return true;
+}
+
+static int solve_chip_llt_one(dpcg_system *h, const double *b, const double *x0, double *x, double rtol_sq, double atol_sq,
+                              int max_iter, int flags, hipStream_t s, int *iters, double *final_res, double *seconds,
+                              double *res_history) {
+    const int64_t n = h->A.n;
+    DPCG_TRY(ensure_work(h, max_iter, false, false));
+    const int kSlots = chip_slot_doubles();
+    if (!h->chip_part) DPCG_TRY(dev_alloc(&h->chip_part, kSlots + 8 * 256 + 2 + 128));
+    if (!h->chip_zp) DPCG_TRY(dev_alloc(&h->chip_zp, chip_zp_doubles(n)));
+    if (!h->chip_rt) DPCG_TRY(dev_alloc(&h->chip_rt, 2 * chip_zp_doubles(n)));      // two vectors of 2 x (n + pad) granules
+    if (h->perm) {
+        if (!h->pb) DPCG_TRY(dev_alloc(&h->pb, n));
+        launch_gather_f64(n, h->perm, b, h->pb, s);
+        b = h->pb;
+        if (x0) {
+            launch_gather_f64(n, h->perm, x0, h->t, s);
+            x0 = h->t;
+        }
+    }
+    const CsrDev &Lm = llt_l(h), &Tm = llt_t(h);
+    ChipLltDesc d;
+    memset(&d, 0, sizeof(d));
+    d.n = (int)n;
+    d.max_iter = max_iter;
+    d.init_check_r = (flags & DPCG_INIT_CHECK_R) ? 1 : 0;
+    d.hist_cap = h->hist_cap;
+    d.per = chip_rows_per_wg(n);
+    d.band = std::max(h->planA.max_band, std::max(h->planL.max_band, h->planLt.max_band));
+    d.rp = h->A.rowptr; d.ci = h->A.col; d.val = h->A.val;
+    d.lrp = Lm.rowptr; d.lci = Lm.col; d.lval = Lm.val;
+    d.trp = Tm.rowptr; d.tci = Tm.col; d.tval = Tm.val;
+    d.b = b; d.x0 = x0;
+    d.x = (x && !h->perm) ? x : h->x;
+    d.hist = h->hist;
+    d.zp = h->chip_zp;
+    d.rpub = h->chip_rt;
+    d.tpub = h->chip_rt + chip_zp_doubles(n);
+    d.rtol_sq = rtol_sq; d.atol_sq = atol_sq;
+    d.out = h->scal;
+    d.part = h->chip_part;
+    d.err = reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256);
+    static const bool plain_ok = [] { const char *e = getenv("DPCG_CHIP_LOCAL"); return !(e && e[0] == '0'); }();
+    d.xcc = plain_ok ? reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256 + 2) : nullptr;
+    // r and t = L^T r reach the neighbours as self-validating granules keyed by a per-launch nonce (DPCG_CHIP_LLT_SYNC=0, development:
+    // plain vectors and a chip-wide barrier per product)
+    static const bool tagged = [] { const char *e = getenv("DPCG_CHIP_LLT_SYNC"); return !(e && e[0] == '0'); }();
+    static std::atomic<unsigned> launch_nonce{0};
+    unsigned nonce = 0;
+    if (tagged)
+        do { nonce = ++launch_nonce; } while (nonce == 0);
+    d.nonce = nonce;
+    const int max_l = std::max(h->planL.max_row_len, h->planLt.max_row_len);
+    const int st0 = launch_pcg_chip_llt(d, h->planA.max_row_len, max_l, s, true);
+    if (st0 != DPCG_OK) return st0;
+    launch_fill_pending(h->chip_part, kSlots, s);
+    DPCG_HIP(hipMemsetAsync(d.err, 0, 2 * sizeof(int), s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    std::lock_guard<std::mutex> one_team_launch(team_launch_mutex());
+    const auto t0 = std::chrono::steady_clock::now();                                // cg.py:69 (the launch is the loop)
+    DPCG_TRY(launch_pcg_chip_llt(d, h->planA.max_row_len, max_l, s));
+    DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    const auto t1 = std::chrono::steady_clock::now();                                // cg.py:88
+    DPCG_CHECK_LAUNCH();
+    const Scalars sc = *h->scal_host;
+    if (sc.status < 0) {
+        set_error("chip solve (M = L L^T): a workgroup waited (20 ms) for one that never became resident");
+        return sc.status;
+    }
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    if (iters) *iters = sc.k;
+    if (final_res) *final_res = sc.res;
+    bool pending = false;
+    if (res_history) {
+        DPCG_HIP(hipMemcpyAsync(res_history, h->hist, (size_t)(sc.k + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+        pending = true;
+    }
+    if (x && h->perm) launch_scatter_f64(n, h->perm, h->x, x, s);
+    if (pending) DPCG_HIP(hipStreamSynchronize(s));
+    return sc.status;
+}
+
 extern "C" int dpcg_debug_occupy(int workgroups, double milliseconds, dpcg_stream_t stream) {
     if (workgroups < 1 || workgroups > 4096 || !(milliseconds > 0.0) || milliseconds > 2000.0) return invalid("dpcg_debug_occupy: bad arguments");
     DPCG_TRY(launch_occupy(workgroups, milliseconds, (hipStream_t)stream));
@@ -809,7 +915,7 @@ extern "C" int dpcg_debug_occupy(int workgroups, double milliseconds, dpcg_strea
 
 extern "C" int dpcg_get_chip_info(dpcg_handle_t h, int32_t out[8], double trace_us[8]) {
     if (!h || !out) return invalid("dpcg_get_chip_info: NULL argument");
-    const bool el = chip_eligible(h, 0, nullptr);
+    const bool el = chip_eligible(h, 0, nullptr) || chip_llt_eligible(h, 0, nullptr);
     out[0] = el ? (chip_default(h, 0) ? 2 : 1) : 0;          // 2: a plain dpcg_solve takes the chip kernel
     out[1] = chip_workgroups();
     out[2] = chip_threads();
@@ -856,6 +962,11 @@ extern "C" int dpcg_solve(dpcg_handle_t h, const double *b, const double *x0, do
                                       seconds, res_history);
         if (st != DPCG_ERR_STATE) return st;
         // the workgroups never became co-resident, or the kernel was refused up front: the multi-launch path needs no such thing
+    }
+    if (chip_llt_eligible(h, flags, x_true) && ((flags & DPCG_TEAM) || chip_default(h, flags))) {
+        const int st = solve_chip_llt_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
+                                          seconds, res_history);
+        if (st != DPCG_ERR_STATE) return st;
     }
     Solve sv;
     sv.h = h;

@@ -2186,8 +2186,12 @@ def test_bench_script_control_flow_at_two_ranks(golden):
     total = line["value"] * line["ms_per_step"] * 1e-3 * line["steps"]       # iterations of all ranks in the timed region
     assert abs(total - 2 * 2 * it) < 0.01 * 2 * 2 * it, total
     rf = line["roofline"]
-    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0.3 < rf["frac"] < 1.0 and rf["achieved"] > 0
-    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["us_per_launch"] * 1e-6) / 1e9) < 1.0
+    # the timed solve is the whole-chip kernel (dpcg_chip.hip): its ALGORITHMIC bytes are served on chip, so they exceed what HBM could
+    # deliver (frac > 1 is the point); the streaming SpMV kernel that serves larger systems is reported beside it, below the peak
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["achieved"] > 0 and rf["kernel"].startswith("k_pcg_chip")
+    assert rf["updates_per_launch"] == it and 0.5 < rf["frac"] < 6.0 and rf["regime"].startswith("on_chip_resident")
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["us_per_launch"] * 1e-6) / 1e9) < 0.002 * rf["achieved"]
+    assert 0.3 < rf["streaming_spmv_kernel"]["frac"] < 1.0 and rf["spmv_phase"]["us_per_update"] > 0
     assert "cpu_baseline" not in line and "extra" not in line
     _check_scatter_gather_keys(line, systems=2, it=it, mode="specs")
 
@@ -2985,4 +2989,44 @@ def test_one_launch_solves_when_somebody_else_holds_cus(D, name, make, form):
     side.synchronize()
     again = S.solve(b)
     assert np.array_equal(again.res_history, one_launch.res_history)
+    S.close()
+
+
+@pytest.mark.parametrize("name,make,factor", [
+    ("poisson2d_256_learned_like", lambda: O.poisson2d(256), "learned"),        # BASELINE config 2's shape: 65 536 rows, 15 entries a row of L
+    ("poisson2d_100_ic0", lambda: O.poisson2d(100), "ic0"),                     # 10 000 rows: most threads without a row
+    ("poisson3d_30_ic0", lambda: O.poisson3d(30), "ic0"),                       # 7 entries a row of A
+    ("poisson2d_400_ic0", lambda: O.poisson2d(400), "ic0"),                     # 160 000 rows: two rows a thread
+    ("unstructured2d_300_ic0", lambda: O.unstructured_like(O.poisson2d(300), seed=2), "ic0")])   # 90 000 rows, scattered: reordered inside the library
+def test_chip_llt_solve_equals_the_device_tree_oracle_bit_for_bit(D, name, make, factor):
+    """M = L L^T MULTIPLIED (test.py:81-88,100-105) beyond the one-workgroup kernel: a plain call is ONE launch on the whole chip with
+    A, L^T and L resident (dpcg_chip_llt.hip).  Against the C oracle with that kernel's reduction tree and the SAME factor: history,
+    count and x EQUAL -- x0 and a capped run included -- and the multi-launch path within 1e-10 where the recurrence is stable."""
+    A = make()
+    n = A.shape[0]
+    b = O.rhs(n, 0)
+    S = D.CsrSystem.from_any(A)
+    perm = S.permutation() if S.reordered else None
+    assert S.reordered == name.startswith("unstructured")
+    L = O.learned_like_factor_preconditioning(A) if factor == "learned" else CO.ic0(A)
+    S.set_preconditioner(D.LLtMultiply(L))
+    ci = S.chip_info()
+    assert ci["chip_by_default"], ci
+    B = _permuted(A, perm) if perm is not None else A
+    bb = b[perm] if perm is not None else b
+    Lq = _permuted(L, perm) if perm is not None else L          # a reordered handle multiplies by P L P^T and its transpose (rows summed in THEIR column order)
+    tree = {**S.reduction_geometry(), "form": "chip", "rows_per_workgroup": ci["rows_per_workgroup"]}
+    for x0, max_iter in ((None, 1024), (O.rhs(n, 5), 40)):
+        res = S.solve(_dev(b), None if x0 is None else _dev(x0), max_iter=max_iter)
+        x0p = None if x0 is None else (x0[perm] if perm is not None else x0)
+        _, it, hist, x = CO.pcg(B, bb, "llt_multiply", L=Lq, x0=x0p, max_iter=max_iter, device_tree=tree)
+        assert res.iterations == it, (name, res.iterations, it)
+        assert np.array_equal(res.res_history, hist), (name, int(np.argmax(res.res_history != hist[:len(res.res_history)])))
+        xs = res.x.cpu().numpy()
+        assert np.array_equal(xs[perm] if perm is not None else xs, x), name
+    multi = S.solve(_dev(b), flags=D._lib.NO_SMALL)
+    full = S.solve(_dev(b))
+    assert abs(multi.iterations - full.iterations) <= 1 and not np.array_equal(multi.res_history, full.res_history)
+    m = min(len(multi.res_history), len(full.res_history), 40)
+    np.testing.assert_allclose(multi.res_history[:m], full.res_history[:m], rtol=1e-9)
     S.close()
