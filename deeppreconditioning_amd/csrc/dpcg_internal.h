@@ -353,7 +353,7 @@ void launch_fused_init(Scalars *scal, hipStream_t s);
 // K3 with the x update deferred to every second update (see k_update_xp_deferred); `odd`: this is update 1, 3, 5, ...
 void launch_update_xp_deferred(bool odd, int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
                                const double *z, const double *p_in, double *p_out, double *x, float *p32, double *hist,
-                               int hist_cap, int grid, hipStream_t s, const double *zd, int n_part_rr);
+                               int hist_cap, int grid, hipStream_t s, const double *zd, int n_part_rr, bool nt = false);
 void launch_final_deferred(int64_t n, Scalars *scal, double *x, const double *p0, const double *p1, int grid,
                            hipStream_t s);
 void launch_final_fused(int64_t n, Scalars *scal, const double *part_rr, int n_part, double *hist, int hist_cap,
@@ -377,7 +377,7 @@ void launch_update_r_two_kernel(int precond_fused, int64_t n, Scalars *scal, con
                                 double *part_rr, int grid, hipStream_t s);
 void launch_update_r(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
                      const double *q, double *r, const double *dinv, double *z, double *part_rz, double *part_rr,
-                     int grid, hipStream_t s, int store_z = 1);
+                     int grid, hipStream_t s, int store_z = 1, bool nt = false);
 void launch_update_r_ride(int64_t n, Scalars *scal, const double *part_pq, int n_part_pq, const double *q, double *r,
                           const double *first_level_diag, const int32_t *pos, double *lm_out, int first_level_rows,
                           double *part_rr, int grid, hipStream_t s, bool two_kernel = false);

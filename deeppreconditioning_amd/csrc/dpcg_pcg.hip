@@ -5,6 +5,19 @@
 
 namespace dpcg {
 
+// 16-byte non-temporal accesses (the builtin wants a native vector type)
+typedef double nt_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 nt_load2(const double2 *p) {
+    const nt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_d2 *>(p));
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void nt_store2(double2 v, double2 *p) {
+    nt_d2 w;
+    w.x = v.x;
+    w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_d2 *>(p));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Vector updates of the iteration (cg.py:78-83) in two passes of 40 bytes per row each:
 //   K2 (k_update_r):  alpha;  r -= alpha q;  z = dinv r;  partials <r,z>, <r,r>     reads q,r,dinv  writes r,z
@@ -21,7 +34,10 @@ struct RideArgs {
     double *out;            // the lower solve's solution vector by position (Levels::lm_out)
     int count;              // rows of the first level (positions 0 .. count)
 };
-template <int PRE, bool F2 = false>   // F2: KB of the two-kernel iteration (workgroup 0 also advances k and rz_prev)
+// NT (systems whose vectors stream from HBM: 256^3): q -- read once here -- is loaded and r stored non-temporally, so that the kernel
+// does not leave an L2 full of dirty lines behind (their write-back is what the next launch waits for: 6 us at every K3 -> K1
+// boundary of the 256^3 loop) and the streams do not evict what IS reused.
+template <int PRE, bool F2 = false, bool NT = false>   // F2: KB of the two-kernel iteration (workgroup 0 also advances k and rz_prev)
 __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restrict__ sc,
                                                      const double *__restrict__ part_pq, int n_part_pq,
                                                      const double *__restrict__ q, double *__restrict__ r,
@@ -41,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
     int2 pa = make_int2(0, 0);
     bool have = i < n2;
     if (have) {
-        qa = q2[i];
+        qa = NT ? nt_load2(q2 + i) : q2[i];
         ra = r2[i];
         if (PRE == 1 || PRE == 3) da = d2[i];
         if (PRE == 3) pa = pos2[i];
@@ -77,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
         i += stride;
         have = i < n2;
         if (have) {
-            qa = q2[i];
+            qa = NT ? nt_load2(q2 + i) : q2[i];
             ra = r2[i];
             if (PRE == 1 || PRE == 3) da = d2[i];
             if (PRE == 3) pa = pos2[i];
@@ -85,7 +101,8 @@ __global__ __launch_bounds__(kBlock) void k_update_r(int64_t n, Scalars *__restr
         double2 rn;
         rn.x = rc.x - alpha * qc.x;                                     // cg.py:80
         rn.y = rc.y - alpha * qc.y;
-        r2[cur] = rn;
+        if (NT) nt_store2(rn, r2 + cur);
+        else r2[cur] = rn;
         a_rr += rn.x * rn.x;                                            // cg.py:86
         a_rr += rn.y * rn.y;
         if (PRE == 3) {                                                 // first level of L y = r (cg.py:81)
@@ -189,8 +206,18 @@ void launch_final_fused(int64_t n, Scalars *scal, const double *part_rr, int n_p
 
 void launch_update_r(int precond_fused, int64_t n, Scalars *scal, const double *part_pq, int n_part_pq,
                      const double *q, double *r, const double *dinv, double *z, double *part_rz, double *part_rr,
-                     int grid, hipStream_t s, int store_z) {
+                     int grid, hipStream_t s, int store_z, bool nt) {
     const RideArgs none{nullptr, nullptr, 0};
+    if (nt && precond_fused == 1 && !store_z) {
+        hipLaunchKernelGGL((k_update_r<1, false, true>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, dinv, z,
+                           part_rz, part_rr, store_z, none);
+        return;
+    }
+    if (nt && precond_fused == 0) {
+        hipLaunchKernelGGL((k_update_r<0, false, true>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, dinv, z,
+                           part_rz, part_rr, store_z, none);
+        return;
+    }
     if (precond_fused == 0)
         hipLaunchKernelGGL(k_update_r<0>, dim3(grid), dim3(kBlock), 0, s, n, scal, part_pq, n_part_pq, q, r, dinv, z,
                            part_rz, part_rr, store_z, none);
@@ -336,7 +363,7 @@ void launch_update_xp(int64_t n, Scalars *scal, const double *part_rz, const dou
 //                                  odd update j+1 -> x = (x + alpha_j p_j) + alpha_{j+1} p_{j+1}, then p_{j+2} over p_j.
 // Same operations in the same order as x += alpha p every update (cg.py:79): bit-identical iterates; per two updates
 // one x read and one x write are replaced by one extra read of p.  k_final_deferred applies a pending half.
-template <bool P32, bool ODD, bool MANY>
+template <bool P32, bool ODD, bool MANY, bool NT = false>   // NT: as in k_update_r -- x (read and rewritten every second update) and the new p
 __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalars *__restrict__ sc,
                                                                const double *__restrict__ part_rz,
                                                                const double *__restrict__ part_rr, int n_part,
@@ -361,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalar
         pa = pi2[i];
         if (ODD) {
             qa = po2[i];
-            xa = x2[i];
+            xa = NT ? nt_load2(x2 + i) : x2[i];
         }
         if (zd) da = zd2[i];
     }
@@ -396,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalar
             pa = pi2[i];
             if (ODD) {
                 qa = po2[i];
-                xa = x2[i];
+                xa = NT ? nt_load2(x2 + i) : x2[i];
             }
             if (zd) da = zd2[i];
         }
@@ -410,12 +437,14 @@ __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalar
             xn.y = xc.y + alpha_prev * qc.y;
             xn.x = xn.x + alpha * pc.x;                                 // ... and of this one
             xn.y = xn.y + alpha * pc.y;
-            x2[cur] = xn;
+            if (NT) nt_store2(xn, x2 + cur);
+            else x2[cur] = xn;
         }
         double2 pn;
         pn.x = zc.x + beta * pc.x;                                      // cg.py:83
         pn.y = zc.y + beta * pc.y;
-        po2[cur] = pn;
+        if (NT) nt_store2(pn, po2 + cur);
+        else po2[cur] = pn;
         if (P32) f2[cur] = make_float2((float)pn.x, (float)pn.y);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -433,8 +462,17 @@ __global__ __launch_bounds__(kBlock) void k_update_xp_deferred(int64_t n, Scalar
 
 void launch_update_xp_deferred(bool odd, int64_t n, Scalars *scal, const double *part_rz, const double *part_rr, int n_part,
                                const double *z, const double *p_in, double *p_out, double *x, float *p32, double *hist,
-                               int hist_cap, int grid, hipStream_t s, const double *zd, int n_part_rr) {
+                               int hist_cap, int grid, hipStream_t s, const double *zd, int n_part_rr, bool nt) {
     const bool many = n_part > kVecPartSlots * kBlock;
+    if (nt && !p32 && !many) {
+        if (odd)
+            hipLaunchKernelGGL((k_update_xp_deferred<false, true, false, true>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, part_rr,
+                               n_part, z, p_in, p_out, x, p32, hist, hist_cap, zd, n_part_rr);
+        else
+            hipLaunchKernelGGL((k_update_xp_deferred<false, false, false, true>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz, part_rr,
+                               n_part, z, p_in, p_out, x, p32, hist, hist_cap, zd, n_part_rr);
+        return;
+    }
 #define DPCG_K3D(P32V, ODDV, MANYV)                                                                                     \
     hipLaunchKernelGGL((k_update_xp_deferred<P32V, ODDV, MANYV>), dim3(grid), dim3(kBlock), 0, s, n, scal, part_rz,     \
                        part_rr, n_part, z, p_in, p_out, x, p32, hist, hist_cap, zd, n_part_rr)

@@ -27,6 +27,13 @@ static bool defer_x_eligible(const dpcg_system *h, int flags, const double *x_tr
     return enabled && !x_true && !fuse_eligible(h, flags, x_true);
 }
 
+// The vector kernels of a system whose streams exceed the Infinity Cache (the x-tile SpMV reads them non-temporally: 256^3) store what
+// they produce non-temporally too.  DPCG_VEC_NT=0/1: development knob.
+static bool vec_nt(const dpcg_system *h) {
+    static const int knob = [] { const char *e = getenv("DPCG_VEC_NT"); return e ? atoi(e) : -1; }();
+    return knob >= 0 ? knob != 0 : (h->planA.kernel == SPMV_TILE && h->planA.stream_nt);
+}
+
 // One PCG update (cg.py:75-86) as kernel launches on `s`; `j` = index of this update within the solve (its parity
 // selects the p buffer in the deferred-x form: a replayed graph chunk has an even length and starts at an even j).
 static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hipStream_t s, int j) {
@@ -73,7 +80,7 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
                              h->lvlL.level_ptr[1], h->part_rr, h->vec_grid, s);
     else
         launch_update_r(pre, n, h->scal, h->part_pq, h->planA.grid, h->q, h->r, h->dinv, h->z, h->part_rz, h->part_rr,
-                        h->vec_grid, s, z_on_the_fly ? 0 : 1);
+                        h->vec_grid, s, z_on_the_fly ? 0 : 1, vec_nt(h));
     const int np_rz = pre == 2 ? rz_partial_count(h) : h->vec_grid;
     if (pre == 2) {
         int np = 0;
@@ -84,7 +91,7 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
     if (defer_x)
         launch_update_xp_deferred((j & 1) != 0, n, h->scal, h->part_rz, h->part_rr, np_rz, z, p_cur, p_next, h->x,
                                   f32 ? h->p32 : nullptr, h->hist, h->hist_cap, h->vec_grid, s,
-                                  z_on_the_fly ? h->dinv : nullptr, h->vec_grid);
+                                  z_on_the_fly ? h->dinv : nullptr, h->vec_grid, vec_nt(h));
     else
         launch_update_xp(n, h->scal, h->part_rz, h->part_rr, np_rz, z, h->p, h->x, f32 ? h->p32 : nullptr, h->hist,
                          h->hist_cap, h->vec_grid, s, z_on_the_fly ? h->dinv : nullptr, h->vec_grid);
@@ -99,7 +106,7 @@ static int enqueue_iteration(dpcg_system *h, int flags, const double *x_true, hi
 static int ensure_graph(dpcg_system *h, int flags, int chunk) {
     const int key = (h->precond << 8) | (flags & (DPCG_SPMV_F32 | DPCG_VAL32_IF_LOSSLESS | DPCG_NO_FUSE)) |
                     (h->A.val32_lossless == 1 ? 64 : 0) | (fuse_eligible(h, flags, nullptr) ? 128 : 0) |
-                    (defer_x_eligible(h, flags, nullptr) ? 1024 : 0);
+                    (defer_x_eligible(h, flags, nullptr) ? 1024 : 0) | (vec_nt(h) ? 2048 : 0);
     if (h->graph_exec && h->graph_key == key && h->graph_chunk == chunk) return DPCG_OK;
     drop_graph(h);
     HandleExtras &ex = extras()[h];
