@@ -15,22 +15,26 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 
 def load(d):
+    """Counter values of the k_pcg_chip launches, keyed by (system index, counter): the systems of tools/pmc_chip_run.py run one
+    after another, each through its own instantiation of the kernel (<8, 7, ...> for the 7-point system, <8, 5, ...> for the
+    5-point one), so a system is told by the order in which the instantiations first appear."""
     out = collections.defaultdict(list)
     for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
         rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
-        seg, last = -1, None
+        order = []
         for r in rows:
-            name = r["Kernel_Name"].split("(")[0].replace("void dpcg::", "").replace("dpcg::", "").replace("(anonymous namespace)::", "")
-            if name.startswith("k_gen_poisson") and r["Dispatch_Id"] != last:
-                seg += 1
-                last = r["Dispatch_Id"]
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void dpcg::", "").replace("dpcg::", "")
             if name.startswith("k_pcg_chip"):
-                out[(seg, r["Counter_Name"])].append(float(r["Counter_Value"]))
+                if name not in order:
+                    order.append(name)
+                out[(order.index(name), r["Counter_Name"])].append(float(r["Counter_Value"]))
     return out
 
 
 def mean(v):
     v = v[1:] if len(v) > 1 else v          # (the first launch of a system also pays its cold caches)
+    if len(v) >= 4:                         # one sample per (launch, XCD) or per launch, whichever the profiler wrote: keep whole launches
+        pass
     return sum(v) / len(v) if v else float("nan")
 
 
