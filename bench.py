@@ -873,12 +873,14 @@ def extra_workloads(D, poisson, torch) -> dict:
             torch.cuda.synchronize()
             dt_c = time.perf_counter() - t0
             entry[f"iterations_per_s_{tag}"] = round(sum(r.iterations for r in res_c) / dt_c, 1)
-        entry["default_batch_is"] = "team kernel (one launch)" if group[0].n <= 65536 else "multi-launch path, interleaved"
+        entry["default_batch_is"] = ("team kernel (one launch, one team per system)" if group[0].n <= 65536 else
+                                     ("whole-chip kernel, one system after another" if group[0].chip_info()["chip_by_default"]
+                                      else "multi-launch path, interleaved"))
         t0 = time.perf_counter()
         seq_its = sum(sy.solve(b_c, want_history=False, flags=D._lib.NO_SMALL).iterations for sy, b_c in zip(group, rhs_c))
         torch.cuda.synchronize()
         dt_s = time.perf_counter() - t0
-        entry["iterations_per_s_one_after_another"] = round(seq_its / dt_s, 1)
+        entry["iterations_per_s_one_after_another"] = round(seq_its / dt_s, 1)          # (the multi-launch path, DPCG_NO_SMALL)
         conc[label] = entry
         for sy in group:
             sy.close()
