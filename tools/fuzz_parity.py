@@ -13,8 +13,10 @@ from oracle import oracle as O
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-only = int(sys.argv[3]) if len(sys.argv) > 3 else None      # replay ONE case of a seed (same random draws), with its histories
-SIZES = [1, 2, 63, 64, 255, 256, 257, 1000, 3071, 3072, 3073, 4608, 4609, 6144, 6145, 9000, 20000, 70000, 400000]
+only = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != "chip" else None      # replay ONE case of a seed (same random draws), with its histories
+CHIP_ONLY = "chip" in sys.argv[3:]       # `cases seed chip`: sizes, row lengths and bandwidths the whole-chip kernels take
+SIZES = [1, 2, 63, 64, 255, 256, 257, 1000, 3071, 3072, 3073, 4608, 4609, 6144, 6145, 9000, 20000, 65536, 65537, 70000, 131073, 400000,
+         600000, 1048576]        # (65 537 .. 1 048 576: the whole-chip kernels when rows and bandwidth allow)
 
 
 def random_spd(n, per_row, band, scramble):
@@ -37,10 +39,13 @@ def random_spd(n, per_row, band, scramble):
 
 
 bad = 0
+chip_seen = {}
+if CHIP_ONLY:
+    SIZES = [6145, 9000, 20000, 65537, 70000, 100000, 131073, 262144, 262145, 400000, 524289, 600000, 1000000, 1048576]
 for case in range(cases):
     n = int(rng.choice(SIZES))
-    per_row = int(rng.choice([1, 2, 4, 6, 10, 20, 50]))
-    band = int(rng.choice([2, 8, 64, 1000, max(2, n)]))
+    per_row = int(rng.choice([1, 2, 4, 6] if CHIP_ONLY else [1, 2, 4, 6, 10, 20, 50]))
+    band = int(rng.choice([2, 8, 64, 1000, 20000] if CHIP_ONLY else [2, 8, 64, 1000, max(2, n)]))
     scramble = bool(rng.integers(0, 2)) and n < 100000
     if n * per_row > 6_000_000:
         per_row = 4
@@ -99,7 +104,7 @@ for case in range(cases):
     if not (np.array_equal(ylo, ref_lo) and np.array_equal(yup, CO.sptrsv_upper(CO.transpose_csr(Ltri), ref_lo))):
         bad += 1
         print("SPTRSV MISMATCH", tag, S.info()["levels_lower"])
-    kinds = (["none", "jacobi"] + (["ic0_solve", "ic0_multiply"] if n <= 70000 else [])
+    kinds = (["none", "jacobi"] + (["ic0_solve", "ic0_multiply"] if n <= 131073 else [])
              + (["ic0_csr", "ict_solve"] if n <= 6145 else []))
     Lf = None
     for kind in kinds:
@@ -191,12 +196,28 @@ for case in range(cases):
             if kind in ("none", "jacobi"):     # round 4: the multi-launch forms against the device-tree oracle (CSR-vector kernel included), bit for bit
                 tree_hist = CO.pcg(B, bo, kind, x0=x0o, device_tree=S.reduction_geometry(),
                                    **(dict(dinv=O.jacobi_dinv(B)) if kind == "jacobi" else {}))[1:3]
+            # round 5: a plain call of a chip-sized system is ONE launch on the whole chip (dpcg_chip.hip / dpcg_chip_llt.hip): bit for
+            # bit against the oracle with THAT tree (M = L L^T multiplied: on the matrices the handle iterates on)
+            chip_hist = None
+            ci = S.chip_info()
+            if ci["chip_by_default"] and kind in ("none", "jacobi", "ic0_multiply"):
+                ctree = {**S.reduction_geometry(), "form": "chip", "rows_per_workgroup": ci["rows_per_workgroup"]}
+                if kind == "ic0_multiply":
+                    Lq = Lf[perm][:, perm].tocsr() if S.reordered else Lf
+                    Lq.sort_indices()
+                    chip_hist = CO.pcg(B, bo, "llt_multiply", L=Lq, x0=x0o, device_tree=ctree)[1:3]
+                else:
+                    chip_hist = CO.pcg(B, bo, kind, x0=x0o, device_tree=ctree, **(dict(dinv=O.jacobi_dinv(B)) if kind == "jacobi" else {}))[1:3]
+                chip_seen[kind] = chip_seen.get(kind, 0) + 1
             for flags in (0, D._lib.NO_SMALL, D._lib.NO_SMALL | D._lib.NO_FUSE):
                 r = S.solve(torch.from_numpy(b).cuda(), x0_dev, flags=flags)
                 h = r.res_history
                 if tree_hist is not None and flags and not (r.iterations == tree_hist[0] and np.array_equal(h, tree_hist[1])):
                     bad += 1
                     print("BITS MISMATCH against the device-tree oracle", tag, kind, "flags", flags, r.iterations, tree_hist[0])
+                if chip_hist is not None and flags == 0 and not (r.iterations == chip_hist[0] and np.array_equal(h, chip_hist[1])):
+                    bad += 1
+                    print("BITS MISMATCH of the whole-chip solve against the chip-tree oracle", tag, kind, r.iterations, chip_hist[0])
                 m = min(len(h), len(hist))
                 # M = L L^T multiplied is the reference's own "unstable" technique (test.py:45): rounding differences
                 # grow to O(1) within tens of updates, so only the first entries and a count window are comparable;
@@ -239,4 +260,4 @@ for case in range(cases):
             bad += 1
             print("EXCEPTION", tag, kind, repr(e)[:200])
     S.close()
-print(f"fuzz: {cases} cases, {bad} mismatches")
+print(f"fuzz: {cases} cases, {bad} mismatches; whole-chip solves checked to the bit: {chip_seen}")
