@@ -3,7 +3,7 @@
 // of 15 entries a row -- hand-written for gfx950 (MI355X), the whole chip as one team like dpcg_chip.hip.
 //
 // The multi-launch update of that system is five launches of 1-2 us of work each behind 2 us boundaries: 21.3 us per update, 0.2 of the
-// roofline.  A team on one XCD (dpcg_team.hip) cannot hold it: L and L^T are 23.5 MB, six times an XCD's L2.  Over 256 CUs they are
+// roofline (here: 9.2 us).  A team on one XCD (dpcg_team.hip) cannot hold it: L and L^T are 23.5 MB, six times an XCD's L2.  Over 256 CUs they are
 // 92 KB each: here A, L^T and L of a workgroup's rows live in LDS / registers for the whole solve (39 eight-byte value slots per
 // thread in LDS, the rest in registers; columns as 16-bit offsets from the row), one launch, cg.py:58-90:
 //   * 256 workgroups x 512 threads, workgroup v owns rows [v * per, (v + 1) * per), thread t rows v * per + t + 512 k (k < RPT <= 2).
@@ -30,10 +30,16 @@ namespace {
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// RPT: rows per thread (1, 2); WA: entry slots per row of A (5, 7); WL: entry slots per row of L and of L^T (4, 8, 16)
-template <int RPT, int WA, int WL>
+// RPT: rows per thread (1, 2); WA: entry slots per row of A (5, 7); WL: entry slots per row of L and of L^T (4, 8, 16).
+// SPLIT (RPT == 1, <= 256 rows per workgroup -- config 2: otherwise half the lanes would idle while the others gather and validate 2 x 16
+// granules a row): TWO lanes per row.  Both hold the row's vectors and compute q = A p (redundantly); of a factor row lane h of the
+// pair holds, gathers and validates entries [h * WL/2, (h + 1) * WL/2), the products are then added in CSR order -- the even lane's,
+// its sum handed to the odd lane, the odd lane's -- so the row sum keeps its bits; dot products count a row once (even lanes).
+template <int RPT, int WA, int WL, bool SPLIT = false>
 __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_llt(const ChipLltDesc d) {
-    constexpr int WR = WA + 2 * WL;                                  // entry slots of a row: A | L^T | L
+    static_assert(!SPLIT || (RPT == 1 && WL % 2 == 0), "two lanes per row: one row per pair");
+    constexpr int WLS = SPLIT ? WL / 2 : WL;                         // factor-row entries a thread holds
+    constexpr int WR = WA + 2 * WLS;                                 // entry slots of a thread's row: A | L^T | L
     constexpr int NS = RPT * WR;
     constexpr int NLDS = NS < kChipLdsSlots ? NS : kChipLdsSlots;
     constexpr int NREG = NS - NLDS;                                  // the first NREG slots live in registers
@@ -42,9 +48,12 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_llt(const ChipLltDesc
     __shared__ double s_res[2][2];
     __shared__ int s_flag;
     const int t = threadIdx.x;
+    const int tr = SPLIT ? (t >> 1) : t;                             // the thread's row slot in the workgroup
+    const int half = SPLIT ? (t & 1) : 0;
+    const bool counts = half == 0;                                   // (of a pair, the even lane publishes and counts in the dot products)
     const int v = ((int)blockIdx.x & 7) * (kChipWGs / 8) + ((int)blockIdx.x >> 3);
     const int grp = (int)blockIdx.x & 7, rank = (int)blockIdx.x >> 3;
-    const int row0 = v * d.per + t;
+    const int row0 = v * d.per + tr;
     const int glo = grp * (kChipWGs / 8) * d.per;
     const int ghi = (glo + (kChipWGs / 8) * d.per < d.n) ? glo + (kChipWGs / 8) * d.per : d.n;
     const int zp_remote = (d.n + kChipZpPad) * 16, v8_remote = (d.n + kChipZpPad) * 8;
@@ -60,17 +69,24 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_llt(const ChipLltDesc
     double bb_loc = 0.0;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        const int loc = k * kChipThreads + t, i = row0 + k * kChipThreads;
+        const int loc = k * kChipThreads + tr, i = row0 + k * kChipThreads;
         const bool valid = loc < d.per && i < d.n;
         const int ic = valid ? i : 0;
-        const int a0 = d.rp[ic], a1 = d.rp[ic + 1], t0 = d.trp[ic], t1 = d.trp[ic + 1], l0 = d.lrp[ic], l1 = d.lrp[ic + 1];
+        const int a0 = d.rp[ic], a1 = d.rp[ic + 1];
+        int t0 = d.trp[ic], t1 = d.trp[ic + 1], l0 = d.lrp[ic], l1 = d.lrp[ic + 1];
+        if (SPLIT) {                                                  // this lane's half of the factor rows
+            t0 = t0 + half * WLS < t1 ? t0 + half * WLS : t1;
+            t1 = t0 + WLS < t1 ? t0 + WLS : t1;
+            l0 = l0 + half * WLS < l1 ? l0 + half * WLS : l1;
+            l1 = l0 + WLS < l1 ? l0 + WLS : l1;
+        }
         const double bi = d.b[ic];
         const double xi = d.x0 ? d.x0[ic] : 0.0;
         lens[k] = valid ? (0x80000000u | (unsigned)(a1 - a0) | ((unsigned)(t1 - t0) << 5) | ((unsigned)(l1 - l0) << 10)) : 0u;
         x[k] = valid ? xi : 0.0;
         r[k] = valid ? bi : 0.0;
         p[k] = q[k] = 0.0;
-        if (valid) bb_loc += bi * bi;
+        if (valid && counts) bb_loc += bi * bi;
         auto take = [&](int first, int W, const int32_t *ci, const double *val, int e0, int len) {
 #pragma unroll
             for (int j = 0; j < W; ++j) {
@@ -88,12 +104,13 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_llt(const ChipLltDesc
         };
         take(0, WA, d.ci, d.val, a0, a1 - a0);
         __builtin_amdgcn_sched_barrier(0);
-        take(WA, WL, d.tci, d.tval, t0, t1 - t0);
+        take(WA, WLS, d.tci, d.tval, t0, t1 - t0);
         __builtin_amdgcn_sched_barrier(0);
-        take(WA + WL, WL, d.lci, d.lval, l0, l1 - l0);
+        take(WA + WLS, WLS, d.lci, d.lval, l0, l1 - l0);
         __builtin_amdgcn_sched_barrier(0);
     }
     auto row_on = [&](int k) -> bool { return (lens[k] & 0x80000000u) != 0; };
+    auto row_counts = [&](int k) -> bool { return counts && (lens[k] & 0x80000000u) != 0; };   // ... and this lane speaks for it
     bool local = false;
 
     Exchange X;
@@ -229,12 +246,35 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_llt(const ChipLltDesc
                 }
             }
             double acc = 0.0;
+            if (SPLIT) {
+                double prod[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (j < W) {
-                    const int s = k * WR + first + j;
-                    const double a = s < NREG ? vr[s < NREG ? s : 0] : lvt[(s - NREG) * kChipThreads];
-                    if (j < len) acc += a * lo_f64(g[j]);
+                for (int j = 0; j < 16; ++j) {
+                    if (j < W) {
+                        const int s = k * WR + first + j;
+                        const double a = s < NREG ? vr[s < NREG ? s : 0] : lvt[(s - NREG) * kChipThreads];
+                        prod[j] = a * lo_f64(g[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j < W && half == 0 && j < len) acc += prod[j];          // the row's first entries, in order ...
+                const double first_half = __shfl(acc, (int)(threadIdx.x & 63u) & ~1);
+                if (half == 1) {
+                    acc = first_half;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (j < W && j < len) acc += prod[j];                   // ... then the rest onto that sum: the CSR order
+                }
+                acc = __shfl(acc, (int)(threadIdx.x & 63u) | 1);                // both lanes of the pair hold the row's sum
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (j < W) {
+                        const int s = k * WR + first + j;
+                        const double a = s < NREG ? vr[s < NREG ? s : 0] : lvt[(s - NREG) * kChipThreads];
+                        if (j < len) acc += a * lo_f64(g[j]);
+                    }
                 }
             }
             y[k] = acc;
@@ -257,26 +297,27 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_llt(const ChipLltDesc
             const unsigned long long key_r = make_key(++pub_gen);
 #pragma unroll
             for (int k = 0; k < RPT; ++k)
-                if (row_on(k)) publish_tagged(r_rs, k, r[k], key_r);
+                if (row_on(k) && counts) publish_tagged(r_rs, k, r[k], key_r);
             double tv[RPT];
-            if (!products_tagged(WA, WL, 5, tv, r_rs, key_r)) return false;
+            if (!products_tagged(WA, WLS, 5, tv, r_rs, key_r)) return false;
             const unsigned long long key_t = make_key(++pub_gen);
 #pragma unroll
             for (int k = 0; k < RPT; ++k)
-                if (row_on(k)) publish_tagged(t_rs, k, tv[k], key_t);
-            return products_tagged(WA + WL, WL, 10, z, t_rs, key_t);
+                if (row_on(k) && counts) publish_tagged(t_rs, k, tv[k], key_t);
+            return products_tagged(WA + WLS, WLS, 10, z, t_rs, key_t);
         }
+        if (SPLIT) return false;                                  // (two lanes per row: the self-validating form only; the launcher sees to it)
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
             if (row_on(k)) publish8(r_rs, k, r[k]);
         if (!data_barrier()) return false;
         double tv[RPT];
-        row_products(WA, WL, 5, tv, fetch8(r_rs));
+        row_products(WA, WLS, 5, tv, fetch8(r_rs));
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
             if (row_on(k)) publish8(t_rs, k, tv[k]);
         if (!data_barrier()) return false;
-        row_products(WA + WL, WL, 10, z, fetch8(t_rs));
+        row_products(WA + WLS, WLS, 10, z, fetch8(t_rs));
         return true;
     };
 
@@ -297,7 +338,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_llt(const ChipLltDesc
     if (alive && d.x0) {                                          // r = b - A x0 (cg.py:60): x0 published as "z", beta = 0
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
-            if (row_on(k)) publish_zp(k, x[k], 0.0);
+            if (row_counts(k)) publish_zp(k, x[k], 0.0);
         alive = data_barrier();
         if (alive) {
             spmv_a(0.0);
@@ -311,7 +352,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_llt(const ChipLltDesc
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         p[k] = z[k];                                              // cg.py:62
-        if (row_on(k)) {
+        if (row_counts(k)) {
             rz_loc += r[k] * z[k];
             t0_loc += d.init_check_r ? r[k] * r[k] : z[k] * z[k];  // cg.py:66: the first test is on z
             publish_zp(k, z[k], 0.0);                             // p_0 = z_0 + 0 * p_{-1}
@@ -335,7 +376,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_llt(const ChipLltDesc
         double pq_loc = 0.0;
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
-            if (row_on(k)) pq_loc += q[k] * p[k];
+            if (row_counts(k)) pq_loc += q[k] * p[k];
         double pq = 0.0;
         if (!(alive = exchange2(X, pq_loc, 0.0, false, pq, dummy))) break;       // every SpMV of this update is done
         const double alpha = rz / pq;                             // cg.py:78
@@ -348,7 +389,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_llt(const ChipLltDesc
         double rz_new_loc = 0.0, rr_loc = 0.0;
 #pragma unroll
         for (int k = 0; k < RPT; ++k)
-            if (row_on(k)) {
+            if (row_counts(k)) {
                 rz_new_loc += r[k] * z[k];
                 rr_loc += r[k] * r[k];
                 publish_zp(k, z[k], p[k]);                        // z_{k+1} and p_k for the next update's gathers
@@ -368,7 +409,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_llt(const ChipLltDesc
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
-        if (row_on(k)) d.x[row0 + k * kChipThreads] = x[k];
+        if (row_counts(k)) d.x[row0 + k * kChipThreads] = x[k];
     if (v == 0 && t == 0) {
         Scalars *sc = d.out;
         sc->k = k_done;
@@ -379,24 +420,24 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_llt(const ChipLltDesc
     }
 }
 
-template <int RPT, int WA, int WL>
+template <int RPT, int WA, int WL, bool SPLIT>
 int chip_llt_launch(const ChipLltDesc &d, hipStream_t s, bool check_only) {
-    constexpr int NS = RPT * (WA + 2 * WL);
+    constexpr int NS = RPT * (WA + 2 * (SPLIT ? WL / 2 : WL));
     constexpr int NLDS = NS < kChipLdsSlots ? NS : kChipLdsSlots;
     const int lds = NLDS * kChipThreads * (int)sizeof(double);
     static int resident = -1;
     if (resident < 0) {
-        if (hipFuncSetAttribute((const void *)k_pcg_chip_llt<RPT, WA, WL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_pcg_chip_llt<RPT, WA, WL, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return DPCG_ERR_HIP;
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_pcg_chip_llt<RPT, WA, WL>, kChipThreads, (size_t)lds) !=
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_pcg_chip_llt<RPT, WA, WL, SPLIT>, kChipThreads, (size_t)lds) !=
             hipSuccess)
             return DPCG_ERR_HIP;
         resident = per_cu;
     }
     if (resident < 1) return DPCG_ERR_STATE;
     if (check_only) return DPCG_OK;
-    hipLaunchKernelGGL((k_pcg_chip_llt<RPT, WA, WL>), dim3(kChipWGs), dim3(kChipThreads), (size_t)lds, s, d);
+    hipLaunchKernelGGL((k_pcg_chip_llt<RPT, WA, WL, SPLIT>), dim3(kChipWGs), dim3(kChipThreads), (size_t)lds, s, d);
     return DPCG_OK;
 }
 
@@ -411,8 +452,10 @@ int launch_pcg_chip_llt(const ChipLltDesc &d, int max_a, int max_l, hipStream_t 
     if (max_a < 1 || max_a > 7 || max_l < 1 || max_l > 16 || d.per < 1 || d.per > 2 * kChipThreads) return DPCG_ERR_INVALID;
     const int rpt = (d.per + kChipThreads - 1) / kChipThreads;
     if (rpt > 1 && max_l > 8) return DPCG_ERR_STATE;      // (not compiled: two rows a thread of 16-entry factor rows spill)
-#define DPCG_LLT_L1(WAV) (max_l <= 4 ? chip_llt_launch<1, WAV, 4>(d, s, check_only) : (max_l <= 8 ? chip_llt_launch<1, WAV, 8>(d, s, check_only) : chip_llt_launch<1, WAV, 16>(d, s, check_only)))
-#define DPCG_LLT_L2(WAV) (max_l <= 4 ? chip_llt_launch<2, WAV, 4>(d, s, check_only) : chip_llt_launch<2, WAV, 8>(d, s, check_only))
+    // 16-entry factor rows on <= 256 rows per workgroup (config 2): two lanes per row -- the self-validating form only
+    const bool split = max_l > 8 && d.per <= kChipThreads / 2 && d.nonce != 0;
+#define DPCG_LLT_L1(WAV) (max_l <= 4 ? chip_llt_launch<1, WAV, 4, false>(d, s, check_only) : (max_l <= 8 ? chip_llt_launch<1, WAV, 8, false>(d, s, check_only) : (split ? chip_llt_launch<1, WAV, 16, true>(d, s, check_only) : chip_llt_launch<1, WAV, 16, false>(d, s, check_only))))
+#define DPCG_LLT_L2(WAV) (max_l <= 4 ? chip_llt_launch<2, WAV, 4, false>(d, s, check_only) : chip_llt_launch<2, WAV, 8, false>(d, s, check_only))
     return rpt <= 1 ? (max_a <= 5 ? DPCG_LLT_L1(5) : DPCG_LLT_L1(7)) : (max_a <= 5 ? DPCG_LLT_L2(5) : DPCG_LLT_L2(7));
 #undef DPCG_LLT_L1
 #undef DPCG_LLT_L2

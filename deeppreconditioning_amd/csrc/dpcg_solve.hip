@@ -811,6 +811,10 @@ static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, dou
 // M = L L^T multiplied (the learned technique, IC multiplied) beyond the one-workgroup kernel: the whole chip, L and L^T resident
 static const CsrDev &llt_l(const dpcg_system *h) { return h->perm ? h->Lp : h->L; }
 static const CsrDev &llt_t(const dpcg_system *h) { return h->perm ? h->Ltp : h->Lt; }
+static bool chip_llt_tagged() {       // DPCG_CHIP_LLT_SYNC=0 (development): plain vectors and a chip-wide barrier per product
+    static const bool on = [] { const char *e = getenv("DPCG_CHIP_LLT_SYNC"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static bool chip_llt_eligible(const dpcg_system *h, int flags, const double *x_true) {
     static const bool enabled = [] {
         const char *e = getenv("DPCG_CHIP");
@@ -876,7 +880,7 @@ static int solve_chip_llt_one(dpcg_system *h, const double *b, const double *x0,
     d.xcc = plain_ok ? reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256 + 2) : nullptr;
     // r and t = L^T r reach the neighbours as self-validating granules keyed by a per-launch nonce (DPCG_CHIP_LLT_SYNC=0, development:
     // plain vectors and a chip-wide barrier per product)
-    static const bool tagged = [] { const char *e = getenv("DPCG_CHIP_LLT_SYNC"); return !(e && e[0] == '0'); }();
+    const bool tagged = chip_llt_tagged();
     static std::atomic<unsigned> launch_nonce{0};
     unsigned nonce = 0;
     if (tagged)
@@ -931,7 +935,12 @@ extern "C" int dpcg_get_chip_info(dpcg_handle_t h, int32_t out[8], double trace_
     out[5] = h->planA.max_band;
     if (trace_us)
         for (int i = 0; i < 8; ++i) trace_us[i] = h->chip_trace_us[i];
-    out[6] = (int)h->chip_trace_x[4];                       // the last traced chip solve kept plainly stored copies (every group on one XCD)
+    // bit 0: the last traced chip solve kept plainly stored copies (every group on one XCD); bits 8-15: lanes that share a row in the
+    // form a plain solve takes now (2: M = L L^T multiplied with 16-entry factor rows on <= 256 rows a workgroup; a row's terms of the
+    // dot products then sit in the even lanes)
+    const bool split = chip_llt_eligible(h, 0, nullptr) && std::max(h->planL.max_row_len, h->planLt.max_row_len) > 8 &&
+                       chip_rows_per_wg(h->A.n) <= chip_threads() / 2 && chip_llt_tagged();
+    out[6] = (int)h->chip_trace_x[4] | ((split ? 2 : 1) << 8);
     out[7] = (int)(h->chip_trace_x[5] * 1.0e6);             // DPCG_CHIP_EVENTS=1: the last chip kernel between HIP events on its stream, ns
     return DPCG_OK;
 }

@@ -528,7 +528,8 @@ class CsrSystem:
         tr = (C.c_double * 8)()
         L.check(L.lib().dpcg_get_chip_info(self._h, out, tr))
         return {"chip_eligible": bool(out[0]), "chip_by_default": out[0] == 2, "workgroups": out[1], "threads": out[2],
-                "rows_per_workgroup": out[3], "max_row_len": out[4], "max_band": out[5], "groups_on_one_xcd": bool(out[6]),
+                "rows_per_workgroup": out[3], "max_row_len": out[4], "max_band": out[5], "groups_on_one_xcd": bool(out[6] & 1),
+                "lanes_per_row": (out[6] >> 8) & 255,
                 "kernel_ms": out[7] * 1e-6,
                 "trace_us": {"spmv": tr[0], "sum_pq": tr[1], "update_publish": tr[2], "sum_rz_rr": tr[3], "loop": tr[4],
                              "wait_pq": tr[5], "wait_rz": tr[6], "updates": int(tr[7])}}

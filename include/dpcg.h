@@ -203,8 +203,9 @@ int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]);
  * system with its CURRENT preconditioner is eligible (2: and a plain dpcg_solve takes that form), out[1] = workgroups (256),
  * out[2] = threads of each (512), out[3] = rows per workgroup (ceil(n / 256): workgroup v owns rows v * out[3] .., thread t of it
  * rows v * out[3] + t + 512 k -- what a checker needs to add the dot products in the kernel's order), out[4] = longest row,
- * out[5] = largest |col - row| (-1: not measured, systems beyond 1 048 576 rows), out[6] = 1 when the last traced chip solve found
- * every group of 32 workgroups on one XCD (and kept plainly stored copies in that XCD's L2), out[7] = with DPCG_CHIP_EVENTS=1 in the
+ * out[5] = largest |col - row| (-1: not measured, systems beyond 1 048 576 rows), out[6]: bit 0 = the last traced chip solve found
+ * every group of 32 workgroups on one XCD (and kept plainly stored copies in that XCD's L2), bits 8-15 = lanes that share a row (2: M = L L^T
+ * multiplied with 16-entry factor rows; row v * out[3] + t / 2 then speaks through the even lane t of its pair in the dot products), out[7] = with DPCG_CHIP_EVENTS=1 in the
  * environment, the duration of the last chip kernel in nanoseconds, between HIP events on the stream it ran on.  trace_us (may be NULL): with DPCG_CHIP_TRACE=1 in
  * the environment, microseconds per update that workgroup 0 spent in the phases of the last chip solve -- [0] q = A p (the SpMV
  * phase), [1] sum <p,Ap> incl. its barrier, [2] vector updates + publishing, [3] sum <r,z>, <r,r> incl. its barrier, [4] the whole

@@ -178,13 +178,14 @@ def pcg(A: sp.csr_matrix, b: np.ndarray, kind: str = "none", *, dinv=None, M=Non
     product is summed in the DEVICE's reduction tree (orc_set_dot_tree) instead of the oracle's fixed blocks -- for kind "none" /
     "jacobi" the history then equals the multi-launch HIP solve's BIT FOR BIT.  "form": "small" (+ "small_threads") restates the
     one-workgroup solve of systems up to 6144 rows -- every preconditioner kind it serves: none / jacobi / csr / llt_multiply --,
-    "form": "team" the 32-workgroup team solve, "form": "chip" (+ "rows_per_workgroup" from chip_info()) the whole-chip solve.  "rz_kind" (+ "m_grid", "m_nrb", "m_cyclic"): who sums <r,z> behind an APPLIED
+    "form": "team" the 32-workgroup team solve, "form": "chip" (+ "rows_per_workgroup", "lanes_per_row" from chip_info()) the whole-chip solve.  "rz_kind" (+ "m_grid", "m_nrb", "m_cyclic"): who sums <r,z> behind an APPLIED
     preconditioner in the multi-launch form (orc_set_rz_tree) -- with it "csr", "llt_multiply" and "llt_solve" match bit for bit too,
     as long as the handle's answer is 0..4 (4: colour sweeps; then also "sweep_grid", "sweep_modes", "sweep_rows")."""
     if device_tree is not None:
         form = {"multi": 0, "small": 1, "team": 2, "chip": 3}[device_tree.get("form", "multi")]
         # ("chip": the whole-chip solve -- "rows_per_workgroup" from CsrSystem.chip_info() travels in the small_threads slot)
-        lib().orc_set_dot_tree(1, int(device_tree["spmv_grid"]), int(device_tree["nrb"]), int(device_tree["cyclic"]),
+        lib().orc_set_dot_tree(1, int(device_tree["spmv_grid"]), int(device_tree["nrb"]),
+                               int(device_tree.get("lanes_per_row", 1) if form == 3 else device_tree["cyclic"]),
                                int(device_tree["vec_grid"]), form,
                                int(device_tree["rows_per_workgroup"] if form == 3 else device_tree.get("small_threads", 0)))
         rzk = int(device_tree.get("rz_kind", 0))

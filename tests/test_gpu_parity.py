@@ -3015,7 +3015,8 @@ def test_chip_llt_solve_equals_the_device_tree_oracle_bit_for_bit(D, name, make,
     B = _permuted(A, perm) if perm is not None else A
     bb = b[perm] if perm is not None else b
     Lq = _permuted(L, perm) if perm is not None else L          # a reordered handle multiplies by P L P^T and its transpose (rows summed in THEIR column order)
-    tree = {**S.reduction_geometry(), "form": "chip", "rows_per_workgroup": ci["rows_per_workgroup"]}
+    tree = {**S.reduction_geometry(), "form": "chip", "rows_per_workgroup": ci["rows_per_workgroup"], "lanes_per_row": ci["lanes_per_row"]}
+    assert ci["lanes_per_row"] == (2 if factor == "learned" else 1)           # 16-entry factor rows, 256 rows a workgroup: a pair of lanes per row
     for x0, max_iter in ((None, 1024), (O.rhs(n, 5), 40)):
         res = S.solve(_dev(b), None if x0 is None else _dev(x0), max_iter=max_iter)
         x0p = None if x0 is None else (x0[perm] if perm is not None else x0)

@@ -201,7 +201,7 @@ for case in range(cases):
             chip_hist = None
             ci = S.chip_info()
             if ci["chip_by_default"] and kind in ("none", "jacobi", "ic0_multiply"):
-                ctree = {**S.reduction_geometry(), "form": "chip", "rows_per_workgroup": ci["rows_per_workgroup"]}
+                ctree = {**S.reduction_geometry(), "form": "chip", "rows_per_workgroup": ci["rows_per_workgroup"], "lanes_per_row": ci["lanes_per_row"]}
                 if kind == "ic0_multiply":
                     Lq = Lf[perm][:, perm].tocsr() if S.reordered else Lf
                     Lq.sort_indices()
