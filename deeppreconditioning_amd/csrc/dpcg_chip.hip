@@ -50,7 +50,7 @@ using namespace chip;
 
 namespace {
 
-// RPT: rows per thread (2, 4, 8); WMAX: entry slots per row (5, 7); JAC: M = diag(1 / a_ii) (else M = I: z = r, no dinv registers).
+// RPT: rows per thread (2, 4, 8); WMAX: entry slots per row (5, 7; 9 up to four rows a thread: unstructured meshes); JAC: M = diag(1 / a_ii) (else M = I: z = r, no dinv registers).
 template <int RPT, int WMAX, bool JAC, int MODE>
 __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     constexpr bool TRACE = MODE == 1;      // (development -- MODE 2: q = p instead of the gathers, the loop never stops before max_iter; MODE 3: the gathers
@@ -77,7 +77,10 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     // ---- the matrix slice and the vectors of the own rows: read once ------------------------------------------------------
     double vr[NREG > 0 ? NREG : 1];
     unsigned dl[(NS + 1) / 2];
-    unsigned lens = 0;                     // 4 bits per row: 8 | length for a row that exists, 0 otherwise
+    constexpr int LB = WMAX > 7 ? 8 : 4;    // bits per row in `lens`: the top one = the row exists, below it the length
+    constexpr unsigned LV = 1u << (LB - 1), LM = LV - 1u;
+    static_assert(LB * RPT <= 32, "row lengths of a thread in one register");
+    unsigned lens = 0;
     double x[RPT], r[RPT], p[RPT], q[RPT], dv[JAC ? RPT : 1];
     double bb_loc = 0.0;
     // (unconditional loads from clamped addresses -- a predicated load is a branch with a wait of its own, and 56 of them in a row
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         const double di = JAC ? d.dinv[ic] : 1.0;
         rs_k[k] = rs;
         len_k[k] = valid ? re - rs : 0;
-        lens |= (valid ? (8u | (unsigned)(re - rs)) : 0u) << (4 * k);
+        lens |= (valid ? (LV | (unsigned)(re - rs)) : 0u) << (LB * k);
         x[k] = valid ? xi : 0.0;
         r[k] = valid ? bi : 0.0;
         p[k] = q[k] = 0.0;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        if (row_valid_bits(lens, k)) bb_loc += r[k] * r[k];
+        if ((lens >> (LB * k)) & LV) bb_loc += r[k] * r[k];
         const int i = row0 + k * kChipThreads;
         int cj[WMAX];
         double aj[WMAX];
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         __builtin_amdgcn_sched_barrier(0);
     }
     bool local = false;                     // every group on one XCD (established below, once per solve)
-    auto row_on = [&](int k) -> bool { return ((lens >> (4 * k)) & 8u) != 0; };
+    auto row_on = [&](int k) -> bool { return ((lens >> (LB * k)) & LV) != 0; };
 
     // q = A p_{k} for the own rows; the gathered entries of p_k are recomputed from the published granules {z_k, p_{k-1}}.
     // All WMAX gathers of a row are in flight together, the next row's are issued while this row's are consumed (the compiler
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         for (int k = 0; k < RPT; ++k) {
             if (k + 1 < RPT) request(k + 1, g[(k + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);                     // (keeps the scheduler from hoisting every row's gathers to the top:
-            const int len = (int)((lens >> (4 * k)) & 7u);         //  two rows' granules in flight is what the registers hold)
+            const int len = (int)((lens >> (LB * k)) & LM);        //  two rows' granules in flight is what the registers hold)
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < WMAX; ++j) {
@@ -411,7 +414,8 @@ int launch_occupy(int workgroups, double ms, hipStream_t s) {
 }
 
 int chip_max_rows() { return kChipWGs * kChipThreads * kChipMaxRpt; }
-int chip_max_row_len() { return 7; }
+// rows of up to 9 entries (unstructured meshes) while a thread holds at most four rows (524 288 rows), 7 beyond
+int chip_max_row_len(int64_t n) { return n <= (int64_t)kChipWGs * kChipThreads * 4 ? 9 : 7; }
 int chip_max_band() { return 32767; }
 int chip_workgroups() { return kChipWGs; }
 int chip_threads() { return kChipThreads; }
@@ -428,17 +432,19 @@ void launch_band_and_len(const CsrDev &A, int *out2_zeroed_dev, hipStream_t s) {
 // One system on the whole chip.  max_row_len <= 7; d.per = ceil(n / 256) <= 4096.  check_only: the occupancy query alone.
 // Returns DPCG_OK, DPCG_ERR_STATE when the kernel cannot be resident on every CU, or a negative HIP status.
 int launch_pcg_chip(const ChipDesc &d, int max_row_len, hipStream_t s, bool check_only) {
-    if (max_row_len < 1 || max_row_len > 7 || d.per < 1 || d.per > kChipThreads * kChipMaxRpt) return DPCG_ERR_INVALID;
     const int rpt = (d.per + kChipThreads - 1) / kChipThreads;
+    if (max_row_len < 1 || max_row_len > (rpt <= 4 ? 9 : 7) || d.per < 1 || d.per > kChipThreads * kChipMaxRpt) return DPCG_ERR_INVALID;
     const bool jac = d.precond == DPCG_PRECOND_JACOBI;
     const int mode = d.bench == 3 ? 3 : (d.bench ? 2 : (d.dbg != nullptr ? 1 : 0));
 #define DPCG_CHIP_T(RPTV, WV, JV) (mode == 3 ? chip_launch<RPTV, WV, JV, 3>(d, s, check_only) : mode == 2 ? chip_launch<RPTV, WV, JV, 2>(d, s, check_only) : (mode == 1 ? chip_launch<RPTV, WV, JV, 1>(d, s, check_only) : chip_launch<RPTV, WV, JV, 0>(d, s, check_only)))
 #define DPCG_CHIP_W(RPTV, WV) (jac ? DPCG_CHIP_T(RPTV, WV, true) : DPCG_CHIP_T(RPTV, WV, false))
 #define DPCG_CHIP_R(RPTV) (max_row_len <= 5 ? DPCG_CHIP_W(RPTV, 5) : DPCG_CHIP_W(RPTV, 7))
-    if (rpt <= 2) return DPCG_CHIP_R(2);
-    if (rpt <= 4) return DPCG_CHIP_R(4);
+#define DPCG_CHIP_R9(RPTV) (max_row_len <= 5 ? DPCG_CHIP_W(RPTV, 5) : (max_row_len <= 7 ? DPCG_CHIP_W(RPTV, 7) : DPCG_CHIP_W(RPTV, 9)))
+    if (rpt <= 2) return DPCG_CHIP_R9(2);
+    if (rpt <= 4) return DPCG_CHIP_R9(4);
     return DPCG_CHIP_R(8);
 #undef DPCG_CHIP_R
+#undef DPCG_CHIP_R9
 #undef DPCG_CHIP_W
 #undef DPCG_CHIP_T
 }

@@ -493,7 +493,7 @@ int chip_llt_max_rows();
 int chip_llt_max_row_len();
 int launch_pcg_chip_llt(const ChipLltDesc &d, int max_a, int max_l, hipStream_t s, bool check_only = false);
 int chip_max_rows();
-int chip_max_row_len();
+int chip_max_row_len(int64_t n);
 int chip_max_band();
 int chip_workgroups();
 int chip_threads();

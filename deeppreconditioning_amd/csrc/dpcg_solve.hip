@@ -686,7 +686,7 @@ static bool chip_eligible(const dpcg_system *h, int flags, const double *x_true)
     static const int min_rows = [] { const char *e = getenv("DPCG_CHIP_MIN_ROWS"); return e ? atoi(e) : team_max_rows(); }();
     if (!enabled || x_true || (flags & (DPCG_SPMV_F32 | DPCG_NO_TEAM | DPCG_NO_FUSE | DPCG_VAL32_IF_LOSSLESS))) return false;
     if (h->A.n <= min_rows || h->A.n > chip_max_rows()) return false;
-    if (h->planA.max_row_len < 1 || h->planA.max_row_len > chip_max_row_len()) return false;
+    if (h->planA.max_row_len < 1 || h->planA.max_row_len > chip_max_row_len(h->A.n)) return false;
     if (h->planA.max_band < 0 || h->planA.max_band > chip_max_band()) return false;
     return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI;
 }
@@ -827,7 +827,7 @@ static bool chip_llt_eligible(const dpcg_system *h, int flags, const double *x_t
     if (!enabled || x_true || h->precond != DPCG_PRECOND_LLT_MULTIPLY) return false;
     if (flags & (DPCG_SPMV_F32 | DPCG_NO_TEAM | DPCG_NO_FUSE | DPCG_VAL32_IF_LOSSLESS)) return false;
     if (h->A.n <= kSmallMaxN || h->A.n > chip_llt_max_rows()) return false;
-    if (h->planA.max_row_len < 1 || h->planA.max_row_len > chip_max_row_len()) return false;
+    if (h->planA.max_row_len < 1 || h->planA.max_row_len > 7) return false;        // (dpcg_chip_llt.hip: rows of A of <= 7 entries)
     const int ml = std::max(h->planL.max_row_len, h->planLt.max_row_len);
     if (h->planL.max_row_len < 1 || h->planLt.max_row_len < 1 || ml > chip_llt_max_row_len()) return false;
     if (ml > 8 && h->A.n > chip_llt_max_rows() / 2) return false;      // (two rows a thread of 16-entry factor rows: beyond the registers)

@@ -2834,7 +2834,8 @@ def _chip_tree(S):
     ("poisson3d_80", lambda: O.poisson3d(80), 1024),              # 512 000 rows: 4 rows a thread
     ("poisson2d_512", lambda: O.poisson2d(512), 400),             # 262 144 rows: 2 rows a thread, 5 entries a row
     ("poisson3d_41", lambda: O.poisson3d(41), 1024),              # 68 921 rows: just beyond the team kernel; most threads without a row
-    ("unstructured3d_60", lambda: O.unstructured_like(O.poisson3d(60), seed=1), 1024)])   # scattered numbering + D A D scaling: reordered inside the library, b / x in the caller's numbering
+    ("unstructured3d_60", lambda: O.unstructured_like(O.poisson3d(60), seed=1), 1024),    # scattered numbering + D A D scaling: reordered inside the library, b / x in the caller's numbering
+    ("quadtree_random_400", lambda: O.quadtree_fv_laplacian(400, 5, numbering="random"), 600)])   # a finite-volume mesh with hanging nodes: rows of 2 .. 9 entries (the 9-slot variant, <= 524 288 rows)
 def test_chip_solve_equals_the_device_tree_oracle_bit_for_bit(D, name, make, max_iter):
     """65 537 .. 1 048 576 rows, rows of <= 7 entries, M = I / Jacobi: a plain call is ONE launch of 256 workgroups that keeps matrix
     and vectors in registers and LDS for the whole solve (dpcg_chip.hip).  Against oracle/pcg_oracle.c with THAT kernel's reduction
@@ -2853,7 +2854,9 @@ def test_chip_solve_equals_the_device_tree_oracle_bit_for_bit(D, name, make, max
         ci = S.chip_info()
         if kind == "none" and name.startswith("unstructured"):
             continue         # unpreconditioned CG on the D A D-scaled system is chaotic (the two CPU oracles differ by 19 % there)
-        assert S.reordered == name.startswith("unstructured")
+        if name.startswith("quadtree"):
+            assert int(np.diff(A.indptr).max()) == 9 and ci["max_row_len"] == 9
+        assert S.reordered == (name.startswith("unstructured") or name.startswith("quadtree"))
         assert ci["chip_by_default"] and ci["workgroups"] == 256 and ci["threads"] == 512, ci
         res = S.solve(_dev(b), max_iter=max_iter)
         multi = S.solve(_dev(b), max_iter=max_iter, flags=D._lib.NO_SMALL)
@@ -2862,7 +2865,10 @@ def test_chip_solve_equals_the_device_tree_oracle_bit_for_bit(D, name, make, max
         assert np.array_equal(res.res_history, hist), (name, kind, int(np.argmax(res.res_history != hist)))
         xs = res.x.cpu().numpy()
         assert np.array_equal(xs[perm] if perm is not None else xs, x), (name, kind)
-        np.testing.assert_allclose(multi.res_history, hist, rtol=HIST_RTOL)
+        if name.startswith("quadtree"):      # 600 updates of a stagnating recurrence: two summation orders part ways beyond the first hundred
+            np.testing.assert_allclose(multi.res_history[:100], hist[:100], rtol=1e-8)
+        else:
+            np.testing.assert_allclose(multi.res_history, hist, rtol=HIST_RTOL)
         assert not np.array_equal(multi.res_history, res.res_history)        # (another summation order: it WAS the other path)
         again = S.solve(_dev(b), max_iter=max_iter)
         assert np.array_equal(again.res_history, res.res_history) and torch.equal(again.x, res.x)     # reproducible to the bit
