@@ -24,7 +24,7 @@ DEVICE, HOST = 0, 1
 PRECOND_NONE, PRECOND_JACOBI, PRECOND_CSR, PRECOND_LLT_MULTIPLY, PRECOND_LLT_SOLVE, PRECOND_CALLBACK = 0, 1, 2, 3, 4, 5
 PRECOND_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)   # dpcg_precond_fn
 INIT_CHECK_R, SPMV_F32, NO_GRAPH, NO_SMALL, VAL32_IF_LOSSLESS, NO_FUSE, NO_TEAM, TEAM = 1, 2, 4, 8, 16, 32, 64, 128
-REORDER_NONE, REORDER_AUTO, REORDER_ALWAYS = 0, 1, 2
+REORDER_NONE, REORDER_AUTO, REORDER_ALWAYS, REORDER_REGIONS = 0, 1, 2, 3
 ORDER_CALLER, ORDER_MULTICOLOR = 0, 1
 
 # name -> (restype, argtypes); every symbol include/dpcg.h declares

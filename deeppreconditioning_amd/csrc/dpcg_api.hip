@@ -416,55 +416,81 @@ extern "C" int dpcg_reorder(dpcg_handle_t h, int mode, dpcg_stream_t stream, int
     if (!h) return invalid("dpcg_reorder: NULL handle");
     if (applied) *applied = h->perm ? 1 : 0;
     if (mode == DPCG_REORDER_NONE || h->perm) return DPCG_OK;
-    if (mode != DPCG_REORDER_AUTO && mode != DPCG_REORDER_ALWAYS) return invalid("dpcg_reorder: bad mode");
+    if (mode != DPCG_REORDER_AUTO && mode != DPCG_REORDER_ALWAYS && mode != DPCG_REORDER_REGIONS) return invalid("dpcg_reorder: bad mode");
     hipStream_t s = (hipStream_t)stream;
     SetupScope scope(s, true);
+    // Everything that can fail is built FIRST, into locals; the handle is switched over only when all of it exists
+    // (a failure half way would otherwise leave the old plan on the new matrix).
+    auto adopt = [&](int32_t *perm, int32_t *iperm, CsrDev &B, SpmvPlan &planB) {
+        free_precond(h);                 // an attached preconditioner referred to the old matrix
+        dev_free(h->mc_perm);            // ... and so did a cached colouring
+        dev_free(h->mc_iperm);
+        h->mc_colors = 0;
+        free_ell(h->ell_a);
+        drop_graph(h);
+        dev_free(h->A.val32);            // recreated on demand from the reordered values
+        h->A.val32_lossless = 0;
+        free_plan(h->planA);
+        h->A_user = h->A;                // ownership (or the borrow) moves with the struct
+        h->A = B;
+        h->planA = planB;
+        h->perm = perm;
+        h->iperm = iperm;
+        if (applied) *applied = 1;
+    };
+    // order -> P A P^T -> its SpMV plan, all in locals; *keep = false (AUTO by regions) when the plan is not the x-tile one
+    auto build = [&](bool by_regions, bool tile_or_nothing, bool *keep) -> int {
+        PhaseTimer pt(s);
+        int32_t *perm = nullptr, *iperm = nullptr;
+        int st = by_regions ? region_order(h->A, region_order_default_regions(h->A.n), &perm, &iperm, s) : rcm_order(h->A, &perm, &iperm, nullptr, s);
+        pt.mark(by_regions ? "reorder: regions" : "reorder: RCM");
+        if (st < 0) return st;
+        CsrDev B;
+        SpmvPlan planB;
+        st = permute_csr(h->A, perm, iperm, B, s);
+        pt.mark("reorder: permute");
+        if (st >= 0) st = make_plan(B, planB, s, true);
+        pt.mark("reorder: plan");
+        *keep = st >= 0 && !(tile_or_nothing && planB.kernel != SPMV_TILE);
+        if (!*keep) {
+            dev_free(perm);
+            dev_free(iperm);
+            free_csr(B);
+            free_plan(planB);
+            return st;
+        }
+        adopt(perm, iperm, B, planB);
+        return DPCG_OK;
+    };
+    bool kept = false;
     if (mode == DPCG_REORDER_AUTO) {
-        // only where it pays: systems beyond one XCD's L2 reach whose plan is the gather kernel (no x-tile plan, or too
-        // few row blocks for one) and whose gather really is scattered (measured 64^3 scrambled: 31K -> 55K it/s)
+        // only where it pays: systems beyond one XCD's L2 reach whose plan is the gather kernel (no x-tile plan, or too few row
+        // blocks for one) and
+        //  (a) whose gather really is scattered (measured 64^3 scrambled: 31K -> 55K it/s): reverse Cuthill-McKee; or
+        //  (b) whose gather looks fine on average but whose x-tile plan was REFUSED -- some row blocks touch more than
+        //      kTileMaxChunks chunks of x (an OpenFOAM numbering: refinement appends cells) -- : the region-by-region numbering
+        //      (dpcg_reorder.hip: a few ms where RCM walks 2000 levels), kept only when the x-tile plan takes the result.
+        // DPCG_REORDER_REGIONS = 0: never by regions; 2: by regions ahead of RCM in case (a) too (development knob).
         if (h->planA.kernel != SPMV_STREAM || h->A.n < kReorderMinRows) return DPCG_OK;
         PhaseTimer ptg(s);
         DPCG_TRY(gather_line_ratio(h->A, &h->gather_ratio, s));
         ptg.mark("reorder: gather ratio");
-        if (h->gather_ratio <= 4.0) return DPCG_OK;
+        static const int regions_knob = [] { const char *e = getenv("DPCG_REORDER_REGIONS"); return e ? atoi(e) : 1; }();
+        const bool scattered = h->gather_ratio > 4.0;
+        const bool tile_refused = h->planA.nrb >= kTileMinBlocks && !getenv("DPCG_SPMV_KERNEL");
+        // (a banded system of short rows is solved in one launch by the whole chip, dpcg_chip.hip: a region numbering would cost it its band)
+        const bool chip_shape = h->A.n <= chip_max_rows() && h->planA.max_row_len >= 1 && h->planA.max_row_len <= chip_max_row_len(h->A.n) &&
+                                h->planA.max_band >= 0 && h->planA.max_band <= chip_max_band();
+        if (tile_refused && !chip_shape && regions_knob >= (scattered ? 2 : 1)) {
+            const int st = build(true, true, &kept);
+            if (st < 0 && st != DPCG_ERR_INVALID) return st;
+            if (kept) return DPCG_OK;
+        }
+        if (!scattered) return DPCG_OK;
     }
-    PhaseTimer pt(s);
-    int32_t *perm = nullptr, *iperm = nullptr;
-    int st = rcm_order(h->A, &perm, &iperm, nullptr, s);
-    pt.mark("reorder: RCM");
+    const int st = build(mode == DPCG_REORDER_REGIONS, false, &kept);
     if (st == DPCG_ERR_INVALID && mode == DPCG_REORDER_AUTO) return DPCG_OK;   // not a symmetric pattern: AUTO leaves the handle as it is
-    if (st < 0) return st;
-    // Everything that can fail is built FIRST, into locals; the handle is switched over only when all of it exists
-    // (a failure half way would otherwise leave the old plan on the new matrix).
-    CsrDev B;
-    SpmvPlan planB;
-    st = permute_csr(h->A, perm, iperm, B, s);
-    pt.mark("reorder: permute");
-    if (st >= 0) st = make_plan(B, planB, s, true);
-    pt.mark("reorder: plan");
-    if (st < 0) {
-        dev_free(perm);
-        dev_free(iperm);
-        free_csr(B);
-        free_plan(planB);
-        return st;
-    }
-    free_precond(h);                 // an attached preconditioner referred to the old matrix
-    dev_free(h->mc_perm);            // ... and so did a cached colouring
-    dev_free(h->mc_iperm);
-    h->mc_colors = 0;
-    free_ell(h->ell_a);
-    drop_graph(h);
-    dev_free(h->A.val32);            // recreated on demand from the reordered values
-    h->A.val32_lossless = 0;
-    free_plan(h->planA);
-    h->A_user = h->A;                // ownership (or the borrow) moves with the struct
-    h->A = B;
-    h->planA = planB;
-    h->perm = perm;
-    h->iperm = iperm;
-    if (applied) *applied = 1;
-    return DPCG_OK;
+    return st;
 }
 
 // New values on the pattern the handle was created with (the next pressure system of the same mesh): everything that

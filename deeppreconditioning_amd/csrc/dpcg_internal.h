@@ -524,6 +524,9 @@ int gather_line_ratio(const CsrDev &A, double *ratio, hipStream_t s);
 int permute_csr(const CsrDev &A, const int32_t *perm, const int32_t *iperm, CsrDev &B, hipStream_t s);
 int rcm_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_components, hipStream_t s);
 int multicolor_order(const CsrDev &A, int32_t **perm_out, int32_t **iperm_out, int *n_colors, hipStream_t s);
+// region-by-region numbering (dpcg_reorder.hip): `regions` searches grown at once, numbered region by region, ring by ring
+int region_order(const CsrDev &A, int regions, int32_t **perm_out, int32_t **iperm_out, hipStream_t s);
+int region_order_default_regions(int64_t n);
 // ---- structural analysis of triangular factors on the device (dpcg_analysis.hip) ----
 void launch_check_lower(const CsrDev &L, int *flags, hipStream_t s);
 void launch_row_of(int64_t n, const int32_t *rp, int32_t *row_of, hipStream_t s);

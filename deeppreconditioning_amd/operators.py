@@ -383,7 +383,7 @@ class SolveResult:
 
 
 _REORDER_MODES = {None: L.REORDER_NONE, False: L.REORDER_NONE, "none": L.REORDER_NONE, "auto": L.REORDER_AUTO,
-                  "rcm": L.REORDER_ALWAYS, True: L.REORDER_ALWAYS}
+                  "rcm": L.REORDER_ALWAYS, True: L.REORDER_ALWAYS, "regions": L.REORDER_REGIONS}
 
 
 class CsrSystem:
@@ -391,9 +391,10 @@ class CsrSystem:
 
     rowptr/col int32, val float64 or float32 CUDA tensors are borrowed (kept alive here).
 
-    `reorder`: "auto" (default) lets the library iterate on P A P^T in reverse Cuthill-McKee order when the numbering
-    scatters neighbours (large system, x-tile plan failed, measured x-gather traffic > 4x the bytes used: the
-    OpenFOAM-like case of BASELINE config 3); "rcm" forces it, None / "none" never reorders.  Everything the caller
+    `reorder`: "auto" (default) lets the library iterate on P A P^T when the numbering scatters neighbours (large system,
+    x-tile plan failed): in reverse Cuthill-McKee order when the measured x-gather traffic is > 4x the bytes used, in the
+    cheap region-by-region order when only some row blocks are too scattered (OpenFOAM's numbering after refinement: BASELINE
+    config 3) and the x-tile plan takes the result; "rcm" / "regions" force one, None / "none" never reorders.  Everything the caller
     passes or receives -- b, x0, x, `@`, dinv, M, L -- stays in the caller's numbering (`dpcg_reorder`, include/dpcg.h).
     """
 
@@ -420,7 +421,7 @@ class CsrSystem:
 
     def _reorder(self, mode) -> None:
         if mode not in _REORDER_MODES:
-            raise ValueError("reorder must be 'auto', 'rcm' or None")
+            raise ValueError("reorder must be 'auto', 'rcm', 'regions' or None")
         applied = C.c_int(0)
         if _REORDER_MODES[mode] != L.REORDER_NONE:
             with torch.cuda.device(self.device):

@@ -108,12 +108,15 @@ int dpcg_get_info(dpcg_handle_t h, int64_t *n, int64_t *nnz, int *spmv_kernel, i
  * gathered / scattered on the device, matrices permuted at setup; an IC(0) / L factor is the factor of the caller's
  * matrix, its level schedule merely relabelled).  Call it before attaching a preconditioner (an attached one is
  * dropped).  mode: DPCG_REORDER_AUTO reorders only when the system has >= 65536 rows, its SpMV plan is the gather
- * kernel (no x-tile plan) AND the measured x-gather traffic (distinct 128-byte lines per 256-row block) exceeds 4x
- * the bytes used; DPCG_REORDER_ALWAYS always.
+ * kernel (no x-tile plan) AND either the measured x-gather traffic (distinct 128-byte lines per 256-row block) exceeds
+ * 4x the bytes used (reverse Cuthill-McKee), or the traffic is fine on average but some row blocks are too scattered
+ * for the x-tile plan (OpenFOAM appends refined cells): then the cheap REGION-BY-REGION numbering is tried -- many
+ * breadth-first searches grown at once, numbered region by region and ring by ring -- and kept when the x-tile plan
+ * takes the result.  DPCG_REORDER_ALWAYS: reverse Cuthill-McKee always; DPCG_REORDER_REGIONS: region by region always.
  * *applied (may be NULL) = 1 when the handle now iterates on a reordered matrix.
  * PCG is invariant under symmetric permutation up to the order of floating-point sums: iterates agree with the
  * unpermuted solve to rounding, and to 1e-10 with the CPU reference run on P A P^T (dpcg_get_permutation). */
-enum dpcg_reorder_mode { DPCG_REORDER_NONE = 0, DPCG_REORDER_AUTO = 1, DPCG_REORDER_ALWAYS = 2 };
+enum dpcg_reorder_mode { DPCG_REORDER_NONE = 0, DPCG_REORDER_AUTO = 1, DPCG_REORDER_ALWAYS = 2, DPCG_REORDER_REGIONS = 3 };
 /* New values on the SAME sparsity pattern: val[nnz] in the order of the arrays dpcg_create was given (the caller's
  * promise -- only values are passed).  The reference builds a fresh tensor per sample (data_set.py / test.py:61-68);
  * the pressure systems of one mesh share their pattern, and the SpMV plan and the reordering depend on nothing else,

@@ -119,10 +119,10 @@ def _check_history(res, it, hist, dcount, drift, tag):
     assert stable >= min(m, 20), (tag, stable)              # the tight bar covers a real stretch of every history
 
 
-def _mesh_parity(D, A, expect, max_iter):
+def _mesh_parity(D, A, expect, max_iter, reorder="auto"):
     n = A.shape[0]
     b = O.rhs(n, 0)
-    S = D.CsrSystem.from_any(A)
+    S = D.CsrSystem.from_any(A, reorder=reorder)
     info = S.info()
     if expect.get("reordered") is not None:
         assert S.reordered == expect["reordered"], info
@@ -200,14 +200,15 @@ def test_unstructured_meshes_small(D, name, make):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,make,expect", [
-    ("quadtree_foam_1M", lambda: O.quadtree_fv_laplacian(1000, 0), {"max_colors": 8}),
+    ("quadtree_foam_1M", lambda: O.quadtree_fv_laplacian(1000, 0), {"reordered": True, "kernel": ("tile",), "max_colors": 8}),   # (by regions)
     ("quadtree_random_1M", lambda: O.quadtree_fv_laplacian(1000, 0, numbering="random"),
      {"reordered": True, "kernel": ("tile",), "max_colors": 8}),
     ("delaunay_1M", lambda: O.delaunay_laplacian(1000000, 0), {"reordered": True, "kernel": ("tile",), "max_colors": 9})])
 def test_config3_unstructured_meshes_million_dof(D, name, make, expect):
     """BASELINE config 3 ("OpenFOAM interFoam pressure-correction matrix, ~1M DoF, unstructured CSR") on matrices with irregular
-    degree, triangles and no grid structure: the plain call (the library reorders a scattered numbering by itself and plans the
-    x-tile SpMV on the result), 60 updates each of Jacobi, IC(0) in the caller's order (level-scheduled L / L^T solves) and IC(0)
+    degree, triangles and no grid structure: the plain call (the library reorders a scattered numbering by itself -- reverse
+    Cuthill-McKee; OpenFOAM's numbering, fine on average but too scattered in 12 % of its row blocks, region by region -- and plans
+    the x-tile SpMV on the result), 60 updates each of Jacobi, IC(0) in the caller's order (level-scheduled L / L^T solves) and IC(0)
     in multicolour order against the C oracle on the system the handle iterates on, the oracle's dot products in the device's
     reduction trees -- the colour sweeps' launch-by-launch <r,z> included: counts and histories EQUAL."""
     out = _mesh_parity(D, make(), expect, 60)
@@ -248,4 +249,55 @@ def test_million_row_meshes_full_length_histories(D, name, make):
     _, it_c, hist_c, _ = CO.pcg(B, b[perm], "llt_solve", L=Lq, precond_perm=qinv[perm], device_tree=geo)
     assert res.iterations == it_c and np.array_equal(res.res_history, hist_c), (name, res.iterations, it_c)
     assert it_c <= it            # (IC(0) never needs more updates than Jacobi here; the Delaunay system converges well inside the cap)
+    S.close()
+
+
+def _chunks_per_block(B):
+    """chunks of 64 x entries that the columns of each 256-row block touch (what the x-tile plan stages: at most 40)"""
+    n = B.shape[0]
+    blk = np.repeat(np.arange(n), np.diff(B.indptr)) // 256
+    u = np.unique(blk.astype(np.int64) * (n // 64 + 2) + B.indices // 64)
+    return np.bincount(u // (n // 64 + 2), minlength=(n + 255) // 256)
+
+
+@pytest.mark.gpu
+def test_region_by_region_numbering(D):
+    """The cheap locality order for OpenFOAM's numbering (refinement appends cells: the x-gather is fine on average, 12 % of the row
+    blocks are too scattered for the x-tile plan): forced on a 14K-row mesh -- a permutation, the same from create to create, PCG
+    parity on the system the handle iterates on through `_mesh_parity` -- and chosen BY ITSELF for the 1M-row quadtree mesh in
+    OpenFOAM's numbering, where the x-tile plan then takes every block.  A scattered numbering still goes through reverse
+    Cuthill-McKee (whose band the one-launch solve needs), a banded one is left alone."""
+    A = O.quadtree_fv_laplacian(96, 2)
+    n = A.shape[0]
+    S = D.CsrSystem.from_any(A, reorder="regions")
+    perm = S.permutation()
+    assert S.reordered and np.array_equal(np.sort(perm), np.arange(n))
+    S2 = D.CsrSystem.from_any(A, reorder="regions")
+    assert np.array_equal(S2.permutation(), perm)
+    S2.close()
+    S.close()
+    _mesh_parity(D, A, {"reordered": True}, 200, reorder="regions")
+    for tiny in (O.poisson2d(20), O.poisson2d(2), sp.csr_matrix(np.array([[2.0]]))):      # (fewer regions for few rows; one row)
+        St = D.CsrSystem.from_any(tiny, reorder="regions")
+        assert St.reordered and np.array_equal(np.sort(St.permutation()), np.arange(tiny.shape[0]))
+        St.close()
+    # 1M rows, OpenFOAM's numbering: AUTO takes the regions
+    A = O.quadtree_fv_laplacian(1000, 0)
+    n = A.shape[0]
+    before = _chunks_per_block(A)
+    assert (before > 40).mean() > 0.05
+    S = D.CsrSystem.from_any(A)
+    info = S.info()
+    assert S.reordered and info["spmv_kernel"] == "tile" and info["gather_ratio"] < 4.0, info
+    perm = S.permutation()
+    assert np.array_equal(np.sort(perm), np.arange(n))
+    B = _permuted(A, perm)
+    after = _chunks_per_block(B)
+    assert after.max() <= 40 and after.mean() < 0.7 * before.mean(), (after.max(), after.mean(), before.mean())
+    x = O.rhs(n, 3)
+    assert np.array_equal((S @ _dev(x)).cpu().numpy()[perm], CO.spmv(B, x[perm]))
+    S.close()
+    # a banded system of short rows keeps its numbering (the whole-chip solve needs the band), whatever its size
+    S = D.CsrSystem.from_any(O.poisson2d(700))
+    assert not S.reordered
     S.close()

@@ -37,7 +37,7 @@ def mean(v):
 
 F, W, R = load(fetch_dir), load(write_dir), load(rdreq_dir)
 cases = [l.split() for l in open(run_log) if l.split() and l.split()[0] in
-         ("quadtree_foam", "quadtree_foam_rcm", "quadtree_random", "quadtree_random_gather", "delaunay")]
+         ("quadtree_foam", "quadtree_foam_rcm", "quadtree_random", "quadtree_random_gather", "delaunay", "quadtree_foam_as_is")]
 lines = [f"# SpMV memory-side traffic on the config-3 mesh systems ({tag})", "",
          "`rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 tools/pmc_mesh_run.py`, three passes; per launch of the",
          "in-loop SpMV (+<p,Ap>) kernel.  Algorithmic bytes = nnz x 12 + (n + 1) x 4 + 16 n (SURVEY.md 8-d3).", "",

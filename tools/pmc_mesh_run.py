@@ -1,6 +1,7 @@
 """Workload for the PMC passes over the config-3 mesh systems (rocprofv3 --pmc <C> --kernel-trace -- python3 tools/pmc_mesh_run.py):
 per system a marker dispatch (k_gen_poisson), then the in-loop SpMV (+<p,Ap>) kernel 20 times on the handle as the plain call builds
-it (reorder="auto") and, for the quadtree mesh in OpenFOAM's numbering, also reordered."""
+it (reorder="auto": region by region for the quadtree mesh in OpenFOAM's numbering, reverse Cuthill-McKee for the scattered ones) and,
+for the OpenFOAM numbering, also in RCM order and as it comes."""
 import pathlib
 import sys
 
@@ -16,7 +17,8 @@ CASES = [("quadtree_foam", lambda: meshes.quadtree_fv_laplacian(1000, 0), "auto"
          ("quadtree_foam_rcm", lambda: meshes.quadtree_fv_laplacian(1000, 0), "rcm"),
          ("quadtree_random", lambda: meshes.quadtree_fv_laplacian(1000, 0, numbering="random"), "auto"),
          ("quadtree_random_gather", lambda: meshes.quadtree_fv_laplacian(1000, 0, numbering="random"), None),
-         ("delaunay", lambda: meshes.delaunay_laplacian(1000000, 0), "auto")]
+         ("delaunay", lambda: meshes.delaunay_laplacian(1000000, 0), "auto"),
+         ("quadtree_foam_as_is", lambda: meshes.quadtree_fv_laplacian(1000, 0), None)]      # (round 5: "auto" numbers it region by region)
 if __name__ == "__main__":
     for name, make, mode in CASES:
         A = make()
