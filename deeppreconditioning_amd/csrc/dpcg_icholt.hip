@@ -10,8 +10,10 @@
 // order -- the 64 lanes share a column's work: the loads of its dependencies' entries, the updates of distinct candidates
 // (an LDS hash table keyed by row), the rank-counting sorts of the few candidates -- with every sum in the oracle's order
 // (ascending j, then ascending row; one product and one subtraction at a time; -ffp-contract=off), so the factor equals the
-// CPU restatement bit for bit.  Two dependent memory round trips per column (see k_icholt); times by size: tools/icholt_probe.py,
-// profiles/r04_icholt_probe.txt.  It is the setup of a technique the reference runs on ~2K-row systems.
+// CPU restatement bit for bit.  One dependent memory round trip per column (see k_icholt); times by size: tools/icholt_probe.py,
+// profiles/r04_icholt_probe.txt.  It is the setup of a technique the reference runs on ~2K-row systems: those -- every system whose
+// factor fits one CU's LDS -- go through k_icholt_lds below, a pipeline of four waves over an LDS-resident factor (round 5:
+// 2.7 ms instead of 4.8 at 2.4K rows, profiles/r05_icholt_probe.txt; what is left is the chain of the selection itself).
 #include "dpcg_host.h"
 #include "dpcg_prims.h"
 
@@ -394,6 +396,253 @@ __global__ __launch_bounds__(64) void k_icholt(int n, const int32_t *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same factorisation for systems whose factor fits ONE CU's LDS (the reference's sizes: ~2K rows, test.py:130-135), as a pipeline
+// of W waves of one workgroup.  The algorithm stays a chain -- column k needs L_kj L_ij of its last dependency j = k - 1 -- but only
+// THAT update and the selection (two square roots, a division, the sum of squares) are on the chain: the rest of a column's work (its
+// row of A, its earlier dependencies, the candidates they create) is done by another wave while the columns before it finish.
+//   * wave w takes the columns k = w, w + W, ...;
+//   * the factor lives in an LDS pool in column order (columns finish in order, so the pool is L's strict lower triangle in CSC:
+//     pval[p], pmeta[p] = row | column << 12 | (entries of the column after this one) << 24), each row's kept entries chained through
+//     pnext[p] in ascending column (rhead / rtail);
+//   * a wave walks its row's chain as far as it reaches -- one entry = one dependency: L_kj = pval[p], the entries of column j below
+//     row k follow at p + 1 .. p + rem -- and waits at its end for either a new link or `done >= k` (every column before k final:
+//     the chain is complete); then it selects, appends its column to the pool, links its entries into their rows' chains and
+//     publishes done = k + 1.
+// One wave's LDS operations are performed in order and a store is performed for all its lanes before the wave's next LDS operation:
+// entries are written before the links that lead to them, links before `done` -- the fences are compiler-level only.
+// Anything beyond the plain case (a row of A of more than 64 entries, more than 64 candidates, a row of L of more than 64 entries,
+// a breakdown) ends the kernel with ICHOLT_RETRY: the one-wave kernel above runs the factorisation again and reports what it finds.
+// Every sum in the oracle's order, as above: the factor is the same, bit for bit.
+constexpr int kLdsNil = 0xffff;
+constexpr int kLdsMaxRows = 4096;            // 12 bits of pmeta for the row, 12 for the column
+enum { ICHOLT_RETRY = 6 };
+
+__device__ __forceinline__ int lds_ld_i(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st_i(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int lds_ld_u16(const uint16_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st_u16(uint16_t *p, int v) { __hip_atomic_store(p, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+size_t icholt_lds_bytes(int n, int pool_cap, int waves) {
+    const size_t pool = (size_t)pool_cap + 64, rows = ((size_t)n + 3) & ~(size_t)3;
+    return pool * 8 + (size_t)waves * 64 * 8 + pool * 4 + (size_t)waves * 64 * 4 + (pool + (pool & 1)) * 2 + 3 * rows * 2;
+}
+
+template <int W, bool TR = false>
+__global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__restrict__ arp, const int32_t *__restrict__ aci,
+                                                       const double *__restrict__ av, int add_fill, double tau, int pool_cap,
+                                                       double *diag, int32_t *lrp, int32_t *lci, double *lv, int *status) {
+    constexpr int kNone = 0x7fffffff;
+    extern __shared__ double smem[];
+    const int pool = pool_cap + 64, rows = (n + 3) & ~3;
+    double *const pval = smem;                                          // [pool]
+    double *const sv_all = pval + pool;                                 // [W][64]   a wave's candidates sorted by row
+    uint32_t *const pmeta = (uint32_t *)(sv_all + W * 64);              // [pool]
+    int *const si_all = (int *)(pmeta + pool);                          // [W][64]
+    uint16_t *const pnext = (uint16_t *)(si_all + W * 64);              // [pool (+1)]
+    uint16_t *const rhead = pnext + pool + (pool & 1);                  // [rows]
+    uint16_t *const rtail = rhead + rows;
+    uint16_t *const rcnt = rtail + rows;
+    __shared__ int s_done, s_abort;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int i = threadIdx.x; i < rows; i += W * 64) { rhead[i] = kLdsNil; rtail[i] = kLdsNil; rcnt[i] = 0; }
+    if (threadIdx.x == 0) { s_done = 0; s_abort = 0; }
+    __syncthreads();
+    auto give_up = [&](int col) {
+        if (lane == 0) {
+            if (atomicCAS(&s_abort, 0, 1) == 0) { status[0] = ICHOLT_RETRY; status[1] = col; }
+        }
+    };
+    // this wave's next row of A, fetched a round ahead (its row pointers two rounds ahead: the loads of a row do not wait for them)
+    // (the pointers come through the vector-memory path, lane 0 and lane 1: a scalar load would share its counter with the LDS
+    // operations, and the first LDS read of a column would wait for it)
+    int p0 = 0, p1 = 0, qv = 0, ac = -1;
+    double ax = 0.0;
+    if (w < n) {
+        p0 = arp[w]; p1 = arp[w + 1];
+        if (p0 + lane < p1) { ac = aci[p0 + lane]; ax = av[p0 + lane]; }
+    }
+    if (w + W < n) qv = arp[w + W + (lane & 1)];
+    const long long t_start = wall_clock64();
+    bool alive = true;
+    long long tr[6] = {0, 0, 0, 0, 0, 0}, tc = 0;      // TR: cycles in [0] row of A, [1] waiting, [2] dependencies, [3] selection, [4] publication
+    auto lap = [&](int which) {
+        if (TR) {
+            const long long now = clock64();
+            tr[which] += now - tc;
+            tc = now;
+        }
+    };
+    if (TR) tc = clock64();
+    for (int k = w; k < n && alive; k += W) {
+        const int alen = p1 - p0, my_c = ac;
+        const double my_v = ax;
+        ac = -1;
+        p0 = lane_i(qv, 0); p1 = lane_i(qv, 1);
+        if (k + W < n && p0 + lane < p1) { ac = aci[p0 + lane]; ax = av[p0 + lane]; }
+        if (k + 2 * W < n) qv = arp[k + 2 * W + (lane & 1)];
+        if (alen > 64) { give_up(k); break; }
+        // ---- column k of A: candidates below the diagonal (lane c: candidate c), the diagonal
+        const unsigned long long at_diag = __ballot(my_c == k);
+        const int pk = __popcll(__ballot(my_c > k)) + add_fill;
+        if (!at_diag || pk > kIctCap) { give_up(k); break; }
+        double dg = lane_d(my_v, __ffsll((long long)at_diag) - 1);
+        int me = kNone, nl = alen;
+        double val = 0.0;
+        if (my_c > k) { me = my_c; val = my_v; }
+        // ---- the dependencies, in ascending j as the chain of row k holds them
+        int prev = kLdsNil, spins = 0, base = 0;
+        lap(0);
+        for (;;) {
+            const int d = first_i(lds_ld_i(&s_done));            // columns final | pool entries in use << 13
+            wave_sync();
+            const int p = first_i(prev == kLdsNil ? lds_ld_u16(rhead + k) : lds_ld_u16(pnext + prev));
+            if (p == kLdsNil) {
+                lap(1);
+                if ((d & 0x1fff) >= k) { base = d >> 13; break; }
+                if (lds_ld_i(&s_abort)) { alive = false; break; }
+                if ((++spins & 1023) == 0 && wall_clock64() - t_start > 100000000ll) { give_up(k); alive = false; break; }   // 1 s
+                continue;
+            }
+            wave_sync();
+            const uint32_t em = pmeta[p + lane];
+            const double ev = pval[p + lane];
+            const double lkj = lane_d(ev, 0);
+            const unsigned em0 = (unsigned)lane_i((int)em, 0);
+            const int rem = (int)(em0 >> 24);
+            dg = dg - lkj * lkj;
+            const int erow = (int)(em & 0xfffu);
+            const double prod = lkj * ev;
+            for (int q = 1; q <= rem; ++q) {                      // (no branch inside: a taken branch costs more than these selects)
+                const int ip = lane_i(erow, q);
+                const double pp = lane_d(prod, q);
+                const bool hit = me == ip;
+                const bool fresh = __ballot(hit) == 0ull;
+                const bool take = fresh && lane == nl;
+                const double upd = (take ? 0.0 : val) - pp;
+                val = (hit || take) ? upd : val;
+                me = take ? ip : me;
+                nl += fresh ? 1 : 0;
+            }
+            if (nl > 64) { give_up(k); alive = false; break; }
+            prev = p;
+            lap(2);
+            // the link of column k - 1: no column before k can add another, and the pool ends behind that column
+            if ((int)((em0 >> 12) & 0xfffu) == k - 1) { base = p + rem + 1; break; }
+        }
+        if (!alive) break;
+        if (!(dg > 0.0)) { give_up(k); break; }
+        // ---- the candidates sorted by row (rank counting; lane `rank` receives), norm, threshold, the pk largest (as k_icholt)
+        // (loops of a fixed length for the usual sizes: lanes beyond the candidates hold kNone / 0 and change nothing)
+        int rank = 0;
+        if (nl <= 8) {
+#pragma unroll
+            for (int o = 0; o < 8; ++o) rank += lane_i(me, o) < me ? 1 : 0;
+        } else if (nl <= 16) {
+#pragma unroll
+            for (int o = 0; o < 16; ++o) rank += lane_i(me, o) < me ? 1 : 0;
+        } else {
+            for (int o = 0; o < nl; ++o) rank += lane_i(me, o) < me ? 1 : 0;
+        }
+        const int ncand = __popcll(__ballot(me != kNone));
+        const long long vb = __double_as_longlong(val);
+        const int row_s = __builtin_amdgcn_ds_permute(rank << 2, me);
+        const unsigned lo_s = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)vb);
+        const unsigned hi_s = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)(vb >> 32));
+        const int row = lane < ncand ? row_s : kNone;
+        const double wv = lane < ncand ? __longlong_as_double((long long)(((unsigned long long)hi_s << 32) | lo_s)) : 0.0;
+        // (this wave is the next to publish: the ends of the chains it will append to do not move any more)
+        const int t_tail = lane < ncand ? (int)rtail[row] : kLdsNil, t_cnt = lane < ncand ? (int)rcnt[row] : 0;
+        const double sq = wv * wv, aw = fabs(wv);
+        double ss = 0.0;
+        if (ncand <= 8) {                                          // (+ 0.0 behind the last candidate: the same sum)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) ss = ss + lane_d(sq, c);
+        } else {
+            for (int c = 0; c < ncand; ++c) ss = ss + lane_d(sq, c);
+        }
+        const double both = sqrt(lane == 0 ? ss : dg);                 // lane 0: the norm; the others: the pivot
+        const double dk = lane_d(both, 1);
+        const double bound = tau * lane_d(both, 0);
+        const bool pass = lane < ncand && !(aw < bound);
+        const unsigned long long passed = __ballot(pass);
+        bool kp = pass;
+        if (__popcll(passed) > pk) {
+            int better = 0;
+            const double mag = pass ? aw : -1.0;                   // (a candidate below the threshold beats nobody)
+            if (ncand <= 8) {
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    const double other = lane_d(mag, o);
+                    better += (other > aw || (other == aw && o < lane)) ? 1 : 0;
+                }
+            } else {
+                for (int o = 0; o < ncand; ++o) {
+                    const double other = lane_d(mag, o);
+                    better += (other > aw || (other == aw && o < lane)) ? 1 : 0;
+                }
+            }
+            kp = pass && better < pk;
+        }
+        const unsigned long long kept = __ballot(kp);
+        const int nkept = __popcll(kept), pos = __popcll(kept & below);
+        lap(3);
+        // ---- column k joins the pool; its entries join their rows' chains; done = k + 1
+        if (base + nkept > pool_cap) { give_up(k); break; }
+        if (__ballot(kp && t_cnt >= kIctCap)) { give_up(k); break; }
+        const int at = base + pos;
+        // (in this order: whoever sees a link finds the entries behind it, and -- the next wave to publish, which may have gone ahead on
+        // the link alone -- the new ends of the chains; `done` only ever grows: the wave of column k + 1 may publish before this store)
+        if (kp) {
+            pval[at] = wv / dk;
+            pmeta[at] = (uint32_t)row | (uint32_t)k << 12 | (uint32_t)(nkept - 1 - pos) << 24;
+            pnext[at] = kLdsNil;
+            rtail[row] = (uint16_t)at;
+            rcnt[row] = (uint16_t)(t_cnt + 1);
+        }
+        wave_sync();
+        if (kp) {
+            if (t_tail == kLdsNil) lds_st_u16(rhead + row, at);
+            else lds_st_u16(pnext + t_tail, at);
+        }
+        wave_sync();
+        if (lane == 0) {
+            atomicMax(&s_done, (k + 1) | (base + nkept) << 13);
+            diag[k] = dk;
+        }
+        wave_sync();
+        lap(4);
+    }
+    if (TR && lane == 0)
+        for (int q = 0; q < 5; ++q) status[8 + w * 8 + q] = (int)(tr[q] >> 4);
+    __syncthreads();
+    if (s_abort) return;
+    // ---- L as CSR (row i = its chain, columns ascending, then the diagonal): row pointers by a scan over the threads' runs of rows
+    constexpr int T = W * 64;
+    const int per = (n + T - 1) / T, r_lo = min(n, (int)threadIdx.x * per), r_hi = min(n, r_lo + per);
+    int mine = 0;
+    for (int i = r_lo; i < r_hi; ++i) mine += rcnt[i] + 1;
+    int *const sums = si_all;                                             // [T]
+    sums[threadIdx.x] = mine;
+    __syncthreads();
+    int at = 0;
+    for (int u = 0; u < (int)threadIdx.x; ++u) at += sums[u];
+    if (threadIdx.x == T - 1) { lrp[n] = at + mine; status[2] = at + mine; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");               // (diag[] was stored by other waves of this workgroup)
+    for (int i = r_lo; i < r_hi; ++i) {
+        lrp[i] = at;
+        for (int p = rhead[i]; p != kLdsNil; p = pnext[p]) {
+            lci[at] = (int)((pmeta[p] >> 12) & 0xfffu);
+            lv[at] = pval[p];
+            ++at;
+        }
+        lci[at] = i;
+        lv[at] = __hip_atomic_load(diag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ++at;
+    }
+}
+
 // L as CSR: row i = its list (columns ascending) followed by the diagonal
 __global__ __launch_bounds__(kBlock) void k_icholt_count(int n, const int *__restrict__ rcnt, int32_t *__restrict__ cnt) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -434,6 +683,59 @@ int icholt_factor(const CsrDev &A, int add_fill_in, double threshold, CsrDev &Lf
         return st;
     };
     int st = DPCG_OK;
+    // ---- systems whose factor fits one CU's LDS: the pipeline of waves (k_icholt_lds).  DPCG_ICHOLT_LDS=0: never (development / tests);
+    // DPCG_ICHOLT_WAVES = 4 | 8 | 16 (development)
+    {
+        const char *e_lds = getenv("DPCG_ICHOLT_LDS"), *e_waves = getenv("DPCG_ICHOLT_WAVES");
+        const bool lds_on = !(e_lds && e_lds[0] == '0');
+        const int waves_arg = e_waves ? atoi(e_waves) : 4, waves = waves_arg == 8 || waves_arg == 16 ? waves_arg : 4;   // (one a SIMD)
+        // kept entries: at most nnz(A[k+1:, k]) + add_fill_in a column = the strict upper triangle of A + n add_fill_in
+        const int64_t pool_cap = (A.nnz - n + 1) / 2 + n * (int64_t)add_fill_in + 1;
+        if (lds_on && n >= 1 && n <= kLdsMaxRows && pool_cap < 0xff00 && icholt_lds_bytes((int)n, (int)pool_cap, waves) + 64 <= 160 * 1024) {
+            const int64_t cap_nnz = pool_cap + n;
+            if ((st = dev_alloc(&diag, n)) < 0 || (st = dev_alloc(&status, 8 + 16 * 8)) < 0 || (st = dev_alloc(&Lf.rowptr, n + 1)) < 0 ||
+                (st = dev_alloc(&Lf.col, cap_nnz)) < 0 || (st = dev_alloc(&Lf.val, cap_nnz)) < 0)
+                return cleanup(st);
+            hipError_t e = hipMemsetAsync(status, 0, 4 * sizeof(int), s);
+            if (e != hipSuccess) return cleanup(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
+            const size_t lds = icholt_lds_bytes((int)n, (int)pool_cap, waves);
+            const bool trace = getenv("DPCG_ICHOLT_TRACE") != nullptr;          // (development: cycles by phase, per wave, on stderr)
+#define DPCG_ICHOLT_LDS_LAUNCH(WV, TRC)                                                                                              \
+    do {                                                                                                                             \
+        e = hipFuncSetAttribute((const void *)k_icholt_lds<WV, TRC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+        if (e == hipSuccess)                                                                                                         \
+            hipLaunchKernelGGL((k_icholt_lds<WV, TRC>), dim3(1), dim3(WV * 64), lds, s, (int)n, A.rowptr, A.col, A.val, add_fill_in, \
+                               threshold, (int)pool_cap, diag, Lf.rowptr, Lf.col, Lf.val, status);                                   \
+    } while (0)
+            if (trace && waves == 8) DPCG_ICHOLT_LDS_LAUNCH(8, true);
+            else if (trace) DPCG_ICHOLT_LDS_LAUNCH(4, true);
+            else if (waves == 8) DPCG_ICHOLT_LDS_LAUNCH(8, false);
+            else if (waves == 16) DPCG_ICHOLT_LDS_LAUNCH(16, false);
+            else DPCG_ICHOLT_LDS_LAUNCH(4, false);
+#undef DPCG_ICHOLT_LDS_LAUNCH
+            int h_st[3] = {0, 0, 0};
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(h_st, status, sizeof(h_st), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return cleanup(hip_fail(e, "icholt (LDS)", __FILE__, __LINE__));
+            if (trace) {
+                int h_tr[16 * 8] = {0};
+                const int tw = waves == 8 ? 8 : 4;
+                (void)hipMemcpy(h_tr, status + 8, sizeof(h_tr), hipMemcpyDeviceToHost);
+                for (int wv = 0; wv < (waves == 8 ? 8 : 4); ++wv)
+                    fprintf(stderr, "[icholt lds] wave %d: cycles per column (of %lld): row of A %.0f, waiting %.0f, dependencies %.0f, selection %.0f, publication %.0f\n",
+                            wv, (long long)n, h_tr[wv * 8 + 0] * 16.0 * tw / n, h_tr[wv * 8 + 1] * 16.0 * tw / n, h_tr[wv * 8 + 2] * 16.0 * tw / n,
+                            h_tr[wv * 8 + 3] * 16.0 * tw / n, h_tr[wv * 8 + 4] * 16.0 * tw / n);
+            }
+            if (h_st[0] == ICHOLT_OK) {
+                Lf.nnz = h_st[2];
+                return cleanup(DPCG_OK);
+            }
+            // not the plain case: the one-wave kernel runs it again (and names what is wrong, if something is)
+            dev_free(diag); dev_free(status); dev_free(Lf.rowptr); dev_free(Lf.col); dev_free(Lf.val);
+            diag = nullptr; status = nullptr; Lf.rowptr = nullptr; Lf.col = nullptr; Lf.val = nullptr;
+        }
+    }
     const int64_t wide = n * kIctCap;
     if ((st = dev_alloc(&rcnt, n)) < 0 || (st = dev_alloc(&rcol, wide)) < 0 || (st = dev_alloc(&rcc, wide)) < 0 ||
         (st = dev_alloc(&rval, wide)) < 0 || (st = dev_alloc(&crow, wide)) < 0 ||

@@ -1757,19 +1757,21 @@ def _banded_random_spd(n, per_row, band, seed):
     return A
 
 
-@pytest.mark.parametrize("regs", ["1", "0"])
-def test_icholt_as_ilupp_defines_it(D, monkeypatch, regs):
+@pytest.mark.parametrize("lds,regs", [("1", "1"), ("0", "1"), ("0", "0")])
+def test_icholt_as_ilupp_defines_it(D, monkeypatch, lds, regs):
     """`ICholT` = `ilupp.icholt(A, add_fill_in, threshold)`, the reference harness's default technique (test.py:81-88), factored
     on the device column by column with ILU++'s dual-threshold rule.  The ilupp binary is absent (parity unpinned against it):
     the device factor equals the restatement of the published algorithm, oracle.icholt, BIT FOR BIT -- pattern and values --
     on grids, scaled / scrambled systems, a quadtree mesh with hanging nodes and a Delaunay graph, a banded random matrix whose
-    columns hold more than 64 candidates (the LDS selection) -- for the harness's arguments and others, with the candidates of
-    a column in registers (`regs` = 1, the default) and with every column through the LDS hash table (DPCG_ICHOLT_REGS=0: the
-    path of columns with many updates); PCG with the factor solved and multiplied matches the oracle with the same factor;
+    columns hold more than 64 candidates (the LDS selection) -- for the harness's arguments and others; as the plain call runs it
+    (systems whose factor fits one CU's LDS: the pipeline of waves, k_icholt_lds, which hands the columns beyond its plain case
+    to the one-wave kernel), with the one-wave kernel alone (DPCG_ICHOLT_LDS=0), candidates of a column in registers, and with
+    every column through its LDS hash table (DPCG_ICHOLT_REGS=0: the path of columns with many updates); PCG with the factor solved and multiplied matches the oracle with the same factor;
     the limits and the error paths of the ABI."""
     from deeppreconditioning_amd._lib import DpcgError, ERR_INVALID, ERR_PIVOT
     monkeypatch.setenv("DPCG_ICHOLT_REGS", regs)
-    cases = [(O.poisson2d(24), 1, 0.1), (O.poisson2d(24), 0, 0.0), (O.poisson3d(10), 1, 0.1), (O.poisson3d(10), 3, 0.01),
+    monkeypatch.setenv("DPCG_ICHOLT_LDS", lds)
+    cases = [(O.poisson2d(49), 1, 0.1), (O.poisson2d(24), 1, 0.1), (O.poisson2d(24), 0, 0.0), (O.poisson3d(10), 1, 0.1), (O.poisson3d(10), 3, 0.01),
              (O.unstructured_like(O.poisson3d(9), seed=2), 1, 0.1), (O.unstructured_like(O.poisson2d(40), seed=5), 2, 0.05),
              (O.quadtree_fv_laplacian(40, 1), 1, 0.1), (O.quadtree_fv_laplacian(40, 1, numbering="random"), 4, 0.001),
              (O.delaunay_laplacian(3000, 4), 1, 0.1), (_banded_random_spd(400, 10, 150, 7), 8, 1e-4), (O.poisson2d(12), 200, 0.0)]

@@ -49,7 +49,9 @@ for case in range(cases):
         Lref = O.icholt(A, fill, thr)
     except ValueError as e:
         Lref = str(e)
-    for regs in ("1", "0"):
+    for lds, regs in (("1", "1"), ("0", "1"), ("0", "0")):
+        os.environ["DPCG_ICHOLT_LDS"] = lds
+        os.environ["DPCG_ICHOLT_WAVES"] = str(int(rng.choice([4, 8, 16])))
         os.environ["DPCG_ICHOLT_REGS"] = regs
         S = D.CsrSystem.from_any(A, reorder=None)
         try:
@@ -64,7 +66,7 @@ for case in range(cases):
             ok = np.array_equal(got[0], Lref.indptr) and np.array_equal(got[1], Lref.indices) and np.array_equal(got[2], Lref.data)
         if not ok:
             bad += 1
-            print(f"MISMATCH case {case} regs {regs}: n {n} per_row {per_row} band {band} scramble {scramble} dominance {dominance} fill {fill} thr {thr}: "
+            print(f"MISMATCH case {case} lds {lds} regs {regs}: n {n} per_row {per_row} band {band} scramble {scramble} dominance {dominance} fill {fill} thr {thr}: "
                   f"oracle {Lref if isinstance(Lref, str) else 'factor'} / device {got if isinstance(got, str) else 'factor'}", flush=True)
     what = Lref if isinstance(Lref, str) else f"nnz(L) {Lref.nnz}"
     print(f"case {case}: n {n} per_row {per_row} band {band} scramble {scramble} fill {fill} thr {thr}: {what}", flush=True)
