@@ -55,6 +55,10 @@ template <int RPT, int WMAX, bool JAC, int MODE>
 __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     constexpr bool TRACE = MODE == 1;      // (development -- MODE 2: q = p instead of the gathers, the loop never stops before max_iter; MODE 3: the gathers
                                            // issued, but every one out of range: no memory request, zeros returned)
+    // MODE 4: BASELINE config 5 -- `A @ pk` (cg.py:75) with the matrix values and pk STORED in fp32, products and sums in fp64 (the
+    // contract of DPCG_SPMV_F32: the oracle's orc_spmv_mixed).  The values are rounded once, where they are read; a gathered p is
+    // rounded where it is recomputed.  Everything else is the fp64 arithmetic of MODE 0 (x0 = 0 only: cg.py:60 reads the fp64 A).
+    constexpr bool F32 = MODE == 4;
     constexpr int NS = RPT * WMAX;                                   // entry slots of a thread
     constexpr int NLDS = NS < kChipLdsSlots ? NS : kChipLdsSlots;    // ... whose values live in LDS
     constexpr int NREG = NS - NLDS;                                  // ... and in registers (the first NREG slots)
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
             const int s = k * WMAX + j;
             const bool on = j < len_k[k];
             const int c = on ? cj[j] : i;
-            const double a = on ? aj[j] : 0.0;
+            const double a = on ? (F32 ? (double)(float)aj[j] : aj[j]) : 0.0;
             const unsigned del = (unsigned)(c - i + 32768) & 0xffffu;
             if (s & 1) dl[s >> 1] |= del << 16;
             else dl[s >> 1] = del;
@@ -171,7 +175,8 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
             for (int j = 0; j < WMAX; ++j) {
                 const int s = k * WMAX + j;
                 const double a = s < NREG ? vr[s < NREG ? s : 0] : lvt[(s - NREG) * kChipThreads];
-                const double pc = lo_f64(g[k & 1][j]) + beta * hi_f64(g[k & 1][j]);    // = p_k[c], cg.py:83
+                const double pc64 = lo_f64(g[k & 1][j]) + beta * hi_f64(g[k & 1][j]);  // = p_k[c], cg.py:83
+                const double pc = F32 ? (double)(float)pc64 : pc64;
                 if (j < len) acc += a * pc;
             }
             q[k] = acc;
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         ++k_done;
         if (v == 0 && t == 0 && k_done < d.hist_cap) d.hist[k_done] = res;
         const bool conv = (res < d.rtol_sq) || (rr < d.atol_sq);  // cg.py:71, tested before the next update's work
-        if (MODE >= 2) continue;                                  // (development: a fixed number of updates whatever the numbers do)
+        if (MODE == 2 || MODE == 3) continue;                                 // (development: a fixed number of updates whatever the numbers do)
         if (conv) { stop = true; status = DPCG_OK; }
         else if (!(res == res)) { stop = true; status = DPCG_BREAKDOWN; }
     }
@@ -435,8 +440,9 @@ int launch_pcg_chip(const ChipDesc &d, int max_row_len, hipStream_t s, bool chec
     const int rpt = (d.per + kChipThreads - 1) / kChipThreads;
     if (max_row_len < 1 || max_row_len > (rpt <= 4 ? 9 : 7) || d.per < 1 || d.per > kChipThreads * kChipMaxRpt) return DPCG_ERR_INVALID;
     const bool jac = d.precond == DPCG_PRECOND_JACOBI;
-    const int mode = d.bench == 3 ? 3 : (d.bench ? 2 : (d.dbg != nullptr ? 1 : 0));
-#define DPCG_CHIP_T(RPTV, WV, JV) (mode == 3 ? chip_launch<RPTV, WV, JV, 3>(d, s, check_only) : mode == 2 ? chip_launch<RPTV, WV, JV, 2>(d, s, check_only) : (mode == 1 ? chip_launch<RPTV, WV, JV, 1>(d, s, check_only) : chip_launch<RPTV, WV, JV, 0>(d, s, check_only)))
+    const int mode = d.bench == 3 ? 3 : (d.bench ? 2 : (d.dbg != nullptr ? 1 : (d.f32 ? 4 : 0)));
+    if (d.f32 && (mode != 4 || d.x0)) return DPCG_ERR_INVALID;
+#define DPCG_CHIP_T(RPTV, WV, JV) (mode == 4 ? chip_launch<RPTV, WV, JV, 4>(d, s, check_only) : mode == 3 ? chip_launch<RPTV, WV, JV, 3>(d, s, check_only) : mode == 2 ? chip_launch<RPTV, WV, JV, 2>(d, s, check_only) : (mode == 1 ? chip_launch<RPTV, WV, JV, 1>(d, s, check_only) : chip_launch<RPTV, WV, JV, 0>(d, s, check_only)))
 #define DPCG_CHIP_W(RPTV, WV) (jac ? DPCG_CHIP_T(RPTV, WV, true) : DPCG_CHIP_T(RPTV, WV, false))
 #define DPCG_CHIP_R(RPTV) (max_row_len <= 5 ? DPCG_CHIP_W(RPTV, 5) : DPCG_CHIP_W(RPTV, 7))
 #define DPCG_CHIP_R9(RPTV) (max_row_len <= 5 ? DPCG_CHIP_W(RPTV, 5) : (max_row_len <= 7 ? DPCG_CHIP_W(RPTV, 7) : DPCG_CHIP_W(RPTV, 9)))

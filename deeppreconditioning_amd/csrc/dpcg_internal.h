@@ -462,6 +462,7 @@ struct ChipDesc {
     double *zp;                // 2 x (n + 4096) granules {z_{k+1}[i], p_k[i]}: the copy read inside a group and the written-through one
     int band;                  // largest |col - row| of the matrix
     int bench;                 // development (DPCG_CHIP_BENCH): the kernel variant without the gathers of q = A p (q = p) that never stops before max_iter
+    int f32;                   // DPCG_SPMV_F32 (BASELINE config 5): matrix values and p of `A @ p` stored in fp32, products and sums in fp64; x0 = 0 only
     int *xcc;                  // 256 words: the XCD every workgroup found itself on (exchanged once per solve); null: never store plainly
     double rtol_sq, atol_sq;
     Scalars *out;

@@ -684,7 +684,7 @@ static bool chip_eligible(const dpcg_system *h, int flags, const double *x_true)
         return cus >= chip_workgroups();         // one workgroup per CU, all resident
     }();
     static const int min_rows = [] { const char *e = getenv("DPCG_CHIP_MIN_ROWS"); return e ? atoi(e) : team_max_rows(); }();
-    if (!enabled || x_true || (flags & (DPCG_SPMV_F32 | DPCG_NO_TEAM | DPCG_NO_FUSE | DPCG_VAL32_IF_LOSSLESS))) return false;
+    if (!enabled || x_true || (flags & (DPCG_NO_TEAM | DPCG_NO_FUSE | DPCG_VAL32_IF_LOSSLESS))) return false;   // (DPCG_SPMV_F32: with x0 = 0, see the callers)
     if (h->A.n <= min_rows || h->A.n > chip_max_rows()) return false;
     if (h->planA.max_row_len < 1 || h->planA.max_row_len > chip_max_row_len(h->A.n)) return false;
     if (h->planA.max_band < 0 || h->planA.max_band > chip_max_band()) return false;
@@ -732,10 +732,12 @@ static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, dou
     d.part = h->chip_part;
     d.err = reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256);
     d.band = h->planA.max_band;
+    d.f32 = (flags & DPCG_SPMV_F32) ? 1 : 0;
     { const char *e = getenv("DPCG_CHIP_BENCH"); d.bench = e ? atoi(e) : 0; }
+    static const bool trace = [] { const char *e = getenv("DPCG_CHIP_TRACE"); return e && e[0] == '1'; }();
+    if (d.f32 && (d.bench || trace || x0)) return DPCG_ERR_STATE;                      // (the caller goes on with the launches)
     static const bool plain_ok = [] { const char *e = getenv("DPCG_CHIP_LOCAL"); return !(e && e[0] == '0'); }();   // development: 0 = everything written through
     d.xcc = plain_ok ? reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256 + 2) : nullptr;
-    static const bool trace = [] { const char *e = getenv("DPCG_CHIP_TRACE"); return e && e[0] == '1'; }();
     d.dbg = trace ? reinterpret_cast<unsigned long long *>(h->chip_part + kSlots) : nullptr;
     const int st0 = launch_pcg_chip(d, h->planA.max_row_len, s, true);                // refused up front when it cannot be resident
     if (st0 != DPCG_OK) return st0;

@@ -2879,6 +2879,45 @@ def test_chip_solve_equals_the_device_tree_oracle_bit_for_bit(D, name, make, max
     S.close()
 
 
+@pytest.mark.parametrize("name,make,max_iter", [
+    ("poisson3d_100", lambda: O.poisson3d(100), 1024),                                            # config 5's size on the headline grid
+    ("unstructured3d_100", lambda: O.unstructured_like(O.poisson3d(100), seed=0), 1024),          # config 5 as bench.py runs it (reordered, D A D: values not fp32 numbers)
+    ("quadtree_random_400", lambda: O.quadtree_fv_laplacian(400, 5, numbering="random"), 300)])   # rows of up to 9 entries
+def test_chip_solve_mixed_precision_equals_the_oracle_bit_for_bit(D, name, make, max_iter):
+    """BASELINE config 5 in the one-launch kernel (MODE 4 of k_pcg_chip): `A @ pk` with the matrix values and the gathered pk stored
+    in fp32, products and sums in fp64, everything else fp64 -- orc_pcg_mixed with the chip kernel's reduction tree: history, count
+    and x EQUAL; the same count as fp64 here; a start vector takes the launches (cg.py:60 reads the fp64 matrix)."""
+    A = make()
+    n = A.shape[0]
+    S = D.CsrSystem.from_any(A)
+    b = O.rhs(n, 0)
+    perm = S.permutation() if S.reordered else None
+    B = _permuted(A, perm) if perm is not None else A
+    bb = b[perm] if perm is not None else b
+    S.set_preconditioner(D.Jacobi())
+    assert S.chip_info()["chip_by_default"]
+    F32 = D._lib.SPMV_F32
+    res = S.solve(_dev(b), max_iter=max_iter, flags=F32)
+    f64 = S.solve(_dev(b), max_iter=max_iter)
+    multi = S.solve(_dev(b), max_iter=max_iter, flags=F32 | D._lib.NO_SMALL)
+    _, it, hist, x = CO.pcg(B, bb, "jacobi", dinv=O.jacobi_dinv(B), max_iter=max_iter, mixed=True, device_tree=_chip_tree(S))
+    assert res.iterations == it and res.status == multi.status, (name, res.iterations, it)
+    assert np.array_equal(res.res_history, hist), (name, int(np.argmax(res.res_history != hist)))
+    xs = res.x.cpu().numpy()
+    assert np.array_equal(xs[perm] if perm is not None else xs, x)
+    assert not np.array_equal(res.res_history, f64.res_history) and not np.array_equal(res.res_history, multi.res_history)
+    if not name.startswith("quadtree"):
+        assert res.iterations == f64.iterations == multi.iterations
+        np.testing.assert_allclose(res.res_history, f64.res_history, rtol=1e-4)     # (the bound _check_mixed uses)
+    # a start vector: the fp64 `b - A x0` of cg.py:60 -- not this kernel's; the call falls through to the launches
+    x0 = O.rhs(n, 4)
+    with_x0 = S.solve(_dev(b), x0=_dev(x0), max_iter=20, flags=F32)
+    with_x0_multi = S.solve(_dev(b), x0=_dev(x0), max_iter=20, flags=F32 | D._lib.NO_SMALL)
+    assert np.array_equal(with_x0.res_history, with_x0_multi.res_history)
+    S.close()
+
+
+
 def test_chip_solve_arguments_and_edges(D):
     """x0 (cg.py:58-60), caps, both first tests (cg.py:66 / scipy's), b = 0, and what keeps a system OFF the chip kernel: the flags of
     the other forms, a preconditioner it does not fuse, rows of more than 7 entries, a bandwidth beyond 16-bit offsets."""
