@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     constexpr bool TRACE = MODE == 1;      // (development -- MODE 2: q = p instead of the gathers, the loop never stops before max_iter; MODE 3: the gathers
                                            // issued, but every one out of range: no memory request, zeros returned)
     // MODE 4: BASELINE config 5 -- `A @ pk` (cg.py:75) with the matrix values and pk STORED in fp32, products and sums in fp64 (the
-    // contract of DPCG_SPMV_F32: the oracle's orc_spmv_mixed).  The values are rounded once, where they are read; a gathered p is
+    // contract of DPCG_SPMV_F32: the CPU restatement's mixed product).  The values are rounded once, where they are read; a gathered p is
     // rounded where it is recomputed.  Everything else is the fp64 arithmetic of MODE 0 (x0 = 0 only: cg.py:60 reads the fp64 A).
     constexpr bool F32 = MODE == 4;
     constexpr int NS = RPT * WMAX;                                   // entry slots of a thread
