@@ -536,7 +536,7 @@ def mesh_workloads(D, poisson, torch, solve_twice, pmc_all) -> dict:
              "spmv_roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                "algorithmic_bytes_per_launch": b_alg, "us_per_launch": round(ms * 1e3, 2),
                                "traffic": tr["bytes"] if tr else None, "traffic_over_algorithmic": tr["ratio"] if tr else None,
-                               "traffic_source": "profiles/r04_mesh_spmv_traffic.md (rocprofv3 --pmc passes of tools/pmc_mesh_run.py)"}}
+                               "traffic_source": "profiles/r05_mesh_spmv_traffic.md (rocprofv3 --pmc passes of tools/pmc_mesh_run.py)"}}
         r = solve_twice(S, b)
         e["jacobi"] = {"iterations": r.iterations, "status": r.status, "final_res": r.final_res, "ms": round(r.seconds * 1e3, 3),
                        "us_per_update": round(r.seconds / max(r.iterations, 1) * 1e6, 1), "iterations_per_s": round(r.iterations / r.seconds, 1)}
