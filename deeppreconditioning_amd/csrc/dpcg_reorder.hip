@@ -1389,6 +1389,19 @@ static int two_colors_by_regions(const CsrDev &A, int32_t *color, int *flags, bo
 // smallest such neighbour (k_region_push / k_region_settle: the same vertex, rows hold ascending columns); the sort is stable.
 // perm[new] = old, iperm[old] = new (device, owned by the caller afterwards); vertices no region reached keep their order at the end.
 namespace {
+// seeds for the numbering: as k_region_seed, but where two seeds fall on one vertex the SMALLER region takes it whatever order the
+// threads run in (state arrives filled with 0x7f: the numbering must be the same from run to run, a colouring need not care)
+__global__ void k_region_seed_min(int64_t n, int32_t *step, int32_t *state, int *visited, int regions, int32_t *front, int *front_n) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= regions) return;
+    const int64_t v = (int64_t)(((unsigned long long)jp_priority(r + 1) * (unsigned long long)n) >> 32);
+    if (atomicCAS(step + v, -1, 0) == -1) {
+        atomicAdd(visited, 1);
+        front[atomicAdd(front_n, 1)] = (int32_t)v;
+    }
+    atomicMin(state + v, r << 1);
+}
+
 __global__ __launch_bounds__(kBlock) void k_region_keys(int64_t n, const int32_t *__restrict__ step, const int32_t *__restrict__ state,
                                                         const int32_t *__restrict__ rank, int regions, uint32_t *__restrict__ key,
                                                         int32_t *__restrict__ vertex) {
@@ -1425,7 +1438,8 @@ int region_order(const CsrDev &A, int regions, int32_t **perm_out, int32_t **ipe
         DPCG_TRY(front1.alloc(n)); DPCG_TRY(cand.alloc(n));
         DPCG_HIP(hipMemsetAsync(cand.p, 0x7f, (size_t)n * sizeof(int32_t), s));
     }
-    hipLaunchKernelGGL(k_region_seed, dim3((regions + 63) / 64), dim3(64), 0, s, n, step.p, state.p, flags.p, regions, front0.p, front_n.p);
+    DPCG_HIP(hipMemsetAsync(state.p, 0x7f, (size_t)n * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_region_seed_min, dim3((regions + 63) / 64), dim3(64), 0, s, n, step.p, state.p, flags.p, regions, front0.p, front_n.p);
     int32_t *const front[2] = {front0.p, front1.p};
     const int grow_grid = rows_grid(n / 4 + 1, 2048);
     int visited = 0, cur = 0;

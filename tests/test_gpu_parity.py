@@ -1771,7 +1771,7 @@ def test_icholt_as_ilupp_defines_it(D, monkeypatch, lds, regs):
     from deeppreconditioning_amd._lib import DpcgError, ERR_INVALID, ERR_PIVOT
     monkeypatch.setenv("DPCG_ICHOLT_REGS", regs)
     monkeypatch.setenv("DPCG_ICHOLT_LDS", lds)
-    cases = [(O.poisson2d(49), 1, 0.1), (O.poisson2d(24), 1, 0.1), (O.poisson2d(24), 0, 0.0), (O.poisson3d(10), 1, 0.1), (O.poisson3d(10), 3, 0.01),
+    cases = [(O.poisson2d(49), 1, 0.1), (sp.csr_matrix(np.array([[4.0]])), 1, 0.1), (O.poisson2d(2), 1, 0.1), (O.poisson2d(24), 1, 0.1), (O.poisson2d(24), 0, 0.0), (O.poisson3d(10), 1, 0.1), (O.poisson3d(10), 3, 0.01),
              (O.unstructured_like(O.poisson3d(9), seed=2), 1, 0.1), (O.unstructured_like(O.poisson2d(40), seed=5), 2, 0.05),
              (O.quadtree_fv_laplacian(40, 1), 1, 0.1), (O.quadtree_fv_laplacian(40, 1, numbering="random"), 4, 0.001),
              (O.delaunay_laplacian(3000, 4), 1, 0.1), (_banded_random_spd(400, 10, 150, 7), 8, 1e-4), (O.poisson2d(12), 200, 0.0)]
