@@ -1,3 +1,3 @@
-"""`uibk.deep_preconditioning.model` on PyTorch-ROCm without spconv (model.py:13-179)."""
-from deeppreconditioning_amd.model import (PreconditionerNet, PreconditionerSparseUNet, SparseConv2d,  # noqa: F401
-                                           SparseInverseConv2d, SparseSequential, SubMConv2d, sparse_add)
+"""`uibk.deep_preconditioning.model` on PyTorch-ROCm without spconv: `PreconditionerNet` (model.py:13-59), the network of the solve
+path.  `PreconditionerSparseUNet` (model.py:62-179) is outside this path and is not provided."""
+from deeppreconditioning_amd.model import PreconditionerNet, SparseConv2d, SparseSequential  # noqa: F401

@@ -1,11 +1,10 @@
 """spconv-free forward pass of `PreconditionerNet` (drop-in for `uibk/deep_preconditioning/model.py:13-59`; the U-Net
-variant of model.py:62-179 is out of scope and fenced off in extras_unet.py).
+variant of model.py:62-179 is out of scope: SURVEY.md 8-f1 names model.py:13-59 only).
 
 `spconv` ships CUDA-only wheels (`pyproject.toml:20`), so on ROCm the reference model cannot even be imported.
 This module re-states the pieces the network needs on plain PyTorch-ROCm ops -- the host code the north star
 keeps in Python: a `SparseConvTensor`-like container (`utils.SparseBatch`), a regular (output-dilating, optionally
-strided) `SparseConv2d` evaluated as rulebook gather -> GEMM -> scatter-add, `SubMConv2d`, `SparseInverseConv2d`,
-`sparse_add` and `SparseSequential`.  Module/parameter names
+strided) `SparseConv2d` evaluated as rulebook gather -> GEMM -> scatter-add, and `SparseSequential`.  Module/parameter names
 follow the reference so that a `best.pt` state_dict (`train.py:183-186`, keys `layers.{i}.weight|bias`) loads.
 
 Parity status: UNPINNED.  Neither spconv nor a checkpoint is available in the build container.  The arithmetic is
@@ -87,7 +86,7 @@ class SparseConv2d(nn.Module):
         rem = uniq - ob * (Ho * Wo)
         indices = torch.stack((ob, rem // Wo, rem % Wo), dim=1).to(t.indices.dtype)
         result = SparseBatch(out, indices, [Ho, Wo], t.batch_size, t.indice_dict)
-        if self.indice_key is not None:       # what the paired SparseInverseConv2d needs: who fed whom through which offset
+        if self.indice_key is not None:       # (spconv's indice_key: who fed whom through which offset, kept for whoever pairs an inverse convolution with this one)
             result.indice_dict[self.indice_key] = {"dst": dst[:-1].view(kh * kw, nnz), "scratch": uniq.numel() + 1,
                                                    "in_indices": t.indices, "in_shape": list(t.spatial_shape)}
         return result
@@ -308,19 +307,6 @@ def forward_cost(net, t: SparseBatch) -> dict:
         total_b += byts
         sites_in = sites.value
     return {"layers": out, "flops": total_f, "min_hbm_bytes": total_b}
-
-
-# `PreconditionerSparseUNet` and its sub-manifold / inverse convolutions (model.py:62-179 of the reference) are OUTSIDE the
-# hot-path scope (SURVEY.md 8-f1 names model.py:13-59 only): they live, fenced off, in extras_unet.py and resolve lazily so
-# that `params.yaml: model: PreconditionerSparseUNet` and the reference's import lines keep working.
-_UNET_NAMES = ("SubMConv2d", "SparseInverseConv2d", "sparse_add", "PreconditionerSparseUNet")
-
-
-def __getattr__(name):
-    if name in _UNET_NAMES:
-        from . import extras_unet
-        return getattr(extras_unet, name)
-    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
 def load_reference_state_dict(model: nn.Module, state: dict) -> None:
