@@ -157,7 +157,7 @@ for case in range(cases):
                 okind = {"none": "none", "jacobi": "jacobi", "ic0_solve": "llt_solve"}[kind]
                 itm, hm = CO.pcg(Bm, bm, okind, x0=x0m, mixed=True, **kwm)[1:3]
                 hn = np.array(O.preconditioned_conjugate_gradient(O.MixedOperatorX0(Bm), bm, O.Precond(okind, **kwm), x0=x0m)[2])
-                rm = S.solve(torch.from_numpy(b).cuda(), x0_dev, flags=D._lib.SPMV_F32)
+                rm = S.solve(torch.from_numpy(b).cuda(), x0_dev, flags=D._lib.SPMV_F32 | D._lib.NO_SMALL)     # (the launches: the whole-chip kernel's mixed form is checked below)
                 if kind in ("none", "jacobi"):
                     # round 4: the oracle sums in the DEVICE's reduction tree, so there is no drift to bound -- bit for bit
                     # (rows too long for the in-order kernels take the CSR-vector SpMV, whose shuffle-tree row sums are restated too)
@@ -209,6 +209,14 @@ for case in range(cases):
                 else:
                     chip_hist = CO.pcg(B, bo, kind, x0=x0o, device_tree=ctree, **(dict(dinv=O.jacobi_dinv(B)) if kind == "jacobi" else {}))[1:3]
                 chip_seen[kind] = chip_seen.get(kind, 0) + 1
+                # ... and config 5 in the same kernel (MODE 4; without a start vector: cg.py:60 reads the fp64 matrix)
+                if kind in ("none", "jacobi") and x0_dev is None:
+                    mixed_ref = CO.pcg(B, bo, kind, mixed=True, device_tree=ctree, **(dict(dinv=O.jacobi_dinv(B)) if kind == "jacobi" else {}))[1:3]
+                    rm = S.solve(torch.from_numpy(b).cuda(), None, flags=D._lib.SPMV_F32)
+                    chip_seen[kind + "_mixed"] = chip_seen.get(kind + "_mixed", 0) + 1
+                    if not (rm.iterations == mixed_ref[0] and np.array_equal(rm.res_history, mixed_ref[1])):
+                        bad += 1
+                        print("BITS MISMATCH of the mixed whole-chip solve against the chip-tree oracle", tag, kind, rm.iterations, mixed_ref[0])
             for flags in (0, D._lib.NO_SMALL, D._lib.NO_SMALL | D._lib.NO_FUSE):
                 r = S.solve(torch.from_numpy(b).cuda(), x0_dev, flags=flags)
                 h = r.res_history
