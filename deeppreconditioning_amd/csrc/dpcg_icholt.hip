@@ -416,6 +416,7 @@ __global__ __launch_bounds__(64) void k_icholt(int n, const int32_t *__restrict_
 // Every sum in the oracle's order, as above: the factor is the same, bit for bit.
 constexpr int kLdsNil = 0xffff;
 constexpr int kLdsMaxRows = 4096;            // 12 bits of pmeta for the row, 12 for the column
+constexpr int kLdsMail = 8;                  // mailboxes: the column a wave has just selected, for the wave of the next column
 enum { ICHOLT_RETRY = 6 };
 
 __device__ __forceinline__ int lds_ld_i(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -425,7 +426,7 @@ __device__ __forceinline__ void lds_st_u16(uint16_t *p, int v) { __hip_atomic_st
 
 size_t icholt_lds_bytes(int n, int pool_cap, int waves) {
     const size_t pool = (size_t)pool_cap + 64, rows = ((size_t)n + 3) & ~(size_t)3;
-    return pool * 8 + (size_t)waves * 64 * 8 + pool * 4 + (size_t)waves * 64 * 4 + (pool + (pool & 1)) * 2 + 3 * rows * 2;
+    return pool * 8 + (size_t)kLdsMail * 64 * 8 + pool * 4 + ((size_t)waves + kLdsMail) * 64 * 4 + (pool + (pool & 1)) * 2 + 3 * rows * 2;
 }
 
 template <int W, bool TR = false>
@@ -436,18 +437,20 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
     extern __shared__ double smem[];
     const int pool = pool_cap + 64, rows = (n + 3) & ~3;
     double *const pval = smem;                                          // [pool]
-    double *const sv_all = pval + pool;                                 // [W][64]   a wave's candidates sorted by row
-    uint32_t *const pmeta = (uint32_t *)(sv_all + W * 64);              // [pool]
-    int *const si_all = (int *)(pmeta + pool);                          // [W][64]
-    uint16_t *const pnext = (uint16_t *)(si_all + W * 64);              // [pool (+1)]
+    double *const mb_val = pval + pool;                                 // [kLdsMail][64]   a column's kept values ...
+    uint32_t *const pmeta = (uint32_t *)(mb_val + kLdsMail * 64);       // [pool]
+    int *const si_all = (int *)(pmeta + pool);                          // [W][64]          (the scan of the row lengths at the end)
+    int *const mb_row = si_all + W * 64;                                // [kLdsMail][64]   ... and their rows, ascending
+    uint16_t *const pnext = (uint16_t *)(mb_row + kLdsMail * 64);       // [pool (+1)]
     uint16_t *const rhead = pnext + pool + (pool & 1);                  // [rows]
     uint16_t *const rtail = rhead + rows;
     uint16_t *const rcnt = rtail + rows;
-    __shared__ int s_done, s_abort;
+    __shared__ int s_done, s_abort, mb_tag[kLdsMail], mb_info[kLdsMail];     // mailbox k & 7: tag = k + 1 once column k's entries are in it, info = kept | pool position << 8
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int i = threadIdx.x; i < rows; i += W * 64) { rhead[i] = kLdsNil; rtail[i] = kLdsNil; rcnt[i] = 0; }
     if (threadIdx.x == 0) { s_done = 0; s_abort = 0; }
+    if (threadIdx.x < kLdsMail) mb_tag[threadIdx.x] = 0;
     __syncthreads();
     auto give_up = [&](int col) {
         if (lane == 0) {
@@ -493,6 +496,17 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
         if (my_c > k) { me = my_c; val = my_v; }
         // ---- the dependencies, in ascending j as the chain of row k holds them
         int prev = kLdsNil, spins = 0, base = 0;
+        bool by_mail = false;           // the last dependency came through the mailbox: column k - 1 may still be publishing
+        // one (row, product) pair of a dependency: the candidate of that row, or a new one (no branch: a taken branch costs more)
+        auto update = [&](int ip, double pp) {
+            const bool hit = me == ip;
+            const bool fresh = __ballot(hit) == 0ull;
+            const bool take = fresh && lane == nl;
+            const double upd = (take ? 0.0 : val) - pp;
+            val = (hit || take) ? upd : val;
+            me = take ? ip : me;
+            nl += fresh ? 1 : 0;
+        };
         lap(0);
         for (;;) {
             const int d = first_i(lds_ld_i(&s_done));            // columns final | pool entries in use << 13
@@ -500,7 +514,33 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
             const int p = first_i(prev == kLdsNil ? lds_ld_u16(rhead + k) : lds_ld_u16(pnext + prev));
             if (p == kLdsNil) {
                 lap(1);
-                if ((d & 0x1fff) >= k) { base = d >> 13; break; }
+                const int nd = d & 0x1fff;
+                if (nd >= k) { base = d >> 13; break; }
+                if (nd == k - 1) {
+                    // every column before k - 1 is final and its links are walked: only column k - 1 can still add a dependency, and
+                    // it hands its entries over the moment it has selected them -- before it publishes them
+                    const int slot = (k - 1) & (kLdsMail - 1);
+                    const int tag = first_i(lds_ld_i(mb_tag + slot));
+                    wave_sync();
+                    const int info = first_i(lds_ld_i(mb_info + slot));
+                    const int erow = mb_row[slot * 64 + lane];
+                    const double ev = mb_val[slot * 64 + lane];
+                    if (tag == k) {
+                        const int nk = info & 0xff;
+                        const unsigned long long hit = __ballot(lane < nk && erow == k);
+                        if (hit) {
+                            const int hl = __ffsll((long long)hit) - 1;
+                            const double lkj = lane_d(ev, hl);
+                            dg = dg - lkj * lkj;
+                            const double prod = lkj * ev;
+                            for (int q = hl + 1; q < nk; ++q) update(lane_i(erow, q), lane_d(prod, q));
+                        }
+                        base = (info >> 8) + nk;
+                        by_mail = true;
+                        lap(2);
+                        break;
+                    }
+                }
                 if (lds_ld_i(&s_abort)) { alive = false; break; }
                 if ((++spins & 1023) == 0 && wall_clock64() - t_start > 100000000ll) { give_up(k); alive = false; break; }   // 1 s
                 continue;
@@ -514,23 +554,14 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
             dg = dg - lkj * lkj;
             const int erow = (int)(em & 0xfffu);
             const double prod = lkj * ev;
-            for (int q = 1; q <= rem; ++q) {                      // (no branch inside: a taken branch costs more than these selects)
-                const int ip = lane_i(erow, q);
-                const double pp = lane_d(prod, q);
-                const bool hit = me == ip;
-                const bool fresh = __ballot(hit) == 0ull;
-                const bool take = fresh && lane == nl;
-                const double upd = (take ? 0.0 : val) - pp;
-                val = (hit || take) ? upd : val;
-                me = take ? ip : me;
-                nl += fresh ? 1 : 0;
-            }
+            for (int q = 1; q <= rem; ++q) update(lane_i(erow, q), lane_d(prod, q));
             if (nl > 64) { give_up(k); alive = false; break; }
             prev = p;
             lap(2);
             // the link of column k - 1: no column before k can add another, and the pool ends behind that column
             if ((int)((em0 >> 12) & 0xfffu) == k - 1) { base = p + rem + 1; break; }
         }
+        if (nl > 64) { give_up(k); break; }
         if (!alive) break;
         if (!(dg > 0.0)) { give_up(k); break; }
         // ---- the candidates sorted by row (rank counting; lane `rank` receives), norm, threshold, the pk largest (as k_icholt)
@@ -552,8 +583,6 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
         const unsigned hi_s = (unsigned)__builtin_amdgcn_ds_permute(rank << 2, (int)(vb >> 32));
         const int row = lane < ncand ? row_s : kNone;
         const double wv = lane < ncand ? __longlong_as_double((long long)(((unsigned long long)hi_s << 32) | lo_s)) : 0.0;
-        // (this wave is the next to publish: the ends of the chains it will append to do not move any more)
-        const int t_tail = lane < ncand ? (int)rtail[row] : kLdsNil, t_cnt = lane < ncand ? (int)rcnt[row] : 0;
         const double sq = wv * wv, aw = fabs(wv);
         double ss = 0.0;
         if (ncand <= 8) {                                          // (+ 0.0 behind the last candidate: the same sum)
@@ -588,14 +617,32 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
         const unsigned long long kept = __ballot(kp);
         const int nkept = __popcll(kept), pos = __popcll(kept & below);
         lap(3);
-        // ---- column k joins the pool; its entries join their rows' chains; done = k + 1
+        // ---- the column is handed to the wave of column k + 1 (its mailbox) the moment it is selected ...
         if (base + nkept > pool_cap) { give_up(k); break; }
+        const double lq = wv / dk;
+        {
+            const int slot = k & (kLdsMail - 1);
+            if (kp) { mb_row[slot * 64 + pos] = row; mb_val[slot * 64 + pos] = lq; }
+            if (lane == 0) lds_st_i(mb_info + slot, nkept | base << 8);
+            wave_sync();
+            if (lane == 0) lds_st_i(mb_tag + slot, k + 1);
+        }
+        // ---- ... then joins the pool, its entries their rows' chains, done = k + 1.  A column that came through the mailbox waits for
+        // its predecessor to have published (the ends of the chains it appends to are that column's; usually long done)
+        if (by_mail) {
+            int turns = 0;
+            while ((first_i(lds_ld_i(&s_done)) & 0x1fff) < k) {
+                if (lds_ld_i(&s_abort) || ((++turns & 1023) == 0 && wall_clock64() - t_start > 100000000ll)) { alive = false; break; }
+            }
+            if (!alive) { give_up(k); break; }
+        }
+        wave_sync();
+        const int t_tail = kp ? (int)rtail[row] : kLdsNil, t_cnt = kp ? (int)rcnt[row] : 0;
         if (__ballot(kp && t_cnt >= kIctCap)) { give_up(k); break; }
         const int at = base + pos;
-        // (in this order: whoever sees a link finds the entries behind it, and -- the next wave to publish, which may have gone ahead on
-        // the link alone -- the new ends of the chains; `done` only ever grows: the wave of column k + 1 may publish before this store)
+        // (in this order: whoever sees a link finds the entries behind it and the new ends of the chains; `done` only ever grows)
         if (kp) {
-            pval[at] = wv / dk;
+            pval[at] = lq;
             pmeta[at] = (uint32_t)row | (uint32_t)k << 12 | (uint32_t)(nkept - 1 - pos) << 24;
             pnext[at] = kLdsNil;
             rtail[row] = (uint16_t)at;
