@@ -13,7 +13,7 @@
 // CPU restatement bit for bit.  One dependent memory round trip per column (see k_icholt); times by size: tools/icholt_probe.py,
 // profiles/r04_icholt_probe.txt.  It is the setup of a technique the reference runs on ~2K-row systems: those -- every system whose
 // factor fits one CU's LDS -- go through k_icholt_lds below, a pipeline of four waves over an LDS-resident factor (round 5:
-// 2.7 ms instead of 4.8 at 2.4K rows, profiles/r05_icholt_probe.txt; what is left is the chain of the selection itself).
+// 2.4 ms instead of 4.8 at 2.4K rows, profiles/r05_icholt_probe.txt; what is left is one wave's instruction stream per column).
 #include "dpcg_host.h"
 #include "dpcg_prims.h"
 
@@ -408,7 +408,11 @@ __global__ __launch_bounds__(64) void k_icholt(int n, const int32_t *__restrict_
 //   * a wave walks its row's chain as far as it reaches -- one entry = one dependency: L_kj = pval[p], the entries of column j below
 //     row k follow at p + 1 .. p + rem -- and waits at its end for either a new link or `done >= k` (every column before k final:
 //     the chain is complete); then it selects, appends its column to the pool, links its entries into their rows' chains and
-//     publishes done = k + 1.
+//     publishes done = k + 1;
+//   * the LAST dependency (column k - 1, in a banded numbering) does not wait for that publication: a wave that has walked its chain
+//     to the end while done = k - 1 polls the MAILBOX of column k - 1 -- the kept (row, value) pairs, written the moment they are
+//     selected -- and goes on to its own selection while its predecessor is still publishing (it waits for done >= k only before
+//     it appends: the ends of the chains are its predecessor's until then).
 // One wave's LDS operations are performed in order and a store is performed for all its lanes before the wave's next LDS operation:
 // entries are written before the links that lead to them, links before `done` -- the fences are compiler-level only.
 // Anything beyond the plain case (a row of A of more than 64 entries, more than 64 candidates, a row of L of more than 64 entries,
@@ -426,19 +430,21 @@ __device__ __forceinline__ void lds_st_u16(uint16_t *p, int v) { __hip_atomic_st
 
 size_t icholt_lds_bytes(int n, int pool_cap, int waves) {
     const size_t pool = (size_t)pool_cap + 64, rows = ((size_t)n + 3) & ~(size_t)3;
-    return pool * 8 + (size_t)kLdsMail * 64 * 8 + pool * 4 + ((size_t)waves + kLdsMail) * 64 * 4 + (pool + (pool & 1)) * 2 + 3 * rows * 2;
+    return pool * 8 + (size_t)kLdsMail * 64 * 8 + rows * 8 + pool * 4 + ((size_t)waves + kLdsMail) * 64 * 4 + (pool + (pool & 1)) * 2 + 3 * rows * 2;
 }
 
 template <int W, bool TR = false>
 __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__restrict__ arp, const int32_t *__restrict__ aci,
                                                        const double *__restrict__ av, int add_fill, double tau, int pool_cap,
-                                                       double *diag, int32_t *lrp, int32_t *lci, double *lv, int *status) {
+                                                       int32_t *lrp, int32_t *lci, double *lv, int *status) {
     constexpr int kNone = 0x7fffffff;
     extern __shared__ double smem[];
     const int pool = pool_cap + 64, rows = (n + 3) & ~3;
     double *const pval = smem;                                          // [pool]
     double *const mb_val = pval + pool;                                 // [kLdsMail][64]   a column's kept values ...
-    uint32_t *const pmeta = (uint32_t *)(mb_val + kLdsMail * 64);       // [pool]
+    double *const dgl = mb_val + kLdsMail * 64;                         // [rows]           the diagonal of L (a store to memory per column would
+                                                                        //                  hold up the wave's next loads: one counter for both)
+    uint32_t *const pmeta = (uint32_t *)(dgl + rows);                   // [pool]
     int *const si_all = (int *)(pmeta + pool);                          // [W][64]          (the scan of the row lengths at the end)
     int *const mb_row = si_all + W * 64;                                // [kLdsMail][64]   ... and their rows, ascending
     uint16_t *const pnext = (uint16_t *)(mb_row + kLdsMail * 64);       // [pool (+1)]
@@ -518,31 +524,35 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
                 if (nd >= k) { base = d >> 13; break; }
                 if (nd == k - 1) {
                     // every column before k - 1 is final and its links are walked: only column k - 1 can still add a dependency, and
-                    // it hands its entries over the moment it has selected them -- before it publishes them
+                    // it hands its entries over the moment it has selected them -- before it publishes them.  ONE word is polled
+                    // (the waves that wait share the LDS with the wave that works)
                     const int slot = (k - 1) & (kLdsMail - 1);
-                    const int tag = first_i(lds_ld_i(mb_tag + slot));
+                    for (;;) {
+                        if (first_i(lds_ld_i(mb_tag + slot)) == k) break;
+                        if ((++spins & 63) == 0 && (lds_ld_i(&s_abort) || wall_clock64() - t_start > 100000000ll)) { alive = false; break; }
+                    }
+                    if (!alive) { give_up(k); break; }
                     wave_sync();
                     const int info = first_i(lds_ld_i(mb_info + slot));
                     const int erow = mb_row[slot * 64 + lane];
                     const double ev = mb_val[slot * 64 + lane];
-                    if (tag == k) {
-                        const int nk = info & 0xff;
-                        const unsigned long long hit = __ballot(lane < nk && erow == k);
-                        if (hit) {
-                            const int hl = __ffsll((long long)hit) - 1;
-                            const double lkj = lane_d(ev, hl);
-                            dg = dg - lkj * lkj;
-                            const double prod = lkj * ev;
-                            for (int q = hl + 1; q < nk; ++q) update(lane_i(erow, q), lane_d(prod, q));
-                        }
-                        base = (info >> 8) + nk;
-                        by_mail = true;
-                        lap(2);
-                        break;
+                    const int nk = info & 0xff;
+                    const unsigned long long hit = __ballot(lane < nk && erow == k);
+                    if (hit) {
+                        const int hl = __ffsll((long long)hit) - 1;
+                        const double lkj = lane_d(ev, hl);
+                        dg = dg - lkj * lkj;
+                        const double prod = lkj * ev;
+                        for (int q = hl + 1; q < nk; ++q) update(lane_i(erow, q), lane_d(prod, q));
                     }
+                    base = (info >> 8) + nk;
+                    by_mail = true;
+                    lap(2);
+                    break;
                 }
                 if (lds_ld_i(&s_abort)) { alive = false; break; }
                 if ((++spins & 1023) == 0 && wall_clock64() - t_start > 100000000ll) { give_up(k); alive = false; break; }   // 1 s
+                __builtin_amdgcn_s_sleep(2);          // (two or more columns ahead of the chain: no hurry, and the LDS is the others')
                 continue;
             }
             wave_sync();
@@ -656,7 +666,7 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
         wave_sync();
         if (lane == 0) {
             atomicMax(&s_done, (k + 1) | (base + nkept) << 13);
-            diag[k] = dk;
+            dgl[k] = dk;
         }
         wave_sync();
         lap(4);
@@ -676,7 +686,6 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
     int at = 0;
     for (int u = 0; u < (int)threadIdx.x; ++u) at += sums[u];
     if (threadIdx.x == T - 1) { lrp[n] = at + mine; status[2] = at + mine; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");               // (diag[] was stored by other waves of this workgroup)
     for (int i = r_lo; i < r_hi; ++i) {
         lrp[i] = at;
         for (int p = rhead[i]; p != kLdsNil; p = pnext[p]) {
@@ -685,7 +694,7 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
             ++at;
         }
         lci[at] = i;
-        lv[at] = __hip_atomic_load(diag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lv[at] = dgl[i];
         ++at;
     }
 }
@@ -740,7 +749,7 @@ int icholt_factor(const CsrDev &A, int add_fill_in, double threshold, CsrDev &Lf
         const int64_t pool_cap = (A.nnz - n + 1) / 2 + n * (int64_t)add_fill_in + 1;
         if (lds_on && n >= 1 && n <= kLdsMaxRows && pool_cap < 0xff00 && icholt_lds_bytes((int)n, (int)pool_cap, waves) + 64 <= 160 * 1024) {
             const int64_t cap_nnz = pool_cap + n;
-            if ((st = dev_alloc(&diag, n)) < 0 || (st = dev_alloc(&status, 8 + 16 * 8)) < 0 || (st = dev_alloc(&Lf.rowptr, n + 1)) < 0 ||
+            if ((st = dev_alloc(&status, 8 + 16 * 8)) < 0 || (st = dev_alloc(&Lf.rowptr, n + 1)) < 0 ||
                 (st = dev_alloc(&Lf.col, cap_nnz)) < 0 || (st = dev_alloc(&Lf.val, cap_nnz)) < 0)
                 return cleanup(st);
             hipError_t e = hipMemsetAsync(status, 0, 4 * sizeof(int), s);
@@ -752,7 +761,7 @@ int icholt_factor(const CsrDev &A, int add_fill_in, double threshold, CsrDev &Lf
         e = hipFuncSetAttribute((const void *)k_icholt_lds<WV, TRC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
         if (e == hipSuccess)                                                                                                         \
             hipLaunchKernelGGL((k_icholt_lds<WV, TRC>), dim3(1), dim3(WV * 64), lds, s, (int)n, A.rowptr, A.col, A.val, add_fill_in, \
-                               threshold, (int)pool_cap, diag, Lf.rowptr, Lf.col, Lf.val, status);                                   \
+                               threshold, (int)pool_cap, Lf.rowptr, Lf.col, Lf.val, status);                                   \
     } while (0)
             if (trace && waves == 8) DPCG_ICHOLT_LDS_LAUNCH(8, true);
             else if (trace) DPCG_ICHOLT_LDS_LAUNCH(4, true);
@@ -779,8 +788,8 @@ int icholt_factor(const CsrDev &A, int add_fill_in, double threshold, CsrDev &Lf
                 return cleanup(DPCG_OK);
             }
             // not the plain case: the one-wave kernel runs it again (and names what is wrong, if something is)
-            dev_free(diag); dev_free(status); dev_free(Lf.rowptr); dev_free(Lf.col); dev_free(Lf.val);
-            diag = nullptr; status = nullptr; Lf.rowptr = nullptr; Lf.col = nullptr; Lf.val = nullptr;
+            dev_free(status); dev_free(Lf.rowptr); dev_free(Lf.col); dev_free(Lf.val);
+            status = nullptr; Lf.rowptr = nullptr; Lf.col = nullptr; Lf.val = nullptr;
         }
     }
     const int64_t wide = n * kIctCap;
