@@ -430,7 +430,7 @@ __device__ __forceinline__ void lds_st_u16(uint16_t *p, int v) { __hip_atomic_st
 
 size_t icholt_lds_bytes(int n, int pool_cap, int waves) {
     const size_t pool = (size_t)pool_cap + 64, rows = ((size_t)n + 3) & ~(size_t)3;
-    return pool * 8 + (size_t)kLdsMail * 64 * 8 + rows * 8 + pool * 4 + ((size_t)waves + kLdsMail) * 64 * 4 + (pool + (pool & 1)) * 2 + 3 * rows * 2;
+    return pool * 8 + (size_t)kLdsMail * 64 * 8 + rows * 8 + pool * 4 + ((size_t)waves + kLdsMail) * 64 * 4 + (pool + (pool & 1)) * 2 + 5 * rows * 2;
 }
 
 template <int W, bool TR = false>
@@ -451,6 +451,8 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
     uint16_t *const rhead = pnext + pool + (pool & 1);                  // [rows]
     uint16_t *const rtail = rhead + rows;
     uint16_t *const rcnt = rtail + rows;
+    uint16_t *const ub = rcnt + rows;                                   // [rows]  where column k of A is staged: sum of the count bounds before it
+    uint16_t *const acnt = ub + rows;                                   // [rows]  entries of A below the diagonal in column k
     __shared__ int s_done, s_abort, mb_tag[kLdsMail], mb_info[kLdsMail];     // mailbox k & 7: tag = k + 1 once column k's entries are in it, info = kept | pool position << 8
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -463,16 +465,52 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
             if (atomicCAS(&s_abort, 0, 1) == 0) { status[0] = ICHOLT_RETRY; status[1] = col; }
         }
     };
-    // this wave's next row of A, fetched a round ahead (its row pointers two rounds ahead: the loads of a row do not wait for them)
-    // (the pointers come through the vector-memory path, lane 0 and lane 1: a scalar load would share its counter with the LDS
-    // operations, and the first LDS read of a column would wait for it)
-    int p0 = 0, p1 = 0, qv = 0, ac = -1;
-    double ax = 0.0;
-    if (w < n) {
-        p0 = arp[w]; p1 = arp[w + 1];
-        if (p0 + lane < p1) { ac = aci[p0 + lane]; ax = av[p0 + lane]; }
+    // ---- A into the pool, once: column k's entries below the diagonal (= row k right of it) at ub[k] = the sum of the count bounds
+    // p_j = nnz(A[j+1:, j]) + add_fill of the columns before it.  Column j's kept entries end at or before ub[j + 1] (it keeps at most
+    // p_j, and starts at or before ub[j]), so a staged column is still there when its wave reads it -- at the START of its work on
+    // that column -- and the loop below touches no memory outside the LDS (a load issued one column ahead was not back in time:
+    // ~900 cycles a column).
+    {
+        constexpr int T = W * 64;
+        bool bad = false;
+        const int per = (n + T - 1) / T, r_lo = min(n, (int)threadIdx.x * per), r_hi = min(n, r_lo + per);
+        int mine = 0;
+        for (int k = r_lo; k < r_hi; ++k) {
+            int cu = 0;
+            double dv = 0.0;
+            bool has = false;
+            for (int q = arp[k]; q < arp[k + 1]; ++q) {
+                const int c = aci[q];
+                if (c > k) ++cu;
+                else if (c == k) { dv = av[q]; has = true; }
+            }
+            if (!has || cu + add_fill > kIctCap) bad = true;
+            acnt[k] = (uint16_t)cu;
+            dgl[k] = dv;
+            mine += cu + add_fill;
+        }
+        si_all[threadIdx.x] = mine;
+        if (bad) atomicExch(&s_abort, 2);
+        __syncthreads();
+        int at = 0;
+        for (int u = 0; u < (int)threadIdx.x; ++u) at += si_all[u];
+        if (threadIdx.x == T - 1 && at + mine > pool_cap) atomicExch(&s_abort, 2);
+        __syncthreads();
+        if (s_abort) {                    // (a missing diagonal, a count bound over the cap, a pattern that is not symmetric: the one-wave kernel reports it)
+            if (threadIdx.x == 0) { status[0] = ICHOLT_RETRY; status[1] = 0; }
+            return;
+        }
+        for (int k = r_lo; k < r_hi; ++k) {
+            ub[k] = (uint16_t)at;
+            int j = at;
+            for (int q = arp[k]; q < arp[k + 1]; ++q) {
+                const int c = aci[q];
+                if (c > k) { pmeta[j] = (uint32_t)c; pval[j] = av[q]; ++j; }
+            }
+            at += (int)acnt[k] + add_fill;
+        }
+        __syncthreads();
     }
-    if (w + W < n) qv = arp[w + W + (lane & 1)];
     const long long t_start = wall_clock64();
     bool alive = true;
     long long tr[6] = {0, 0, 0, 0, 0, 0}, tc = 0;      // TR: cycles in [0] row of A, [1] waiting, [2] dependencies, [3] selection, [4] publication
@@ -485,21 +523,12 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
     };
     if (TR) tc = clock64();
     for (int k = w; k < n && alive; k += W) {
-        const int alen = p1 - p0, my_c = ac;
-        const double my_v = ax;
-        ac = -1;
-        p0 = lane_i(qv, 0); p1 = lane_i(qv, 1);
-        if (k + W < n && p0 + lane < p1) { ac = aci[p0 + lane]; ax = av[p0 + lane]; }
-        if (k + 2 * W < n) qv = arp[k + 2 * W + (lane & 1)];
-        if (alen > 64) { give_up(k); break; }
-        // ---- column k of A: candidates below the diagonal (lane c: candidate c), the diagonal
-        const unsigned long long at_diag = __ballot(my_c == k);
-        const int pk = __popcll(__ballot(my_c > k)) + add_fill;
-        if (!at_diag || pk > kIctCap) { give_up(k); break; }
-        double dg = lane_d(my_v, __ffsll((long long)at_diag) - 1);
-        int me = kNone, nl = alen;
-        double val = 0.0;
-        if (my_c > k) { me = my_c; val = my_v; }
+        // ---- column k of A out of the pool: candidates below the diagonal (lane c: candidate c, rows ascending), the diagonal
+        const int u0 = (int)ub[k], cu = (int)acnt[k];
+        const int pk = cu + add_fill;
+        int me = lane < cu ? (int)pmeta[u0 + lane] : kNone, nl = cu;
+        double val = lane < cu ? pval[u0 + lane] : 0.0;
+        double dg = dgl[k];
         // ---- the dependencies, in ascending j as the chain of row k holds them
         int prev = kLdsNil, spins = 0, base = 0;
         bool by_mail = false;           // the last dependency came through the mailbox: column k - 1 may still be publishing
