@@ -468,8 +468,7 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
     // ---- A into the pool, once: column k's entries below the diagonal (= row k right of it) at ub[k] = the sum of the count bounds
     // p_j = nnz(A[j+1:, j]) + add_fill of the columns before it.  Column j's kept entries end at or before ub[j + 1] (it keeps at most
     // p_j, and starts at or before ub[j]), so a staged column is still there when its wave reads it -- at the START of its work on
-    // that column -- and the loop below touches no memory outside the LDS (a load issued one column ahead was not back in time:
-    // ~900 cycles a column).
+    // that column -- and the loop below touches no memory outside the LDS.
     {
         constexpr int T = W * 64;
         bool bad = false;
