@@ -1,3 +1,5 @@
+"""ICholT / IC(0) setup at the reference's sizes, phase by phase (DPCG_SETUP_TRACE=1), and -- DPCG_ICHOLT_TRACE=1 -- the cycles a wave of
+k_icholt_lds spends per column in each phase.    DPCG_SETUP_TRACE=1 [DPCG_ICHOLT_TRACE=1] [DPCG_ICHOLT_WAVES=4|8|16] python tools/icholt_trace.py"""
 import time, torch
 import deeppreconditioning_amd as D
 from deeppreconditioning_amd import meshes, poisson
