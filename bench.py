@@ -485,13 +485,13 @@ def main() -> None:
             s4.solve(b4, max_iter=8, want_history=False)
             r4 = s4.solve(b4, max_iter=48, want_history=False)
             in_loop = {"pcg_us_per_update": round(r4.seconds / max(r4.iterations, 1) * 1e6, 1), "updates": r4.iterations}
-            tr = ROOT / "profiles" / "r04_kernel_trace_256cubed_summary.txt"
-            if tr.exists():
+            tr = next((t for t in (ROOT / "profiles" / f"r0{k}_kernel_trace_256cubed_summary.txt" for k in (5, 4)) if t.exists()), None)
+            if tr is not None:
                 for ln in tr.read_text().splitlines():
                     if ln.startswith("k_spmv_tile") and "median" in ln:
                         in_loop["k1_us_median_in_loop_rocprof"] = float(ln.split("median")[1].split("us")[0])
                         in_loop["k1_frac_in_loop_rocprof"] = round(b4_alg / (in_loop["k1_us_median_in_loop_rocprof"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-                        in_loop["source"] = "profiles/r04_kernel_trace_256cubed_summary.txt (rocprofv3 --kernel-trace of tools/trace_run_c4.py)"
+                        in_loop["source"] = f"profiles/{tr.name} (rocprofv3 --kernel-trace of tools/trace_run_c4.py)"
                         break
             line["roofline"]["hbm_bound_256cubed"]["in_loop"] = in_loop
             s4.close()

@@ -420,6 +420,7 @@ __global__ __launch_bounds__(64) void k_icholt(int n, const int32_t *__restrict_
 // Every sum in the oracle's order, as above: the factor is the same, bit for bit.
 constexpr int kLdsNil = 0xffff;
 constexpr int kLdsMaxRows = 4096;            // 12 bits of pmeta for the row, 12 for the column
+constexpr int kGmMaxRows = 8192;             // (the workspace form: 13 + 13 bits)
 constexpr int kLdsMail = 8;                  // mailboxes: the column a wave has just selected, for the wave of the next column
 enum { ICHOLT_RETRY = 6 };
 
@@ -428,26 +429,52 @@ __device__ __forceinline__ void lds_st_i(int *p, int v) { __hip_atomic_store(p, 
 __device__ __forceinline__ int lds_ld_u16(const uint16_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st_u16(uint16_t *p, int v) { __hip_atomic_store(p, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-size_t icholt_lds_bytes(int n, int pool_cap, int waves) {
+// pool, chains and staged A (in LDS, or -- GM -- in a workspace in memory), and what stays in LDS either way
+size_t icholt_big_bytes(int n, int pool_cap) {
     const size_t pool = (size_t)pool_cap + 64, rows = ((size_t)n + 3) & ~(size_t)3;
-    return pool * 8 + (size_t)kLdsMail * 64 * 8 + rows * 8 + pool * 4 + ((size_t)waves + kLdsMail) * 64 * 4 + (pool + (pool & 1)) * 2 + 5 * rows * 2;
+    return pool * 8 + rows * 8 + pool * 4 + (pool + (pool & 1)) * 2 + 5 * rows * 2;
+}
+size_t icholt_small_bytes(int waves) { return (size_t)kLdsMail * 64 * 8 + ((size_t)waves + kLdsMail) * 64 * 4; }
+size_t icholt_lds_bytes(int n, int pool_cap, int waves) { return icholt_small_bytes(waves) + icholt_big_bytes(n, pool_cap); }
+
+// GM = true: the same pipeline for factors beyond one CU's LDS (up to 8192 rows and 65 K kept entries: the reference's larger meshes,
+// 5.5 K rows): pool, chains and the staged A live in a workspace in memory -- the waves of ONE workgroup reach it through agent-scope
+// loads (a line another wave wrote may sit stale in the CU's L1) and order their stores with a release fence where the LDS form
+// relies on the order of LDS operations; `done`, the mailboxes (the chain's hand-off) and the scan scratch stay in LDS.
+template <bool GM, typename T>
+__device__ __forceinline__ T sh_ld(const T *p) {
+    if (GM) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <bool GM, typename T>
+__device__ __forceinline__ void sh_st(T *p, T v) {
+    if (GM) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// what was stored before is there for whoever sees what is stored after
+template <bool GM>
+__device__ __forceinline__ void sh_release() {
+    if (GM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else wave_sync();
 }
 
-template <int W, bool TR = false>
+template <int W, bool TR = false, bool GM = false>
 __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__restrict__ arp, const int32_t *__restrict__ aci,
                                                        const double *__restrict__ av, int add_fill, double tau, int pool_cap,
-                                                       int32_t *lrp, int32_t *lci, double *lv, int *status) {
+                                                       int32_t *lrp, int32_t *lci, double *lv, int *status, double *ws) {
     constexpr int kNone = 0x7fffffff;
+    constexpr int RB = GM ? 13 : 12;                                    // bits of pmeta for the row, and for the column; the rest: entries after this one
+    constexpr uint32_t RM = (1u << RB) - 1u;
     extern __shared__ double smem[];
     const int pool = pool_cap + 64, rows = (n + 3) & ~3;
-    double *const pval = smem;                                          // [pool]
-    double *const mb_val = pval + pool;                                 // [kLdsMail][64]   a column's kept values ...
-    double *const dgl = mb_val + kLdsMail * 64;                         // [rows]           the diagonal of L (a store to memory per column would
-                                                                        //                  hold up the wave's next loads: one counter for both)
-    uint32_t *const pmeta = (uint32_t *)(dgl + rows);                   // [pool]
-    int *const si_all = (int *)(pmeta + pool);                          // [W][64]          (the scan of the row lengths at the end)
+    double *const mb_val = smem;                                        // [kLdsMail][64]   a column's kept values ...
+    int *const si_all = (int *)(mb_val + kLdsMail * 64);                // [W][64]          (the scans of the row lengths)
     int *const mb_row = si_all + W * 64;                                // [kLdsMail][64]   ... and their rows, ascending
-    uint16_t *const pnext = (uint16_t *)(mb_row + kLdsMail * 64);       // [pool (+1)]
+    double *const big = GM ? ws : (double *)(mb_row + kLdsMail * 64);   // pool, chains, staged A: LDS, or the workspace
+    double *const pval = big;                                           // [pool]
+    double *const dgl = pval + pool;                                    // [rows]           the diagonal of L
+    uint32_t *const pmeta = (uint32_t *)(dgl + rows);                   // [pool]
+    uint16_t *const pnext = (uint16_t *)(pmeta + pool);                 // [pool (+1)]
     uint16_t *const rhead = pnext + pool + (pool & 1);                  // [rows]
     uint16_t *const rtail = rhead + rows;
     uint16_t *const rcnt = rtail + rows;
@@ -456,7 +483,7 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
     __shared__ int s_done, s_abort, mb_tag[kLdsMail], mb_info[kLdsMail];     // mailbox k & 7: tag = k + 1 once column k's entries are in it, info = kept | pool position << 8
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int i = threadIdx.x; i < rows; i += W * 64) { rhead[i] = kLdsNil; rtail[i] = kLdsNil; rcnt[i] = 0; }
+    for (int i = threadIdx.x; i < rows; i += W * 64) { sh_st<GM>(rhead + i, (uint16_t)kLdsNil); sh_st<GM>(rtail + i, (uint16_t)kLdsNil); sh_st<GM>(rcnt + i, (uint16_t)0); }
     if (threadIdx.x == 0) { s_done = 0; s_abort = 0; }
     if (threadIdx.x < kLdsMail) mb_tag[threadIdx.x] = 0;
     __syncthreads();
@@ -484,8 +511,8 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
                 else if (c == k) { dv = av[q]; has = true; }
             }
             if (!has || cu + add_fill > kIctCap) bad = true;
-            acnt[k] = (uint16_t)cu;
-            dgl[k] = dv;
+            sh_st<GM>(acnt + k, (uint16_t)cu);
+            sh_st<GM>(dgl + k, dv);
             mine += cu + add_fill;
         }
         si_all[threadIdx.x] = mine;
@@ -500,14 +527,15 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
             return;
         }
         for (int k = r_lo; k < r_hi; ++k) {
-            ub[k] = (uint16_t)at;
+            sh_st<GM>(ub + k, (uint16_t)at);
             int j = at;
             for (int q = arp[k]; q < arp[k + 1]; ++q) {
                 const int c = aci[q];
-                if (c > k) { pmeta[j] = (uint32_t)c; pval[j] = av[q]; ++j; }
+                if (c > k) { sh_st<GM>(pmeta + j, (uint32_t)c); sh_st<GM>(pval + j, av[q]); ++j; }
             }
-            at += (int)acnt[k] + add_fill;
+            at = j + add_fill;
         }
+        if (GM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // (the staged columns are in memory before anybody reads them)
         __syncthreads();
     }
     const long long t_start = wall_clock64();
@@ -523,11 +551,11 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
     if (TR) tc = clock64();
     for (int k = w; k < n && alive; k += W) {
         // ---- column k of A out of the pool: candidates below the diagonal (lane c: candidate c, rows ascending), the diagonal
-        const int u0 = (int)ub[k], cu = (int)acnt[k];
+        const int u0 = (int)sh_ld<GM>(ub + k), cu = (int)sh_ld<GM>(acnt + k);
         const int pk = cu + add_fill;
-        int me = lane < cu ? (int)pmeta[u0 + lane] : kNone, nl = cu;
-        double val = lane < cu ? pval[u0 + lane] : 0.0;
-        double dg = dgl[k];
+        int me = lane < cu ? (int)sh_ld<GM>(pmeta + u0 + lane) : kNone, nl = cu;
+        double val = lane < cu ? sh_ld<GM>(pval + u0 + lane) : 0.0;
+        double dg = sh_ld<GM>(dgl + k);
         // ---- the dependencies, in ascending j as the chain of row k holds them
         int prev = kLdsNil, spins = 0, base = 0;
         bool by_mail = false;           // the last dependency came through the mailbox: column k - 1 may still be publishing
@@ -543,13 +571,13 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
         };
         lap(0);
         for (;;) {
-            const int d = first_i(lds_ld_i(&s_done));            // columns final | pool entries in use << 13
+            const int d = first_i(lds_ld_i(&s_done));            // columns final | pool entries in use << 14
             wave_sync();
-            const int p = first_i(prev == kLdsNil ? lds_ld_u16(rhead + k) : lds_ld_u16(pnext + prev));
+            const int p = first_i((int)(prev == kLdsNil ? sh_ld<GM>(rhead + k) : sh_ld<GM>(pnext + prev)));
             if (p == kLdsNil) {
                 lap(1);
-                const int nd = d & 0x1fff;
-                if (nd >= k) { base = d >> 13; break; }
+                const int nd = d & 0x3fff;
+                if (nd >= k) { base = d >> 14; break; }
                 if (nd == k - 1) {
                     // every column before k - 1 is final and its links are walked: only column k - 1 can still add a dependency, and
                     // it hands its entries over the moment it has selected them -- before it publishes them.  ONE word is polled
@@ -584,20 +612,20 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
                 continue;
             }
             wave_sync();
-            const uint32_t em = pmeta[p + lane];
-            const double ev = pval[p + lane];
+            const uint32_t em = sh_ld<GM>(pmeta + p + lane);
+            const double ev = sh_ld<GM>(pval + p + lane);
             const double lkj = lane_d(ev, 0);
             const unsigned em0 = (unsigned)lane_i((int)em, 0);
-            const int rem = (int)(em0 >> 24);
+            const int rem = (int)(em0 >> (2 * RB));
             dg = dg - lkj * lkj;
-            const int erow = (int)(em & 0xfffu);
+            const int erow = (int)(em & RM);
             const double prod = lkj * ev;
             for (int q = 1; q <= rem; ++q) update(lane_i(erow, q), lane_d(prod, q));
             if (nl > 64) { give_up(k); alive = false; break; }
             prev = p;
             lap(2);
             // the link of column k - 1: no column before k can add another, and the pool ends behind that column
-            if ((int)((em0 >> 12) & 0xfffu) == k - 1) { base = p + rem + 1; break; }
+            if ((int)((em0 >> RB) & RM) == k - 1) { base = p + rem + 1; break; }
         }
         if (nl > 64) { give_up(k); break; }
         if (!alive) break;
@@ -669,45 +697,44 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
         // its predecessor to have published (the ends of the chains it appends to are that column's; usually long done)
         if (by_mail) {
             int turns = 0;
-            while ((first_i(lds_ld_i(&s_done)) & 0x1fff) < k) {
+            while ((first_i(lds_ld_i(&s_done)) & 0x3fff) < k) {
                 if (lds_ld_i(&s_abort) || ((++turns & 1023) == 0 && wall_clock64() - t_start > 100000000ll)) { alive = false; break; }
             }
             if (!alive) { give_up(k); break; }
         }
         wave_sync();
-        const int t_tail = kp ? (int)rtail[row] : kLdsNil, t_cnt = kp ? (int)rcnt[row] : 0;
+        const int t_tail = kp ? (int)sh_ld<GM>(rtail + row) : kLdsNil, t_cnt = kp ? (int)sh_ld<GM>(rcnt + row) : 0;
         if (__ballot(kp && t_cnt >= kIctCap)) { give_up(k); break; }
         const int at = base + pos;
         // (in this order: whoever sees a link finds the entries behind it and the new ends of the chains; `done` only ever grows)
         if (kp) {
-            pval[at] = lq;
-            pmeta[at] = (uint32_t)row | (uint32_t)k << 12 | (uint32_t)(nkept - 1 - pos) << 24;
-            pnext[at] = kLdsNil;
-            rtail[row] = (uint16_t)at;
-            rcnt[row] = (uint16_t)(t_cnt + 1);
+            sh_st<GM>(pval + at, lq);
+            sh_st<GM>(pmeta + at, (uint32_t)row | (uint32_t)k << RB | (uint32_t)(nkept - 1 - pos) << (2 * RB));
+            sh_st<GM>(pnext + at, (uint16_t)kLdsNil);
+            sh_st<GM>(rtail + row, (uint16_t)at);
+            sh_st<GM>(rcnt + row, (uint16_t)(t_cnt + 1));
         }
-        wave_sync();
+        if (lane == 0) sh_st<GM>(dgl + k, dk);
+        sh_release<GM>();
         if (kp) {
-            if (t_tail == kLdsNil) lds_st_u16(rhead + row, at);
-            else lds_st_u16(pnext + t_tail, at);
+            if (t_tail == kLdsNil) sh_st<GM>(rhead + row, (uint16_t)at);
+            else sh_st<GM>(pnext + t_tail, (uint16_t)at);
         }
-        wave_sync();
-        if (lane == 0) {
-            atomicMax(&s_done, (k + 1) | (base + nkept) << 13);
-            dgl[k] = dk;
-        }
+        sh_release<GM>();
+        if (lane == 0) atomicMax(&s_done, (k + 1) | (base + nkept) << 14);
         wave_sync();
         lap(4);
     }
     if (TR && lane == 0)
         for (int q = 0; q < 5; ++q) status[8 + w * 8 + q] = (int)(tr[q] >> 4);
+    if (GM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (s_abort) return;
     // ---- L as CSR (row i = its chain, columns ascending, then the diagonal): row pointers by a scan over the threads' runs of rows
     constexpr int T = W * 64;
     const int per = (n + T - 1) / T, r_lo = min(n, (int)threadIdx.x * per), r_hi = min(n, r_lo + per);
     int mine = 0;
-    for (int i = r_lo; i < r_hi; ++i) mine += rcnt[i] + 1;
+    for (int i = r_lo; i < r_hi; ++i) mine += (int)sh_ld<GM>(rcnt + i) + 1;
     int *const sums = si_all;                                             // [T]
     sums[threadIdx.x] = mine;
     __syncthreads();
@@ -716,13 +743,13 @@ __global__ __launch_bounds__(W * 64) void k_icholt_lds(int n, const int32_t *__r
     if (threadIdx.x == T - 1) { lrp[n] = at + mine; status[2] = at + mine; }
     for (int i = r_lo; i < r_hi; ++i) {
         lrp[i] = at;
-        for (int p = rhead[i]; p != kLdsNil; p = pnext[p]) {
-            lci[at] = (int)((pmeta[p] >> 12) & 0xfffu);
-            lv[at] = pval[p];
+        for (int p = (int)sh_ld<GM>(rhead + i); p != kLdsNil; p = (int)sh_ld<GM>(pnext + p)) {
+            lci[at] = (int)((sh_ld<GM>(pmeta + p) >> RB) & RM);
+            lv[at] = sh_ld<GM>(pval + p);
             ++at;
         }
         lci[at] = i;
-        lv[at] = dgl[i];
+        lv[at] = sh_ld<GM>(dgl + i);
         ++at;
     }
 }
@@ -775,38 +802,50 @@ int icholt_factor(const CsrDev &A, int add_fill_in, double threshold, CsrDev &Lf
         const int waves_arg = e_waves ? atoi(e_waves) : 4, waves = waves_arg == 8 || waves_arg == 16 ? waves_arg : 4;   // (one a SIMD)
         // kept entries: at most nnz(A[k+1:, k]) + add_fill_in a column = the strict upper triangle of A + n add_fill_in
         const int64_t pool_cap = (A.nnz - n + 1) / 2 + n * (int64_t)add_fill_in + 1;
-        if (lds_on && n >= 1 && n <= kLdsMaxRows && pool_cap < 0xff00 && icholt_lds_bytes((int)n, (int)pool_cap, waves) + 64 <= 160 * 1024) {
+        // DPCG_ICHOLT_LDS = 2: the workspace form even where the LDS form fits (development / tests)
+        const bool in_lds = n <= kLdsMaxRows && icholt_lds_bytes((int)n, (int)pool_cap, waves) + 64 <= 160 * 1024 && !(e_lds && e_lds[0] == '2');
+        const bool in_mem = !in_lds && n <= kGmMaxRows;
+        if (lds_on && n >= 1 && pool_cap < 0xff00 && (in_lds || in_mem)) {
             const int64_t cap_nnz = pool_cap + n;
+            double *ws = nullptr;
             if ((st = dev_alloc(&status, 8 + 16 * 8)) < 0 || (st = dev_alloc(&Lf.rowptr, n + 1)) < 0 ||
-                (st = dev_alloc(&Lf.col, cap_nnz)) < 0 || (st = dev_alloc(&Lf.val, cap_nnz)) < 0)
+                (st = dev_alloc(&Lf.col, cap_nnz)) < 0 || (st = dev_alloc(&Lf.val, cap_nnz)) < 0 ||
+                (in_mem && (st = dev_alloc(&ws, (int64_t)(icholt_big_bytes((int)n, (int)pool_cap) / 8 + 2))) < 0)) {
+                dev_free(ws);
                 return cleanup(st);
+            }
             hipError_t e = hipMemsetAsync(status, 0, 4 * sizeof(int), s);
-            if (e != hipSuccess) return cleanup(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
-            const size_t lds = icholt_lds_bytes((int)n, (int)pool_cap, waves);
+            if (e != hipSuccess) { dev_free(ws); return cleanup(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__)); }
+            const size_t lds = in_lds ? icholt_lds_bytes((int)n, (int)pool_cap, waves) : icholt_small_bytes(waves);
             const bool trace = getenv("DPCG_ICHOLT_TRACE") != nullptr;          // (development: cycles by phase, per wave, on stderr)
-#define DPCG_ICHOLT_LDS_LAUNCH(WV, TRC)                                                                                              \
+#define DPCG_ICHOLT_LDS_LAUNCH(WV, TRC, GMV)                                                                                         \
     do {                                                                                                                             \
-        e = hipFuncSetAttribute((const void *)k_icholt_lds<WV, TRC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+        e = hipFuncSetAttribute((const void *)k_icholt_lds<WV, TRC, GMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         if (e == hipSuccess)                                                                                                         \
-            hipLaunchKernelGGL((k_icholt_lds<WV, TRC>), dim3(1), dim3(WV * 64), lds, s, (int)n, A.rowptr, A.col, A.val, add_fill_in, \
-                               threshold, (int)pool_cap, Lf.rowptr, Lf.col, Lf.val, status);                                   \
+            hipLaunchKernelGGL((k_icholt_lds<WV, TRC, GMV>), dim3(1), dim3(WV * 64), lds, s, (int)n, A.rowptr, A.col, A.val,         \
+                               add_fill_in, threshold, (int)pool_cap, Lf.rowptr, Lf.col, Lf.val, status, ws);                        \
     } while (0)
-            if (trace && waves == 8) DPCG_ICHOLT_LDS_LAUNCH(8, true);
-            else if (trace) DPCG_ICHOLT_LDS_LAUNCH(4, true);
-            else if (waves == 8) DPCG_ICHOLT_LDS_LAUNCH(8, false);
-            else if (waves == 16) DPCG_ICHOLT_LDS_LAUNCH(16, false);
-            else DPCG_ICHOLT_LDS_LAUNCH(4, false);
+            if (in_mem) {
+                if (trace) DPCG_ICHOLT_LDS_LAUNCH(4, true, true);
+                else if (waves == 8) DPCG_ICHOLT_LDS_LAUNCH(8, false, true);
+                else DPCG_ICHOLT_LDS_LAUNCH(4, false, true);
+            } else if (trace && waves == 8) DPCG_ICHOLT_LDS_LAUNCH(8, true, false);
+            else if (trace) DPCG_ICHOLT_LDS_LAUNCH(4, true, false);
+            else if (waves == 8) DPCG_ICHOLT_LDS_LAUNCH(8, false, false);
+            else if (waves == 16) DPCG_ICHOLT_LDS_LAUNCH(16, false, false);
+            else DPCG_ICHOLT_LDS_LAUNCH(4, false, false);
 #undef DPCG_ICHOLT_LDS_LAUNCH
             int h_st[3] = {0, 0, 0};
             if (e == hipSuccess) e = hipGetLastError();
             if (e == hipSuccess) e = hipMemcpyAsync(h_st, status, sizeof(h_st), hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
+            dev_free(ws);                                                       // (the stream is idle)
             if (e != hipSuccess) return cleanup(hip_fail(e, "icholt (LDS)", __FILE__, __LINE__));
             if (trace) {
                 int h_tr[16 * 8] = {0};
-                const int tw = waves == 8 ? 8 : 4;
+                const int tw = (waves == 8 && !in_mem) ? 8 : 4;
                 (void)hipMemcpy(h_tr, status + 8, sizeof(h_tr), hipMemcpyDeviceToHost);
-                for (int wv = 0; wv < (waves == 8 ? 8 : 4); ++wv)
+                for (int wv = 0; wv < tw; ++wv)
                     fprintf(stderr, "[icholt lds] wave %d: cycles per column (of %lld): row of A %.0f, waiting %.0f, dependencies %.0f, selection %.0f, publication %.0f\n",
                             wv, (long long)n, h_tr[wv * 8 + 0] * 16.0 * tw / n, h_tr[wv * 8 + 1] * 16.0 * tw / n, h_tr[wv * 8 + 2] * 16.0 * tw / n,
                             h_tr[wv * 8 + 3] * 16.0 * tw / n, h_tr[wv * 8 + 4] * 16.0 * tw / n);

@@ -1746,7 +1746,7 @@ def _banded_random_spd(n, per_row, band, seed):
     return A
 
 
-@pytest.mark.parametrize("lds,regs", [("1", "1"), ("0", "1"), ("0", "0")])
+@pytest.mark.parametrize("lds,regs", [("1", "1"), ("2", "1"), ("0", "1"), ("0", "0")])
 def test_icholt_as_ilupp_defines_it(D, monkeypatch, lds, regs):
     """`ICholT` = `ilupp.icholt(A, add_fill_in, threshold)`, the reference harness's default technique (test.py:81-88), factored
     on the device column by column with ILU++'s dual-threshold rule.  The ilupp binary is absent (parity unpinned against it):
@@ -1754,7 +1754,8 @@ def test_icholt_as_ilupp_defines_it(D, monkeypatch, lds, regs):
     on grids, scaled / scrambled systems, a quadtree mesh with hanging nodes and a Delaunay graph, a banded random matrix whose
     columns hold more than 64 candidates (the LDS selection) -- for the harness's arguments and others; as the plain call runs it
     (systems whose factor fits one CU's LDS: the pipeline of waves, k_icholt_lds, which hands the columns beyond its plain case
-    to the one-wave kernel), with the one-wave kernel alone (DPCG_ICHOLT_LDS=0), candidates of a column in registers, and with
+    to the one-wave kernel; DPCG_ICHOLT_LDS=2: the same pipeline with pool and chains in a workspace in memory, the form of factors
+    beyond the LDS up to 8192 rows), with the one-wave kernel alone (DPCG_ICHOLT_LDS=0), candidates of a column in registers, and with
     every column through its LDS hash table (DPCG_ICHOLT_REGS=0: the path of columns with many updates); PCG with the factor solved and multiplied matches the oracle with the same factor;
     the limits and the error paths of the ABI."""
     from deeppreconditioning_amd._lib import DpcgError, ERR_INVALID, ERR_PIVOT

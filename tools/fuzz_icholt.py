@@ -49,7 +49,7 @@ for case in range(cases):
         Lref = O.icholt(A, fill, thr)
     except ValueError as e:
         Lref = str(e)
-    for lds, regs in (("1", "1"), ("0", "1"), ("0", "0")):
+    for lds, regs in (("1", "1"), ("2", "1"), ("0", "1"), ("0", "0")):
         os.environ["DPCG_ICHOLT_LDS"] = lds
         os.environ["DPCG_ICHOLT_WAVES"] = str(int(rng.choice([4, 8, 16])))
         os.environ["DPCG_ICHOLT_REGS"] = regs
