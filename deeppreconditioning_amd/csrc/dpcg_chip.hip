@@ -59,6 +59,12 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     // contract of DPCG_SPMV_F32: the CPU restatement's mixed product).  The values are rounded once, where they are read; a gathered p is
     // rounded where it is recomputed.  Everything else is the fp64 arithmetic of MODE 0 (x0 = 0 only: cg.py:60 reads the fp64 A).
     constexpr bool F32 = MODE == 4;
+    // MODE 5: the matrix is NOT resident -- rows too long (or columns too far) for the slots above: a 1M-row finite-volume mesh with
+    // rows of 9, a Delaunay graph with rows of 21.  Same skeleton (vectors in registers, published granules, two exchanges an update),
+    // but q = A p streams the workgroup's CSR segment every update the way the CSR-stream SpMV does: the 512 rows of a slot are 512
+    // CONSECUTIVE rows, their entries one contiguous run of col / val; lane t takes entry e0 + t, gathers the granule of its column,
+    // parks value x p in LDS, and after a barrier thread t adds its row's products in column order -- the same sum.  WMAX = 1 here.
+    constexpr bool STREAM = MODE == 5;
     constexpr int NS = RPT * WMAX;                                   // entry slots of a thread
     constexpr int NLDS = NS < kChipLdsSlots ? NS : kChipLdsSlots;    // ... whose values live in LDS
     constexpr int NREG = NS - NLDS;                                  // ... and in registers (the first NREG slots)
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         const double di = JAC ? d.dinv[ic] : 1.0;
         rs_k[k] = rs;
         len_k[k] = valid ? re - rs : 0;
-        lens |= (valid ? (LV | (unsigned)(re - rs)) : 0u) << (LB * k);
+        lens |= (valid ? (LV | (STREAM ? 0u : (unsigned)(re - rs))) : 0u) << (LB * k);
         x[k] = valid ? xi : 0.0;
         r[k] = valid ? bi : 0.0;
         p[k] = q[k] = 0.0;
@@ -110,6 +116,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         if ((lens >> (LB * k)) & LV) bb_loc += r[k] * r[k];
+        if (STREAM) continue;
         const int i = row0 + k * kChipThreads;
         int cj[WMAX];
         double aj[WMAX];
@@ -184,6 +191,113 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         }
     };
 
+    // ---- MODE 5: the streamed product, wave by wave: the 64 rows a wave owns in a slot are 64 CONSECUTIVE rows, their entries one
+    // contiguous run of col / val.  Lane l takes entry e0 + l, gathers the granule of its column, parks value x p in the WAVE's part
+    // of the LDS, and then adds its own row's products in column order.  No workgroup barrier: the eight waves run their slots
+    // independently, one waits for memory while another adds.  LDS: products [8 waves][d.stream_cap], then per thread and slot the
+    // row's offset into its wave's run and its length.
+    double *const st_prod = chip_lv + (t >> 6) * (STREAM ? d.stream_cap : 0);
+    int *const st_rs = reinterpret_cast<int *>(chip_lv + (STREAM ? (kChipThreads / 64) * d.stream_cap : 0));
+    int *const st_len = st_rs + RPT * kChipThreads;
+    int *const st_run = st_len + RPT * kChipThreads + (t >> 6) * 2 * (RPT + 1);      // this wave's run of slot k: [st_run[2k], st_run[2k + 1])
+    const __amdgpu_buffer_rsrc_t ci_rs = chip_rsrc(const_cast<int32_t *>(d.ci), STREAM ? (unsigned)d.rp_nnz * 4u : 4u);
+    const __amdgpu_buffer_rsrc_t val_rs = chip_rsrc(const_cast<double *>(d.val), STREAM ? (unsigned)d.rp_nnz * 8u : 8u);
+    if (STREAM) {
+        const int wg_lo = v * d.per, wg_hi = (wg_lo + d.per < d.n) ? wg_lo + d.per : d.n;
+        const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int f0 = wg_lo + k * kChipThreads + wv * 64;
+            const int first = f0 < wg_hi ? f0 : wg_hi, last = first + 64 < wg_hi ? first + 64 : wg_hi;
+            const int q0 = d.rp[first], q1 = d.rp[last];
+            if ((t & 63) == 0) { st_run[2 * k] = q0; st_run[2 * k + 1] = q1; }
+            st_rs[k * kChipThreads + t] = rs_k[k] - q0;
+            st_len[k * kChipThreads + t] = len_k[k];
+        }
+        if ((t & 63) == 0) { st_run[2 * RPT] = 0; st_run[2 * RPT + 1] = 0; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    auto spmv_stream = [&](double beta) {
+        constexpr int U = 6;                                      // entries of a lane per group: 384 a wave -- a run of 64 short rows is one group
+        int glo_l = glo, span_l = local ? ghi - glo : 0;
+        const int local_shift = grp * 128;
+        const int lane = t & 63;
+        asm volatile("" : "+s"(glo_l), "+s"(span_l));
+        auto r0 = [&](int k) { return __builtin_amdgcn_readfirstlane(st_run[2 * k]); };          // (k <= RPT: the last pair is an empty run)
+        auto r1 = [&](int k) { return __builtin_amdgcn_readfirstlane(st_run[2 * k + 1]); };
+        // the groups of the wave, one after another: (slot, first entry); slot = RPT: no more
+        auto next_group = [&](int k, int e, int &nk, int &ne) {
+            nk = k;
+            ne = e + U * 64;
+            if (k >= RPT || ne >= r1(k)) {
+                nk = k < RPT ? k + 1 : RPT;
+                while (nk < RPT && r1(nk) <= r0(nk)) ++nk;
+                ne = nk < RPT ? r0(nk) : 0;
+            }
+        };
+        auto fetch = [&](int k, int eb, int (&cc)[U], double (&aa)[U]) {
+            const int s0 = r0(k), s1 = r1(k);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (eb + u * 64 >= s1) continue;                  // (the whole chunk lies beyond the run: the same for every lane)
+                const int e = eb + u * 64 + lane;
+                const int ec = e < s1 ? e : s0;
+                cc[u] = __builtin_amdgcn_raw_buffer_load_b32(ci_rs, ec * 4, 0, 0);
+                const u32x2 av2 = __builtin_amdgcn_raw_buffer_load_b64(val_rs, ec * 8, 0, 0);
+                aa[u] = __longlong_as_double((long long)(((unsigned long long)av2.y << 32) | av2.x));
+            }
+        };
+        auto gather = [&](const int (&cc)[U], u32x4 (&gg)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool own = (unsigned)(cc[u] - glo_l) < (unsigned)span_l;
+                gg[u] = __builtin_amdgcn_raw_buffer_load_b128(zp_rs, cc[u] * 16 + (own ? local_shift : remote_base), 0, kSc1);
+            }
+        };
+        // A pipeline three groups deep: while group i's products are parked and added, the granules of group i + 1 and the col / val of
+        // group i + 2 are in flight (a wave that waits all the same leaves the memory pipeline to the other seven)
+        int k0 = RPT, e0 = 0, k1, e1, k2, e2;
+        { int kk = 0; while (kk < RPT && r1(kk) <= r0(kk)) ++kk; k0 = kk; e0 = kk < RPT ? r0(kk) : 0; }
+        next_group(k0, e0, k1, e1);
+        next_group(k1, e1, k2, e2);
+        int c1[U], c2[U];
+        double a0[U], a1[U], a2[U];
+        u32x4 g0[U], g1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { c1[u] = 0; c2[u] = 0; a0[u] = a1[u] = a2[u] = 0.0; g0[u] = g1[u] = pack_f64x2(0.0, 0.0); }
+        if (k0 < RPT) { fetch(k0, e0, c1, a0); gather(c1, g0); }
+        if (k1 < RPT) fetch(k1, e1, c1, a1);
+        while (k0 < RPT) {
+            if (k2 < RPT) fetch(k2, e2, c2, a2);
+            if (k1 < RPT) gather(c1, g1);
+            const int s0 = r0(k0), s1 = r1(k0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * 64 + lane;
+                const double pc = lo_f64(g0[u]) + beta * hi_f64(g0[u]);             // = p_k[c], cg.py:83
+                if (e < s1) st_prod[e - s0] = a0[u] * pc;
+            }
+            if (k1 != k0) {                                       // the run is complete: every lane adds its row, in column order
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int rs = st_rs[k0 * kChipThreads + t], len = st_len[k0 * kChipThreads + t];
+                double acc = 0.0;
+                for (int j = 0; j < len; ++j) acc += st_prod[rs + j];
+#pragma unroll
+                for (int kk = 0; kk < RPT; ++kk)
+                    if (kk == k0) q[kk] = acc;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();                  // (the next run's products overwrite these)
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a0[u] = a1[u]; a1[u] = a2[u]; c1[u] = c2[u]; g0[u] = g1[u]; }
+            k0 = k1; e0 = e1;
+            k1 = k2; e1 = e2;
+            next_group(k1, e1, k2, e2);
+        }
+    };
+
     // Two chip-wide sums at once, and a chip barrier in the same breath (see the header).  `publish`: the workgroup's granule stores
     // must be visible to whoever passes this point, so every wave drains them first.  Every workgroup returns the same bits.
     // DPCG_CHIP_TRACE: where an update's time goes -- ticks (100 MHz) of thread 0 of EVERY workgroup, accumulated in LDS (registers
@@ -234,7 +348,8 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
             if (row_on(k)) publish(k, x[k], 0.0);
         alive = chip_sum2(0.0, 0.0, true, dummy, dummy2);
         if (alive) {
-            spmv(0.0);
+            if (STREAM) spmv_stream(0.0);
+            else spmv(0.0);
 #pragma unroll
             for (int k = 0; k < RPT; ++k) r[k] = r[k] - q[k];
             alive = chip_sum2(0.0, 0.0, false, dummy, dummy2);    // everybody has read x0 out of the granules before z_0 overwrites them
@@ -276,7 +391,8 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
 #pragma unroll
             for (int k = 0; k < RPT; ++k) q[k] = p[k];
         } else {
-            spmv(beta);                                           // cg.py:75
+            if (STREAM) spmv_stream(beta);
+            else spmv(beta);                                      // cg.py:75
         }
         double pq_loc = 0.0;
 #pragma unroll
@@ -377,13 +493,17 @@ template <int RPT, int WMAX, bool JAC, int MODE>
 int chip_launch(const ChipDesc &d, hipStream_t s, bool check_only) {
     constexpr int NS = RPT * WMAX;
     constexpr int NLDS = NS < kChipLdsSlots ? NS : kChipLdsSlots;
-    const int lds = NLDS * kChipThreads * (int)sizeof(double);
+    // (MODE 5: the product buffer of one slot, the rows' offsets and lengths, the bounds of the runs; the attribute and the occupancy
+    // are those of the largest buffer the form admits)
+    const int lds_max5 = chip_stream_max_row_len() * kChipThreads * (int)sizeof(double) + RPT * kChipThreads * 8 + 1024;
+    const int lds = MODE == 5 ? (kChipThreads / 64) * d.stream_cap * (int)sizeof(double) + RPT * kChipThreads * 8 + 1024 : NLDS * kChipThreads * (int)sizeof(double);
+    const int lds_attr = MODE == 5 ? lds_max5 : lds;
     static int resident = -1;              // workgroups the occupancy query admits per CU (once per instantiation)
     if (resident < 0) {
-        if (hipFuncSetAttribute((const void *)k_pcg_chip<RPT, WMAX, JAC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_pcg_chip<RPT, WMAX, JAC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr) != hipSuccess)
             return DPCG_ERR_HIP;
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_pcg_chip<RPT, WMAX, JAC, MODE>, kChipThreads, (size_t)lds) !=
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_pcg_chip<RPT, WMAX, JAC, MODE>, kChipThreads, (size_t)lds_attr) !=
             hipSuccess)
             return DPCG_ERR_HIP;
         resident = per_cu;
@@ -421,6 +541,7 @@ int launch_occupy(int workgroups, double ms, hipStream_t s) {
 int chip_max_rows() { return kChipWGs * kChipThreads * kChipMaxRpt; }
 // rows of up to 9 entries (unstructured meshes) while a thread holds at most four rows (524 288 rows), 7 beyond
 int chip_max_row_len(int64_t n) { return n <= (int64_t)kChipWGs * kChipThreads * 4 ? 9 : 7; }
+int chip_stream_max_row_len() { return 30; }      // 30 x 512 x 8 B = 123 KB of products + 33 KB of row tables (8 rows a thread) of the 160 KB
 int chip_max_band() { return 32767; }
 int chip_workgroups() { return kChipWGs; }
 int chip_threads() { return kChipThreads; }
@@ -438,8 +559,18 @@ void launch_band_and_len(const CsrDev &A, int *out2_zeroed_dev, hipStream_t s) {
 // Returns DPCG_OK, DPCG_ERR_STATE when the kernel cannot be resident on every CU, or a negative HIP status.
 int launch_pcg_chip(const ChipDesc &d, int max_row_len, hipStream_t s, bool check_only) {
     const int rpt = (d.per + kChipThreads - 1) / kChipThreads;
-    if (max_row_len < 1 || max_row_len > (rpt <= 4 ? 9 : 7) || d.per < 1 || d.per > kChipThreads * kChipMaxRpt) return DPCG_ERR_INVALID;
     const bool jac = d.precond == DPCG_PRECOND_JACOBI;
+    if (d.stream_cap > 0) {                // the streamed form (MODE 5)
+        if (max_row_len < 1 || max_row_len > chip_stream_max_row_len() || d.stream_cap < max_row_len * 64 || d.per < 1 ||
+            d.per > kChipThreads * kChipMaxRpt || d.f32 || d.bench || d.dbg)
+            return DPCG_ERR_INVALID;
+#define DPCG_CHIP_S(RPTV) (jac ? chip_launch<RPTV, 1, true, 5>(d, s, check_only) : chip_launch<RPTV, 1, false, 5>(d, s, check_only))
+        if (rpt <= 2) return DPCG_CHIP_S(2);
+        if (rpt <= 4) return DPCG_CHIP_S(4);
+        return DPCG_CHIP_S(8);
+#undef DPCG_CHIP_S
+    }
+    if (max_row_len < 1 || max_row_len > (rpt <= 4 ? 9 : 7) || d.per < 1 || d.per > kChipThreads * kChipMaxRpt) return DPCG_ERR_INVALID;
     const int mode = d.bench == 3 ? 3 : (d.bench ? 2 : (d.dbg != nullptr ? 1 : (d.f32 ? 4 : 0)));
     if (d.f32 && (mode != 4 || d.x0)) return DPCG_ERR_INVALID;
 #define DPCG_CHIP_T(RPTV, WV, JV) (mode == 4 ? chip_launch<RPTV, WV, JV, 4>(d, s, check_only) : mode == 3 ? chip_launch<RPTV, WV, JV, 3>(d, s, check_only) : mode == 2 ? chip_launch<RPTV, WV, JV, 2>(d, s, check_only) : (mode == 1 ? chip_launch<RPTV, WV, JV, 1>(d, s, check_only) : chip_launch<RPTV, WV, JV, 0>(d, s, check_only)))

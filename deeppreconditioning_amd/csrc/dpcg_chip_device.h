@@ -20,6 +20,7 @@ constexpr int kChipSlotBytes = kChipS1Bytes + 4 * 8 * 8 * 16;  // + chip-level s
 constexpr int kSc1 = 16;                // cache-policy operand of the buffer builtins on gfx950: bit 4 = sc1 (agent scope)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t chip_rsrc(const void *p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);

@@ -462,6 +462,9 @@ struct ChipDesc {
     double *zp;                // 2 x (n + 4096) granules {z_{k+1}[i], p_k[i]}: the copy read inside a group and the written-through one
     int band;                  // largest |col - row| of the matrix
     int bench;                 // development (DPCG_CHIP_BENCH): the kernel variant without the gathers of q = A p (q = p) that never stops before max_iter
+    int stream_cap;            // > 0: the matrix is streamed every update (MODE 5: rows too long or columns too far for the resident form); entries the
+                               // 64 rows a wave owns in one slot hold at most (its LDS product buffer, doubles)
+    int rp_nnz;                // entries of the matrix (the extent of the streamed form's col / val buffers)
     int f32;                   // DPCG_SPMV_F32 (BASELINE config 5): matrix values and p of `A @ p` stored in fp32, products and sums in fp64; x0 = 0 only
     int *xcc;                  // 256 words: the XCD every workgroup found itself on (exchanged once per solve); null: never store plainly
     double rtol_sq, atol_sq;
@@ -496,6 +499,7 @@ int launch_pcg_chip_llt(const ChipLltDesc &d, int max_a, int max_l, hipStream_t 
 int chip_max_rows();
 int chip_max_row_len(int64_t n);
 int chip_max_band();
+int chip_stream_max_row_len();    // rows of the streamed form (dpcg_chip.hip MODE 5): the LDS holds the products of 512 of them
 int chip_workgroups();
 int chip_threads();
 int chip_slot_doubles();          // reduction slots (doubles) of a chip solve

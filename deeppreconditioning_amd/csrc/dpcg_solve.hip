@@ -674,6 +674,11 @@ static int solve_team_one(dpcg_system *h, const double *b, const double *x0, dou
 // ------------------------------------------------------------------------------------------------
 // 65 537 .. 1 048 576 rows, rows of <= 7 entries, half-bandwidth < 32 768 (stencils; meshes after the library's RCM), M = I / Jacobi:
 // matrix and vectors stay in registers and LDS for the whole solve.  DPCG_CHIP=0 / DPCG_CHIP_MIN_ROWS: development knobs.
+// the resident form: every row in the slots of its thread, every column within the 16-bit reach of its row
+static bool chip_resident_shape(const dpcg_system *h) {
+    return h->planA.max_row_len >= 1 && h->planA.max_row_len <= chip_max_row_len(h->A.n) && h->planA.max_band >= 0 &&
+           h->planA.max_band <= chip_max_band();
+}
 static bool chip_eligible(const dpcg_system *h, int flags, const double *x_true) {
     static const bool enabled = [] {
         const char *e = getenv("DPCG_CHIP");
@@ -686,9 +691,19 @@ static bool chip_eligible(const dpcg_system *h, int flags, const double *x_true)
     static const int min_rows = [] { const char *e = getenv("DPCG_CHIP_MIN_ROWS"); return e ? atoi(e) : team_max_rows(); }();
     if (!enabled || x_true || (flags & (DPCG_NO_TEAM | DPCG_NO_FUSE | DPCG_VAL32_IF_LOSSLESS))) return false;   // (DPCG_SPMV_F32: with x0 = 0, see the callers)
     if (h->A.n <= min_rows || h->A.n > chip_max_rows()) return false;
-    if (h->planA.max_row_len < 1 || h->planA.max_row_len > chip_max_row_len(h->A.n)) return false;
-    if (h->planA.max_band < 0 || h->planA.max_band > chip_max_band()) return false;
-    return h->precond == DPCG_PRECOND_NONE || h->precond == DPCG_PRECOND_JACOBI;
+    if (h->planA.max_row_len < 1 || h->planA.max_band < 0) return false;
+    if (h->precond != DPCG_PRECOND_NONE && h->precond != DPCG_PRECOND_JACOBI) return false;
+    if (chip_resident_shape(h)) return true;
+    // rows too long or columns too far for the resident form: the same kernel with the matrix streamed (dpcg_chip.hip MODE 5) -- fp64,
+    // 524 289 rows and more (below, the launches' x-tile SpMV has the L2 to itself), rows of at most 12 entries by default: measured on the
+    // 1M-row meshes (profiles/r05_chip_stream_probe.txt) 24.6-26.3 us an update against 28.4-28.5 for the launches on the quadtree
+    // meshes (rows of up to 9), but 35.2 against 31.2 on the Delaunay graph (rows of up to 21: half-empty groups).
+    // DPCG_CHIP_STREAM=0: never; 1: from 65 537 rows and for rows of up to 30 entries (development / tests)
+    const char *e = getenv("DPCG_CHIP_STREAM");
+    if (e && e[0] == '0') return false;
+    const bool wide = e && e[0] == '1';
+    const int64_t from = wide ? 0 : (int64_t)chip_workgroups() * chip_threads() * 4;
+    return h->A.n > from && h->planA.max_row_len <= (wide ? chip_stream_max_row_len() : 12) && !(flags & DPCG_SPMV_F32);
 }
 // a plain call takes it (DPCG_NO_SMALL = "no whole-solve kernel for one system" keeps the launches, as for the other two)
 static bool chip_default(const dpcg_system *h, int flags) {
@@ -733,9 +748,12 @@ static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, dou
     d.err = reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256);
     d.band = h->planA.max_band;
     d.f32 = (flags & DPCG_SPMV_F32) ? 1 : 0;
+    d.rp_nnz = (int)std::min<int64_t>(h->A.nnz, 0x1fffffff);
+    d.stream_cap = (chip_resident_shape(h) || h->A.nnz > 0x1fffffff) ? 0 : h->planA.max_row_len * 64;     // (products of the 64 rows of a wave)
     { const char *e = getenv("DPCG_CHIP_BENCH"); d.bench = e ? atoi(e) : 0; }
     static const bool trace = [] { const char *e = getenv("DPCG_CHIP_TRACE"); return e && e[0] == '1'; }();
     if (d.f32 && (d.bench || trace || x0)) return DPCG_ERR_STATE;                      // (the caller goes on with the launches)
+    if (d.stream_cap > 0 && (d.bench || trace || d.f32)) return DPCG_ERR_STATE;
     static const bool plain_ok = [] { const char *e = getenv("DPCG_CHIP_LOCAL"); return !(e && e[0] == '0'); }();   // development: 0 = everything written through
     d.xcc = plain_ok ? reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256 + 2) : nullptr;
     d.dbg = trace ? reinterpret_cast<unsigned long long *>(h->chip_part + kSlots) : nullptr;

@@ -2908,6 +2908,48 @@ def test_chip_solve_mixed_precision_equals_the_oracle_bit_for_bit(D, name, make,
 
 
 
+@pytest.mark.parametrize("name,make,max_iter,env", [
+    ("quadtree_random_1000", lambda: O.quadtree_fv_laplacian(1000, 0, numbering="random"), 150, None),   # 1M rows of up to 9 entries, in RCM order
+    ("quadtree_foam_1000", lambda: O.quadtree_fv_laplacian(1000, 0), 150, None),      # OpenFOAM's numbering, region by region: no band -- every granule written through
+    ("delaunay_1M", lambda: O.delaunay_laplacian(1000000, 0), 150, "1"),               # rows of up to 21 entries (not taken by default: the launches are faster there)
+    ("delaunay_100K", lambda: O.delaunay_laplacian(100000, 3), 400, "1"),              # 2 rows a thread (DPCG_CHIP_STREAM=1: from 65 537 rows)
+    ("quadtree_random_600", lambda: O.quadtree_fv_laplacian(600, 2, numbering="random"), 300, "1")])   # (373K rows of up to 9 entries: the resident form takes it -- the knob must not change that)
+def test_chip_stream_solve_equals_the_device_tree_oracle_bit_for_bit(D, monkeypatch, name, make, max_iter, env):
+    """The one-launch kernel with the matrix STREAMED (k_pcg_chip MODE 5): 1M-row meshes whose rows are too long (9, 21 entries) or
+    whose columns reach too far for the resident form keep the vectors in registers and exchange through the granules, and stream
+    their CSR run every update.  Same rows per thread, same trees: history, count and x EQUAL to the oracle with the chip tree."""
+    if env is not None:
+        monkeypatch.setenv("DPCG_CHIP_STREAM", env)
+    A = make()
+    n = A.shape[0]
+    S = D.CsrSystem.from_any(A)
+    b = O.rhs(n, 0)
+    perm = S.permutation() if S.reordered else None
+    B = _permuted(A, perm) if perm is not None else A
+    bb = b[perm] if perm is not None else b
+    S.set_preconditioner(D.Jacobi())
+    ci = S.chip_info()
+    assert ci["chip_by_default"], ci
+    resident = ci["max_row_len"] <= (9 if n <= 524288 else 7) and ci["max_band"] <= 32767
+    if name != "quadtree_random_600":
+        assert not resident, ci                    # (these are the streamed form's systems)
+    res = S.solve(_dev(b), max_iter=max_iter)
+    multi = S.solve(_dev(b), max_iter=max_iter, flags=D._lib.NO_SMALL)
+    _, it, hist, x = CO.pcg(B, bb, "jacobi", dinv=O.jacobi_dinv(B), max_iter=max_iter, device_tree=_chip_tree(S))
+    assert res.iterations == it == multi.iterations and res.status == multi.status, (name, res.iterations, it)
+    assert np.array_equal(res.res_history, hist), (name, int(np.argmax(res.res_history != hist)))
+    xs = res.x.cpu().numpy()
+    assert np.array_equal(xs[perm] if perm is not None else xs, x), name
+    np.testing.assert_allclose(multi.res_history[:100], hist[:100], rtol=1e-8)
+    assert not np.array_equal(multi.res_history, res.res_history)            # (another summation order: it WAS the other path)
+    x0 = O.rhs(n, 9)
+    with_x0 = S.solve(_dev(b), x0=_dev(x0), max_iter=30)
+    _, it0, hist0, _ = CO.pcg(B, bb, "jacobi", dinv=O.jacobi_dinv(B), x0=x0[perm] if perm is not None else x0, max_iter=30, device_tree=_chip_tree(S))
+    assert with_x0.iterations == it0 and np.array_equal(with_x0.res_history, hist0), name
+    S.close()
+
+
+
 def test_chip_solve_arguments_and_edges(D):
     """x0 (cg.py:58-60), caps, both first tests (cg.py:66 / scipy's), b = 0, and what keeps a system OFF the chip kernel: the flags of
     the other forms, a preconditioner it does not fuse, rows of more than 7 entries, a bandwidth beyond 16-bit offsets."""
