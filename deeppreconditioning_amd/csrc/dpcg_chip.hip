@@ -218,67 +218,96 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    // A wave's groups of 64 SU entries pass through a ring: the col / val of a group are fetched SNF iterations before its granules are
+    // gathered, the granules SNG iterations before its products are parked -- at ~0.5 us an iteration that is the two memory round
+    // trips of a group, so a wave that has its data never waits; the first SNF groups of the NEXT update are fetched when this one's
+    // product ends (the matrix does not change) and ride through the exchanges in registers: the pipeline is filled once per solve.
+    constexpr int SU = 3, SNG = 2, SNF = 3, SND = SNG + SNF;
+    int sc[SND + 1][SU];
+    double sa[SND + 1][SU];
+    auto st_r0 = [&](int k) { return __builtin_amdgcn_readfirstlane(st_run[2 * k]); };          // (k <= RPT: the last pair is an empty run)
+    auto st_r1 = [&](int k) { return __builtin_amdgcn_readfirstlane(st_run[2 * k + 1]); };
+    // the groups of the wave, one after another: (slot, first entry); slot = RPT: no more
+    auto st_next = [&](int k, int e, int &nk, int &ne) {
+        nk = k;
+        ne = e + SU * 64;
+        if (k >= RPT || ne >= st_r1(k)) {
+            nk = k < RPT ? k + 1 : RPT;
+            while (nk < RPT && st_r1(nk) <= st_r0(nk)) ++nk;
+            ne = nk < RPT ? st_r0(nk) : 0;
+        }
+    };
+    auto st_first = [&](int &k, int &e) {
+        k = 0;
+        while (k < RPT && st_r1(k) <= st_r0(k)) ++k;
+        e = k < RPT ? st_r0(k) : 0;
+    };
+    auto st_fetch = [&](int k, int eb, int (&cc)[SU], double (&aa)[SU]) {
+        if (k >= RPT) return;
+        const int s0 = st_r0(k), s1 = st_r1(k), lane = t & 63;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            if (eb + u * 64 >= s1) continue;                      // (the whole chunk lies beyond the run: the same for every lane)
+            const int e = eb + u * 64 + lane;
+            const int ec = e < s1 ? e : s0;
+            cc[u] = __builtin_amdgcn_raw_buffer_load_b32(ci_rs, ec * 4, 0, 0);
+            const u32x2 av2 = __builtin_amdgcn_raw_buffer_load_b64(val_rs, ec * 8, 0, 0);
+            aa[u] = __longlong_as_double((long long)(((unsigned long long)av2.y << 32) | av2.x));
+        }
+    };
+    auto st_prefetch = [&]() {                                    // the first SNF groups: before the first product, and behind every product
+        int k, e;
+        st_first(k, e);
+#pragma unroll
+        for (int j = 0; j < SNF; ++j) {
+            st_fetch(k, e, sc[j], sa[j]);
+            int nk, ne;
+            st_next(k, e, nk, ne);
+            k = nk; e = ne;
+        }
+    };
+    if (STREAM) {
+#pragma unroll
+        for (int j = 0; j <= SND; ++j)
+#pragma unroll
+            for (int u = 0; u < SU; ++u) { sc[j][u] = 0; sa[j][u] = 0.0; }
+        st_prefetch();
+    }
     auto spmv_stream = [&](double beta) {
-        constexpr int U = 6;                                      // entries of a lane per group: 384 a wave -- a run of 64 short rows is one group
         int glo_l = glo, span_l = local ? ghi - glo : 0;
         const int local_shift = grp * 128;
         const int lane = t & 63;
         asm volatile("" : "+s"(glo_l), "+s"(span_l));
-        auto r0 = [&](int k) { return __builtin_amdgcn_readfirstlane(st_run[2 * k]); };          // (k <= RPT: the last pair is an empty run)
-        auto r1 = [&](int k) { return __builtin_amdgcn_readfirstlane(st_run[2 * k + 1]); };
-        // the groups of the wave, one after another: (slot, first entry); slot = RPT: no more
-        auto next_group = [&](int k, int e, int &nk, int &ne) {
-            nk = k;
-            ne = e + U * 64;
-            if (k >= RPT || ne >= r1(k)) {
-                nk = k < RPT ? k + 1 : RPT;
-                while (nk < RPT && r1(nk) <= r0(nk)) ++nk;
-                ne = nk < RPT ? r0(nk) : 0;
-            }
-        };
-        auto fetch = [&](int k, int eb, int (&cc)[U], double (&aa)[U]) {
-            const int s0 = r0(k), s1 = r1(k);
+        u32x4 sg[SNG + 1][SU];
+        auto gather = [&](const int (&cc)[SU], u32x4 (&gg)[SU]) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (eb + u * 64 >= s1) continue;                  // (the whole chunk lies beyond the run: the same for every lane)
-                const int e = eb + u * 64 + lane;
-                const int ec = e < s1 ? e : s0;
-                cc[u] = __builtin_amdgcn_raw_buffer_load_b32(ci_rs, ec * 4, 0, 0);
-                const u32x2 av2 = __builtin_amdgcn_raw_buffer_load_b64(val_rs, ec * 8, 0, 0);
-                aa[u] = __longlong_as_double((long long)(((unsigned long long)av2.y << 32) | av2.x));
-            }
-        };
-        auto gather = [&](const int (&cc)[U], u32x4 (&gg)[U]) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < SU; ++u) {
                 const bool own = (unsigned)(cc[u] - glo_l) < (unsigned)span_l;
                 gg[u] = __builtin_amdgcn_raw_buffer_load_b128(zp_rs, cc[u] * 16 + (own ? local_shift : remote_base), 0, kSc1);
             }
         };
-        // A pipeline three groups deep: while group i's products are parked and added, the granules of group i + 1 and the col / val of
-        // group i + 2 are in flight (a wave that waits all the same leaves the memory pipeline to the other seven)
-        int k0 = RPT, e0 = 0, k1, e1, k2, e2;
-        { int kk = 0; while (kk < RPT && r1(kk) <= r0(kk)) ++kk; k0 = kk; e0 = kk < RPT ? r0(kk) : 0; }
-        next_group(k0, e0, k1, e1);
-        next_group(k1, e1, k2, e2);
-        int c1[U], c2[U];
-        double a0[U], a1[U], a2[U];
-        u32x4 g0[U], g1[U];
+        // descriptors of the groups i .. i + SND (stage j = group i + j); stages 0 .. SNF - 1 arrive fetched
+        int gk[SND + 1], ge[SND + 1];
+        st_first(gk[0], ge[0]);
 #pragma unroll
-        for (int u = 0; u < U; ++u) { c1[u] = 0; c2[u] = 0; a0[u] = a1[u] = a2[u] = 0.0; g0[u] = g1[u] = pack_f64x2(0.0, 0.0); }
-        if (k0 < RPT) { fetch(k0, e0, c1, a0); gather(c1, g0); }
-        if (k1 < RPT) fetch(k1, e1, c1, a1);
-        while (k0 < RPT) {
-            if (k2 < RPT) fetch(k2, e2, c2, a2);
-            if (k1 < RPT) gather(c1, g1);
-            const int s0 = r0(k0), s1 = r1(k0);
+        for (int j = 1; j <= SND; ++j) st_next(gk[j - 1], ge[j - 1], gk[j], ge[j]);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+        for (int j = SNF; j < SND; ++j) st_fetch(gk[j], ge[j], sc[j], sa[j]);
+#pragma unroll
+        for (int j = 0; j < SNG; ++j)
+            if (gk[j] < RPT) gather(sc[j], sg[j]);
+        while (gk[0] < RPT) {
+            st_fetch(gk[SND], ge[SND], sc[SND], sa[SND]);
+            if (gk[SNG] < RPT) gather(sc[SNG], sg[SNG]);
+            const int k0 = gk[0], e0 = ge[0];
+            const int s0 = st_r0(k0), s1 = st_r1(k0);
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
                 const int e = e0 + u * 64 + lane;
-                const double pc = lo_f64(g0[u]) + beta * hi_f64(g0[u]);             // = p_k[c], cg.py:83
-                if (e < s1) st_prod[e - s0] = a0[u] * pc;
+                const double pc = lo_f64(sg[0][u]) + beta * hi_f64(sg[0][u]);       // = p_k[c], cg.py:83
+                if (e < s1) st_prod[e - s0] = sa[0][u] * pc;
             }
-            if (k1 != k0) {                                       // the run is complete: every lane adds its row, in column order
+            if (gk[1] != k0) {                                    // the run is complete: every lane adds its row, in column order
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const int rs = st_rs[k0 * kChipThreads + t], len = st_len[k0 * kChipThreads + t];
@@ -290,12 +319,20 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();                  // (the next run's products overwrite these)
             }
+            // the ring turns
 #pragma unroll
-            for (int u = 0; u < U; ++u) { a0[u] = a1[u]; a1[u] = a2[u]; c1[u] = c2[u]; g0[u] = g1[u]; }
-            k0 = k1; e0 = e1;
-            k1 = k2; e1 = e2;
-            next_group(k1, e1, k2, e2);
+            for (int j = 0; j < SND; ++j) {
+                gk[j] = gk[j + 1]; ge[j] = ge[j + 1];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) { sc[j][u] = sc[j + 1][u]; sa[j][u] = sa[j + 1][u]; }
+            }
+#pragma unroll
+            for (int j = 0; j < SNG; ++j)
+#pragma unroll
+                for (int u = 0; u < SU; ++u) sg[j][u] = sg[j + 1][u];
+            st_next(gk[SND - 1], ge[SND - 1], gk[SND], ge[SND]);
         }
+        st_prefetch();                                            // (for the next product: in flight through the exchanges)
     };
 
     // Two chip-wide sums at once, and a chip barrier in the same breath (see the header).  `publish`: the workgroup's granule stores
