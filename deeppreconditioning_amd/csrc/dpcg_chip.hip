@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
             const int first = f0 < wg_hi ? f0 : wg_hi, last = first + 64 < wg_hi ? first + 64 : wg_hi;
             const int q0 = d.rp[first], q1 = d.rp[last];
             if ((t & 63) == 0) { st_run[2 * k] = q0; st_run[2 * k + 1] = q1; }
-            st_rs[k * kChipThreads + t] = rs_k[k] - q0;
+            st_rs[k * kChipThreads + t] = len_k[k] > 0 ? rs_k[k] - q0 : 0;
             st_len[k * kChipThreads + t] = len_k[k];
         }
         if ((t & 63) == 0) { st_run[2 * RPT] = 0; st_run[2 * RPT + 1] = 0; }
@@ -219,35 +219,41 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         __builtin_amdgcn_wave_barrier();
     }
     // A wave's groups of 64 SU entries pass through a ring: the col / val of a group are fetched SNF iterations before its granules are
-    // gathered, the granules SNG iterations before its products are parked -- at ~0.5 us an iteration that is the two memory round
-    // trips of a group, so a wave that has its data never waits; the first SNF groups of the NEXT update are fetched when this one's
-    // product ends (the matrix does not change) and ride through the exchanges in registers: the pipeline is filled once per solve.
-    constexpr int SU = 3, SNG = 2, SNF = 3, SND = SNG + SNF;
+    // gathered, the granules SNG iterations before its products are parked; the first SNF groups of the NEXT update are fetched when this
+    // one's product ends (the matrix does not change) and ride through the exchanges in registers.  The list of a wave's groups is the
+    // same every update: it is written to LDS once (st_grp: slot | last group of its run << 8, first entry, the run's bounds).
+    constexpr int SU = 3, SNG = 1, SNF = 2, SND = SNG + SNF;
     int sc[SND + 1][SU];
     double sa[SND + 1][SU];
-    auto st_r0 = [&](int k) { return __builtin_amdgcn_readfirstlane(st_run[2 * k]); };          // (k <= RPT: the last pair is an empty run)
-    auto st_r1 = [&](int k) { return __builtin_amdgcn_readfirstlane(st_run[2 * k + 1]); };
-    // the groups of the wave, one after another: (slot, first entry); slot = RPT: no more
-    auto st_next = [&](int k, int e, int &nk, int &ne) {
-        nk = k;
-        ne = e + SU * 64;
-        if (k >= RPT || ne >= st_r1(k)) {
-            nk = k < RPT ? k + 1 : RPT;
-            while (nk < RPT && st_r1(nk) <= st_r0(nk)) ++nk;
-            ne = nk < RPT ? st_r0(nk) : 0;
+    int4 *const st_grp = reinterpret_cast<int4 *>(st_run + 2 * (RPT + 1) * (kChipThreads / 64 - (t >> 6))) + (t >> 6) * kChipStreamGroups;
+    int n_grp = 0;
+    if (STREAM) {
+        if ((t & 63) == 0) {                                      // (once per solve: a few dozen groups a wave)
+            int g = 0;
+            for (int k = 0; k < RPT; ++k) {
+                const int s0 = st_run[2 * k], s1 = st_run[2 * k + 1];
+                for (int e = s0; e < s1 && g < kChipStreamGroups; e += SU * 64) {
+                    const int last = e + SU * 64 >= s1 ? 1 : 0;
+                    st_grp[g++] = make_int4(k | last << 8, e, s0, s1);
+                }
+            }
+            st_run[2 * RPT] = g;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        n_grp = __builtin_amdgcn_readfirstlane(st_run[2 * RPT]);
+    }
+    auto st_desc = [&](int g) -> int4 {                           // group g of this wave (beyond the last: an empty one)
+        int4 dd = make_int4(RPT, 0, 0, 0);
+        if (g < n_grp) dd = st_grp[g];
+        return make_int4(__builtin_amdgcn_readfirstlane(dd.x), __builtin_amdgcn_readfirstlane(dd.y), __builtin_amdgcn_readfirstlane(dd.z),
+                         __builtin_amdgcn_readfirstlane(dd.w));
     };
-    auto st_first = [&](int &k, int &e) {
-        k = 0;
-        while (k < RPT && st_r1(k) <= st_r0(k)) ++k;
-        e = k < RPT ? st_r0(k) : 0;
-    };
-    auto st_fetch = [&](int k, int eb, int (&cc)[SU], double (&aa)[SU]) {
-        if (k >= RPT) return;
-        const int s0 = st_r0(k), s1 = st_r1(k), lane = t & 63;
+    auto st_fetch = [&](const int4 dd, int (&cc)[SU], double (&aa)[SU]) {
+        const int eb = dd.y, s0 = dd.z, s1 = dd.w, lane = t & 63;
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
-            if (eb + u * 64 >= s1) continue;                      // (the whole chunk lies beyond the run: the same for every lane)
+            if (eb + u * 64 >= s1) continue;                      // (the whole chunk lies beyond the run -- or there is no group: the same for every lane)
             const int e = eb + u * 64 + lane;
             const int ec = e < s1 ? e : s0;
             cc[u] = __builtin_amdgcn_raw_buffer_load_b32(ci_rs, ec * 4, 0, 0);
@@ -256,15 +262,8 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         }
     };
     auto st_prefetch = [&]() {                                    // the first SNF groups: before the first product, and behind every product
-        int k, e;
-        st_first(k, e);
 #pragma unroll
-        for (int j = 0; j < SNF; ++j) {
-            st_fetch(k, e, sc[j], sa[j]);
-            int nk, ne;
-            st_next(k, e, nk, ne);
-            k = nk; e = ne;
-        }
+        for (int j = 0; j < SNF; ++j) st_fetch(st_desc(j), sc[j], sa[j]);
     };
     if (STREAM) {
 #pragma unroll
@@ -286,33 +285,37 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
                 gg[u] = __builtin_amdgcn_raw_buffer_load_b128(zp_rs, cc[u] * 16 + (own ? local_shift : remote_base), 0, kSc1);
             }
         };
-        // descriptors of the groups i .. i + SND (stage j = group i + j); stages 0 .. SNF - 1 arrive fetched
-        int gk[SND + 1], ge[SND + 1];
-        st_first(gk[0], ge[0]);
+        // stage j = group i + j; stages 0 .. SNF - 1 arrive fetched
+        int4 dg[SND + 1];
 #pragma unroll
-        for (int j = 1; j <= SND; ++j) st_next(gk[j - 1], ge[j - 1], gk[j], ge[j]);
+        for (int j = 0; j <= SND; ++j) dg[j] = st_desc(j);
 #pragma unroll
-        for (int j = SNF; j < SND; ++j) st_fetch(gk[j], ge[j], sc[j], sa[j]);
+        for (int j = SNF; j < SND; ++j) st_fetch(dg[j], sc[j], sa[j]);
 #pragma unroll
         for (int j = 0; j < SNG; ++j)
-            if (gk[j] < RPT) gather(sc[j], sg[j]);
-        while (gk[0] < RPT) {
-            st_fetch(gk[SND], ge[SND], sc[SND], sa[SND]);
-            if (gk[SNG] < RPT) gather(sc[SNG], sg[SNG]);
-            const int k0 = gk[0], e0 = ge[0];
-            const int s0 = st_r0(k0), s1 = st_r1(k0);
+            if (j < n_grp) gather(sc[j], sg[j]);
+        for (int i = 0; i < n_grp; ++i) {
+            const int4 dnew = st_desc(i + SND + 1);               // (asked for now, wanted when the ring turns)
+            st_fetch(dg[SND], sc[SND], sa[SND]);
+            if (i + SNG < n_grp) gather(sc[SNG], sg[SNG]);
+            const int k0 = dg[0].x & 0xff, e0 = dg[0].y, s0 = dg[0].z, s1 = dg[0].w;
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
                 const int e = e0 + u * 64 + lane;
                 const double pc = lo_f64(sg[0][u]) + beta * hi_f64(sg[0][u]);       // = p_k[c], cg.py:83
                 if (e < s1) st_prod[e - s0] = sa[0][u] * pc;
             }
-            if (gk[1] != k0) {                                    // the run is complete: every lane adds its row, in column order
+            if (dg[0].x >> 8) {                                   // the run is complete: every lane adds its row, in column order
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const int rs = st_rs[k0 * kChipThreads + t], len = st_len[k0 * kChipThreads + t];
+                double pv[8];                                     // (eight reads in flight, then the sum in order; longer rows go on one by one)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[j] = st_prod[rs + (j < len ? j : 0)];
                 double acc = 0.0;
-                for (int j = 0; j < len; ++j) acc += st_prod[rs + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = j < len ? acc + pv[j] : acc;
+                for (int j = 8; j < len; ++j) acc += st_prod[rs + j];
 #pragma unroll
                 for (int kk = 0; kk < RPT; ++kk)
                     if (kk == k0) q[kk] = acc;
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
             // the ring turns
 #pragma unroll
             for (int j = 0; j < SND; ++j) {
-                gk[j] = gk[j + 1]; ge[j] = ge[j + 1];
+                dg[j] = dg[j + 1];
 #pragma unroll
                 for (int u = 0; u < SU; ++u) { sc[j][u] = sc[j + 1][u]; sa[j][u] = sa[j + 1][u]; }
             }
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
             for (int j = 0; j < SNG; ++j)
 #pragma unroll
                 for (int u = 0; u < SU; ++u) sg[j][u] = sg[j + 1][u];
-            st_next(gk[SND - 1], ge[SND - 1], gk[SND], ge[SND]);
+            dg[SND] = dnew;
         }
         st_prefetch();                                            // (for the next product: in flight through the exchanges)
     };
@@ -532,8 +535,8 @@ int chip_launch(const ChipDesc &d, hipStream_t s, bool check_only) {
     constexpr int NLDS = NS < kChipLdsSlots ? NS : kChipLdsSlots;
     // (MODE 5: the product buffer of one slot, the rows' offsets and lengths, the bounds of the runs; the attribute and the occupancy
     // are those of the largest buffer the form admits)
-    const int lds_max5 = chip_stream_max_row_len() * kChipThreads * (int)sizeof(double) + RPT * kChipThreads * 8 + 1024;
-    const int lds = MODE == 5 ? (kChipThreads / 64) * d.stream_cap * (int)sizeof(double) + RPT * kChipThreads * 8 + 1024 : NLDS * kChipThreads * (int)sizeof(double);
+    const int lds_max5 = chip_stream_max_row_len() * kChipThreads * (int)sizeof(double) + RPT * kChipThreads * 8 + 1024 + (kChipThreads / 64) * kChipStreamGroups * 16;
+    const int lds = MODE == 5 ? (kChipThreads / 64) * d.stream_cap * (int)sizeof(double) + RPT * kChipThreads * 8 + 1024 + (kChipThreads / 64) * kChipStreamGroups * 16 : NLDS * kChipThreads * (int)sizeof(double);
     const int lds_attr = MODE == 5 ? lds_max5 : lds;
     static int resident = -1;              // workgroups the occupancy query admits per CU (once per instantiation)
     if (resident < 0) {
@@ -578,7 +581,7 @@ int launch_occupy(int workgroups, double ms, hipStream_t s) {
 int chip_max_rows() { return kChipWGs * kChipThreads * kChipMaxRpt; }
 // rows of up to 9 entries (unstructured meshes) while a thread holds at most four rows (524 288 rows), 7 beyond
 int chip_max_row_len(int64_t n) { return n <= (int64_t)kChipWGs * kChipThreads * 4 ? 9 : 7; }
-int chip_stream_max_row_len() { return 30; }      // 30 x 512 x 8 B = 123 KB of products + 33 KB of row tables (8 rows a thread) of the 160 KB
+int chip_stream_max_row_len() { return 24; }      // 24 x 512 x 8 B = 98 KB of products + 33 KB of row tables (8 rows a thread) + 8 KB of group lists
 int chip_max_band() { return 32767; }
 int chip_workgroups() { return kChipWGs; }
 int chip_threads() { return kChipThreads; }

@@ -21,6 +21,7 @@ constexpr int kSc1 = 16;                // cache-policy operand of the buffer bu
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kChipStreamGroups = 64;      // groups of 192 entries a wave walks per update in the streamed form (8 slots x 64 rows x 24 entries / 192)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t chip_rsrc(const void *p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);

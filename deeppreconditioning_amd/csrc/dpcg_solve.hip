@@ -695,15 +695,14 @@ static bool chip_eligible(const dpcg_system *h, int flags, const double *x_true)
     if (h->precond != DPCG_PRECOND_NONE && h->precond != DPCG_PRECOND_JACOBI) return false;
     if (chip_resident_shape(h)) return true;
     // rows too long or columns too far for the resident form: the same kernel with the matrix streamed (dpcg_chip.hip MODE 5) -- fp64,
-    // 524 289 rows and more (below, the launches' x-tile SpMV has the L2 to itself), rows of at most 12 entries by default: measured on the
-    // 1M-row meshes (profiles/r05_chip_stream_probe.txt) 24.6-26.3 us an update against 28.4-28.5 for the launches on the quadtree
-    // meshes (rows of up to 9), but 35.2 against 31.2 on the Delaunay graph (rows of up to 21: half-empty groups).
-    // DPCG_CHIP_STREAM=0: never; 1: from 65 537 rows and for rows of up to 30 entries (development / tests)
+    // 524 289 rows and more (below, the launches' x-tile SpMV has the L2 to itself), rows of up to 24 entries.  Measured on the 1M-row
+    // meshes (profiles/r05_chip_stream_probe.txt): 22.1-23.3 us an update against 28.4-28.6 for the launches on the quadtree meshes
+    // (rows of up to 9), 28.1 against 31.4 on the Delaunay graph (rows of up to 21).
+    // DPCG_CHIP_STREAM=0: never; 1: from 65 537 rows (development / tests)
     const char *e = getenv("DPCG_CHIP_STREAM");
     if (e && e[0] == '0') return false;
-    const bool wide = e && e[0] == '1';
-    const int64_t from = wide ? 0 : (int64_t)chip_workgroups() * chip_threads() * 4;
-    return h->A.n > from && h->planA.max_row_len <= (wide ? chip_stream_max_row_len() : 12) && !(flags & DPCG_SPMV_F32);
+    const int64_t from = (e && e[0] == '1') ? 0 : (int64_t)chip_workgroups() * chip_threads() * 4;
+    return h->A.n > from && h->planA.max_row_len <= chip_stream_max_row_len() && !(flags & DPCG_SPMV_F32);
 }
 // a plain call takes it (DPCG_NO_SMALL = "no whole-solve kernel for one system" keeps the launches, as for the other two)
 static bool chip_default(const dpcg_system *h, int flags) {
