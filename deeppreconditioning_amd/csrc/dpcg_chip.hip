@@ -222,7 +222,13 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     // gathered, the granules SNG iterations before its products are parked; the first SNF groups of the NEXT update are fetched when this
     // one's product ends (the matrix does not change) and ride through the exchanges in registers.  The list of a wave's groups is the
     // same every update: it is written to LDS once (st_grp: slot | last group of its run << 8, first entry, the run's bounds).
-    constexpr int SU = 3, SNG = 1, SNF = 2, SND = SNG + SNF;
+#ifndef DPCG_STREAM_SU             // (development: A/B builds of the ring's geometry)
+#define DPCG_STREAM_SU 3
+#endif
+#ifndef DPCG_STREAM_SNF
+#define DPCG_STREAM_SNF 2
+#endif
+    constexpr int SU = DPCG_STREAM_SU, SNG = 1, SNF = DPCG_STREAM_SNF, SND = SNG + SNF;
     int sc[SND + 1][SU];
     double sa[SND + 1][SU];
     int4 *const st_grp = reinterpret_cast<int4 *>(st_run + 2 * (RPT + 1) * (kChipThreads / 64 - (t >> 6))) + (t >> 6) * kChipStreamGroups;
