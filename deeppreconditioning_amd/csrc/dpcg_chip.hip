@@ -61,10 +61,8 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     constexpr bool F32 = MODE == 4;
     // MODE 5: the matrix is NOT resident -- rows too long (or columns too far) for the slots above: a 1M-row finite-volume mesh with
     // rows of 9, a Delaunay graph with rows of 21.  Same skeleton (vectors in registers, published granules, two exchanges an update),
-    // but q = A p streams the workgroup's CSR segment every update the way the CSR-stream SpMV does: the 512 rows of a slot are 512
-    // CONSECUTIVE rows, their entries one contiguous run of col / val; lane t takes entry e0 + t, gathers the granule of its column,
-    // parks value x p in LDS, and after a barrier thread t adds its row's products in column order -- the same sum.  WMAX = 1 here.
-    constexpr bool STREAM = MODE == 5;
+    // but q = A p streams the workgroup's CSR every update, wave by wave (see spmv_stream below).
+    constexpr bool STREAM = MODE == 5;                           // (WMAX then carries the ring's group size, see SU below)
     constexpr int NS = RPT * WMAX;                                   // entry slots of a thread
     constexpr int NLDS = NS < kChipLdsSlots ? NS : kChipLdsSlots;    // ... whose values live in LDS
     constexpr int NREG = NS - NLDS;                                  // ... and in registers (the first NREG slots)
@@ -222,13 +220,10 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     // gathered, the granules SNG iterations before its products are parked; the first SNF groups of the NEXT update are fetched when this
     // one's product ends (the matrix does not change) and ride through the exchanges in registers.  The list of a wave's groups is the
     // same every update: it is written to LDS once (st_grp: slot | last group of its run << 8, first entry, the run's bounds).
-#ifndef DPCG_STREAM_SU             // (development: A/B builds of the ring's geometry)
-#define DPCG_STREAM_SU 3
-#endif
-#ifndef DPCG_STREAM_SNF
-#define DPCG_STREAM_SNF 2
-#endif
-    constexpr int SU = DPCG_STREAM_SU, SNG = 1, SNF = DPCG_STREAM_SNF, SND = SNG + SNF;
+    // (the geometry of the ring by measurement on the 1M-row meshes, us per update for SU / SNF = 3/2, 4/1, 4/2, 5/1, 6/1: quadtree in region
+    // order 23.4 23.3 24.3 23.3 21.7, in RCM order 21.9 21.9 22.9 22.3 20.6, Delaunay 28.3 25.6 26.1 26.4 27.6 -- a run of 64 short rows
+    // in ONE group of 384, longer rows in groups of 256; the launcher passes SU as WMAX)
+    constexpr int SU = STREAM ? WMAX : 3, SNG = 1, SNF = 1, SND = SNG + SNF;
     int sc[SND + 1][SU];
     double sa[SND + 1][SU];
     int4 *const st_grp = reinterpret_cast<int4 *>(st_run + 2 * (RPT + 1) * (kChipThreads / 64 - (t >> 6))) + (t >> 6) * kChipStreamGroups;
@@ -610,11 +605,16 @@ int launch_pcg_chip(const ChipDesc &d, int max_row_len, hipStream_t s, bool chec
         if (max_row_len < 1 || max_row_len > chip_stream_max_row_len() || d.stream_cap < max_row_len * 64 || d.per < 1 ||
             d.per > kChipThreads * kChipMaxRpt || d.f32 || d.bench || d.dbg)
             return DPCG_ERR_INVALID;
-#define DPCG_CHIP_S(RPTV) (jac ? chip_launch<RPTV, 1, true, 5>(d, s, check_only) : chip_launch<RPTV, 1, false, 5>(d, s, check_only))
+        // entries of a lane per group (the kernel's SU, passed as WMAX): 6 where a run of 64 rows fits ONE group of 384 (<= 5.6 entries a
+        // row on average), else 4
+        const bool short_rows = (double)d.rp_nnz <= 5.6 * (double)d.n;
+#define DPCG_CHIP_S2(RPTV, SUV) (jac ? chip_launch<RPTV, SUV, true, 5>(d, s, check_only) : chip_launch<RPTV, SUV, false, 5>(d, s, check_only))
+#define DPCG_CHIP_S(RPTV) (short_rows ? DPCG_CHIP_S2(RPTV, 6) : DPCG_CHIP_S2(RPTV, 4))
         if (rpt <= 2) return DPCG_CHIP_S(2);
         if (rpt <= 4) return DPCG_CHIP_S(4);
         return DPCG_CHIP_S(8);
 #undef DPCG_CHIP_S
+#undef DPCG_CHIP_S2
     }
     if (max_row_len < 1 || max_row_len > (rpt <= 4 ? 9 : 7) || d.per < 1 || d.per > kChipThreads * kChipMaxRpt) return DPCG_ERR_INVALID;
     const int mode = d.bench == 3 ? 3 : (d.bench ? 2 : (d.dbg != nullptr ? 1 : (d.f32 ? 4 : 0)));

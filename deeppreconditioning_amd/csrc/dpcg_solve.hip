@@ -696,8 +696,8 @@ static bool chip_eligible(const dpcg_system *h, int flags, const double *x_true)
     if (chip_resident_shape(h)) return true;
     // rows too long or columns too far for the resident form: the same kernel with the matrix streamed (dpcg_chip.hip MODE 5) -- fp64,
     // 524 289 rows and more (below, the launches' x-tile SpMV has the L2 to itself), rows of up to 24 entries.  Measured on the 1M-row
-    // meshes (profiles/r05_chip_stream_probe.txt): 22.1-23.3 us an update against 28.4-28.6 for the launches on the quadtree meshes
-    // (rows of up to 9), 28.1 against 31.4 on the Delaunay graph (rows of up to 21).
+    // meshes (profiles/r05_chip_stream_probe.txt): 21.0-22.1 us an update against 28.8-28.9 for the launches on the quadtree meshes
+    // (rows of up to 9), 25.5 against 31.3 on the Delaunay graph (rows of up to 21).
     // DPCG_CHIP_STREAM=0: never; 1: from 65 537 rows (development / tests)
     const char *e = getenv("DPCG_CHIP_STREAM");
     if (e && e[0] == '0') return false;
