@@ -695,14 +695,12 @@ static bool chip_eligible(const dpcg_system *h, int flags, const double *x_true)
     if (h->precond != DPCG_PRECOND_NONE && h->precond != DPCG_PRECOND_JACOBI) return false;
     if (chip_resident_shape(h)) return true;
     // rows too long or columns too far for the resident form: the same kernel with the matrix streamed (dpcg_chip.hip MODE 5) -- fp64,
-    // 524 289 rows and more (below, the launches' x-tile SpMV has the L2 to itself), rows of up to 24 entries.  Measured on the 1M-row
-    // meshes (profiles/r05_chip_stream_probe.txt): 21.0-22.1 us an update against 28.8-28.9 for the launches on the quadtree meshes
-    // (rows of up to 9), 25.5 against 31.3 on the Delaunay graph (rows of up to 21).
-    // DPCG_CHIP_STREAM=0: never; 1: from 65 537 rows (development / tests)
+    // rows of up to 24 entries.  Measured against the launches, us per update (profiles/r05_chip_stream_probe.txt): 1M-row quadtree meshes
+    // (rows of up to 9) 21.0-22.1 / 28.8-28.9, Delaunay graphs (rows of up to 21) of 1M rows 25.5 / 31.3, 500K 14.3 / 21.7, 250K 8.9 / 17.9,
+    // 100K 6.8 / 12.6.  DPCG_CHIP_STREAM=0: never (development)
     const char *e = getenv("DPCG_CHIP_STREAM");
     if (e && e[0] == '0') return false;
-    const int64_t from = (e && e[0] == '1') ? 0 : (int64_t)chip_workgroups() * chip_threads() * 4;
-    return h->A.n > from && h->planA.max_row_len <= chip_stream_max_row_len() && !(flags & DPCG_SPMV_F32);
+    return h->planA.max_row_len <= chip_stream_max_row_len() && !(flags & DPCG_SPMV_F32);
 }
 // a plain call takes it (DPCG_NO_SMALL = "no whole-solve kernel for one system" keeps the launches, as for the other two)
 static bool chip_default(const dpcg_system *h, int flags) {

@@ -2912,8 +2912,8 @@ def test_chip_solve_mixed_precision_equals_the_oracle_bit_for_bit(D, name, make,
     ("quadtree_random_1000", lambda: O.quadtree_fv_laplacian(1000, 0, numbering="random"), 150, None),   # 1M rows of up to 9 entries, in RCM order
     ("quadtree_foam_1000", lambda: O.quadtree_fv_laplacian(1000, 0), 150, None),      # OpenFOAM's numbering, region by region: no band -- every granule written through
     ("delaunay_1M", lambda: O.delaunay_laplacian(1000000, 0), 150, None),              # rows of up to 21 entries
-    ("delaunay_100K", lambda: O.delaunay_laplacian(100000, 3), 400, "1"),              # 2 rows a thread (DPCG_CHIP_STREAM=1: from 65 537 rows)
-    ("quadtree_random_600", lambda: O.quadtree_fv_laplacian(600, 2, numbering="random"), 300, "1")])   # (373K rows of up to 9 entries: the resident form takes it -- the knob must not change that)
+    ("delaunay_100K", lambda: O.delaunay_laplacian(100000, 3), 400, None),             # 2 rows a thread
+    ("quadtree_random_600", lambda: O.quadtree_fv_laplacian(600, 2, numbering="random"), 300, None)])   # (373K rows of up to 9 entries: the resident form takes it)
 def test_chip_stream_solve_equals_the_device_tree_oracle_bit_for_bit(D, monkeypatch, name, make, max_iter, env):
     """The one-launch kernel with the matrix STREAMED (k_pcg_chip MODE 5): 1M-row meshes whose rows are too long (9, 21 entries) or
     whose columns reach too far for the resident form keep the vectors in registers and exchange through the granules, and stream
