@@ -672,7 +672,8 @@ static int solve_team_one(dpcg_system *h, const double *b, const double *x0, dou
 // ------------------------------------------------------------------------------------------------
 // cache-sized systems: the whole solve in one launch, the whole chip as one team (dpcg_chip.hip)
 // ------------------------------------------------------------------------------------------------
-// 65 537 .. 1 048 576 rows, rows of <= 7 entries, half-bandwidth < 32 768 (stencils; meshes after the library's RCM), M = I / Jacobi:
+// 65 537 .. 1 048 576 rows, M = I / Jacobi; rows of <= 7 entries (9 up to 524 288 rows), half-bandwidth < 32 768 (stencils; meshes after the
+// library's RCM): matrix and vectors resident -- otherwise, rows of up to 24 entries: the vectors resident, the matrix streamed;
 // matrix and vectors stay in registers and LDS for the whole solve.  DPCG_CHIP=0 / DPCG_CHIP_MIN_ROWS: development knobs.
 // the resident form: every row in the slots of its thread, every column within the 16-bit reach of its row
 static bool chip_resident_shape(const dpcg_system *h) {

@@ -2670,10 +2670,10 @@ def test_spmv_tile_plan_with_blocks_that_gather(D, monkeypatch):
     assert np.array_equal(S.spmv_f32(_dev(x.astype(np.float32))).cpu().numpy(), CO.spmv_mixed(A, x).astype(np.float32))
     S.set_preconditioner(D.Jacobi())
     b = O.rhs(n, 0)
-    res = S.solve(_dev(b), max_iter=200)
+    res = S.solve(_dev(b), max_iter=200, flags=D._lib.NO_SMALL)          # (the launches: a plain call streams this matrix in the one-launch kernel)
     _, it, hist, xo = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A), max_iter=200, device_tree=S.reduction_geometry())
     assert res.iterations == it and np.array_equal(res.res_history, hist) and np.array_equal(res.x.cpu().numpy(), xo)
-    mixed = S.solve(_dev(b), max_iter=200, flags=D._lib.SPMV_F32)
+    mixed = S.solve(_dev(b), max_iter=200, flags=D._lib.SPMV_F32 | D._lib.NO_SMALL)
     _, itm, hm, _ = CO.pcg(A, b, "jacobi", dinv=O.jacobi_dinv(A), max_iter=200, mixed=True, device_tree=S.reduction_geometry())
     assert mixed.iterations == itm and np.array_equal(mixed.res_history, hm)
     S.close()
@@ -2952,7 +2952,8 @@ def test_chip_stream_solve_equals_the_device_tree_oracle_bit_for_bit(D, monkeypa
 
 def test_chip_solve_arguments_and_edges(D):
     """x0 (cg.py:58-60), caps, both first tests (cg.py:66 / scipy's), b = 0, and what keeps a system OFF the chip kernel: the flags of
-    the other forms, a preconditioner it does not fuse, rows of more than 7 entries, a bandwidth beyond 16-bit offsets."""
+    the other forms, a preconditioner it does not fuse, rows of more than 24 entries; a bandwidth beyond 16-bit offsets takes its
+    streamed form."""
     A = O.poisson3d(64)
     n = A.shape[0]
     b, x0 = O.rhs(n, 1), O.rhs(n, 7)
@@ -2985,7 +2986,7 @@ def test_chip_solve_arguments_and_edges(D):
     A9.sort_indices()
     S9 = D.CsrSystem.from_any(A9, reorder=None)
     S9.set_preconditioner(D.Jacobi())
-    assert S9.chip_info()["max_row_len"] > 7 and not S9.chip_info()["chip_eligible"]
+    assert S9.chip_info()["max_row_len"] == 25 and not S9.chip_info()["chip_eligible"]      # (the streamed form parks 64 x 24 products a wave)
     S9.close()
     P = O.poisson3d(48)                                 # 110 592 rows; one coupling 40 000 rows away: beyond 16-bit offsets
     m = P.shape[0]
@@ -2995,12 +2996,11 @@ def test_chip_solve_arguments_and_edges(D):
     Sw = D.CsrSystem.from_any(W, reorder=None)
     Sw.set_preconditioner(D.Jacobi())
     ciw = Sw.chip_info()
-    assert ciw["max_band"] == 40000 and not ciw["chip_eligible"]
+    assert ciw["max_band"] == 40000 and ciw["chip_by_default"]          # (no 16-bit offset reaches that far: the STREAMED form of the kernel)
     bw = O.rhs(m, 2)
     rw = Sw.solve(_dev(bw))
-    _, itw, histw, _ = CO.pcg(W, bw, "jacobi", dinv=O.jacobi_dinv(W))
-    assert rw.iterations == itw
-    np.testing.assert_allclose(rw.res_history, histw, rtol=HIST_RTOL)
+    _, itw, histw, xw = CO.pcg(W, bw, "jacobi", dinv=O.jacobi_dinv(W), device_tree=_chip_tree(Sw))
+    assert rw.iterations == itw and np.array_equal(rw.res_history, histw) and np.array_equal(rw.x.cpu().numpy(), xw)
     Sw.close()
 
 
