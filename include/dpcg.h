@@ -201,8 +201,10 @@ int dpcg_set_precond_callback(dpcg_handle_t h, dpcg_precond_fn fn, void *user);
  * blocks: 0 its slab by virtual block, 1 blocks b, b + G, ..., 2 the same by virtual block), out[15] = 1 when the first of them is the
  * lower solve's last launch --, 9 a tree the checker does not restate: more than 16 sweeps). */
 int dpcg_get_reduction_geometry(dpcg_handle_t h, int32_t out[16]);
-/* The whole-chip solve (dpcg_chip.hip: 65 537 .. 1 048 576 rows, rows of <= 7 entries, half-bandwidth < 32 768, M = I / Jacobi -- matrix
- * and vectors stay in registers and LDS for the whole solve, cg.py:58-90 in ONE launch of 256 workgroups).  out[0] = 1 when the
+/* The whole-chip solve (dpcg_chip.hip: 65 537 .. 1 048 576 rows, M = I / Jacobi, cg.py:58-90 in ONE launch of 256 workgroups -- rows of
+ * <= 7 entries (9 up to 524 288 rows) within 32 767 columns of the diagonal: matrix and vectors stay in registers and LDS for the whole
+ * solve; otherwise, rows of <= 24 entries: the vectors stay, the matrix is streamed every update; the same rows per thread and the same
+ * reduction trees either way).  out[0] = 1 when the
  * system with its CURRENT preconditioner is eligible (2: and a plain dpcg_solve takes that form), out[1] = workgroups (256),
  * out[2] = threads of each (512), out[3] = rows per workgroup (ceil(n / 256): workgroup v owns rows v * out[3] .., thread t of it
  * rows v * out[3] + t + 512 k -- what a checker needs to add the dot products in the kernel's order), out[4] = longest row,
