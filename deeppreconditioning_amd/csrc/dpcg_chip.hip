@@ -58,11 +58,11 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     // MODE 4: BASELINE config 5 -- `A @ pk` (cg.py:75) with the matrix values and pk STORED in fp32, products and sums in fp64 (the
     // contract of DPCG_SPMV_F32: the CPU restatement's mixed product).  The values are rounded once, where they are read; a gathered p is
     // rounded where it is recomputed.  Everything else is the fp64 arithmetic of MODE 0 (x0 = 0 only: cg.py:60 reads the fp64 A).
-    constexpr bool F32 = MODE == 4;
+    constexpr bool F32 = MODE == 4 || MODE == 6;                      // (6: the streamed form with fp32-stored operands)
     // MODE 5: the matrix is NOT resident -- rows too long (or columns too far) for the slots above: a 1M-row finite-volume mesh with
     // rows of 9, a Delaunay graph with rows of 21.  Same skeleton (vectors in registers, published granules, two exchanges an update),
     // but q = A p streams the workgroup's CSR every update, wave by wave (see spmv_stream below).
-    constexpr bool STREAM = MODE == 5;                           // (WMAX then carries the ring's group size, see SU below)
+    constexpr bool STREAM = MODE == 5 || MODE == 6;                           // (WMAX then carries the ring's group size, see SU below)
     constexpr int NS = RPT * WMAX;                                   // entry slots of a thread
     constexpr int NLDS = NS < kChipLdsSlots ? NS : kChipLdsSlots;    // ... whose values live in LDS
     constexpr int NREG = NS - NLDS;                                  // ... and in registers (the first NREG slots)
@@ -303,8 +303,9 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
                 const int e = e0 + u * 64 + lane;
-                const double pc = lo_f64(sg[0][u]) + beta * hi_f64(sg[0][u]);       // = p_k[c], cg.py:83
-                if (e < s1) st_prod[e - s0] = sa[0][u] * pc;
+                const double pc64 = lo_f64(sg[0][u]) + beta * hi_f64(sg[0][u]);     // = p_k[c], cg.py:83
+                const double pc = F32 ? (double)(float)pc64 : pc64, av = F32 ? (double)(float)sa[0][u] : sa[0][u];
+                if (e < s1) st_prod[e - s0] = av * pc;
             }
             if (dg[0].x >> 8) {                                   // the run is complete: every lane adds its row, in column order
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -537,8 +538,8 @@ int chip_launch(const ChipDesc &d, hipStream_t s, bool check_only) {
     // (MODE 5: the product buffer of one slot, the rows' offsets and lengths, the bounds of the runs; the attribute and the occupancy
     // are those of the largest buffer the form admits)
     const int lds_max5 = chip_stream_max_row_len() * kChipThreads * (int)sizeof(double) + RPT * kChipThreads * 8 + 1024 + (kChipThreads / 64) * kChipStreamGroups * 16;
-    const int lds = MODE == 5 ? (kChipThreads / 64) * d.stream_cap * (int)sizeof(double) + RPT * kChipThreads * 8 + 1024 + (kChipThreads / 64) * kChipStreamGroups * 16 : NLDS * kChipThreads * (int)sizeof(double);
-    const int lds_attr = MODE == 5 ? lds_max5 : lds;
+    const int lds = (MODE == 5 || MODE == 6) ? (kChipThreads / 64) * d.stream_cap * (int)sizeof(double) + RPT * kChipThreads * 8 + 1024 + (kChipThreads / 64) * kChipStreamGroups * 16 : NLDS * kChipThreads * (int)sizeof(double);
+    const int lds_attr = (MODE == 5 || MODE == 6) ? lds_max5 : lds;
     static int resident = -1;              // workgroups the occupancy query admits per CU (once per instantiation)
     if (resident < 0) {
         if (hipFuncSetAttribute((const void *)k_pcg_chip<RPT, WMAX, JAC, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr) != hipSuccess)
@@ -603,18 +604,20 @@ int launch_pcg_chip(const ChipDesc &d, int max_row_len, hipStream_t s, bool chec
     const bool jac = d.precond == DPCG_PRECOND_JACOBI;
     if (d.stream_cap > 0) {                // the streamed form (MODE 5)
         if (max_row_len < 1 || max_row_len > chip_stream_max_row_len() || d.stream_cap < max_row_len * 64 || d.per < 1 ||
-            d.per > kChipThreads * kChipMaxRpt || d.f32 || d.bench || d.dbg)
+            d.per > kChipThreads * kChipMaxRpt || d.bench || d.dbg || (d.f32 && d.x0))
             return DPCG_ERR_INVALID;
         // entries of a lane per group (the kernel's SU, passed as WMAX): 6 where a run of 64 rows fits ONE group of 384 (<= 5.6 entries a
         // row on average), else 4
         const bool short_rows = (double)d.rp_nnz <= 5.6 * (double)d.n;
-#define DPCG_CHIP_S2(RPTV, SUV) (jac ? chip_launch<RPTV, SUV, true, 5>(d, s, check_only) : chip_launch<RPTV, SUV, false, 5>(d, s, check_only))
+#define DPCG_CHIP_S3(RPTV, SUV, MV) (jac ? chip_launch<RPTV, SUV, true, MV>(d, s, check_only) : chip_launch<RPTV, SUV, false, MV>(d, s, check_only))
+#define DPCG_CHIP_S2(RPTV, SUV) (d.f32 ? DPCG_CHIP_S3(RPTV, SUV, 6) : DPCG_CHIP_S3(RPTV, SUV, 5))
 #define DPCG_CHIP_S(RPTV) (short_rows ? DPCG_CHIP_S2(RPTV, 6) : DPCG_CHIP_S2(RPTV, 4))
         if (rpt <= 2) return DPCG_CHIP_S(2);
         if (rpt <= 4) return DPCG_CHIP_S(4);
         return DPCG_CHIP_S(8);
 #undef DPCG_CHIP_S
 #undef DPCG_CHIP_S2
+#undef DPCG_CHIP_S3
     }
     if (max_row_len < 1 || max_row_len > (rpt <= 4 ? 9 : 7) || d.per < 1 || d.per > kChipThreads * kChipMaxRpt) return DPCG_ERR_INVALID;
     const int mode = d.bench == 3 ? 3 : (d.bench ? 2 : (d.dbg != nullptr ? 1 : (d.f32 ? 4 : 0)));

@@ -701,7 +701,7 @@ static bool chip_eligible(const dpcg_system *h, int flags, const double *x_true)
     // 100K 6.8 / 12.6.  DPCG_CHIP_STREAM=0: never (development)
     const char *e = getenv("DPCG_CHIP_STREAM");
     if (e && e[0] == '0') return false;
-    return h->planA.max_row_len <= chip_stream_max_row_len() && !(flags & DPCG_SPMV_F32);
+    return h->planA.max_row_len <= chip_stream_max_row_len();
 }
 // a plain call takes it (DPCG_NO_SMALL = "no whole-solve kernel for one system" keeps the launches, as for the other two)
 static bool chip_default(const dpcg_system *h, int flags) {
@@ -751,7 +751,7 @@ static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, dou
     { const char *e = getenv("DPCG_CHIP_BENCH"); d.bench = e ? atoi(e) : 0; }
     static const bool trace = [] { const char *e = getenv("DPCG_CHIP_TRACE"); return e && e[0] == '1'; }();
     if (d.f32 && (d.bench || trace || x0)) return DPCG_ERR_STATE;                      // (the caller goes on with the launches)
-    if (d.stream_cap > 0 && (d.bench || trace || d.f32)) return DPCG_ERR_STATE;
+    if (d.stream_cap > 0 && (d.bench || trace)) return DPCG_ERR_STATE;
     static const bool plain_ok = [] { const char *e = getenv("DPCG_CHIP_LOCAL"); return !(e && e[0] == '0'); }();   // development: 0 = everything written through
     d.xcc = plain_ok ? reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256 + 2) : nullptr;
     d.dbg = trace ? reinterpret_cast<unsigned long long *>(h->chip_part + kSlots) : nullptr;

@@ -2872,7 +2872,8 @@ def test_chip_solve_equals_the_device_tree_oracle_bit_for_bit(D, name, make, max
 @pytest.mark.parametrize("name,make,max_iter", [
     ("poisson3d_100", lambda: O.poisson3d(100), 1024),                                            # config 5's size on the headline grid
     ("unstructured3d_100", lambda: O.unstructured_like(O.poisson3d(100), seed=0), 1024),          # config 5 as bench.py runs it (reordered, D A D: values not fp32 numbers)
-    ("quadtree_random_400", lambda: O.quadtree_fv_laplacian(400, 5, numbering="random"), 300)])   # rows of up to 9 entries
+    ("quadtree_random_400", lambda: O.quadtree_fv_laplacian(400, 5, numbering="random"), 300),    # rows of up to 9 entries
+    ("quadtree_random_1000", lambda: O.quadtree_fv_laplacian(1000, 0, numbering="random"), 120)])  # ... at 1M rows: the STREAMED form (MODE 6)
 def test_chip_solve_mixed_precision_equals_the_oracle_bit_for_bit(D, name, make, max_iter):
     """BASELINE config 5 in the one-launch kernel (MODE 4 of k_pcg_chip): `A @ pk` with the matrix values and the gathered pk stored
     in fp32, products and sums in fp64, everything else fp64 -- orc_pcg_mixed with the chip kernel's reduction tree: history, count
