@@ -210,8 +210,7 @@ for case in range(cases):
                     chip_hist = CO.pcg(B, bo, kind, x0=x0o, device_tree=ctree, **(dict(dinv=O.jacobi_dinv(B)) if kind == "jacobi" else {}))[1:3]
                 chip_seen[kind] = chip_seen.get(kind, 0) + 1
                 # ... and config 5 in the same kernel (MODE 4; without a start vector: cg.py:60 reads the fp64 matrix)
-                resident = ci["max_row_len"] <= (9 if n <= 524288 else 7) and ci["max_band"] <= 32767      # (the streamed form is fp64 only)
-                if kind in ("none", "jacobi") and x0_dev is None and resident:
+                if kind in ("none", "jacobi") and x0_dev is None:
                     mixed_ref = CO.pcg(B, bo, kind, mixed=True, device_tree=ctree, **(dict(dinv=O.jacobi_dinv(B)) if kind == "jacobi" else {}))[1:3]
                     rm = S.solve(torch.from_numpy(b).cuda(), None, flags=D._lib.SPMV_F32)
                     chip_seen[kind + "_mixed"] = chip_seen.get(kind + "_mixed", 0) + 1
