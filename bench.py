@@ -87,54 +87,111 @@ def time_apply(system, b, torch, reps: int = 20) -> float:
     return (time.perf_counter() - t0) / reps * 1e6
 
 
-def chip_roofline(system, b, check, k1: dict, traffic) -> dict:
-    """`roofline` object when the timed solve is the whole-chip kernel (dpcg_chip.hip: cg.py:58-90 in ONE launch, matrix and vectors
-    resident in LDS / registers).  `achieved` = ALGORITHMIC bytes of the launch -- updates x (B_spmv + 76 n), the accounting of the
-    multi-launch update it replaces -- over the kernel's duration between HIP events on its stream.  The bytes are
-    algorithmic: they are served on chip, so `frac` > 1 says that the solve no longer moves them, not that HBM got faster; `traffic`
-    (PMC) is what crossed the memory-side interface.  `spmv_phase`: the same kernel WITHOUT its gathers (development mode
-    DPCG_CHIP_BENCH: q = p, the loop runs the same number of updates) -- the difference is what q = A p costs per update."""
+L2_PEAK_GBS = 34500.0  # the eight 4 MiB L2s together, /opt/skills/guides/MI355X_MICROARCH.md "L2 (per XCD)" (36.9 TB/s with L1 reuse; sc1 gathers bypass the L1)
+
+
+def l2_gather_ceiling(system, offsets) -> dict:
+    """What the chip delivers for the access the whole-chip kernel's SpMV phase makes, with nothing else going on (dpcg_debug_l2_gather: the
+    same 256 x 512 geometry and placement, a table of n / 8 sixteen-byte granules per XCD stored plainly by that XCD's workgroups, every
+    thread gathering 8 x 7 granules per pass at the system's own column offsets with agent-scope loads): GB/s of gathered bytes with two rows'
+    gathers in flight per lane (what the solve kernel's registers hold) and with four, and with the table written through (every gather
+    then leaves the L2 for the memory side: what the cross-XCD copy costs)."""
+    import ctypes as C
+    from deeppreconditioning_amd import _lib as L
+    per_group = max(((system.n // 8) // 32) * 32, 32 * 512)
+    offs = (C.c_int32 * 7)(*[int(o) for o in offsets])
+    out = {"granules_per_xcd": per_group, "table_bytes_per_xcd": per_group * 16, "offsets_in_granules": [int(o) for o in offsets],
+           "bytes_per_pass": 256 * 512 * 8 * 7 * 16}
+    for key, depth, wt in (("plain_depth2", 2, 0), ("plain_depth4", 4, 0), ("written_through_depth2", 2, 1)):
+        best = 0.0
+        for _ in range(3):
+            gbs, us, loc = C.c_double(), C.c_double(), C.c_int()
+            L.check(L.lib().dpcg_debug_l2_gather(per_group, 40 if wt else 200, offs, depth, wt, None, C.byref(gbs), C.byref(us), C.byref(loc)))
+            best = max(best, gbs.value)
+        out[key] = round(best, 1)
+        out["groups_on_one_xcd"] = bool(loc.value)
+    return out
+
+
+def chip_roofline(system, b, check, k1: dict, traffic, counters=None, offsets=None) -> dict:
+    """`roofline` object when the timed solve is the whole-chip kernel (dpcg_chip.hip: cg.py:58-90 in ONE launch, matrix and vectors resident
+    in LDS / registers).  The level that serves this kernel's bytes is the L2s, not HBM: per update every matrix entry gathers one 16-byte
+    granule {z, p} of its column (nnz x 16 B, agent-scope loads that hit the owner XCD's L2) and every row publishes one (n x 16 B).
+    `achieved` = those bytes x updates over the kernel's duration between HIP events on its stream; `peak` = the eight L2s together
+    (34.5 TB/s); `frac_of_measured_ceiling` = against the same gathers alone (`measured_l2_gather_gbs`, dpcg_debug_l2_gather), measured live.
+    `phases`: the kernel against its two development variants -- the gathers issued but out of range (no memory request; what is left is
+    instruction issue, DPCG_CHIP_BENCH=3) and no gathers at all (q = p; DPCG_CHIP_BENCH=1) -- all three between HIP events here and in
+    the committed rocprofv3 kernel trace (profiles/r06_chip_kernel_stats.csv).  `traffic`: what crossed the L2s' memory side (PMC)."""
     n, nnz = system.n, system.nnz
     its = check.iterations
     os.environ["DPCG_CHIP_EVENTS"] = "1"
+    times = {}
     try:
-        full = []
-        for _ in range(12):
-            r = system.solve(b, want_history=False)
-            assert r.iterations == its
-            full.append(system.chip_info()["kernel_ms"])
-        os.environ["DPCG_CHIP_BENCH"] = "1"
-        skip = []
-        for _ in range(12):
-            system.solve(b, max_iter=its, want_history=False)
-            skip.append(system.chip_info()["kernel_ms"])
+        for key, env in (("full", None), ("no_gathers", "1"), ("gathers_issued_out_of_range", "3")):
+            if env is None:
+                os.environ.pop("DPCG_CHIP_BENCH", None)
+            else:
+                os.environ["DPCG_CHIP_BENCH"] = env
+            v = []
+            for _ in range(12):
+                r = system.solve(b, max_iter=(1024 if env is None else its), want_history=False)
+                assert r.iterations == its
+                v.append(system.chip_info()["kernel_ms"])
+            times[key] = float(np.median(v[2:]))
     finally:
         os.environ.pop("DPCG_CHIP_EVENTS", None)
         os.environ.pop("DPCG_CHIP_BENCH", None)
-    ms_full, ms_skip = float(np.median(full[2:])), float(np.median(skip[2:]))
-    b_spmv = spmv_bytes(n, nnz)
-    b_upd = b_spmv + int(9.5 * 8 * n)
-    achieved = its * b_upd / (ms_full * 1e-3) / 1e9
+    ms_full, ms_skip, ms_issue = times["full"], times["no_gathers"], times["gathers_issued_out_of_range"]
+    gathered, published = 16 * nnz, 16 * n
+    b_l2 = gathered + published
     us_upd = ms_full * 1e3 / its
+    achieved = b_l2 / (us_upd * 1e-6) / 1e9
     us_spmv = max((ms_full - ms_skip) * 1e3 / its, 1e-3)
+    us_bytes = max((ms_full - ms_issue) * 1e3 / its, 1e-3)
+    # the system's own column offsets, in granules: what the ceiling probe gathers at
     ci = system.chip_info()
-    return {"bound": "hbm", "kernel": f"k_pcg_chip (the whole solve, cg.py:58-90, in one launch of {ci['workgroups']} workgroups x {ci['threads']} threads; "
-                                      f"{ci['rows_per_workgroup']} rows per workgroup, matrix and vectors resident in LDS / registers)",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "algorithmic_bytes_per_launch": its * b_upd, "algorithmic_bytes_per_update": b_upd,
-            "us_per_launch": round(ms_full * 1e3, 2), "updates_per_launch": its, "us_per_update": round(us_upd, 3),
-            "timing": "HIP events on the launch stream around the kernel (DPCG_CHIP_EVENTS), median of 10 launches",
-            "regime": "on_chip_resident: the algorithmic bytes of an update are served from LDS / registers (matrix, x, r, p, q) and the XCDs' "
-                      "L2 (the published granules); frac > 1 of the HBM peak means they no longer cross the memory interface -- `traffic` is "
-                      "what did.  The streaming SpMV kernel (systems beyond 1,048,576 rows, other preconditioners) is `streaming_spmv_kernel`; "
-                      "its HBM-bound figure is `hbm_bound_256cubed`",
-            "spmv_phase": {"us_per_update": round(us_spmv, 3), "achieved": round(b_spmv / (us_spmv * 1e-6) / 1e9, 1), "unit": "GB/s",
-                           "frac": round(b_spmv / (us_spmv * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": b_spmv,
-                           "us_per_update_without_gathers": round(ms_skip * 1e3 / its, 3),
-                           "method": "kernel time minus the same kernel without the gathers of q = A p (DPCG_CHIP_BENCH), per update"},
-            "streaming_spmv_kernel": {k: k1[k] for k in ("kernel", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch", "us_per_launch",
-                                                          "traffic_source", "frac_of_measured_ceiling") if k in k1},
-            "measured_stream_gbs": k1.get("measured_stream_gbs")}
+    offs = offsets if offsets is not None else [0] * 7
+    ceil = l2_gather_ceiling(system, offs)
+    ceil_best = max(ceil["plain_depth2"], ceil["plain_depth4"])
+    b_hbm = spmv_bytes(n, nnz) + int(9.5 * 8 * n)
+    out = {"bound": "l2", "kernel": f"k_pcg_chip (the whole solve, cg.py:58-90, in one launch of {ci['workgroups']} workgroups x {ci['threads']} threads; "
+                                    f"{ci['rows_per_workgroup']} rows per workgroup, matrix and vectors resident in LDS / registers, operands of q = A p "
+                                    f"gathered as 16-byte granules out of the XCDs' L2s)",
+           "achieved": round(achieved, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / L2_PEAK_GBS, 4),
+           "frac_of_measured_ceiling": round(achieved / ceil_best, 4), "measured_l2_gather_gbs": ceil,
+           "traffic": traffic, "traffic_level": "memory side of the L2s (PMC, profiles/r06_chip_traffic.md); L2-level request / hit counters: `l2_counters`",
+           "l2_counters": counters,
+           "l2_bytes_per_update": b_l2, "l2_bytes_per_launch": its * b_l2, "gathered_bytes_per_update": gathered, "published_bytes_per_update": published,
+           "us_per_launch": round(ms_full * 1e3, 2), "updates_per_launch": its, "us_per_update": round(us_upd, 3),
+           "timing": "HIP events on the launch stream around the kernel (DPCG_CHIP_EVENTS), median of 10 launches",
+           "phases": {"us_per_update": {"whole": round(us_upd, 3), "without_gathers": round(ms_skip * 1e3 / its, 3),
+                                        "gathers_issued_out_of_range": round(ms_issue * 1e3 / its, 3)},
+                      "spmv_phase": {"us_per_update": round(us_spmv, 3), "achieved": round(gathered / (us_spmv * 1e-6) / 1e9, 1), "unit": "GB/s",
+                                     "frac": round(gathered / (us_spmv * 1e-6) / 1e9 / L2_PEAK_GBS, 4),
+                                     "frac_of_measured_ceiling": round(gathered / (us_spmv * 1e-6) / 1e9 / ceil_best, 4),
+                                     "method": "kernel minus its variant without the gathers (q = p), per update: issue + bytes of q = A p"},
+                      "gathered_bytes_alone": {"us_per_update": round(us_bytes, 3), "achieved": round(gathered / (us_bytes * 1e-6) / 1e9, 1), "unit": "GB/s",
+                                               "frac": round(gathered / (us_bytes * 1e-6) / 1e9 / L2_PEAK_GBS, 4),
+                                               "method": "kernel minus its variant whose gathers are issued out of range (no memory request)"},
+                      "exchanges_and_updates_us": round(ms_skip * 1e3 / its, 3),
+                      "reading": "the update is latency-bound outside the gathers: two chip-wide exchanges (reduction + barrier, two hops each) and the "
+                                 "register updates move almost no bytes"},
+           "regime": "on_chip_resident: matrix, x, r, p, q, dinv live in LDS / registers for the whole solve; the only operands that move are the "
+                     "granules, XCD-locally through the L2s.  The HBM roofline applies to the kernels that stream from memory: `streaming_spmv_kernel` "
+                     "(systems beyond 1,048,576 rows, other preconditioners) and `hbm_bound_256cubed`",
+           "hbm_algorithmic_equivalent": {"bytes_per_update": b_hbm, "gbs": round(b_hbm / (us_upd * 1e-6) / 1e9, 1),
+                                          "note": "SURVEY.md 8-d3's bytes of the multi-launch update this kernel replaces (B_spmv + 76 n) over its time: "
+                                                  "they are served on chip, so this is NOT a fraction of anything -- kept for comparison across rounds"},
+           "streaming_spmv_kernel": {"bound": "hbm", **{k: k1[k] for k in ("kernel", "achieved", "peak", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                                                            "us_per_launch", "traffic_source", "frac_of_measured_ceiling") if k in k1}},
+           "measured_stream_gbs": k1.get("measured_stream_gbs")}
+    return out
+
+
+def stencil_offsets(dim: int, grid: int) -> list:
+    """Column offsets (col - row) of an interior row of the synthetic Poisson system, padded to 7: the pattern the L2 gather probe reads at."""
+    o = [-grid * grid, -grid, -1, 0, 1, grid, grid * grid] if dim == 3 else [-grid, -1, 0, 1, grid, 0, 0]
+    return o
 
 
 def parse_args():
@@ -429,7 +486,8 @@ def main() -> None:
         }
         chip = system.chip_info()
         if chip["chip_by_default"] and args.precond in ("jacobi", "none"):
-            line["roofline"] = chip_roofline(system, poisson.rhs(n, 0), check, line["roofline"], pmc_all.get(f"chip_{args.dim}d_{args.n}"))
+            line["roofline"] = chip_roofline(system, poisson.rhs(n, 0), check, line["roofline"], pmc_all.get(f"chip_{args.dim}d_{args.n}"),
+                                             pmc_all.get(f"chip_{args.dim}d_{args.n}_l2_counters"), stencil_offsets(args.dim, args.n))
         if per_rank is not None:
             line["per_rank"] = per_rank
             line["gathered_records"] = comm["gathered_records"]

@@ -56,6 +56,7 @@ SIGNATURES = {
     "dpcg_get_reduction_geometry": (_int, [_p, _p]),
     "dpcg_get_chip_info": (_int, [_p, _p, _p]),
     "dpcg_debug_occupy": (_int, [_int, C.c_double, _p]),
+    "dpcg_debug_l2_gather": (_int, [_int, _int, C.POINTER(C.c_int32), _int, _int, _p, C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_int)]),
     "dpcg_get_factor": (_int, [_p, _p, _p, _p]),
     "dpcg_spmv": (_int, [_p, _p, _p, _p]),
     "dpcg_spmv_f32": (_int, [_p, _p, _p, _p]),

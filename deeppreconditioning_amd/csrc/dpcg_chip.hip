@@ -476,9 +476,11 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         if (conv) { stop = true; status = DPCG_OK; }
         else if (!(res == res)) { stop = true; status = DPCG_BREAKDOWN; }
     }
+    // (after a wait that ran out the workgroups are not at the same update: nothing is stored -- d.x may be the caller's buffer, and the
+    // caller may have passed it as x0 too, which the multi-launch path that takes over must find untouched)
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
-        if (row_on(k)) d.x[row0 + k * kChipThreads] = x[k];
+        if (alive && row_on(k)) d.x[row0 + k * kChipThreads] = x[k];
     if (timed) {                            // eight words per workgroup: [4] the loop, [7] (workgroup 0) `local` in bit 0
         unsigned long long *o = d.dbg + 8 * v;
         o[0] = s_tk[0]; o[1] = s_tk[1]; o[2] = s_tk[2]; o[3] = s_tk[3]; o[4] = wall_clock64() - tk_start;
@@ -502,10 +504,10 @@ __global__ __launch_bounds__(kBlock) void k_band_and_len(int64_t n, const int32_
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const int s = rp[i], e = rp[i + 1];
         len = e - s > len ? e - s : len;
-        if (e > s) {                       // columns ascend within a row: the extremes are its ends
-            const int lo = (int)i - ci[s], hi = ci[e - 1] - (int)i;
-            band = lo > band ? lo : band;
-            band = hi > band ? hi : band;
+        for (int k = s; k < e; ++k) {      // every entry: nothing here may assume that a caller's columns ascend within a row
+            const int dlt = ci[k] - (int)i;
+            const int ad = dlt < 0 ? -dlt : dlt;
+            band = ad > band ? ad : band;
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -577,6 +579,85 @@ int launch_occupy(int workgroups, double ms, hipStream_t s) {
         attr_set = true;
     }
     hipLaunchKernelGGL(k_occupy, dim3(workgroups), dim3(256), (size_t)lds, s, (unsigned long long)(ms * 1.0e5), (int *)nullptr);
+    return DPCG_OK;
+}
+
+// ---- the measured ceiling of the chip kernel's gathers (bench.py: `roofline.frac_of_measured_ceiling`) ---------------------------------
+// The whole-chip solve serves the operands of q = A p out of the eight L2s: 16-byte granules, stored plainly by the workgroups of the
+// owner's XCD, gathered with sc1 loads, 64 consecutive granules (1 KiB) per wave instruction.  This kernel does THAT and nothing else:
+// the same 256 x 512 geometry and placement, the same table per XCD (`per_group` granules of 16 bytes, written plainly by the group's
+// own workgroups inside the launch, behind the same exchange), `reps` passes in which every thread gathers RPT x 7 granules at the
+// given offsets from its rows (wrapped into its group's part of the table) and xors them into a register.  DEPTH rows' gathers are
+// in flight per lane (the solve kernel: 2 -- what its registers hold).  Ticks of the 100 MHz clock per workgroup -> ticks[v].
+template <int DEPTH>
+__global__ __launch_bounds__(kChipThreads) void k_l2_gather_probe(double *table, int per_group, int reps, const int *offs7, double *part, int *err, int *xcc,
+                                                                  unsigned long long *ticks, unsigned *sink, int sc1_only) {
+    constexpr int RPT = 8, W = 7;
+    __shared__ double sh[2 * 16];
+    __shared__ double s_res[2][2];
+    __shared__ int s_flag;
+    const int t = threadIdx.x;
+    const int grp = (int)blockIdx.x & 7, rank = (int)blockIdx.x >> 3;
+    const int v = grp * (kChipWGs / 8) + rank;
+    const int per = per_group / (kChipWGs / 8);                 // granules a workgroup writes
+    const int glo = grp * per_group;
+    const __amdgpu_buffer_rsrc_t rs = chip_rsrc(table, 8u * (unsigned)per_group * 16u);
+    Exchange X;
+    X.part_rs = chip_rsrc(part, (unsigned)kChipSlotBytes);
+    X.v = v; X.grp = grp; X.rank = rank; X.sh = sh; X.s_res = s_res; X.s_flag = &s_flag; X.err = err;
+    bool alive = true;
+    const bool local = groups_on_one_xcd(X, xcc, alive) && !sc1_only;
+    X.local = local;
+    for (int loc = t; loc < per; loc += kChipThreads) {
+        const int i = glo + rank * per + loc;
+        if (local) __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2((double)i, 1.0), rs, i * 16, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(pack_f64x2((double)i, 1.0), rs, i * 16, 0, kSc1);
+    }
+    double d0 = 0.0, d1 = 0.0;
+    if (alive) alive = exchange2(X, 0.0, 0.0, true, d0, d1);
+    int off[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) off[j] = offs7[j];
+    int row[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) row[k] = (rank * per + t + k * kChipThreads) % per_group;      // position inside the group's part
+    unsigned acc = 0;
+    const unsigned long long t0 = wall_clock64();
+    for (int rep = 0; alive && rep < reps; ++rep) {
+        u32x4 g[DEPTH][W];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) asm volatile("" : "+v"(row[k]));
+        auto request = [&](int k, u32x4 (&gk)[W]) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                int c = row[k] + off[j];
+                c = c < 0 ? c + per_group : (c >= per_group ? c - per_group : c);
+                gk[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (glo + c) * 16, 0, kSc1);
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < DEPTH - 1; ++k) request(k, g[k]);
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            if (k + DEPTH - 1 < RPT) request(k + DEPTH - 1, g[(k + DEPTH - 1) % DEPTH]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc ^= g[k % DEPTH][j].x ^ g[k % DEPTH][j].z;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = wall_clock64();
+    if (t == 0) ticks[v] = alive ? t1 - t0 : 0ull;
+    if (acc == 0x9e3779b9u) *sink = acc;
+    if (v == 0 && t == 0) xcc[kChipWGs] = local ? 1 : 0;
+}
+
+// reps passes of 256 x 512 x 8 x 7 sixteen-byte gathers; out_ticks: 256 words; xcc: 257 ints ([256] <- the groups sat on one XCD each)
+int launch_l2_gather_probe(double *table, int per_group, int reps, const int *offs7_dev, int depth, bool sc1_only, double *part, int *err, int *xcc,
+                           unsigned long long *ticks, unsigned *sink, hipStream_t s) {
+    if (per_group < kChipThreads * (kChipWGs / 8) || per_group % (kChipWGs / 8) != 0 || reps < 1) return DPCG_ERR_INVALID;
+    if (depth == 4) hipLaunchKernelGGL(k_l2_gather_probe<4>, dim3(kChipWGs), dim3(kChipThreads), 0, s, table, per_group, reps, offs7_dev, part, err, xcc, ticks, sink, sc1_only ? 1 : 0);
+    else hipLaunchKernelGGL(k_l2_gather_probe<2>, dim3(kChipWGs), dim3(kChipThreads), 0, s, table, per_group, reps, offs7_dev, part, err, xcc, ticks, sink, sc1_only ? 1 : 0);
     return DPCG_OK;
 }
 

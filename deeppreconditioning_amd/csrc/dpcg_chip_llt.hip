@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_llt(const ChipLltDesc
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
-        if (row_counts(k)) d.x[row0 + k * kChipThreads] = x[k];
+        if (alive && row_counts(k)) d.x[row0 + k * kChipThreads] = x[k];     // (nothing after a wait that ran out: see dpcg_chip.hip)
     if (v == 0 && t == 0) {
         Scalars *sc = d.out;
         sc->k = k_done;

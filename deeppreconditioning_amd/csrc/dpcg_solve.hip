@@ -498,7 +498,9 @@ static bool team_eligible(const dpcg_system *h, int flags, const double *x_true)
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
         return cus >= 256;                       // eight teams of 32 workgroups, one workgroup per CU, all resident
     }();
-    if (!enabled || x_true || (flags & (DPCG_SPMV_F32 | DPCG_NO_TEAM | DPCG_NO_FUSE | DPCG_VAL32_IF_LOSSLESS))) return false;
+    // (DPCG_VAL32_IF_LOSSLESS is a permission about how the matrix is STREAMED; the one-launch forms keep it on chip in fp64 and
+    // return the same bits)
+    if (!enabled || x_true || (flags & (DPCG_SPMV_F32 | DPCG_NO_TEAM | DPCG_NO_FUSE))) return false;
     if (h->A.n <= team_min_rows() || h->A.n > team_max_rows() || h->perm) return false;
     if (h->planA.max_row_len < 1 || h->planA.max_row_len > team_max_row_len()) return false;   // rows live in registers
     if (h->planA.kernel == SPMV_VECTOR) return false;     // long rows: the multi-launch path's row-sharing kernel
@@ -578,6 +580,37 @@ static std::mutex &team_launch_mutex() {
     return *m;
 }
 
+// Back-off of the one-launch forms (one workgroup team / whole chip): they assume that all of their workgroups become co-resident, and
+// a launch that cannot (RCCL kernels or another process holding CUs, a long kernel on another stream) spins for the full 20 ms bound
+// before the call goes on through the launches.  Three such timeouts in a row and the one-launch forms are skipped for a cool-down
+// (2 s, doubling up to 32 s while the re-probes keep failing); a launch that completes clears it.  One warning per process.
+struct CoResidency {
+    std::atomic<int> misses{0};
+    std::atomic<long long> closed_until_ns{0};
+    std::atomic<int> cooldown_s{2};
+    std::atomic<bool> warned{false};
+    static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    bool open() const { return now_ns() >= closed_until_ns.load(std::memory_order_relaxed); }
+    void launched_fine() {
+        misses.store(0, std::memory_order_relaxed);
+        cooldown_s.store(2, std::memory_order_relaxed);
+    }
+    void timed_out() {
+        if (misses.fetch_add(1, std::memory_order_relaxed) + 1 < 3) return;
+        const int cd = cooldown_s.load(std::memory_order_relaxed);
+        closed_until_ns.store(now_ns() + (long long)cd * 1000000000ll, std::memory_order_relaxed);
+        cooldown_s.store(std::min(2 * cd, 32), std::memory_order_relaxed);
+        misses.store(2, std::memory_order_relaxed);            // (the re-probe after the cool-down closes it again at its first timeout)
+        if (!warned.exchange(true))
+            fprintf(stderr, "[dpcg] the one-launch solve kernels could not become co-resident three times in a row (somebody else holds CUs): "
+                            "solving through the multi-launch path, re-probing every %d s and up\n", cd);
+    }
+};
+static CoResidency &co_residency() {
+    static CoResidency *c = new CoResidency();
+    return *c;
+}
+
 static int ensure_team(dpcg_system *h, hipStream_t s) {
     DPCG_TRY(build_ell(h->A, h->ell_a, s));
     if (h->ell_a.W > team_max_row_len()) return invalid("team solve: a row has more than 7 entries");
@@ -648,9 +681,11 @@ static int solve_team_one(dpcg_system *h, const double *b, const double *x0, dou
     DPCG_CHECK_LAUNCH();
     const Scalars sc = *h->scal_host;
     if (sc.status < 0) {
+        co_residency().timed_out();
         set_error("team solve: a workgroup waited (20 ms) for a team member that never arrived");
         return sc.status;
     }
+    co_residency().launched_fine();
     if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
     if (iters) *iters = sc.k;
     if (final_res) *final_res = sc.res;
@@ -690,7 +725,9 @@ static bool chip_eligible(const dpcg_system *h, int flags, const double *x_true)
         return cus >= chip_workgroups();         // one workgroup per CU, all resident
     }();
     static const int min_rows = [] { const char *e = getenv("DPCG_CHIP_MIN_ROWS"); return e ? atoi(e) : team_max_rows(); }();
-    if (!enabled || x_true || (flags & (DPCG_NO_TEAM | DPCG_NO_FUSE | DPCG_VAL32_IF_LOSSLESS))) return false;   // (DPCG_SPMV_F32: with x0 = 0, see the callers)
+    // (DPCG_SPMV_F32: with x0 = 0, see the callers; DPCG_VAL32_IF_LOSSLESS: a permission about how the matrix is streamed -- resident in
+    // fp64 the results are the same bits, so the flag does not keep a system off the chip)
+    if (!enabled || x_true || (flags & (DPCG_NO_TEAM | DPCG_NO_FUSE))) return false;
     if (h->A.n <= min_rows || h->A.n > chip_max_rows()) return false;
     if (h->planA.max_row_len < 1 || h->planA.max_band < 0) return false;
     if (h->precond != DPCG_PRECOND_NONE && h->precond != DPCG_PRECOND_JACOBI) return false;
@@ -785,9 +822,11 @@ static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, dou
     DPCG_CHECK_LAUNCH();
     const Scalars sc = *h->scal_host;
     if (sc.status < 0) {
+        co_residency().timed_out();
         set_error("chip solve: a workgroup waited (20 ms) for one that never became resident");
         return sc.status;
     }
+    co_residency().launched_fine();
     if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
     if (iters) *iters = sc.k;
     if (final_res) *final_res = sc.res;
@@ -843,7 +882,7 @@ static bool chip_llt_eligible(const dpcg_system *h, int flags, const double *x_t
         return cus >= chip_workgroups();
     }();
     if (!enabled || x_true || h->precond != DPCG_PRECOND_LLT_MULTIPLY) return false;
-    if (flags & (DPCG_SPMV_F32 | DPCG_NO_TEAM | DPCG_NO_FUSE | DPCG_VAL32_IF_LOSSLESS)) return false;
+    if (flags & (DPCG_SPMV_F32 | DPCG_NO_TEAM | DPCG_NO_FUSE)) return false;
     if (h->A.n <= kSmallMaxN || h->A.n > chip_llt_max_rows()) return false;
     if (h->planA.max_row_len < 1 || h->planA.max_row_len > 7) return false;        // (dpcg_chip_llt.hip: rows of A of <= 7 entries)
     const int ml = std::max(h->planL.max_row_len, h->planLt.max_row_len);
@@ -919,9 +958,11 @@ static int solve_chip_llt_one(dpcg_system *h, const double *b, const double *x0,
     DPCG_CHECK_LAUNCH();
     const Scalars sc = *h->scal_host;
     if (sc.status < 0) {
+        co_residency().timed_out();
         set_error("chip solve (M = L L^T): a workgroup waited (20 ms) for one that never became resident");
         return sc.status;
     }
+    co_residency().launched_fine();
     if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
     if (iters) *iters = sc.k;
     if (final_res) *final_res = sc.res;
@@ -939,6 +980,53 @@ extern "C" int dpcg_debug_occupy(int workgroups, double milliseconds, dpcg_strea
     if (workgroups < 1 || workgroups > 4096 || !(milliseconds > 0.0) || milliseconds > 2000.0) return invalid("dpcg_debug_occupy: bad arguments");
     DPCG_TRY(launch_occupy(workgroups, milliseconds, (hipStream_t)stream));
     DPCG_CHECK_LAUNCH();
+    return DPCG_OK;
+}
+
+extern "C" int dpcg_debug_l2_gather(int granules_per_group, int reps, const int32_t offsets[7], int depth, int written_through, dpcg_stream_t stream,
+                                    double *gbs, double *us_per_pass, int *groups_local) {
+    if (!offsets || granules_per_group < 32 * chip_threads() || granules_per_group % 32 != 0 || granules_per_group > (1 << 22) || reps < 1 || reps > 100000 ||
+        (depth != 2 && depth != 4))
+        return invalid("dpcg_debug_l2_gather: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int kSlots = chip_slot_doubles();
+    double *table = nullptr, *part = nullptr;
+    int *ints = nullptr;                   // 7 offsets | err (2) | xcc (257)
+    unsigned long long *ticks = nullptr;
+    DPCG_TRY(dev_alloc(&table, (size_t)8 * granules_per_group * 2));
+    DPCG_TRY(dev_alloc(&part, kSlots));
+    DPCG_TRY(dev_alloc(&ints, 8 + 2 + 260));
+    DPCG_TRY(dev_alloc(&ticks, 256 + 1));
+    int st = DPCG_OK;
+    std::vector<unsigned long long> w(256);
+    int flags[2] = {0, 0};
+    hipError_t e = hipMemsetAsync(ints, 0, (8 + 2 + 260) * sizeof(int), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(ints, offsets, 7 * sizeof(int), hipMemcpyHostToDevice, s);
+    launch_fill_pending(part, kSlots, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> one_team_launch(team_launch_mutex());
+        st = launch_l2_gather_probe(table, granules_per_group, reps, ints, depth, written_through != 0, part, ints + 8, ints + 10, ticks,
+                                    reinterpret_cast<unsigned *>(ticks + 256), s);
+        if (st == DPCG_OK) e = hipStreamSynchronize(s);
+    }
+    if (e == hipSuccess && st == DPCG_OK) e = hipMemcpy(w.data(), ticks, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && st == DPCG_OK) e = hipMemcpy(flags, ints + 8, sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && st == DPCG_OK) e = hipMemcpy(flags + 1, ints + 10 + 256, sizeof(int), hipMemcpyDeviceToHost);
+    dev_free(table); dev_free(part); dev_free(ints); dev_free(ticks);
+    DPCG_HIP(e);
+    if (st != DPCG_OK) return st;
+    unsigned long long worst = 0;
+    for (unsigned long long x : w) worst = std::max(worst, x);
+    if (flags[0] || worst == 0) {
+        set_error("dpcg_debug_l2_gather: the workgroups never became co-resident");
+        return DPCG_ERR_STATE;
+    }
+    const double us = (double)worst * 0.01;                   // 100 MHz
+    const double bytes = (double)reps * 256.0 * 512.0 * 8.0 * 7.0 * 16.0;
+    if (gbs) *gbs = bytes / (us * 1.0e-6) / 1.0e9;
+    if (us_per_pass) *us_per_pass = us / reps;
+    if (groups_local) *groups_local = flags[1];
     return DPCG_OK;
 }
 
@@ -979,25 +1067,26 @@ extern "C" int dpcg_solve(dpcg_handle_t h, const double *b, const double *x0, do
                           double *final_res, double *seconds, double *res_history, const double *x_true,
                           double *err_history) {
     DPCG_TRY(check_solve_args(h, b, max_iter, flags, x_true, err_history));
-    const bool team_first = team_eligible(h, flags, x_true) && ((flags & DPCG_TEAM) || single_team_default(h, flags));
+    const bool one_launch_open = co_residency().open();      // (false during the cool-down after repeated co-residency timeouts)
+    const bool team_first = one_launch_open && team_eligible(h, flags, x_true) && ((flags & DPCG_TEAM) || single_team_default(h, flags));
     if (small_eligible(h, flags, x_true) && !team_first)
         return solve_small_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
                                seconds, res_history);
     // a single team by default (tools/team_crossover_probe.py)
-    if (team_eligible(h, flags, x_true) && ((flags & DPCG_TEAM) || single_team_default(h, flags))) {
+    if (team_first) {
         const int st = solve_team_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
                                       seconds, res_history);
         if (st != DPCG_ERR_STATE) return st;
         // the team never became co-resident (a plain launch assumes it): the multi-launch path below needs no such thing
     }
     // cache-sized systems on the whole chip
-    if (chip_eligible(h, flags, x_true) && ((flags & DPCG_TEAM) || chip_default(h, flags))) {
+    if (one_launch_open && chip_eligible(h, flags, x_true) && ((flags & DPCG_TEAM) || chip_default(h, flags))) {
         const int st = solve_chip_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
                                       seconds, res_history);
         if (st != DPCG_ERR_STATE) return st;
         // the workgroups never became co-resident, or the kernel was refused up front: the multi-launch path needs no such thing
     }
-    if (chip_llt_eligible(h, flags, x_true) && ((flags & DPCG_TEAM) || chip_default(h, flags))) {
+    if (one_launch_open && chip_llt_eligible(h, flags, x_true) && ((flags & DPCG_TEAM) || chip_default(h, flags))) {
         const int st = solve_chip_llt_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
                                           seconds, res_history);
         if (st != DPCG_ERR_STATE) return st;
@@ -1089,7 +1178,7 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
     }
     bool all_chip = true;
     for (int i = 0; i < count; ++i) all_chip = all_chip && chip_eligible(handles[i], flags, nullptr);
-    if (all_chip && ((flags & DPCG_TEAM) || chip_default(handles[0], flags))) {
+    if (all_chip && co_residency().open() && ((flags & DPCG_TEAM) || chip_default(handles[0], flags))) {
         // cache-sized systems: the whole chip serves one system at a time (7-13 us per update against 30 for the launches -- nothing to
         // interleave), and a batch member's result is bit for bit that of its single solve
         int worst_chip = DPCG_OK;
@@ -1114,7 +1203,7 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
     }
     bool all_team = true;
     for (int i = 0; i < count; ++i) all_team = all_team && team_eligible(handles[i], flags, nullptr);
-    if (all_team && ((flags & DPCG_TEAM) || single_team_default(handles[0], flags))) {      // (any count: one team already beats the launches)
+    if (all_team && co_residency().open() && ((flags & DPCG_TEAM) || single_team_default(handles[0], flags))) {      // (any count: one team already beats the launches)
         // up to eight systems per launch, one team (normally: one XCD) each; the launches follow one another
         struct TeamScratch {
             TeamDesc *descs = nullptr;
@@ -1153,6 +1242,7 @@ extern "C" int dpcg_solve_batch(int count, dpcg_handle_t *handles, const double 
                 const Scalars sc = *hi->scal_host;
                 if (sc.status < 0) {
                     team_timed_out = true;
+                    co_residency().timed_out();
                     break;
                 }
                 if (iters) iters[g0 + i] = sc.k;

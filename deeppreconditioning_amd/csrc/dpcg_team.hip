@@ -371,7 +371,7 @@ __global__ __launch_bounds__(kTeamThreads) void k_pcg_team(const TeamDesc *__res
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
-        if (row[k] >= 0) d.x[row[k]] = x[k];
+        if (alive && row[k] >= 0) d.x[row[k]] = x[k];
     if (timed) {
         d.dbg[0] = tk[0]; d.dbg[1] = tk[1]; d.dbg[2] = tk[2]; d.dbg[3] = tk[3]; d.dbg[4] = wall_clock64() - tk_start;
         d.dbg[5] = tk_bsum_a; d.dbg[6] = tk_drain; d.dbg[7] = tk_bsum - tk_bsum_a;

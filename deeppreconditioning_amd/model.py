@@ -1,5 +1,5 @@
 """spconv-free forward pass of `PreconditionerNet` (drop-in for `uibk/deep_preconditioning/model.py:13-59`; the U-Net
-variant of model.py:62-179 is out of scope: SURVEY.md 8-f1 names model.py:13-59 only).
+variant of model.py:62-179 is out of scope and fenced off in extras_unet.py, resolved lazily).
 
 `spconv` ships CUDA-only wheels (`pyproject.toml:20`), so on ROCm the reference model cannot even be imported.
 This module re-states the pieces the network needs on plain PyTorch-ROCm ops -- the host code the north star
@@ -307,6 +307,19 @@ def forward_cost(net, t: SparseBatch) -> dict:
         total_b += byts
         sites_in = sites.value
     return {"layers": out, "flops": total_f, "min_hbm_bytes": total_b}
+
+
+# `PreconditionerSparseUNet` and its sub-manifold / inverse convolutions (model.py:62-179 of the reference) are OUTSIDE the
+# hot-path scope (SURVEY.md 8-f1 names model.py:13-59 only): they live, fenced off, in extras_unet.py and resolve lazily so
+# that `params.yaml: model: PreconditionerSparseUNet` (test.py:215, train.py:154) and the reference's import lines keep working.
+_UNET_NAMES = ("SubMConv2d", "SparseInverseConv2d", "sparse_add", "PreconditionerSparseUNet")
+
+
+def __getattr__(name):
+    if name in _UNET_NAMES:
+        from . import extras_unet
+        return getattr(extras_unet, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
 def load_reference_state_dict(model: nn.Module, state: dict) -> None:

@@ -751,7 +751,7 @@ def test_reference_import_lines_resolve_through_the_compat_shim(D, monkeypatch):
                                 size=(400, 400)).to_sparse_csr()
     duration, iterations, info = cg_mod.preconditioned_conjugate_gradient(torch.from_numpy(A.toarray()), b, M)
     assert iterations == CO.pcg(A, O.rhs(400, 0), "jacobi", dinv=O.jacobi_dinv(A))[1] and info == 0
-    assert hasattr(models, "PreconditionerNet") and not hasattr(models, "PreconditionerSparseUNet")     # (outside the path: SURVEY.md 2 #4)
+    assert hasattr(models, "PreconditionerNet") and hasattr(models, "PreconditionerSparseUNet")     # (the U-Net variant: outside the path, SURVEY.md 2 #4 -- fenced off, resolved lazily)
     for name, attrs in (("utils", ("sparse_matvec_mul", "benchmark_cg")), ("metrics", ("inverse_loss", "frobenius_loss")),
                         ("data_set", ("SludgePatternDataSet", "StAnDataSet")),
                         ("test", ("BenchmarkSuite", "main"))):
@@ -1088,6 +1088,18 @@ def test_lossless_fp32_value_storage_is_bit_identical(D):
     b = _dev(O.rhs(A32.shape[0], 0))
     r0, r1 = S.solve(b, flags=D._lib.NO_SMALL), S.solve(b, flags=flag)
     assert np.array_equal(r0.res_history, r1.res_history) and torch.equal(r0.x, r1.x)
+    # a chip-sized system: the flag is a permission about how the matrix is STREAMED -- it does not keep a system off the one-launch
+    # forms (matrix resident in fp64: the same bits), so the flagged call IS the plain call
+    A = O.poisson3d(41)
+    S = D.CsrSystem.from_any(A, reorder=None)
+    S.set_preconditioner(D.Jacobi())
+    b = _dev(O.rhs(A.shape[0], 0))
+    assert S.chip_info()["chip_by_default"]
+    plain, flagged, multi = S.solve(b), S.solve(b, flags=D._lib.VAL32_IF_LOSSLESS), S.solve(b, flags=flag)
+    assert np.array_equal(plain.res_history, flagged.res_history) and torch.equal(plain.x, flagged.x)
+    assert plain.iterations == multi.iterations and not np.array_equal(plain.res_history, multi.res_history)   # (the launches sum in another order)
+    _, it, hist, x = CO.pcg(A, O.rhs(A.shape[0], 0), "jacobi", dinv=O.jacobi_dinv(A), device_tree=_chip_tree(S))
+    assert flagged.iterations == it and np.array_equal(flagged.res_history, hist) and np.array_equal(flagged.x.cpu().numpy(), x)
 
 
 def test_solve_batch_general_path_interleaves_streams(D):
@@ -1627,7 +1639,8 @@ def test_inverse_loss_on_sparse_operands(D, golden):
         f_sparse = pre.features.clone().requires_grad_(True)
         metrics.inverse_loss(systems, pre.replace_feature(f_sparse), panel_columns=16).backward()
         f_dense = pre.features.clone().requires_grad_(True)
-        metrics.inverse_loss_dense(systems, pre.replace_feature(f_dense)).backward()
+        from dense_checkers import inverse_loss_dense
+        inverse_loss_dense(systems, pre.replace_feature(f_dense)).backward()
         np.testing.assert_allclose(f_sparse.grad.cpu().numpy(), f_dense.grad.cpu().numpy(), rtol=2e-4, atol=1e-6)
     # 65 536 unknowns: tril of the 256^2 Poisson matrix, L = its Jacobi-scaled lower triangle (the dense form: 17 GB per matrix)
     from deeppreconditioning_amd import model as mdl
@@ -2949,6 +2962,34 @@ def test_chip_stream_solve_equals_the_device_tree_oracle_bit_for_bit(D, monkeypa
     assert with_x0.iterations == it0 and np.array_equal(with_x0.res_history, hist0), name
     S.close()
 
+
+
+def test_chip_solve_takes_rows_whose_columns_do_not_ascend(D):
+    """Nothing validates that a caller's CSR parts have ascending columns (the launches never needed it).  The whole-chip kernel encodes
+    columns as 16-bit offsets and decides from the matrix's bandwidth which rows other XCDs gather: the bandwidth is measured over
+    EVERY entry, not from a row's first and last one.  Rows reordered so that their ends are the nearest neighbours: the band is still
+    the stencil's, the one-launch solve equals the oracle on the same (unsorted) parts bit for bit."""
+    A = O.poisson3d(41)
+    n = A.shape[0]
+    rp, ci, v = A.indptr.copy(), A.indices.copy(), A.data.copy()
+    for i in range(n):
+        s, e = rp[i], rp[i + 1]
+        order = np.argsort(np.abs(ci[s:e] - i), kind="stable")[::-1]          # farthest first ...
+        order = np.concatenate((order[-1:], order[:-1]))[::-1] if e - s > 2 else order   # ... then rotated: both ends near the diagonal
+        ci[s:e], v[s:e] = ci[s:e][order], v[s:e][order]
+    ends = np.maximum(np.abs(ci[rp[:-1]] - np.arange(n)), np.abs(ci[rp[1:] - 1] - np.arange(n))).max()
+    assert ends < 41 * 41                                             # (what the first / last entry alone would have measured)
+    S = D.CsrSystem.from_any((rp, ci, v), reorder=None)
+    S.set_preconditioner(D.Jacobi())
+    cinfo = S.chip_info()
+    assert cinfo["chip_by_default"] and cinfo["max_band"] == 41 * 41, cinfo
+    b = O.rhs(n, 0)
+    res = S.solve(_dev(b))
+    U = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    assert not U.has_sorted_indices
+    _, it, hist, x = CO.pcg(U, b, "jacobi", dinv=O.jacobi_dinv(A), device_tree=_chip_tree(S))
+    assert res.iterations == it and np.array_equal(res.res_history, hist) and np.array_equal(res.x.cpu().numpy(), x)
+    S.close()
 
 
 def test_chip_solve_arguments_and_edges(D):

@@ -222,7 +222,8 @@ def test_config3_unstructured_meshes_million_dof(D, name, make, expect):
 def test_million_row_meshes_full_length_histories(D, name, make):
     """The 1M-row meshes to the END of their histories (the reference's defaults: rtol 1e-8 squared, cap 1024 -- cg.py:51), not the
     first 60 updates: Jacobi and IC(0) in multicolour order through the plain multi-launch path against the C oracle with the device's
-    reduction trees on the system the handle iterates on -- counts, every residual of up to 1025, and x under Jacobi EQUAL."""
+    reduction trees on the system the handle iterates on -- counts, every residual of up to 1025, and x under Jacobi EQUAL; Jacobi also
+    through the DEFAULT call (the streamed whole-chip form) and, on one mesh, with config 5's fp32-stored operands, to the end."""
     A = make()
     n = A.shape[0]
     b = O.rhs(n, 0)
@@ -235,6 +236,21 @@ def test_million_row_meshes_full_length_histories(D, name, make):
     _, it, hist, xs = CO.pcg(B, b[perm], "jacobi", dinv=O.jacobi_dinv(B), device_tree=S.reduction_geometry())
     assert res.iterations == it and len(hist) == it + 1 and np.array_equal(res.res_history, hist), (name, res.iterations, it)
     assert np.array_equal(res.x.cpu().numpy()[perm], xs)
+    # ... and the DEFAULT call (the one-launch kernel with the matrix streamed, k_pcg_chip MODE 5) to the end of ITS history, x included,
+    # against the oracle with the whole-chip reduction tree; then config 5's fp32-stored operands (MODE 6) likewise
+    ci = S.chip_info()
+    assert ci["chip_by_default"], ci
+    chip_tree = {**S.reduction_geometry(), "form": "chip", "rows_per_workgroup": ci["rows_per_workgroup"]}
+    res_d = S.solve(_dev(b))
+    _, it_d, hist_d, xs_d = CO.pcg(B, b[perm], "jacobi", dinv=O.jacobi_dinv(B), device_tree=chip_tree)
+    assert res_d.iterations == it_d and len(hist_d) == it_d + 1 and np.array_equal(res_d.res_history, hist_d), (name, res_d.iterations, it_d)
+    assert np.array_equal(res_d.x.cpu().numpy()[perm], xs_d)
+    assert not np.array_equal(res_d.res_history, res.res_history)          # (another summation order: it WAS the other form)
+    if name == "quadtree_random_1M":
+        res_m = S.solve(_dev(b), flags=D._lib.SPMV_F32)
+        _, it_m, hist_m, xs_m = CO.pcg(B, b[perm], "jacobi", dinv=O.jacobi_dinv(B), mixed=True, device_tree=chip_tree)
+        assert res_m.iterations == it_m and np.array_equal(res_m.res_history, hist_m), (name, res_m.iterations, it_m)
+        assert np.array_equal(res_m.x.cpu().numpy()[perm], xs_m)
     S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
     nc, q = S.precond_ordering()
     Lq = CO.ic0(_permuted(A, q))
