@@ -589,6 +589,7 @@ int launch_occupy(int workgroups, double ms, hipStream_t s) {
 // own workgroups inside the launch, behind the same exchange), `reps` passes in which every thread gathers RPT x 7 granules at the
 // given offsets from its rows (wrapped into its group's part of the table) and xors them into a register.  DEPTH rows' gathers are
 // in flight per lane (the solve kernel: 2 -- what its registers hold).  Ticks of the 100 MHz clock per workgroup -> ticks[v].
+namespace {
 template <int DEPTH>
 __global__ __launch_bounds__(kChipThreads) void k_l2_gather_probe(double *table, int per_group, int reps, const int *offs7, double *part, int *err, int *xcc,
                                                                   unsigned long long *ticks, unsigned *sink, int sc1_only) {
@@ -651,6 +652,8 @@ __global__ __launch_bounds__(kChipThreads) void k_l2_gather_probe(double *table,
     if (acc == 0x9e3779b9u) *sink = acc;
     if (v == 0 && t == 0) xcc[kChipWGs] = local ? 1 : 0;
 }
+
+}  // namespace
 
 // reps passes of 256 x 512 x 8 x 7 sixteen-byte gathers; out_ticks: 256 words; xcc: 257 ints ([256] <- the groups sat on one XCD each)
 int launch_l2_gather_probe(double *table, int per_group, int reps, const int *offs7_dev, int depth, bool sc1_only, double *part, int *err, int *xcc,
