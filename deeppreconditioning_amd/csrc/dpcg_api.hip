@@ -334,6 +334,15 @@ void free_precond(dpcg_system *h, bool keep_parked) {
     free_plan(h->planM);
     free_plan(h->planL);
     free_plan(h->planLt);
+    free_chip_trsv_lists(h->trsv_l);
+    free_chip_trsv_lists(h->trsv_u);
+    dev_free(h->trsv_lv0);
+    dev_free(h->trsv_diag0);
+    dev_free(h->trsv_fval);
+    dev_free(h->trsv_fcol);
+    dev_free(h->trsv_fmeta);
+    h->trsv_rpt = h->trsv_wmax = h->trsv_band = 0;
+    h->trsv_state = 0;
     if (h->fmap != h->mc_perm) dev_free(h->fmap);            // (the handle's cached colouring is not the preconditioner's to free)
     if (h->fmap_inv != h->mc_iperm) dev_free(h->fmap_inv);
     h->fmap = h->fmap_inv = nullptr;

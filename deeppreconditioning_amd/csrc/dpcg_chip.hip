@@ -594,6 +594,7 @@ template <int DEPTH>
 __global__ __launch_bounds__(kChipThreads) void k_l2_gather_probe(double *table, int per_group, int reps, const int *offs7, double *part, int *err, int *xcc,
                                                                   unsigned long long *ticks, unsigned *sink, int sc1_only) {
     constexpr int RPT = 8, W = 7;
+    extern __shared__ __attribute__((aligned(16))) double probe_lds[];     // (unused: the solve kernel's footprint -- one workgroup per CU, the same placement)
     __shared__ double sh[2 * 16];
     __shared__ double s_res[2][2];
     __shared__ int s_flag;
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(kChipThreads) void k_l2_gather_probe(double *table,
     }
     const unsigned long long t1 = wall_clock64();
     if (t == 0) ticks[v] = alive ? t1 - t0 : 0ull;
-    if (acc == 0x9e3779b9u) *sink = acc;
+    if (acc == 0x9e3779b9u) { *sink = acc; probe_lds[t] = 1.0; }
     if (v == 0 && t == 0) xcc[kChipWGs] = local ? 1 : 0;
 }
 
@@ -659,8 +660,15 @@ __global__ __launch_bounds__(kChipThreads) void k_l2_gather_probe(double *table,
 int launch_l2_gather_probe(double *table, int per_group, int reps, const int *offs7_dev, int depth, bool sc1_only, double *part, int *err, int *xcc,
                            unsigned long long *ticks, unsigned *sink, hipStream_t s) {
     if (per_group < kChipThreads * (kChipWGs / 8) || per_group % (kChipWGs / 8) != 0 || reps < 1) return DPCG_ERR_INVALID;
-    if (depth == 4) hipLaunchKernelGGL(k_l2_gather_probe<4>, dim3(kChipWGs), dim3(kChipThreads), 0, s, table, per_group, reps, offs7_dev, part, err, xcc, ticks, sink, sc1_only ? 1 : 0);
-    else hipLaunchKernelGGL(k_l2_gather_probe<2>, dim3(kChipWGs), dim3(kChipThreads), 0, s, table, per_group, reps, offs7_dev, part, err, xcc, ticks, sink, sc1_only ? 1 : 0);
+    const int lds = kChipLdsSlots * kChipThreads * (int)sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_l2_gather_probe<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DPCG_ERR_HIP;
+        if (hipFuncSetAttribute((const void *)k_l2_gather_probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DPCG_ERR_HIP;
+        attr_set = true;
+    }
+    if (depth == 4) hipLaunchKernelGGL(k_l2_gather_probe<4>, dim3(kChipWGs), dim3(kChipThreads), (size_t)lds, s, table, per_group, reps, offs7_dev, part, err, xcc, ticks, sink, sc1_only ? 1 : 0);
+    else hipLaunchKernelGGL(k_l2_gather_probe<2>, dim3(kChipWGs), dim3(kChipThreads), (size_t)lds, s, table, per_group, reps, offs7_dev, part, err, xcc, ticks, sink, sc1_only ? 1 : 0);
     return DPCG_OK;
 }
 

@@ -212,6 +212,17 @@ void launch_fill_pending(double *v, int64_t n, hipStream_t s);
 // largest entry count of the blocks {blk[2b], blk[2b+1]} of a level-ordered copy -> *out_dev (atomicMax)
 void launch_sfs_block_max(const int32_t *blk, int nblk, const int32_t *lo_rowptr, int *out_dev, hipStream_t s);
 
+// (dpcg_chip_trsv.hip; the comment is with ChipTrsvDesc below)
+struct ChipTrsvLists {
+    int32_t *first_blk = nullptr, *first_ent = nullptr;     // 2049 each
+    int4 *blk = nullptr;
+    double *val = nullptr;
+    int32_t *col = nullptr;
+    int n_blk = 0, n_ent = 0;
+    int band = 0;              // largest |col - row| of the factor in the handle's numbering
+    int max_row = 0;           // most off-diagonal entries of a row
+    int n_levels = 0;
+};
 }  // namespace dpcg
 
 struct dpcg_system {
@@ -277,6 +288,15 @@ struct dpcg_system {
     double *chip_part = nullptr;             // the chip kernel's reduction slots (4 x 256 x 2 doubles) + 8 trace words + the error flag
     double *chip_zp = nullptr;               // ... and its published granules
     double *chip_rt = nullptr;               // M = L L^T multiplied on the chip: the published r and t = L^T r
+    // M = L L^T solved on the chip (dpcg_chip_trsv.hip): the block lists of L and L^T, built at the first solve with this preconditioner
+    // (trsv_state: 0 not tried yet, 1 built, -1 this factor does not fit the form) and dropped with it
+    dpcg::ChipTrsvLists trsv_l, trsv_u;
+    int32_t *trsv_lv0 = nullptr;
+    double *trsv_diag0 = nullptr;
+    double *trsv_fval = nullptr;             // the resident form's plan (<= 524 288 rows): trsv_rpt != 0
+    int32_t *trsv_fcol = nullptr, *trsv_fmeta = nullptr;
+    int trsv_rpt = 0, trsv_wmax = 0, trsv_band = 0;
+    int trsv_state = 0;
     double chip_trace_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // ... over the 256 workgroups: SpMV phase max / mean, publish max / mean, `local`
     double chip_trace_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DPCG_CHIP_TRACE: us per update by phase of the last chip solve ([7] = updates)
     dpcg::SmallEll ell_a, ell_m, ell_t;      // slab-ELL copies of A, M (or L), L^T for the small-system kernel
@@ -473,6 +493,49 @@ struct ChipDesc {
     int *err;
     unsigned long long *dbg;   // DPCG_CHIP_TRACE=1: 8 words per workgroup, ticks (100 MHz) its thread 0 spent per phase of the updates; else null
 };
+// dpcg_chip_trsv.hip: M applied by two triangular solves (L y = r, L^T z = y) inside the whole-chip kernel.  The block lists of one triangular
+// factor in the chip kernel's geometry: per chip wave (workgroup v, wave w: index 8 v + w) the blocks [first_blk[i], first_blk[i + 1]), each
+// {k | W << 8 | level << 16, lane mask lo, hi, first entry}; entries {val, col} compacted over a block's active lanes.
+struct ChipTrsvDesc {
+    int n, max_iter, init_check_r, hist_cap, per, band;
+    const int32_t *rp, *ci;
+    const double *val;
+    const double *b, *x0;
+    double *x, *hist;
+    double *zp;                // 2 x (n + 4096) granules {z, p}
+    double *ypub, *zpub;       // 2 x (n + 4096) self-validating granules each: y = L^-1 r and z = L^-T y as the other workgroups see them
+    const int32_t *first_l, *first_u;
+    const int4 *blk_l, *blk_u;
+    const double *val_l, *val_u;
+    const int32_t *col_l, *col_u;
+    int nent_l, nent_u;
+    // the resident form (<= 4 rows a thread): the factor by workgroup, slot, thread (k_trsv_res_plan), the level counts
+    const double *fval;
+    const int32_t *fcol, *fmeta;
+    int nlev_l, nlev_u;
+    const int32_t *lv0;        // [256][512]: bits 0-7 the thread's slots whose row has no dependency in L, bits 8-15 in L^T
+    const double *diag0;       // [256][8][512]: the factor's diagonal by workgroup, slot, thread
+    double rtol_sq, atol_sq;
+    Scalars *out;
+    double *part;
+    int *err;
+    int *xcc;
+    unsigned int nonce;        // per launch: keys the self-validating granules
+    unsigned long long *dbg;   // DPCG_CHIP_TRACE=1: 64 words per workgroup (8 waves x 8 phases of the apply), ticks of the 100 MHz clock; else null
+};
+int chip_trsv_max_levels();
+int chip_trsv_max_factor_row();
+int build_chip_trsv_lists(int n, int per, int nlev, const CsrDev &F, const int32_t *lvl, const int32_t *f_of_handle, const int32_t *handle_of_f, bool upper,
+                          ChipTrsvLists &out, int32_t *lv0, double *diag0, hipStream_t s);
+int64_t chip_trsv_diag_doubles();
+int build_chip_trsv_resident(int n, int per, int rpt, int wmax, const CsrDev &L, const CsrDev &U, const int32_t *lvl_l, const int32_t *lvl_u,
+                             const int32_t *f_of_handle, const int32_t *handle_of_f, double **fval, int32_t **fcol, int32_t **fmeta, int *misfit, int *band,
+                             hipStream_t s);
+int chip_trsv_resident_rpt(int per);
+int chip_trsv_resident_wmax(int max_a, int rpt);
+int launch_pcg_chip_trsv_resident(const ChipTrsvDesc &d, int rpt, int wmax, hipStream_t s, bool check_only = false);
+void free_chip_trsv_lists(ChipTrsvLists &l);
+int launch_pcg_chip_trsv(const ChipTrsvDesc &d, int max_a, int max_l, hipStream_t s, bool check_only = false);
 // dpcg_chip_llt.hip: the same for M = L L^T multiplied (6 145 .. 262 144 rows, rows of A <= 7 and of L, L^T <= 16 entries)
 struct ChipLltDesc {
     int n, max_iter, init_check_r, hist_cap, per, band;

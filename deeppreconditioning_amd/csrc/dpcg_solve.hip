@@ -10,6 +10,7 @@
 #include <thread>
 
 #include "dpcg_host.h"
+#include "dpcg_prims.h"
 
 // ------------------------------------------------------------------------------------------------
 // the solve
@@ -976,6 +977,251 @@ static int solve_chip_llt_one(dpcg_system *h, const double *b, const double *x0,
     return sc.status;
 }
 
+// M = (L L^T)^-1 by two triangular solves on the whole chip (dpcg_chip_trsv.hip): A resident, L and L^T streamed as per-wave block lists
+// (built here once per preconditioner: dependency levels of both triangles by the sync-free analysis, then the lists in the chip kernel's
+// geometry), y and z handed from level to level as self-validating granules.
+static bool chip_trsv_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("DPCG_CHIP");
+        if (e && e[0] == '0') return false;
+        e = getenv("DPCG_CHIP_TRSV");
+        if (e && e[0] == '0') return false;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        return cus >= chip_workgroups();
+    }();
+    return on;
+}
+static int chip_trsv_min_rows() {
+    static const int v = [] { const char *e = getenv("DPCG_CHIP_TRSV_MIN_ROWS"); return e ? atoi(e) : 16384; }();
+    return v;
+}
+// what can be told without the lists (they are built at the first solve)
+static bool chip_trsv_shape(const dpcg_system *h, int flags, const double *x_true) {
+    if (!chip_trsv_enabled() || x_true || h->precond != DPCG_PRECOND_LLT_SOLVE || h->trsv_state < 0) return false;
+    if (flags & (DPCG_SPMV_F32 | DPCG_NO_TEAM | DPCG_NO_FUSE)) return false;
+    if (h->A.n < chip_trsv_min_rows() || h->A.n > chip_max_rows()) return false;
+    if (!chip_resident_shape(h)) return false;                       // (A resident: rows of <= 7 entries, 9 up to 524 288 rows; 16-bit column offsets)
+    if (h->L.nnz <= 0 || h->Lt.nnz <= 0) return false;
+    return true;
+}
+static void free_chip_trsv(dpcg_system *h) {
+    free_chip_trsv_lists(h->trsv_l);
+    free_chip_trsv_lists(h->trsv_u);
+    dev_free(h->trsv_lv0);
+    dev_free(h->trsv_diag0);
+    dev_free(h->trsv_fval);
+    dev_free(h->trsv_fcol);
+    dev_free(h->trsv_fmeta);
+    h->trsv_rpt = h->trsv_wmax = h->trsv_band = 0;
+}
+static int ensure_chip_trsv(dpcg_system *h, hipStream_t s) {
+    if (h->trsv_state != 0) return DPCG_OK;
+    const int64_t n = h->A.n;
+    PhaseTimer pt(s);
+    int32_t *lvl[2] = {nullptr, nullptr}, *ctl = nullptr;
+    auto done = [&](int state, int code) {
+        dev_free(lvl[0]); dev_free(lvl[1]); dev_free(ctl);
+        if (state < 0) free_chip_trsv(h);
+        h->trsv_state = state;
+        return code;
+    };
+    int st;
+    if ((st = dev_alloc(&lvl[0], n)) < 0 || (st = dev_alloc(&lvl[1], n)) < 0) return done(0, st);
+    if ((st = dev_alloc(&ctl, 4)) < 0) return done(0, st);
+    // factor index <-> handle index: the factor's own numbering (multicolour IC(0)) or the caller's (a reordered handle)
+    const int32_t *handle_of_f = h->fmap ? h->fmap : h->iperm;
+    const int32_t *f_of_handle = h->fmap ? h->fmap_inv : h->perm;
+    const int per = chip_rows_per_wg(n);
+    int nlev[2] = {0, 0};
+    for (int upper = 0; upper < 2; ++upper) {                          // dependency levels of both triangles (sync-free analysis, dpcg_analysis.hip)
+        const CsrDev &F = upper ? h->Lt : h->L;
+        DPCG_HIP(hipMemsetAsync(lvl[upper], 0xff, (size_t)n * sizeof(int32_t), s));
+        DPCG_HIP(hipMemsetAsync(ctl, 0, 4 * sizeof(int32_t), s));
+        launch_levels_syncfree(n, F.rowptr, F.col, upper != 0, lvl[upper], reinterpret_cast<unsigned int *>(ctl), ctl + 1, s);
+        if ((st = reduce_max_i32(lvl[upper], ctl + 2, n, s)) < 0) return done(0, st);
+        int32_t h_ctl[4] = {0, 0, 0, 0};
+        DPCG_HIP(hipMemcpyAsync(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
+        DPCG_HIP(hipStreamSynchronize(s));
+        if (h_ctl[1] || h_ctl[2] < 0) return done(-1, DPCG_OK);
+        nlev[upper] = h_ctl[2] + 1;
+        // Every level is a hand-off from one workgroup to another -- publish, become visible, be gathered: ~1.2 us inside an XCD, ~3 across
+        // -- and a chain of them is all a many-level solve is: measured at 216 K / 512 K rows with IC(0) in a scattered caller's order, 17 /
+        // 18 levels: 66 / 94 us per update here against 72 / 87 for the launches (whose sync-free kernels wait in the same way).  Few levels
+        // (multicolour orders: 2-9) are where this form wins (2-4 x); beyond 16 the launches keep the solve (natural orders of grids: hundreds).
+        static const int level_limit = [] { const char *e = getenv("DPCG_CHIP_TRSV_MAX_LEVELS"); return e ? std::min(atoi(e), chip_trsv_max_levels()) : 16; }();
+        if (nlev[upper] > level_limit) return done(-1, DPCG_OK);
+    }
+    h->trsv_l.n_levels = nlev[0];
+    h->trsv_u.n_levels = nlev[1];
+    pt.mark("chip trsv: levels");
+    // <= 4 rows a thread: the factor resident beside the matrix
+    static const bool resident_on = [] { const char *e = getenv("DPCG_CHIP_TRSV_RESIDENT"); return !(e && e[0] == '0'); }();
+    const int rpt = chip_trsv_resident_rpt(per), wmax = rpt ? chip_trsv_resident_wmax(h->planA.max_row_len, rpt) : 0;
+    if (resident_on && rpt && wmax) {
+        int misfit = 0, band = 0;
+        if ((st = build_chip_trsv_resident((int)n, per, rpt, wmax, h->L, h->Lt, lvl[0], lvl[1], f_of_handle, handle_of_f, &h->trsv_fval, &h->trsv_fcol,
+                                           &h->trsv_fmeta, &misfit, &band, s)) < 0)
+            return done(-1, st);
+        pt.mark("chip trsv: resident plan");
+        if (!misfit && std::max(band, h->planA.max_band) <= chip_max_band()) {
+            h->trsv_rpt = rpt;
+            h->trsv_wmax = wmax;
+            h->trsv_band = band;
+            return done(1, DPCG_OK);
+        }
+        dev_free(h->trsv_fval); dev_free(h->trsv_fcol); dev_free(h->trsv_fmeta);       // (a factor with fill: the streamed form may still take it)
+    }
+    // Beyond 524 288 rows (8 rows a thread) the factor cannot sit beside the matrix and would be STREAMED (the block lists below).  Measured at
+    // 1M rows that form loses to the launches (IC(0) in multicolour order: 66 against 58 us per update -- every dependent step of a block is a
+    // memory-side round trip of ~1.2 us, and the kernel spills): it is kept for factors the resident form refuses at <= 4 rows a thread
+    // (fill: a row's L and L^T parts beyond its slots) and, beyond, behind DPCG_CHIP_TRSV_STREAM=1 (development).
+    static const bool stream_big = [] { const char *e = getenv("DPCG_CHIP_TRSV_STREAM"); return e && e[0] == '1'; }();
+    if (!rpt && !stream_big) return done(-1, DPCG_OK);
+    if (!h->trsv_lv0 && (st = dev_alloc(&h->trsv_lv0, (int64_t)chip_workgroups() * chip_threads())) < 0) return done(0, st);
+    if (!h->trsv_diag0 && (st = dev_alloc(&h->trsv_diag0, chip_trsv_diag_doubles())) < 0) return done(0, st);
+    DPCG_HIP(hipMemsetAsync(h->trsv_lv0, 0, (size_t)chip_workgroups() * chip_threads() * sizeof(int32_t), s));
+    for (int upper = 0; upper < 2; ++upper) {
+        const CsrDev &F = upper ? h->Lt : h->L;
+        ChipTrsvLists &out = upper ? h->trsv_u : h->trsv_l;
+        if ((st = build_chip_trsv_lists((int)n, per, nlev[upper], F, lvl[upper], f_of_handle, handle_of_f, upper != 0, out, h->trsv_lv0, h->trsv_diag0, s)) < 0) return done(-1, st);
+        out.n_levels = nlev[upper];
+        if (out.max_row > chip_trsv_max_factor_row() || out.max_row > std::max(h->planA.max_row_len, 5) - 1 ||
+            std::max(out.band, h->planA.max_band) > chip_max_band())
+            return done(-1, DPCG_OK);
+        pt.mark(upper ? "chip lists (L^T)" : "chip lists (L)");
+    }
+    return done(1, DPCG_OK);
+}
+
+static int solve_chip_trsv_one(dpcg_system *h, const double *b, const double *x0, double *x, double rtol_sq, double atol_sq,
+                               int max_iter, int flags, hipStream_t s, int *iters, double *final_res, double *seconds,
+                               double *res_history) {
+    const int64_t n = h->A.n;
+    DPCG_TRY(ensure_chip_trsv(h, s));
+    if (h->trsv_state != 1) return DPCG_ERR_STATE;                 // this factor keeps the launches
+    DPCG_TRY(ensure_work(h, max_iter, false, false));
+    const int kSlots = chip_slot_doubles();
+    if (!h->chip_part) DPCG_TRY(dev_alloc(&h->chip_part, kSlots + 8 * 256 + 2 + 128));
+    if (!h->chip_zp) DPCG_TRY(dev_alloc(&h->chip_zp, chip_zp_doubles(n)));
+    if (!h->chip_rt) DPCG_TRY(dev_alloc(&h->chip_rt, 2 * chip_zp_doubles(n)));
+    if (h->perm) {
+        if (!h->pb) DPCG_TRY(dev_alloc(&h->pb, n));
+        launch_gather_f64(n, h->perm, b, h->pb, s);
+        b = h->pb;
+        if (x0) {
+            launch_gather_f64(n, h->perm, x0, h->t, s);
+            x0 = h->t;
+        }
+    }
+    ChipTrsvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.n = (int)n;
+    d.max_iter = max_iter;
+    d.init_check_r = (flags & DPCG_INIT_CHECK_R) ? 1 : 0;
+    d.hist_cap = h->hist_cap;
+    d.per = chip_rows_per_wg(n);
+    d.band = std::max(h->planA.max_band, h->trsv_rpt ? h->trsv_band : std::max(h->trsv_l.band, h->trsv_u.band));
+    d.rp = h->A.rowptr; d.ci = h->A.col; d.val = h->A.val;
+    d.b = b; d.x0 = x0;
+    d.x = (x && !h->perm) ? x : h->x;
+    d.hist = h->hist;
+    d.zp = h->chip_zp;
+    d.ypub = h->chip_rt;
+    d.zpub = h->chip_rt + chip_zp_doubles(n);
+    d.first_l = h->trsv_l.first_blk; d.first_u = h->trsv_u.first_blk;
+    d.blk_l = h->trsv_l.blk; d.blk_u = h->trsv_u.blk;
+    d.val_l = h->trsv_l.val; d.val_u = h->trsv_u.val;
+    d.col_l = h->trsv_l.col; d.col_u = h->trsv_u.col;
+    d.nent_l = h->trsv_l.n_ent; d.nent_u = h->trsv_u.n_ent;
+    d.lv0 = h->trsv_lv0; d.diag0 = h->trsv_diag0;
+    d.fval = h->trsv_fval; d.fcol = h->trsv_fcol; d.fmeta = h->trsv_fmeta;
+    d.nlev_l = h->trsv_l.n_levels; d.nlev_u = h->trsv_u.n_levels;
+    const bool resident = h->trsv_rpt != 0;
+    auto launch = [&](bool check_only) {
+        return resident ? launch_pcg_chip_trsv_resident(d, h->trsv_rpt, h->trsv_wmax, s, check_only)
+                        : launch_pcg_chip_trsv(d, h->planA.max_row_len, std::max(h->trsv_l.max_row, h->trsv_u.max_row), s, check_only);
+    };
+    d.rtol_sq = rtol_sq; d.atol_sq = atol_sq;
+    d.out = h->scal;
+    d.part = h->chip_part;
+    d.err = reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256);
+    static const bool plain_ok = [] { const char *e = getenv("DPCG_CHIP_LOCAL"); return !(e && e[0] == '0'); }();
+    d.xcc = plain_ok ? reinterpret_cast<int *>(h->chip_part + kSlots + 8 * 256 + 2) : nullptr;
+    static std::atomic<unsigned> launch_nonce{0x40000000u};
+    unsigned nonce = 0;
+    do { nonce = ++launch_nonce; } while (nonce == 0);
+    d.nonce = nonce;
+    static const bool trace = [] { const char *e = getenv("DPCG_CHIP_TRACE"); return e && e[0] == '1'; }();
+    unsigned long long *dbg = nullptr;
+    if (trace) {
+        DPCG_TRY(dev_alloc(&dbg, 256 * 64));
+        d.dbg = dbg;
+    }
+    const int st0 = launch(true);
+    if (st0 != DPCG_OK) return st0;
+    launch_fill_pending(h->chip_part, kSlots, s);
+    DPCG_HIP(hipMemsetAsync(d.err, 0, 2 * sizeof(int), s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    std::lock_guard<std::mutex> one_team_launch(team_launch_mutex());
+    static hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const char *ev_env = getenv("DPCG_CHIP_EVENTS");
+    const bool events = ev_env && ev_env[0] == '1';
+    if (events && !ev0) {
+        DPCG_HIP(hipEventCreate(&ev0));
+        DPCG_HIP(hipEventCreate(&ev1));
+    }
+    const auto t0 = std::chrono::steady_clock::now();                                // cg.py:69 (the launch is the loop)
+    if (events) DPCG_HIP(hipEventRecord(ev0, s));
+    DPCG_TRY(launch(false));
+    if (events) DPCG_HIP(hipEventRecord(ev1, s));
+    DPCG_HIP(hipMemcpyAsync(h->scal_host, h->scal, sizeof(Scalars), hipMemcpyDeviceToHost, s));
+    DPCG_HIP(hipStreamSynchronize(s));
+    const auto t1 = std::chrono::steady_clock::now();                                // cg.py:88
+    if (events) {
+        float ms = 0.0f;
+        DPCG_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        h->chip_trace_x[5] = (double)ms;
+    }
+    DPCG_CHECK_LAUNCH();
+    const Scalars sc = *h->scal_host;
+    if (sc.status < 0) {
+        co_residency().timed_out();
+        set_error("chip solve (triangular solves): a workgroup waited (20 ms) for one that never became resident");
+        return sc.status;
+    }
+    co_residency().launched_fine();
+    if (dbg) {                                                 // us per update by phase of the apply: mean and slowest wave of the chip
+        std::vector<unsigned long long> w(256 * 64);
+        DPCG_HIP(hipMemcpy(w.data(), dbg, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        dev_free(dbg);
+        const double us = sc.k > 0 ? 0.01 / (sc.k + 1) : 0.0;   // (the applies: one per update and the first)
+        static const char *names[8] = {"L sweep+prologue", "L blocks", "L polling again", "L^T sweep+prologue", "L^T blocks", "L^T polling again", "wait behind the apply", "blocks that polled again (count per apply)"};
+        fprintf(stderr, "[dpcg chip trsv] %d updates; us per apply by phase, mean over the 2048 waves / slowest wave:\n", sc.k);
+        for (int ph = 0; ph < 8; ++ph) {
+            double sum = 0, mx = 0;
+            for (int wv = 0; wv < 2048; ++wv) {
+                const double val = (double)w[(size_t)wv * 8 + ph] * (ph == 7 ? (sc.k > 0 ? 1.0 / (sc.k + 1) : 0.0) : us);
+                sum += val;
+                mx = std::max(mx, val);
+            }
+            fprintf(stderr, "    %-44s %8.2f / %8.2f\n", names[ph], sum / 2048, mx);
+        }
+    }
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    if (iters) *iters = sc.k;
+    if (final_res) *final_res = sc.res;
+    bool pending = false;
+    if (res_history) {
+        DPCG_HIP(hipMemcpyAsync(res_history, h->hist, (size_t)(sc.k + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+        pending = true;
+    }
+    if (x && h->perm) launch_scatter_f64(n, h->perm, h->x, x, s);
+    if (pending) DPCG_HIP(hipStreamSynchronize(s));
+    return sc.status;
+}
+
 extern "C" int dpcg_debug_occupy(int workgroups, double milliseconds, dpcg_stream_t stream) {
     if (workgroups < 1 || workgroups > 4096 || !(milliseconds > 0.0) || milliseconds > 2000.0) return invalid("dpcg_debug_occupy: bad arguments");
     DPCG_TRY(launch_occupy(workgroups, milliseconds, (hipStream_t)stream));
@@ -1032,7 +1278,8 @@ extern "C" int dpcg_debug_l2_gather(int granules_per_group, int reps, const int3
 
 extern "C" int dpcg_get_chip_info(dpcg_handle_t h, int32_t out[8], double trace_us[8]) {
     if (!h || !out) return invalid("dpcg_get_chip_info: NULL argument");
-    const bool el = chip_eligible(h, 0, nullptr) || chip_llt_eligible(h, 0, nullptr);
+    if (chip_trsv_shape(h, 0, nullptr) && h->trsv_state == 0) (void)ensure_chip_trsv(h, nullptr);     // (whether the factor fits is known once its lists exist)
+    const bool el = chip_eligible(h, 0, nullptr) || chip_llt_eligible(h, 0, nullptr) || (chip_trsv_shape(h, 0, nullptr) && h->trsv_state == 1);
     out[0] = el ? (chip_default(h, 0) ? 2 : 1) : 0;          // 2: a plain dpcg_solve takes the chip kernel
     out[1] = chip_workgroups();
     out[2] = chip_threads();
@@ -1085,6 +1332,12 @@ extern "C" int dpcg_solve(dpcg_handle_t h, const double *b, const double *x0, do
                                       seconds, res_history);
         if (st != DPCG_ERR_STATE) return st;
         // the workgroups never became co-resident, or the kernel was refused up front: the multi-launch path needs no such thing
+    }
+    if (one_launch_open && chip_trsv_shape(h, flags, x_true) && ((flags & DPCG_TEAM) || chip_default(h, flags))) {
+        const int st = solve_chip_trsv_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
+                                           seconds, res_history);
+        if (st != DPCG_ERR_STATE) return st;
+        // (the factor does not fit the form -- too many levels, rows too long -- or the workgroups never became co-resident: the launches)
     }
     if (one_launch_open && chip_llt_eligible(h, flags, x_true) && ((flags & DPCG_TEAM) || chip_default(h, flags))) {
         const int st = solve_chip_llt_one(h, b, x0, x, rtol_sq, atol_sq, max_iter, flags, (hipStream_t)stream, iters, final_res,
