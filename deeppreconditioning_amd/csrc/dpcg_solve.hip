@@ -1050,14 +1050,15 @@ static int ensure_chip_trsv(dpcg_system *h, hipStream_t s) {
         // -- and a chain of them is all a many-level solve is: measured at 216 K / 512 K rows with IC(0) in a scattered caller's order, 17 /
         // 18 levels: 66 / 94 us per update here against 72 / 87 for the launches (whose sync-free kernels wait in the same way).  Few levels
         // (multicolour orders: 2-9) are where this form wins (2-4 x); beyond 16 the launches keep the solve (natural orders of grids: hundreds).
-        static const int level_limit = [] { const char *e = getenv("DPCG_CHIP_TRSV_MAX_LEVELS"); return e ? std::min(atoi(e), chip_trsv_max_levels()) : 16; }();
+        // (the three development knobs of this routine are read per plan, not per process: a plan is built once per preconditioner)
+        const int level_limit = [] { const char *e = getenv("DPCG_CHIP_TRSV_MAX_LEVELS"); return e ? std::min(atoi(e), chip_trsv_max_levels()) : 16; }();
         if (nlev[upper] > level_limit) return done(-1, DPCG_OK);
     }
     h->trsv_l.n_levels = nlev[0];
     h->trsv_u.n_levels = nlev[1];
     pt.mark("chip trsv: levels");
     // <= 4 rows a thread: the factor resident beside the matrix
-    static const bool resident_on = [] { const char *e = getenv("DPCG_CHIP_TRSV_RESIDENT"); return !(e && e[0] == '0'); }();
+    const bool resident_on = [] { const char *e = getenv("DPCG_CHIP_TRSV_RESIDENT"); return !(e && e[0] == '0'); }();
     const int rpt = chip_trsv_resident_rpt(per), wmax = rpt ? chip_trsv_resident_wmax(h->planA.max_row_len, rpt) : 0;
     if (resident_on && rpt && wmax) {
         int misfit = 0, band = 0;
@@ -1077,7 +1078,7 @@ static int ensure_chip_trsv(dpcg_system *h, hipStream_t s) {
     // 1M rows that form loses to the launches (IC(0) in multicolour order: 66 against 58 us per update -- every dependent step of a block is a
     // memory-side round trip of ~1.2 us, and the kernel spills): it is kept for factors the resident form refuses at <= 4 rows a thread
     // (fill: a row's L and L^T parts beyond its slots) and, beyond, behind DPCG_CHIP_TRSV_STREAM=1 (development).
-    static const bool stream_big = [] { const char *e = getenv("DPCG_CHIP_TRSV_STREAM"); return e && e[0] == '1'; }();
+    const bool stream_big = [] { const char *e = getenv("DPCG_CHIP_TRSV_STREAM"); return e && e[0] == '1'; }();
     if (!rpt && !stream_big) return done(-1, DPCG_OK);
     if (!h->trsv_lv0 && (st = dev_alloc(&h->trsv_lv0, (int64_t)chip_workgroups() * chip_threads())) < 0) return done(0, st);
     if (!h->trsv_diag0 && (st = dev_alloc(&h->trsv_diag0, chip_trsv_diag_doubles())) < 0) return done(0, st);

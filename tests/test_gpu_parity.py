@@ -3076,8 +3076,117 @@ def test_chip_solve_with_everything_written_through(D):
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
+def _factor_for_oracle(S, A, perm, ordering):
+    """The factor the handle solves with, restated on the CPU, and how the oracle addresses it from the system the handle iterates on."""
+    n = A.shape[0]
+    if ordering == "multicolor":
+        nc, q = S.precond_ordering()
+        Lf = CO.ic0(_permuted(A, q))
+        qinv = np.empty(n, dtype=np.int32)
+        qinv[q] = np.arange(n, dtype=np.int32)
+        return Lf, dict(precond_perm=qinv[perm] if perm is not None else qinv)
+    return CO.ic0(A), (dict(precond_perm=perm) if perm is not None else {})
+
+
+@pytest.mark.parametrize("name,make,ordering,env", [
+    ("poisson2d_256", lambda: O.poisson2d(256), "multicolor", {}),                                      # BASELINE config 2's system: one row a thread, 5 entries
+    ("poisson3d_41", lambda: O.poisson3d(41), "multicolor", {}),                                        # 68 921 rows: most threads of a workgroup without a row
+    ("unstructured3d_60", lambda: O.unstructured_like(O.poisson3d(60), seed=1), "multicolor", {}),      # reordered inside the library; two rows a thread
+    ("unstructured3d_60", lambda: O.unstructured_like(O.poisson3d(60), seed=1), "caller", {"DPCG_CHIP_TRSV_MAX_LEVELS": "32"}),   # 17 levels (beyond the default limit)
+    ("unstructured3d_80", lambda: O.unstructured_like(O.poisson3d(80), seed=0), "multicolor", {}),      # 512 000 rows: four rows a thread -- the resident form's capacity
+    ("quadtree_random_400", lambda: O.quadtree_fv_laplacian(400, 5, numbering="random"), "multicolor", {}),   # rows of 2 .. 9 entries, four colours
+    ("quadtree_random_400", lambda: O.quadtree_fv_laplacian(400, 5, numbering="random"), "caller", {}),       # ... its caller's order: 13 levels
+    ("unstructured3d_60", lambda: O.unstructured_like(O.poisson3d(60), seed=1), "multicolor", {"DPCG_CHIP_TRSV_RESIDENT": "0"}),   # the STREAMED form (block lists)
+    ("quadtree_random_400", lambda: O.quadtree_fv_laplacian(400, 5, numbering="random"), "caller", {"DPCG_CHIP_TRSV_RESIDENT": "0"})])
+def test_chip_trsv_solve_equals_the_device_tree_oracle_bit_for_bit(D, monkeypatch, name, make, ordering, env):
+    """M = (L L^T)^-1 applied by two triangular solves (IC(0) solved with: test.py:81-88 taken as a solve; BASELINE config 3's "level-scheduled
+    L / L^T trisolve") in ONE launch on the whole chip (dpcg_chip_trsv.hip): up to 524 288 rows the factor sits in the LDS beside the
+    matrix in registers, rows solved level by level, y and z handed over as self-validating granules; the streamed form (block lists)
+    for factors the resident one refuses.  Against the C oracle -- sequential substitution, dot products in the whole-chip tree -- history,
+    count and x EQUAL, x0 and a capped run included; the multi-launch path agrees to 1e-10 where the recurrence is stable."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    A = make()
+    n = A.shape[0]
+    S = D.CsrSystem.from_any(A)
+    perm = S.permutation() if S.reordered else None
+    B = _permuted(A, perm) if perm is not None else A
+    b = O.rhs(n, 0)
+    bb = b[perm] if perm is not None else b
+    S.set_preconditioner(D.IC0("solve", ordering=ordering) if ordering == "multicolor" else D.IC0("solve"))
+    ci = S.chip_info()
+    assert ci["chip_by_default"], (ci, S.info())
+    Lf, kw = _factor_for_oracle(S, A, perm, ordering)
+    tree = _chip_tree(S)
+    res = S.solve(_dev(b))
+    multi = S.solve(_dev(b), flags=D._lib.NO_SMALL)
+    _, it, hist, x = CO.pcg(B, bb, "llt_solve", L=Lf, device_tree=tree, **kw)
+    assert res.iterations == it == multi.iterations and res.status == multi.status == 0, (name, res.iterations, it, multi.iterations)
+    assert np.array_equal(res.res_history, hist), (name, int(np.argmax(res.res_history != hist)))
+    xs = res.x.cpu().numpy()
+    assert np.array_equal(xs[perm] if perm is not None else xs, x), name
+    np.testing.assert_allclose(multi.res_history[:25], hist[:25], rtol=1e-10)
+    assert not np.array_equal(multi.res_history, res.res_history)             # (another summation order: it WAS the other path)
+    again = S.solve(_dev(b))
+    assert np.array_equal(again.res_history, res.res_history) and torch.equal(again.x, res.x)     # reproducible to the bit
+    # a start vector, caps, the first test on r
+    x0 = O.rhs(n, 5)
+    x0p = x0[perm] if perm is not None else x0
+    for max_iter in (0, 1, 7):
+        r0 = S.solve(_dev(b), x0=_dev(x0), max_iter=max_iter)
+        _, it0, hist0, xo = CO.pcg(B, bb, "llt_solve", L=Lf, x0=x0p, max_iter=max_iter, device_tree=tree, **kw)
+        assert r0.iterations == it0 and r0.status == 1 and np.array_equal(r0.res_history, hist0), (name, max_iter)
+        xr = r0.x.cpu().numpy()
+        assert np.array_equal(xr[perm] if perm is not None else xr, xo)
+    rr = S.solve(_dev(b), flags=D._lib.INIT_CHECK_R, rtol_sq=1e-6)
+    _, itr, histr, _ = CO.pcg(B, bb, "llt_solve", L=Lf, rtol=1e-6, init_check="r", device_tree=tree, **kw)
+    assert rr.iterations == itr and np.array_equal(rr.res_history, histr)
+    # new values on the same pattern: the plan follows the factor
+    if name == "poisson3d_41":
+        A2 = A.copy()
+        A2.data = A2.data * np.where(A2.indices == np.repeat(np.arange(n), np.diff(A2.indptr)), 1.5, 1.0)
+        S.update_values(A2.data)
+        S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+        assert S.chip_info()["chip_by_default"]
+        Lf2, kw2 = _factor_for_oracle(S, A2, perm, ordering)
+        r2 = S.solve(_dev(b))
+        _, it2, hist2, _ = CO.pcg(A2, b, "llt_solve", L=Lf2, device_tree=_chip_tree(S), **kw2)
+        assert r2.iterations == it2 and np.array_equal(r2.res_history, hist2)
+    S.close()
+
+
+def test_chip_trsv_keeps_off_what_it_cannot_take(D):
+    """What stays on the launches: natural orders of grids (hundreds of levels: every level is a hand-off), factors with fill whose rows do not
+    fit the slots (icholt), systems beyond the resident form's 524 288 rows, mixed precision; and the flags of the other forms."""
+    A = O.poisson3d(41)
+    b = _dev(O.rhs(A.shape[0], 0))
+    S = D.CsrSystem.from_any(A, reorder=None)
+    S.set_preconditioner(D.IC0("solve"))                                       # natural order: 121 levels
+    assert S.info()["levels_lower"] > 16 and not S.chip_info()["chip_by_default"]
+    ref = S.solve(b, flags=D._lib.NO_SMALL)
+    res = S.solve(b)
+    assert np.array_equal(res.res_history, ref.res_history)                    # the plain call IS the launches
+    S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+    assert S.chip_info()["chip_by_default"]
+    chip = S.solve(b)
+    for flags in (D._lib.NO_SMALL, D._lib.NO_TEAM, D._lib.NO_FUSE, D._lib.NO_GRAPH, D._lib.SPMV_F32):
+        other = S.solve(b, flags=flags)
+        assert other.status == 0 and not np.array_equal(other.res_history, chip.res_history), flags
+    S.set_preconditioner(D.ICholT("solve", add_fill_in=1, threshold=0.01))     # fill beyond the pattern of A: rows of L and L^T beyond the slots
+    rf = S.solve(b)
+    rl = S.solve(b, flags=D._lib.NO_SMALL)
+    assert rf.status == 0 and rf.iterations == rl.iterations
+    np.testing.assert_allclose(rf.res_history, rl.res_history, rtol=1e-8)
+    S.close()
+    big = D.CsrSystem.from_any(O.unstructured_like(O.poisson3d(100), seed=0))
+    big.set_preconditioner(D.IC0("solve", ordering="multicolor"))
+    assert not big.chip_info()["chip_by_default"]                              # 1M rows: eight rows a thread -- the factor does not fit beside the matrix
+    big.close()
+
+
 @pytest.mark.parametrize("name,make,form", [("poisson2d_150", lambda: O.poisson2d(150), "team"),
-                                            ("poisson3d_64", lambda: O.poisson3d(64), "chip")])
+                                            ("poisson3d_64", lambda: O.poisson3d(64), "chip"),
+                                            ("poisson3d_64", lambda: O.poisson3d(64), "chip_trsv")])
 def test_one_launch_solves_when_somebody_else_holds_cus(D, name, make, form):
     """The one-launch solves (team: 4 097 .. 65 536 rows; chip: up to 1 048 576) need their workgroups co-resident.  A plain launch
     cannot promise that when a long-running kernel of another stream holds CUs -- here 96 workgroups that take a whole CU each for
@@ -3089,7 +3198,7 @@ def test_one_launch_solves_when_somebody_else_holds_cus(D, name, make, form):
     n = A.shape[0]
     b = _dev(O.rhs(n, 2))
     S = D.CsrSystem.from_any(A, reorder=None)
-    S.set_preconditioner(D.Jacobi())
+    S.set_preconditioner(D.IC0("solve", ordering="multicolor") if form == "chip_trsv" else D.Jacobi())
     if form == "team":
         assert S.reduction_geometry()["team_by_default"]
     else:
