@@ -94,22 +94,23 @@ def l2_gather_ceiling(system, offsets) -> dict:
     """What the chip delivers for the access the whole-chip kernel's SpMV phase makes, with nothing else going on (dpcg_debug_l2_gather: the
     same 256 x 512 geometry and placement, a table of n / 8 sixteen-byte granules per XCD stored plainly by that XCD's workgroups, every
     thread gathering 8 x 7 granules per pass at the system's own column offsets with agent-scope loads): GB/s of gathered bytes with two rows'
-    gathers in flight per lane (what the solve kernel's registers hold) and with four, and with the table written through (every gather
-    then leaves the L2 for the memory side: what the cross-XCD copy costs)."""
+    gathers in flight per lane (what the solve kernel's registers hold) and with four, and gathering the NEIGHBOURING XCD's part of a table
+    that was written through (every gather then leaves the L2 for the memory side: the path of the granules another XCD owns)."""
     import ctypes as C
     from deeppreconditioning_amd import _lib as L
     per_group = max(((system.n // 8) // 32) * 32, 32 * 512)
     offs = (C.c_int32 * 7)(*[int(o) for o in offsets])
     out = {"granules_per_xcd": per_group, "table_bytes_per_xcd": per_group * 16, "offsets_in_granules": [int(o) for o in offsets],
            "bytes_per_pass": 256 * 512 * 8 * 7 * 16}
-    for key, depth, wt in (("plain_depth2", 2, 0), ("plain_depth4", 4, 0), ("written_through_depth2", 2, 1)):
+    for key, depth, wt in (("plain_depth2", 2, 0), ("plain_depth4", 4, 0), ("other_xcd_written_through_depth2", 2, 2)):
         best = 0.0
         for _ in range(3):
             gbs, us, loc = C.c_double(), C.c_double(), C.c_int()
             L.check(L.lib().dpcg_debug_l2_gather(per_group, 40 if wt else 200, offs, depth, wt, None, C.byref(gbs), C.byref(us), C.byref(loc)))
             best = max(best, gbs.value)
         out[key] = round(best, 1)
-        out["groups_on_one_xcd"] = bool(loc.value)
+        if not wt:
+            out["groups_on_one_xcd"] = bool(loc.value)
     return out
 
 
@@ -874,8 +875,37 @@ def extra_workloads(D, poisson, torch) -> dict:
     s3n.set_preconditioner(D.IC0("solve"))
     r = solve_twice(s3n, b3)
     c3["not_reordered"]["ic0_solve_us_per_update"] = round(r.seconds / r.iterations * 1e6, 1)
+    c3["time_to_solution_ms"] = {k: c3[k]["ms"] for k in ("jacobi", "ic0_multicolor_solve", "ic0_solve")}
+    c3["triangular_solve_form"] = ("launches: at 1M rows (8 rows a thread) the factor does not fit on the chip beside the matrix, and the streamed "
+                                   "one-launch form loses to the launches (66 against 58 us per update) -- see c3_unstructured3d_80 for the resident form")
     out["c3_unstructured3d_100"] = c3
     del s3, s3n, A
+    # config 3 at the capacity of the one-launch kernel WITH the triangular solves inside (dpcg_chip_trsv.hip: <= 524 288 rows, matrix in
+    # registers, L / L^T in LDS): the same stand-in at 80^3 = 512 000 rows, and the 216 000-row one; plain calls, the launches beside them
+    for tag, grid in (("c3_unstructured3d_80", 80), ("c3_unstructured3d_60", 60)):
+        Ah = poisson.unstructured_like_csr(3, grid, 0)
+        sh = D.CsrSystem.from_any(Ah)
+        bh = poisson.rhs(sh.n, 0)
+        ch = {"dof": sh.n, "nnz": sh.nnz, "reordered": sh.info()["reordered"]}
+        for name, pc in (("jacobi", D.Jacobi()), ("ic0_multicolor_solve", D.IC0("solve", ordering="multicolor")), ("ic0_solve", D.IC0("solve"))):
+            sh.set_preconditioner(pc)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sh.set_preconditioner(pc)
+            one_launch = sh.chip_info()["chip_by_default"]            # (for the triangular solves this also builds the kernel's plan: part of the setup)
+            torch.cuda.synchronize()
+            setup_ms = (time.perf_counter() - t0) * 1e3
+            r = solve_twice(sh, bh)
+            rl = solve_twice(sh, bh, flags=D._lib.NO_SMALL)
+            ch[name] = {"iterations": r.iterations, "one_launch": bool(one_launch), "ms": round(r.seconds * 1e3, 3),
+                        "us_per_update": round(r.seconds / r.iterations * 1e6, 2), "iterations_per_s": round(r.iterations / r.seconds, 1),
+                        "setup_ms": round(setup_ms, 2), "levels": sh.info()["levels_lower"] if name != "jacobi" else None,
+                        "launches_us_per_update": round(rl.seconds / rl.iterations * 1e6, 2), "launches_ms": round(rl.seconds * 1e3, 3)}
+        ch["time_to_solution_ms"] = {k: ch[k]["ms"] for k in ("jacobi", "ic0_multicolor_solve", "ic0_solve")}
+        ch["time_to_solution_launches_ms"] = {k: ch[k]["launches_ms"] for k in ("jacobi", "ic0_multicolor_solve", "ic0_solve")}
+        out[tag] = ch
+        sh.close()
+        del sh, Ah
     out.update(mesh_workloads(D, poisson, torch, solve_twice, pmc_all))
     # config 5: mixed fp32 SpMV / fp64 everything else on the headline system
     s5 = poisson.poisson_system(3, 100)

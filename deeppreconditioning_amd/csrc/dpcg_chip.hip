@@ -41,6 +41,7 @@
 // Row sums run in CSR order and every dot product in a fixed tree (restated by the tests' CPU checker, form "chip"), so history, count and
 // x equal the CPU restatement's bit for bit.
 #include <algorithm>
+#include <type_traits>
 
 #include "dpcg_chip_device.h"
 
@@ -64,9 +65,14 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     // but q = A p streams the workgroup's CSR every update, wave by wave (see spmv_stream below).
     constexpr bool STREAM = MODE == 5 || MODE == 6;                           // (WMAX then carries the ring's group size, see SU below)
     constexpr int NS = RPT * WMAX;                                   // entry slots of a thread
-    constexpr int NLDS = NS < kChipLdsSlots ? NS : kChipLdsSlots;    // ... whose values live in LDS
+    // (MODE 4 -- config 5: the values ARE fp32 numbers, and they are STORED as such: 4-byte slots, twice as many in the same LDS -- rows of
+    // 9 entries at 8 rows a thread, i.e. the 1M-row finite-volume meshes, resident)
+    constexpr bool F32_SLOTS = MODE == 4;
+    constexpr int kLdsCap = F32_SLOTS ? 2 * kChipLdsSlots : kChipLdsSlots;
+    constexpr int NLDS = NS < kLdsCap ? NS : kLdsCap;                // ... whose values live in LDS
     constexpr int NREG = NS - NLDS;                                  // ... and in registers (the first NREG slots)
-    extern __shared__ __attribute__((aligned(16))) double chip_lv[];   // [NLDS][512]: slot s of thread t at [(s - NREG) * 512 + t]
+    extern __shared__ __attribute__((aligned(16))) double chip_lv[];   // [NLDS][512]: slot s of thread t at [(s - NREG) * 512 + t] (fp32 slots: floats)
+    float *const chip_lf = reinterpret_cast<float *>(chip_lv);
     __shared__ double sh[2 * 16];          // block sums: two halves used in turn, 2 x 8 wave sums each
     __shared__ double s_res[2][2];         // the reduced pair, two sets in turn
     __shared__ int s_flag;
@@ -87,8 +93,9 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     unsigned dl[(NS + 1) / 2];
     constexpr int LB = WMAX > 7 ? 8 : 4;    // bits per row in `lens`: the top one = the row exists, below it the length
     constexpr unsigned LV = 1u << (LB - 1), LM = LV - 1u;
-    static_assert(LB * RPT <= 32, "row lengths of a thread in one register");
-    unsigned lens = 0;
+    static_assert(LB * RPT <= 64, "row lengths of a thread in one or two registers");
+    typedef typename std::conditional<(LB * RPT > 32), unsigned long long, unsigned>::type lens_t;
+    lens_t lens = 0;
     double x[RPT], r[RPT], p[RPT], q[RPT], dv[JAC ? RPT : 1];
     double bb_loc = 0.0;
     // (unconditional loads from clamped addresses -- a predicated load is a branch with a wait of its own, and 56 of them in a row
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         const double di = JAC ? d.dinv[ic] : 1.0;
         rs_k[k] = rs;
         len_k[k] = valid ? re - rs : 0;
-        lens |= (valid ? (LV | (STREAM ? 0u : (unsigned)(re - rs))) : 0u) << (LB * k);
+        lens |= (lens_t)(valid ? (LV | (STREAM ? 0u : (unsigned)(re - rs))) : 0u) << (LB * k);
         x[k] = valid ? xi : 0.0;
         r[k] = valid ? bi : 0.0;
         p[k] = q[k] = 0.0;
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-        if ((lens >> (LB * k)) & LV) bb_loc += r[k] * r[k];
+        if ((unsigned)(lens >> (LB * k)) & LV) bb_loc += r[k] * r[k];
         if (STREAM) continue;
         const int i = row0 + k * kChipThreads;
         int cj[WMAX];
@@ -134,12 +141,13 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
             if (s & 1) dl[s >> 1] |= del << 16;
             else dl[s >> 1] = del;
             if (s < NREG) vr[s < NREG ? s : 0] = a;
+            else if (F32_SLOTS) chip_lf[(s - NREG) * kChipThreads + t] = (float)a;
             else chip_lv[(s - NREG) * kChipThreads + t] = a;
         }
         __builtin_amdgcn_sched_barrier(0);
     }
     bool local = false;                     // every group on one XCD (established below, once per solve)
-    auto row_on = [&](int k) -> bool { return ((lens >> (LB * k)) & LV) != 0; };
+    auto row_on = [&](int k) -> bool { return ((unsigned)(lens >> (LB * k)) & LV) != 0; };
 
     // q = A p_{k} for the own rows; the gathered entries of p_k are recomputed from the published granules {z_k, p_{k-1}}.
     // All WMAX gathers of a row are in flight together, the next row's are issued while this row's are consumed (the compiler
@@ -151,6 +159,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         int tl = t;
         asm volatile("" : "+v"(tl));
         const double *lvt = chip_lv + tl;
+        const float *lft = chip_lf + tl;
         int glo_l = glo, span_l = local ? ghi - glo : 0;
         const int local_shift = grp * 128;
         asm volatile("" : "+s"(glo_l), "+s"(span_l));            // (and the 56 `own` lane masks)
@@ -174,12 +183,12 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip(const ChipDesc d) {
         for (int k = 0; k < RPT; ++k) {
             if (k + 1 < RPT) request(k + 1, g[(k + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);                     // (keeps the scheduler from hoisting every row's gathers to the top:
-            const int len = (int)((lens >> (LB * k)) & LM);        //  two rows' granules in flight is what the registers hold)
+            const int len = (int)((unsigned)(lens >> (LB * k)) & LM);        //  two rows' granules in flight is what the registers hold)
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < WMAX; ++j) {
                 const int s = k * WMAX + j;
-                const double a = s < NREG ? vr[s < NREG ? s : 0] : lvt[(s - NREG) * kChipThreads];
+                const double a = s < NREG ? vr[s < NREG ? s : 0] : (F32_SLOTS ? (double)lft[(s - NREG) * kChipThreads] : lvt[(s - NREG) * kChipThreads]);
                 const double pc64 = lo_f64(g[k & 1][j]) + beta * hi_f64(g[k & 1][j]);  // = p_k[c], cg.py:83
                 const double pc = F32 ? (double)(float)pc64 : pc64;
                 if (j < len) acc += a * pc;
@@ -536,11 +545,12 @@ __global__ __launch_bounds__(kBlock) void k_band_and_len(int64_t n, const int32_
 template <int RPT, int WMAX, bool JAC, int MODE>
 int chip_launch(const ChipDesc &d, hipStream_t s, bool check_only) {
     constexpr int NS = RPT * WMAX;
-    constexpr int NLDS = NS < kChipLdsSlots ? NS : kChipLdsSlots;
+    constexpr int kLdsCap = MODE == 4 ? 2 * kChipLdsSlots : kChipLdsSlots;        // (MODE 4: 4-byte value slots)
+    constexpr int NLDS = NS < kLdsCap ? NS : kLdsCap;
     // (MODE 5: the product buffer of one slot, the rows' offsets and lengths, the bounds of the runs; the attribute and the occupancy
     // are those of the largest buffer the form admits)
     const int lds_max5 = chip_stream_max_row_len() * kChipThreads * (int)sizeof(double) + RPT * kChipThreads * 8 + 1024 + (kChipThreads / 64) * kChipStreamGroups * 16;
-    const int lds = (MODE == 5 || MODE == 6) ? (kChipThreads / 64) * d.stream_cap * (int)sizeof(double) + RPT * kChipThreads * 8 + 1024 + (kChipThreads / 64) * kChipStreamGroups * 16 : NLDS * kChipThreads * (int)sizeof(double);
+    const int lds = (MODE == 5 || MODE == 6) ? (kChipThreads / 64) * d.stream_cap * (int)sizeof(double) + RPT * kChipThreads * 8 + 1024 + (kChipThreads / 64) * kChipStreamGroups * 16 : NLDS * kChipThreads * (MODE == 4 ? (int)sizeof(float) : (int)sizeof(double));
     const int lds_attr = (MODE == 5 || MODE == 6) ? lds_max5 : lds;
     static int resident = -1;              // workgroups the occupancy query admits per CU (once per instantiation)
     if (resident < 0) {
@@ -603,6 +613,7 @@ __global__ __launch_bounds__(kChipThreads) void k_l2_gather_probe(double *table,
     const int v = grp * (kChipWGs / 8) + rank;
     const int per = per_group / (kChipWGs / 8);                 // granules a workgroup writes
     const int glo = grp * per_group;
+    const int rglo = sc1_only == 2 ? ((grp + 1) & 7) * per_group : glo;      // (2: gather the part the NEXT group wrote through -- another XCD's)
     const __amdgpu_buffer_rsrc_t rs = chip_rsrc(table, 8u * (unsigned)per_group * 16u);
     Exchange X;
     X.part_rs = chip_rsrc(part, (unsigned)kChipSlotBytes);
@@ -634,7 +645,7 @@ __global__ __launch_bounds__(kChipThreads) void k_l2_gather_probe(double *table,
             for (int j = 0; j < W; ++j) {
                 int c = row[k] + off[j];
                 c = c < 0 ? c + per_group : (c >= per_group ? c - per_group : c);
-                gk[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (glo + c) * 16, 0, kSc1);
+                gk[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (rglo + c) * 16, 0, kSc1);
             }
         };
 #pragma unroll
@@ -657,7 +668,7 @@ __global__ __launch_bounds__(kChipThreads) void k_l2_gather_probe(double *table,
 }  // namespace
 
 // reps passes of 256 x 512 x 8 x 7 sixteen-byte gathers; out_ticks: 256 words; xcc: 257 ints ([256] <- the groups sat on one XCD each)
-int launch_l2_gather_probe(double *table, int per_group, int reps, const int *offs7_dev, int depth, bool sc1_only, double *part, int *err, int *xcc,
+int launch_l2_gather_probe(double *table, int per_group, int reps, const int *offs7_dev, int depth, int sc1_only, double *part, int *err, int *xcc,
                            unsigned long long *ticks, unsigned *sink, hipStream_t s) {
     if (per_group < kChipThreads * (kChipWGs / 8) || per_group % (kChipWGs / 8) != 0 || reps < 1) return DPCG_ERR_INVALID;
     const int lds = kChipLdsSlots * kChipThreads * (int)sizeof(double);
@@ -667,14 +678,15 @@ int launch_l2_gather_probe(double *table, int per_group, int reps, const int *of
         if (hipFuncSetAttribute((const void *)k_l2_gather_probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DPCG_ERR_HIP;
         attr_set = true;
     }
-    if (depth == 4) hipLaunchKernelGGL(k_l2_gather_probe<4>, dim3(kChipWGs), dim3(kChipThreads), (size_t)lds, s, table, per_group, reps, offs7_dev, part, err, xcc, ticks, sink, sc1_only ? 1 : 0);
-    else hipLaunchKernelGGL(k_l2_gather_probe<2>, dim3(kChipWGs), dim3(kChipThreads), (size_t)lds, s, table, per_group, reps, offs7_dev, part, err, xcc, ticks, sink, sc1_only ? 1 : 0);
+    if (depth == 4) hipLaunchKernelGGL(k_l2_gather_probe<4>, dim3(kChipWGs), dim3(kChipThreads), (size_t)lds, s, table, per_group, reps, offs7_dev, part, err, xcc, ticks, sink, sc1_only);
+    else hipLaunchKernelGGL(k_l2_gather_probe<2>, dim3(kChipWGs), dim3(kChipThreads), (size_t)lds, s, table, per_group, reps, offs7_dev, part, err, xcc, ticks, sink, sc1_only);
     return DPCG_OK;
 }
 
 int chip_max_rows() { return kChipWGs * kChipThreads * kChipMaxRpt; }
 // rows of up to 9 entries (unstructured meshes) while a thread holds at most four rows (524 288 rows), 7 beyond
-int chip_max_row_len(int64_t n) { return n <= (int64_t)kChipWGs * kChipThreads * 4 ? 9 : 7; }
+// ... with fp32-stored values (DPCG_SPMV_F32: 4-byte slots) rows of 9 entries at any size
+int chip_max_row_len(int64_t n, bool f32_slots) { return (f32_slots || n <= (int64_t)kChipWGs * kChipThreads * 4) ? 9 : 7; }
 int chip_stream_max_row_len() { return 24; }      // 24 x 512 x 8 B = 98 KB of products + 33 KB of row tables (8 rows a thread) + 8 KB of group lists
 int chip_max_band() { return 32767; }
 int chip_workgroups() { return kChipWGs; }
@@ -711,9 +723,10 @@ int launch_pcg_chip(const ChipDesc &d, int max_row_len, hipStream_t s, bool chec
 #undef DPCG_CHIP_S2
 #undef DPCG_CHIP_S3
     }
-    if (max_row_len < 1 || max_row_len > (rpt <= 4 ? 9 : 7) || d.per < 1 || d.per > kChipThreads * kChipMaxRpt) return DPCG_ERR_INVALID;
     const int mode = d.bench == 3 ? 3 : (d.bench ? 2 : (d.dbg != nullptr ? 1 : (d.f32 ? 4 : 0)));
+    if (max_row_len < 1 || max_row_len > ((rpt <= 4 || mode == 4) ? 9 : 7) || d.per < 1 || d.per > kChipThreads * kChipMaxRpt) return DPCG_ERR_INVALID;
     if (d.f32 && (mode != 4 || d.x0)) return DPCG_ERR_INVALID;
+    if (rpt > 4 && max_row_len > 7) return jac ? chip_launch<8, 9, true, 4>(d, s, check_only) : chip_launch<8, 9, false, 4>(d, s, check_only);   // (4-byte slots)
 #define DPCG_CHIP_T(RPTV, WV, JV) (mode == 4 ? chip_launch<RPTV, WV, JV, 4>(d, s, check_only) : mode == 3 ? chip_launch<RPTV, WV, JV, 3>(d, s, check_only) : mode == 2 ? chip_launch<RPTV, WV, JV, 2>(d, s, check_only) : (mode == 1 ? chip_launch<RPTV, WV, JV, 1>(d, s, check_only) : chip_launch<RPTV, WV, JV, 0>(d, s, check_only)))
 #define DPCG_CHIP_W(RPTV, WV) (jac ? DPCG_CHIP_T(RPTV, WV, true) : DPCG_CHIP_T(RPTV, WV, false))
 #define DPCG_CHIP_R(RPTV) (max_row_len <= 5 ? DPCG_CHIP_W(RPTV, 5) : DPCG_CHIP_W(RPTV, 7))

@@ -556,13 +556,13 @@ struct ChipLltDesc {
     int *xcc;
     unsigned int nonce;        // != 0: r and t travel as self-validating granules keyed by (nonce, generation); unique per launch
 };
-int launch_l2_gather_probe(double *table, int per_group, int reps, const int *offs7_dev, int depth, bool sc1_only, double *part, int *err, int *xcc,
+int launch_l2_gather_probe(double *table, int per_group, int reps, const int *offs7_dev, int depth, int sc1_only, double *part, int *err, int *xcc,
                            unsigned long long *ticks, unsigned *sink, hipStream_t s);
 int chip_llt_max_rows();
 int chip_llt_max_row_len();
 int launch_pcg_chip_llt(const ChipLltDesc &d, int max_a, int max_l, hipStream_t s, bool check_only = false);
 int chip_max_rows();
-int chip_max_row_len(int64_t n);
+int chip_max_row_len(int64_t n, bool f32_slots = false);
 int chip_max_band();
 int chip_stream_max_row_len();    // rows of the streamed form (dpcg_chip.hip MODE 5): the LDS holds the products of 512 of them
 int chip_workgroups();

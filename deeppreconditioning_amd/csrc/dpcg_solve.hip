@@ -712,8 +712,8 @@ static int solve_team_one(dpcg_system *h, const double *b, const double *x0, dou
 // library's RCM): matrix and vectors resident -- otherwise, rows of up to 24 entries: the vectors resident, the matrix streamed;
 // matrix and vectors stay in registers and LDS for the whole solve.  DPCG_CHIP=0 / DPCG_CHIP_MIN_ROWS: development knobs.
 // the resident form: every row in the slots of its thread, every column within the 16-bit reach of its row
-static bool chip_resident_shape(const dpcg_system *h) {
-    return h->planA.max_row_len >= 1 && h->planA.max_row_len <= chip_max_row_len(h->A.n) && h->planA.max_band >= 0 &&
+static bool chip_resident_shape(const dpcg_system *h, bool f32_slots = false) {
+    return h->planA.max_row_len >= 1 && h->planA.max_row_len <= chip_max_row_len(h->A.n, f32_slots) && h->planA.max_band >= 0 &&
            h->planA.max_band <= chip_max_band();
 }
 static bool chip_eligible(const dpcg_system *h, int flags, const double *x_true) {
@@ -785,7 +785,8 @@ static int solve_chip_one(dpcg_system *h, const double *b, const double *x0, dou
     d.band = h->planA.max_band;
     d.f32 = (flags & DPCG_SPMV_F32) ? 1 : 0;
     d.rp_nnz = (int)std::min<int64_t>(h->A.nnz, 0x1fffffff);
-    d.stream_cap = (chip_resident_shape(h) || h->A.nnz > 0x1fffffff) ? 0 : h->planA.max_row_len * 64;     // (products of the 64 rows of a wave)
+    // (config 5 with x0 = 0 stores the values as fp32: twice the slots -- rows of 9 entries resident at any size)
+    d.stream_cap = (chip_resident_shape(h, d.f32 != 0 && !x0) || h->A.nnz > 0x1fffffff) ? 0 : h->planA.max_row_len * 64;     // (products of the 64 rows of a wave)
     { const char *e = getenv("DPCG_CHIP_BENCH"); d.bench = e ? atoi(e) : 0; }
     static const bool trace = [] { const char *e = getenv("DPCG_CHIP_TRACE"); return e && e[0] == '1'; }();
     if (d.f32 && (d.bench || trace || x0)) return DPCG_ERR_STATE;                      // (the caller goes on with the launches)
@@ -1233,7 +1234,7 @@ extern "C" int dpcg_debug_occupy(int workgroups, double milliseconds, dpcg_strea
 extern "C" int dpcg_debug_l2_gather(int granules_per_group, int reps, const int32_t offsets[7], int depth, int written_through, dpcg_stream_t stream,
                                     double *gbs, double *us_per_pass, int *groups_local) {
     if (!offsets || granules_per_group < 32 * chip_threads() || granules_per_group % 32 != 0 || granules_per_group > (1 << 22) || reps < 1 || reps > 100000 ||
-        (depth != 2 && depth != 4))
+        (depth != 2 && depth != 4) || written_through < 0 || written_through > 2)
         return invalid("dpcg_debug_l2_gather: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const int kSlots = chip_slot_doubles();
@@ -1253,7 +1254,7 @@ extern "C" int dpcg_debug_l2_gather(int granules_per_group, int reps, const int3
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> one_team_launch(team_launch_mutex());
-        st = launch_l2_gather_probe(table, granules_per_group, reps, ints, depth, written_through != 0, part, ints + 8, ints + 10, ticks,
+        st = launch_l2_gather_probe(table, granules_per_group, reps, ints, depth, written_through, part, ints + 8, ints + 10, ticks,
                                     reinterpret_cast<unsigned *>(ticks + 256), s);
         if (st == DPCG_OK) e = hipStreamSynchronize(s);
     }

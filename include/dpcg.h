@@ -226,8 +226,9 @@ int dpcg_debug_occupy(int workgroups, double milliseconds, dpcg_stream_t stream)
  * (dpcg_chip.hip) gathers -- 16-byte granules stored plainly by the workgroups of the owner's XCD, read with agent-scope loads, 64
  * consecutive granules per wave instruction -- with nothing else going on: 256 workgroups x 512 threads, `granules_per_group` granules per
  * XCD (a multiple of 32, >= 16 384), `reps` passes of 8 x 7 gathers per thread at `offsets` (in granules, relative to the thread's rows,
- * wrapped inside the XCD's part), `depth` (2 | 4) rows' gathers in flight per lane; `written_through` != 0: the table written through
- * instead (every gather then leaves the L2).  Out: GB/s of gathered bytes, us per pass, whether every group sat on one XCD.
+ * wrapped inside the XCD's part), `depth` (2 | 4) rows' gathers in flight per lane; `written_through` = 1: the table written through
+ * instead of plainly (the lines still stay in the writer's L2); 2: written through AND gathered by the neighbouring XCD (every gather
+ * then leaves the L2 for the memory side: the path of the granules another XCD owns).  Out: GB/s of gathered bytes, us per pass, whether every group sat on one XCD.
  * DPCG_ERR_STATE when the workgroups could not be co-resident.  No reference counterpart. */
 int dpcg_debug_l2_gather(int granules_per_group, int reps, const int32_t offsets[7], int depth, int written_through, dpcg_stream_t stream,
                          double *gbs, double *us_per_pass, int *groups_local);
