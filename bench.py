@@ -599,6 +599,10 @@ def mesh_workloads(D, poisson, torch, solve_twice, pmc_all) -> dict:
         r = solve_twice(S, b)
         e["jacobi"] = {"iterations": r.iterations, "status": r.status, "final_res": r.final_res, "ms": round(r.seconds * 1e3, 3),
                        "us_per_update": round(r.seconds / max(r.iterations, 1) * 1e6, 1), "iterations_per_s": round(r.iterations / r.seconds, 1)}
+        # config 5 on the mesh: fp32-stored SpMV operands (4-byte value slots: rows of 9 entries resident at 1M rows when the numbering has a band)
+        rm = solve_twice(S, b, flags=D._lib.SPMV_F32)
+        e["jacobi_mixed_precision"] = {"iterations": rm.iterations, "us_per_update": round(rm.seconds / max(rm.iterations, 1) * 1e6, 1),
+                                       "iterations_per_s": round(rm.iterations / rm.seconds, 1), "final_res_recurrence": rm.final_res}
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         S.set_preconditioner(D.IC0("solve", ordering="multicolor"))
