@@ -204,7 +204,13 @@ struct Solve {
     volatile unsigned long long *prog() { return extras()[h].prog_host; }
 
     int enqueue_some() {
-        bool graph_now = use_graph && (max_iter - enq) >= chunk && (many_launches || !(t_iter > 25e-6));
+        // Replayed chunks for short updates (the launch overhead is what a chunk amortises) AND for long ones.  (Until round 6 updates longer
+        // than 25 us were enqueued launch by launch: nothing to amortise there, it seemed -- but at 256^3 the queue idles 5.9 us between the
+        // last launch of one host call and the first of the next (the K3 -> K1 gap of the traces of rounds 4-5: with or without non-temporal
+        // stores), and not inside a replayed graph: 521.2 -> 516.8 us per update.  In between -- 25 .. 100 us, the 1M-row launch path, where
+        // no such gap shows -- single launches stay: a chunk overshoots the converged solve by up to its length.  DPCG_GRAPH_ALWAYS=0: the old rule.)
+        static const bool graph_long = [] { const char *e = getenv("DPCG_GRAPH_ALWAYS"); return !(e && e[0] == '0'); }();
+        bool graph_now = use_graph && (max_iter - enq) >= chunk && (many_launches || !(t_iter > 25e-6) || (graph_long && t_iter > 100e-6));
         // DPCG_DRIVER_ALTERNATE (tests): mix single updates and replayed chunks -- 1, 8, 1, 1, 8, ... -- which is what a
         // per-update time hovering around the 25 us threshold does to the choice above
         if (alternate) graph_now = graph_now && (calls++ % 3) != 0;
