@@ -210,7 +210,8 @@ struct Solve {
         // stores), and not inside a replayed graph: 521.2 -> 516.8 us per update.  In between -- 25 .. 100 us, the 1M-row launch path, where
         // no such gap shows -- single launches stay: a chunk overshoots the converged solve by up to its length.  DPCG_GRAPH_ALWAYS=0: the old rule.)
         static const bool graph_long = [] { const char *e = getenv("DPCG_GRAPH_ALWAYS"); return !(e && e[0] == '0'); }();
-        bool graph_now = use_graph && (max_iter - enq) >= chunk && (many_launches || !(t_iter > 25e-6) || (graph_long && t_iter > 100e-6));
+        static const double long_s = [] { const char *e = getenv("DPCG_GRAPH_LONG_US"); return (e ? atof(e) : 100.0) * 1e-6; }();
+        bool graph_now = use_graph && (max_iter - enq) >= chunk && (many_launches || !(t_iter > 25e-6) || (graph_long && t_iter > long_s));
         // DPCG_DRIVER_ALTERNATE (tests): mix single updates and replayed chunks -- 1, 8, 1, 1, 8, ... -- which is what a
         // per-update time hovering around the 25 us threshold does to the choice above
         if (alternate) graph_now = graph_now && (calls++ % 3) != 0;
