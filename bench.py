@@ -95,7 +95,8 @@ def l2_gather_ceiling(system, offsets) -> dict:
     same 256 x 512 geometry and placement, a table of n / 8 sixteen-byte granules per XCD stored plainly by that XCD's workgroups, every
     thread gathering 8 x 7 granules per pass at the system's own column offsets with agent-scope loads): GB/s of gathered bytes with two rows'
     gathers in flight per lane (what the solve kernel's registers hold) and with four, and gathering the NEIGHBOURING XCD's part of a table
-    that was written through (every gather then leaves the L2 for the memory side: the path of the granules another XCD owns)."""
+    that was written through (a STATIC table: after the first pass its lines sit in the reader's L2 as well -- the rate is the same; what a
+    granule that another XCD rewrites every update costs is a memory-side round trip of ~2 us, a latency this probe does not see)."""
     import ctypes as C
     from deeppreconditioning_amd import _lib as L
     per_group = max(((system.n // 8) // 32) * 32, 32 * 512)
