@@ -948,7 +948,8 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_trsv_res(const ChipTr
         // are already gathered (two named register sets in turn).  Never across a level boundary: there the operands are not published yet
         // -- gathering ahead made twice as many blocks poll again (512 K rows, 18 levels: 94 -> 112 us per update).
         // (With four rows a thread the second register set spills and the lookahead loses -- 512 K rows, two colours: 23.2 -> 25.0 us per
-        // update -- so it is taken up to two rows a thread: 167 K-row quadtree mesh, four colours: 26.9 -> 24.5; its caller's order, 13 levels: 57.6 -> 47.6.)
+        // update; with the iterate x moved into the LDS to make room it fits without a spill and gains nothing: 24.3 against 24.1-24.3 -- so it
+        // is taken up to two rows a thread: 167 K-row quadtree mesh, four colours: 26.9 -> 24.5; its caller's order, 13 levels: 57.6 -> 47.6.)
         if constexpr (RPT <= 4) {
             Blk Ba, Bb;
             bool have_a = false;
