@@ -686,9 +686,6 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_trsv_res(const ChipTr
     __shared__ unsigned long long s_tr[TRACE ? 8 * 8 : 1];
     double *const f_val = res_lds;
     unsigned *const f_off = reinterpret_cast<unsigned *>(res_lds + NS * kChipThreads);
-    // four rows a thread: the iterate x lives in the LDS too (touched once per update; its registers go to the block lookahead)
-    constexpr bool X_LDS = RPT == 4;
-    double *const x_lds = reinterpret_cast<double *>(f_off + NOFF * kChipThreads);
     const int t = threadIdx.x, lane = t & 63;
     const int v = ((int)blockIdx.x & 7) * (kChipWGs / 8) + ((int)blockIdx.x >> 3);
     const int row0 = v * d.per + t;
@@ -720,7 +717,6 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_trsv_res(const ChipTr
         const int len = valid ? re - rs : 0;
         lens |= (valid ? (LV | (unsigned)len) : 0u) << (LB * k);
         x[k] = valid ? (d.x0 ? d.x0[ic] : 0.0) : 0.0;
-        if (X_LDS) x_lds[k * kChipThreads + t] = x[k];
         r[k] = valid ? d.b[ic] : 0.0;
         p[k] = q[k] = z[k] = 0.0;
         if (valid) bb_loc += r[k] * r[k];
@@ -950,7 +946,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_trsv_res(const ChipTr
         // (With four rows a thread the second register set spills and the lookahead loses -- 512 K rows, two colours: 23.2 -> 25.0 us per
         // update; with the iterate x moved into the LDS to make room it fits without a spill and gains nothing: 24.3 against 24.1-24.3 -- so it
         // is taken up to two rows a thread: 167 K-row quadtree mesh, four colours: 26.9 -> 24.5; its caller's order, 13 levels: 57.6 -> 47.6.)
-        if constexpr (RPT <= 4) {
+        if constexpr (RPT <= 2) {
             Blk Ba, Bb;
             bool have_a = false;
             for (;;) {
@@ -1046,8 +1042,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_trsv_res(const ChipTr
         const double alpha = rz / pq;                             // cg.py:78
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            if (X_LDS) x_lds[k * kChipThreads + t] = x_lds[k * kChipThreads + t] + alpha * p[k];      // cg.py:79
-            else x[k] = x[k] + alpha * p[k];
+            x[k] = x[k] + alpha * p[k];                           // cg.py:79
             r[k] = r[k] - alpha * q[k];                           // cg.py:80
         }
         if (!(alive = apply_m())) break;                          // cg.py:81
@@ -1075,7 +1070,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_trsv_res(const ChipTr
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
-        if (alive && row_on(k)) d.x[row0 + k * kChipThreads] = X_LDS ? x_lds[k * kChipThreads + t] : x[k];
+        if (alive && row_on(k)) d.x[row0 + k * kChipThreads] = x[k];
     if (TRACE && d.dbg) {
         __syncthreads();
         if (t < 64) d.dbg[v * 64 + t] = s_tr[t];
@@ -1093,8 +1088,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_trsv_res(const ChipTr
 template <int RPT, int WMAX, bool TRACE = false>
 int chip_trsv_res_launch(const ChipTrsvDesc &d, hipStream_t s, bool check_only) {
     constexpr int NS = RPT * WMAX;
-    const int lds = NS * kChipThreads * (int)sizeof(double) + ((NS + 1) / 2) * kChipThreads * (int)sizeof(unsigned) +
-                    (RPT == 4 ? RPT * kChipThreads * (int)sizeof(double) : 0);            // (four rows a thread: + the iterate)
+    const int lds = NS * kChipThreads * (int)sizeof(double) + ((NS + 1) / 2) * kChipThreads * (int)sizeof(unsigned);
     static int resident = -1;
     if (resident < 0) {
         if (hipFuncSetAttribute((const void *)k_pcg_chip_trsv_res<RPT, WMAX, TRACE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
