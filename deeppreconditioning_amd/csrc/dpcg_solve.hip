@@ -1002,7 +1002,9 @@ static bool chip_trsv_enabled() {
     return on;
 }
 static int chip_trsv_min_rows() {
-    static const int v = [] { const char *e = getenv("DPCG_CHIP_TRSV_MIN_ROWS"); return e ? atoi(e) : 16384; }();
+    // (from 1 024 rows: measured with IC(0) in multicolour order, us per update, launches -> this kernel: 1 674 rows (quadtree mesh, 4 colours)
+    // 29.4 -> 14.9, 4 268 rows 32.6 -> 16.5, 10 000 rows 25.5 -> 9.1, 13 824 rows 32.3 -> 11.7 -- an update of the launches is launch-bound there)
+    static const int v = [] { const char *e = getenv("DPCG_CHIP_TRSV_MIN_ROWS"); return e ? atoi(e) : 1024; }();
     return v;
 }
 // what can be told without the lists (they are built at the first solve)
