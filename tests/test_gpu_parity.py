@@ -3098,6 +3098,7 @@ def _factor_for_oracle(S, A, perm, ordering):
 
 
 @pytest.mark.parametrize("name,make,ordering,env", [
+    ("quadtree_64", lambda: O.quadtree_fv_laplacian(64, 1), "multicolor", {}),                           # 4 268 rows (the reference's larger meshes): 17 rows a workgroup
     ("poisson2d_256", lambda: O.poisson2d(256), "multicolor", {}),                                      # BASELINE config 2's system: one row a thread, 5 entries
     ("poisson3d_41", lambda: O.poisson3d(41), "multicolor", {}),                                        # 68 921 rows: most threads of a workgroup without a row
     ("unstructured3d_60", lambda: O.unstructured_like(O.poisson3d(60), seed=1), "multicolor", {}),      # reordered inside the library; two rows a thread
