@@ -490,6 +490,10 @@ def main() -> None:
         if chip["chip_by_default"] and args.precond in ("jacobi", "none"):
             line["roofline"] = chip_roofline(system, poisson.rhs(n, 0), check, line["roofline"], pmc_all.get(f"chip_{args.dim}d_{args.n}"),
                                              pmc_all.get(f"chip_{args.dim}d_{args.n}_l2_counters"), stencil_offsets(args.dim, args.n))
+            if world == 1 and args.systems_per_gpu == 1:
+                # what a solve costs beyond its kernel -- the Python call, the slot pre-fill, the memset, the gather of b and the syncs around the
+                # launch (all inside `value`'s wall clock, none of it inside the kernel's duration)
+                line["roofline"]["per_solve_time_outside_the_kernel_us"] = round(line["ms_per_step"] * 1e3 - line["roofline"]["us_per_launch"], 1)
         if per_rank is not None:
             line["per_rank"] = per_rank
             line["gathered_records"] = comm["gathered_records"]

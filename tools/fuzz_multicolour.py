@@ -125,7 +125,15 @@ for case in range(cases):
         what = f"solve (iterations {res.iterations} vs {it})"
         # ... and with the oracle's dot products in the device's reduction trees (the colour sweeps' <r,z> included): bit for bit
         geo = S.reduction_geometry()
-        if ok and geo["rz_kind"] in (1, 2, 4) and geo["spmv_kernel"] != "vector" and (n > 6144 or (flags & D._lib.NO_SMALL)):
+        ci = S.chip_info()
+        if ok and ci["chip_by_default"] and flags == 0:
+            # (round 6) the plain call was the one-launch kernel with the triangular solves inside: the whole-chip tree
+            tree = {**geo, "form": "chip", "rows_per_workgroup": ci["rows_per_workgroup"]}
+            _, it_t, hist_t, _ = CO.pcg(B, bb, "llt_solve", L=Lref, precond_perm=pperm, max_iter=60, device_tree=tree)
+            ok = res.iterations == it_t and np.array_equal(res.res_history, hist_t)
+            what = f"solve against the whole-chip-tree oracle (iterations {res.iterations} vs {it_t})"
+            bitwise += 1
+        elif ok and geo["rz_kind"] in (1, 2, 4) and geo["spmv_kernel"] != "vector" and (n > 6144 or (flags & D._lib.NO_SMALL)):
             if geo["rz_kind"] == 4:
                 hidx = q
                 if S.reordered:
