@@ -3232,6 +3232,51 @@ def test_one_launch_solves_when_somebody_else_holds_cus(D, name, make, form):
     S.close()
 
 
+def test_one_launch_forms_back_off_after_repeated_timeouts(D):
+    """When CUs stay taken (RCCL kernels, another process, a long kernel on another stream) every one-launch solve would spin for its full
+    20 ms bound before the launches take over.  After three such timeouts in a row the one-launch forms are skipped for a cool-down (2 s):
+    the fourth solve goes straight to the launches; once the cool-down is over and the CUs are free, a plain call is the one-launch form again.
+    (Run in a child process: the back-off is per process.)"""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import time, numpy as np, torch
+        import deeppreconditioning_amd as D
+        from oracle import oracle as O
+        A = O.poisson3d(64)
+        S = D.CsrSystem.from_any(A, reorder=None)
+        S.set_preconditioner(D.Jacobi())
+        b = torch.from_numpy(O.rhs(A.shape[0], 2)).cuda()
+        assert S.chip_info()["chip_by_default"]
+        one_launch = S.solve(b)
+        multi = S.solve(b, flags=D._lib.NO_SMALL)
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        D._lib.check(D._lib.lib().dpcg_debug_occupy(96, 600.0, side.cuda_stream))
+        time.sleep(0.03)
+        times = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            r = S.solve(b)
+            times.append(time.perf_counter() - t0)
+            assert r.status == 0 and np.array_equal(r.res_history, multi.res_history)       # every one of them: the launches' history
+        assert min(times[:3]) > 0.02, times                     # three timeouts of 20 ms each ...
+        assert max(times[3:]) < 0.015, times                    # ... then no more waiting
+        side.synchronize()
+        again = S.solve(b)
+        assert np.array_equal(again.res_history, multi.res_history)                         # still inside the cool-down
+        time.sleep(2.2)
+        back = S.solve(b)
+        assert np.array_equal(back.res_history, one_launch.res_history)                     # re-probed: the one-launch form again
+        print("ok", [round(t * 1e3, 1) for t in times])
+    """)
+    root = __import__("pathlib").Path(__file__).resolve().parents[1]
+    env = dict(__import__("os").environ, PYTHONPATH=str(root))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("name,make,factor", [
     ("poisson2d_256_learned_like", lambda: O.poisson2d(256), "learned"),        # BASELINE config 2's shape: 65 536 rows, 15 entries a row of L
     ("poisson2d_100_ic0", lambda: O.poisson2d(100), "ic0"),                     # 10 000 rows: most threads without a row
