@@ -628,16 +628,18 @@ __global__ __launch_bounds__(kChipThreads) void k_trsv_res_plan(int n, int per, 
                                                                 const double *__restrict__ lval, const int32_t *__restrict__ urp, const int32_t *__restrict__ uci,
                                                                 const double *__restrict__ uval, const int32_t *__restrict__ lvl_l, const int32_t *__restrict__ lvl_u,
                                                                 const int32_t *__restrict__ f_of_handle, const int32_t *__restrict__ handle_of_f,
-                                                                double *fval, int32_t *fcol, int32_t *fmeta, int *flags /* [0] misfit, [1] band */) {
+                                                                double *fval, int32_t *fcol, int32_t *fmeta, int *flags /* [0] misfit, [1] band */,
+                                                                int tstride /* threads of a workgroup that can own a row: 512, or per rounded up to 64 for small systems --
+                                                                               the arrays hold that many entries per slot */) {
     const int t = threadIdx.x, v = blockIdx.x;
     int band = 0;
-    for (int k = 0; k < rpt; ++k) {
+    for (int k = 0; k < rpt && t < tstride; ++k) {
         const int loc = k * kChipThreads + t, i = v * per + loc;
         const bool valid = loc < per && i < n;
-        const size_t mbase = ((size_t)v * rpt + k) * kChipThreads + t;
+        const size_t mbase = ((size_t)v * rpt + k) * tstride + t;
         int meta = 0;
         for (int j = 0; j < wmax; ++j) {
-            const size_t e = ((size_t)v * rpt * wmax + (size_t)k * wmax + j) * kChipThreads + t;
+            const size_t e = ((size_t)v * rpt * wmax + (size_t)k * wmax + j) * tstride + t;
             fval[e] = j == wmax - 1 ? 1.0 : 0.0;
             fcol[e] = -1;
         }
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(kChipThreads) void k_trsv_res_plan(int n, int per, 
                 atomicOr(&flags[0], 1);
             } else {
                 for (int j = 0; j < nl; ++j) {                    // L: diagonal last
-                    const size_t e = ((size_t)v * rpt * wmax + (size_t)k * wmax + j) * kChipThreads + t;
+                    const size_t e = ((size_t)v * rpt * wmax + (size_t)k * wmax + j) * tstride + t;
                     const int c = handle_of_f ? handle_of_f[lci[ls + j]] : lci[ls + j];
                     fval[e] = lval[ls + j];
                     fcol[e] = c;
@@ -657,14 +659,14 @@ __global__ __launch_bounds__(kChipThreads) void k_trsv_res_plan(int n, int per, 
                     band = dlt > band ? dlt : band;
                 }
                 for (int j = 0; j < nu; ++j) {                    // L^T: diagonal first
-                    const size_t e = ((size_t)v * rpt * wmax + (size_t)k * wmax + nl + j) * kChipThreads + t;
+                    const size_t e = ((size_t)v * rpt * wmax + (size_t)k * wmax + nl + j) * tstride + t;
                     const int c = handle_of_f ? handle_of_f[uci[us + 1 + j]] : uci[us + 1 + j];
                     fval[e] = uval[us + 1 + j];
                     fcol[e] = c;
                     const int dlt = c > i ? c - i : i - c;
                     band = dlt > band ? dlt : band;
                 }
-                fval[((size_t)v * rpt * wmax + (size_t)k * wmax + wmax - 1) * kChipThreads + t] = lval[le - 1];
+                fval[((size_t)v * rpt * wmax + (size_t)k * wmax + wmax - 1) * tstride + t] = lval[le - 1];
                 meta = nl | (nu << 4) | (lvl_l[f] << 8) | (lvl_u[f] << 14) | (1 << 20);
             }
         }
@@ -720,7 +722,7 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_trsv_res(const ChipTr
         r[k] = valid ? d.b[ic] : 0.0;
         p[k] = q[k] = z[k] = 0.0;
         if (valid) bb_loc += r[k] * r[k];
-        meta[k] = d.fmeta[(v * RPT + k) * kChipThreads + t];
+        meta[k] = t < d.tstride ? d.fmeta[(v * RPT + k) * d.tstride + t] : 0;
 #pragma unroll
         for (int j = 0; j < WMAX; ++j) {
             const int s = k * WMAX + j;
@@ -741,9 +743,10 @@ __global__ __launch_bounds__(kChipThreads) void k_pcg_chip_trsv_res(const ChipTr
 #pragma unroll
             for (int j = 0; j < WMAX; ++j) {
                 const int s = k * WMAX + j;
-                const size_t e = ((size_t)v * NS + s) * kChipThreads + t;
-                f_val[s * kChipThreads + t] = d.fval[e];
-                const int c = d.fcol[e];
+                const size_t e = ((size_t)v * NS + s) * d.tstride + t;
+                const bool has = t < d.tstride;                   // (small systems: the plan holds the threads that can own a row)
+                f_val[s * kChipThreads + t] = has ? d.fval[has ? e : 0] : (j == WMAX - 1 ? 1.0 : 0.0);
+                const int c = has ? d.fcol[has ? e : 0] : -1;
                 const unsigned del = c >= 0 ? (unsigned)(c - i + 32768) & 0xffffu : 0u;
                 if (s & 1) fo[s >> 1] |= del << 16;
                 else fo[s >> 1] = del;
@@ -1176,19 +1179,22 @@ void free_chip_trsv_lists(ChipTrsvLists &l) {
 // *misfit: some row's two factor rows do not fit its wmax - 1 slots; *band: largest |col - row| of the factor in the handle's numbering.
 int build_chip_trsv_resident(int n, int per, int rpt, int wmax, const CsrDev &L, const CsrDev &U, const int32_t *lvl_l, const int32_t *lvl_u,
                              const int32_t *f_of_handle, const int32_t *handle_of_f, double **fval, int32_t **fcol, int32_t **fmeta, int *misfit, int *band,
-                             hipStream_t s) {
+                             int *tstride_out, hipStream_t s) {
     int *flags = nullptr;
     int st;
     if ((st = dev_alloc(&flags, 2)) < 0) return st;
-    const int64_t slots = (int64_t)kChipWGs * rpt * wmax * kChipThreads;
-    if ((st = dev_alloc(fval, slots)) < 0 || (st = dev_alloc(fcol, slots)) < 0 || (st = dev_alloc(fmeta, (int64_t)kChipWGs * rpt * kChipThreads)) < 0) {
+    // a system of a few thousand rows gives a workgroup a handful of them: the plan holds only the threads that can own one
+    const int tstride = per >= kChipThreads ? kChipThreads : std::min(kChipThreads, ((per + 63) / 64) * 64);
+    *tstride_out = tstride;
+    const int64_t slots = (int64_t)kChipWGs * rpt * wmax * tstride;
+    if ((st = dev_alloc(fval, slots)) < 0 || (st = dev_alloc(fcol, slots)) < 0 || (st = dev_alloc(fmeta, (int64_t)kChipWGs * rpt * tstride)) < 0) {
         dev_free(flags);
         return st;
     }
     int h_flags[2] = {0, 0};
     hipError_t e = hipMemsetAsync(flags, 0, 2 * sizeof(int), s);
     hipLaunchKernelGGL(k_trsv_res_plan, dim3(kChipWGs), dim3(kChipThreads), 0, s, n, per, rpt, wmax, L.rowptr, L.col, L.val, U.rowptr, U.col, U.val, lvl_l, lvl_u,
-                       f_of_handle, handle_of_f, *fval, *fcol, *fmeta, flags);
+                       f_of_handle, handle_of_f, *fval, *fcol, *fmeta, flags, tstride);
     if (e == hipSuccess) e = hipMemcpyAsync(h_flags, flags, sizeof(h_flags), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess) e = hipGetLastError();

@@ -295,7 +295,7 @@ struct dpcg_system {
     double *trsv_diag0 = nullptr;
     double *trsv_fval = nullptr;             // the resident form's plan (<= 524 288 rows): trsv_rpt != 0
     int32_t *trsv_fcol = nullptr, *trsv_fmeta = nullptr;
-    int trsv_rpt = 0, trsv_wmax = 0, trsv_band = 0;
+    int trsv_rpt = 0, trsv_wmax = 0, trsv_band = 0, trsv_tstride = 512;
     int trsv_state = 0;
     double chip_trace_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // ... over the 256 workgroups: SpMV phase max / mean, publish max / mean, `local`
     double chip_trace_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DPCG_CHIP_TRACE: us per update by phase of the last chip solve ([7] = updates)
@@ -513,6 +513,7 @@ struct ChipTrsvDesc {
     const double *fval;
     const int32_t *fcol, *fmeta;
     int nlev_l, nlev_u;
+    int tstride;               // entries per slot in fval / fcol / fmeta: 512, or rows-per-workgroup rounded up to 64 (small systems)
     const int32_t *lv0;        // [256][512]: bits 0-7 the thread's slots whose row has no dependency in L, bits 8-15 in L^T
     const double *diag0;       // [256][8][512]: the factor's diagonal by workgroup, slot, thread
     double rtol_sq, atol_sq;
@@ -530,7 +531,7 @@ int build_chip_trsv_lists(int n, int per, int nlev, const CsrDev &F, const int32
 int64_t chip_trsv_diag_doubles();
 int build_chip_trsv_resident(int n, int per, int rpt, int wmax, const CsrDev &L, const CsrDev &U, const int32_t *lvl_l, const int32_t *lvl_u,
                              const int32_t *f_of_handle, const int32_t *handle_of_f, double **fval, int32_t **fcol, int32_t **fmeta, int *misfit, int *band,
-                             hipStream_t s);
+                             int *tstride_out, hipStream_t s);
 int chip_trsv_resident_rpt(int per);
 int chip_trsv_resident_wmax(int max_a, int rpt);
 int launch_pcg_chip_trsv_resident(const ChipTrsvDesc &d, int rpt, int wmax, hipStream_t s, bool check_only = false);

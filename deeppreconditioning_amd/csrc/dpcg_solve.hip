@@ -1073,7 +1073,7 @@ static int ensure_chip_trsv(dpcg_system *h, hipStream_t s) {
     if (resident_on && rpt && wmax) {
         int misfit = 0, band = 0;
         if ((st = build_chip_trsv_resident((int)n, per, rpt, wmax, h->L, h->Lt, lvl[0], lvl[1], f_of_handle, handle_of_f, &h->trsv_fval, &h->trsv_fcol,
-                                           &h->trsv_fmeta, &misfit, &band, s)) < 0)
+                                           &h->trsv_fmeta, &misfit, &band, &h->trsv_tstride, s)) < 0)
             return done(-1, st);
         pt.mark("chip trsv: resident plan");
         if (!misfit && std::max(band, h->planA.max_band) <= chip_max_band()) {
@@ -1149,6 +1149,7 @@ static int solve_chip_trsv_one(dpcg_system *h, const double *b, const double *x0
     d.lv0 = h->trsv_lv0; d.diag0 = h->trsv_diag0;
     d.fval = h->trsv_fval; d.fcol = h->trsv_fcol; d.fmeta = h->trsv_fmeta;
     d.nlev_l = h->trsv_l.n_levels; d.nlev_u = h->trsv_u.n_levels;
+    d.tstride = h->trsv_tstride;
     const bool resident = h->trsv_rpt != 0;
     auto launch = [&](bool check_only) {
         return resident ? launch_pcg_chip_trsv_resident(d, h->trsv_rpt, h->trsv_wmax, s, check_only)
