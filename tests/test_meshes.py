@@ -246,7 +246,7 @@ def test_million_row_meshes_full_length_histories(D, name, make):
     assert res_d.iterations == it_d and len(hist_d) == it_d + 1 and np.array_equal(res_d.res_history, hist_d), (name, res_d.iterations, it_d)
     assert np.array_equal(res_d.x.cpu().numpy()[perm], xs_d)
     assert not np.array_equal(res_d.res_history, res.res_history)          # (another summation order: it WAS the other form)
-    if name == "quadtree_random_1M":
+    if name in ("quadtree_random_1M", "quadtree_foam_1M"):      # (RCM order: 4-byte value slots, resident -- MODE 4; OpenFOAM's numbering: no band, streamed -- MODE 6)
         res_m = S.solve(_dev(b), flags=D._lib.SPMV_F32)
         _, it_m, hist_m, xs_m = CO.pcg(B, b[perm], "jacobi", dinv=O.jacobi_dinv(B), mixed=True, device_tree=chip_tree)
         assert res_m.iterations == it_m and np.array_equal(res_m.res_history, hist_m), (name, res_m.iterations, it_m)
