@@ -1059,9 +1059,11 @@ static int ensure_chip_trsv(dpcg_system *h, hipStream_t s) {
         // Every level is a hand-off from one workgroup to another -- publish, become visible, be gathered: ~1.2 us inside an XCD, ~3 across
         // -- and a chain of them is all a many-level solve is: measured at 216 K / 512 K rows with IC(0) in a scattered caller's order, 17 /
         // 18 levels: 66 / 94 us per update here against 72 / 87 for the launches (whose sync-free kernels wait in the same way).  Few levels
-        // (multicolour orders: 2-9) are where this form wins (2-4 x); beyond 16 the launches keep the solve (natural orders of grids: hundreds).
+        // (multicolour orders: 2-9) are where this form wins (2-4 x); beyond 16 (18 up to two rows a thread) the launches keep the solve (natural orders of grids: hundreds).
         // (the three development knobs of this routine are read per plan, not per process: a plan is built once per preconditioner)
-        const int level_limit = [] { const char *e = getenv("DPCG_CHIP_TRSV_MAX_LEVELS"); return e ? std::min(atoi(e), chip_trsv_max_levels()) : 16; }();
+        // (up to two rows a thread -- 262 144 rows -- a level is cheaper here, the level's next block being gathered ahead: 18)
+        const int level_default = chip_rows_per_wg(n) <= 2 * chip_threads() ? 18 : 16;
+        const int level_limit = [&] { const char *e = getenv("DPCG_CHIP_TRSV_MAX_LEVELS"); return e ? std::min(atoi(e), chip_trsv_max_levels()) : level_default; }();
         if (nlev[upper] > level_limit) return done(-1, DPCG_OK);
     }
     h->trsv_l.n_levels = nlev[0];
